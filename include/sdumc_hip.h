@@ -1,0 +1,353 @@
+/* sdumc_hip.h — C ABI of libsdumc_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the ONE hot path of WarmCongee/SDUMC: the
+ * WengnetMOSEIMultViewsTextMissing forward/backward, its losses and the Adam
+ * step.  The reference has no native code; what its Python calls
+ * on this path are torch eager ops.  Each entry point below names the reference
+ * code it replaces (file:line relative to the reference repo).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 unless stated otherwise;
+ *     tensors are dense row-major with the strides given;
+ *   - every function enqueues work on `stream` (a hipStream_t passed as void*)
+ *     and returns immediately: no allocation, no synchronisation, no host
+ *     copies -> every call is hipGraph-capturable;
+ *   - return value: 0 = ok, <0 = SDUMC_E* (never throws across the ABI);
+ *   - scratch memory is caller-owned; *_workspace_bytes() says how much.
+ */
+#ifndef SDUMC_HIP_H
+#define SDUMC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDUMC_OK 0
+#define SDUMC_EINVAL (-1)   /* bad argument (shape, alignment, null pointer) */
+#define SDUMC_ELAUNCH (-2)  /* hipLaunch / HIP runtime error */
+#define SDUMC_ENOMEM (-3)   /* workspace too small */
+
+#define SDUMC_MAX_GROUPS 8
+#define SDUMC_D 256         /* general_dim            (model :191) */
+#define SDUMC_H 128         /* layers_list[-1]        (model :187) */
+#define SDUMC_NQ 7          /* multi-view queries     (model :332) */
+#define SDUMC_RNC_DIM 64    /* orgin_linear_change out (model :246-250) */
+#define SDUMC_N_SITES 35    /* nn.Dropout call sites of one forward */
+
+/* ------------------------------------------------------------------------
+ * Dropout descriptor.  Replaces nn.Dropout / aten::bernoulli_ (model :54,:77,
+ * :270).  Masks are a pure function of (seed, call, site, sample, row, col):
+ * Philox4x32-10, ctr = (row*(width/4)+col/4, sample0+sample, site, call+stream),
+ * key = seed; element dropped when word[col%4] < threshold; kept elements are
+ * multiplied by `scale`.  The row space of the tensor the descriptor is attached
+ * to is [streams][samples][rows][width].
+ * ---------------------------------------------------------------------- */
+typedef struct sdumc_dropout {
+  uint32_t enabled;    /* 0 = identity (eval mode) */
+  uint32_t site;       /* 0..SDUMC_N_SITES-1 */
+  uint32_t threshold;  /* floor(p * 2^32) */
+  float scale;         /* 1/(1-p) */
+  uint32_t rows;       /* rows per sample (T, NQ or 1) */
+  uint32_t width;      /* row width, multiple of 4 */
+  uint32_t samples;    /* samples per stream (local batch B) */
+  uint32_t sample0;    /* global index of local sample 0 (data-parallel shard offset) */
+  uint32_t call0;      /* Philox call index of stream 0 (ignored when dev_state != NULL) */
+  uint32_t stream0;    /* added to the stream index (a tensor that holds only stream 1 passes 1) */
+  uint32_t seed_lo, seed_hi;
+  const uint32_t* dev_state; /* optional device {seed_lo, seed_hi, call0}: lets a captured
+                                hipGraph draw fresh masks on every replay */
+} sdumc_dropout;
+
+/* ------------------------------------------------------------------------
+ * fp32 MFMA GEMM (v_mfma_f32_32x32x2_f32), grouped, with the fusions this path
+ * needs.  Replaces F.linear / torch.bmm / their autograd (aten::addmm, mm).
+ *   layout SDUMC_NT: C[M,N] = A[M,K] . B[N,K]^T   (forward Linear: x.W^T)
+ *   layout SDUMC_NN: C[M,N] = A[M,K] . B[K,N]     (dX = dY.W)
+ *   layout SDUMC_TN: C[M,N] = A[K,M]^T . B[K,N]   (dW = dY^T.X)
+ * ---------------------------------------------------------------------- */
+enum { SDUMC_NT = 0, SDUMC_NN = 1, SDUMC_TN = 2 };
+enum { SDUMC_ACT_NONE = 0, SDUMC_ACT_RELU = 1, SDUMC_ACT_TANH = 2 };
+
+typedef struct sdumc_gemm {
+  int32_t layout, M, N, K;
+  int32_t groups;                        /* 1..SDUMC_MAX_GROUPS independent problems of one shape */
+  const float* A[SDUMC_MAX_GROUPS];
+  const float* B[SDUMC_MAX_GROUPS];
+  float* C[SDUMC_MAX_GROUPS];
+  const float* bias[SDUMC_MAX_GROUPS];   /* [N] or NULL */
+  int32_t lda, ldb, ldc;
+  int32_t a_row_mod;   /* >0: A's source row = row % a_row_mod (NT/NN rows = m; TN rows = k).
+                          Lets the two streams share one x_audio / x_video in HBM. */
+  int32_t b_row_mod;   /* TN only: B's source row = k % b_row_mod */
+  sdumc_dropout a_drop; /* NT/NN: fused dropout on A as it is staged (rows = m, cols = k) */
+  sdumc_dropout b_drop; /* TN: fused dropout on B as it is staged (rows = k, cols = n) */
+  int32_t act;          /* epilogue activation */
+  sdumc_dropout c_drop; /* epilogue dropout on C (rows = m, cols = n) */
+  int32_t c_drop_group_stride; /* group g uses site c_drop.site + g * stride (grouped MLPs) */
+  int32_t accumulate;   /* C += result (requires act none, no c_drop, no bias) */
+  int32_t splitk;       /* >1: K split over workgroups, fp32 slabs in `workspace`, deterministic reduce */
+  int32_t tile;         /* 0 auto, 1 = 128x128, 2 = 64x64 */
+  float* workspace;
+  size_t workspace_bytes;
+} sdumc_gemm;
+
+size_t sdumc_gemm_workspace_bytes(const sdumc_gemm* g);
+int sdumc_gemm_f32(const sdumc_gemm* g, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Attention pooling over the time axis = the body shared by
+ *   FRA2UTT_new.forward     (model :56-68; nq = 1, query = attention_context_vector, q_stride 0)
+ *   Cross_Attention.forward (model :79-95; nq = 7, query = query_proj(multi_query))
+ * after the key projection K = tanh(drop(x).W^T + b) has been produced by
+ * sdumc_gemm_f32 (NT, a_drop, act tanh).
+ *   S[v,t,i] = K[v,t,:].Q[v,i,:] ; A = softmax_t(0.3 S) ; O[v,i,:] = sum_t A[v,t,i] drop(x)[v,t,:]
+ *   out = drop_out(O)
+ * v = virtual sample = stream*B + b; x row of v is (v % x_samples).
+ * ---------------------------------------------------------------------- */
+typedef struct sdumc_attnpool {
+  int32_t V;           /* virtual samples (streams * B) */
+  int32_t T;           /* frames */
+  int32_t nq;          /* 1..8 */
+  int32_t x_samples;   /* x holds this many samples; x row of v = v % x_samples */
+  const float* x;      /* [x_samples, T, 256] */
+  const float* keys;   /* [V, T, 256] tanh keys */
+  const float* q;      /* [V or 1, nq, 256] projected queries */
+  int64_t q_stride;    /* floats between the queries of consecutive v (0 = shared) */
+  float scale;         /* 0.3 */
+  sdumc_dropout x_drop;   /* the input dropout (same descriptor the key GEMM used) */
+  sdumc_dropout out_drop; /* the output dropout, rows = nq */
+  float* attn;         /* [V, T, nq]  softmax weights (returned by the reference, saved for backward) */
+  float* pooled;       /* [V, nq, 256] O before the output dropout (saved for backward) */
+  float* out;          /* [V, nq, 256] */
+} sdumc_attnpool;
+
+int sdumc_attnpool_fwd(const sdumc_attnpool* p, void* stream);
+
+/* backward of the above. Produces
+ *   dz    [V,T,256]  gradient w.r.t. the pre-tanh key projection (feeds the dW / dX GEMMs)
+ *   dxd   [V,T,256]  gradient w.r.t. drop(x) through the pooling ("V") path; the key-projection
+ *                    path is ADDED to it by the caller's NN GEMM (accumulate=1)
+ *   dq    [V,nq,256] gradient w.r.t. the projected queries (nq=1 shared query: per-v partials,
+ *                    reduce over v with sdumc_colsum)
+ */
+typedef struct sdumc_attnpool_bwd {
+  sdumc_attnpool f;      /* the forward descriptor (x, keys, q, attn, pooled, dropouts) */
+  const float* dout;     /* [V, nq, 256] gradient w.r.t. out */
+  float* dz;
+  float* dxd;
+  float* dq;
+  float* workspace;      /* >= sdumc_attnpool_bwd_workspace_bytes(V, T, nq): per-chunk dq slabs */
+  size_t workspace_bytes;
+} sdumc_attnpool_bwd_t;
+
+size_t sdumc_attnpool_bwd_workspace_bytes(int32_t V, int32_t T, int32_t nq);
+int sdumc_attnpool_bwd(const sdumc_attnpool_bwd_t* p, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Small fused element-wise / reduction kernels of the utterance-level network.
+ * ---------------------------------------------------------------------- */
+
+/* dz = dy * [y > 0] * scale  (backward of Linear->ReLU->Dropout given the saved
+ * post-dropout output y, model :264-273);  in place allowed.  n elements. */
+int sdumc_relu_drop_bwd(const float* dy, const float* y, float scale, float* dz, int64_t n, void* stream);
+
+/* out[j] (+)= sum_r a[r, j], a is [rows, cols] with leading dimension lda (bias gradients).
+ * Deterministic two-stage reduction; workspace >= sdumc_colsum_workspace_bytes. */
+size_t sdumc_colsum_workspace_bytes(int64_t rows, int32_t cols);
+int sdumc_colsum(const float* a, int64_t rows, int32_t cols, int32_t lda, float* out, int32_t accumulate,
+                 float* workspace, void* stream);
+
+/* y[i] = sum_k x_k[i] (k <= 8 inputs), or out = a + b*c style helpers */
+int sdumc_add_n(const float* const* xs, int32_t k, float* y, int64_t n, void* stream);
+
+/* dx[b,t,:] = sum over `k` (site,stream) terms of g_k[v,t,:] * mask_k   (model backward of the
+ * four dropout applications that read one projected feature tensor x) */
+typedef struct sdumc_dropsum {
+  int32_t terms;                 /* <= 8 */
+  const float* g[8];             /* each [samples, T, 256] (already offset to the stream) */
+  sdumc_dropout drop[8];         /* per-term dropout; stream offset given through call0/dev_state + stream_idx */
+  int32_t stream_idx[8];
+  int32_t samples, T;
+  float* dx;                     /* [samples, T, 256] */
+} sdumc_dropsum;
+int sdumc_dropsum_bwd(const sdumc_dropsum* p, void* stream);
+
+/* Modality fusion (model :301-332 algebra).  u [V,3,256], alpha [V,3]
+ *   qin [7][V,256] = (f, f_at, f_tv, f_av, u_a, u_t, u_v)                         */
+int sdumc_fusion_fwd(const float* u, const float* alpha, float* qin, int32_t V, void* stream);
+/* dqin [7][V,256] -> du [V,3,256] (overwritten), dalpha [V,3] (ACCUMULATED: the second-level
+ * fusion's contribution is already there, it runs earlier in the backward order) */
+int sdumc_fusion_bwd(const float* u, const float* alpha, const float* dqin, float* du, float* dalpha,
+                     int32_t V, void* stream);
+
+/* Second-level fusion (model :346-358).  c [3][V,7,128] (modality-major), alpha [V,3] -> h [V,7,128] */
+int sdumc_hweight_fwd(const float* c, const float* alpha, float* h, int32_t V, void* stream);
+/* dh [V,7,128] -> dc [3][V,7,128] = alpha_m dh (+ dct [V,7,128] on m = 1, the external gradient of
+ * cross_hiddens[:,1]; may be NULL), dalpha [V,3] (overwritten) */
+int sdumc_hweight_bwd(const float* c, const float* alpha, const float* dh, const float* dct, float* dc,
+                      float* dalpha, int32_t V, void* stream);
+/* z[v,:] = sum_i beta[v,i] h[v,i,:]  (model :356-358) */
+int sdumc_zpool_fwd(const float* h, const float* beta, float* z, int32_t V, void* stream);
+/* dz [V,128] -> dh [V,7,128] (overwritten), dbeta [V,7] (overwritten) */
+int sdumc_zpool_bwd(const float* h, const float* beta, const float* dz, float* dh, float* dbeta,
+                    int32_t V, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Losses (toolkit/utils/loss.py) — value and gradient in one call.
+ * ---------------------------------------------------------------------- */
+
+/* MSELoss (loss.py:19-33): loss = sum((pred-target)^2)/denom; dpred = w*2*(pred-target)/denom.
+ * denom = len(pred) of the GLOBAL batch (= rows on one GPU).  loss_out (device scalar) is WRITTEN
+ * with the unweighted local sum / denom. */
+int sdumc_mse_fwd_bwd(const float* pred, const float* target, int32_t rows, float denom, float weight,
+                      float* loss_out, float* dpred, void* stream);
+
+/* Sum of squared differences, for RMSELoss (loss.py:37-51) = sqrt(ssd / numel).
+ * Splitting ssd from the sqrt lets data-parallel ranks all-reduce ssd first. */
+int sdumc_ssd(const float* a, const float* b, int64_t n, float* ssd_out, float* workspace, void* stream);
+size_t sdumc_ssd_workspace_bytes(int64_t n);
+/* da (+)= w*(a-b)/(rmse*numel_global), db (+)= -that ; rmse = sqrt(*ssd_global/numel_global)
+ * loss_out written with rmse.  da / db may be NULL (detached side, main :148). */
+int sdumc_rmse_bwd(const float* a, const float* b, int64_t n_local, const float* ssd_global, double numel_global,
+                   float weight, float* loss_out, float* da, int32_t da_accumulate, float* db,
+                   int32_t db_accumulate, void* stream);
+
+/* RnCLoss (loss.py:271-315). feats [n,dim] = cat(r_stream0, r_stream1), labels [n] (already
+ * repeated).  Computes the loss over ALL n rows and the gradient for rows
+ * [row0, row0+rows_local) only (data-parallel: every rank holds the gathered feats).
+ * loss_out written with the unweighted loss; dfeats [rows_local, dim] overwritten with
+ * weight * dLoss/dfeats. */
+size_t sdumc_rnc_workspace_bytes(int32_t n);
+int sdumc_rnc_fwd_bwd(const float* feats, const float* labels, int32_t n, int32_t dim, float temperature,
+                      float weight, int32_t row0, int32_t rows_local, float* loss_out, float* dfeats,
+                      float* workspace, void* stream);
+/* gradient rows [row0, row0+rows) from the workspace a previous sdumc_rnc_fwd_bwd call filled
+ * (a data-parallel rank owns two row ranges of the gathered matrix: its stream-0 and stream-1 rows) */
+int sdumc_rnc_dfeat_rows(const float* feats, int32_t n, int32_t dim, float temperature, float weight, int32_t row0,
+                         int32_t rows, float* dfeats, float* workspace, void* stream);
+/* the boolean neg_mask of loss.py:303 for anchor i, exported for the bit-exactness test:
+ * mask [n, n-1, n-1] uint8, diagonal removed as loss.py:294-296 does */
+int sdumc_rnc_mask(const float* labels, int32_t n, uint8_t* mask, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Optimiser: torch.optim.Adam(lr, betas, eps, weight_decay) with coupled L2
+ * (main :317) over one flat parameter bucket.  hyper (device, 4 floats) =
+ * {lr (host-written), step count t (incremented by the call), lr/(1-beta1^t), sqrt(1-beta2^t)}:
+ * kept on the device so that a captured graph replays with the right step count.
+ * grad_scale multiplies the gradient first (1/world_size after a sum all-reduce).
+ * ---------------------------------------------------------------------- */
+int sdumc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                    float* hyper, float beta1, float beta2, float eps, float weight_decay,
+                    float grad_scale, void* stream);
+
+/* misc */
+/* dst[r, 0:cols] = src[r, 0:cols] for r < rows, with leading dimensions */
+/* dst[r, 0:cols] += src[r, 0:cols] */
+int sdumc_axpy2d(const float* src, int32_t ld_src, float* dst, int32_t ld_dst, int32_t rows, int32_t cols, void* stream);
+int sdumc_copy2d(const float* src, int32_t ld_src, float* dst, int32_t ld_dst, int32_t rows, int32_t cols, void* stream);
+int sdumc_fill(float* p, float v, int64_t n, void* stream);
+/* device rng/step state helpers: state = {seed_lo, seed_hi, call0}; adds `inc` to call0 */
+int sdumc_rng_advance(uint32_t* dev_state, uint32_t inc, void* stream);
+/* writes the dropout mask values (0 or scale) of a [streams*samples, rows, width] tensor: test hook */
+int sdumc_dropout_mask(const sdumc_dropout* d, int32_t streams, float* mask, void* stream);
+const char* sdumc_version(void);
+
+/* ========================================================================
+ * Network level: WengnetMOSEIMultViewsTextMissing (model :186-370) as one call.
+ *
+ * Parameters live in ONE flat fp32 buffer: the live parameters (those that receive a
+ * gradient) first, the dead ones after; every tensor starts on a
+ * 16-byte boundary.  sdumc_param_table() prints "name offset rows cols live\n" lines with the
+ * reference's state_dict names, so the Python nn.Module exposes nn.Parameters that are views of
+ * the flat buffer and the published checkpoint loads by name.
+ * ==================================================================== */
+int64_t sdumc_param_count(int32_t da, int32_t dt, int32_t dv);      /* floats in the flat buffer */
+int64_t sdumc_param_live_count(int32_t da, int32_t dt, int32_t dv); /* floats in the live prefix (gradient bucket) */
+int32_t sdumc_param_table(int32_t da, int32_t dt, int32_t dv, char* buf, size_t buflen); /* bytes written or <0 */
+
+typedef struct sdumc_net_dims {
+  int32_t B;        /* local batch */
+  int32_t streams;  /* 1 = one reference forward call; 2 = both streams of main :119,:131 batched */
+  int32_t Ta, Tv;   /* frames of audio / video (padded to the batch max by the collater) */
+  int32_t Tt[2];    /* frames of the text-slot input of stream 0 (text) and stream 1 (feat4) */
+  int32_t da, dt, dv;   /* feature widths = args.input_dims[0:3] (model :193-195) */
+  int32_t train;    /* 1: dropout on (model.train()), 0: identity (model.eval()) */
+  int32_t sample0;  /* global index of local sample 0 (data-parallel shard offset) */
+  double p_frame;   /* 0.5: nn.Dropout inside FRA2UTT_new / Cross_Attention (model :54,:77) */
+  double p_mlp;     /* 0.3: constructor default dropout (model :187) */
+} sdumc_net_dims;
+
+typedef struct sdumc_net_io {
+  const float* audio;    /* [B, Ta, da] */
+  const float* video;    /* [B, Tv, dv] */
+  const float* text[2];  /* [B, Tt[s], dt]: stream 0 = text, stream 1 = feat4 (streams==1: text[0]) */
+  float* params;         /* flat parameter buffer */
+  const uint32_t* rng_state; /* device {seed_lo, seed_hi, call0}; stream s draws call0 + s */
+  void* workspace;       /* >= sdumc_net_workspace_bytes(dims); holds the activations saved for backward,
+                            so it must stay untouched between forward and backward */
+  size_t workspace_bytes;
+  /* outputs, V = streams*B rows, stream-major (model :370) */
+  float* vals;           /* [V, 1]      vals_out */
+  float* fused;          /* [V, 128]    cross_fused_feat */
+  float* rnc;            /* [V, 64]     feat4rnc */
+  float* text_hidden;    /* [V, 256]    text_hidden (after cross_text_query_mlp, model :329) */
+  float* cross_text;     /* [V, 7, 128] cross_hiddens[:,1] */
+} sdumc_net_io;
+
+size_t sdumc_net_workspace_bytes(const sdumc_net_dims* d);
+int sdumc_net_forward(const sdumc_net_dims* d, const sdumc_net_io* io, void* stream);
+
+typedef struct sdumc_net_grads {
+  const float* d_vals;        /* gradients w.r.t. the five outputs, same shapes; NULL = zero */
+  const float* d_fused;
+  const float* d_rnc;
+  const float* d_text_hidden;
+  const float* d_cross_text;
+  float* grads;               /* [live count] flat gradient bucket; every live tensor is OVERWRITTEN
+                                 (alignment padding is left untouched: allocate it zeroed) */
+} sdumc_net_grads;
+
+/* loss.backward() through the network (main :149).  Needs the workspace of the matching forward. */
+int sdumc_net_backward(const sdumc_net_dims* d, const sdumc_net_io* io, const sdumc_net_grads* g, void* stream);
+
+/* Two-stream self-distillation step (main :119-150). */
+typedef struct sdumc_step_cfg {
+  float weights[6];      /* full_mse, missing_mse, text_feat, text_query_feat, features, rnc (main :234-239) */
+  float temperature;     /* RnCLoss temperature = 2 (loss.py:272) */
+  float beta1, beta2, eps, weight_decay;   /* Adam (main :317) */
+  const float* labels;   /* [B] sentiment values of the local samples */
+  float* adam_m;         /* [live count] */
+  float* adam_v;         /* [live count] */
+  float* hyper;          /* device float[4], see sdumc_adam_step */
+  float* losses;         /* device float[8]: total, mse_full, mse_missing, rmse_text, rmse_query, rmse_fused, rnc, 0.
+                            MSE entries are the LOCAL sum / B_global (sum over ranks = global value). */
+  /* data-parallel exactness; all zero/NULL on one GPU */
+  int32_t B_global;      /* 0 -> B */
+  const float* ssd_global;        /* device float[3]: all-reduced sums of squared differences (text, query, fused) */
+  const float* rnc_feats_global;  /* [2*B_global, 64] = cat(r_stream0 of all ranks, r_stream1 of all ranks) */
+  const float* rnc_labels_global; /* [2*B_global] */
+  int32_t rnc_row0[2];   /* rows of this rank's stream-0 / stream-1 features in the gathered matrix */
+} sdumc_step_cfg;
+
+size_t sdumc_loss_workspace_bytes(const sdumc_net_dims* d, int32_t B_global);
+/* local sums of squared differences of the three RMSE pairs -> ssd_out float[3] (for the all-reduce) */
+int sdumc_loss_ssd(const sdumc_net_dims* d, const sdumc_net_io* io, float* ssd_out, void* scratch,
+                   size_t scratch_bytes, void* stream);
+/* loss values + gradients w.r.t. the five network outputs (written to the d_* buffers of `g`,
+ * which here are OUTPUTS and must all be non-NULL) */
+int sdumc_loss_backward(const sdumc_net_dims* d, const sdumc_net_io* io, const sdumc_step_cfg* cfg,
+                        const sdumc_net_grads* g, void* scratch, size_t scratch_bytes, void* stream);
+
+/* forward (both streams) + losses + backward + Adam on one GPU.  workspace >= sdumc_step_workspace_bytes. */
+size_t sdumc_step_workspace_bytes(const sdumc_net_dims* d);
+int sdumc_train_step(const sdumc_net_dims* d, const sdumc_net_io* io, const sdumc_step_cfg* cfg, void* stream);
+/* byte offset of the flat gradient bucket inside the sdumc_train_step workspace (tests, DP all-reduce) */
+size_t sdumc_step_grads_offset(const sdumc_net_dims* d);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDUMC_HIP_H */

@@ -1,0 +1,198 @@
+"""ctypes binding of libsdumc_hip.so (include/sdumc_hip.h).
+
+There is NO fallback: if the shared library is missing or a symbol is absent the
+import of any product module raises.  PyTorch-ROCm tensors provide device
+memory and streams; every pointer crossing this boundary is `tensor.data_ptr()`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libsdumc_hip.so")
+
+MAX_GROUPS = 8
+D, H, NQ, RNC_DIM, N_SITES = 256, 128, 7, 64, 35
+NT, NN, TN = 0, 1, 2
+ACT_NONE, ACT_RELU, ACT_TANH = 0, 1, 2
+
+c_float_p = C.c_void_p  # device pointers travel as integers
+
+
+class Dropout(C.Structure):
+    _fields_ = [("enabled", C.c_uint32), ("site", C.c_uint32), ("threshold", C.c_uint32), ("scale", C.c_float),
+                ("rows", C.c_uint32), ("width", C.c_uint32), ("samples", C.c_uint32), ("sample0", C.c_uint32),
+                ("call0", C.c_uint32), ("stream0", C.c_uint32), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
+                ("dev_state", C.c_void_p)]
+
+
+class Gemm(C.Structure):
+    _fields_ = [("layout", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("groups", C.c_int32),
+                ("A", C.c_void_p * MAX_GROUPS), ("B", C.c_void_p * MAX_GROUPS),
+                ("C", C.c_void_p * MAX_GROUPS), ("bias", C.c_void_p * MAX_GROUPS),
+                ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
+                ("a_row_mod", C.c_int32), ("b_row_mod", C.c_int32),
+                ("a_drop", Dropout), ("b_drop", Dropout),
+                ("act", C.c_int32), ("c_drop", Dropout), ("c_drop_group_stride", C.c_int32),
+                ("accumulate", C.c_int32), ("splitk", C.c_int32), ("tile", C.c_int32),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class AttnPool(C.Structure):
+    _fields_ = [("V", C.c_int32), ("T", C.c_int32), ("nq", C.c_int32), ("x_samples", C.c_int32),
+                ("x", C.c_void_p), ("keys", C.c_void_p), ("q", C.c_void_p), ("q_stride", C.c_int64),
+                ("scale", C.c_float), ("x_drop", Dropout), ("out_drop", Dropout),
+                ("attn", C.c_void_p), ("pooled", C.c_void_p), ("out", C.c_void_p)]
+
+
+class AttnPoolBwd(C.Structure):
+    _fields_ = [("f", AttnPool), ("dout", C.c_void_p), ("dz", C.c_void_p), ("dxd", C.c_void_p),
+                ("dq", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class DropSum(C.Structure):
+    _fields_ = [("terms", C.c_int32), ("g", C.c_void_p * 8), ("drop", Dropout * 8),
+                ("stream_idx", C.c_int32 * 8), ("samples", C.c_int32), ("T", C.c_int32), ("dx", C.c_void_p)]
+
+
+class NetDims(C.Structure):
+    _fields_ = [("B", C.c_int32), ("streams", C.c_int32),
+                ("Ta", C.c_int32), ("Tv", C.c_int32), ("Tt", C.c_int32 * 2),
+                ("da", C.c_int32), ("dt", C.c_int32), ("dv", C.c_int32),
+                ("train", C.c_int32), ("sample0", C.c_int32),
+                ("p_frame", C.c_double), ("p_mlp", C.c_double)]
+
+
+class NetIO(C.Structure):
+    _fields_ = [("audio", C.c_void_p), ("video", C.c_void_p), ("text", C.c_void_p * 2),
+                ("params", C.c_void_p), ("rng_state", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                # outputs, each [streams*B, ...]
+                ("vals", C.c_void_p), ("fused", C.c_void_p), ("rnc", C.c_void_p),
+                ("text_hidden", C.c_void_p), ("cross_text", C.c_void_p)]
+
+
+class NetGrads(C.Structure):
+    _fields_ = [("d_vals", C.c_void_p), ("d_fused", C.c_void_p), ("d_rnc", C.c_void_p),
+                ("d_text_hidden", C.c_void_p), ("d_cross_text", C.c_void_p),
+                ("grads", C.c_void_p)]
+
+
+class StepCfg(C.Structure):
+    _fields_ = [("weights", C.c_float * 6), ("temperature", C.c_float),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
+                ("labels", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("hyper", C.c_void_p),
+                ("losses", C.c_void_p),
+                ("B_global", C.c_int32), ("ssd_global", C.c_void_p), ("rnc_feats_global", C.c_void_p),
+                ("rnc_labels_global", C.c_void_p), ("rnc_row0", C.c_int32 * 2)]
+
+
+_SIGS = {
+    "sdumc_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(Gemm)]),
+    "sdumc_gemm_f32": (C.c_int, [C.POINTER(Gemm), C.c_void_p]),
+    "sdumc_attnpool_fwd": (C.c_int, [C.POINTER(AttnPool), C.c_void_p]),
+    "sdumc_attnpool_bwd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "sdumc_attnpool_bwd": (C.c_int, [C.POINTER(AttnPoolBwd), C.c_void_p]),
+    "sdumc_relu_drop_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
+    "sdumc_colsum_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "sdumc_colsum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sdumc_add_n": (C.c_int, [C.POINTER(C.c_void_p), C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "sdumc_dropsum_bwd": (C.c_int, [C.POINTER(DropSum), C.c_void_p]),
+    "sdumc_fusion_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "sdumc_fusion_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "sdumc_hweight_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "sdumc_hweight_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "sdumc_zpool_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "sdumc_zpool_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "sdumc_mse_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdumc_ssd_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "sdumc_ssd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdumc_rmse_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_double, C.c_float, C.c_void_p,
+                                 C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]),
+    "sdumc_rnc_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "sdumc_rnc_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32,
+                                    C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdumc_rnc_dfeat_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_int32,
+                                       C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdumc_rnc_mask": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sdumc_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                  C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "sdumc_copy2d": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sdumc_axpy2d": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sdumc_fill": (C.c_int, [C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
+    "sdumc_rng_advance": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "sdumc_dropout_mask": (C.c_int, [C.POINTER(Dropout), C.c_int32, C.c_void_p, C.c_void_p]),
+    "sdumc_version": (C.c_char_p, []),
+    # network level (engine.hip)
+    "sdumc_param_count": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "sdumc_param_live_count": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
+    "sdumc_param_table": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]),
+    "sdumc_net_workspace_bytes": (C.c_size_t, [C.POINTER(NetDims)]),
+    "sdumc_net_forward": (C.c_int, [C.POINTER(NetDims), C.POINTER(NetIO), C.c_void_p]),
+    "sdumc_net_backward": (C.c_int, [C.POINTER(NetDims), C.POINTER(NetIO), C.POINTER(NetGrads), C.c_void_p]),
+    "sdumc_step_workspace_bytes": (C.c_size_t, [C.POINTER(NetDims)]),
+    "sdumc_train_step": (C.c_int, [C.POINTER(NetDims), C.POINTER(NetIO), C.POINTER(StepCfg), C.c_void_p]),
+    "sdumc_loss_workspace_bytes": (C.c_size_t, [C.POINTER(NetDims), C.c_int32]),
+    "sdumc_loss_ssd": (C.c_int, [C.POINTER(NetDims), C.POINTER(NetIO), C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sdumc_loss_backward": (C.c_int, [C.POINTER(NetDims), C.POINTER(NetIO), C.POINTER(StepCfg), C.POINTER(NetGrads),
+                                      C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sdumc_step_grads_offset": (C.c_size_t, [C.POINTER(NetDims)]),
+}
+
+EXPORTS = tuple(_SIGS)
+
+
+class SdumcError(RuntimeError):
+    pass
+
+
+_ERR = {-1: "SDUMC_EINVAL (bad argument)", -2: "SDUMC_ELAUNCH (HIP launch/runtime error)",
+        -3: "SDUMC_ENOMEM (workspace too small)"}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise SdumcError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C sdumc_amd/csrc`. sdumc_amd has no CPU or PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGS.items():
+        fn = getattr(lib, name)  # AttributeError (loud) if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise SdumcError(f"{what} failed: {_ERR.get(rc, rc)}")
+
+
+def current_stream():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def drop_threshold(p):
+    return int(float(p) * 4294967296.0)
+
+
+def make_dropout(enabled, site, p, rows, width, samples, sample0=0, call0=0, seed=0, dev_state=None):
+    import numpy as np
+    d = Dropout()
+    d.enabled = 1 if enabled else 0
+    d.site = site
+    d.threshold = drop_threshold(p)
+    d.scale = float(np.float32(1.0) / (np.float32(1.0) - np.float32(p)))
+    d.rows, d.width, d.samples, d.sample0, d.call0 = rows, width, samples, sample0, call0
+    d.seed_lo, d.seed_hi = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF
+    d.dev_state = ptr(dev_state)
+    return d

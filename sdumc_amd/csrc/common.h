@@ -1,0 +1,101 @@
+// common.h — shared device/host helpers for libsdumc_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/sdumc_hip.h"
+
+#define SDUMC_CHECK_LAUNCH()                                 \
+  do {                                                       \
+    if (hipGetLastError() != hipSuccess) return SDUMC_ELAUNCH; \
+  } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
+
+// ---------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. SC'11).  Bit-identical to oracle/philox.py.
+// ---------------------------------------------------------------------------
+struct Philox4 {
+  uint32_t w[4];
+};
+
+__device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                 uint32_t k0, uint32_t k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0;
+    c1 = lo1;
+    c2 = hi0 ^ c3 ^ k1;
+    c3 = lo0;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  Philox4 o;
+  o.w[0] = c0; o.w[1] = c1; o.w[2] = c2; o.w[3] = c3;
+  return o;
+}
+
+// Resolved (device-side) view of an sdumc_dropout.
+struct DropRT {
+  uint32_t enabled, site, threshold, rows, qwidth, samples, sample0, call0, stream0, k0, k1;
+  float scale;
+};
+
+__device__ __forceinline__ DropRT drop_resolve(const sdumc_dropout& d) {
+  DropRT r;
+  r.enabled = d.enabled;
+  r.site = d.site;
+  r.threshold = d.threshold;
+  r.rows = d.rows ? d.rows : 1u;
+  r.qwidth = d.width >> 2;
+  r.samples = d.samples ? d.samples : 1u;
+  r.sample0 = d.sample0;
+  r.stream0 = d.stream0;
+  r.scale = d.scale;
+  if (d.dev_state) {
+    r.k0 = d.dev_state[0];
+    r.k1 = d.dev_state[1];
+    r.call0 = d.dev_state[2];
+  } else {
+    r.k0 = d.seed_lo;
+    r.k1 = d.seed_hi;
+    r.call0 = d.call0;
+  }
+  return r;
+}
+
+// The 4 multiplicative mask values of columns [4*cq, 4*cq+4) of virtual row `vrow`
+// (row space [streams][samples][rows]).
+__device__ __forceinline__ f32x4 drop_mask4(const DropRT& d, uint32_t vrow, uint32_t cq) {
+  const uint32_t v = vrow / d.rows;
+  const uint32_t r = vrow - v * d.rows;
+  const uint32_t s = v / d.samples;
+  const uint32_t b = v - s * d.samples;
+  const Philox4 p = philox4x32_10(r * d.qwidth + cq, d.sample0 + b, d.site, d.call0 + d.stream0 + s, d.k0, d.k1);
+  f32x4 m;
+  m[0] = p.w[0] >= d.threshold ? d.scale : 0.f;
+  m[1] = p.w[1] >= d.threshold ? d.scale : 0.f;
+  m[2] = p.w[2] >= d.threshold ? d.scale : 0.f;
+  m[3] = p.w[3] >= d.threshold ? d.scale : 0.f;
+  return m;
+}
+
+__device__ __forceinline__ float drop_mask1(const DropRT& d, uint32_t vrow, uint32_t col) {
+  const f32x4 m = drop_mask4(d, vrow, col >> 2);
+  return m[col & 3];
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}

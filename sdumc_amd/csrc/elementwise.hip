@@ -1,0 +1,348 @@
+// elementwise.hip — the small fused element-wise / reduction kernels of the utterance-level
+// network (model :293-368) and of its backward.  All HBM/L2-streaming: 16-B accesses where the
+// layout allows, wave64 shuffles for the per-sample dot products.
+#include "common.h"
+
+namespace {
+
+constexpr int D = SDUMC_D;
+constexpr int H = SDUMC_H;
+constexpr int NQ = SDUMC_NQ;
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
+
+__global__ void relu_drop_bwd_kernel(const float* dy, const float* y, float scale, float* dz, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dz[i] = y[i] > 0.f ? dy[i] * scale : 0.f;
+}
+
+// ---- column sums -------------------------------------------------------------------------
+constexpr int CS_ROWS = 512;  // rows per first-stage chunk
+__global__ __launch_bounds__(256) void colsum_stage1(const float* a, int64_t rows, int cols, int lda, float* part) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.y * CS_ROWS;
+  const int64_t r1 = min(rows, r0 + CS_ROWS);
+  float acc = 0.f;
+  if (c < cols)
+    for (int64_t r = r0 + rl; r < r1; r += 4) acc += a[r * lda + c];
+  red[rl][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (rl == 0 && c < cols) part[(size_t)blockIdx.y * cols + c] = red[0][c & 63] + red[1][c & 63] + red[2][c & 63] + red[3][c & 63];
+}
+__global__ void colsum_stage2(const float* part, int nchunk, int cols, float* out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= cols) return;
+  float acc = accumulate ? out[c] : 0.f;
+  for (int k = 0; k < nchunk; ++k) acc += part[(size_t)k * cols + c];
+  out[c] = acc;
+}
+
+struct AddN {
+  const float* x[8];
+};
+__global__ void add_n_kernel(AddN a, int k, float* y, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = a.x[0][i];
+  for (int j = 1; j < k; ++j) s += a.x[j][i];
+  y[i] = s;
+}
+
+__global__ void copy2d_kernel(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+  dst[(size_t)r * ld_dst + c] = src[(size_t)r * ld_src + c];
+}
+
+__global__ void axpy2d_kernel(const float* src, int ld_src, float* dst, int ld_dst, int rows, int cols) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * cols) return;
+  const int r = (int)(i / cols), c = (int)(i - (int64_t)r * cols);
+  dst[(size_t)r * ld_dst + c] += src[(size_t)r * ld_src + c];
+}
+
+__global__ void fill_kernel(float* p, float v, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+__global__ void rng_advance_kernel(uint32_t* st, uint32_t inc) { st[2] += inc; }
+
+__global__ void dropout_mask_kernel(const sdumc_dropout d, int64_t nquads, float* mask) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nquads) return;
+  const DropRT r = drop_resolve(d);
+  const uint32_t vrow = (uint32_t)(i / r.qwidth), cq = (uint32_t)(i - (int64_t)vrow * r.qwidth);
+  f32x4 m = {1.f, 1.f, 1.f, 1.f};
+  if (r.enabled) m = drop_mask4(r, vrow, cq);
+  st4(mask + 4 * i, m);
+}
+
+// dx[b,t,:] = sum_k g_k[b,t,:] * mask_k  : one thread per 4 channels
+__global__ void dropsum_bwd_kernel(const sdumc_dropsum p, int64_t nquads) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nquads) return;
+  const uint32_t row = (uint32_t)(i / (D / 4)), cq = (uint32_t)(i - (int64_t)row * (D / 4));  // row = b*T + t
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < p.terms; ++k) {
+    f32x4 g = ld4(p.g[k] + 4 * i);
+    const DropRT d = drop_resolve(p.drop[k]);
+    if (d.enabled) g *= drop_mask4(d, (uint32_t)p.stream_idx[k] * (uint32_t)(p.samples * p.T) + row, cq);
+    acc += g;
+  }
+  st4(p.dx + 4 * i, acc);
+}
+
+// ---- modality fusion (model :301-332): one wave per virtual sample ---------------------------
+__global__ __launch_bounds__(256) void fusion_fwd_kernel(const float* u, const float* alpha, float* qin, int V) {
+  const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (v >= V) return;
+  const f32x4 ua = ld4(u + ((size_t)v * 3 + 0) * D + 4 * lane);
+  const f32x4 ut = ld4(u + ((size_t)v * 3 + 1) * D + 4 * lane);
+  const f32x4 uv = ld4(u + ((size_t)v * 3 + 2) * D + 4 * lane);
+  const float aa = alpha[v * 3 + 0], at = alpha[v * 3 + 1], av = alpha[v * 3 + 2];
+  const size_t o = (size_t)v * D + 4 * lane, gs = (size_t)V * D;
+  st4(qin + 0 * gs + o, ua * aa + ut * at + uv * av);
+  st4(qin + 1 * gs + o, ua * aa + ut * at);
+  st4(qin + 2 * gs + o, ut * at + uv * av);
+  st4(qin + 3 * gs + o, ua * aa + uv * av);
+  st4(qin + 4 * gs + o, ua);
+  st4(qin + 5 * gs + o, ut);
+  st4(qin + 6 * gs + o, uv);
+}
+
+__global__ __launch_bounds__(256) void fusion_bwd_kernel(const float* u, const float* alpha, const float* dqin,
+                                                         float* du, float* dalpha, int V) {
+  const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (v >= V) return;
+  const size_t o = (size_t)v * D + 4 * lane, gs = (size_t)V * D;
+  const f32x4 df = ld4(dqin + o), dfat = ld4(dqin + gs + o), dftv = ld4(dqin + 2 * gs + o),
+              dfav = ld4(dqin + 3 * gs + o);
+  const f32x4 ga = df + dfat + dfav, gt = df + dfat + dftv, gv = df + dftv + dfav;
+  const f32x4 ua = ld4(u + ((size_t)v * 3 + 0) * D + 4 * lane);
+  const f32x4 ut = ld4(u + ((size_t)v * 3 + 1) * D + 4 * lane);
+  const f32x4 uv = ld4(u + ((size_t)v * 3 + 2) * D + 4 * lane);
+  const float aa = alpha[v * 3 + 0], at = alpha[v * 3 + 1], av = alpha[v * 3 + 2];
+  st4(du + ((size_t)v * 3 + 0) * D + 4 * lane, ga * aa + ld4(dqin + 4 * gs + o));
+  st4(du + ((size_t)v * 3 + 1) * D + 4 * lane, gt * at + ld4(dqin + 5 * gs + o));
+  st4(du + ((size_t)v * 3 + 2) * D + 4 * lane, gv * av + ld4(dqin + 6 * gs + o));
+  const float da = wave_sum(dot4(ga, ua)), dt = wave_sum(dot4(gt, ut)), dv = wave_sum(dot4(gv, uv));
+  if (lane == 0) {
+    dalpha[v * 3 + 0] += da;
+    dalpha[v * 3 + 1] += dt;
+    dalpha[v * 3 + 2] += dv;
+  }
+}
+
+// ---- second-level fusion (model :346-349): h = sum_m alpha_m c_m, one wave per (v, i) -----------
+__global__ __launch_bounds__(256) void hweight_fwd_kernel(const float* c, const float* alpha, float* h, int V) {
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // index over V*7*128/4
+  const int64_t total = (int64_t)V * NQ * H / 4;
+  if (e >= total) return;
+  const int v = (int)(e / (NQ * H / 4));
+  const int64_t r = e - (int64_t)v * (NQ * H / 4);
+  const size_t gs = (size_t)V * NQ * H;  // c is [3][V,7,128]
+  const float* cb = c + (size_t)v * NQ * H + 4 * r;
+  st4(h + 4 * e, ld4(cb) * alpha[v * 3] + ld4(cb + gs) * alpha[v * 3 + 1] + ld4(cb + 2 * gs) * alpha[v * 3 + 2]);
+}
+
+// one 256-thread workgroup per v: dc_m = alpha_m dh (+ dct on m = 1), dalpha_m = <dh, c_m>
+__global__ __launch_bounds__(256) void hweight_bwd_kernel(const float* c, const float* alpha, const float* dh,
+                                                          const float* dct, float* dc, float* dalpha, int V) {
+  __shared__ float red[3][4];
+  const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float acc[3] = {0.f, 0.f, 0.f};
+  const float a0 = alpha[v * 3], a1 = alpha[v * 3 + 1], a2 = alpha[v * 3 + 2];
+  for (int e = tid; e < NQ * H / 4; e += 256) {
+    const f32x4 g = ld4(dh + (size_t)v * NQ * H + 4 * e);
+    const size_t gs = (size_t)V * NQ * H;  // c, dc are [3][V,7,128]
+    const size_t cb = (size_t)v * NQ * H + 4 * e;
+    acc[0] += dot4(g, ld4(c + cb));
+    acc[1] += dot4(g, ld4(c + cb + gs));
+    acc[2] += dot4(g, ld4(c + cb + 2 * gs));
+    st4(dc + cb, g * a0);
+    f32x4 g1 = g * a1;
+    if (dct) g1 += ld4(dct + (size_t)v * NQ * H + 4 * e);
+    st4(dc + cb + gs, g1);
+    st4(dc + cb + 2 * gs, g * a2);
+  }
+#pragma unroll
+  for (int m = 0; m < 3; ++m) {
+    const float s = wave_sum(acc[m]);
+    if (lane == 0) red[m][wave] = s;
+  }
+  __syncthreads();
+  if (tid < 3) dalpha[v * 3 + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+}
+
+// z[v,:] = sum_i beta_i h_i : thread per (v, 4 channels)
+__global__ void zpool_fwd_kernel(const float* h, const float* beta, float* z, int V) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= V * (H / 4)) return;
+  const int v = e / (H / 4), cq = e - v * (H / 4);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) acc += ld4(h + ((size_t)v * NQ + i) * H + 4 * cq) * beta[v * NQ + i];
+  st4(z + (size_t)v * H + 4 * cq, acc);
+}
+
+// one wave per v (lanes 0..31 hold 4 channels each): dh_i = beta_i dz ; dbeta_i = <dz, h_i>
+__global__ __launch_bounds__(256) void zpool_bwd_kernel(const float* h, const float* beta, const float* dz, float* dh,
+                                                        float* dbeta, int V) {
+  const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (v >= V) return;
+  const bool on = lane < H / 4;
+  f32x4 g = {0.f, 0.f, 0.f, 0.f};
+  if (on) g = ld4(dz + (size_t)v * H + 4 * lane);
+#pragma unroll
+  for (int i = 0; i < NQ; ++i) {
+    float d = 0.f;
+    if (on) {
+      d = dot4(g, ld4(h + ((size_t)v * NQ + i) * H + 4 * lane));
+      st4(dh + ((size_t)v * NQ + i) * H + 4 * lane, g * beta[v * NQ + i]);
+    }
+    d = wave_sum(d);
+    if (lane == 0) dbeta[v * NQ + i] = d;
+  }
+}
+
+inline unsigned nblk(int64_t n, int b = 256) { return (unsigned)((n + b - 1) / b); }
+
+}  // namespace
+
+extern "C" int sdumc_relu_drop_bwd(const float* dy, const float* y, float scale, float* dz, int64_t n, void* stream) {
+  if (!dy || !y || !dz || n < 0) return SDUMC_EINVAL;
+  if (n == 0) return SDUMC_OK;
+  hipLaunchKernelGGL(relu_drop_bwd_kernel, dim3(nblk(n)), dim3(256), 0, as_stream(stream), dy, y, scale, dz, n);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" size_t sdumc_colsum_workspace_bytes(int64_t rows, int32_t cols) {
+  const int64_t nchunk = (rows + CS_ROWS - 1) / CS_ROWS;
+  return (size_t)nchunk * cols * sizeof(float);
+}
+
+extern "C" int sdumc_colsum(const float* a, int64_t rows, int32_t cols, int32_t lda, float* out, int32_t accumulate,
+                            float* workspace, void* stream) {
+  if (!a || !out || !workspace || rows <= 0 || cols <= 0 || lda < cols) return SDUMC_EINVAL;
+  const int nchunk = (int)((rows + CS_ROWS - 1) / CS_ROWS);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(colsum_stage1, dim3((cols + 63) / 64, nchunk), dim3(256), 0, st, a, rows, cols, lda, workspace);
+  SDUMC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(colsum_stage2, dim3(nblk(cols)), dim3(256), 0, st, workspace, nchunk, cols, out, accumulate);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_add_n(const float* const* xs, int32_t k, float* y, int64_t n, void* stream) {
+  if (!xs || k < 1 || k > 8 || !y || n < 0) return SDUMC_EINVAL;
+  AddN a;
+  for (int i = 0; i < 8; ++i) a.x[i] = i < k ? xs[i] : nullptr;
+  if (n == 0) return SDUMC_OK;
+  hipLaunchKernelGGL(add_n_kernel, dim3(nblk(n)), dim3(256), 0, as_stream(stream), a, k, y, n);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_copy2d(const float* src, int32_t ld_src, float* dst, int32_t ld_dst, int32_t rows, int32_t cols,
+                            void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || ld_src < cols || ld_dst < cols) return SDUMC_EINVAL;
+  hipLaunchKernelGGL(copy2d_kernel, dim3(nblk((int64_t)rows * cols)), dim3(256), 0, as_stream(stream), src, ld_src, dst,
+                     ld_dst, rows, cols);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_axpy2d(const float* src, int32_t ld_src, float* dst, int32_t ld_dst, int32_t rows, int32_t cols,
+                            void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || ld_src < cols || ld_dst < cols) return SDUMC_EINVAL;
+  hipLaunchKernelGGL(axpy2d_kernel, dim3(nblk((int64_t)rows * cols)), dim3(256), 0, as_stream(stream), src, ld_src, dst,
+                     ld_dst, rows, cols);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_fill(float* p, float v, int64_t n, void* stream) {
+  if (!p || n < 0) return SDUMC_EINVAL;
+  if (n == 0) return SDUMC_OK;
+  hipLaunchKernelGGL(fill_kernel, dim3(nblk(n)), dim3(256), 0, as_stream(stream), p, v, n);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_rng_advance(uint32_t* dev_state, uint32_t inc, void* stream) {
+  if (!dev_state) return SDUMC_EINVAL;
+  hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, as_stream(stream), dev_state, inc);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_dropout_mask(const sdumc_dropout* d, int32_t streams, float* mask, void* stream) {
+  if (!d || !mask || streams < 1 || (d->width & 3) || d->width == 0) return SDUMC_EINVAL;
+  const int64_t nquads = (int64_t)streams * d->samples * (d->rows ? d->rows : 1) * (d->width / 4);
+  hipLaunchKernelGGL(dropout_mask_kernel, dim3(nblk(nquads)), dim3(256), 0, as_stream(stream), *d, nquads, mask);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_dropsum_bwd(const sdumc_dropsum* p, void* stream) {
+  if (!p || p->terms < 1 || p->terms > 8 || !p->dx || p->samples <= 0 || p->T <= 0) return SDUMC_EINVAL;
+  for (int k = 0; k < p->terms; ++k)
+    if (!p->g[k]) return SDUMC_EINVAL;
+  const int64_t nquads = (int64_t)p->samples * p->T * (D / 4);
+  hipLaunchKernelGGL(dropsum_bwd_kernel, dim3(nblk(nquads)), dim3(256), 0, as_stream(stream), *p, nquads);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_fusion_fwd(const float* u, const float* alpha, float* qin, int32_t V, void* stream) {
+  if (!u || !alpha || !qin || V <= 0) return SDUMC_EINVAL;
+  hipLaunchKernelGGL(fusion_fwd_kernel, dim3((V + 3) / 4), dim3(256), 0, as_stream(stream), u, alpha, qin, V);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_fusion_bwd(const float* u, const float* alpha, const float* dqin, float* du, float* dalpha,
+                                int32_t V, void* stream) {
+  if (!u || !alpha || !dqin || !du || !dalpha || V <= 0) return SDUMC_EINVAL;
+  hipLaunchKernelGGL(fusion_bwd_kernel, dim3((V + 3) / 4), dim3(256), 0, as_stream(stream), u, alpha, dqin, du, dalpha, V);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_hweight_fwd(const float* c, const float* alpha, float* h, int32_t V, void* stream) {
+  if (!c || !alpha || !h || V <= 0) return SDUMC_EINVAL;
+  hipLaunchKernelGGL(hweight_fwd_kernel, dim3(nblk((int64_t)V * NQ * H / 4)), dim3(256), 0, as_stream(stream), c, alpha, h, V);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_hweight_bwd(const float* c, const float* alpha, const float* dh, const float* dct, float* dc,
+                                 float* dalpha, int32_t V, void* stream) {
+  if (!c || !alpha || !dh || !dc || !dalpha || V <= 0) return SDUMC_EINVAL;
+  hipLaunchKernelGGL(hweight_bwd_kernel, dim3(V), dim3(256), 0, as_stream(stream), c, alpha, dh, dct, dc, dalpha, V);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_zpool_fwd(const float* h, const float* beta, float* z, int32_t V, void* stream) {
+  if (!h || !beta || !z || V <= 0) return SDUMC_EINVAL;
+  hipLaunchKernelGGL(zpool_fwd_kernel, dim3(nblk((int64_t)V * (H / 4))), dim3(256), 0, as_stream(stream), h, beta, z, V);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_zpool_bwd(const float* h, const float* beta, const float* dz, float* dh, float* dbeta, int32_t V,
+                               void* stream) {
+  if (!h || !beta || !dz || !dh || !dbeta || V <= 0) return SDUMC_EINVAL;
+  hipLaunchKernelGGL(zpool_bwd_kernel, dim3((V + 3) / 4), dim3(256), 0, as_stream(stream), h, beta, dz, dh, dbeta, V);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" const char* sdumc_version(void) { return "sdumc_hip 0.1 (gfx950)"; }

@@ -1,0 +1,1051 @@
+// engine.hip — WengnetMOSEIMultViewsTextMissing forward / backward and the two-stream
+// self-distillation step as a sequence of HIP kernel launches on one stream (host side of the C ABI).
+//
+//   sdumc_net_forward   model :275-370 for 1 stream, or for both streams of main :119,:131 at once
+//   sdumc_net_backward  loss.backward() (main :149) through that network, hand-derived
+//   sdumc_loss_backward main :137-148 (MSE x2, RMSE x3, RnC) value + gradient w.r.t. network outputs
+//   sdumc_train_step    main :119-150 on one GPU: forward, losses, backward, Adam
+//
+// "Virtual batch": the two streams are stacked, V = streams*B rows, stream-major.  Every
+// utterance-level layer then runs ONCE on V rows (the reference calls the same weights twice);
+// the audio/video frame projections are computed once and shared by both streams (a_row_mod), only
+// the dropout masks differ per stream (Philox call index = call0 + stream).
+// No allocation, no synchronisation, no host copies: everything here is hipGraph-capturable.
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "common.h"
+
+extern "C" int sdumc_axpy2d(const float* src, int32_t ld_src, float* dst, int32_t ld_dst, int32_t rows, int32_t cols,
+                            void* stream);
+
+namespace {
+
+constexpr int D = SDUMC_D, H = SDUMC_H, NQ = SDUMC_NQ, RD = SDUMC_RNC_DIM;
+
+// dropout call sites in the reference's call order (oracle/sdumc_oracle.py SITE_*)
+constexpr int SITE_IN[2][3] = {{0, 2, 4}, {21, 23, 25}};    // [fra|cross][modality] input dropout
+constexpr int SITE_OUT[2][3] = {{1, 3, 5}, {22, 24, 26}};   // output dropout
+constexpr int SITE_UMLP0 = 6, SITE_UMLP1 = 7;               // + 2*m
+constexpr int SITE_ATT0 = 12, SITE_ATT1 = 13, SITE_QUERY = 14;
+constexpr int SITE_CMLP0 = 27, SITE_CMLP1 = 28;             // + 2*m
+constexpr int SITE_CATT0 = 33, SITE_CATT1 = 34;
+
+#define RET(x)                 \
+  do {                         \
+    int _rc = (x);             \
+    if (_rc != SDUMC_OK) return _rc; \
+  } while (0)
+
+// ------------------------------------------------------------------------------------------
+// parameter layout
+// ------------------------------------------------------------------------------------------
+struct Lin {
+  int64_t w = 0, b = 0;
+  int out = 0, in = 0;
+};
+struct PEntry {
+  std::string name;
+  int64_t off;
+  int rows, cols;  // cols = 0 for 1-D tensors
+  bool live;
+};
+struct ParamMap {
+  Lin frame[3], fra_proj[3], umlp0[3], umlp3[3], att0, att3, fc_att, query[7], ca_q[3], ca_in[3], cmlp0[3], cmlp3[3],
+      catt0, catt3, cross_fc_att, fc_out_v, rnc0, rnc2;
+  int64_t fra_ctx[3] = {0, 0, 0};
+  int64_t live = 0, total = 0;
+  std::vector<PEntry> table;
+};
+
+inline int64_t align4(int64_t n) { return (n + 3) & ~(int64_t)3; }
+
+struct PBuilder {
+  ParamMap& pm;
+  int64_t cur = 0;
+  bool live = true;
+  int64_t add(const std::string& name, int rows, int cols) {
+    const int64_t off = cur;
+    pm.table.push_back({name, off, rows, cols, live});
+    cur += align4((int64_t)rows * (cols ? cols : 1));
+    return off;
+  }
+  Lin lin(const std::string& name, int out, int in) {
+    Lin l;
+    l.out = out;
+    l.in = in;
+    l.w = add(name + ".weight", out, in);
+    l.b = add(name + ".bias", out, 0);
+    return l;
+  }
+};
+
+ParamMap build_params_uncached(int da, int dt, int dv);
+// the layout depends on the three feature widths only: build it once per (da, dt, dv)
+const ParamMap& build_params(int da, int dt, int dv) {
+  static std::mutex mu;
+  static std::map<std::tuple<int, int, int>, ParamMap> cache;
+  std::lock_guard<std::mutex> lock(mu);
+  auto key = std::make_tuple(da, dt, dv);
+  auto it = cache.find(key);
+  if (it == cache.end()) it = cache.emplace(key, build_params_uncached(da, dt, dv)).first;
+  return it->second;
+}
+
+ParamMap build_params_uncached(int da, int dt, int dv) {
+  ParamMap pm;
+  PBuilder b{pm};
+  static const char* MOD[3] = {"audio", "text", "video"};
+  static const char* QN[7] = {"fused", "at", "tv", "av", "audio", "text", "video"};
+  const int din[3] = {da, dt, dv};
+  for (int m = 0; m < 3; ++m) pm.frame[m] = b.lin("frame_dim_reshape_" + std::to_string(m), D, din[m]);
+  for (int m = 0; m < 3; ++m) {
+    const std::string p = "fra2utt_" + std::to_string(m);
+    pm.fra_ctx[m] = b.add(p + ".attention_context_vector", 1, D);
+    pm.fra_proj[m] = b.lin(p + ".input_proj", D, D);
+  }
+  for (int m = 0; m < 3; ++m) {
+    pm.umlp0[m] = b.lin(std::string(MOD[m]) + "_mlp.0", D, D);
+    pm.umlp3[m] = b.lin(std::string(MOD[m]) + "_mlp.3", D, D);
+  }
+  pm.att0 = b.lin("attention_mlp.0", D, 3 * D);
+  pm.att3 = b.lin("attention_mlp.3", D, D);
+  pm.fc_att = b.lin("fc_att", 3, D);
+  for (int i = 0; i < 7; ++i) pm.query[i] = b.lin(std::string("cross_") + QN[i] + "_query_mlp.0", D, D);
+  for (int m = 0; m < 3; ++m) {
+    const std::string p = "cross_att_fra2utt_" + std::to_string(m);
+    pm.ca_q[m] = b.lin(p + ".query_proj", D, D);
+    pm.ca_in[m] = b.lin(p + ".input_proj", D, D);
+  }
+  for (int m = 0; m < 3; ++m) {
+    pm.cmlp0[m] = b.lin(std::string("cross_") + MOD[m] + "_mlp.0", D, D);
+    pm.cmlp3[m] = b.lin(std::string("cross_") + MOD[m] + "_mlp.3", H, D);
+  }
+  pm.catt0 = b.lin("cross_attention_mlp.0", D, NQ * H);
+  pm.catt3 = b.lin("cross_attention_mlp.3", H, D);
+  pm.cross_fc_att = b.lin("cross_fc_att", NQ, H);
+  pm.fc_out_v = b.lin("fc_out_v", 1, H);
+  pm.rnc0 = b.lin("orgin_linear_change.0", RD, H);
+  pm.rnc2 = b.lin("orgin_linear_change.2", RD, RD);
+  pm.live = b.cur;
+  // parameters that exist for state_dict compatibility but never receive a gradient
+  // (model :202-203, :242, :244, :257, :260)
+  b.live = false;
+  struct AE {
+    const char* name;
+    int dim, lat;
+  } aes[2] = {{"missing_text_imagination_mlp", D, 128}, {"missing_cross_text_query_imagination_mlp", 128, 64}};
+  for (const AE& a : aes) {
+    const std::string p = a.name;
+    b.lin(p + ".transition.0", a.dim, a.dim * 3);
+    b.lin(p + ".transition.2", a.dim, a.dim);
+    b.lin(p + ".encoder_0.0", a.lat, a.dim);
+    b.lin(p + ".decoder_0.0", a.dim, a.lat);
+  }
+  b.lin("fc_out_e", 1, H);
+  b.lin("fc_out_ev", 1, 1);
+  b.add("prelu.weight", 6, 0);
+  b.add("layer_normali.weight", D, 0);
+  b.add("layer_normali.bias", D, 0);
+  pm.total = b.cur;
+  return pm;
+}
+
+// ------------------------------------------------------------------------------------------
+// workspace plan (offsets in floats; every buffer 64-float = 256-byte aligned)
+// ------------------------------------------------------------------------------------------
+struct Seg {       // a run of virtual samples of one modality that share T and sit contiguously
+  int s0;          // first stream in the run
+  int V;           // virtual samples in the run
+  int T;
+  int x_samples;   // samples held by the x buffer (B when both streams share x, else V)
+  int64_t x_off;   // offset of the x buffer
+  int64_t row0;    // first virtual row (v*T + t) of the run inside the modality's row space
+};
+
+struct Plan {
+  int B = 0, S = 0, V = 0;
+  int64_t cur = 0;
+  int T[3][2];
+  int64_t x[3][2];          // projected features; audio/video: [m][0] only
+  int64_t rows[3];          // virtual rows of modality m = sum over streams of B*T
+  std::vector<Seg> segs[3];
+  int64_t keys[2][3], attn[2][3], pooled[2][3];
+  int64_t hpre, u1, u, att1, att2, alpha, qin, q, qp, ca_out, c1, c, h, e1, e2, beta, z, vals, r1, r;
+  // backward
+  int64_t dz[2][3], dxd[2][3], dx[3][2];
+  int64_t d_hpre, d_u1, d_u, d_att1, d_att2, d_alpha, d_qin, d_q, d_qp, d_ca_out, d_c1, d_c, d_h, d_e1, d_e2, d_beta,
+      d_z, d_r1, dq_fra;
+  int64_t scratch = 0, scratch_floats = 0;
+  int64_t alloc(int64_t n) {
+    const int64_t o = cur;
+    cur += (n + 63) & ~(int64_t)63;
+    return o;
+  }
+};
+
+int pick_splitk(int M, int N, int K, int groups) {
+  const long tiles = (long)((M + 127) / 128) * ((N + 127) / 128) * groups;
+  if (tiles >= 256) return 1;
+  long s = (384 + tiles - 1) / tiles;
+  const long kmax = K / 256;
+  if (s > kmax) s = kmax;
+  return s < 1 ? 1 : (int)s;
+}
+
+size_t attnpool_bwd_ws_floats(int V, int T, int nq) { return (size_t)V * ((T + 63) / 64) * nq * D; }
+
+bool make_plan(const sdumc_net_dims& d, Plan& p) {
+  if (d.B <= 0 || (d.streams != 1 && d.streams != 2) || d.Ta <= 0 || d.Tv <= 0 || d.Tt[0] <= 0) return false;
+  if (d.streams == 2 && d.Tt[1] <= 0) return false;
+  if (d.da <= 0 || d.dt <= 0 || d.dv <= 0) return false;
+  p.B = d.B;
+  p.S = d.streams;
+  p.V = d.B * d.streams;
+  const int B = p.B, S = p.S, V = p.V;
+  for (int s = 0; s < 2; ++s) {
+    p.T[0][s] = d.Ta;
+    p.T[1][s] = d.Tt[s < S ? s : 0];
+    p.T[2][s] = d.Tv;
+  }
+  // x buffers; the text buffers of the two streams are adjacent so that equal T merges them
+  p.x[0][0] = p.alloc((int64_t)B * d.Ta * D);
+  p.x[0][1] = p.x[0][0];
+  p.x[2][0] = p.alloc((int64_t)B * d.Tv * D);
+  p.x[2][1] = p.x[2][0];
+  {
+    const int64_t n0 = (int64_t)B * p.T[1][0] * D;
+    const int64_t n1 = S == 2 ? (int64_t)B * p.T[1][1] * D : 0;
+    p.x[1][0] = p.alloc(n0 + n1);
+    p.x[1][1] = p.x[1][0] + n0;
+  }
+  for (int m = 0; m < 3; ++m) {
+    p.segs[m].clear();
+    if (m != 1 || S == 1 || p.T[1][0] == p.T[1][1]) {
+      Seg sg;
+      sg.s0 = 0;
+      sg.V = V;
+      sg.T = p.T[m][0];
+      sg.x_samples = (m == 1) ? V : B;
+      sg.x_off = p.x[m][0];
+      sg.row0 = 0;
+      p.segs[m].push_back(sg);
+      p.rows[m] = (int64_t)V * sg.T;
+    } else {
+      int64_t row0 = 0;
+      for (int s = 0; s < 2; ++s) {
+        Seg sg;
+        sg.s0 = s;
+        sg.V = B;
+        sg.T = p.T[1][s];
+        sg.x_samples = B;
+        sg.x_off = p.x[1][s];
+        sg.row0 = row0;
+        p.segs[m].push_back(sg);
+        row0 += (int64_t)B * sg.T;
+      }
+      p.rows[m] = row0;
+    }
+  }
+  const int nq[2] = {1, NQ};
+  for (int k = 0; k < 2; ++k)
+    for (int m = 0; m < 3; ++m) {
+      p.keys[k][m] = p.alloc(p.rows[m] * D);
+      p.attn[k][m] = p.alloc(p.rows[m] * nq[k]);
+      p.pooled[k][m] = p.alloc((int64_t)V * nq[k] * D);
+    }
+  p.hpre = p.alloc(3LL * V * D);
+  p.u1 = p.alloc(3LL * V * D);
+  p.u = p.alloc(3LL * V * D);
+  p.att1 = p.alloc((int64_t)V * D);
+  p.att2 = p.alloc((int64_t)V * D);
+  p.alpha = p.alloc((int64_t)V * 3);
+  p.qin = p.alloc(7LL * V * D);
+  p.q = p.alloc(7LL * V * D);
+  p.qp = p.alloc(3LL * V * NQ * D);
+  p.ca_out = p.alloc(3LL * V * NQ * D);
+  p.c1 = p.alloc(3LL * V * NQ * D);
+  p.c = p.alloc(3LL * V * NQ * H);
+  p.h = p.alloc((int64_t)V * NQ * H);
+  p.e1 = p.alloc((int64_t)V * D);
+  p.e2 = p.alloc((int64_t)V * H);
+  p.beta = p.alloc((int64_t)V * NQ);
+  p.z = p.alloc((int64_t)V * H);
+  p.vals = p.alloc(V);
+  p.r1 = p.alloc((int64_t)V * RD);
+  p.r = p.alloc((int64_t)V * RD);
+  // backward
+  for (int k = 0; k < 2; ++k)
+    for (int m = 0; m < 3; ++m) {
+      p.dz[k][m] = p.alloc(p.rows[m] * D);
+      p.dxd[k][m] = p.alloc(p.rows[m] * D);
+    }
+  p.dx[0][0] = p.dx[0][1] = p.alloc((int64_t)B * d.Ta * D);
+  p.dx[2][0] = p.dx[2][1] = p.alloc((int64_t)B * d.Tv * D);
+  p.dx[1][0] = p.alloc((int64_t)B * p.T[1][0] * D);
+  p.dx[1][1] = S == 2 ? p.alloc((int64_t)B * p.T[1][1] * D) : p.dx[1][0];
+  p.d_hpre = p.alloc(3LL * V * D);
+  p.d_u1 = p.alloc(3LL * V * D);
+  p.d_u = p.alloc(3LL * V * D);
+  p.d_att1 = p.alloc((int64_t)V * D);
+  p.d_att2 = p.alloc((int64_t)V * D);
+  p.d_alpha = p.alloc((int64_t)V * 3);
+  p.d_qin = p.alloc(7LL * V * D);
+  p.d_q = p.alloc(7LL * V * D);
+  p.d_qp = p.alloc(3LL * V * NQ * D);
+  p.d_ca_out = p.alloc(3LL * V * NQ * D);
+  p.d_c1 = p.alloc(3LL * V * NQ * D);
+  p.d_c = p.alloc(3LL * V * NQ * H);
+  p.d_h = p.alloc((int64_t)V * NQ * H);
+  p.d_e1 = p.alloc((int64_t)V * D);
+  p.d_e2 = p.alloc((int64_t)V * H);
+  p.d_beta = p.alloc((int64_t)V * NQ);
+  p.d_z = p.alloc((int64_t)V * H);
+  p.d_r1 = p.alloc((int64_t)V * RD);
+  p.dq_fra = p.alloc(3LL * V * D);
+  // scratch shared by split-K slabs, column-sum partials and the attention-pool dq slabs
+  int64_t sc = 1 << 16;
+  const int din[3] = {d.da, d.dt, d.dv};
+  for (int m = 0; m < 3; ++m) {
+    for (int s = 0; s < S; ++s) {
+      const int K = B * p.T[m][s];
+      sc = std::max<int64_t>(sc, (int64_t)pick_splitk(D, din[m], K, 1) * D * din[m]);
+    }
+    sc = std::max<int64_t>(sc, (int64_t)pick_splitk(D, D, (int)p.rows[m], 1) * D * D);
+    for (const Seg& sg : p.segs[m]) sc = std::max<int64_t>(sc, (int64_t)attnpool_bwd_ws_floats(sg.V, sg.T, NQ));
+    sc = std::max<int64_t>(sc, (int64_t)((p.rows[m] + 511) / 512 + 1) * D);
+  }
+  sc = std::max<int64_t>(sc, (int64_t)8 * 4 * D * NQ * H);  // grouped utterance-level split-K upper bound
+  p.scratch_floats = sc;
+  p.scratch = p.alloc(sc);
+  return true;
+}
+
+// ------------------------------------------------------------------------------------------
+struct Ctx {
+  const sdumc_net_dims& d;
+  const sdumc_net_io& io;
+  hipStream_t st;
+  const ParamMap& pm;
+  Plan pl;
+  float* W;     // workspace base
+  float* P;     // parameters
+  float* G;     // gradient bucket (backward only)
+  float* p(int64_t off) const { return W + off; }
+};
+
+sdumc_dropout mkdrop(const Ctx& c, int site, double prob, int rows, int width, int stream0 = 0) {
+  sdumc_dropout r;
+  memset(&r, 0, sizeof(r));
+  r.enabled = c.d.train ? 1u : 0u;
+  r.site = (uint32_t)site;
+  r.threshold = (uint32_t)(uint64_t)(prob * 4294967296.0);
+  r.scale = 1.0f / (1.0f - (float)prob);
+  r.rows = (uint32_t)rows;
+  r.width = (uint32_t)width;
+  r.samples = (uint32_t)c.d.B;
+  r.sample0 = (uint32_t)c.d.sample0;
+  r.stream0 = (uint32_t)stream0;
+  r.dev_state = c.io.rng_state;
+  return r;
+}
+
+sdumc_gemm G_(int layout, int M, int N, int K, int groups = 1) {
+  sdumc_gemm g;
+  memset(&g, 0, sizeof(g));
+  g.layout = layout;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.groups = groups;
+  return g;
+}
+
+int run(const Ctx& c, sdumc_gemm& g) {
+  g.workspace = c.p(c.pl.scratch);
+  g.workspace_bytes = (size_t)c.pl.scratch_floats * sizeof(float);
+  while (g.splitk > 1 && sdumc_gemm_workspace_bytes(&g) > g.workspace_bytes) --g.splitk;
+  return sdumc_gemm_f32(&g, c.st);
+}
+
+// y = act(x W^T + b) (+ dropout), single group
+int lin_fwd(const Ctx& c, const Lin& L, const float* x, int lda, int M, float* y, int ldc, int act,
+            const sdumc_dropout* drop) {
+  sdumc_gemm g = G_(SDUMC_NT, M, L.out, L.in);
+  g.A[0] = x;
+  g.lda = lda;
+  g.B[0] = c.P + L.w;
+  g.ldb = L.in;
+  g.bias[0] = c.P + L.b;
+  g.C[0] = y;
+  g.ldc = ldc;
+  g.act = act;
+  if (drop) g.c_drop = *drop;
+  return run(c, g);
+}
+
+int colsum(const Ctx& c, const float* a, int64_t rows, int cols, int lda, float* out, int accumulate) {
+  return sdumc_colsum(a, rows, cols, lda, out, accumulate, c.p(c.pl.scratch), c.st);
+}
+
+// backward of y = act(x W^T + b) given dzv = gradient w.r.t. the pre-activation, [M, L.out] with ld lddz:
+//   dW = dz^T x, db = colsum(dz), dx (=|+=) dz W
+int lin_bwd(const Ctx& c, const Lin& L, const float* dzv, int lddz, const float* x, int ldx, int M, float* dx, int lddx,
+            int dx_accumulate) {
+  sdumc_gemm gw = G_(SDUMC_TN, L.out, L.in, M);
+  gw.A[0] = dzv;
+  gw.lda = lddz;
+  gw.B[0] = x;
+  gw.ldb = ldx;
+  gw.C[0] = c.G + L.w;
+  gw.ldc = L.in;
+  gw.splitk = pick_splitk(L.out, L.in, M, 1);
+  RET(run(c, gw));
+  RET(colsum(c, dzv, M, L.out, lddz, c.G + L.b, 0));
+  if (dx) {
+    sdumc_gemm gx = G_(SDUMC_NN, M, L.in, L.out);
+    gx.A[0] = dzv;
+    gx.lda = lddz;
+    gx.B[0] = c.P + L.w;
+    gx.ldb = L.in;
+    gx.C[0] = dx;
+    gx.ldc = lddx;
+    gx.accumulate = dx_accumulate;
+    RET(run(c, gx));
+  }
+  return SDUMC_OK;
+}
+
+// grouped version: identical shapes, per-group pointers given by base + g*stride (floats)
+struct GroupPtrs {
+  const float* dz;  int64_t dz_gs;  int lddz;
+  const float* x;   int64_t x_gs;   int ldx;
+  float* dx;        int64_t dx_gs;  int lddx;
+};
+int lin_bwd_grouped(const Ctx& c, const Lin* L, int ng, int M, const GroupPtrs& q) {
+  sdumc_gemm gw = G_(SDUMC_TN, L[0].out, L[0].in, M, ng);
+  sdumc_gemm gx = G_(SDUMC_NN, M, L[0].in, L[0].out, ng);
+  for (int g = 0; g < ng; ++g) {
+    gw.A[g] = q.dz + g * q.dz_gs;
+    gw.B[g] = q.x + g * q.x_gs;
+    gw.C[g] = c.G + L[g].w;
+    gx.A[g] = q.dz + g * q.dz_gs;
+    gx.B[g] = c.P + L[g].w;
+    gx.C[g] = q.dx ? q.dx + g * q.dx_gs : nullptr;
+  }
+  gw.lda = q.lddz;
+  gw.ldb = q.ldx;
+  gw.ldc = L[0].in;
+  gw.splitk = pick_splitk(L[0].out, L[0].in, M, ng);
+  RET(run(c, gw));
+  for (int g = 0; g < ng; ++g) RET(colsum(c, q.dz + g * q.dz_gs, M, L[g].out, q.lddz, c.G + L[g].b, 0));
+  if (q.dx) {
+    gx.lda = q.lddz;
+    gx.ldb = L[0].in;
+    gx.ldc = q.lddx;
+    RET(run(c, gx));
+  }
+  return SDUMC_OK;
+}
+
+int check_io(const sdumc_net_dims* d, const sdumc_net_io* io) {
+  if (!d || !io) return SDUMC_EINVAL;
+  if (!io->audio || !io->video || !io->text[0] || !io->params || !io->workspace) return SDUMC_EINVAL;
+  if (d->streams == 2 && !io->text[1]) return SDUMC_EINVAL;
+  if (d->train && !io->rng_state) return SDUMC_EINVAL;
+  if (reinterpret_cast<uintptr_t>(io->workspace) & 255) return SDUMC_EINVAL;
+  if (reinterpret_cast<uintptr_t>(io->params) & 15) return SDUMC_EINVAL;
+  return SDUMC_OK;
+}
+
+// the attention-pooling descriptor of (site kind k, modality m, run sg) — shared by forward and backward
+sdumc_attnpool attn_desc(const Ctx& c, int k, int m, const Seg& sg) {
+  const Plan& pl = c.pl;
+  const int nq = k == 0 ? 1 : NQ;
+  sdumc_attnpool a;
+  memset(&a, 0, sizeof(a));
+  a.V = sg.V;
+  a.T = sg.T;
+  a.nq = nq;
+  a.x_samples = sg.x_samples;
+  a.x = c.p(sg.x_off);
+  a.keys = c.p(pl.keys[k][m]) + sg.row0 * D;
+  if (k == 0) {
+    a.q = c.P + c.pm.fra_ctx[m];
+    a.q_stride = 0;
+  } else {
+    a.q = c.p(pl.qp) + ((int64_t)m * pl.V + (int64_t)sg.s0 * pl.B) * NQ * D;
+    a.q_stride = (int64_t)NQ * D;
+  }
+  a.scale = 0.3f;
+  a.x_drop = mkdrop(c, SITE_IN[k][m], c.d.p_frame, sg.T, D, sg.s0);
+  a.out_drop = mkdrop(c, SITE_OUT[k][m], c.d.p_frame, nq, D, sg.s0);
+  a.attn = c.p(pl.attn[k][m]) + sg.row0 * nq;
+  a.pooled = c.p(pl.pooled[k][m]) + (int64_t)sg.s0 * pl.B * nq * D;
+  float* outbase = k == 0 ? c.p(pl.hpre) + (int64_t)m * pl.V * D : c.p(pl.ca_out) + (int64_t)m * pl.V * NQ * D;
+  a.out = outbase + (int64_t)sg.s0 * pl.B * nq * D;
+  return a;
+}
+
+// keys = tanh(drop(x) W^T + b) for every run of (k, m)
+int keys_fwd(const Ctx& c, int k, int m) {
+  const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
+  for (const Seg& sg : c.pl.segs[m]) {
+    sdumc_gemm g = G_(SDUMC_NT, sg.V * sg.T, D, D);
+    g.A[0] = c.p(sg.x_off);
+    g.lda = D;
+    g.a_row_mod = sg.x_samples < sg.V ? sg.x_samples * sg.T : 0;
+    g.a_drop = mkdrop(c, SITE_IN[k][m], c.d.p_frame, sg.T, D, sg.s0);
+    g.B[0] = c.P + L.w;
+    g.ldb = D;
+    g.bias[0] = c.P + L.b;
+    g.C[0] = c.p(c.pl.keys[k][m]) + sg.row0 * D;
+    g.ldc = D;
+    g.act = SDUMC_ACT_TANH;
+    RET(run(c, g));
+    sdumc_attnpool a = attn_desc(c, k, m, sg);
+    RET(sdumc_attnpool_fwd(&a, c.st));
+  }
+  return SDUMC_OK;
+}
+
+int forward(const Ctx& c) {
+  const Plan& pl = c.pl;
+  const ParamMap& pm = c.pm;
+  const int B = pl.B, S = pl.S, V = pl.V;
+  const int din[3] = {c.d.da, c.d.dt, c.d.dv};
+  // 1. frame_dim_reshape_{0,1,2} (model :282-284); audio/video once for both streams
+  for (int m = 0; m < 3; ++m)
+    for (int s = 0; s < (m == 1 ? S : 1); ++s) {
+      const float* in = m == 0 ? c.io.audio : (m == 2 ? c.io.video : c.io.text[s]);
+      RET(lin_fwd(c, pm.frame[m], in, din[m], B * pl.T[m][s], c.p(pl.x[m][s]), D, SDUMC_ACT_NONE, nullptr));
+    }
+  // 2. fra2utt_{0,1,2} (model :288-290)
+  for (int m = 0; m < 3; ++m) RET(keys_fwd(c, 0, m));
+  // 3. audio/text/video_mlp (model :293-295), grouped over the modality
+  {
+    sdumc_gemm g = G_(SDUMC_NT, V, D, D, 3);
+    for (int m = 0; m < 3; ++m) {
+      g.A[m] = c.p(pl.hpre) + (int64_t)m * V * D;
+      g.B[m] = c.P + pm.umlp0[m].w;
+      g.bias[m] = c.P + pm.umlp0[m].b;
+      g.C[m] = c.p(pl.u1) + (int64_t)m * V * D;
+    }
+    g.lda = g.ldb = g.ldc = D;
+    g.act = SDUMC_ACT_RELU;
+    g.c_drop = mkdrop(c, SITE_UMLP0, c.d.p_mlp, 1, D);
+    g.c_drop_group_stride = 2;
+    RET(run(c, g));
+    for (int m = 0; m < 3; ++m) {
+      g.A[m] = c.p(pl.u1) + (int64_t)m * V * D;
+      g.B[m] = c.P + pm.umlp3[m].w;
+      g.bias[m] = c.P + pm.umlp3[m].b;
+      g.C[m] = c.p(pl.u) + m * D;  // u is [V, 3, D]: the torch.cat of model :301 for free
+    }
+    g.ldc = 3 * D;
+    g.c_drop = mkdrop(c, SITE_UMLP1, c.d.p_mlp, 1, D);
+    RET(run(c, g));
+  }
+  // 4. attention_mlp + fc_att (model :302-303)
+  {
+    sdumc_dropout d0 = mkdrop(c, SITE_ATT0, c.d.p_mlp, 1, D), d1 = mkdrop(c, SITE_ATT1, c.d.p_mlp, 1, D);
+    RET(lin_fwd(c, pm.att0, c.p(pl.u), 3 * D, V, c.p(pl.att1), D, SDUMC_ACT_RELU, &d0));
+    RET(lin_fwd(c, pm.att3, c.p(pl.att1), D, V, c.p(pl.att2), D, SDUMC_ACT_RELU, &d1));
+    RET(lin_fwd(c, pm.fc_att, c.p(pl.att2), D, V, c.p(pl.alpha), 3, SDUMC_ACT_NONE, nullptr));
+  }
+  // 5. fused / at / tv / av features (model :305-320)
+  RET(sdumc_fusion_fwd(c.p(pl.u), c.p(pl.alpha), c.p(pl.qin), V, c.st));
+  // 6. the 7 query MLPs, written straight into multi_query [V,7,D] (model :324-332)
+  {
+    sdumc_gemm g = G_(SDUMC_NT, V, D, D, 7);
+    for (int i = 0; i < 7; ++i) {
+      g.A[i] = c.p(pl.qin) + (int64_t)i * V * D;
+      g.B[i] = c.P + pm.query[i].w;
+      g.bias[i] = c.P + pm.query[i].b;
+      g.C[i] = c.p(pl.q) + i * D;
+    }
+    g.lda = g.ldb = D;
+    g.ldc = NQ * D;
+    g.act = SDUMC_ACT_RELU;
+    g.c_drop = mkdrop(c, SITE_QUERY, c.d.p_mlp, 1, D);
+    g.c_drop_group_stride = 1;
+    RET(run(c, g));
+  }
+  // 7. query_proj of the three Cross_Attention blocks (model :85)
+  {
+    sdumc_gemm g = G_(SDUMC_NT, V * NQ, D, D, 3);
+    for (int m = 0; m < 3; ++m) {
+      g.A[m] = c.p(pl.q);
+      g.B[m] = c.P + pm.ca_q[m].w;
+      g.bias[m] = c.P + pm.ca_q[m].b;
+      g.C[m] = c.p(pl.qp) + (int64_t)m * V * NQ * D;
+    }
+    g.lda = g.ldb = g.ldc = D;
+    RET(run(c, g));
+  }
+  // 8. cross_att_fra2utt_{0,1,2} (model :334-336)
+  for (int m = 0; m < 3; ++m) RET(keys_fwd(c, 1, m));
+  // 9. cross_{audio,text,video}_mlp (model :338-340)
+  {
+    sdumc_gemm g = G_(SDUMC_NT, V * NQ, D, D, 3);
+    for (int m = 0; m < 3; ++m) {
+      g.A[m] = c.p(pl.ca_out) + (int64_t)m * V * NQ * D;
+      g.B[m] = c.P + pm.cmlp0[m].w;
+      g.bias[m] = c.P + pm.cmlp0[m].b;
+      g.C[m] = c.p(pl.c1) + (int64_t)m * V * NQ * D;
+    }
+    g.lda = g.ldb = g.ldc = D;
+    g.act = SDUMC_ACT_RELU;
+    g.c_drop = mkdrop(c, SITE_CMLP0, c.d.p_mlp, NQ, D);
+    g.c_drop_group_stride = 2;
+    RET(run(c, g));
+    g.N = H;
+    for (int m = 0; m < 3; ++m) {
+      g.A[m] = c.p(pl.c1) + (int64_t)m * V * NQ * D;
+      g.B[m] = c.P + pm.cmlp3[m].w;
+      g.bias[m] = c.P + pm.cmlp3[m].b;
+      g.C[m] = c.p(pl.c) + (int64_t)m * V * NQ * H;
+    }
+    g.ldc = H;
+    g.c_drop = mkdrop(c, SITE_CMLP1, c.d.p_mlp, NQ, H);
+    RET(run(c, g));
+  }
+  // 10. modality-weighted sum (model :346-349)
+  RET(sdumc_hweight_fwd(c.p(pl.c), c.p(pl.alpha), c.p(pl.h), V, c.st));
+  // 11. cross_attention_mlp + cross_fc_att (model :352-354)
+  {
+    sdumc_dropout d0 = mkdrop(c, SITE_CATT0, c.d.p_mlp, 1, D), d1 = mkdrop(c, SITE_CATT1, c.d.p_mlp, 1, H);
+    RET(lin_fwd(c, pm.catt0, c.p(pl.h), NQ * H, V, c.p(pl.e1), D, SDUMC_ACT_RELU, &d0));
+    RET(lin_fwd(c, pm.catt3, c.p(pl.e1), D, V, c.p(pl.e2), H, SDUMC_ACT_RELU, &d1));
+    RET(lin_fwd(c, pm.cross_fc_att, c.p(pl.e2), H, V, c.p(pl.beta), NQ, SDUMC_ACT_NONE, nullptr));
+  }
+  // 12. cross_fused_feat, regression head, RnC embedding (model :356-368)
+  RET(sdumc_zpool_fwd(c.p(pl.h), c.p(pl.beta), c.p(pl.z), V, c.st));
+  RET(lin_fwd(c, pm.fc_out_v, c.p(pl.z), H, V, c.p(pl.vals), 1, SDUMC_ACT_NONE, nullptr));
+  RET(lin_fwd(c, pm.rnc0, c.p(pl.z), H, V, c.p(pl.r1), RD, SDUMC_ACT_RELU, nullptr));
+  RET(lin_fwd(c, pm.rnc2, c.p(pl.r1), RD, V, c.p(pl.r), RD, SDUMC_ACT_NONE, nullptr));
+  // outputs (model :370)
+  if (c.io.vals) RET(sdumc_copy2d(c.p(pl.vals), 1, c.io.vals, 1, V, 1, c.st));
+  if (c.io.fused) RET(sdumc_copy2d(c.p(pl.z), H, c.io.fused, H, V, H, c.st));
+  if (c.io.rnc) RET(sdumc_copy2d(c.p(pl.r), RD, c.io.rnc, RD, V, RD, c.st));
+  if (c.io.text_hidden) RET(sdumc_copy2d(c.p(pl.q) + 5 * D, NQ * D, c.io.text_hidden, D, V, D, c.st));
+  if (c.io.cross_text) RET(sdumc_copy2d(c.p(pl.c) + (int64_t)V * NQ * H, NQ * H, c.io.cross_text, NQ * H, V, NQ * H, c.st));
+  return SDUMC_OK;
+}
+
+// backward of the attention-pool site (k, m): dz, dxd, dq, then dW/db of input_proj and dxd += dz W
+int keys_bwd(const Ctx& c, int k, int m, const float* dout_base /* [V, nq, D] */, float* dq_base /* [V, nq, D] */) {
+  const Plan& pl = c.pl;
+  const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
+  const int nq = k == 0 ? 1 : NQ;
+  float* dz = c.p(pl.dz[k][m]);
+  float* dxd = c.p(pl.dxd[k][m]);
+  for (const Seg& sg : pl.segs[m]) {
+    sdumc_attnpool_bwd_t b;
+    memset(&b, 0, sizeof(b));
+    b.f = attn_desc(c, k, m, sg);
+    const int64_t voff = (int64_t)sg.s0 * pl.B * nq * D;
+    b.dout = dout_base + voff;
+    b.dz = dz + sg.row0 * D;
+    b.dxd = dxd + sg.row0 * D;
+    b.dq = dq_base + voff;
+    b.workspace = c.p(pl.scratch);
+    b.workspace_bytes = (size_t)pl.scratch_floats * sizeof(float);
+    RET(sdumc_attnpool_bwd(&b, c.st));
+  }
+  // dW = dz^T drop(x): one GEMM per run (runs differ in their x buffer), later runs accumulate
+  bool first = true;
+  for (const Seg& sg : pl.segs[m]) {
+    const int rows = sg.V * sg.T;
+    sdumc_gemm g = G_(SDUMC_TN, D, D, rows);
+    g.A[0] = dz + sg.row0 * D;
+    g.lda = D;
+    g.B[0] = c.p(sg.x_off);
+    g.ldb = D;
+    g.b_row_mod = sg.x_samples < sg.V ? sg.x_samples * sg.T : 0;
+    g.b_drop = mkdrop(c, SITE_IN[k][m], c.d.p_frame, sg.T, D, sg.s0);
+    g.C[0] = c.G + L.w;
+    g.ldc = D;
+    g.accumulate = first ? 0 : 1;
+    g.splitk = pick_splitk(D, D, rows, 1);
+    RET(run(c, g));
+    first = false;
+  }
+  RET(colsum(c, dz, pl.rows[m], D, D, c.G + L.b, 0));
+  // dxd += dz W (the key-projection path joins the pooling path)
+  sdumc_gemm g = G_(SDUMC_NN, (int)pl.rows[m], D, D);
+  g.A[0] = dz;
+  g.lda = D;
+  g.B[0] = c.P + L.w;
+  g.ldb = D;
+  g.C[0] = dxd;
+  g.ldc = D;
+  g.accumulate = 1;
+  return run(c, g);
+}
+
+int backward(const Ctx& c, const sdumc_net_grads& og) {
+  const Plan& pl = c.pl;
+  const ParamMap& pm = c.pm;
+  const int B = pl.B, S = pl.S, V = pl.V;
+  const int din[3] = {c.d.da, c.d.dt, c.d.dv};
+  const float s_mlp = c.d.train ? 1.0f / (1.0f - (float)c.d.p_mlp) : 1.0f;
+  hipStream_t st = c.st;
+  RET(sdumc_fill(c.G, 0.f, pm.live, st));
+
+  // 12'. heads: r = L2(relu(L0(z))), vals = fc_out_v(z), plus the external gradient of cross_fused_feat
+  float* d_z = c.p(pl.d_z);
+  if (og.d_rnc) {
+    RET(lin_bwd(c, pm.rnc2, og.d_rnc, RD, c.p(pl.r1), RD, V, c.p(pl.d_r1), RD, 0));
+    RET(sdumc_relu_drop_bwd(c.p(pl.d_r1), c.p(pl.r1), 1.0f, c.p(pl.d_r1), (int64_t)V * RD, st));
+    RET(lin_bwd(c, pm.rnc0, c.p(pl.d_r1), RD, c.p(pl.z), H, V, d_z, H, 0));
+  } else {
+    RET(sdumc_fill(d_z, 0.f, (int64_t)V * H, st));
+  }
+  if (og.d_vals) RET(lin_bwd(c, pm.fc_out_v, og.d_vals, 1, c.p(pl.z), H, V, d_z, H, 1));
+  if (og.d_fused) RET(sdumc_axpy2d(og.d_fused, H, d_z, H, V, H, st));
+  RET(sdumc_zpool_bwd(c.p(pl.h), c.p(pl.beta), d_z, c.p(pl.d_h), c.p(pl.d_beta), V, st));
+  // 11'. cross_fc_att, cross_attention_mlp
+  RET(lin_bwd(c, pm.cross_fc_att, c.p(pl.d_beta), NQ, c.p(pl.e2), H, V, c.p(pl.d_e2), H, 0));
+  RET(sdumc_relu_drop_bwd(c.p(pl.d_e2), c.p(pl.e2), s_mlp, c.p(pl.d_e2), (int64_t)V * H, st));
+  RET(lin_bwd(c, pm.catt3, c.p(pl.d_e2), H, c.p(pl.e1), D, V, c.p(pl.d_e1), D, 0));
+  RET(sdumc_relu_drop_bwd(c.p(pl.d_e1), c.p(pl.e1), s_mlp, c.p(pl.d_e1), (int64_t)V * D, st));
+  RET(lin_bwd(c, pm.catt0, c.p(pl.d_e1), D, c.p(pl.h), NQ * H, V, c.p(pl.d_h), NQ * H, 1));
+  // 10'. modality-weighted sum; the external gradient of cross_hiddens[:,1] joins here
+  RET(sdumc_hweight_bwd(c.p(pl.c), c.p(pl.alpha), c.p(pl.d_h), og.d_cross_text, c.p(pl.d_c), c.p(pl.d_alpha), V, st));
+  // 9'. cross_{audio,text,video}_mlp
+  {
+    const int M = V * NQ;
+    RET(sdumc_relu_drop_bwd(c.p(pl.d_c), c.p(pl.c), s_mlp, c.p(pl.d_c), 3LL * M * H, st));
+    GroupPtrs q3 = {c.p(pl.d_c), (int64_t)M * H, H, c.p(pl.c1), (int64_t)M * D, D, c.p(pl.d_c1), (int64_t)M * D, D};
+    RET(lin_bwd_grouped(c, pm.cmlp3, 3, M, q3));
+    RET(sdumc_relu_drop_bwd(c.p(pl.d_c1), c.p(pl.c1), s_mlp, c.p(pl.d_c1), 3LL * M * D, st));
+    GroupPtrs q0 = {c.p(pl.d_c1), (int64_t)M * D, D, c.p(pl.ca_out), (int64_t)M * D, D, c.p(pl.d_ca_out), (int64_t)M * D, D};
+    RET(lin_bwd_grouped(c, pm.cmlp0, 3, M, q0));
+  }
+  // 8'. the three Cross_Attention blocks
+  for (int m = 0; m < 3; ++m)
+    RET(keys_bwd(c, 1, m, c.p(pl.d_ca_out) + (int64_t)m * V * NQ * D, c.p(pl.d_qp) + (int64_t)m * V * NQ * D));
+  // 7'. query_proj: dW/db per modality, d_q = sum_m d_qp[m] W_q[m]
+  {
+    const int M = V * NQ;
+    sdumc_gemm gw = G_(SDUMC_TN, D, D, M, 3);
+    for (int m = 0; m < 3; ++m) {
+      gw.A[m] = c.p(pl.d_qp) + (int64_t)m * M * D;
+      gw.B[m] = c.p(pl.q);
+      gw.C[m] = c.G + pm.ca_q[m].w;
+    }
+    gw.lda = gw.ldb = gw.ldc = D;
+    gw.splitk = pick_splitk(D, D, M, 3);
+    RET(run(c, gw));
+    for (int m = 0; m < 3; ++m) {
+      RET(colsum(c, c.p(pl.d_qp) + (int64_t)m * M * D, M, D, D, c.G + pm.ca_q[m].b, 0));
+      sdumc_gemm gx = G_(SDUMC_NN, M, D, D);
+      gx.A[0] = c.p(pl.d_qp) + (int64_t)m * M * D;
+      gx.lda = D;
+      gx.B[0] = c.P + pm.ca_q[m].w;
+      gx.ldb = D;
+      gx.C[0] = c.p(pl.d_q);
+      gx.ldc = D;
+      gx.accumulate = m > 0;
+      RET(run(c, gx));
+    }
+    if (og.d_text_hidden) RET(sdumc_axpy2d(og.d_text_hidden, D, c.p(pl.d_q) + 5 * D, NQ * D, V, D, st));
+  }
+  // 6'. the 7 query MLPs
+  {
+    RET(sdumc_relu_drop_bwd(c.p(pl.d_q), c.p(pl.q), s_mlp, c.p(pl.d_q), 7LL * V * D, st));
+    GroupPtrs qq = {c.p(pl.d_q), D, NQ * D, c.p(pl.qin), (int64_t)V * D, D, c.p(pl.d_qin), (int64_t)V * D, D};
+    RET(lin_bwd_grouped(c, pm.query, 7, V, qq));
+  }
+  // 5'. fusion algebra (d_alpha already holds the second-level contribution)
+  RET(sdumc_fusion_bwd(c.p(pl.u), c.p(pl.alpha), c.p(pl.d_qin), c.p(pl.d_u), c.p(pl.d_alpha), V, st));
+  // 4'. fc_att, attention_mlp
+  RET(lin_bwd(c, pm.fc_att, c.p(pl.d_alpha), 3, c.p(pl.att2), D, V, c.p(pl.d_att2), D, 0));
+  RET(sdumc_relu_drop_bwd(c.p(pl.d_att2), c.p(pl.att2), s_mlp, c.p(pl.d_att2), (int64_t)V * D, st));
+  RET(lin_bwd(c, pm.att3, c.p(pl.d_att2), D, c.p(pl.att1), D, V, c.p(pl.d_att1), D, 0));
+  RET(sdumc_relu_drop_bwd(c.p(pl.d_att1), c.p(pl.att1), s_mlp, c.p(pl.d_att1), (int64_t)V * D, st));
+  RET(lin_bwd(c, pm.att0, c.p(pl.d_att1), D, c.p(pl.u), 3 * D, V, c.p(pl.d_u), 3 * D, 1));
+  // 3'. audio/text/video_mlp
+  {
+    RET(sdumc_relu_drop_bwd(c.p(pl.d_u), c.p(pl.u), s_mlp, c.p(pl.d_u), 3LL * V * D, st));
+    GroupPtrs q3 = {c.p(pl.d_u), D, 3 * D, c.p(pl.u1), (int64_t)V * D, D, c.p(pl.d_u1), (int64_t)V * D, D};
+    RET(lin_bwd_grouped(c, pm.umlp3, 3, V, q3));
+    RET(sdumc_relu_drop_bwd(c.p(pl.d_u1), c.p(pl.u1), s_mlp, c.p(pl.d_u1), 3LL * V * D, st));
+    GroupPtrs q0 = {c.p(pl.d_u1), (int64_t)V * D, D, c.p(pl.hpre), (int64_t)V * D, D, c.p(pl.d_hpre), (int64_t)V * D, D};
+    RET(lin_bwd_grouped(c, pm.umlp0, 3, V, q0));
+  }
+  // 2'. fra2utt_{0,1,2}; the shared context vector's gradient is the sum of the per-sample dq
+  for (int m = 0; m < 3; ++m) {
+    float* dq = c.p(pl.dq_fra) + (int64_t)m * V * D;
+    RET(keys_bwd(c, 0, m, c.p(pl.d_hpre) + (int64_t)m * V * D, dq));
+    RET(colsum(c, dq, V, D, D, c.G + pm.fra_ctx[m], 0));
+  }
+  // 1'. dx = sum of the (up to) four masked paths into each projected feature tensor, then
+  //     frame_dim_reshape dW = dx^T feat (split-K), db = colsum(dx)
+  for (int m = 0; m < 3; ++m)
+    for (int s = 0; s < (m == 1 ? S : 1); ++s) {
+      const int T = pl.T[m][s];
+      sdumc_dropsum ds;
+      memset(&ds, 0, sizeof(ds));
+      ds.samples = B;
+      ds.T = T;
+      ds.dx = c.p(pl.dx[m][s]);
+      int nt = 0;
+      for (int k = 0; k < 2; ++k)
+        for (int ss = 0; ss < S; ++ss) {
+          if (m == 1 && ss != s) continue;
+          int64_t roff = 0;  // virtual-row offset of stream ss inside modality m
+          for (int q = 0; q < ss; ++q) roff += (int64_t)B * pl.T[m][q];
+          ds.g[nt] = c.p(pl.dxd[k][m]) + roff * D;
+          ds.drop[nt] = mkdrop(c, SITE_IN[k][m], c.d.p_frame, T, D, 0);
+          ds.stream_idx[nt] = ss;
+          ++nt;
+        }
+      ds.terms = nt;
+      RET(sdumc_dropsum_bwd(&ds, st));
+      const float* in = m == 0 ? c.io.audio : (m == 2 ? c.io.video : c.io.text[s]);
+      const int rows = B * T;
+      sdumc_gemm g = G_(SDUMC_TN, D, din[m], rows);
+      g.A[0] = c.p(pl.dx[m][s]);
+      g.lda = D;
+      g.B[0] = in;
+      g.ldb = din[m];
+      g.C[0] = c.G + pm.frame[m].w;
+      g.ldc = din[m];
+      g.accumulate = s > 0;
+      g.splitk = pick_splitk(D, din[m], rows, 1);
+      RET(run(c, g));
+      RET(colsum(c, c.p(pl.dx[m][s]), rows, D, D, c.G + pm.frame[m].b, s > 0));
+    }
+  return SDUMC_OK;
+}
+
+__global__ void total_loss_kernel(float* losses, float w0, float w1, float w2, float w3, float w4, float w5) {
+  losses[0] = w0 * losses[1] + w1 * losses[2] + w2 * losses[3] + w3 * losses[4] + w4 * losses[5] + w5 * losses[6];
+  losses[7] = 0.f;
+}
+
+struct LossScratch {
+  float* ssd;      // [3] (+1 pad)
+  float* ssd_ws;   // 3 partial regions
+  int64_t ssd_ws_each;
+  float* labels2;  // [2B]
+  float* rnc_ws;
+  size_t total_floats;
+};
+LossScratch loss_scratch(const sdumc_net_dims& d, int B_global, float* base) {
+  LossScratch s;
+  const int Bg = B_global > 0 ? B_global : d.B;
+  int64_t cur = 0;
+  auto al = [&](int64_t n) {
+    const int64_t o = cur;
+    cur += (n + 63) & ~(int64_t)63;
+    return o;
+  };
+  const int64_t o_ssd = al(4);
+  s.ssd_ws_each = (int64_t)(sdumc_ssd_workspace_bytes((int64_t)d.B * NQ * H) / sizeof(float)) + 64;
+  const int64_t o_ws = al(3 * s.ssd_ws_each);
+  const int64_t o_l2 = al(2LL * d.B);
+  const int64_t o_rnc = al((int64_t)(sdumc_rnc_workspace_bytes(2 * Bg) / sizeof(float)));
+  s.total_floats = (size_t)cur;
+  s.ssd = base ? base + o_ssd : nullptr;
+  s.ssd_ws = base ? base + o_ws : nullptr;
+  s.labels2 = base ? base + o_l2 : nullptr;
+  s.rnc_ws = base ? base + o_rnc : nullptr;
+  return s;
+}
+
+int loss_ssd(const sdumc_net_dims& d, const sdumc_net_io& io, float* ssd_out, const LossScratch& ls, hipStream_t st) {
+  const int B = d.B;
+  if (!io.text_hidden || !io.cross_text || !io.fused) return SDUMC_EINVAL;
+  RET(sdumc_ssd(io.text_hidden + (int64_t)B * D, io.text_hidden, (int64_t)B * D, ssd_out + 0, ls.ssd_ws, st));
+  RET(sdumc_ssd(io.cross_text + (int64_t)B * NQ * H, io.cross_text, (int64_t)B * NQ * H, ssd_out + 1,
+                ls.ssd_ws + ls.ssd_ws_each, st));
+  RET(sdumc_ssd(io.fused + (int64_t)B * H, io.fused, (int64_t)B * H, ssd_out + 2, ls.ssd_ws + 2 * ls.ssd_ws_each, st));
+  return SDUMC_OK;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" int64_t sdumc_param_count(int32_t da, int32_t dt, int32_t dv) { return build_params(da, dt, dv).total; }
+extern "C" int64_t sdumc_param_live_count(int32_t da, int32_t dt, int32_t dv) { return build_params(da, dt, dv).live; }
+extern "C" int32_t sdumc_param_table(int32_t da, int32_t dt, int32_t dv, char* buf, size_t buflen) {
+  const ParamMap& pm = build_params(da, dt, dv);
+  std::string s;
+  for (const PEntry& e : pm.table) {
+    char line[256];
+    snprintf(line, sizeof(line), "%s %lld %d %d %d\n", e.name.c_str(), (long long)e.off, e.rows, e.cols, e.live ? 1 : 0);
+    s += line;
+  }
+  if (!buf || s.size() + 1 > buflen) return -(int32_t)(s.size() + 1);
+  memcpy(buf, s.c_str(), s.size() + 1);
+  return (int32_t)s.size();
+}
+
+extern "C" size_t sdumc_net_workspace_bytes(const sdumc_net_dims* d) {
+  Plan p;
+  if (!d || !make_plan(*d, p)) return 0;
+  return (size_t)p.cur * sizeof(float);
+}
+
+extern "C" int sdumc_net_forward(const sdumc_net_dims* d, const sdumc_net_io* io, void* stream) {
+  RET(check_io(d, io));
+  Ctx c{*d, *io, as_stream(stream), build_params(d->da, d->dt, d->dv), Plan(), nullptr, nullptr, nullptr};
+  if (!make_plan(*d, c.pl)) return SDUMC_EINVAL;
+  if (io->workspace_bytes < (size_t)c.pl.cur * sizeof(float)) return SDUMC_ENOMEM;
+  c.W = static_cast<float*>(io->workspace);
+  c.P = io->params;
+  return forward(c);
+}
+
+extern "C" int sdumc_net_backward(const sdumc_net_dims* d, const sdumc_net_io* io, const sdumc_net_grads* g,
+                                  void* stream) {
+  RET(check_io(d, io));
+  if (!g || !g->grads || (reinterpret_cast<uintptr_t>(g->grads) & 15)) return SDUMC_EINVAL;
+  Ctx c{*d, *io, as_stream(stream), build_params(d->da, d->dt, d->dv), Plan(), nullptr, nullptr, nullptr};
+  if (!make_plan(*d, c.pl)) return SDUMC_EINVAL;
+  if (io->workspace_bytes < (size_t)c.pl.cur * sizeof(float)) return SDUMC_ENOMEM;
+  c.W = static_cast<float*>(io->workspace);
+  c.P = io->params;
+  c.G = g->grads;
+  return backward(c, *g);
+}
+
+extern "C" size_t sdumc_loss_workspace_bytes(const sdumc_net_dims* d, int32_t B_global) {
+  if (!d || d->B <= 0) return 0;
+  return loss_scratch(*d, B_global, nullptr).total_floats * sizeof(float);
+}
+
+extern "C" int sdumc_loss_ssd(const sdumc_net_dims* d, const sdumc_net_io* io, float* ssd_out, void* scratch,
+                              size_t scratch_bytes, void* stream) {
+  if (!d || !io || !ssd_out || !scratch || d->streams != 2) return SDUMC_EINVAL;
+  const LossScratch ls = loss_scratch(*d, 0, static_cast<float*>(scratch));
+  if (scratch_bytes < ls.total_floats * sizeof(float)) return SDUMC_ENOMEM;
+  return loss_ssd(*d, *io, ssd_out, ls, as_stream(stream));
+}
+
+extern "C" int sdumc_loss_backward(const sdumc_net_dims* d, const sdumc_net_io* io, const sdumc_step_cfg* cfg,
+                                   const sdumc_net_grads* g, void* scratch, size_t scratch_bytes, void* stream) {
+  if (!d || !io || !cfg || !g || !scratch || d->streams != 2) return SDUMC_EINVAL;
+  if (!io->vals || !io->fused || !io->rnc || !io->text_hidden || !io->cross_text) return SDUMC_EINVAL;
+  if (!g->d_vals || !g->d_fused || !g->d_rnc || !g->d_text_hidden || !g->d_cross_text) return SDUMC_EINVAL;
+  if (!cfg->labels || !cfg->losses) return SDUMC_EINVAL;
+  hipStream_t st = as_stream(stream);
+  const int B = d->B, Bg = cfg->B_global > 0 ? cfg->B_global : B;
+  const LossScratch ls = loss_scratch(*d, cfg->B_global, static_cast<float*>(scratch));
+  if (scratch_bytes < ls.total_floats * sizeof(float)) return SDUMC_ENOMEM;
+  float* dv = const_cast<float*>(g->d_vals);
+  float* df = const_cast<float*>(g->d_fused);
+  float* dr = const_cast<float*>(g->d_rnc);
+  float* dth = const_cast<float*>(g->d_text_hidden);
+  float* dct = const_cast<float*>(g->d_cross_text);
+  float* L = cfg->losses;
+  const float* w = cfg->weights;
+  // MSELoss on both streams (main :137-138)
+  RET(sdumc_mse_fwd_bwd(io->vals, cfg->labels, B, (float)Bg, w[0], L + 1, dv, st));
+  RET(sdumc_mse_fwd_bwd(io->vals + B, cfg->labels, B, (float)Bg, w[1], L + 2, dv + B, st));
+  // RMSELoss x3 (main :148): teacher side detached for text_feat / text_query_feat, not for features
+  const float* ssd = cfg->ssd_global;
+  if (!ssd) {
+    RET(loss_ssd(*d, *io, ls.ssd, ls, st));
+    ssd = ls.ssd;
+  }
+  RET(sdumc_fill(dth, 0.f, (int64_t)B * D, st));
+  RET(sdumc_rmse_bwd(io->text_hidden + (int64_t)B * D, io->text_hidden, (int64_t)B * D, ssd + 0, (double)Bg * D, w[2],
+                     L + 3, dth + (int64_t)B * D, 0, nullptr, 0, st));
+  RET(sdumc_fill(dct, 0.f, (int64_t)B * NQ * H, st));
+  RET(sdumc_rmse_bwd(io->cross_text + (int64_t)B * NQ * H, io->cross_text, (int64_t)B * NQ * H, ssd + 1,
+                     (double)Bg * NQ * H, w[3], L + 4, dct + (int64_t)B * NQ * H, 0, nullptr, 0, st));
+  RET(sdumc_rmse_bwd(io->fused + (int64_t)B * H, io->fused, (int64_t)B * H, ssd + 2, (double)Bg * H, w[4], L + 5,
+                     df + (int64_t)B * H, 0, df, 0, st));
+  // RnCLoss over cat(r_stream0, r_stream1) with labels repeated (main :134,:140; loss.py:282-283)
+  if (cfg->rnc_feats_global) {
+    if (!cfg->rnc_labels_global) return SDUMC_EINVAL;
+    RET(sdumc_rnc_fwd_bwd(cfg->rnc_feats_global, cfg->rnc_labels_global, 2 * Bg, RD, cfg->temperature, w[5],
+                          cfg->rnc_row0[0], B, L + 6, dr, ls.rnc_ws, st));
+    RET(sdumc_rnc_dfeat_rows(cfg->rnc_feats_global, 2 * Bg, RD, cfg->temperature, w[5], cfg->rnc_row0[1], B,
+                             dr + (int64_t)B * RD, ls.rnc_ws, st));
+  } else {
+    RET(sdumc_copy2d(cfg->labels, 1, ls.labels2, 1, B, 1, st));
+    RET(sdumc_copy2d(cfg->labels, 1, ls.labels2 + B, 1, B, 1, st));
+    RET(sdumc_rnc_fwd_bwd(io->rnc, ls.labels2, 2 * B, RD, cfg->temperature, w[5], 0, 2 * B, L + 6, dr, ls.rnc_ws, st));
+  }
+  hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(1), 0, st, L, w[0], w[1], w[2], w[3], w[4], w[5]);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+namespace {
+struct StepLayout {
+  size_t net, grads, dout, loss, total;  // byte offsets / sizes
+  size_t live;
+};
+StepLayout step_layout(const sdumc_net_dims& d) {
+  StepLayout s;
+  auto up = [](size_t n) { return (n + 255) & ~(size_t)255; };
+  s.live = (size_t)build_params(d.da, d.dt, d.dv).live;
+  const size_t V = (size_t)d.B * 2;
+  s.net = 0;
+  size_t cur = up(sdumc_net_workspace_bytes(&d));
+  s.grads = cur;
+  cur += up(s.live * sizeof(float));
+  s.dout = cur;
+  cur += up(V * (64 + H + RD + D + NQ * H) * sizeof(float));
+  s.loss = cur;
+  cur += up(sdumc_loss_workspace_bytes(&d, 0));
+  s.total = cur;
+  return s;
+}
+}  // namespace
+
+extern "C" size_t sdumc_step_workspace_bytes(const sdumc_net_dims* d) {
+  if (!d || d->streams != 2) return 0;
+  Plan p;
+  if (!make_plan(*d, p)) return 0;
+  return step_layout(*d).total;
+}
+
+extern "C" int sdumc_train_step(const sdumc_net_dims* d, const sdumc_net_io* io, const sdumc_step_cfg* cfg,
+                                void* stream) {
+  RET(check_io(d, io));
+  if (!cfg || d->streams != 2 || !cfg->adam_m || !cfg->adam_v || !cfg->hyper) return SDUMC_EINVAL;
+  const StepLayout sl = step_layout(*d);
+  if (io->workspace_bytes < sl.total) return SDUMC_ENOMEM;
+  char* base = static_cast<char*>(io->workspace);
+  sdumc_net_io nio = *io;
+  nio.workspace = base + sl.net;
+  nio.workspace_bytes = sl.grads - sl.net;
+  RET(sdumc_net_forward(d, &nio, stream));
+  const size_t V = (size_t)d->B * 2;
+  float* dout = reinterpret_cast<float*>(base + sl.dout);
+  sdumc_net_grads g;
+  g.d_vals = dout;
+  g.d_fused = dout + 64 * V;
+  g.d_rnc = g.d_fused + H * V;
+  g.d_text_hidden = g.d_rnc + RD * V;
+  g.d_cross_text = g.d_text_hidden + D * V;
+  g.grads = reinterpret_cast<float*>(base + sl.grads);
+  RET(sdumc_loss_backward(d, &nio, cfg, &g, base + sl.loss, sl.total - sl.loss, stream));
+  RET(sdumc_net_backward(d, &nio, &g, stream));
+  RET(sdumc_adam_step(io->params, g.grads, cfg->adam_m, cfg->adam_v, (int64_t)sl.live, cfg->hyper, cfg->beta1,
+                      cfg->beta2, cfg->eps, cfg->weight_decay, 1.0f, stream));
+  if (d->train) RET(sdumc_rng_advance(const_cast<uint32_t*>(io->rng_state), 2, stream));
+  return SDUMC_OK;
+}
+
+// gradient bucket of the most recent sdumc_train_step inside its workspace (for tests / DP all-reduce)
+extern "C" size_t sdumc_step_grads_offset(const sdumc_net_dims* d) {
+  if (!d || d->streams != 2) return 0;
+  return step_layout(*d).grads;
+}

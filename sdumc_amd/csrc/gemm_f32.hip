@@ -1,0 +1,310 @@
+// gemm_f32.hip — grouped fp32 GEMM on the gfx950 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// Replaces, on the SDUMC hot path, every torch Linear / bmm and its autograd:
+//   frame_dim_reshape_{0,1,2}          model :193-195,282-284   (NT, M = B*T up to 24k, K = 1024/4096)
+//   input_proj of FRA2UTT_new / Cross_Attention (model :60,:82)  (NT + fused input dropout + tanh)
+//   every utterance-level Linear (model :264-273, :293-368)      (NT + bias + ReLU + dropout)
+//   dX = dY.W (NN), dW = dY^T.X (TN, split-K) of all of the above (main :149 loss.backward())
+//
+// Design (MI355X-first):
+//   * exact-fp32 MFMA 32x32x2: 64 FLOP/clk/SIMD = the fp32 roofline of the chip (155 TF measured).
+//   * 256 threads = 4 waves (2x2); block tile 128x128 (wave 64x64 = 2x2 MFMA tiles, 64 accumulator
+//     VGPRs) or 64x64 for the launch-bound utterance-level layers; BK = 32.
+//   * global -> registers (16-B loads, prefetch of tile t+1 in flight during the MFMAs of tile t)
+//     -> LDS -> fragments.  k-contiguous operands are staged as [row][BK+4]: the +4 pad makes the
+//     ds_read_b128 fragment reads (4 k-steps per read) conflict-free; the k index inside an MFMA
+//     group is permuted identically for A and B (lane half h supplies k = 8g + 4h + s), which any
+//     product sum is invariant to.  row-contiguous operands (NN's B, TN's A and B) are staged as
+//     [k][row] and read with conflict-free ds_read_b32.
+//   * fusions: dropout (Philox, recomputed, never stored) on the staged A (NT/NN) or B (TN) operand,
+//     source-row modulo (the two streams share x_audio/x_video), bias + ReLU/tanh + dropout epilogue,
+//     accumulate, deterministic split-K (slabs + ordered reduce; no float atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;
+
+struct TileLoadCtx {
+  const float* p;
+  int ld;
+  int row_mod;
+  bool vec;
+  DropRT drop;
+};
+
+// Load one [BR x BK] operand tile into registers.
+// KC = true : matrix stored [R][K] (k contiguous): thread -> (row = tid/8 + 32 j, k = 4 (tid%8))
+// KC = false: matrix stored [K][R] (R contiguous): thread -> (k = tid/(BR/4) + (1024/BR) j, r = 4 (tid % (BR/4)))
+// "row" in the dropout / row_mod sense is the non-channel index: R index for KC, K index otherwise.
+template <int BR, bool KC>
+__device__ __forceinline__ void load_tile(f32x4 (&reg)[BR / 32], const TileLoadCtx& c, int r0, int R, int k0,
+                                          int kend, int tid) {
+  constexpr int P = BR / 32;
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    int row, ch, row_lim, ch_lim;
+    if (KC) {
+      row = r0 + (tid >> 3) + 32 * j;
+      ch = k0 + 4 * (tid & 7);
+      row_lim = R;
+      ch_lim = kend;
+    } else {
+      constexpr int Q = BR / 4;
+      constexpr int RP = 256 / Q;
+      row = k0 + tid / Q + RP * j;
+      ch = r0 + 4 * (tid % Q);
+      row_lim = kend;
+      ch_lim = R;
+    }
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (row < row_lim && ch < ch_lim) {
+      const int srow = c.row_mod > 0 ? row % c.row_mod : row;
+      const float* src = c.p + (size_t)srow * c.ld + ch;
+      if (c.vec) {
+        v = *reinterpret_cast<const f32x4*>(src);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (ch + e < ch_lim) v[e] = src[e];
+      }
+      if (c.drop.enabled) {
+        const f32x4 m = drop_mask4(c.drop, (uint32_t)row, (uint32_t)(ch >> 2));
+        v *= m;
+      }
+    }
+    reg[j] = v;
+  }
+}
+
+template <int BR, bool KC>
+__device__ __forceinline__ void store_tile(float* lds, const f32x4 (&reg)[BR / 32], int tid) {
+  constexpr int P = BR / 32;
+#pragma unroll
+  for (int j = 0; j < P; ++j) {
+    if (KC) {
+      const int row = (tid >> 3) + 32 * j;
+      *reinterpret_cast<f32x4*>(lds + row * LDK + 4 * (tid & 7)) = reg[j];
+    } else {
+      constexpr int Q = BR / 4;
+      constexpr int RP = 256 / Q;
+      const int k = tid / Q + RP * j;
+      *reinterpret_cast<f32x4*>(lds + k * BR + 4 * (tid % Q)) = reg[j];
+    }
+  }
+}
+
+// fragment of MFMA group g (8 consecutive k) for the 32 rows starting at `base`:
+// element s (0..3) is operand k = 8g + 4h + s of row base + i  (i = lane&31, h = lane>>5)
+template <int BR, bool KC>
+__device__ __forceinline__ f32x4 read_frag(const float* lds, int base, int g, int li, int lh) {
+  if (KC) {
+    return *reinterpret_cast<const f32x4*>(lds + (base + li) * LDK + 8 * g + 4 * lh);
+  } else {
+    f32x4 v;
+    const float* p = lds + (8 * g + 4 * lh) * BR + base + li;
+    v[0] = p[0];
+    v[1] = p[BR];
+    v[2] = p[2 * BR];
+    v[3] = p[3 * BR];
+    return v;
+  }
+}
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  if (act == SDUMC_ACT_RELU) return fmaxf(v, 0.f);
+  if (act == SDUMC_ACT_TANH) return tanhf(v);
+  return v;
+}
+
+template <int BM, int BN, bool A_K, bool B_K>
+__global__ __launch_bounds__(256) void gemm_kernel(const sdumc_gemm g, const int nsplit, const int kchunk) {
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+  constexpr int A_ELEMS = A_K ? BM * LDK : BK * BM;
+  constexpr int B_ELEMS = B_K ? BN * LDK : BK * BN;
+  __shared__ __attribute__((aligned(16))) float lds[A_ELEMS + B_ELEMS];
+  float* As = lds;
+  float* Bs = lds + A_ELEMS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int grp = blockIdx.z / nsplit, ks = blockIdx.z - grp * nsplit;
+  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  const int kbeg = ks * kchunk;
+  const int kend = min(g.K, kbeg + kchunk);
+
+  TileLoadCtx ca, cb;
+  ca.p = g.A[grp];
+  ca.ld = g.lda;
+  ca.row_mod = g.a_row_mod;
+  cb.p = g.B[grp];
+  cb.ld = g.ldb;
+  cb.row_mod = (!A_K && !B_K) ? g.b_row_mod : 0;
+  // 16-byte vector loads need aligned rows and a channel extent that is a multiple of 4
+  {
+    const int a_ch = A_K ? g.K : g.M;
+    const int b_ch = B_K ? g.K : g.N;
+    ca.vec = ((g.lda & 3) == 0) && ((a_ch & 3) == 0) && ((reinterpret_cast<uintptr_t>(ca.p) & 15) == 0);
+    cb.vec = ((g.ldb & 3) == 0) && ((b_ch & 3) == 0) && ((reinterpret_cast<uintptr_t>(cb.p) & 15) == 0);
+  }
+  ca.drop = drop_resolve(g.a_drop);
+  cb.drop = drop_resolve(g.b_drop);
+  if (!A_K) ca.drop.enabled = 0;          // a_drop is defined for row-major [M][K] A only
+  if (A_K || B_K) cb.drop.enabled = 0;    // b_drop is defined for TN only
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  f32x4 ra[BM / 32], rb[BN / 32];
+  if (kbeg < kend) {
+    load_tile<BM, A_K>(ra, ca, m0, g.M, kbeg, kend, tid);
+    load_tile<BN, B_K>(rb, cb, n0, g.N, kbeg, kend, tid);
+  }
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    __syncthreads();  // everyone is done reading the previous tile
+    store_tile<BM, A_K>(As, ra, tid);
+    store_tile<BN, B_K>(Bs, rb, tid);
+    __syncthreads();
+    if (k0 + BK < kend) {  // prefetch: in flight during the MFMAs below
+      load_tile<BM, A_K>(ra, ca, m0, g.M, k0 + BK, kend, tid);
+      load_tile<BN, B_K>(rb, cb, n0, g.N, k0 + BK, kend, tid);
+    }
+#pragma unroll
+    for (int gq = 0; gq < BK / 8; ++gq) {
+      f32x4 af[TM], bf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = read_frag<BM, A_K>(As, wm0 + 32 * i, gq, li, lh);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bf[j] = read_frag<BN, B_K>(Bs, wn0 + 32 * j, gq, li, lh);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+  const bool to_slab = nsplit > 1;
+  float* C = to_slab ? g.workspace + ((size_t)blockIdx.z) * (size_t)g.M * g.N : g.C[grp];
+  const int ldc = to_slab ? g.N : g.ldc;
+  const float* bias = to_slab ? nullptr : g.bias[grp];
+  DropRT cd = drop_resolve(g.c_drop);
+  cd.site += (uint32_t)(grp * g.c_drop_group_stride);
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = n0 + wn0 + 32 * j + li;
+      if (col >= g.N) continue;
+      const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        if (row >= g.M) continue;
+        float v = acc[i][j][e];
+        float* dst = C + (size_t)row * ldc + col;
+        if (!to_slab) {
+          v = apply_act(v + bv, g.act);
+          if (cd.enabled) v *= drop_mask1(cd, (uint32_t)row, (uint32_t)col);
+          if (g.accumulate) v += *dst;
+        }
+        *dst = v;
+      }
+    }
+}
+
+// ordered (deterministic) reduction of the split-K slabs + the epilogue
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const sdumc_gemm g, const int nsplit) {
+  const int grp = blockIdx.y;
+  const size_t mn = (size_t)g.M * g.N;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= mn) return;
+  const float* s = g.workspace + (size_t)grp * nsplit * mn + idx;
+  float v = 0.f;
+  for (int z = 0; z < nsplit; ++z) v += s[(size_t)z * mn];
+  const int row = (int)(idx / g.N), col = (int)(idx - (size_t)row * g.N);
+  if (g.bias[grp]) v += g.bias[grp][col];
+  v = apply_act(v, g.act);
+  if (g.c_drop.enabled) {
+    DropRT cd = drop_resolve(g.c_drop);
+    cd.site += (uint32_t)(grp * g.c_drop_group_stride);
+    v *= drop_mask1(cd, (uint32_t)row, (uint32_t)col);
+  }
+  float* dst = g.C[grp] + (size_t)row * g.ldc + col;
+  if (g.accumulate) v += *dst;
+  *dst = v;
+}
+
+int effective_splitk(const sdumc_gemm* g) {
+  int s = g->splitk > 1 ? g->splitk : 1;
+  const int ktiles = (g->K + BK - 1) / BK;
+  if (s > ktiles) s = ktiles;
+  return s < 1 ? 1 : s;
+}
+
+template <int BM, int BN>
+int launch(const sdumc_gemm& g, int nsplit, int kchunk, hipStream_t st) {
+  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.groups * nsplit);
+  switch (g.layout) {
+    case SDUMC_NT: hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true>), grid, dim3(256), 0, st, g, nsplit, kchunk); break;
+    case SDUMC_NN: hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false>), grid, dim3(256), 0, st, g, nsplit, kchunk); break;
+    case SDUMC_TN: hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false>), grid, dim3(256), 0, st, g, nsplit, kchunk); break;
+    default: return SDUMC_EINVAL;
+  }
+  return SDUMC_OK;
+}
+
+}  // namespace
+
+extern "C" size_t sdumc_gemm_workspace_bytes(const sdumc_gemm* g) {
+  if (!g) return 0;
+  const int s = effective_splitk(g);
+  if (s <= 1) return 0;
+  return (size_t)s * g->groups * (size_t)g->M * g->N * sizeof(float);
+}
+
+extern "C" int sdumc_gemm_f32(const sdumc_gemm* gp, void* stream) {
+  if (!gp) return SDUMC_EINVAL;
+  const sdumc_gemm& g = *gp;
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.groups < 1 || g.groups > SDUMC_MAX_GROUPS) return SDUMC_EINVAL;
+  if (g.layout < 0 || g.layout > 2) return SDUMC_EINVAL;
+  for (int i = 0; i < g.groups; ++i)
+    if (!g.A[i] || !g.B[i] || !g.C[i]) return SDUMC_EINVAL;
+  if (g.accumulate && (g.act != SDUMC_ACT_NONE || g.c_drop.enabled)) return SDUMC_EINVAL;
+  if ((g.a_drop.enabled && (g.a_drop.width & 3)) || (g.b_drop.enabled && (g.b_drop.width & 3)) ||
+      (g.c_drop.enabled && (g.c_drop.width & 3)))
+    return SDUMC_EINVAL;
+  const int nsplit = effective_splitk(&g);
+  int kchunk = g.K;
+  if (nsplit > 1) {
+    if (!g.workspace || g.workspace_bytes < sdumc_gemm_workspace_bytes(&g)) return SDUMC_ENOMEM;
+    const int ktiles = (g.K + BK - 1) / BK;
+    kchunk = ((ktiles + nsplit - 1) / nsplit) * BK;
+  }
+  hipStream_t st = as_stream(stream);
+  int tile = g.tile;
+  if (tile == 0) {
+    const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.groups * nsplit;
+    tile = big >= 96 ? 1 : 2;
+  }
+  int rc = tile == 1 ? launch<128, 128>(g, nsplit, kchunk, st) : launch<64, 64>(g, nsplit, kchunk, st);
+  if (rc != SDUMC_OK) return rc;
+  SDUMC_CHECK_LAUNCH();
+  if (nsplit > 1) {
+    const size_t mn = (size_t)g.M * g.N;
+    dim3 grid((unsigned)((mn + 255) / 256), g.groups);
+    hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, st, g, nsplit);
+    SDUMC_CHECK_LAUNCH();
+  }
+  return SDUMC_OK;
+}

@@ -1,0 +1,297 @@
+// loss.hip — the loss reductions of the self-distillation step, value + gradient.
+//   MSELoss   toolkit/utils/loss.py:19-33   sum((p-t)^2)/len(p)
+//   RMSELoss  toolkit/utils/loss.py:37-51   sqrt(mean((a-b)^2))   (split: ssd, then sqrt -> DP-exact)
+//   RnCLoss   toolkit/utils/loss.py:271-315 Rank-N-Contrast; the boolean neg_mask (loss.py:303) is
+//             evaluated with the same fp32 operations as the reference, so membership is bit-exact.
+// All sums run in a fixed order (no float atomics): results are bitwise reproducible.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float block_sum_256(float v, float* red /*[4]*/) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void mse_kernel(const float* pred, const float* target, int rows, float denom,
+                                                  float weight, float* loss_out, float* dpred) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  const float inv = 1.f / denom;
+  for (int i = threadIdx.x; i < rows; i += 256) {
+    const float d = pred[i] - target[i];
+    acc += d * d;
+    if (dpred) dpred[i] = weight * 2.f * d * inv;
+  }
+  const float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) *loss_out = s * inv;
+}
+
+constexpr int SSD_CHUNK = 8192;
+__global__ __launch_bounds__(256) void ssd_stage1(const float* a, const float* b, int64_t n, float* part) {
+  __shared__ float red[4];
+  const int64_t i0 = (int64_t)blockIdx.x * SSD_CHUNK, i1 = min(n, i0 + SSD_CHUNK);
+  float acc = 0.f;
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    const float d = a[i] - b[i];
+    acc += d * d;
+  }
+  const float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void ssd_stage2(const float* part, int nchunk, float* out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < nchunk; i += 256) acc += part[i];
+  const float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) *out = s;
+}
+
+__global__ void rmse_bwd_kernel(const float* a, const float* b, int64_t n, const float* ssd, float inv_numel,
+                                float weight, float* loss_out, float* da, int da_acc, float* db, int db_acc) {
+  const float rmse = sqrtf(*ssd * inv_numel);
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i == 0 && loss_out) *loss_out = rmse;
+  if (i >= n) return;
+  // d sqrt(mean)/da = (a-b) / (numel * rmse)   (0/0 -> NaN exactly like torch's sqrt backward)
+  const float g = weight * (a[i] - b[i]) * inv_numel / rmse;
+  if (da) da[i] = da_acc ? da[i] + g : g;
+  if (db) db[i] = db_acc ? db[i] - g : -g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Rank-N-Contrast.  Workspace layout (floats): dist[n*n] e[n*n] ldiff[n*n] invD[n*n] G[n*n]
+// rowmax[n] rowloss[n]
+// ---------------------------------------------------------------------------------------------
+struct RncWs {
+  float *dist, *e, *ldiff, *invD, *G, *rowmax, *rowloss;
+};
+__host__ __device__ inline RncWs rnc_ws(float* w, int n) {
+  RncWs r;
+  const size_t nn = (size_t)n * n;
+  r.dist = w;
+  r.e = w + nn;
+  r.ldiff = w + 2 * nn;
+  r.invD = w + 3 * nn;
+  r.G = w + 4 * nn;
+  r.rowmax = w + 5 * nn;
+  r.rowloss = r.rowmax + n;
+  return r;
+}
+
+// one workgroup per anchor row i: distances, label differences, row max, exp
+__global__ __launch_bounds__(256) void rnc_pairs_kernel(const float* f, const float* y, int n, int dim, float inv_t,
+                                                        RncWs w) {
+  extern __shared__ float fi[];  // [dim]
+  __shared__ float red[4];
+  const int i = blockIdx.x;
+  for (int c = threadIdx.x; c < dim; c += 256) fi[c] = f[(size_t)i * dim + c];
+  __syncthreads();
+  const float yi = y[i];
+  float mx = -INFINITY;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    float s = 0.f;
+    for (int c = 0; c < dim; ++c) {
+      const float d = fi[c] - f[(size_t)j * dim + c];
+      s += d * d;
+    }
+    const float dist = sqrtf(s);
+    w.dist[(size_t)i * n + j] = dist;
+    w.ldiff[(size_t)i * n + j] = fabsf(yi - y[j]);
+    mx = fmaxf(mx, -dist * inv_t);
+  }
+  mx = wave_max(mx);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  if (threadIdx.x == 0) w.rowmax[i] = mx;
+  for (int j = threadIdx.x; j < n; j += 256) w.e[(size_t)i * n + j] = expf(-w.dist[(size_t)i * n + j] * inv_t - mx);
+}
+
+// one workgroup per anchor i: D_ik = sum_{j != i} [ldiff_ij >= ldiff_ik - 1e-4] e_ij ; row loss
+__global__ __launch_bounds__(256) void rnc_denoms_kernel(int n, float inv_t, RncWs w) {
+  extern __shared__ float sm[];  // ld[n], e[n]
+  __shared__ float red[4];
+  float* ld = sm;
+  float* ee = sm + n;
+  const int i = blockIdx.x;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    ld[j] = w.ldiff[(size_t)i * n + j];
+    ee[j] = w.e[(size_t)i * n + j];
+  }
+  __syncthreads();
+  const float mx = w.rowmax[i];
+  float acc = 0.f;
+  for (int k = threadIdx.x; k < n; k += 256) {
+    if (k == i) {
+      w.invD[(size_t)i * n + k] = 0.f;
+      continue;
+    }
+    const float thr = __fsub_rn(ld[k], 0.0001f);
+    float dsum = 0.f;
+    for (int j = 0; j < n; ++j)
+      if (j != i && ld[j] >= thr) dsum += ee[j];
+    w.invD[(size_t)i * n + k] = 1.f / dsum;
+    const float logit = -w.dist[(size_t)i * n + k] * inv_t - mx;
+    acc += logit - logf(dsum);
+  }
+  const float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) w.rowloss[i] = s;
+}
+
+__global__ __launch_bounds__(256) void rnc_loss_kernel(int n, RncWs w, float* loss_out) {
+  __shared__ float red[4];
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) acc += w.rowloss[i];
+  const float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) *loss_out = -s / ((float)n * (float)(n - 1));
+}
+
+// G_ij = dLoss/dlogit_ij = -c (1 - e_ij sum_{k != i} [ldiff_ij >= ldiff_ik - 1e-4] / D_ik)
+__global__ __launch_bounds__(256) void rnc_glogit_kernel(int n, RncWs w) {
+  extern __shared__ float sm[];  // thr[n], invD[n]
+  float* thr = sm;
+  float* iD = sm + n;
+  const int i = blockIdx.x;
+  for (int k = threadIdx.x; k < n; k += 256) {
+    thr[k] = __fsub_rn(w.ldiff[(size_t)i * n + k], 0.0001f);
+    iD[k] = w.invD[(size_t)i * n + k];
+  }
+  __syncthreads();
+  const float c = 1.f / ((float)n * (float)(n - 1));
+  for (int j = threadIdx.x; j < n; j += 256) {
+    float g = 0.f;
+    if (j != i) {
+      const float lj = w.ldiff[(size_t)i * n + j];
+      float s = 0.f;
+      for (int k = 0; k < n; ++k)
+        if (k != i && lj >= thr[k]) s += iD[k];
+      g = -c * (1.f - w.e[(size_t)i * n + j] * s);
+    }
+    w.G[(size_t)i * n + j] = g;
+  }
+}
+
+// df_i = -(1/t) sum_j (G_ij + G_ji) (f_i - f_j) / dist_ij ; one workgroup per local row
+__global__ __launch_bounds__(256) void rnc_dfeat_kernel(const float* f, int n, int dim, float inv_t, float weight,
+                                                        int row0, RncWs w, float* df) {
+  extern __shared__ float sm[];  // coef[n], then red[4][dim]
+  float* coef = sm;
+  float* red = sm + n;
+  const int i = row0 + blockIdx.x;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    const float d = w.dist[(size_t)i * n + j];
+    coef[j] = (j != i && d > 0.f) ? (w.G[(size_t)i * n + j] + w.G[(size_t)j * n + i]) / d : 0.f;
+  }
+  __syncthreads();
+  const int part = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int c0 = 0; c0 < dim; c0 += 64) {
+    const int c = c0 + lane;
+    float acc = 0.f;
+    if (c < dim) {
+      const float fic = f[(size_t)i * dim + c];
+      for (int j = part; j < n; j += 4) acc += coef[j] * (fic - f[(size_t)j * dim + c]);
+    }
+    red[part * 64 + lane] = acc;
+    __syncthreads();
+    if (part == 0 && c < dim)
+      df[(size_t)blockIdx.x * dim + c] = -weight * inv_t * (red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane]);
+    __syncthreads();
+  }
+}
+
+__global__ void rnc_mask_kernel(const float* y, int n, uint8_t* mask) {
+  const int64_t total = (int64_t)n * (n - 1) * (n - 1);
+  const int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int i = (int)(e / ((int64_t)(n - 1) * (n - 1)));
+  const int64_t r = e - (int64_t)i * (n - 1) * (n - 1);
+  int k = (int)(r / (n - 1)), j = (int)(r - (int64_t)k * (n - 1));
+  k += (k >= i);
+  j += (j >= i);
+  const float dij = fabsf(y[i] - y[j]), dik = fabsf(y[i] - y[k]);
+  mask[e] = dij >= __fsub_rn(dik, 0.0001f) ? 1 : 0;
+}
+
+}  // namespace
+
+extern "C" int sdumc_mse_fwd_bwd(const float* pred, const float* target, int32_t rows, float denom, float weight,
+                                 float* loss_out, float* dpred, void* stream) {
+  if (!pred || !target || !loss_out || rows <= 0 || denom <= 0.f) return SDUMC_EINVAL;
+  hipLaunchKernelGGL(mse_kernel, dim3(1), dim3(256), 0, as_stream(stream), pred, target, rows, denom, weight, loss_out, dpred);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" size_t sdumc_ssd_workspace_bytes(int64_t n) { return (size_t)((n + SSD_CHUNK - 1) / SSD_CHUNK) * sizeof(float); }
+
+extern "C" int sdumc_ssd(const float* a, const float* b, int64_t n, float* ssd_out, float* workspace, void* stream) {
+  if (!a || !b || !ssd_out || !workspace || n <= 0) return SDUMC_EINVAL;
+  const int nchunk = (int)((n + SSD_CHUNK - 1) / SSD_CHUNK);
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(ssd_stage1, dim3(nchunk), dim3(256), 0, st, a, b, n, workspace);
+  SDUMC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(ssd_stage2, dim3(1), dim3(256), 0, st, workspace, nchunk, ssd_out);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_rmse_bwd(const float* a, const float* b, int64_t n_local, const float* ssd_global,
+                              double numel_global, float weight, float* loss_out, float* da, int32_t da_accumulate,
+                              float* db, int32_t db_accumulate, void* stream) {
+  if (!a || !b || !ssd_global || n_local <= 0 || numel_global <= 0) return SDUMC_EINVAL;
+  hipLaunchKernelGGL(rmse_bwd_kernel, dim3((unsigned)((n_local + 255) / 256)), dim3(256), 0, as_stream(stream), a, b,
+                     n_local, ssd_global, (float)(1.0 / numel_global), weight, loss_out, da, da_accumulate, db,
+                     db_accumulate);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" size_t sdumc_rnc_workspace_bytes(int32_t n) { return ((size_t)5 * n * n + 2 * (size_t)n) * sizeof(float); }
+
+extern "C" int sdumc_rnc_fwd_bwd(const float* feats, const float* labels, int32_t n, int32_t dim, float temperature,
+                                 float weight, int32_t row0, int32_t rows_local, float* loss_out, float* dfeats,
+                                 float* workspace, void* stream) {
+  if (!feats || !labels || !loss_out || !workspace || n < 2 || dim <= 0 || temperature <= 0.f) return SDUMC_EINVAL;
+  if (row0 < 0 || rows_local < 0 || row0 + rows_local > n) return SDUMC_EINVAL;
+  if ((size_t)n * 2 * sizeof(float) + 1024 > 64 * 1024) return SDUMC_EINVAL;  // n <= ~8000
+  hipStream_t st = as_stream(stream);
+  const RncWs w = rnc_ws(workspace, n);
+  const float inv_t = 1.f / temperature;
+  hipLaunchKernelGGL(rnc_pairs_kernel, dim3(n), dim3(256), dim * sizeof(float), st, feats, labels, n, dim, inv_t, w);
+  SDUMC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rnc_denoms_kernel, dim3(n), dim3(256), 2 * n * sizeof(float), st, n, inv_t, w);
+  SDUMC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(rnc_loss_kernel, dim3(1), dim3(256), 0, st, n, w, loss_out);
+  SDUMC_CHECK_LAUNCH();
+  if (dfeats && rows_local > 0) {
+    hipLaunchKernelGGL(rnc_glogit_kernel, dim3(n), dim3(256), 2 * n * sizeof(float), st, n, w);
+    SDUMC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(rnc_dfeat_kernel, dim3(rows_local), dim3(256), (n + 256) * sizeof(float), st, feats, n, dim,
+                       inv_t, weight, row0, w, dfeats);
+    SDUMC_CHECK_LAUNCH();
+  }
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_rnc_dfeat_rows(const float* feats, int32_t n, int32_t dim, float temperature, float weight,
+                                    int32_t row0, int32_t rows, float* dfeats, float* workspace, void* stream) {
+  if (!feats || !dfeats || !workspace || n < 2 || dim <= 0 || row0 < 0 || rows <= 0 || row0 + rows > n) return SDUMC_EINVAL;
+  const RncWs w = rnc_ws(workspace, n);
+  hipLaunchKernelGGL(rnc_dfeat_kernel, dim3(rows), dim3(256), (n + 256) * sizeof(float), as_stream(stream), feats, n,
+                     dim, 1.f / temperature, weight, row0, w, dfeats);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_rnc_mask(const float* labels, int32_t n, uint8_t* mask, void* stream) {
+  if (!labels || !mask || n < 2) return SDUMC_EINVAL;
+  const int64_t total = (int64_t)n * (n - 1) * (n - 1);
+  hipLaunchKernelGGL(rnc_mask_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), labels, n, mask);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}

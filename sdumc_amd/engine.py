@@ -1,0 +1,246 @@
+"""Thin Python host over the network-level C ABI (include/sdumc_hip.h, engine.hip).
+
+PyTorch-ROCm is used for device memory and streams only.  Everything numeric
+happens in libsdumc_hip.so; there is no CPU or torch fallback.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr
+
+D, H, NQ, RNC_DIM = _lib.D, _lib.H, _lib.NQ, _lib.RNC_DIM
+P_FRAME, P_MLP = 0.5, 0.3        # model :54,:77 / model :187 (constructor default; --dropout is never forwarded)
+DEFAULT_WEIGHTS = (0.5, 0.5, 0.1, 0.7, 0.1, 0.8)      # main :234-239
+PUBLISHED_WEIGHTS = (0.5, 0.5, 0.0, 0.0, 0.13, 0.5)   # shell/main_text_missing_icassp.sh:6
+
+
+class ParamLayout:
+    """name -> (offset, shape, live) of the flat parameter buffer for feature widths (da, dt, dv)."""
+
+    _cache = {}
+
+    def __init__(self, da, dt, dv):
+        self.dims = (int(da), int(dt), int(dv))
+        need = -lib.sdumc_param_table(*self.dims, None, 0)
+        buf = C.create_string_buffer(need)
+        n = lib.sdumc_param_table(*self.dims, buf, need)
+        if n < 0:
+            raise _lib.SdumcError("sdumc_param_table failed")
+        self.entries = {}
+        self.order = []
+        for line in buf.value.decode().splitlines():
+            name, off, rows, cols, live = line.split()
+            shape = (int(rows), int(cols)) if int(cols) else (int(rows),)
+            self.entries[name] = (int(off), shape, bool(int(live)))
+            self.order.append(name)
+        self.total = lib.sdumc_param_count(*self.dims)
+        self.live = lib.sdumc_param_live_count(*self.dims)
+
+    @classmethod
+    def get(cls, da, dt, dv):
+        key = (int(da), int(dt), int(dv))
+        if key not in cls._cache:
+            cls._cache[key] = cls(*key)
+        return cls._cache[key]
+
+    def views(self, flat):
+        """dict name -> view of `flat` (no copies)."""
+        out = {}
+        for name in self.order:
+            off, shape, _ = self.entries[name]
+            n = 1
+            for s in shape:
+                n *= s
+            out[name] = flat[off:off + n].view(shape)
+        return out
+
+    def live_names(self):
+        return [n for n in self.order if self.entries[n][2]]
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.SdumcError("sdumc_amd runs on the GPU only: got a CPU tensor (there is no CPU fallback)")
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise _lib.SdumcError("expected contiguous float32 tensors")
+
+
+def make_dims(B, streams, Ta, Tv, Tt, dims, train, sample0=0):
+    d = _lib.NetDims()
+    d.B, d.streams, d.Ta, d.Tv = B, streams, Ta, Tv
+    d.Tt[0] = Tt[0]
+    d.Tt[1] = Tt[1] if len(Tt) > 1 else Tt[0]
+    d.da, d.dt, d.dv = dims[0], dims[1], dims[2]
+    d.train = 1 if train else 0
+    d.sample0 = sample0
+    d.p_frame, d.p_mlp = P_FRAME, P_MLP
+    return d
+
+
+class RngState:
+    """Device-resident {seed_lo, seed_hi, call}: lets captured graphs draw fresh masks per replay."""
+
+    def __init__(self, seed, device, call=0):
+        self.t = torch.tensor([seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, call], dtype=torch.int64,
+                              device="cpu").to(torch.int32).to(device)
+
+    def set_call(self, call):
+        self.t[2] = call
+
+    @property
+    def call(self):
+        return int(self.t[2].item()) & 0xFFFFFFFF
+
+
+class NetCall:
+    """One network invocation (1 or 2 streams): owns workspace + outputs, supports backward."""
+
+    def __init__(self, flat_params, audio, texts, video, train, rng, sample0=0):
+        texts = list(texts)
+        _require_cuda(flat_params, audio, video, *texts)
+        S = len(texts)
+        B, Ta, da = audio.shape
+        Tv, dv = video.shape[1], video.shape[2]
+        dt = texts[0].shape[2]
+        for t in texts:
+            if t.shape[0] != B or t.shape[2] != dt:
+                raise _lib.SdumcError("text-slot inputs must share batch and width (SURVEY §8b: feat4 width == text width)")
+        if video.shape[0] != B:
+            raise _lib.SdumcError("batch mismatch")
+        self.dims = make_dims(B, S, Ta, Tv, [t.shape[1] for t in texts], (da, dt, dv), train, sample0)
+        self.layout = ParamLayout.get(da, dt, dv)
+        if flat_params.numel() != self.layout.total:
+            raise _lib.SdumcError("flat parameter buffer has the wrong size")
+        dev = audio.device
+        nbytes = lib.sdumc_net_workspace_bytes(C.byref(self.dims))
+        if nbytes == 0:
+            raise _lib.SdumcError("invalid network dimensions")
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        V = B * S
+        self.V, self.B, self.S = V, B, S
+        self.vals = torch.empty(V, 1, device=dev)
+        self.fused = torch.empty(V, H, device=dev)
+        self.rnc = torch.empty(V, RNC_DIM, device=dev)
+        self.text_hidden = torch.empty(V, D, device=dev)
+        self.cross_text = torch.empty(V, NQ, H, device=dev)
+        self._keep = (flat_params, audio, texts, video, rng)
+        io = _lib.NetIO()
+        io.audio, io.video = ptr(audio), ptr(video)
+        io.text[0] = ptr(texts[0])
+        io.text[1] = ptr(texts[1]) if S == 2 else None
+        io.params = ptr(flat_params)
+        io.rng_state = ptr(rng.t) if rng is not None else None
+        io.workspace, io.workspace_bytes = ptr(self.workspace), nbytes
+        io.vals, io.fused, io.rnc = ptr(self.vals), ptr(self.fused), ptr(self.rnc)
+        io.text_hidden, io.cross_text = ptr(self.text_hidden), ptr(self.cross_text)
+        self.io = io
+
+    def forward(self):
+        check(lib.sdumc_net_forward(C.byref(self.dims), C.byref(self.io), _lib.current_stream()), "sdumc_net_forward")
+        return self.vals, self.fused, self.rnc, self.text_hidden, self.cross_text
+
+    def backward(self, d_vals, d_fused, d_rnc, d_text_hidden, d_cross_text, grads=None):
+        """Returns the flat gradient bucket [live] (allocated zeroed when not given)."""
+        _require_cuda(d_vals, d_fused, d_rnc, d_text_hidden, d_cross_text)
+        if grads is None:
+            grads = torch.zeros(self.layout.live, device=self.vals.device)
+        g = _lib.NetGrads()
+        g.d_vals, g.d_fused, g.d_rnc = ptr(d_vals), ptr(d_fused), ptr(d_rnc)
+        g.d_text_hidden, g.d_cross_text = ptr(d_text_hidden), ptr(d_cross_text)
+        g.grads = ptr(grads)
+        check(lib.sdumc_net_backward(C.byref(self.dims), C.byref(self.io), C.byref(g), _lib.current_stream()),
+              "sdumc_net_backward")
+        return grads
+
+
+class TrainStep:
+    """The fused two-stream self-distillation step (main :119-150) on one GPU:
+    forward(both streams) -> 6 losses -> backward -> Adam, ~150 launches on one stream,
+    optionally captured into a hipGraph (torch.cuda.CUDAGraph) and replayed."""
+
+    def __init__(self, flat_params, B, T, dims, weights=DEFAULT_WEIGHTS, lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=1e-5, seed=0, train=True, sample0=0):
+        Ta, Tt, Tv, T4 = T
+        self.layout = ParamLayout.get(dims[0], dims[1], dims[2])
+        dev = flat_params.device
+        _require_cuda(flat_params)
+        self.params = flat_params
+        self.dims = make_dims(B, 2, Ta, Tv, (Tt, T4), dims, train, sample0)
+        nbytes = lib.sdumc_step_workspace_bytes(C.byref(self.dims))
+        if nbytes == 0:
+            raise _lib.SdumcError("invalid step dimensions")
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        self.rng = RngState(seed, dev)
+        V = 2 * B
+        self.B, self.V = B, V
+        self.audio = torch.empty(B, Ta, dims[0], device=dev)
+        self.text = torch.empty(B, Tt, dims[1], device=dev)
+        self.video = torch.empty(B, Tv, dims[2], device=dev)
+        self.feat4 = torch.empty(B, T4, dims[1], device=dev)
+        self.labels = torch.empty(B, device=dev)
+        self.vals = torch.empty(V, 1, device=dev)
+        self.fused = torch.empty(V, H, device=dev)
+        self.rnc = torch.empty(V, RNC_DIM, device=dev)
+        self.text_hidden = torch.empty(V, D, device=dev)
+        self.cross_text = torch.empty(V, NQ, H, device=dev)
+        self.adam_m = torch.zeros(self.layout.live, device=dev)
+        self.adam_v = torch.zeros(self.layout.live, device=dev)
+        self.hyper = torch.tensor([lr, 0.0, 0.0, 0.0], device=dev)
+        self.losses = torch.zeros(8, device=dev)
+        io = _lib.NetIO()
+        io.audio, io.video = ptr(self.audio), ptr(self.video)
+        io.text[0], io.text[1] = ptr(self.text), ptr(self.feat4)
+        io.params, io.rng_state = ptr(flat_params), ptr(self.rng.t)
+        io.workspace, io.workspace_bytes = ptr(self.workspace), nbytes
+        io.vals, io.fused, io.rnc = ptr(self.vals), ptr(self.fused), ptr(self.rnc)
+        io.text_hidden, io.cross_text = ptr(self.text_hidden), ptr(self.cross_text)
+        self.io = io
+        cfg = _lib.StepCfg()
+        for i, w in enumerate(weights):
+            cfg.weights[i] = w
+        cfg.temperature = 2.0
+        cfg.beta1, cfg.beta2, cfg.eps, cfg.weight_decay = betas[0], betas[1], eps, weight_decay
+        cfg.labels, cfg.adam_m, cfg.adam_v = ptr(self.labels), ptr(self.adam_m), ptr(self.adam_v)
+        cfg.hyper, cfg.losses = ptr(self.hyper), ptr(self.losses)
+        self.cfg = cfg
+        self.graph = None
+        goff = lib.sdumc_step_grads_offset(C.byref(self.dims))
+        self.grads = self.workspace[goff:goff + 4 * self.layout.live].view(torch.float32)
+
+    def set_batch(self, audio, text, video, feat4, labels):
+        """Copies one batch into the step's resident input buffers (shapes are fixed per TrainStep)."""
+        self.audio.copy_(audio, non_blocking=True)
+        self.text.copy_(text, non_blocking=True)
+        self.video.copy_(video, non_blocking=True)
+        self.feat4.copy_(feat4, non_blocking=True)
+        self.labels.copy_(labels.reshape(-1), non_blocking=True)
+
+    def set_lr(self, lr):
+        self.hyper[0] = lr
+
+    def launch(self, stream=None):
+        st = _lib.current_stream() if stream is None else stream
+        check(lib.sdumc_train_step(C.byref(self.dims), C.byref(self.io), C.byref(self.cfg), st), "sdumc_train_step")
+
+    def capture(self):
+        """Capture one step into a hipGraph; run() then replays it (launch overhead ~ one graph launch)."""
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        # the capture itself does not execute; state (params, Adam, rng) is untouched by it
+        with torch.cuda.graph(g, stream=s):
+            self.launch()
+        self.graph = g
+
+    def run(self):
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.launch()
+        return self.losses

@@ -1,0 +1,168 @@
+"""Operator-level Python wrappers over the C ABI (one function per entry point of
+include/sdumc_hip.h).  Used by the drop-in modules, the data-parallel trainer and
+the parity tests.  Device tensors in, device tensors out; no fallback path."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import lib, check, ptr, make_dropout
+
+NT, NN, TN = _lib.NT, _lib.NN, _lib.TN
+ACT_NONE, ACT_RELU, ACT_TANH = _lib.ACT_NONE, _lib.ACT_RELU, _lib.ACT_TANH
+
+
+def _st():
+    return _lib.current_stream()
+
+
+def gemm(layout, A, B, M, N, K, bias=None, C_out=None, lda=None, ldb=None, ldc=None, act=ACT_NONE, a_row_mod=0,
+         b_row_mod=0, a_drop=None, b_drop=None, c_drop=None, c_drop_group_stride=0, accumulate=False, splitk=1,
+         tile=0):
+    """Grouped when A/B/(bias)/C_out are lists."""
+    As = A if isinstance(A, (list, tuple)) else [A]
+    Bs = B if isinstance(B, (list, tuple)) else [B]
+    groups = len(As)
+    dev = As[0].device
+    if C_out is None:
+        Cs = [torch.empty(M, N, device=dev) for _ in range(groups)]
+    else:
+        Cs = C_out if isinstance(C_out, (list, tuple)) else [C_out]
+    biases = bias if isinstance(bias, (list, tuple)) else [bias] * groups
+    g = _lib.Gemm()
+    g.layout, g.M, g.N, g.K, g.groups = layout, M, N, K, groups
+    for i in range(groups):
+        g.A[i], g.B[i], g.C[i], g.bias[i] = ptr(As[i]), ptr(Bs[i]), ptr(Cs[i]), ptr(biases[i])
+    g.lda = lda if lda is not None else (K if layout != TN else M)
+    g.ldb = ldb if ldb is not None else (K if layout == NT else N)
+    g.ldc = ldc if ldc is not None else N
+    g.a_row_mod, g.b_row_mod = a_row_mod, b_row_mod
+    if a_drop is not None:
+        g.a_drop = a_drop
+    if b_drop is not None:
+        g.b_drop = b_drop
+    if c_drop is not None:
+        g.c_drop = c_drop
+    g.c_drop_group_stride = c_drop_group_stride
+    g.act, g.accumulate, g.splitk, g.tile = act, 1 if accumulate else 0, splitk, tile
+    need = lib.sdumc_gemm_workspace_bytes(C.byref(g))
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+    g.workspace, g.workspace_bytes = ptr(ws), need
+    check(lib.sdumc_gemm_f32(C.byref(g), _st()), "sdumc_gemm_f32")
+    return Cs if isinstance(A, (list, tuple)) else Cs[0]
+
+
+def attnpool_desc(x, keys, q, V, T, nq, x_samples, q_stride, x_drop, out_drop, attn, pooled, out, scale=0.3):
+    a = _lib.AttnPool()
+    a.V, a.T, a.nq, a.x_samples = V, T, nq, x_samples
+    a.x, a.keys, a.q, a.q_stride, a.scale = ptr(x), ptr(keys), ptr(q), q_stride, scale
+    if x_drop is not None:
+        a.x_drop = x_drop
+    if out_drop is not None:
+        a.out_drop = out_drop
+    a.attn, a.pooled, a.out = ptr(attn), ptr(pooled), ptr(out)
+    return a
+
+
+def attnpool_fwd(x, keys, q, nq, x_samples=None, q_shared=False, x_drop=None, out_drop=None):
+    V, T, Dm = keys.shape
+    dev = keys.device
+    attn = torch.empty(V, T, nq, device=dev)
+    pooled = torch.empty(V, nq, Dm, device=dev)
+    out = torch.empty(V, nq, Dm, device=dev)
+    a = attnpool_desc(x, keys, q, V, T, nq, x_samples or x.shape[0], 0 if q_shared else nq * Dm, x_drop, out_drop,
+                      attn, pooled, out)
+    check(lib.sdumc_attnpool_fwd(C.byref(a), _st()), "sdumc_attnpool_fwd")
+    return out, attn, pooled, a
+
+
+def attnpool_bwd(desc, dout, keep):
+    """desc: the AttnPool returned by attnpool_fwd; keep: tensors that must stay alive."""
+    V, T, nq = desc.V, desc.T, desc.nq
+    dev = dout.device
+    dz = torch.empty(V, T, _lib.D, device=dev)
+    dxd = torch.empty(V, T, _lib.D, device=dev)
+    dq = torch.empty(V, nq, _lib.D, device=dev)
+    need = lib.sdumc_attnpool_bwd_workspace_bytes(V, T, nq)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    b = _lib.AttnPoolBwd()
+    b.f = desc
+    b.dout, b.dz, b.dxd, b.dq = ptr(dout), ptr(dz), ptr(dxd), ptr(dq)
+    b.workspace, b.workspace_bytes = ptr(ws), need
+    check(lib.sdumc_attnpool_bwd(C.byref(b), _st()), "sdumc_attnpool_bwd")
+    return dz, dxd, dq
+
+
+def dropout_mask(d, streams):
+    n = streams * d.samples * max(d.rows, 1) * d.width
+    dev = torch.device("cuda")
+    m = torch.empty(n, device=dev)
+    check(lib.sdumc_dropout_mask(C.byref(d), streams, ptr(m), _st()), "sdumc_dropout_mask")
+    return m.view(streams * d.samples, max(d.rows, 1), d.width)
+
+
+def colsum(a, accumulate_into=None):
+    rows, cols = a.shape
+    out = accumulate_into if accumulate_into is not None else torch.empty(cols, device=a.device)
+    ws = torch.empty(max(lib.sdumc_colsum_workspace_bytes(rows, cols), 16), dtype=torch.uint8, device=a.device)
+    check(lib.sdumc_colsum(ptr(a), rows, cols, a.stride(0), ptr(out), 1 if accumulate_into is not None else 0,
+                           ptr(ws), _st()), "sdumc_colsum")
+    return out
+
+
+def mse_fwd_bwd(pred, target, weight=1.0, denom=None):
+    rows = pred.numel()
+    loss = torch.empty(1, device=pred.device)
+    dpred = torch.empty_like(pred)
+    check(lib.sdumc_mse_fwd_bwd(ptr(pred), ptr(target), rows, float(denom or rows), weight, ptr(loss), ptr(dpred),
+                                _st()), "sdumc_mse_fwd_bwd")
+    return loss, dpred
+
+
+def ssd(a, b):
+    n = a.numel()
+    out = torch.empty(1, device=a.device)
+    ws = torch.empty(max(lib.sdumc_ssd_workspace_bytes(n), 16), dtype=torch.uint8, device=a.device)
+    check(lib.sdumc_ssd(ptr(a), ptr(b), n, ptr(out), ptr(ws), _st()), "sdumc_ssd")
+    return out
+
+
+def rmse_fwd_bwd(a, b, weight=1.0, ssd_global=None, numel_global=None, need_db=True):
+    s = ssd_global if ssd_global is not None else ssd(a, b)
+    loss = torch.empty(1, device=a.device)
+    da = torch.empty_like(a)
+    db = torch.empty_like(b) if need_db else None
+    check(lib.sdumc_rmse_bwd(ptr(a), ptr(b), a.numel(), ptr(s), float(numel_global or a.numel()), weight, ptr(loss),
+                             ptr(da), 0, ptr(db), 0, _st()), "sdumc_rmse_bwd")
+    return loss, da, db
+
+
+def rnc_fwd_bwd(feats, labels, temperature=2.0, weight=1.0, row0=0, rows_local=None):
+    n, dim = feats.shape
+    rows_local = n if rows_local is None else rows_local
+    loss = torch.empty(1, device=feats.device)
+    df = torch.empty(rows_local, dim, device=feats.device)
+    ws = torch.empty(lib.sdumc_rnc_workspace_bytes(n), dtype=torch.uint8, device=feats.device)
+    check(lib.sdumc_rnc_fwd_bwd(ptr(feats), ptr(labels), n, dim, temperature, weight, row0, rows_local, ptr(loss),
+                                ptr(df), ptr(ws), _st()), "sdumc_rnc_fwd_bwd")
+    return loss, df, ws
+
+
+def rnc_dfeat_rows(feats, ws, row0, rows, temperature=2.0, weight=1.0):
+    n, dim = feats.shape
+    df = torch.empty(rows, dim, device=feats.device)
+    check(lib.sdumc_rnc_dfeat_rows(ptr(feats), n, dim, temperature, weight, row0, rows, ptr(df), ptr(ws), _st()),
+          "sdumc_rnc_dfeat_rows")
+    return df
+
+
+def rnc_mask(labels):
+    n = labels.numel()
+    m = torch.empty(n, n - 1, n - 1, dtype=torch.uint8, device=labels.device)
+    check(lib.sdumc_rnc_mask(ptr(labels), n, ptr(m), _st()), "sdumc_rnc_mask")
+    return m
+
+
+def adam_step(param, grad, m, v, hyper, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-5, grad_scale=1.0):
+    check(lib.sdumc_adam_step(ptr(param), ptr(grad), ptr(m), ptr(v), param.numel(), ptr(hyper), beta1, beta2, eps,
+                              weight_decay, grad_scale, _st()), "sdumc_adam_step")
