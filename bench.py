@@ -1,0 +1,221 @@
+#!/usr/bin/env python3
+"""bench.py — train samples/s of the SDUMC two-stream self-distillation step at MOSEI feature shapes.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" = main_frame_val_text_missing.py:119-150 on one batch of synthetic pre-extracted features
+already resident in HBM: forward of both streams, the 6-term loss, backward, Adam.  Nothing is skipped.
+Workload = BASELINE.json configs[1] ("CMU-MOSEI features, batch=64 ... 1xMI355X fp32") per GPU;
+N > 1 shards the batch (weak scaling: 64 samples per GPU, global batch 64*N) with ONE RCCL all-reduce
+of the flat gradient bucket per step plus the two exactness exchanges (sdumc_amd/trainer.py).
+
+Output: ONE JSON line on rank 0 (contract in the task description) with `roofline` (dominant kernel,
+HIP events on the launch stream) and `cpu_baseline` (the CPU oracle = port of the reference's torch-eager
+path, timed on this box's host cores; rank 0, N=1 only).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+B_PER_GPU = 64
+T_MOSEI = (375, 32, 225, 32)            # (T_audio, T_text, T_video, T_feat4)   SURVEY §8 C2
+DIMS = (1024, 4096, 1024, 4096)         # WavLM-L / Vicuna-7B / MANet / Vicuna-7B
+TRAIN_FLOPS_PER_SAMPLE = 1980.7e6       # algorithmic, audio/video projection counted once
+PEAK_F32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: dense fp32 matrix peak
+
+
+def synthetic_shard(B, rank, seed=1234):
+    """SURVEY §8(d) synthetic inputs (features ~N(0,1), labels ~U(-3,3)); one generator per rank."""
+    g = torch.Generator().manual_seed(seed + rank)
+    feats = [torch.randn(B, T_MOSEI[i], DIMS[i], generator=g) for i in range(4)]
+    vals = torch.rand(B, generator=g) * 6 - 3
+    return feats[0], feats[1], feats[2], feats[3], vals
+
+
+def init_flat_params(engine, device, seed=0):
+    """Random-init weights of the reference architecture (nn.Linear defaults, xavier context vectors)."""
+    import math
+    lay = engine.ParamLayout.get(*DIMS[:3])
+    flat = torch.zeros(lay.total)
+    g = torch.Generator().manual_seed(seed)
+    views = lay.views(flat)
+    for name in lay.order:
+        v = views[name]
+        if name.endswith("attention_context_vector"):
+            v.copy_(torch.randn(v.shape, generator=g) * math.sqrt(2.0 / (v.shape[0] + v.shape[1])))
+        elif name == "prelu.weight":
+            v.fill_(0.25)
+        elif name == "layer_normali.weight":
+            v.fill_(1.0)
+        elif name == "layer_normali.bias":
+            v.zero_()
+        else:
+            fan_in = v.shape[1] if v.dim() == 2 else views[name[:-5] + ".weight"].shape[1]
+            v.copy_((torch.rand(v.shape, generator=g) * 2 - 1) / math.sqrt(fan_in))
+    return flat.to(device), lay
+
+
+def roofline_leg(_lib, launch, steps):
+    """Eager (un-captured) replays of the same step with a HIP event pair around every GEMM launch,
+    on the launch stream.  Returns the dominant GEMM variant's achieved TFLOP/s."""
+    lib = _lib.lib
+    torch.cuda.synchronize()
+    lib.sdumc_profile_enable(1)
+    for _ in range(steps):
+        launch()
+    torch.cuda.synchronize()
+    arr = (_lib.ProfEntry * 6)()
+    n = lib.sdumc_profile_report(arr, 6)
+    lib.sdumc_profile_enable(0)
+    rows = []
+    for i in range(max(n, 0)):
+        e = arr[i]
+        if e.launches:
+            rows.append({"kernel": e.name.decode(), "launches_per_step": e.launches / steps,
+                         "avg_us": 1e3 * e.total_ms / e.launches,
+                         "gflop_per_launch": e.total_flops / e.launches / 1e9,
+                         "tflops": e.total_flops / (e.total_ms * 1e-3) / 1e12,
+                         "ms_per_step": e.total_ms / steps})
+    rows.sort(key=lambda r: -r["ms_per_step"])
+    top = rows[0]
+    return {"bound": "mfma", "achieved": round(top["tflops"], 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(top["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "kernel": top["kernel"], "avg_launch_us": round(top["avg_us"], 2),
+            "gflop_per_launch": round(top["gflop_per_launch"], 3),
+            "launches_per_step": top["launches_per_step"],
+            "gemm_ms_per_step": round(sum(r["ms_per_step"] for r in rows), 4),
+            "all_gemm_variants": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]}
+
+
+def cpu_baseline_leg(steps=3):
+    """The CPU oracle (torch-eager port of the reference op sequence, native dropout RNG exactly like the
+    reference) on this box's host cores: the same B=64 MOSEI-shaped two-stream train step."""
+    from oracle import sdumc_oracle as O
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    P = O.init_params(DIMS, seed=0)
+    batch = O.synthetic_batch(B_PER_GPU, T_MOSEI, DIMS, seed=1234)
+    state = {}
+    O.train_step(P, state, *batch, mode="native", step=0)        # warm-up
+    best = float("inf")
+    for i in range(steps):
+        t0 = time.perf_counter()
+        O.train_step(P, state, *batch, mode="native", step=i + 1)
+        best = min(best, time.perf_counter() - t0)
+    return {"value": round(B_PER_GPU / best, 2), "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} train steps (best-of) of the same B={B_PER_GPU} MOSEI-shaped batch after 1 warm-up, "
+                      f"torch {torch.__version__} eager fp32, {torch.get_num_threads()} threads",
+            "sec_per_step": round(best, 4)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: sdumc_amd has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    import torch.distributed as dist
+    from sdumc_amd import _lib, engine
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+
+    flat, lay = init_flat_params(engine, dev)
+    batch = [t.to(dev) for t in synthetic_shard(B_PER_GPU, rank)]
+
+    if world == 1:
+        step = engine.TrainStep(flat, B_PER_GPU, T_MOSEI, DIMS, seed=2024)
+        step.set_batch(*batch)
+        if not args.no_graph:
+            step.capture()
+        run = step.run
+    else:
+        from sdumc_amd.trainer import DataParallelStep
+        step = DataParallelStep(flat, B_PER_GPU, T_MOSEI, DIMS, seed=2024, exact=True)
+        step.set_batch(*batch)
+        run = step.step
+
+    for _ in range(args.warmup):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    losses = (step.losses if world == 1 else step.be.losses).cpu()
+    if not torch.isfinite(losses).all():
+        raise SystemExit(f"non-finite loss: {losses.tolist()}")
+
+    value = world * B_PER_GPU * args.steps / dt
+    out = {
+        "metric": "train samples/sec at MOSEI feature shapes (two-stream forward + 6-term loss + backward + Adam)",
+        "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1]: CMU-MOSEI-shaped features, batch=64 per GPU, fp32, both streams "
+                               "(text + text-missing/feat4) with self-distillation",
+                   "batch_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU,
+                   "T_audio_text_video_feat4": list(T_MOSEI), "feature_dims": list(DIMS),
+                   "parallelism": f"dp{world}" if world > 1 else "single",
+                   "launch": "eager" if (args.no_graph or world > 1) else "hipGraph replay",
+                   "params": lay.total, "final_loss": round(float(losses[0]), 5)},
+        "whole_step_tflops": round(value * TRAIN_FLOPS_PER_SAMPLE / 1e12, 2),
+        "whole_step_frac_of_f32_mfma_peak": round(value * TRAIN_FLOPS_PER_SAMPLE / 1e12 / (world * PEAK_F32_MFMA_TFLOPS), 4),
+    }
+    if not args.no_roofline:     # every rank runs it (the DP step has collectives); rank 0 reports
+        roof = roofline_leg(_lib, step.launch if world == 1 else step.step, max(3, min(10, args.steps)))
+        if rank == 0:
+            out["roofline"] = roof
+    if rank == 0 and world == 1:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_leg()
+            out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -255,6 +255,18 @@ int sdumc_rng_advance(uint32_t* dev_state, uint32_t inc, void* stream);
 int sdumc_dropout_mask(const sdumc_dropout* d, int32_t streams, float* mask, void* stream);
 const char* sdumc_version(void);
 
+/* Optional per-launch timing of the GEMM kernels with HIP events recorded on the launch stream
+ * (bench.py's roofline leg; not for use under graph capture).  enable(1) clears and starts,
+ * report() synchronises the recorded events and aggregates per kernel variant. */
+typedef struct sdumc_prof_entry {
+  const char* name;      /* e.g. "gemm_nt_128x128" */
+  int64_t launches;
+  double total_ms;
+  double total_flops;    /* algorithmic: 2*M*N*K*groups per launch */
+} sdumc_prof_entry;
+int sdumc_profile_enable(int on);
+int sdumc_profile_report(sdumc_prof_entry* out, int max_entries);
+
 /* ========================================================================
  * Network level: WengnetMOSEIMultViewsTextMissing (model :186-370) as one call.
  *

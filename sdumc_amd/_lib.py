@@ -87,7 +87,13 @@ class StepCfg(C.Structure):
                 ("rnc_labels_global", C.c_void_p), ("rnc_row0", C.c_int32 * 2)]
 
 
+class ProfEntry(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("launches", C.c_int64), ("total_ms", C.c_double), ("total_flops", C.c_double)]
+
+
 _SIGS = {
+    "sdumc_profile_enable": (C.c_int, [C.c_int]),
+    "sdumc_profile_report": (C.c_int, [C.POINTER(ProfEntry), C.c_int]),
     "sdumc_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(Gemm)]),
     "sdumc_gemm_f32": (C.c_int, [C.POINTER(Gemm), C.c_void_p]),
     "sdumc_attnpool_fwd": (C.c_int, [C.POINTER(AttnPool), C.c_void_p]),

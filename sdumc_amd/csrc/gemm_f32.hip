@@ -19,9 +19,24 @@
 //   * fusions: dropout (Philox, recomputed, never stored) on the staged A (NT/NN) or B (TN) operand,
 //     source-row modulo (the two streams share x_audio/x_video), bias + ReLU/tanh + dropout epilogue,
 //     accumulate, deterministic split-K (slabs + ordered reduce; no float atomics).
+#include <mutex>
+#include <vector>
+
 #include "common.h"
 
 namespace {
+
+// ---- optional per-launch timing with HIP events on the launch stream (bench.py roofline leg) -----
+struct ProfRec {
+  hipEvent_t a, b;
+  int variant;  // layout * 2 + (tile == 64x64)
+  double flops;
+};
+bool g_prof_on = false;
+std::vector<ProfRec> g_prof;
+std::mutex g_prof_mu;
+const char* const kVariantName[6] = {"gemm_nt_128x128", "gemm_nt_64x64", "gemm_nn_128x128",
+                                     "gemm_nn_64x64",   "gemm_tn_128x128", "gemm_tn_64x64"};
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;
@@ -297,9 +312,22 @@ extern "C" int sdumc_gemm_f32(const sdumc_gemm* gp, void* stream) {
     const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.groups * nsplit;
     tile = big >= 96 ? 1 : 2;
   }
+  ProfRec rec;
+  const bool prof = g_prof_on;
+  if (prof) {
+    if (hipEventCreate(&rec.a) != hipSuccess || hipEventCreate(&rec.b) != hipSuccess) return SDUMC_ELAUNCH;
+    rec.variant = g.layout * 2 + (tile == 1 ? 0 : 1);
+    rec.flops = 2.0 * g.M * (double)g.N * g.K * g.groups;
+    (void)hipEventRecord(rec.a, st);
+  }
   int rc = tile == 1 ? launch<128, 128>(g, nsplit, kchunk, st) : launch<64, 64>(g, nsplit, kchunk, st);
   if (rc != SDUMC_OK) return rc;
   SDUMC_CHECK_LAUNCH();
+  if (prof) {
+    (void)hipEventRecord(rec.b, st);
+    std::lock_guard<std::mutex> lock(g_prof_mu);
+    g_prof.push_back(rec);
+  }
   if (nsplit > 1) {
     const size_t mn = (size_t)g.M * g.N;
     dim3 grid((unsigned)((mn + 255) / 256), g.groups);
@@ -307,4 +335,36 @@ extern "C" int sdumc_gemm_f32(const sdumc_gemm* gp, void* stream) {
     SDUMC_CHECK_LAUNCH();
   }
   return SDUMC_OK;
+}
+
+// ---- profiling hooks ------------------------------------------------------------------------
+extern "C" int sdumc_profile_enable(int on) {
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  for (ProfRec& r : g_prof) {
+    (void)hipEventDestroy(r.a);
+    (void)hipEventDestroy(r.b);
+  }
+  g_prof.clear();
+  g_prof_on = on != 0;
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_profile_report(sdumc_prof_entry* out, int max_entries) {
+  if (!out || max_entries < 6) return SDUMC_EINVAL;
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  for (int v = 0; v < 6; ++v) {
+    out[v].name = kVariantName[v];
+    out[v].launches = 0;
+    out[v].total_ms = 0.0;
+    out[v].total_flops = 0.0;
+  }
+  for (ProfRec& r : g_prof) {
+    if (hipEventSynchronize(r.b) != hipSuccess) return SDUMC_ELAUNCH;
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) != hipSuccess) return SDUMC_ELAUNCH;
+    out[r.variant].launches += 1;
+    out[r.variant].total_ms += ms;
+    out[r.variant].total_flops += r.flops;
+  }
+  return 6;
 }

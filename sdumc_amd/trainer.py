@@ -1,0 +1,182 @@
+"""Data-parallel two-stream self-distillation step (the reference has no DP: SURVEY §2.2, §8e).
+
+One process per GPU, plain batch sharding, weights replicated.  Per step:
+  1. local forward of both streams                                   (HIP, sdumc_net_forward)
+  2. exactness exchanges so that DP(N x B) == single process(N*B):
+       - all-reduce of the three RMSE sums of squared differences (RMSELoss is the sqrt of a GLOBAL
+         mean, toolkit/utils/loss.py:37-51)
+       - all-gather of the RnC embeddings and labels (RnCLoss uses in-batch negatives over n = 2*B_global,
+         loss.py:271-315); every rank evaluates the full loss and keeps the gradient of its own rows
+  3. loss gradients w.r.t. the local outputs, backward                (HIP)
+  4. ONE all-reduce (sum) of the flat gradient bucket over RCCL/xGMI (15.4 MB fp32)
+  5. fused Adam on the flat bucket                                    (HIP)
+Dropout masks are keyed by the GLOBAL sample index, so results do not depend on N.
+
+The compute backend is injectable: the product default is HipBackend (no fallback); tests inject
+a CPU backend to check the collective algebra under gloo.
+"""
+import ctypes as C
+
+import torch
+import torch.distributed as dist
+
+
+def _world():
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+class HipBackend:
+    """Per-rank compute on one MI355X through the C ABI."""
+
+    def __init__(self, flat_params, B, T, dims, weights, lr, betas, eps, weight_decay, seed, sample0, B_global):
+        from . import _lib, engine
+        self._lib, self._engine = _lib, engine
+        lib = _lib.lib
+        dev = flat_params.device
+        Ta, Tt, Tv, T4 = T
+        self.B, self.B_global = B, B_global
+        self.layout = engine.ParamLayout.get(dims[0], dims[1], dims[2])
+        self.params = flat_params
+        self.audio = torch.empty(B, Ta, dims[0], device=dev)
+        self.text = torch.empty(B, Tt, dims[1], device=dev)
+        self.video = torch.empty(B, Tv, dims[2], device=dev)
+        self.feat4 = torch.empty(B, T4, dims[1], device=dev)
+        self.labels = torch.empty(B, device=dev)
+        self.rng = engine.RngState(seed, dev)
+        self.call = engine.NetCall(flat_params, self.audio, [self.text, self.feat4], self.video, True, self.rng,
+                                   sample0=sample0)
+        V = 2 * B
+        self.d_vals = torch.empty(V, 1, device=dev)
+        self.d_fused = torch.empty(V, engine.H, device=dev)
+        self.d_rnc = torch.empty(V, engine.RNC_DIM, device=dev)
+        self.d_text_hidden = torch.empty(V, engine.D, device=dev)
+        self.d_cross_text = torch.empty(V, engine.NQ, engine.H, device=dev)
+        self.grads = torch.zeros(self.layout.live, device=dev)
+        self.adam_m = torch.zeros(self.layout.live, device=dev)
+        self.adam_v = torch.zeros(self.layout.live, device=dev)
+        self.hyper = torch.tensor([lr, 0.0, 0.0, 0.0], device=dev)
+        self.losses = torch.zeros(8, device=dev)
+        self.ssd = torch.zeros(4, device=dev)
+        nb = lib.sdumc_loss_workspace_bytes(C.byref(self.call.dims), B_global)
+        self.loss_ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+        cfg = _lib.StepCfg()
+        for i, w in enumerate(weights):
+            cfg.weights[i] = w
+        cfg.temperature = 2.0
+        cfg.beta1, cfg.beta2, cfg.eps, cfg.weight_decay = betas[0], betas[1], eps, weight_decay
+        cfg.labels, cfg.adam_m, cfg.adam_v = _lib.ptr(self.labels), _lib.ptr(self.adam_m), _lib.ptr(self.adam_v)
+        cfg.hyper, cfg.losses = _lib.ptr(self.hyper), _lib.ptr(self.losses)
+        cfg.B_global = B_global
+        self.cfg = cfg
+        g = _lib.NetGrads()
+        g.d_vals, g.d_fused, g.d_rnc = _lib.ptr(self.d_vals), _lib.ptr(self.d_fused), _lib.ptr(self.d_rnc)
+        g.d_text_hidden, g.d_cross_text = _lib.ptr(self.d_text_hidden), _lib.ptr(self.d_cross_text)
+        g.grads = _lib.ptr(self.grads)
+        self.g = g
+        self.betas, self.eps, self.wd = betas, eps, weight_decay
+
+    def set_batch(self, audio, text, video, feat4, labels):
+        self.audio.copy_(audio, non_blocking=True)
+        self.text.copy_(text, non_blocking=True)
+        self.video.copy_(video, non_blocking=True)
+        self.feat4.copy_(feat4, non_blocking=True)
+        self.labels.copy_(labels.reshape(-1), non_blocking=True)
+
+    def forward(self):
+        self.call.forward()
+        return self.call.rnc                     # [2B, 64], stream-major
+
+    def local_ssd(self):
+        lib, _lib = self._lib.lib, self._lib
+        _lib.check(lib.sdumc_loss_ssd(C.byref(self.call.dims), C.byref(self.call.io), _lib.ptr(self.ssd),
+                                      _lib.ptr(self.loss_ws), self.loss_ws.numel(), _lib.current_stream()),
+                   "sdumc_loss_ssd")
+        return self.ssd[:3]
+
+    def loss_backward(self, ssd_global=None, feats_global=None, labels_global=None, row0=(0, 0)):
+        lib, _lib = self._lib.lib, self._lib
+        self._keep = (ssd_global, feats_global, labels_global)
+        self.cfg.ssd_global = _lib.ptr(ssd_global)
+        self.cfg.rnc_feats_global = _lib.ptr(feats_global)
+        self.cfg.rnc_labels_global = _lib.ptr(labels_global)
+        self.cfg.rnc_row0[0], self.cfg.rnc_row0[1] = row0
+        _lib.check(lib.sdumc_loss_backward(C.byref(self.call.dims), C.byref(self.call.io), C.byref(self.cfg),
+                                           C.byref(self.g), _lib.ptr(self.loss_ws), self.loss_ws.numel(),
+                                           _lib.current_stream()), "sdumc_loss_backward")
+        return self.losses
+
+    def backward(self):
+        lib, _lib = self._lib.lib, self._lib
+        _lib.check(lib.sdumc_net_backward(C.byref(self.call.dims), C.byref(self.call.io), C.byref(self.g),
+                                          _lib.current_stream()), "sdumc_net_backward")
+        return self.grads
+
+    def adam(self, grad_scale=1.0):
+        lib, _lib = self._lib.lib, self._lib
+        _lib.check(lib.sdumc_adam_step(_lib.ptr(self.params), _lib.ptr(self.grads), _lib.ptr(self.adam_m),
+                                       _lib.ptr(self.adam_v), self.layout.live, _lib.ptr(self.hyper), self.betas[0],
+                                       self.betas[1], self.eps, self.wd, grad_scale, _lib.current_stream()),
+                   "sdumc_adam_step")
+        _lib.check(lib.sdumc_rng_advance(_lib.ptr(self.rng.t), 2, _lib.current_stream()), "sdumc_rng_advance")
+
+    def set_lr(self, lr):
+        self.hyper[0] = lr
+
+
+class DataParallelStep:
+    """`step()` = one optimisation step of the global batch B_global = world_size * B.
+
+    exact=True  : the exchanges of SURVEY §8e -> identical to one process on the whole batch.
+    exact=False : local losses (standard DDP semantics: mean of per-shard gradients); NOT
+                  comparable to the single-process result because RMSE / RnC are not batch-linear.
+    """
+
+    def __init__(self, flat_params, B, T, dims, weights=(0.5, 0.5, 0.1, 0.7, 0.1, 0.8), lr=1e-4, betas=(0.9, 0.999),
+                 eps=1e-8, weight_decay=1e-5, seed=0, exact=True, backend_factory=None):
+        self.rank, self.world = _world()
+        self.B, self.exact = B, exact
+        self.B_global = B * self.world if exact else B
+        factory = backend_factory or HipBackend
+        self.be = factory(flat_params, B, T, dims, weights, lr, betas, eps, weight_decay, seed, self.rank * B,
+                          self.B_global)
+        self.weights = weights
+
+    def set_batch(self, *batch):
+        """The LOCAL shard: rows [rank*B, (rank+1)*B) of the global batch."""
+        self.be.set_batch(*batch)
+
+    def _gather(self, t):
+        parts = [torch.empty_like(t) for _ in range(self.world)]
+        dist.all_gather(parts, t.contiguous())
+        return parts
+
+    def step(self):
+        be, B, W = self.be, self.B, self.world
+        rnc = be.forward()
+        if W > 1 and self.exact:
+            ssd = be.local_ssd().clone()
+            dist.all_reduce(ssd)
+            parts = self._gather(rnc)                       # each [2B, 64] = (stream 0 rows, stream 1 rows)
+            feats = torch.cat([p[:B] for p in parts] + [p[B:] for p in parts]).contiguous()
+            lab = torch.cat(self._gather(be.labels))
+            labels2 = torch.cat([lab, lab]).contiguous()
+            losses = be.loss_backward(ssd, feats, labels2, (self.rank * B, W * B + self.rank * B))
+        else:
+            losses = be.loss_backward()
+        grads = be.backward()
+        if W > 1:
+            dist.all_reduce(grads)                          # ONE flat bucket over RCCL / xGMI
+        be.adam(1.0 if (self.exact or W == 1) else 1.0 / W)
+        return losses
+
+    def global_losses(self, losses):
+        """[total, mse_full, mse_missing, rmse_text, rmse_query, rmse_fused, rnc] of the GLOBAL batch."""
+        l = losses.clone()
+        if self.world > 1 and self.exact:
+            mse = l[1:3].clone()
+            dist.all_reduce(mse)                            # MSE terms are local sums / B_global
+            l[1:3] = mse
+            l[0] = sum(w * v for w, v in zip(self.weights, l[1:7]))
+        return l

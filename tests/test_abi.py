@@ -1,0 +1,71 @@
+"""CPU-only: the C-ABI library loads and exports every symbol include/sdumc_hip.h declares;
+host-side helpers that need no GPU (parameter layout, workspace queries) behave."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from sdumc_amd import _lib
+    header = open(os.path.join(ROOT, "include", "sdumc_hip.h")).read()
+    declared = set(re.findall(r"\b(sdumc_[a-z0-9_]+)\s*\(", header))
+    assert declared, "header parse failed"
+    nm = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH]).decode()
+    exported = {l.split()[-1] for l in nm.splitlines() if " T " in l}
+    assert declared <= exported, sorted(declared - exported)
+    assert declared == set(_lib.EXPORTS), sorted(declared ^ set(_lib.EXPORTS))
+    assert b"gfx950" in _lib.lib.sdumc_version()
+
+
+def test_struct_sizes_match_the_header():
+    """ctypes mirrors vs the C compiler's view of include/sdumc_hip.h."""
+    import tempfile
+    from sdumc_amd import _lib
+    src = r'''
+#include <stdio.h>
+#include "sdumc_hip.h"
+int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(sdumc_dropout), sizeof(sdumc_gemm),
+ sizeof(sdumc_attnpool), sizeof(sdumc_attnpool_bwd_t), sizeof(sdumc_dropsum), sizeof(sdumc_net_dims),
+ sizeof(sdumc_net_io), sizeof(sdumc_net_grads), sizeof(sdumc_step_cfg)); return 0;}
+'''
+    with tempfile.TemporaryDirectory() as td:
+        open(os.path.join(td, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), os.path.join(td, "t.c"), "-o", os.path.join(td, "t")])
+        sizes = [int(v) for v in subprocess.check_output([os.path.join(td, "t")]).split()]
+    mine = [C.sizeof(c) for c in (_lib.Dropout, _lib.Gemm, _lib.AttnPool, _lib.AttnPoolBwd, _lib.DropSum, _lib.NetDims,
+                                  _lib.NetIO, _lib.NetGrads, _lib.StepCfg)]
+    assert sizes == mine
+
+
+def test_param_table_and_workspace_queries():
+    from sdumc_amd import _lib
+    from sdumc_amd.engine import ParamLayout, make_dims
+    from oracle import sdumc_oracle as O
+    lay = ParamLayout.get(1024, 4096, 1024)
+    shapes = O.param_shapes((1024, 4096, 1024, 4096))
+    assert {k: tuple(v[1]) for k, v in lay.entries.items()} == {k: tuple(v) for k, v in shapes.items()}
+    assert lay.total == 4268884 + 16 and lay.live == 3857291 + 5
+    offs = sorted((v[0], int(np.prod(v[1]))) for v in lay.entries.values())
+    for (o0, n0), (o1, _) in zip(offs, offs[1:]):
+        assert o0 + n0 <= o1 and o1 % 4 == 0
+    d = make_dims(64, 2, 375, 225, (32, 32), (1024, 4096, 1024), True)
+    n = _lib.lib.sdumc_net_workspace_bytes(C.byref(d))
+    s = _lib.lib.sdumc_step_workspace_bytes(C.byref(d))
+    assert 0 < n < s < 4 << 30
+    bad = make_dims(0, 2, 375, 225, (32, 32), (1024, 4096, 1024), True)
+    assert _lib.lib.sdumc_net_workspace_bytes(C.byref(bad)) == 0
+    # bad arguments come back as error codes, never as exceptions across the ABI
+    assert _lib.lib.sdumc_gemm_f32(None, None) == -1
+    assert _lib.lib.sdumc_net_forward(C.byref(d), None, None) == -1
+
+
+def test_product_path_never_imports_the_oracle():
+    for root, _, files in os.walk(os.path.join(ROOT, "sdumc_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                assert "oracle" not in open(os.path.join(root, f)).read(), f

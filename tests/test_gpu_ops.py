@@ -1,0 +1,234 @@
+"""GPU parity tests, operator level: each C-ABI kernel against the CPU oracle
+(torch fp32/fp64 on the host).  Tolerances: fp32 1e-3 is the north-star bar;
+these tests hold the kernels to 1e-4 or tighter.  Dropout masks, RnC masks and
+index math are bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from sdumc_amd import ops as o
+    return o
+
+
+def dev(t):
+    return t.cuda().contiguous()
+
+
+def close(got, want, tol=1e-4, msg=""):
+    got = got.detach().cpu().double().numpy()
+    want = want.detach().cpu().double().numpy() if isinstance(want, torch.Tensor) else np.asarray(want, dtype=np.float64)
+    scale = max(1.0, np.abs(want).max())
+    np.testing.assert_allclose(got, want, rtol=tol, atol=tol * scale, err_msg=msg)
+
+
+def test_dropout_mask_bit_exact(ops):
+    from oracle import philox
+    from sdumc_amd._lib import make_dropout
+    for p, rows, width, samples, streams, sample0, site, call, seed in [
+            (0.5, 11, 256, 3, 2, 0, 4, 7, 12345), (0.3, 7, 128, 5, 1, 40, 28, 2, (1 << 40) + 17),
+            (0.3, 1, 256, 4, 2, 3, 12, 0, 99)]:
+        d = make_dropout(True, site, p, rows, width, samples, sample0=sample0, call0=call, seed=seed)
+        got = ops.dropout_mask(d, streams).cpu().numpy()
+        want = np.concatenate([philox.dropout_mask(samples, rows, width, p, seed, call + s, site, sample0)
+                               for s in range(streams)])
+        np.testing.assert_array_equal(got, want)
+    # device-resident state overrides seed/call
+    st = torch.tensor([5, 0, 9], dtype=torch.int32).cuda()
+    d = make_dropout(True, 3, 0.5, 2, 8, 2, dev_state=st)
+    np.testing.assert_array_equal(ops.dropout_mask(d, 1).cpu().numpy(), philox.dropout_mask(2, 2, 8, 0.5, 5, 9, 3))
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(128, 256, 256, 0), (300, 256, 1024, 1), (77, 3, 256, 2), (64, 7, 128, 0),
+                                        (513, 130, 96, 1), (2048, 256, 4096, 0), (5, 1, 128, 0)])
+def test_gemm_nt_bias_act(ops, M, N, K, tile):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    A, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    ref = A.double() @ W.double().T + b.double()
+    for act, f in ((ops.ACT_NONE, lambda x: x), (ops.ACT_RELU, torch.relu), (ops.ACT_TANH, torch.tanh)):
+        got = ops.gemm(ops.NT, dev(A), dev(W), M, N, K, bias=dev(b), act=act, tile=tile)
+        close(got, f(ref), 2e-5, f"act={act}")
+
+
+def test_gemm_nn_tn_accumulate_splitk(ops):
+    g = torch.Generator().manual_seed(3)
+    M, N, K = 200, 256, 384
+    A, Bm = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g) / K ** 0.5
+    close(ops.gemm(ops.NN, dev(A), dev(Bm), M, N, K), A.double() @ Bm.double(), 2e-5)
+    C0 = torch.randn(M, N, generator=g)
+    Cd = dev(C0.clone())
+    ops.gemm(ops.NN, dev(A), dev(Bm), M, N, K, C_out=Cd, accumulate=True)
+    close(Cd, C0.double() + A.double() @ Bm.double(), 2e-5)
+    # TN: dW = dY^T X with a long reduction dimension, with and without split-K (deterministic)
+    R, Mo, Ni = 5000, 256, 320
+    dY, X = torch.randn(R, Mo, generator=g), torch.randn(R, Ni, generator=g)
+    ref = dY.double().T @ X.double()
+    for sk in (1, 7, 16):
+        got = ops.gemm(ops.TN, dev(dY), dev(X), Mo, Ni, R, splitk=sk)
+        close(got, ref, 2e-5, f"splitk={sk}")
+        again = ops.gemm(ops.TN, dev(dY), dev(X), Mo, Ni, R, splitk=sk)
+        assert torch.equal(got, again), "split-K reduction must be bitwise reproducible"
+    acc = dev(torch.ones(Mo, Ni))
+    ops.gemm(ops.TN, dev(dY), dev(X), Mo, Ni, R, C_out=acc, splitk=5, accumulate=True)
+    close(acc, ref + 1, 2e-5)
+    # unaligned leading dimensions (fc_att backward: [rows,3])
+    dY3, X3 = torch.randn(130, 3, generator=g), torch.randn(130, 256, generator=g)
+    close(ops.gemm(ops.TN, dev(dY3), dev(X3), 3, 256, 130), dY3.double().T @ X3.double(), 2e-5)
+    W3 = torch.randn(3, 256, generator=g)
+    close(ops.gemm(ops.NN, dev(dY3), dev(W3), 130, 256, 3), dY3.double() @ W3.double(), 2e-5)
+
+
+def test_gemm_grouped_strided_and_dropout(ops):
+    from oracle import philox
+    from sdumc_amd._lib import make_dropout
+    g = torch.Generator().manual_seed(5)
+    V, Dm = 24, 256
+    xs = [torch.randn(V, Dm, generator=g) for _ in range(3)]
+    Ws = [torch.randn(Dm, Dm, generator=g) / 16 for _ in range(3)]
+    bs = [torch.randn(Dm, generator=g) for _ in range(3)]
+    out = torch.zeros(V, 3 * Dm).cuda()
+    seed, call = 77, 4
+    cd = make_dropout(True, 7, 0.3, 1, Dm, 12, sample0=2, call0=call, seed=seed)  # 2 streams x 12 samples
+    ops.gemm(ops.NT, [dev(x) for x in xs], [dev(w) for w in Ws], V, Dm, Dm, bias=[dev(b) for b in bs],
+             C_out=[out[:, m * Dm:] for m in range(3)], ldc=3 * Dm, act=ops.ACT_RELU, c_drop=cd, c_drop_group_stride=2)
+    for m in range(3):
+        mask = np.concatenate([philox.dropout_mask(12, 1, Dm, 0.3, seed, call + s, 7 + 2 * m, 2) for s in range(2)])
+        ref = torch.relu(xs[m].double() @ Ws[m].double().T + bs[m].double()) * torch.from_numpy(mask.reshape(V, Dm)).double()
+        close(out[:, m * Dm:(m + 1) * Dm], ref, 2e-5, f"group {m}")
+
+
+def test_gemm_fused_input_dropout_and_row_mod(ops):
+    """K = tanh(drop(x) W^T + b) with both streams sharing x (a_row_mod), and dW = dz^T drop(x) (TN b_drop)."""
+    from oracle import philox
+    from sdumc_amd._lib import make_dropout
+    g = torch.Generator().manual_seed(8)
+    B, T, Dm, S = 3, 37, 256, 2
+    x = torch.randn(B, T, Dm, generator=g)
+    W, b = torch.randn(Dm, Dm, generator=g) / 16, torch.randn(Dm, generator=g)
+    seed, call, site = 4242, 10, 21
+    ad = make_dropout(True, site, 0.5, T, Dm, B, call0=call, seed=seed)
+    got = ops.gemm(ops.NT, dev(x), dev(W), S * B * T, Dm, Dm, bias=dev(b), act=ops.ACT_TANH, a_row_mod=B * T, a_drop=ad)
+    masks = np.concatenate([philox.dropout_mask(B, T, Dm, 0.5, seed, call + s, site) for s in range(S)])
+    xd = torch.cat([x, x]).double() * torch.from_numpy(masks).double()
+    close(got, torch.tanh(xd.reshape(-1, Dm) @ W.double().T + b.double()), 2e-5)
+    dz = torch.randn(S * B * T, Dm, generator=g)
+    gw = ops.gemm(ops.TN, dev(dz), dev(x), Dm, Dm, S * B * T, b_row_mod=B * T, b_drop=ad, splitk=3)
+    close(gw, dz.double().T @ xd.reshape(-1, Dm), 2e-5)
+
+
+def _attn_ref(x, W, b, q, xmask, omask, dtype=torch.float64):
+    xd = (x * xmask).to(dtype)
+    keys = torch.tanh(xd @ W.to(dtype).T + b.to(dtype))
+    s = 0.3 * keys @ q.to(dtype).transpose(1, 2)
+    a = torch.softmax(s, dim=1)
+    pooled = a.transpose(1, 2) @ xd
+    return pooled * omask.to(dtype), a, pooled, keys
+
+
+@pytest.mark.parametrize("nq,T,shared_q", [(7, 37, False), (1, 5, True), (7, 130, False), (1, 375, True)])
+def test_attnpool_fwd_bwd(ops, nq, T, shared_q):
+    from oracle import philox
+    from sdumc_amd._lib import make_dropout
+    g = torch.Generator().manual_seed(nq * 100 + T)
+    B, S, Dm = 3, 2, 256
+    V = B * S
+    x = torch.randn(B, T, Dm, generator=g)
+    W, b = torch.randn(Dm, Dm, generator=g) / 16, torch.randn(Dm, generator=g) * 0.1
+    q = torch.randn(1 if shared_q else V, nq, Dm, generator=g) / 4
+    seed, call = 31, 6
+    xdrop = make_dropout(True, 23, 0.5, T, Dm, B, call0=call, seed=seed)
+    odrop = make_dropout(True, 24, 0.5, nq, Dm, B, call0=call, seed=seed)
+    xm = torch.from_numpy(np.concatenate([philox.dropout_mask(B, T, Dm, 0.5, seed, call + s, 23) for s in range(S)]))
+    om = torch.from_numpy(np.concatenate([philox.dropout_mask(B, nq, Dm, 0.5, seed, call + s, 24) for s in range(S)]))
+    xx = torch.cat([x] * S).double().requires_grad_()
+    Wd, bd, qd = W.double().requires_grad_(), b.double().requires_grad_(), q.double().requires_grad_()
+    out_ref, a_ref, pooled_ref, keys_ref = _attn_ref(xx, Wd, bd, qd.expand(V, nq, Dm), xm, om)
+    # HIP: keys from the fused GEMM, then the pooling kernels
+    xg = dev(x)
+    keys = ops.gemm(ops.NT, xg, dev(W), V * T, Dm, Dm, bias=dev(b), act=ops.ACT_TANH, a_row_mod=B * T,
+                    a_drop=xdrop).view(V, T, Dm)
+    qg = dev(q)
+    out, attn, pooled, desc = ops.attnpool_fwd(xg, keys, qg, nq, x_samples=B, q_shared=shared_q, x_drop=xdrop,
+                                               out_drop=odrop)
+    close(keys, keys_ref, 2e-5)
+    close(attn, a_ref, 2e-5)
+    close(pooled, pooled_ref, 2e-5)
+    close(out, out_ref, 2e-5)
+    np.testing.assert_allclose(attn.sum(1).cpu().numpy(), 1.0, rtol=1e-5)
+    # backward
+    dout = torch.randn(V, nq, Dm, generator=g)
+    out_ref.backward(dout.double())
+    dz, dxd, dq = ops.attnpool_bwd(desc, dev(dout), (xg, keys, qg))
+    # dW, db through the key projection; dxd total = pooling path + dz W
+    gw = ops.gemm(ops.TN, dz.view(-1, Dm), xg, Dm, Dm, V * T, b_row_mod=B * T, b_drop=xdrop, splitk=2)
+    close(gw, Wd.grad, 1e-4)
+    close(ops.colsum(dz.view(-1, Dm)), bd.grad, 1e-4)
+    ops.gemm(ops.NN, dz.view(-1, Dm), dev(W), V * T, Dm, Dm, C_out=dxd.view(-1, Dm), accumulate=True)
+    close(dxd * xm.cuda(), xx.grad, 1e-4)
+    dq_ref = qd.grad
+    close(dq.sum(0, keepdim=True) if shared_q else dq, dq_ref, 1e-4)
+
+
+def test_losses_against_reference_goldens(ops, golden):
+    g = golden("losses")
+    T = lambda k: dev(torch.from_numpy(g[k]))
+    loss, dp = ops.mse_fwd_bwd(T("mse_pred"), T("mse_tgt"))
+    close(loss, g["mse"].reshape(1), 1e-6)
+    close(dp, g["mse_dpred"], 1e-6)
+    for tag in ("2d", "3d"):
+        loss, da, db = ops.rmse_fwd_bwd(T(f"rmse{tag}_a"), T(f"rmse{tag}_b"))
+        close(loss, g[f"rmse{tag}"].reshape(1), 1e-6)
+        close(da, g[f"rmse{tag}_da"], 1e-5)
+        close(db, g[f"rmse{tag}_db"], 1e-5)
+    for tag in ("rnc", "rnctie"):
+        f = torch.from_numpy(g[f"{tag}_f"])
+        feats = dev(torch.cat([f[:, 0], f[:, 1]], dim=0))
+        y2 = dev(torch.from_numpy(g[f"{tag}_y"]).repeat(2, 1).reshape(-1))
+        loss, df, ws = ops.rnc_fwd_bwd(feats, y2)
+        close(loss, g[tag].reshape(1), 1e-5)
+        B = f.shape[0]
+        want = np.concatenate([g[f"{tag}_df"][:, 0], g[f"{tag}_df"][:, 1]], axis=0)
+        close(df, want, 1e-4)
+        np.testing.assert_array_equal(ops.rnc_mask(y2).cpu().numpy(), g[f"{tag}_mask"])   # bit-exact membership
+        # a data-parallel rank owns two row ranges of the gathered matrix
+        part = ops.rnc_dfeat_rows(feats, ws, B, B)
+        close(part, want[B:], 1e-4)
+
+
+def test_rnc_large_matches_oracle(ops):
+    from oracle import sdumc_oracle as O
+    g = torch.Generator().manual_seed(2)
+    B = 48
+    f = torch.randn(B, 2, 64, generator=g).requires_grad_()
+    y = (torch.rand(B, 1, generator=g) * 6 - 3).round(decimals=1)   # many ties
+    l = O.rnc_loss(f, y)
+    l.backward()
+    feats = dev(torch.cat([f[:, 0], f[:, 1]], dim=0).detach())
+    loss, df, _ = ops.rnc_fwd_bwd(feats, dev(y.repeat(2, 1).reshape(-1)), weight=0.8)
+    close(loss, l.detach().reshape(1), 1e-5)
+    close(df, 0.8 * torch.cat([f.grad[:, 0], f.grad[:, 1]]), 1e-4)
+    np.testing.assert_array_equal(ops.rnc_mask(dev(y.repeat(2, 1).reshape(-1))).cpu().numpy(),
+                                  O.rnc_masks(y.repeat(2, 1)).numpy())
+
+
+def test_adam_matches_torch(ops):
+    g = torch.Generator().manual_seed(4)
+    n = 10007
+    p0 = torch.randn(n, generator=g)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([p], lr=1e-4, weight_decay=1e-5)
+    pd, m, v = dev(p0.clone()), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    hyper = torch.tensor([1e-4, 0, 0, 0]).cuda()
+    for step in range(4):
+        grad = torch.randn(n, generator=g)
+        p.grad = grad.clone()
+        opt.step()
+        ops.adam_step(pd, dev(grad), m, v, hyper)
+        close((pd.cpu() - p0) * 1e4, (p.detach() - p0) * 1e4, 1e-4, f"step {step}")
+    assert float(hyper[1]) == 4.0
