@@ -70,7 +70,7 @@ def _require_cuda(*tensors):
             raise _lib.SdumcError("expected contiguous float32 tensors")
 
 
-def make_dims(B, streams, Ta, Tv, Tt, dims, train, sample0=0):
+def make_dims(B, streams, Ta, Tv, Tt, dims, train, sample0=0, p_mlp=P_MLP):
     d = _lib.NetDims()
     d.B, d.streams, d.Ta, d.Tv = B, streams, Ta, Tv
     d.Tt[0] = Tt[0]
@@ -78,7 +78,7 @@ def make_dims(B, streams, Ta, Tv, Tt, dims, train, sample0=0):
     d.da, d.dt, d.dv = dims[0], dims[1], dims[2]
     d.train = 1 if train else 0
     d.sample0 = sample0
-    d.p_frame, d.p_mlp = P_FRAME, P_MLP
+    d.p_frame, d.p_mlp = P_FRAME, p_mlp
     return d
 
 
@@ -100,7 +100,7 @@ class RngState:
 class NetCall:
     """One network invocation (1 or 2 streams): owns workspace + outputs, supports backward."""
 
-    def __init__(self, flat_params, audio, texts, video, train, rng, sample0=0):
+    def __init__(self, flat_params, audio, texts, video, train, rng, sample0=0, p_mlp=P_MLP):
         texts = list(texts)
         _require_cuda(flat_params, audio, video, *texts)
         S = len(texts)
@@ -112,7 +112,7 @@ class NetCall:
                 raise _lib.SdumcError("text-slot inputs must share batch and width (SURVEY §8b: feat4 width == text width)")
         if video.shape[0] != B:
             raise _lib.SdumcError("batch mismatch")
-        self.dims = make_dims(B, S, Ta, Tv, [t.shape[1] for t in texts], (da, dt, dv), train, sample0)
+        self.dims = make_dims(B, S, Ta, Tv, [t.shape[1] for t in texts], (da, dt, dv), train, sample0, p_mlp)
         self.layout = ParamLayout.get(da, dt, dv)
         if flat_params.numel() != self.layout.total:
             raise _lib.SdumcError("flat parameter buffer has the wrong size")

@@ -297,9 +297,28 @@ def gen_collate(out):
     np.savez_compressed(os.path.join(out, "collate.npz"), **d)
 
 
+def gen_init(ref_model, out):
+    """state_dict of the reference right after `torch.manual_seed(0); Model(args)`: names, shapes,
+    registration order and a digest per tensor (pins the drop-in module's initialisation stream)."""
+    import contextlib
+    import io
+    dims = (48, 32, 40, 32)
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = ref_model.WengnetMOSEIMultViewsTextMissing(types.SimpleNamespace(input_dims=dims))
+    names = [k for k, _ in net.named_parameters()]
+    sd = net.state_dict()
+    assert list(sd) == names
+    np.savez_compressed(os.path.join(out, "init.npz"), dims=np.array(dims), names=np.array(names),
+                        shapes=np.array([list(sd[k].shape) + [0] * (2 - sd[k].dim()) for k in names]),
+                        digest=np.stack([digest(sd[k], k) for k in names]),
+                        fc_att_weight=np32(sd["fc_att.weight"]), ctx0=np32(sd["fra2utt_0.attention_context_vector"]))
+
+
 def main():
     torch.set_num_threads(4)
     ref_model, ref_loss = load_reference()
+    gen_init(ref_model, HERE)
     gen_blocks(ref_model, HERE)
     gen_forward(ref_model, HERE)
     gen_losses(ref_loss, HERE)

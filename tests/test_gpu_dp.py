@@ -1,0 +1,59 @@
+"""GPU: the HIP backend of the data-parallel trainer, two ranks simulated in one process (the
+collectives are replaced by explicit sums/concats): shard gradients summed == full-batch gradient,
+post-Adam parameters identical to the single-GPU fused step."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_simulated_ranks_equal_full_batch():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import sdumc_oracle as O
+    from sdumc_amd import engine
+    from sdumc_amd.trainer import HipBackend
+    dims, Tn, B, W, seed = (64, 32, 48, 32), (70, 6, 30, 5), 4, 2, 99
+    weights = engine.DEFAULT_WEIGHTS
+    P = O.init_params(dims, seed=3)
+    lay = engine.ParamLayout.get(*dims[:3])
+
+    def flat():
+        f = torch.zeros(lay.total)
+        for k, v in lay.views(f).items():
+            v.copy_(P[k])
+        return f.cuda()
+
+    gb = [t.cuda() for t in O.synthetic_batch(B * W, Tn, dims, seed=8)]
+    full_p = flat()
+    ts = engine.TrainStep(full_p, B * W, Tn, dims, weights=weights, seed=seed)
+    ts.set_batch(*gb)
+    ref_losses = ts.run().cpu().clone()
+    ref_grads = ts.grads.clone()
+
+    bes = []
+    for r in range(W):
+        be = HipBackend(flat(), B, Tn, dims, weights, 1e-4, (0.9, 0.999), 1e-8, 1e-5, seed, r * B, B * W)
+        be.set_batch(*[t[r * B:(r + 1) * B].contiguous() for t in gb])
+        bes.append(be)
+    rncs = [be.forward().clone() for be in bes]
+    ssd = sum(be.local_ssd().clone() for be in bes)                                   # all-reduce
+    feats = torch.cat([p[:B] for p in rncs] + [p[B:] for p in rncs]).contiguous()     # all-gather + reorder
+    lab = torch.cat([be.labels for be in bes])
+    labels2 = torch.cat([lab, lab]).contiguous()
+    ls = [be.loss_backward(ssd, feats, labels2, (r * B, W * B + r * B)).cpu().clone() for r, be in enumerate(bes)]
+    gsum = sum(be.backward().clone() for be in bes)                                   # gradient all-reduce
+    np.testing.assert_allclose(gsum.cpu().numpy(), ref_grads.cpu().numpy(), rtol=2e-3, atol=2e-6)
+    # global loss terms: MSE entries are local sums / B_global; RMSE and RnC are global already
+    np.testing.assert_allclose((ls[0][1:3] + ls[1][1:3]).numpy(), ref_losses[1:3].numpy(), rtol=1e-5)
+    np.testing.assert_allclose(ls[0][3:7].numpy(), ref_losses[3:7].numpy(), rtol=1e-5)
+    np.testing.assert_allclose(ls[1][3:7].numpy(), ref_losses[3:7].numpy(), rtol=1e-5)
+    for be in bes:
+        be.grads.copy_(gsum)
+        be.adam(1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(bes[0].params, bes[1].params)
+    np.testing.assert_allclose(((bes[0].params - flat()) * 1e4).cpu().numpy(), ((full_p - flat()) * 1e4).cpu().numpy(),
+                               rtol=2e-2, atol=2e-2)
+    assert bes[0].rng.call == 2
