@@ -105,19 +105,34 @@ def cpu_baseline_leg(steps=3):
         cores = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    torch.set_num_threads(cores)
     P = O.init_params(DIMS, seed=0)
     batch = O.synthetic_batch(B_PER_GPU, T_MOSEI, DIMS, seed=1234)
     state = {}
-    O.train_step(P, state, *batch, mode="native", step=0)        # warm-up
-    best = float("inf")
-    for i in range(steps):
-        t0 = time.perf_counter()
-        O.train_step(P, state, *batch, mode="native", step=i + 1)
-        best = min(best, time.perf_counter() - t0)
-    return {"value": round(B_PER_GPU / best, 2), "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": f"{steps} train steps (best-of) of the same B={B_PER_GPU} MOSEI-shaped batch after 1 warm-up, "
-                      f"torch {torch.__version__} eager fp32, {torch.get_num_threads()} threads",
+    # torch eager does not scale to all hardware threads on this op mix (measured on the 2x64-core GPU
+    # host: 8-16 threads ~88 samples/s, 64 threads 49, 256 threads 0.3): probe a few thread counts,
+    # bounded to ~30 s in total, and report the best one together with the thread count it used.
+    budget_end = time.perf_counter() + 30.0
+    best, best_threads, step_idx, tried = float("inf"), 0, 0, []
+    for n in sorted({t for t in (8, 16, 32, 64) if t <= cores} or {cores}):
+        if time.perf_counter() > budget_end:
+            break
+        torch.set_num_threads(n)
+        O.train_step(P, state, *batch, mode="native", step=step_idx)        # warm-up at this thread count
+        step_idx += 1
+        mine = float("inf")
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            O.train_step(P, state, *batch, mode="native", step=step_idx)
+            step_idx += 1
+            mine = min(mine, time.perf_counter() - t0)
+            if time.perf_counter() > budget_end:
+                break
+        tried.append((n, round(B_PER_GPU / mine, 1)))
+        if mine < best:
+            best, best_threads = mine, n
+    return {"value": round(B_PER_GPU / best, 2), "unit": "samples/s", "cores": best_threads, "kind": "port",
+            "sample": f"best of <= {steps} train steps per thread count of the same B={B_PER_GPU} MOSEI-shaped batch, "
+                      f"torch {torch.__version__} eager fp32; (threads, samples/s) tried: {tried}; host has {cores} hw threads",
             "sec_per_step": round(best, 4)}
 
 

@@ -88,8 +88,11 @@ typedef struct sdumc_gemm {
   sdumc_dropout c_drop; /* epilogue dropout on C (rows = m, cols = n) */
   int32_t c_drop_group_stride; /* group g uses site c_drop.site + g * stride (grouped MLPs) */
   int32_t accumulate;   /* C += result (requires act none, no c_drop, no bias) */
-  int32_t splitk;       /* >1: K split over workgroups, fp32 slabs in `workspace`, deterministic reduce */
+  int32_t splitk;       /* 0: auto (tile + split chosen to fill 256 CUs); 1: no split; >1: K split over workgroups.
+                           Split results go through fp32 slabs in `workspace` and an ordered, deterministic reduce */
   int32_t tile;         /* 0 auto, 1 = 128x128, 2 = 64x64 */
+  float* colsum_a[SDUMC_MAX_GROUPS]; /* TN only, optional: out[m] (+)= sum_k A[k,m] fused into the staging of A
+                           (the bias gradient when A = dz); `accumulate` applies to it too */
   float* workspace;
   size_t workspace_bytes;
 } sdumc_gemm;

@@ -323,6 +323,7 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
     sc = std::max<int64_t>(sc, (int64_t)((p.rows[m] + 511) / 512 + 1) * D);
   }
   sc = std::max<int64_t>(sc, (int64_t)8 * 4 * D * NQ * H);  // grouped utterance-level split-K upper bound
+  sc = std::max<int64_t>(sc, (int64_t)13 << 20);            // auto split-K: <= ~(320 + tiles) slabs of 64 KiB
   p.scratch_floats = sc;
   p.scratch = p.alloc(sc);
   return true;
@@ -371,7 +372,6 @@ sdumc_gemm G_(int layout, int M, int N, int K, int groups = 1) {
 int run(const Ctx& c, sdumc_gemm& g) {
   g.workspace = c.p(c.pl.scratch);
   g.workspace_bytes = (size_t)c.pl.scratch_floats * sizeof(float);
-  while (g.splitk > 1 && sdumc_gemm_workspace_bytes(&g) > g.workspace_bytes) --g.splitk;
   return sdumc_gemm_f32(&g, c.st);
 }
 
@@ -406,9 +406,8 @@ int lin_bwd(const Ctx& c, const Lin& L, const float* dzv, int lddz, const float*
   gw.ldb = ldx;
   gw.C[0] = c.G + L.w;
   gw.ldc = L.in;
-  gw.splitk = pick_splitk(L.out, L.in, M, 1);
+  gw.colsum_a[0] = c.G + L.b;   // db rides along with the staging of dz
   RET(run(c, gw));
-  RET(colsum(c, dzv, M, L.out, lddz, c.G + L.b, 0));
   if (dx) {
     sdumc_gemm gx = G_(SDUMC_NN, M, L.in, L.out);
     gx.A[0] = dzv;
@@ -436,6 +435,7 @@ int lin_bwd_grouped(const Ctx& c, const Lin* L, int ng, int M, const GroupPtrs& 
     gw.A[g] = q.dz + g * q.dz_gs;
     gw.B[g] = q.x + g * q.x_gs;
     gw.C[g] = c.G + L[g].w;
+    gw.colsum_a[g] = c.G + L[g].b;
     gx.A[g] = q.dz + g * q.dz_gs;
     gx.B[g] = c.P + L[g].w;
     gx.C[g] = q.dx ? q.dx + g * q.dx_gs : nullptr;
@@ -443,9 +443,7 @@ int lin_bwd_grouped(const Ctx& c, const Lin* L, int ng, int M, const GroupPtrs& 
   gw.lda = q.lddz;
   gw.ldb = q.ldx;
   gw.ldc = L[0].in;
-  gw.splitk = pick_splitk(L[0].out, L[0].in, M, ng);
   RET(run(c, gw));
-  for (int g = 0; g < ng; ++g) RET(colsum(c, q.dz + g * q.dz_gs, M, L[g].out, q.lddz, c.G + L[g].b, 0));
   if (q.dx) {
     gx.lda = q.lddz;
     gx.ldb = L[0].in;
@@ -673,12 +671,11 @@ int keys_bwd(const Ctx& c, int k, int m, const float* dout_base /* [V, nq, D] */
     g.b_drop = mkdrop(c, SITE_IN[k][m], c.d.p_frame, sg.T, D, sg.s0);
     g.C[0] = c.G + L.w;
     g.ldc = D;
+    g.colsum_a[0] = c.G + L.b;
     g.accumulate = first ? 0 : 1;
-    g.splitk = pick_splitk(D, D, rows, 1);
     RET(run(c, g));
     first = false;
   }
-  RET(colsum(c, dz, pl.rows[m], D, D, c.G + L.b, 0));
   // dxd += dz W (the key-projection path joins the pooling path)
   sdumc_gemm g = G_(SDUMC_NN, (int)pl.rows[m], D, D);
   g.A[0] = dz;
@@ -741,12 +738,11 @@ int backward(const Ctx& c, const sdumc_net_grads& og) {
       gw.A[m] = c.p(pl.d_qp) + (int64_t)m * M * D;
       gw.B[m] = c.p(pl.q);
       gw.C[m] = c.G + pm.ca_q[m].w;
+      gw.colsum_a[m] = c.G + pm.ca_q[m].b;
     }
     gw.lda = gw.ldb = gw.ldc = D;
-    gw.splitk = pick_splitk(D, D, M, 3);
     RET(run(c, gw));
     for (int m = 0; m < 3; ++m) {
-      RET(colsum(c, c.p(pl.d_qp) + (int64_t)m * M * D, M, D, D, c.G + pm.ca_q[m].b, 0));
       sdumc_gemm gx = G_(SDUMC_NN, M, D, D);
       gx.A[0] = c.p(pl.d_qp) + (int64_t)m * M * D;
       gx.lda = D;
@@ -820,10 +816,9 @@ int backward(const Ctx& c, const sdumc_net_grads& og) {
       g.ldb = din[m];
       g.C[0] = c.G + pm.frame[m].w;
       g.ldc = din[m];
+      g.colsum_a[0] = c.G + pm.frame[m].b;
       g.accumulate = s > 0;
-      g.splitk = pick_splitk(D, din[m], rows, 1);
       RET(run(c, g));
-      RET(colsum(c, c.p(pl.dx[m][s]), rows, D, D, c.G + pm.frame[m].b, s > 0));
     }
   return SDUMC_OK;
 }

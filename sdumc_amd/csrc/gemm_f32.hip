@@ -19,6 +19,7 @@
 //   * fusions: dropout (Philox, recomputed, never stored) on the staged A (NT/NN) or B (TN) operand,
 //     source-row modulo (the two streams share x_audio/x_video), bias + ReLU/tanh + dropout epilogue,
 //     accumulate, deterministic split-K (slabs + ordered reduce; no float atomics).
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -177,10 +178,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdumc_gemm g, const int
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // TN only: column sums of A (= the bias gradient when A is dz) ride along with the staging loads of
+  // the first n-tile: every A element passes through exactly one thread of those workgroups.
+  const bool do_cs = !A_K && g.colsum_a[grp] != nullptr && blockIdx.x == 0;
+  f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+
   f32x4 ra[BM / 32], rb[BN / 32];
   if (kbeg < kend) {
     load_tile<BM, A_K>(ra, ca, m0, g.M, kbeg, kend, tid);
     load_tile<BN, B_K>(rb, cb, n0, g.N, kbeg, kend, tid);
+    if (do_cs) {
+#pragma unroll
+      for (int j = 0; j < BM / 32; ++j) csum += ra[j];
+    }
   }
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     __syncthreads();  // everyone is done reading the previous tile
@@ -190,6 +200,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdumc_gemm g, const int
     if (k0 + BK < kend) {  // prefetch: in flight during the MFMAs below
       load_tile<BM, A_K>(ra, ca, m0, g.M, k0 + BK, kend, tid);
       load_tile<BN, B_K>(rb, cb, n0, g.N, k0 + BK, kend, tid);
+      if (do_cs) {
+#pragma unroll
+        for (int j = 0; j < BM / 32; ++j) csum += ra[j];
+      }
     }
 #pragma unroll
     for (int gq = 0; gq < BK / 8; ++gq) {
@@ -208,8 +222,26 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdumc_gemm g, const int
     }
   }
 
-  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
   const bool to_slab = nsplit > 1;
+  if (!A_K && g.colsum_a[grp] != nullptr && blockIdx.x == 0) {   // block-uniform
+    constexpr int Q = BM / 4, RP = 256 / Q;
+    __syncthreads();                                  // the last tile's fragment reads are done
+    *reinterpret_cast<f32x4*>(lds + (tid / Q) * BM + 4 * (tid % Q)) = csum;
+    __syncthreads();
+    if (tid < BM && m0 + tid < g.M) {
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < RP; ++r) sum += lds[r * BM + tid];
+      if (to_slab) {
+        g.workspace[(size_t)g.groups * nsplit * g.M * g.N + (size_t)blockIdx.z * g.M + m0 + tid] = sum;
+      } else {
+        float* dst = g.colsum_a[grp] + m0 + tid;
+        *dst = g.accumulate ? *dst + sum : sum;
+      }
+    }
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
   float* C = to_slab ? g.workspace + ((size_t)blockIdx.z) * (size_t)g.M * g.N : g.C[grp];
   const int ldc = to_slab ? g.N : g.ldc;
   const float* bias = to_slab ? nullptr : g.bias[grp];
@@ -243,7 +275,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const sdumc_gemm g, 
   const int grp = blockIdx.y;
   const size_t mn = (size_t)g.M * g.N;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= mn) return;
+  if (idx >= mn) {
+    const size_t m = idx - mn;                       // tail threads: the fused column sums
+    if (g.colsum_a[grp] != nullptr && m < (size_t)g.M) {
+      const float* cs = g.workspace + (size_t)g.groups * nsplit * mn + (size_t)grp * nsplit * g.M + m;
+      float v = 0.f;
+      for (int z = 0; z < nsplit; ++z) v += cs[(size_t)z * g.M];
+      float* dst = g.colsum_a[grp] + m;
+      *dst = g.accumulate ? *dst + v : v;
+    }
+    return;
+  }
   const float* s = g.workspace + (size_t)grp * nsplit * mn + idx;
   float v = 0.f;
   for (int z = 0; z < nsplit; ++z) v += s[(size_t)z * mn];
@@ -260,11 +302,50 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const sdumc_gemm g, 
   *dst = v;
 }
 
-int effective_splitk(const sdumc_gemm* g) {
-  int s = g->splitk > 1 ? g->splitk : 1;
-  const int ktiles = (g->K + BK - 1) / BK;
-  if (s > ktiles) s = ktiles;
-  return s < 1 ? 1 : s;
+struct GemmPlan {
+  int tile;    // 1 = 128x128, 2 = 64x64
+  int nsplit;
+  int kchunk;
+};
+
+size_t plan_ws_bytes(const sdumc_gemm& g, int nsplit) {
+  if (nsplit <= 1) return 0;
+  bool cs = false;
+  for (int i = 0; i < g.groups; ++i) cs |= g.colsum_a[i] != nullptr;
+  return ((size_t)nsplit * g.groups * (size_t)g.M * g.N + (cs ? (size_t)nsplit * g.groups * g.M : 0)) * sizeof(float);
+}
+
+// Tile and split-K choice (measured on MI355X, tools/gemm_bench.py, profiles/README.md):
+// the kernel core reaches ~110 TF at 4096^3 with either tile, but this path's shapes are skinny
+// (N = 256; M*N is at most 376 tiles of 128x128) and there the 64x64 tile wins clearly
+// (M=48000,K=256: 85 vs 56 TF; M=24000,K=1024: 91 vs 77 TF): four resident workgroups per CU hide each
+// other's prologue/epilogue and the dynamic dispatch balances the tail.  So: 64x64 unless the problem has
+// >= 8192 such tiles; split K until ~1024 workgroups (4 per CU) exist, but keep >= 6 k-tiles (K >= 192)
+// per workgroup -- below that the extra reduce launch costs more than the shorter k-loop saves.
+GemmPlan plan_gemm(const sdumc_gemm& g, size_t ws_bytes) {
+  GemmPlan p;
+  const int ktiles = (g.K + BK - 1) / BK;
+  const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.groups;
+  const long small = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * g.groups;
+  p.tile = g.tile ? g.tile : (small >= 8192 ? 1 : 2);
+  int s;
+  if (g.splitk >= 1) {                                   // explicit
+    s = std::min(g.splitk, ktiles);
+  } else {                                               // auto
+    const long tiles = p.tile == 1 ? big : small;
+    const long want = p.tile == 1 ? 512 : 1024;
+    const long smax = std::max(1, ktiles / 6);
+    s = tiles >= want ? 1 : (int)std::min<long>(smax, (want + tiles - 1) / tiles);
+    if (s < 1) s = 1;
+    while (s > 1 && plan_ws_bytes(g, s) > ws_bytes) --s;
+  }
+  p.nsplit = std::max(1, s);
+  p.kchunk = g.K;
+  if (p.nsplit > 1) {
+    p.kchunk = ((ktiles + p.nsplit - 1) / p.nsplit) * BK;
+    p.nsplit = (ktiles * BK + p.kchunk - 1) / p.kchunk;   // drop empty trailing splits
+  }
+  return p;
 }
 
 template <int BM, int BN>
@@ -282,10 +363,8 @@ int launch(const sdumc_gemm& g, int nsplit, int kchunk, hipStream_t st) {
 }  // namespace
 
 extern "C" size_t sdumc_gemm_workspace_bytes(const sdumc_gemm* g) {
-  if (!g) return 0;
-  const int s = effective_splitk(g);
-  if (s <= 1) return 0;
-  return (size_t)s * g->groups * (size_t)g->M * g->N * sizeof(float);
+  if (!g || g->M <= 0 || g->N <= 0 || g->K <= 0 || g->groups < 1) return 0;
+  return plan_ws_bytes(*g, plan_gemm(*g, (size_t)-1).nsplit);
 }
 
 extern "C" int sdumc_gemm_f32(const sdumc_gemm* gp, void* stream) {
@@ -299,19 +378,12 @@ extern "C" int sdumc_gemm_f32(const sdumc_gemm* gp, void* stream) {
   if ((g.a_drop.enabled && (g.a_drop.width & 3)) || (g.b_drop.enabled && (g.b_drop.width & 3)) ||
       (g.c_drop.enabled && (g.c_drop.width & 3)))
     return SDUMC_EINVAL;
-  const int nsplit = effective_splitk(&g);
-  int kchunk = g.K;
-  if (nsplit > 1) {
-    if (!g.workspace || g.workspace_bytes < sdumc_gemm_workspace_bytes(&g)) return SDUMC_ENOMEM;
-    const int ktiles = (g.K + BK - 1) / BK;
-    kchunk = ((ktiles + nsplit - 1) / nsplit) * BK;
-  }
+  for (int i = 0; i < g.groups; ++i)
+    if (g.colsum_a[i] && g.layout != SDUMC_TN) return SDUMC_EINVAL;
+  const GemmPlan pl = plan_gemm(g, g.workspace ? g.workspace_bytes : 0);
+  const int nsplit = pl.nsplit, kchunk = pl.kchunk, tile = pl.tile;
+  if (nsplit > 1 && (!g.workspace || g.workspace_bytes < plan_ws_bytes(g, nsplit))) return SDUMC_ENOMEM;
   hipStream_t st = as_stream(stream);
-  int tile = g.tile;
-  if (tile == 0) {
-    const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.groups * nsplit;
-    tile = big >= 96 ? 1 : 2;
-  }
   ProfRec rec;
   const bool prof = g_prof_on;
   if (prof) {
@@ -329,7 +401,7 @@ extern "C" int sdumc_gemm_f32(const sdumc_gemm* gp, void* stream) {
     g_prof.push_back(rec);
   }
   if (nsplit > 1) {
-    const size_t mn = (size_t)g.M * g.N;
+    const size_t mn = (size_t)g.M * g.N + (size_t)g.M;   // + M tail threads for the fused column sums
     dim3 grid((unsigned)((mn + 255) / 256), g.groups);
     hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, st, g, nsplit);
     SDUMC_CHECK_LAUNCH();

@@ -69,3 +69,33 @@ def test_product_path_never_imports_the_oracle():
         for f in files:
             if f.endswith(".py"):
                 assert "oracle" not in open(os.path.join(root, f)).read(), f
+
+
+def test_collate_matches_reference_golden(golden):
+    """sdumc_amd.data.collate reproduces pad_to_maxlen_pre_modality_tensor_4 + the batch tuple."""
+    import torch
+    from sdumc_amd.data import collate
+    g = golden("collate")
+    n = len(g["lens"])
+    inst = [{k: torch.from_numpy(g[f"raw_{k}_{b}"]) for k in ("audio", "text", "video", "feat4")} | {"emo": 0, "val": 0.5 * b, "name": f"u{b}"}
+            for b in range(n)]
+    batch, pads, emos, vals, names = collate(inst)
+    for k in ("audios", "texts", "videos", "feat4s"):
+        np.testing.assert_array_equal(batch[k].numpy(), g[k])
+    np.testing.assert_array_equal(np.array(pads), g["pads"])
+    assert names == ["u0", "u1", "u2"] and vals.tolist() == [0.0, 0.5, 1.0] and emos.shape == (n,)
+
+
+def test_schedule_and_metric(golden):
+    from sdumc_amd.schedule import warm_up_with_step_lr
+    from sdumc_amd.metric import eval_mosei_metric
+    np.testing.assert_allclose([warm_up_with_step_lr(e) for e in range(40)], golden("step")["lr_table"], rtol=1e-12)
+    from sklearn.metrics import f1_score, accuracy_score, mean_absolute_error
+    rs = np.random.RandomState(0)
+    y = np.round(rs.uniform(-3, 3, 200), 1); y[:10] = 0
+    p = y + rs.normal(0, 1.0, 200)
+    m = eval_mosei_metric(p, y)
+    nz = y != 0
+    np.testing.assert_allclose(m["mae"], mean_absolute_error(y, p))
+    np.testing.assert_allclose(m["acc2"], accuracy_score(y[nz] > 0, p[nz] > 0))
+    np.testing.assert_allclose(m["f1"], f1_score(y[nz] > 0, p[nz] > 0, average="weighted"))

@@ -77,6 +77,21 @@ def test_gemm_nn_tn_accumulate_splitk(ops):
     acc = dev(torch.ones(Mo, Ni))
     ops.gemm(ops.TN, dev(dY), dev(X), Mo, Ni, R, C_out=acc, splitk=5, accumulate=True)
     close(acc, ref + 1, 2e-5)
+    # fused column sums of A (the bias gradient), every split mode incl. auto (0), with accumulate
+    for sk in (0, 1, 6):
+        for tile in (1, 2):
+            cs = dev(torch.full((Mo,), 2.0))
+            acc = dev(torch.ones(Mo, Ni))
+            ops.gemm(ops.TN, dev(dY), dev(X), Mo, Ni, R, C_out=acc, splitk=sk, tile=tile, accumulate=True, colsum_a=cs)
+            close(acc, ref + 1, 2e-5, f"splitk={sk} tile={tile}")
+            close(cs, dY.double().sum(0) + 2, 2e-5, f"colsum splitk={sk} tile={tile}")
+    cs = torch.empty(3).cuda()
+    got = ops.gemm(ops.TN, dev(dY[:130, :3].contiguous()), dev(X[:130, :256].contiguous()), 3, 256, 130, splitk=0, colsum_a=cs)
+    close(cs, dY[:130, :3].double().sum(0), 2e-5)
+    # auto plan on forward shapes (split-K + bias/activation in the reduce)
+    A2, W2, b2 = torch.randn(2048, 4096, generator=g), torch.randn(256, 4096, generator=g) / 64, torch.randn(256, generator=g)
+    close(ops.gemm(ops.NT, dev(A2), dev(W2), 2048, 256, 4096, bias=dev(b2), act=ops.ACT_RELU, splitk=0),
+          torch.relu(A2.double() @ W2.double().T + b2.double()), 2e-5)
     # unaligned leading dimensions (fc_att backward: [rows,3])
     dY3, X3 = torch.randn(130, 3, generator=g), torch.randn(130, 256, generator=g)
     close(ops.gemm(ops.TN, dev(dY3), dev(X3), 3, 256, 130), dY3.double().T @ X3.double(), 2e-5)
