@@ -59,6 +59,10 @@ typedef struct sdumc_dropout {
   uint32_t seed_lo, seed_hi;
   const uint32_t* dev_state; /* optional device {seed_lo, seed_hi, call0}: lets a captured
                                 hipGraph draw fresh masks on every replay */
+  const uint8_t* bits;       /* optional keep-bits precomputed by sdumc_dropout_bits for exactly this row space:
+                                byte [row * width/4 + q], bit e = keep column 4q+e.  Kernels that stage the same
+                                tile several times (4 n-tiles of a GEMM, forward + backward) then read one byte
+                                instead of re-running Philox (~90 VALU ops per 4 elements) */
 } sdumc_dropout;
 
 /* ------------------------------------------------------------------------
@@ -125,8 +129,11 @@ typedef struct sdumc_attnpool {
   float* attn;         /* [V, T, nq]  softmax weights (returned by the reference, saved for backward) */
   float* pooled;       /* [V, nq, 256] O before the output dropout (saved for backward) */
   float* out;          /* [V, nq, 256] */
+  float* workspace;    /* >= sdumc_attnpool_fwd_workspace_bytes(V, T, nq): per-chunk softmax partials */
+  size_t workspace_bytes;
 } sdumc_attnpool;
 
+size_t sdumc_attnpool_fwd_workspace_bytes(int32_t V, int32_t T, int32_t nq);
 int sdumc_attnpool_fwd(const sdumc_attnpool* p, void* stream);
 
 /* backward of the above. Produces
@@ -254,6 +261,8 @@ int sdumc_copy2d(const float* src, int32_t ld_src, float* dst, int32_t ld_dst, i
 int sdumc_fill(float* p, float v, int64_t n, void* stream);
 /* device rng/step state helpers: state = {seed_lo, seed_hi, call0}; adds `inc` to call0 */
 int sdumc_rng_advance(uint32_t* dev_state, uint32_t inc, void* stream);
+/* keep-bits of a [streams*samples, rows, width] row space, one byte per 4 columns (see sdumc_dropout.bits) */
+int sdumc_dropout_bits(const sdumc_dropout* d, int32_t streams, uint8_t* bits, void* stream);
 /* writes the dropout mask values (0 or scale) of a [streams*samples, rows, width] tensor: test hook */
 int sdumc_dropout_mask(const sdumc_dropout* d, int32_t streams, float* mask, void* stream);
 const char* sdumc_version(void);

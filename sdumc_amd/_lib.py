@@ -22,7 +22,7 @@ class Dropout(C.Structure):
     _fields_ = [("enabled", C.c_uint32), ("site", C.c_uint32), ("threshold", C.c_uint32), ("scale", C.c_float),
                 ("rows", C.c_uint32), ("width", C.c_uint32), ("samples", C.c_uint32), ("sample0", C.c_uint32),
                 ("call0", C.c_uint32), ("stream0", C.c_uint32), ("seed_lo", C.c_uint32), ("seed_hi", C.c_uint32),
-                ("dev_state", C.c_void_p)]
+                ("dev_state", C.c_void_p), ("bits", C.c_void_p)]
 
 
 class Gemm(C.Structure):
@@ -43,7 +43,8 @@ class AttnPool(C.Structure):
     _fields_ = [("V", C.c_int32), ("T", C.c_int32), ("nq", C.c_int32), ("x_samples", C.c_int32),
                 ("x", C.c_void_p), ("keys", C.c_void_p), ("q", C.c_void_p), ("q_stride", C.c_int64),
                 ("scale", C.c_float), ("x_drop", Dropout), ("out_drop", Dropout),
-                ("attn", C.c_void_p), ("pooled", C.c_void_p), ("out", C.c_void_p)]
+                ("attn", C.c_void_p), ("pooled", C.c_void_p), ("out", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
 class AttnPoolBwd(C.Structure):
@@ -97,6 +98,7 @@ _SIGS = {
     "sdumc_profile_report": (C.c_int, [C.POINTER(ProfEntry), C.c_int]),
     "sdumc_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(Gemm)]),
     "sdumc_gemm_f32": (C.c_int, [C.POINTER(Gemm), C.c_void_p]),
+    "sdumc_attnpool_fwd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "sdumc_attnpool_fwd": (C.c_int, [C.POINTER(AttnPool), C.c_void_p]),
     "sdumc_attnpool_bwd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "sdumc_attnpool_bwd": (C.c_int, [C.POINTER(AttnPoolBwd), C.c_void_p]),
@@ -128,6 +130,7 @@ _SIGS = {
     "sdumc_axpy2d": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sdumc_fill": (C.c_int, [C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
     "sdumc_rng_advance": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
+    "sdumc_dropout_bits": (C.c_int, [C.POINTER(Dropout), C.c_int32, C.c_void_p, C.c_void_p]),
     "sdumc_dropout_mask": (C.c_int, [C.POINTER(Dropout), C.c_int32, C.c_void_p, C.c_void_p]),
     "sdumc_version": (C.c_char_p, []),
     # network level (engine.hip)

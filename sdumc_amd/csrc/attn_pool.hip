@@ -10,172 +10,270 @@
 // xd = dropout(x) is never materialised: the Philox mask is recomputed from
 // (seed, call, site, sample, t, channel) wherever xd is needed.
 //
-// These are HBM/L2-streaming kernels (4*T*D*nq flops against a T*D tile): rows are
-// read as whole 1-KiB lines (one 16-B load per lane), dot products reduce with
-// wave64 shuffles, the softmax statistics live in LDS.
+// Structure (MI355X-first): the work is a stream over [V*T] rows of 1 KiB, so the grid is
+// (64-row chunk, v) -- hundreds of workgroups instead of one per sample -- and the softmax is
+// flash-style: every chunk produces (max, sum, unnormalised pooled partial), a tiny per-v kernel
+// combines the chunks and normalises the stored weights.  The row x query products (scores in the
+// forward, dA = xd . dO^T in the backward) are [rows,256] x [256,<=8] contractions: they run on the
+// matrix cores as v_mfma_f32_16x16x4_f32 (queries padded to 16 columns) instead of 64-lane shuffle
+// reductions; the [rows] x [channels] parts stay on the VALU with one 16-B access per lane per row.
+// No float atomics: partials are reduced in a fixed order (bitwise reproducible).
 #include "common.h"
 
 namespace {
 
 constexpr int D = SDUMC_D;       // 256 channels = 64 lanes x 4
 constexpr int MAXQ = 8;
-constexpr int ROWS_PER_WG = 64;  // rows of one v handled by a 4-wave workgroup in the row kernels
+constexpr int CH = 64;           // rows of one v handled by a 4-wave workgroup (16 per wave)
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
 
-// ---- forward pass 1: scaled scores S -> attn buffer ------------------------------------------
-__global__ __launch_bounds__(256) void scores_kernel(const sdumc_attnpool p) {
-  const int v = blockIdx.y;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  f32x4 q[MAXQ];
-#pragma unroll
-  for (int i = 0; i < MAXQ; ++i)
-    if (i < p.nq) q[i] = ld4(p.q + (size_t)v * p.q_stride + (size_t)i * D + 4 * lane);
-  const int t0 = blockIdx.x * ROWS_PER_WG;
-  for (int r = wave; r < ROWS_PER_WG; r += 4) {
-    const int t = t0 + r;
-    if (t >= p.T) break;
-    const f32x4 k = ld4(p.keys + ((size_t)v * p.T + t) * D + 4 * lane);
-    float mine = 0.f;
-#pragma unroll
-    for (int i = 0; i < MAXQ; ++i)
-      if (i < p.nq) {
-        const float s = wave_sum(dot4(k, q[i]));
-        if (lane == i) mine = s;
-      }
-    if (lane < p.nq) p.attn[((size_t)v * p.T + t) * p.nq + lane] = p.scale * mine;
-  }
+// workspace layout of the forward: part [V][nchunk][nq][256], then stats [V][nchunk][2][MAXQ]
+struct FwdWs {
+  float* part;
+  float* stats;
+};
+__host__ __device__ inline FwdWs fwd_ws(float* w, int V, int nchunk, int nq) {
+  FwdWs r;
+  r.part = w;
+  r.stats = w + (size_t)V * nchunk * nq * D;
+  return r;
 }
 
-// ---- forward pass 2: softmax over T (per query) + pooling + output dropout ---------------------
-// one workgroup per virtual sample; dynamic LDS: attn [T*nq] floats + reduction scratch
-__global__ __launch_bounds__(256) void softmax_pool_kernel(const sdumc_attnpool p) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* a_s = smem;                        // [T][nq]
-  float* red = smem + (size_t)p.T * p.nq;   // [4][MAXQ][256] for the cross-wave pooling reduce
-  const int v = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int T = p.T, nq = p.nq;
-  float* attn = p.attn + (size_t)v * T * nq;
-  for (int e = tid; e < T * nq; e += 256) a_s[e] = attn[e];
-  __syncthreads();
-  // softmax statistics: wave w owns queries w, w+4
-  for (int i = wave; i < nq; i += 4) {
-    float m = -INFINITY;
-    for (int t = lane; t < T; t += 64) m = fmaxf(m, a_s[t * nq + i]);
-    m = wave_max(m);
-    float l = 0.f;
-    for (int t = lane; t < T; t += 64) {
-      const float e = expf(a_s[t * nq + i] - m);
-      a_s[t * nq + i] = e;
-      l += e;
+// [16 rows of this wave] x [16 query columns] = sum over 256 channels, on the matrix cores.
+// A operand: lane (r = lane&15, kk = lane>>4) supplies rows[r][16 j + 4 kk + e]; B operand: the same
+// channel of column r.  `rowp` = this lane's row pointer (or nullptr), bq[j] = this lane's B fragments.
+// The B side lives in LDS as [MAXQ][LDQ] (LDQ = 272: rows 16 banks apart -> at most 2-way conflicts).
+constexpr int LDQ = D + 16;
+template <bool DROP>
+__device__ __forceinline__ f32x4 rows_times_cols(const float* rowp, const float* b_lds, const DropRT& d,
+                                                 uint32_t vrow, int r16, int kk) {
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+  for (int j = 0; j < 16; ++j) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f}, bq = {0.f, 0.f, 0.f, 0.f};
+    if (rowp) {
+      a = ld4(rowp + 16 * j + 4 * kk);
+      if (DROP) a *= drop_mask4(d, vrow, (uint32_t)(4 * j + kk));
     }
-    l = wave_sum(l);
-    const float inv = 1.f / l;
-    for (int t = lane; t < T; t += 64) a_s[t * nq + i] *= inv;
+    if (r16 < MAXQ) bq = ld4(b_lds + r16 * LDQ + 16 * j + 4 * kk);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bq[e], acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// ---- forward, pass 1: one workgroup per (chunk of 64 rows, v) -----------------------------------
+__global__ __launch_bounds__(256, 2) void attn_fwd_partial_kernel(const sdumc_attnpool p, float* ws, const int nchunk) {
+  __shared__ __attribute__((aligned(16))) float P_s[CH * MAXQ];
+  __shared__ __attribute__((aligned(16))) float red[4 * MAXQ * D];   // first the query tile, later the pooling reduce
+  __shared__ float wstat[4][16];
+  __shared__ float cstat[16];
+  const int chunk = blockIdx.x, v = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, kk = lane >> 4;
+  const int T = p.T, nq = p.nq;
+  const int t0 = chunk * CH;
+  const FwdWs w = fwd_ws(ws, p.V, nchunk, nq);
+
+  // scores of this wave's 16 rows against the (<= 8) queries
+  float* q_s = red;
+  for (int e = tid; e < MAXQ * (D / 4); e += 256) {
+    const int i = e / (D / 4), cq = e - i * (D / 4);
+    st4(q_s + i * LDQ + 4 * cq, i < nq ? ld4(p.q + (size_t)v * p.q_stride + (size_t)i * D + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f});
   }
   __syncthreads();
-  for (int e = tid; e < T * nq; e += 256) attn[e] = a_s[e];
-
-  // pooling: wave w takes rows t = w, w+4, ...; lane owns channels 4*lane..4*lane+3
+  const int myrow = t0 + 16 * wave + r16;
+  const DropRT nodrop = {};
+  const f32x4 s4 = rows_times_cols<false>(myrow < T ? p.keys + ((size_t)v * T + myrow) * D : nullptr, q_s, nodrop, 0u, r16, kk);
+  // C layout: column (query) = lane & 15, rows = 16 wave + 4 (lane >> 4) + e
+  float s[4], mx = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int t = t0 + 16 * wave + 4 * kk + e;
+    s[e] = t < T ? p.scale * s4[e] : -INFINITY;
+    mx = fmaxf(mx, s[e]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  if (lane < 16) wstat[wave][lane] = mx;
+  __syncthreads();
+  if (tid < 16) cstat[tid] = fmaxf(fmaxf(wstat[0][tid], wstat[1][tid]), fmaxf(wstat[2][tid], wstat[3][tid]));
+  __syncthreads();
+  const float mc = cstat[r16];          // chunk max of my query column (finite: every chunk has >= 1 row)
+  float lsum = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int rl = 16 * wave + 4 * kk + e, t = t0 + rl;
+    const float pe = t < T ? expf(s[e] - mc) : 0.f;
+    lsum += pe;
+    if (r16 < MAXQ) P_s[rl * MAXQ + r16] = pe;
+    if (r16 < nq && t < T) p.attn[((size_t)v * T + t) * nq + r16] = pe;   // normalised by the combine kernel
+  }
+  lsum += __shfl_xor(lsum, 16, 64);
+  lsum += __shfl_xor(lsum, 32, 64);
+  __syncthreads();                      // cstat reads done, P_s complete
+  if (lane < 16) wstat[wave][lane] = lsum;
+  __syncthreads();
+  if (tid < nq) {
+    float* st = w.stats + ((size_t)v * nchunk + chunk) * 2 * MAXQ;
+    st[tid] = cstat[tid];
+    st[MAXQ + tid] = wstat[0][tid] + wstat[1][tid] + wstat[2][tid] + wstat[3][tid];
+  }
+  // unnormalised pooling of this chunk: lane owns channels 4*lane..4*lane+3, wave owns 16 rows
   const DropRT xd = drop_resolve(p.x_drop);
   const int vx = v % p.x_samples;
-  const float* xrow = p.x + (size_t)vx * T * D + 4 * lane;
   f32x4 acc[MAXQ];
 #pragma unroll
   for (int i = 0; i < MAXQ; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int t = wave; t < T; t += 4) {
-    f32x4 x = ld4(xrow + (size_t)t * D);
+#pragma unroll 1
+  for (int r = 0; r < 16; ++r) {
+    const int rl = 16 * wave + r, t = t0 + rl;
+    if (t >= T) break;
+    f32x4 x = ld4(p.x + ((size_t)vx * T + t) * D + 4 * lane);
     if (xd.enabled) x *= drop_mask4(xd, (uint32_t)(v * T + t), (uint32_t)lane);
 #pragma unroll
     for (int i = 0; i < MAXQ; ++i)
-      if (i < nq) acc[i] += x * a_s[t * nq + i];
+      if (i < nq) acc[i] += x * P_s[rl * MAXQ + i];
   }
 #pragma unroll
   for (int i = 0; i < MAXQ; ++i)
-    if (i < nq) st4(red + ((size_t)(wave * MAXQ + i)) * D + 4 * lane, acc[i]);
+    if (i < nq) st4(red + (wave * MAXQ + i) * D + 4 * lane, acc[i]);
   __syncthreads();
-  const DropRT od = drop_resolve(p.out_drop);
   for (int e = tid; e < nq * (D / 4); e += 256) {
     const int i = e / (D / 4), cq = e - i * (D / 4);
-    f32x4 s = ld4(red + (size_t)i * D + 4 * cq);
+    f32x4 sum = ld4(red + i * D + 4 * cq);
 #pragma unroll
-    for (int w = 1; w < 4; ++w) s += ld4(red + ((size_t)(w * MAXQ + i)) * D + 4 * cq);
-    const size_t o = ((size_t)v * nq + i) * D + 4 * cq;
-    st4(p.pooled + o, s);
-    if (od.enabled) s *= drop_mask4(od, (uint32_t)(v * nq + i), (uint32_t)cq);
-    st4(p.out + o, s);
+    for (int ww = 1; ww < 4; ++ww) sum += ld4(red + (ww * MAXQ + i) * D + 4 * cq);
+    st4(w.part + (((size_t)v * nchunk + chunk) * nq + i) * D + 4 * cq, sum);
   }
 }
 
-// ---- backward: one pass over the rows of (v, T-chunk) ----------------------------------------
-// dO = dout * out_mask ; delta_i = dO_i . O_i ; per row t:
-//   dA_i = dO_i . xd_t ; dS_i = 0.3 A_ti (dA_i - delta_i)
-//   dK_t = sum_i dS_i Q_i ; dz_t = dK_t (1 - K_t^2)            -> dz
-//   dxd_t (pool path) = sum_i A_ti dO_i                         -> dxd
-//   dQ_i += dS_i K_t                                            -> per-chunk partials (deterministic)
-__global__ __launch_bounds__(256) void attnpool_bwd_kernel(const sdumc_attnpool_bwd_t b, float* dq_part,
-                                                           const int nchunk) {
-  __shared__ __attribute__((aligned(16))) float dO_s[MAXQ * D];
-  __shared__ __attribute__((aligned(16))) float red[4 * MAXQ * D];
-  __shared__ float delta_s[MAXQ];
-  const sdumc_attnpool& p = b.f;
-  const int v = blockIdx.y, chunk = blockIdx.x;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// ---- forward, pass 2: combine the chunks of one v, normalise the weights, output dropout ---------
+__global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const sdumc_attnpool p, const float* ws, const int nchunk) {
+  extern __shared__ float fac[];   // [nchunk][MAXQ]: exp(m_c - m) / l
+  const int v = blockIdx.x, tid = threadIdx.x;
   const int T = p.T, nq = p.nq;
+  const FwdWs w = fwd_ws(const_cast<float*>(ws), p.V, nchunk, nq);
+  const float* st = w.stats + (size_t)v * nchunk * 2 * MAXQ;
+  if (tid < nq) {
+    float m = -INFINITY;
+    for (int c = 0; c < nchunk; ++c) m = fmaxf(m, st[c * 2 * MAXQ + tid]);
+    float l = 0.f;
+    for (int c = 0; c < nchunk; ++c) l += st[c * 2 * MAXQ + MAXQ + tid] * expf(st[c * 2 * MAXQ + tid] - m);
+    const float inv = 1.f / l;
+    for (int c = 0; c < nchunk; ++c) fac[c * MAXQ + tid] = expf(st[c * 2 * MAXQ + tid] - m) * inv;
+  }
+  __syncthreads();
   const DropRT od = drop_resolve(p.out_drop);
   for (int e = tid; e < nq * (D / 4); e += 256) {
     const int i = e / (D / 4), cq = e - i * (D / 4);
-    f32x4 g = ld4(b.dout + ((size_t)v * nq + i) * D + 4 * cq);
-    if (od.enabled) g *= drop_mask4(od, (uint32_t)(v * nq + i), (uint32_t)cq);
-    st4(dO_s + i * D + 4 * cq, g);
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nchunk; ++c) sum += ld4(w.part + (((size_t)v * nchunk + c) * nq + i) * D + 4 * cq) * fac[c * MAXQ + i];
+    const size_t o = ((size_t)v * nq + i) * D + 4 * cq;
+    st4(p.pooled + o, sum);
+    if (od.enabled) sum *= drop_mask4(od, (uint32_t)(v * nq + i), (uint32_t)cq);
+    st4(p.out + o, sum);
   }
+  float* attn = p.attn + (size_t)v * T * nq;
+  for (int e = tid; e < T * nq; e += 256) {
+    const int t = e / nq, i = e - t * nq;
+    attn[e] *= fac[(t / CH) * MAXQ + i];
+  }
+}
+
+// ---- backward: one workgroup per (chunk, v) ----------------------------------------------------
+// dO = dout * out_mask ; delta_i = dO_i . O_i ; per row t:
+//   dA_i = xd_t . dO_i (matrix cores) ; dS_i = 0.3 A_ti (dA_i - delta_i)
+//   dK_t = sum_i dS_i Q_i ; dz_t = dK_t (1 - K_t^2)            -> dz
+//   dxd_t (pool path) = sum_i A_ti dO_i                         -> dxd
+//   dQ_i += dS_i K_t                                            -> per-chunk slabs (deterministic)
+__global__ __launch_bounds__(256, 2) void attnpool_bwd_kernel(const sdumc_attnpool_bwd_t b, float* dq_part,
+                                                           const int nchunk) {
+  __shared__ __attribute__((aligned(16))) float dO_s[MAXQ * LDQ];
+  __shared__ __attribute__((aligned(16))) float red[4 * MAXQ * D];
+  __shared__ __attribute__((aligned(16))) float dS_s[CH * MAXQ];
+  __shared__ __attribute__((aligned(16))) float A_s[CH * MAXQ];
+  __shared__ float delta_s[16];
+  const sdumc_attnpool& p = b.f;
+  const int chunk = blockIdx.x, v = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r16 = lane & 15, kk = lane >> 4;
+  const int T = p.T, nq = p.nq;
+  const int t0 = chunk * CH;
+  const DropRT od = drop_resolve(p.out_drop);
+  for (int e = tid; e < MAXQ * (D / 4); e += 256) {
+    const int i = e / (D / 4), cq = e - i * (D / 4);
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    if (i < nq) {
+      g = ld4(b.dout + ((size_t)v * nq + i) * D + 4 * cq);
+      if (od.enabled) g *= drop_mask4(od, (uint32_t)(v * nq + i), (uint32_t)cq);
+    }
+    st4(dO_s + i * LDQ + 4 * cq, g);
+  }
+  if (tid < 16) delta_s[tid] = 0.f;
   __syncthreads();
   for (int i = wave; i < nq; i += 4) {
-    const float d = wave_sum(dot4(ld4(dO_s + i * D + 4 * lane), ld4(p.pooled + ((size_t)v * nq + i) * D + 4 * lane)));
+    const float d = wave_sum(dot4(ld4(dO_s + i * LDQ + 4 * lane), ld4(p.pooled + ((size_t)v * nq + i) * D + 4 * lane)));
     if (lane == 0) delta_s[i] = d;
   }
   __syncthreads();
 
-  f32x4 q[MAXQ], dqa[MAXQ];
-  float delta[MAXQ];
+  // dA for this wave's 16 rows on the matrix cores: A = xd rows, B = dO columns
+  const DropRT xd = drop_resolve(p.x_drop);
+  const int vx = v % p.x_samples;
+  {
+    const int myrow = t0 + 16 * wave + r16;
+    const float* rowp = myrow < T ? p.x + ((size_t)vx * T + myrow) * D : nullptr;
+    const uint32_t vrow = (uint32_t)(v * T + myrow);
+    const f32x4 dA = xd.enabled ? rows_times_cols<true>(rowp, dO_s, xd, vrow, r16, kk)
+                                : rows_times_cols<false>(rowp, dO_s, xd, vrow, r16, kk);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int rl = 16 * wave + 4 * kk + e, t = t0 + rl;
+      if (r16 < MAXQ) {
+        float a = 0.f, dS = 0.f;
+        if (r16 < nq && t < T) {
+          a = p.attn[((size_t)v * T + t) * nq + r16];
+          dS = p.scale * a * (dA[e] - delta_s[r16]);
+        }
+        A_s[rl * MAXQ + r16] = a;
+        dS_s[rl * MAXQ + r16] = dS;
+      }
+    }
+  }
+  __syncthreads();
+
+  f32x4 q[MAXQ], g[MAXQ], dqa[MAXQ];
 #pragma unroll
   for (int i = 0; i < MAXQ; ++i) {
     dqa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (i < nq) {
       q[i] = ld4(p.q + (size_t)v * p.q_stride + (size_t)i * D + 4 * lane);
-      delta[i] = delta_s[i];
+      g[i] = ld4(dO_s + i * LDQ + 4 * lane);
     }
   }
-  const DropRT xd = drop_resolve(p.x_drop);
-  const int vx = v % p.x_samples;
-  const int t0 = chunk * ROWS_PER_WG;
-  for (int r = wave; r < ROWS_PER_WG; r += 4) {
-    const int t = t0 + r;
+#pragma unroll 1
+  for (int r = 0; r < 16; ++r) {
+    const int rl = 16 * wave + r, t = t0 + rl;
     if (t >= T) break;
     const size_t row = (size_t)v * T + t;
-    f32x4 x = ld4(p.x + ((size_t)vx * T + t) * D + 4 * lane);
-    if (xd.enabled) x *= drop_mask4(xd, (uint32_t)row, (uint32_t)lane);
     const f32x4 k = ld4(p.keys + row * D + 4 * lane);
     f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < MAXQ; ++i)
       if (i < nq) {
-        const f32x4 g = ld4(dO_s + i * D + 4 * lane);
-        const float a = p.attn[row * nq + i];
-        const float dA = wave_sum(dot4(g, x));
-        const float dS = p.scale * a * (dA - delta[i]);
+        const float dS = dS_s[rl * MAXQ + i], a = A_s[rl * MAXQ + i];
         dk += q[i] * dS;
-        dx += g * a;
+        dx += g[i] * a;
         dqa[i] += k * dS;
       }
     const f32x4 one = {1.f, 1.f, 1.f, 1.f};
     st4(b.dz + row * D + 4 * lane, dk * (one - k * k));
     st4(b.dxd + row * D + 4 * lane, dx);
   }
-  // cross-wave reduce of the dQ partials, then one deterministic slab per (v, chunk)
 #pragma unroll
   for (int i = 0; i < MAXQ; ++i)
     if (i < nq) st4(red + (wave * MAXQ + i) * D + 4 * lane, dqa[i]);
@@ -203,33 +301,35 @@ __global__ __launch_bounds__(256) void dq_reduce_kernel(const float* part, float
 int check(const sdumc_attnpool& p) {
   if (p.V <= 0 || p.T <= 0 || p.nq < 1 || p.nq > MAXQ || p.x_samples <= 0) return SDUMC_EINVAL;
   if (!p.x || !p.keys || !p.q || !p.attn || !p.pooled || !p.out) return SDUMC_EINVAL;
-  if ((size_t)p.T * p.nq * 4 + 4 * MAXQ * D * 4 > 160 * 1024) return SDUMC_EINVAL;  // LDS budget
+  if ((p.T + CH - 1) / CH > 4096) return SDUMC_EINVAL;
   return SDUMC_OK;
 }
 
 }  // namespace
+
+extern "C" size_t sdumc_attnpool_fwd_workspace_bytes(int32_t V, int32_t T, int32_t nq) {
+  const size_t nchunk = (size_t)(T + CH - 1) / CH;
+  return ((size_t)V * nchunk * nq * D + (size_t)V * nchunk * 2 * MAXQ) * sizeof(float);
+}
 
 extern "C" int sdumc_attnpool_fwd(const sdumc_attnpool* pp, void* stream) {
   if (!pp) return SDUMC_EINVAL;
   const sdumc_attnpool& p = *pp;
   int rc = check(p);
   if (rc) return rc;
+  if (!p.workspace || p.workspace_bytes < sdumc_attnpool_fwd_workspace_bytes(p.V, p.T, p.nq)) return SDUMC_ENOMEM;
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(scores_kernel, dim3((p.T + ROWS_PER_WG - 1) / ROWS_PER_WG, p.V), dim3(256), 0, st, p);
+  const int nchunk = (p.T + CH - 1) / CH;
+  hipLaunchKernelGGL(attn_fwd_partial_kernel, dim3(nchunk, p.V), dim3(256), 0, st, p, p.workspace, nchunk);
   SDUMC_CHECK_LAUNCH();
-  const size_t lds = ((size_t)p.T * p.nq + 4 * MAXQ * D) * sizeof(float);
-  if (lds > 64 * 1024) {
-    if (hipFuncSetAttribute((const void*)softmax_pool_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-        hipSuccess)
-      return SDUMC_ELAUNCH;
-  }
-  hipLaunchKernelGGL(softmax_pool_kernel, dim3(p.V), dim3(256), lds, st, p);
+  hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(p.V), dim3(256), (size_t)nchunk * MAXQ * sizeof(float), st, p,
+                     p.workspace, nchunk);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
 }
 
 extern "C" size_t sdumc_attnpool_bwd_workspace_bytes(int32_t V, int32_t T, int32_t nq) {
-  const size_t nchunk = (size_t)(T + ROWS_PER_WG - 1) / ROWS_PER_WG;
+  const size_t nchunk = (size_t)(T + CH - 1) / CH;
   return (size_t)V * nchunk * nq * D * sizeof(float);
 }
 
@@ -240,7 +340,7 @@ extern "C" int sdumc_attnpool_bwd(const sdumc_attnpool_bwd_t* bp, void* stream) 
   if (rc) return rc;
   if (!b.dout || !b.dz || !b.dxd || !b.dq || !b.workspace) return SDUMC_EINVAL;
   const sdumc_attnpool& p = b.f;
-  const int nchunk = (p.T + ROWS_PER_WG - 1) / ROWS_PER_WG;
+  const int nchunk = (p.T + CH - 1) / CH;
   if (b.workspace_bytes < sdumc_attnpool_bwd_workspace_bytes(p.V, p.T, p.nq)) return SDUMC_ENOMEM;
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(attnpool_bwd_kernel, dim3(nchunk, p.V), dim3(256), 0, st, b, b.workspace, nchunk);

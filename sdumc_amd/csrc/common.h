@@ -43,6 +43,7 @@ __device__ __forceinline__ Philox4 philox4x32_10(uint32_t c0, uint32_t c1, uint3
 struct DropRT {
   uint32_t enabled, site, threshold, rows, qwidth, samples, sample0, call0, stream0, k0, k1;
   float scale;
+  const uint8_t* bits;
 };
 
 __device__ __forceinline__ DropRT drop_resolve(const sdumc_dropout& d) {
@@ -56,6 +57,7 @@ __device__ __forceinline__ DropRT drop_resolve(const sdumc_dropout& d) {
   r.sample0 = d.sample0;
   r.stream0 = d.stream0;
   r.scale = d.scale;
+  r.bits = d.bits;
   if (d.dev_state) {
     r.k0 = d.dev_state[0];
     r.k1 = d.dev_state[1];
@@ -71,6 +73,15 @@ __device__ __forceinline__ DropRT drop_resolve(const sdumc_dropout& d) {
 // The 4 multiplicative mask values of columns [4*cq, 4*cq+4) of virtual row `vrow`
 // (row space [streams][samples][rows]).
 __device__ __forceinline__ f32x4 drop_mask4(const DropRT& d, uint32_t vrow, uint32_t cq) {
+  if (d.bits) {   // precomputed keep-bits (sdumc_dropout_bits)
+    const uint32_t b = d.bits[(size_t)vrow * d.qwidth + cq];
+    f32x4 m;
+    m[0] = (b & 1u) ? d.scale : 0.f;
+    m[1] = (b & 2u) ? d.scale : 0.f;
+    m[2] = (b & 4u) ? d.scale : 0.f;
+    m[3] = (b & 8u) ? d.scale : 0.f;
+    return m;
+  }
   const uint32_t v = vrow / d.rows;
   const uint32_t r = vrow - v * d.rows;
   const uint32_t s = v / d.samples;

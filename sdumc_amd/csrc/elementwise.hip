@@ -82,6 +82,16 @@ __global__ void dropout_mask_kernel(const sdumc_dropout d, int64_t nquads, float
   st4(mask + 4 * i, m);
 }
 
+__global__ void dropout_bits_kernel(const sdumc_dropout d, int64_t nquads, uint8_t* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nquads) return;
+  DropRT r = drop_resolve(d);
+  r.bits = nullptr;   // always from Philox
+  const uint32_t vrow = (uint32_t)(i / r.qwidth), cq = (uint32_t)(i - (int64_t)vrow * r.qwidth);
+  const f32x4 m = drop_mask4(r, vrow, cq);
+  out[i] = (uint8_t)((m[0] != 0.f) | ((m[1] != 0.f) << 1) | ((m[2] != 0.f) << 2) | ((m[3] != 0.f) << 3));
+}
+
 // dx[b,t,:] = sum_k g_k[b,t,:] * mask_k  : one thread per 4 channels
 __global__ void dropsum_bwd_kernel(const sdumc_dropsum p, int64_t nquads) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -286,6 +296,14 @@ extern "C" int sdumc_dropout_mask(const sdumc_dropout* d, int32_t streams, float
   if (!d || !mask || streams < 1 || (d->width & 3) || d->width == 0) return SDUMC_EINVAL;
   const int64_t nquads = (int64_t)streams * d->samples * (d->rows ? d->rows : 1) * (d->width / 4);
   hipLaunchKernelGGL(dropout_mask_kernel, dim3(nblk(nquads)), dim3(256), 0, as_stream(stream), *d, nquads, mask);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_dropout_bits(const sdumc_dropout* d, int32_t streams, uint8_t* bits, void* stream) {
+  if (!d || !bits || streams < 1 || (d->width & 3) || d->width == 0) return SDUMC_EINVAL;
+  const int64_t nquads = (int64_t)streams * d->samples * (d->rows ? d->rows : 1) * (d->width / 4);
+  hipLaunchKernelGGL(dropout_bits_kernel, dim3(nblk(nquads)), dim3(256), 0, as_stream(stream), *d, nquads, bits);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
 }

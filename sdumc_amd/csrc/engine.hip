@@ -178,6 +178,7 @@ struct Plan {
   int64_t rows[3];          // virtual rows of modality m = sum over streams of B*T
   std::vector<Seg> segs[3];
   int64_t keys[2][3], attn[2][3], pooled[2][3];
+  int64_t bits[2][3];       // input-dropout keep-bits, one byte per (virtual row, 4 channels)
   int64_t hpre, u1, u, att1, att2, alpha, qin, q, qp, ca_out, c1, c, h, e1, e2, beta, z, vals, r1, r;
   // backward
   int64_t dz[2][3], dxd[2][3], dx[3][2];
@@ -200,7 +201,7 @@ int pick_splitk(int M, int N, int K, int groups) {
   return s < 1 ? 1 : (int)s;
 }
 
-size_t attnpool_bwd_ws_floats(int V, int T, int nq) { return (size_t)V * ((T + 63) / 64) * nq * D; }
+size_t attnpool_bwd_ws_floats(int V, int T, int nq) { return (size_t)V * ((T + 63) / 64) * (nq * D + 16); }  // fwd needs +16/chunk
 
 bool make_plan(const sdumc_net_dims& d, Plan& p) {
   if (d.B <= 0 || (d.streams != 1 && d.streams != 2) || d.Ta <= 0 || d.Tv <= 0 || d.Tt[0] <= 0) return false;
@@ -258,6 +259,7 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
   for (int k = 0; k < 2; ++k)
     for (int m = 0; m < 3; ++m) {
       p.keys[k][m] = p.alloc(p.rows[m] * D);
+      p.bits[k][m] = p.alloc(p.rows[m] * (D / 4) / 4 + 1);
       p.attn[k][m] = p.alloc(p.rows[m] * nq[k]);
       p.pooled[k][m] = p.alloc((int64_t)V * nq[k] * D);
     }
@@ -356,6 +358,14 @@ sdumc_dropout mkdrop(const Ctx& c, int site, double prob, int rows, int width, i
   r.stream0 = (uint32_t)stream0;
   r.dev_state = c.io.rng_state;
   return r;
+}
+
+// the input dropout of attention site (k, m) over run `sg`, with its precomputed keep-bits in train mode
+struct Seg;
+sdumc_dropout in_drop(const Ctx& c, int k, int m, int T, int s0, int64_t row0) {
+  sdumc_dropout d = mkdrop(c, SITE_IN[k][m], c.d.p_frame, T, D, s0);
+  if (d.enabled) d.bits = reinterpret_cast<const uint8_t*>(c.p(c.pl.bits[k][m])) + row0 * (D / 4);
+  return d;
 }
 
 sdumc_gemm G_(int layout, int M, int N, int K, int groups = 1) {
@@ -483,7 +493,7 @@ sdumc_attnpool attn_desc(const Ctx& c, int k, int m, const Seg& sg) {
     a.q_stride = (int64_t)NQ * D;
   }
   a.scale = 0.3f;
-  a.x_drop = mkdrop(c, SITE_IN[k][m], c.d.p_frame, sg.T, D, sg.s0);
+  a.x_drop = in_drop(c, k, m, sg.T, sg.s0, sg.row0);
   a.out_drop = mkdrop(c, SITE_OUT[k][m], c.d.p_frame, nq, D, sg.s0);
   a.attn = c.p(pl.attn[k][m]) + sg.row0 * nq;
   a.pooled = c.p(pl.pooled[k][m]) + (int64_t)sg.s0 * pl.B * nq * D;
@@ -500,7 +510,7 @@ int keys_fwd(const Ctx& c, int k, int m) {
     g.A[0] = c.p(sg.x_off);
     g.lda = D;
     g.a_row_mod = sg.x_samples < sg.V ? sg.x_samples * sg.T : 0;
-    g.a_drop = mkdrop(c, SITE_IN[k][m], c.d.p_frame, sg.T, D, sg.s0);
+    g.a_drop = in_drop(c, k, m, sg.T, sg.s0, sg.row0);
     g.B[0] = c.P + L.w;
     g.ldb = D;
     g.bias[0] = c.P + L.b;
@@ -509,6 +519,8 @@ int keys_fwd(const Ctx& c, int k, int m) {
     g.act = SDUMC_ACT_TANH;
     RET(run(c, g));
     sdumc_attnpool a = attn_desc(c, k, m, sg);
+    a.workspace = c.p(c.pl.scratch);
+    a.workspace_bytes = (size_t)c.pl.scratch_floats * sizeof(float);
     RET(sdumc_attnpool_fwd(&a, c.st));
   }
   return SDUMC_OK;
@@ -525,6 +537,15 @@ int forward(const Ctx& c) {
       const float* in = m == 0 ? c.io.audio : (m == 2 ? c.io.video : c.io.text[s]);
       RET(lin_fwd(c, pm.frame[m], in, din[m], B * pl.T[m][s], c.p(pl.x[m][s]), D, SDUMC_ACT_NONE, nullptr));
     }
+  // keep-bits of the six frame-level input dropouts (2 sites x 3 modalities): Philox runs once per element
+  // here instead of ~10x in the kernels that stage these tiles (4 n-tiles x {NT, TN}, pooling fwd/bwd, dropsum)
+  if (c.d.train)
+    for (int k = 0; k < 2; ++k)
+      for (int m = 0; m < 3; ++m)
+        for (const Seg& sg : pl.segs[m]) {
+          sdumc_dropout d = mkdrop(c, SITE_IN[k][m], c.d.p_frame, sg.T, D, sg.s0);
+          RET(sdumc_dropout_bits(&d, sg.V / B, reinterpret_cast<uint8_t*>(c.p(pl.bits[k][m])) + sg.row0 * (D / 4), c.st));
+        }
   // 2. fra2utt_{0,1,2} (model :288-290)
   for (int m = 0; m < 3; ++m) RET(keys_fwd(c, 0, m));
   // 3. audio/text/video_mlp (model :293-295), grouped over the modality
@@ -668,7 +689,7 @@ int keys_bwd(const Ctx& c, int k, int m, const float* dout_base /* [V, nq, D] */
     g.B[0] = c.p(sg.x_off);
     g.ldb = D;
     g.b_row_mod = sg.x_samples < sg.V ? sg.x_samples * sg.T : 0;
-    g.b_drop = mkdrop(c, SITE_IN[k][m], c.d.p_frame, sg.T, D, sg.s0);
+    g.b_drop = in_drop(c, k, m, sg.T, sg.s0, sg.row0);
     g.C[0] = c.G + L.w;
     g.ldc = D;
     g.colsum_a[0] = c.G + L.b;
@@ -801,8 +822,8 @@ int backward(const Ctx& c, const sdumc_net_grads& og) {
           int64_t roff = 0;  // virtual-row offset of stream ss inside modality m
           for (int q = 0; q < ss; ++q) roff += (int64_t)B * pl.T[m][q];
           ds.g[nt] = c.p(pl.dxd[k][m]) + roff * D;
-          ds.drop[nt] = mkdrop(c, SITE_IN[k][m], c.d.p_frame, T, D, 0);
-          ds.stream_idx[nt] = ss;
+          ds.drop[nt] = in_drop(c, k, m, T, ss, roff);   // row space of this term = stream ss alone
+          ds.stream_idx[nt] = 0;
           ++nt;
         }
       ds.terms = nt;

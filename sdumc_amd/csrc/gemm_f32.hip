@@ -335,7 +335,7 @@ GemmPlan plan_gemm(const sdumc_gemm& g, size_t ws_bytes) {
     const long tiles = p.tile == 1 ? big : small;
     const long want = p.tile == 1 ? 512 : 1024;
     const long smax = std::max(1, ktiles / 6);
-    s = tiles >= want ? 1 : (int)std::min<long>(smax, (want + tiles - 1) / tiles);
+    s = (int)std::min<long>(smax, want / tiles);   // floor: 900 tiles stay unsplit, 128 tiles split 8 ways
     if (s < 1) s = 1;
     while (s > 1 && plan_ws_bytes(g, s) > ws_bytes) --s;
   }

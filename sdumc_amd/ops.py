@@ -76,6 +76,9 @@ def attnpool_fwd(x, keys, q, nq, x_samples=None, q_shared=False, x_drop=None, ou
     out = torch.empty(V, nq, Dm, device=dev)
     a = attnpool_desc(x, keys, q, V, T, nq, x_samples or x.shape[0], 0 if q_shared else nq * Dm, x_drop, out_drop,
                       attn, pooled, out)
+    need = lib.sdumc_attnpool_fwd_workspace_bytes(V, T, nq)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    a.workspace, a.workspace_bytes = ptr(ws), need
     check(lib.sdumc_attnpool_fwd(C.byref(a), _st()), "sdumc_attnpool_fwd")
     return out, attn, pooled, a
 
@@ -103,6 +106,16 @@ def dropout_mask(d, streams):
     m = torch.empty(n, device=dev)
     check(lib.sdumc_dropout_mask(C.byref(d), streams, ptr(m), _st()), "sdumc_dropout_mask")
     return m.view(streams * d.samples, max(d.rows, 1), d.width)
+
+
+def dropout_bits(d, streams):
+    """uint8 keep-bits [streams*samples*rows, width/4] for the row space of `d`; also attaches them to `d`."""
+    n = streams * d.samples * max(d.rows, 1) * (d.width // 4)
+    bits = torch.empty(n, dtype=torch.uint8, device="cuda")
+    saved, d.bits = d.bits, None
+    check(lib.sdumc_dropout_bits(C.byref(d), streams, ptr(bits), _st()), "sdumc_dropout_bits")
+    d.bits = ptr(bits)
+    return bits
 
 
 def colsum(a, accumulate_into=None):

@@ -39,6 +39,12 @@ def test_dropout_mask_bit_exact(ops):
         want = np.concatenate([philox.dropout_mask(samples, rows, width, p, seed, call + s, site, sample0)
                                for s in range(streams)])
         np.testing.assert_array_equal(got, want)
+        # precomputed keep-bits decode to the same mask, and kernels fed with them give identical results
+        bits = ops.dropout_bits(d, streams)
+        unpacked = ((bits.cpu().numpy()[:, None] >> np.arange(4)) & 1).reshape(want.shape).astype(np.float32)
+        np.testing.assert_array_equal(unpacked * np.float32(d.scale), want)
+        np.testing.assert_array_equal(ops.dropout_mask(d, streams).cpu().numpy(), want)   # d.bits now attached
+        d.bits = None
     # device-resident state overrides seed/call
     st = torch.tensor([5, 0, 9], dtype=torch.int32).cuda()
     d = make_dropout(True, 3, 0.5, 2, 8, 2, dev_state=st)
