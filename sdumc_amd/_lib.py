@@ -35,6 +35,7 @@ class Gemm(C.Structure):
                 ("a_drop", Dropout), ("b_drop", Dropout),
                 ("act", C.c_int32), ("c_drop", Dropout), ("c_drop_group_stride", C.c_int32),
                 ("accumulate", C.c_int32), ("splitk", C.c_int32), ("tile", C.c_int32),
+                ("ab_drop_group_stride", C.c_int32), ("ab_drop_bits", C.c_void_p * MAX_GROUPS),
                 ("colsum_a", C.c_void_p * MAX_GROUPS),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 

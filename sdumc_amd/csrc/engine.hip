@@ -502,22 +502,33 @@ sdumc_attnpool attn_desc(const Ctx& c, int k, int m, const Seg& sg) {
   return a;
 }
 
-// keys = tanh(drop(x) W^T + b) for every run of (k, m)
-int keys_fwd(const Ctx& c, int k, int m) {
-  const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
+// keys = tanh(drop(x) W^T + b) of BOTH attention sites of modality m (FRA2UTT_new and Cross_Attention read
+// the same x with different masks and weights): one grouped launch per run -- twice the workgroups per
+// launch, so the last dispatch round of the 64x64 tiles is much fuller than with two launches.
+int keys_gemm_fwd(const Ctx& c, int m) {
   for (const Seg& sg : c.pl.segs[m]) {
-    sdumc_gemm g = G_(SDUMC_NT, sg.V * sg.T, D, D);
-    g.A[0] = c.p(sg.x_off);
-    g.lda = D;
+    sdumc_gemm g = G_(SDUMC_NT, sg.V * sg.T, D, D, 2);
+    for (int k = 0; k < 2; ++k) {
+      const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
+      g.A[k] = c.p(sg.x_off);
+      g.B[k] = c.P + L.w;
+      g.bias[k] = c.P + L.b;
+      g.C[k] = c.p(c.pl.keys[k][m]) + sg.row0 * D;
+      g.ab_drop_bits[k] = in_drop(c, k, m, sg.T, sg.s0, sg.row0).bits;
+    }
+    g.lda = g.ldb = g.ldc = D;
     g.a_row_mod = sg.x_samples < sg.V ? sg.x_samples * sg.T : 0;
-    g.a_drop = in_drop(c, k, m, sg.T, sg.s0, sg.row0);
-    g.B[0] = c.P + L.w;
-    g.ldb = D;
-    g.bias[0] = c.P + L.b;
-    g.C[0] = c.p(c.pl.keys[k][m]) + sg.row0 * D;
-    g.ldc = D;
+    g.a_drop = in_drop(c, 0, m, sg.T, sg.s0, sg.row0);
+    g.ab_drop_group_stride = SITE_IN[1][m] - SITE_IN[0][m];
     g.act = SDUMC_ACT_TANH;
     RET(run(c, g));
+  }
+  return SDUMC_OK;
+}
+
+// softmax-over-time pooling of site (k, m) given its keys (and, for k = 1, the projected queries)
+int pool_fwd(const Ctx& c, int k, int m) {
+  for (const Seg& sg : c.pl.segs[m]) {
     sdumc_attnpool a = attn_desc(c, k, m, sg);
     a.workspace = c.p(c.pl.scratch);
     a.workspace_bytes = (size_t)c.pl.scratch_floats * sizeof(float);
@@ -547,7 +558,8 @@ int forward(const Ctx& c) {
           RET(sdumc_dropout_bits(&d, sg.V / B, reinterpret_cast<uint8_t*>(c.p(pl.bits[k][m])) + sg.row0 * (D / 4), c.st));
         }
   // 2. fra2utt_{0,1,2} (model :288-290)
-  for (int m = 0; m < 3; ++m) RET(keys_fwd(c, 0, m));
+  for (int m = 0; m < 3; ++m) RET(keys_gemm_fwd(c, m));   // keys of fra2utt_m AND cross_att_fra2utt_m
+  for (int m = 0; m < 3; ++m) RET(pool_fwd(c, 0, m));
   // 3. audio/text/video_mlp (model :293-295), grouped over the modality
   {
     sdumc_gemm g = G_(SDUMC_NT, V, D, D, 3);
@@ -610,7 +622,7 @@ int forward(const Ctx& c) {
     RET(run(c, g));
   }
   // 8. cross_att_fra2utt_{0,1,2} (model :334-336)
-  for (int m = 0; m < 3; ++m) RET(keys_fwd(c, 1, m));
+  for (int m = 0; m < 3; ++m) RET(pool_fwd(c, 1, m));
   // 9. cross_{audio,text,video}_mlp (model :338-340)
   {
     sdumc_gemm g = G_(SDUMC_NT, V * NQ, D, D, 3);
@@ -659,52 +671,59 @@ int forward(const Ctx& c) {
   return SDUMC_OK;
 }
 
-// backward of the attention-pool site (k, m): dz, dxd, dq, then dW/db of input_proj and dxd += dz W
-int keys_bwd(const Ctx& c, int k, int m, const float* dout_base /* [V, nq, D] */, float* dq_base /* [V, nq, D] */) {
+// backward of the pooling of site (k, m): dz (pre-tanh key gradient), dxd (pooling path), dq
+int pool_bwd(const Ctx& c, int k, int m, const float* dout_base /* [V, nq, D] */, float* dq_base /* [V, nq, D] */) {
   const Plan& pl = c.pl;
-  const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
   const int nq = k == 0 ? 1 : NQ;
-  float* dz = c.p(pl.dz[k][m]);
-  float* dxd = c.p(pl.dxd[k][m]);
   for (const Seg& sg : pl.segs[m]) {
     sdumc_attnpool_bwd_t b;
     memset(&b, 0, sizeof(b));
     b.f = attn_desc(c, k, m, sg);
     const int64_t voff = (int64_t)sg.s0 * pl.B * nq * D;
     b.dout = dout_base + voff;
-    b.dz = dz + sg.row0 * D;
-    b.dxd = dxd + sg.row0 * D;
+    b.dz = c.p(pl.dz[k][m]) + sg.row0 * D;
+    b.dxd = c.p(pl.dxd[k][m]) + sg.row0 * D;
     b.dq = dq_base + voff;
     b.workspace = c.p(pl.scratch);
     b.workspace_bytes = (size_t)pl.scratch_floats * sizeof(float);
     RET(sdumc_attnpool_bwd(&b, c.st));
   }
-  // dW = dz^T drop(x): one GEMM per run (runs differ in their x buffer), later runs accumulate
+  return SDUMC_OK;
+}
+
+// input_proj backward of BOTH sites of modality m, grouped: dW = dz^T drop(x) (+ db), dxd += dz W
+int keys_gemm_bwd(const Ctx& c, int m) {
+  const Plan& pl = c.pl;
+  // dW: one grouped GEMM per run (runs differ in their x buffer), later runs accumulate
   bool first = true;
   for (const Seg& sg : pl.segs[m]) {
     const int rows = sg.V * sg.T;
-    sdumc_gemm g = G_(SDUMC_TN, D, D, rows);
-    g.A[0] = dz + sg.row0 * D;
-    g.lda = D;
-    g.B[0] = c.p(sg.x_off);
-    g.ldb = D;
+    sdumc_gemm g = G_(SDUMC_TN, D, D, rows, 2);
+    for (int k = 0; k < 2; ++k) {
+      const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
+      g.A[k] = c.p(pl.dz[k][m]) + sg.row0 * D;
+      g.B[k] = c.p(sg.x_off);
+      g.C[k] = c.G + L.w;
+      g.colsum_a[k] = c.G + L.b;
+      g.ab_drop_bits[k] = in_drop(c, k, m, sg.T, sg.s0, sg.row0).bits;
+    }
+    g.lda = g.ldb = g.ldc = D;
     g.b_row_mod = sg.x_samples < sg.V ? sg.x_samples * sg.T : 0;
-    g.b_drop = in_drop(c, k, m, sg.T, sg.s0, sg.row0);
-    g.C[0] = c.G + L.w;
-    g.ldc = D;
-    g.colsum_a[0] = c.G + L.b;
+    g.b_drop = in_drop(c, 0, m, sg.T, sg.s0, sg.row0);
+    g.ab_drop_group_stride = SITE_IN[1][m] - SITE_IN[0][m];
     g.accumulate = first ? 0 : 1;
     RET(run(c, g));
     first = false;
   }
   // dxd += dz W (the key-projection path joins the pooling path)
-  sdumc_gemm g = G_(SDUMC_NN, (int)pl.rows[m], D, D);
-  g.A[0] = dz;
-  g.lda = D;
-  g.B[0] = c.P + L.w;
-  g.ldb = D;
-  g.C[0] = dxd;
-  g.ldc = D;
+  sdumc_gemm g = G_(SDUMC_NN, (int)pl.rows[m], D, D, 2);
+  for (int k = 0; k < 2; ++k) {
+    const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
+    g.A[k] = c.p(pl.dz[k][m]);
+    g.B[k] = c.P + L.w;
+    g.C[k] = c.p(pl.dxd[k][m]);
+  }
+  g.lda = g.ldb = g.ldc = D;
   g.accumulate = 1;
   return run(c, g);
 }
@@ -750,7 +769,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og) {
   }
   // 8'. the three Cross_Attention blocks
   for (int m = 0; m < 3; ++m)
-    RET(keys_bwd(c, 1, m, c.p(pl.d_ca_out) + (int64_t)m * V * NQ * D, c.p(pl.d_qp) + (int64_t)m * V * NQ * D));
+    RET(pool_bwd(c, 1, m, c.p(pl.d_ca_out) + (int64_t)m * V * NQ * D, c.p(pl.d_qp) + (int64_t)m * V * NQ * D));
   // 7'. query_proj: dW/db per modality, d_q = sum_m d_qp[m] W_q[m]
   {
     const int M = V * NQ;
@@ -802,8 +821,9 @@ int backward(const Ctx& c, const sdumc_net_grads& og) {
   // 2'. fra2utt_{0,1,2}; the shared context vector's gradient is the sum of the per-sample dq
   for (int m = 0; m < 3; ++m) {
     float* dq = c.p(pl.dq_fra) + (int64_t)m * V * D;
-    RET(keys_bwd(c, 0, m, c.p(pl.d_hpre) + (int64_t)m * V * D, dq));
+    RET(pool_bwd(c, 0, m, c.p(pl.d_hpre) + (int64_t)m * V * D, dq));
     RET(colsum(c, dq, V, D, D, c.G + pm.fra_ctx[m], 0));
+    RET(keys_gemm_bwd(c, m));   // input_proj of both sites of this modality, grouped
   }
   // 1'. dx = sum of the (up to) four masked paths into each projected feature tensor, then
   //     frame_dim_reshape dW = dx^T feat (split-K), db = colsum(dx)

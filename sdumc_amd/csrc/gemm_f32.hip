@@ -169,6 +169,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdumc_gemm g, const int
   cb.drop = drop_resolve(g.b_drop);
   if (!A_K) ca.drop.enabled = 0;          // a_drop is defined for row-major [M][K] A only
   if (A_K || B_K) cb.drop.enabled = 0;    // b_drop is defined for TN only
+  ca.drop.site += (uint32_t)(grp * g.ab_drop_group_stride);   // grouped launches: per-group site / keep-bits
+  cb.drop.site += (uint32_t)(grp * g.ab_drop_group_stride);
+  if (g.ab_drop_bits[grp]) ca.drop.bits = cb.drop.bits = g.ab_drop_bits[grp];
 
   f32x16 acc[TM][TN];
 #pragma unroll

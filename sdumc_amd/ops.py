@@ -18,7 +18,7 @@ def _st():
 
 def gemm(layout, A, B, M, N, K, bias=None, C_out=None, lda=None, ldb=None, ldc=None, act=ACT_NONE, a_row_mod=0,
          b_row_mod=0, a_drop=None, b_drop=None, c_drop=None, c_drop_group_stride=0, accumulate=False, splitk=1,
-         tile=0, colsum_a=None):
+         tile=0, colsum_a=None, ab_drop_group_stride=0, ab_drop_bits=None):
     """Grouped when A/B/(bias)/C_out are lists."""
     As = A if isinstance(A, (list, tuple)) else [A]
     Bs = B if isinstance(B, (list, tuple)) else [B]
@@ -45,6 +45,10 @@ def gemm(layout, A, B, M, N, K, bias=None, C_out=None, lda=None, ldb=None, ldc=N
         g.c_drop = c_drop
     g.c_drop_group_stride = c_drop_group_stride
     g.act, g.accumulate, g.splitk, g.tile = act, 1 if accumulate else 0, splitk, tile
+    g.ab_drop_group_stride = ab_drop_group_stride
+    if ab_drop_bits is not None:
+        for i in range(groups):
+            g.ab_drop_bits[i] = ptr(ab_drop_bits[i])
     if colsum_a is not None:
         cs = colsum_a if isinstance(colsum_a, (list, tuple)) else [colsum_a]
         for i in range(groups):
