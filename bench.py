@@ -69,6 +69,7 @@ def roofline_leg(_lib, launch, steps):
     on the launch stream.  Returns the dominant GEMM variant's achieved TFLOP/s."""
     lib = _lib.lib
     torch.cuda.synchronize()
+    lib.sdumc_set_concurrency(0)      # one lane: a kernel's event-bracketed duration is then its own
     lib.sdumc_profile_enable(1)
     for _ in range(steps):
         launch()
@@ -76,6 +77,7 @@ def roofline_leg(_lib, launch, steps):
     arr = (_lib.ProfEntry * 6)()
     n = lib.sdumc_profile_report(arr, 6)
     lib.sdumc_profile_enable(0)
+    lib.sdumc_set_concurrency(1)
     rows = []
     for i in range(max(n, 0)):
         e = arr[i]
@@ -141,7 +143,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as one hipGraph instead of launching eagerly (measured slower: graph replay "
+                         "serialises the engine's three lanes, eager launches overlap them)")
+    ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)   # old spelling of the default
+    ap.add_argument("--serial-lanes", action="store_true",
+                    help="keep every kernel on one stream (for rocprofv3 --kernel-trace: per-kernel durations)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -164,13 +171,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
 
+    if args.serial_lanes:
+        _lib.lib.sdumc_set_concurrency(0)
     flat, lay = init_flat_params(engine, dev)
     batch = [t.to(dev) for t in synthetic_shard(B_PER_GPU, rank)]
 
     if world == 1:
         step = engine.TrainStep(flat, B_PER_GPU, T_MOSEI, DIMS, seed=2024)
         step.set_batch(*batch)
-        if not args.no_graph:
+        if args.graph:
             step.capture()
         run = step.run
     else:
@@ -213,7 +222,7 @@ def main():
                    "batch_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU,
                    "T_audio_text_video_feat4": list(T_MOSEI), "feature_dims": list(DIMS),
                    "parallelism": f"dp{world}" if world > 1 else "single",
-                   "launch": "eager" if (args.no_graph or world > 1) else "hipGraph replay",
+                   "launch": "hipGraph replay" if (args.graph and world == 1) else "eager, 3 lanes (caller stream + 2 side streams)",
                    "params": lay.total, "final_loss": round(float(losses[0]), 5)},
         "whole_step_tflops": round(value * TRAIN_FLOPS_PER_SAMPLE / 1e12, 2),
         "whole_step_frac_of_f32_mfma_peak": round(value * TRAIN_FLOPS_PER_SAMPLE / 1e12 / (world * PEAK_F32_MFMA_TFLOPS), 4),

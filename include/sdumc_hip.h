@@ -323,6 +323,11 @@ typedef struct sdumc_net_io {
   float* cross_text;     /* [V, 7, 128] cross_hiddens[:,1] */
 } sdumc_net_io;
 
+/* The network-level calls issue independent branches (the three per-modality chains; the dW GEMMs) on up to
+ * two internal side streams forked from / joined to `stream` with events: the call stays stream-ordered
+ * with respect to `stream`.  sdumc_set_concurrency(0) keeps everything on `stream` (per-kernel profiling:
+ * overlapping kernels share the GPU, so their individual durations stop being meaningful). */
+int sdumc_set_concurrency(int on);
 size_t sdumc_net_workspace_bytes(const sdumc_net_dims* d);
 int sdumc_net_forward(const sdumc_net_dims* d, const sdumc_net_io* io, void* stream);
 

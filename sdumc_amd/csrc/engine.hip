@@ -184,7 +184,7 @@ struct Plan {
   int64_t dz[2][3], dxd[2][3], dx[3][2];
   int64_t d_hpre, d_u1, d_u, d_att1, d_att2, d_alpha, d_qin, d_q, d_qp, d_ca_out, d_c1, d_c, d_h, d_e1, d_e2, d_beta,
       d_z, d_r1, dq_fra;
-  int64_t scratch = 0, scratch_floats = 0;
+  int64_t scratch[3] = {0, 0, 0}, scratch_floats = 0;   // one scratch per lane (stream)
   int64_t alloc(int64_t n) {
     const int64_t o = cur;
     cur += (n + 63) & ~(int64_t)63;
@@ -327,22 +327,90 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
   sc = std::max<int64_t>(sc, (int64_t)8 * 4 * D * NQ * H);  // grouped utterance-level split-K upper bound
   sc = std::max<int64_t>(sc, (int64_t)13 << 20);            // auto split-K: <= ~(320 + tiles) slabs of 64 KiB
   p.scratch_floats = sc;
-  p.scratch = p.alloc(sc);
+  for (int l = 0; l < 3; ++l) p.scratch[l] = p.alloc(sc);
   return true;
 }
 
 // ------------------------------------------------------------------------------------------
+// Lanes: lane 0 is the caller's stream; lanes 1, 2 are internal side streams forked from / joined to it with
+// events.  Independent branches (the three per-modality chains; the dW GEMMs, which are off the dX critical
+// path) are issued on different lanes: eagerly they overlap on the GPU, under hipGraph capture they become
+// parallel branches of the graph.  That fills the partially empty last dispatch round of the big kernels and
+// hides the launch-bound small ones.  Each lane has its own scratch, so concurrent kernels never share slabs.
+struct SideStreams {
+  hipStream_t s[2] = {nullptr, nullptr};
+  hipEvent_t ev[64];
+  int next = 0;
+  bool ok = false;
+};
+SideStreams& side_streams() {
+  static SideStreams S;
+  return S;
+}
+bool g_concurrency = true;   // sdumc_set_concurrency(0): everything on the caller's stream (profiling)
+// created outside any capture (called from the *_workspace_bytes queries every caller makes first)
+void ensure_side_streams() {
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lock(mu);
+  SideStreams& S = side_streams();
+  if (S.ok) return;
+  for (int i = 0; i < 2; ++i)
+    if (hipStreamCreateWithFlags(&S.s[i], hipStreamNonBlocking) != hipSuccess) return;
+  for (int i = 0; i < 64; ++i)
+    if (hipEventCreateWithFlags(&S.ev[i], hipEventDisableTiming) != hipSuccess) return;
+  S.ok = true;
+}
+
 struct Ctx {
   const sdumc_net_dims& d;
   const sdumc_net_io& io;
-  hipStream_t st;
+  mutable hipStream_t st;   // stream of the current lane
   const ParamMap& pm;
   Plan pl;
   float* W;     // workspace base
   float* P;     // parameters
   float* G;     // gradient bucket (backward only)
+  hipStream_t sts[3] = {nullptr, nullptr, nullptr};
+  mutable float* scr = nullptr;   // scratch of the current lane
+  bool multi = false;
   float* p(int64_t off) const { return W + off; }
+  void init_lanes() {
+    const SideStreams& S = side_streams();
+    sts[0] = st;
+    multi = S.ok && g_concurrency;
+    sts[1] = multi ? S.s[0] : st;
+    sts[2] = multi ? S.s[1] : st;
+    use(0);
+  }
+  void use(int lane) const {
+    st = sts[lane];
+    scr = W + pl.scratch[multi ? lane : 0];
+  }
 };
+
+hipEvent_t next_event() {
+  SideStreams& S = side_streams();
+  hipEvent_t e = S.ev[S.next];
+  S.next = (S.next + 1) & 63;
+  return e;
+}
+// lane `from` -> lane `to`: everything issued on `to` after this waits for what `from` has issued so far
+int link(const Ctx& c, int from, int to) {
+  if (!c.multi || from == to) return SDUMC_OK;
+  hipEvent_t e = next_event();
+  if (hipEventRecord(e, c.sts[from]) != hipSuccess) return SDUMC_ELAUNCH;
+  if (hipStreamWaitEvent(c.sts[to], e, 0) != hipSuccess) return SDUMC_ELAUNCH;
+  return SDUMC_OK;
+}
+int fork_all(const Ctx& c) {
+  RET(link(c, 0, 1));
+  return link(c, 0, 2);
+}
+int join_all(const Ctx& c) {
+  RET(link(c, 1, 0));
+  return link(c, 2, 0);
+}
+constexpr int LANE_OF[3] = {0, 2, 1};   // audio (heaviest) stays on the caller's stream, video -> 1, text -> 2
 
 sdumc_dropout mkdrop(const Ctx& c, int site, double prob, int rows, int width, int stream0 = 0) {
   sdumc_dropout r;
@@ -380,7 +448,7 @@ sdumc_gemm G_(int layout, int M, int N, int K, int groups = 1) {
 }
 
 int run(const Ctx& c, sdumc_gemm& g) {
-  g.workspace = c.p(c.pl.scratch);
+  g.workspace = c.scr;
   g.workspace_bytes = (size_t)c.pl.scratch_floats * sizeof(float);
   return sdumc_gemm_f32(&g, c.st);
 }
@@ -402,7 +470,7 @@ int lin_fwd(const Ctx& c, const Lin& L, const float* x, int lda, int M, float* y
 }
 
 int colsum(const Ctx& c, const float* a, int64_t rows, int cols, int lda, float* out, int accumulate) {
-  return sdumc_colsum(a, rows, cols, lda, out, accumulate, c.p(c.pl.scratch), c.st);
+  return sdumc_colsum(a, rows, cols, lda, out, accumulate, c.scr, c.st);
 }
 
 // backward of y = act(x W^T + b) given dzv = gradient w.r.t. the pre-activation, [M, L.out] with ld lddz:
@@ -417,7 +485,10 @@ int lin_bwd(const Ctx& c, const Lin& L, const float* dzv, int lddz, const float*
   gw.C[0] = c.G + L.w;
   gw.ldc = L.in;
   gw.colsum_a[0] = c.G + L.b;   // db rides along with the staging of dz
+  RET(link(c, 0, 1));           // dW is off the dX critical path: lane 1
+  c.use(1);
   RET(run(c, gw));
+  c.use(0);
   if (dx) {
     sdumc_gemm gx = G_(SDUMC_NN, M, L.in, L.out);
     gx.A[0] = dzv;
@@ -453,7 +524,10 @@ int lin_bwd_grouped(const Ctx& c, const Lin* L, int ng, int M, const GroupPtrs& 
   gw.lda = q.lddz;
   gw.ldb = q.ldx;
   gw.ldc = L[0].in;
+  RET(link(c, 0, 1));
+  c.use(1);
   RET(run(c, gw));
+  c.use(0);
   if (q.dx) {
     gx.lda = q.lddz;
     gx.ldb = L[0].in;
@@ -530,7 +604,7 @@ int keys_gemm_fwd(const Ctx& c, int m) {
 int pool_fwd(const Ctx& c, int k, int m) {
   for (const Seg& sg : c.pl.segs[m]) {
     sdumc_attnpool a = attn_desc(c, k, m, sg);
-    a.workspace = c.p(c.pl.scratch);
+    a.workspace = c.scr;
     a.workspace_bytes = (size_t)c.pl.scratch_floats * sizeof(float);
     RET(sdumc_attnpool_fwd(&a, c.st));
   }
@@ -542,24 +616,27 @@ int forward(const Ctx& c) {
   const ParamMap& pm = c.pm;
   const int B = pl.B, S = pl.S, V = pl.V;
   const int din[3] = {c.d.da, c.d.dt, c.d.dv};
-  // 1. frame_dim_reshape_{0,1,2} (model :282-284); audio/video once for both streams
-  for (int m = 0; m < 3; ++m)
-    for (int s = 0; s < (m == 1 ? S : 1); ++s) {
-      const float* in = m == 0 ? c.io.audio : (m == 2 ? c.io.video : c.io.text[s]);
-      RET(lin_fwd(c, pm.frame[m], in, din[m], B * pl.T[m][s], c.p(pl.x[m][s]), D, SDUMC_ACT_NONE, nullptr));
-    }
-  // keep-bits of the six frame-level input dropouts (2 sites x 3 modalities): Philox runs once per element
-  // here instead of ~10x in the kernels that stage these tiles (4 n-tiles x {NT, TN}, pooling fwd/bwd, dropsum)
-  if (c.d.train)
-    for (int k = 0; k < 2; ++k)
-      for (int m = 0; m < 3; ++m)
+  // 1+2. three independent per-modality chains, one per lane:
+  //      keep-bits of the two frame-level input dropouts -> frame_dim_reshape_m (model :282-284; audio/video once
+  //      for both streams) -> keys of fra2utt_m AND cross_att_fra2utt_m -> FRA2UTT pooling (model :288-290)
+  RET(fork_all(c));
+  for (int m = 0; m < 3; ++m) {
+    c.use(LANE_OF[m]);
+    if (c.d.train)   // Philox runs once per element here instead of ~10x in the kernels that stage these tiles
+      for (int k = 0; k < 2; ++k)
         for (const Seg& sg : pl.segs[m]) {
           sdumc_dropout d = mkdrop(c, SITE_IN[k][m], c.d.p_frame, sg.T, D, sg.s0);
           RET(sdumc_dropout_bits(&d, sg.V / B, reinterpret_cast<uint8_t*>(c.p(pl.bits[k][m])) + sg.row0 * (D / 4), c.st));
         }
-  // 2. fra2utt_{0,1,2} (model :288-290)
-  for (int m = 0; m < 3; ++m) RET(keys_gemm_fwd(c, m));   // keys of fra2utt_m AND cross_att_fra2utt_m
-  for (int m = 0; m < 3; ++m) RET(pool_fwd(c, 0, m));
+    for (int s = 0; s < (m == 1 ? S : 1); ++s) {
+      const float* in = m == 0 ? c.io.audio : (m == 2 ? c.io.video : c.io.text[s]);
+      RET(lin_fwd(c, pm.frame[m], in, din[m], B * pl.T[m][s], c.p(pl.x[m][s]), D, SDUMC_ACT_NONE, nullptr));
+    }
+    RET(keys_gemm_fwd(c, m));
+    RET(pool_fwd(c, 0, m));
+  }
+  c.use(0);
+  RET(join_all(c));
   // 3. audio/text/video_mlp (model :293-295), grouped over the modality
   {
     sdumc_gemm g = G_(SDUMC_NT, V, D, D, 3);
@@ -622,7 +699,13 @@ int forward(const Ctx& c) {
     RET(run(c, g));
   }
   // 8. cross_att_fra2utt_{0,1,2} (model :334-336)
-  for (int m = 0; m < 3; ++m) RET(pool_fwd(c, 1, m));
+  RET(fork_all(c));
+  for (int m = 0; m < 3; ++m) {
+    c.use(LANE_OF[m]);
+    RET(pool_fwd(c, 1, m));
+  }
+  c.use(0);
+  RET(join_all(c));
   // 9. cross_{audio,text,video}_mlp (model :338-340)
   {
     sdumc_gemm g = G_(SDUMC_NT, V * NQ, D, D, 3);
@@ -684,7 +767,7 @@ int pool_bwd(const Ctx& c, int k, int m, const float* dout_base /* [V, nq, D] */
     b.dz = c.p(pl.dz[k][m]) + sg.row0 * D;
     b.dxd = c.p(pl.dxd[k][m]) + sg.row0 * D;
     b.dq = dq_base + voff;
-    b.workspace = c.p(pl.scratch);
+    b.workspace = c.scr;
     b.workspace_bytes = (size_t)pl.scratch_floats * sizeof(float);
     RET(sdumc_attnpool_bwd(&b, c.st));
   }
@@ -734,42 +817,46 @@ int backward(const Ctx& c, const sdumc_net_grads& og) {
   const int B = pl.B, S = pl.S, V = pl.V;
   const int din[3] = {c.d.da, c.d.dt, c.d.dv};
   const float s_mlp = c.d.train ? 1.0f / (1.0f - (float)c.d.p_mlp) : 1.0f;
-  hipStream_t st = c.st;
-  RET(sdumc_fill(c.G, 0.f, pm.live, st));
+  RET(sdumc_fill(c.G, 0.f, pm.live, c.st));
 
   // 12'. heads: r = L2(relu(L0(z))), vals = fc_out_v(z), plus the external gradient of cross_fused_feat
   float* d_z = c.p(pl.d_z);
   if (og.d_rnc) {
     RET(lin_bwd(c, pm.rnc2, og.d_rnc, RD, c.p(pl.r1), RD, V, c.p(pl.d_r1), RD, 0));
-    RET(sdumc_relu_drop_bwd(c.p(pl.d_r1), c.p(pl.r1), 1.0f, c.p(pl.d_r1), (int64_t)V * RD, st));
+    RET(sdumc_relu_drop_bwd(c.p(pl.d_r1), c.p(pl.r1), 1.0f, c.p(pl.d_r1), (int64_t)V * RD, c.st));
     RET(lin_bwd(c, pm.rnc0, c.p(pl.d_r1), RD, c.p(pl.z), H, V, d_z, H, 0));
   } else {
-    RET(sdumc_fill(d_z, 0.f, (int64_t)V * H, st));
+    RET(sdumc_fill(d_z, 0.f, (int64_t)V * H, c.st));
   }
   if (og.d_vals) RET(lin_bwd(c, pm.fc_out_v, og.d_vals, 1, c.p(pl.z), H, V, d_z, H, 1));
-  if (og.d_fused) RET(sdumc_axpy2d(og.d_fused, H, d_z, H, V, H, st));
-  RET(sdumc_zpool_bwd(c.p(pl.h), c.p(pl.beta), d_z, c.p(pl.d_h), c.p(pl.d_beta), V, st));
+  if (og.d_fused) RET(sdumc_axpy2d(og.d_fused, H, d_z, H, V, H, c.st));
+  RET(sdumc_zpool_bwd(c.p(pl.h), c.p(pl.beta), d_z, c.p(pl.d_h), c.p(pl.d_beta), V, c.st));
   // 11'. cross_fc_att, cross_attention_mlp
   RET(lin_bwd(c, pm.cross_fc_att, c.p(pl.d_beta), NQ, c.p(pl.e2), H, V, c.p(pl.d_e2), H, 0));
-  RET(sdumc_relu_drop_bwd(c.p(pl.d_e2), c.p(pl.e2), s_mlp, c.p(pl.d_e2), (int64_t)V * H, st));
+  RET(sdumc_relu_drop_bwd(c.p(pl.d_e2), c.p(pl.e2), s_mlp, c.p(pl.d_e2), (int64_t)V * H, c.st));
   RET(lin_bwd(c, pm.catt3, c.p(pl.d_e2), H, c.p(pl.e1), D, V, c.p(pl.d_e1), D, 0));
-  RET(sdumc_relu_drop_bwd(c.p(pl.d_e1), c.p(pl.e1), s_mlp, c.p(pl.d_e1), (int64_t)V * D, st));
+  RET(sdumc_relu_drop_bwd(c.p(pl.d_e1), c.p(pl.e1), s_mlp, c.p(pl.d_e1), (int64_t)V * D, c.st));
   RET(lin_bwd(c, pm.catt0, c.p(pl.d_e1), D, c.p(pl.h), NQ * H, V, c.p(pl.d_h), NQ * H, 1));
   // 10'. modality-weighted sum; the external gradient of cross_hiddens[:,1] joins here
-  RET(sdumc_hweight_bwd(c.p(pl.c), c.p(pl.alpha), c.p(pl.d_h), og.d_cross_text, c.p(pl.d_c), c.p(pl.d_alpha), V, st));
+  RET(sdumc_hweight_bwd(c.p(pl.c), c.p(pl.alpha), c.p(pl.d_h), og.d_cross_text, c.p(pl.d_c), c.p(pl.d_alpha), V, c.st));
   // 9'. cross_{audio,text,video}_mlp
   {
     const int M = V * NQ;
-    RET(sdumc_relu_drop_bwd(c.p(pl.d_c), c.p(pl.c), s_mlp, c.p(pl.d_c), 3LL * M * H, st));
+    RET(sdumc_relu_drop_bwd(c.p(pl.d_c), c.p(pl.c), s_mlp, c.p(pl.d_c), 3LL * M * H, c.st));
     GroupPtrs q3 = {c.p(pl.d_c), (int64_t)M * H, H, c.p(pl.c1), (int64_t)M * D, D, c.p(pl.d_c1), (int64_t)M * D, D};
     RET(lin_bwd_grouped(c, pm.cmlp3, 3, M, q3));
-    RET(sdumc_relu_drop_bwd(c.p(pl.d_c1), c.p(pl.c1), s_mlp, c.p(pl.d_c1), 3LL * M * D, st));
+    RET(sdumc_relu_drop_bwd(c.p(pl.d_c1), c.p(pl.c1), s_mlp, c.p(pl.d_c1), 3LL * M * D, c.st));
     GroupPtrs q0 = {c.p(pl.d_c1), (int64_t)M * D, D, c.p(pl.ca_out), (int64_t)M * D, D, c.p(pl.d_ca_out), (int64_t)M * D, D};
     RET(lin_bwd_grouped(c, pm.cmlp0, 3, M, q0));
   }
   // 8'. the three Cross_Attention blocks
-  for (int m = 0; m < 3; ++m)
+  RET(fork_all(c));
+  for (int m = 0; m < 3; ++m) {
+    c.use(LANE_OF[m]);
     RET(pool_bwd(c, 1, m, c.p(pl.d_ca_out) + (int64_t)m * V * NQ * D, c.p(pl.d_qp) + (int64_t)m * V * NQ * D));
+  }
+  c.use(0);
+  RET(join_all(c));
   // 7'. query_proj: dW/db per modality, d_q = sum_m d_qp[m] W_q[m]
   {
     const int M = V * NQ;
@@ -781,7 +868,10 @@ int backward(const Ctx& c, const sdumc_net_grads& og) {
       gw.colsum_a[m] = c.G + pm.ca_q[m].b;
     }
     gw.lda = gw.ldb = gw.ldc = D;
+    RET(link(c, 0, 1));
+    c.use(1);
     RET(run(c, gw));
+    c.use(0);
     for (int m = 0; m < 3; ++m) {
       sdumc_gemm gx = G_(SDUMC_NN, M, D, D);
       gx.A[0] = c.p(pl.d_qp) + (int64_t)m * M * D;
@@ -793,41 +883,42 @@ int backward(const Ctx& c, const sdumc_net_grads& og) {
       gx.accumulate = m > 0;
       RET(run(c, gx));
     }
-    if (og.d_text_hidden) RET(sdumc_axpy2d(og.d_text_hidden, D, c.p(pl.d_q) + 5 * D, NQ * D, V, D, st));
+    if (og.d_text_hidden) RET(sdumc_axpy2d(og.d_text_hidden, D, c.p(pl.d_q) + 5 * D, NQ * D, V, D, c.st));
   }
   // 6'. the 7 query MLPs
   {
-    RET(sdumc_relu_drop_bwd(c.p(pl.d_q), c.p(pl.q), s_mlp, c.p(pl.d_q), 7LL * V * D, st));
+    RET(sdumc_relu_drop_bwd(c.p(pl.d_q), c.p(pl.q), s_mlp, c.p(pl.d_q), 7LL * V * D, c.st));
     GroupPtrs qq = {c.p(pl.d_q), D, NQ * D, c.p(pl.qin), (int64_t)V * D, D, c.p(pl.d_qin), (int64_t)V * D, D};
     RET(lin_bwd_grouped(c, pm.query, 7, V, qq));
   }
   // 5'. fusion algebra (d_alpha already holds the second-level contribution)
-  RET(sdumc_fusion_bwd(c.p(pl.u), c.p(pl.alpha), c.p(pl.d_qin), c.p(pl.d_u), c.p(pl.d_alpha), V, st));
+  RET(sdumc_fusion_bwd(c.p(pl.u), c.p(pl.alpha), c.p(pl.d_qin), c.p(pl.d_u), c.p(pl.d_alpha), V, c.st));
   // 4'. fc_att, attention_mlp
   RET(lin_bwd(c, pm.fc_att, c.p(pl.d_alpha), 3, c.p(pl.att2), D, V, c.p(pl.d_att2), D, 0));
-  RET(sdumc_relu_drop_bwd(c.p(pl.d_att2), c.p(pl.att2), s_mlp, c.p(pl.d_att2), (int64_t)V * D, st));
+  RET(sdumc_relu_drop_bwd(c.p(pl.d_att2), c.p(pl.att2), s_mlp, c.p(pl.d_att2), (int64_t)V * D, c.st));
   RET(lin_bwd(c, pm.att3, c.p(pl.d_att2), D, c.p(pl.att1), D, V, c.p(pl.d_att1), D, 0));
-  RET(sdumc_relu_drop_bwd(c.p(pl.d_att1), c.p(pl.att1), s_mlp, c.p(pl.d_att1), (int64_t)V * D, st));
+  RET(sdumc_relu_drop_bwd(c.p(pl.d_att1), c.p(pl.att1), s_mlp, c.p(pl.d_att1), (int64_t)V * D, c.st));
   RET(lin_bwd(c, pm.att0, c.p(pl.d_att1), D, c.p(pl.u), 3 * D, V, c.p(pl.d_u), 3 * D, 1));
   // 3'. audio/text/video_mlp
   {
-    RET(sdumc_relu_drop_bwd(c.p(pl.d_u), c.p(pl.u), s_mlp, c.p(pl.d_u), 3LL * V * D, st));
+    RET(sdumc_relu_drop_bwd(c.p(pl.d_u), c.p(pl.u), s_mlp, c.p(pl.d_u), 3LL * V * D, c.st));
     GroupPtrs q3 = {c.p(pl.d_u), D, 3 * D, c.p(pl.u1), (int64_t)V * D, D, c.p(pl.d_u1), (int64_t)V * D, D};
     RET(lin_bwd_grouped(c, pm.umlp3, 3, V, q3));
-    RET(sdumc_relu_drop_bwd(c.p(pl.d_u1), c.p(pl.u1), s_mlp, c.p(pl.d_u1), 3LL * V * D, st));
+    RET(sdumc_relu_drop_bwd(c.p(pl.d_u1), c.p(pl.u1), s_mlp, c.p(pl.d_u1), 3LL * V * D, c.st));
     GroupPtrs q0 = {c.p(pl.d_u1), (int64_t)V * D, D, c.p(pl.hpre), (int64_t)V * D, D, c.p(pl.d_hpre), (int64_t)V * D, D};
     RET(lin_bwd_grouped(c, pm.umlp0, 3, V, q0));
   }
-  // 2'. fra2utt_{0,1,2}; the shared context vector's gradient is the sum of the per-sample dq
+  // 2'+1'. three independent per-modality chains, one per lane:
+  //   fra2utt_m pooling backward (the shared context vector's gradient = sum of the per-sample dq)
+  //   -> input_proj backward of both sites (grouped) -> dx = sum of the (up to) four masked paths into the
+  //   projected features -> frame_dim_reshape_m: dW = dx^T feat (split-K) with db fused
+  RET(fork_all(c));
   for (int m = 0; m < 3; ++m) {
+    c.use(LANE_OF[m]);
     float* dq = c.p(pl.dq_fra) + (int64_t)m * V * D;
     RET(pool_bwd(c, 0, m, c.p(pl.d_hpre) + (int64_t)m * V * D, dq));
     RET(colsum(c, dq, V, D, D, c.G + pm.fra_ctx[m], 0));
-    RET(keys_gemm_bwd(c, m));   // input_proj of both sites of this modality, grouped
-  }
-  // 1'. dx = sum of the (up to) four masked paths into each projected feature tensor, then
-  //     frame_dim_reshape dW = dx^T feat (split-K), db = colsum(dx)
-  for (int m = 0; m < 3; ++m)
+    RET(keys_gemm_bwd(c, m));
     for (int s = 0; s < (m == 1 ? S : 1); ++s) {
       const int T = pl.T[m][s];
       sdumc_dropsum ds;
@@ -847,7 +938,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og) {
           ++nt;
         }
       ds.terms = nt;
-      RET(sdumc_dropsum_bwd(&ds, st));
+      RET(sdumc_dropsum_bwd(&ds, c.st));
       const float* in = m == 0 ? c.io.audio : (m == 2 ? c.io.video : c.io.text[s]);
       const int rows = B * T;
       sdumc_gemm g = G_(SDUMC_TN, D, din[m], rows);
@@ -861,6 +952,9 @@ int backward(const Ctx& c, const sdumc_net_grads& og) {
       g.accumulate = s > 0;
       RET(run(c, g));
     }
+  }
+  c.use(0);
+  RET(join_all(c));
   return SDUMC_OK;
 }
 
@@ -914,6 +1008,11 @@ int loss_ssd(const sdumc_net_dims& d, const sdumc_net_io& io, float* ssd_out, co
 // ==========================================================================================
 // C ABI
 // ==========================================================================================
+extern "C" int sdumc_set_concurrency(int on) {
+  g_concurrency = on != 0;
+  return SDUMC_OK;
+}
+
 extern "C" int64_t sdumc_param_count(int32_t da, int32_t dt, int32_t dv) { return build_params(da, dt, dv).total; }
 extern "C" int64_t sdumc_param_live_count(int32_t da, int32_t dt, int32_t dv) { return build_params(da, dt, dv).live; }
 extern "C" int32_t sdumc_param_table(int32_t da, int32_t dt, int32_t dv, char* buf, size_t buflen) {
@@ -930,6 +1029,7 @@ extern "C" int32_t sdumc_param_table(int32_t da, int32_t dt, int32_t dv, char* b
 }
 
 extern "C" size_t sdumc_net_workspace_bytes(const sdumc_net_dims* d) {
+  ensure_side_streams();   // never called under stream capture: the place to create the internal lanes
   Plan p;
   if (!d || !make_plan(*d, p)) return 0;
   return (size_t)p.cur * sizeof(float);
@@ -942,6 +1042,7 @@ extern "C" int sdumc_net_forward(const sdumc_net_dims* d, const sdumc_net_io* io
   if (io->workspace_bytes < (size_t)c.pl.cur * sizeof(float)) return SDUMC_ENOMEM;
   c.W = static_cast<float*>(io->workspace);
   c.P = io->params;
+  c.init_lanes();
   return forward(c);
 }
 
@@ -955,6 +1056,7 @@ extern "C" int sdumc_net_backward(const sdumc_net_dims* d, const sdumc_net_io* i
   c.W = static_cast<float*>(io->workspace);
   c.P = io->params;
   c.G = g->grads;
+  c.init_lanes();
   return backward(c, *g);
 }
 
