@@ -74,8 +74,8 @@ def roofline_leg(_lib, launch, steps):
     for _ in range(steps):
         launch()
     torch.cuda.synchronize()
-    arr = (_lib.ProfEntry * 6)()
-    n = lib.sdumc_profile_report(arr, 6)
+    arr = (_lib.ProfEntry * 16)()
+    n = lib.sdumc_profile_report(arr, 16)
     lib.sdumc_profile_enable(0)
     lib.sdumc_set_concurrency(1)
     rows = []
@@ -162,6 +162,9 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: sdumc_amd has no CPU fallback")
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev:      # debugging aid only (two ranks on one GPU with SDUMC_DIST_BACKEND=gloo)
+        local_rank %= ndev
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -169,7 +172,11 @@ def main():
     from sdumc_amd import _lib, engine
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)     # "nccl" is RCCL on ROCm
+        backend = os.environ.get("SDUMC_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     if args.serial_lanes:
         _lib.lib.sdumc_set_concurrency(0)

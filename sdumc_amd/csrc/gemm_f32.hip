@@ -36,8 +36,10 @@ struct ProfRec {
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::mutex g_prof_mu;
-const char* const kVariantName[6] = {"gemm_nt_128x128", "gemm_nt_64x64", "gemm_nn_128x128",
-                                     "gemm_nn_64x64",   "gemm_tn_128x128", "gemm_tn_64x64"};
+constexpr int kNumVariants = 9;
+const char* const kVariantName[kNumVariants] = {"gemm_nt_128x128", "gemm_nt_64x64",  "gemm_nn_128x128",
+                                                "gemm_nn_64x64",   "gemm_tn_128x128", "gemm_tn_64x64",
+                                                "gemm_small_nt",   "gemm_small_nn",   "gemm_small_tn"};
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;
@@ -273,6 +275,111 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdumc_gemm g, const int
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Small-problem kernel (the utterance-level layers: M = 2B or 14B rows, N, K <= 896).  These GEMMs are
+// latency-bound, not MFMA-bound: what matters is the length of the dependent chain inside one workgroup.
+// One workgroup = one 32x32 output tile; its four waves split K between them (intra-workgroup split-K);
+// each wave loads its operand slices straight from global memory into registers in MFMA fragment layout
+// (no LDS staging, no barriers in the k-loop, several k-groups of loads in flight at once), then the four
+// partial tiles are summed through LDS in a fixed order and the usual fused epilogue runs.
+// ------------------------------------------------------------------------------------------------
+template <bool A_K, bool B_K>
+__global__ __launch_bounds__(256) void gemm_small_kernel(const sdumc_gemm g, const int kq /* k per wave, multiple of 8 */) {
+  __shared__ float part[4][32 * 33];
+  __shared__ float cs_s[4][32];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 31, lh = lane >> 5;
+  const int grp = blockIdx.z, m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const float* A = g.A[grp];
+  const float* B = g.B[grp];
+  const int K = g.K;
+  const int kbeg = wave * kq, kend = min(K, kbeg + kq);
+  const bool a_ok = m0 + li < g.M, b_ok = n0 + li < g.N;
+  const bool a_vec = A_K && ((g.lda & 3) == 0) && ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(A) & 15) == 0);
+  const bool b_vec = B_K && ((g.ldb & 3) == 0) && ((K & 3) == 0) && ((reinterpret_cast<uintptr_t>(B) & 15) == 0);
+  // k-contiguous operand ([R][K]): this lane's row; row-contiguous operand ([K][R]): this lane's column
+  const float* ap = A_K ? A + (size_t)(m0 + li) * g.lda : A + m0 + li;
+  const float* bp = B_K ? B + (size_t)(n0 + li) * g.ldb : B + n0 + li;
+  const bool do_cs = !A_K && g.colsum_a[grp] != nullptr && blockIdx.x == 0;
+  float csum = 0.f;
+
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+  // one 8-k group: this lane supplies k .. k+3 (same k for A and B)
+  auto load_group = [&](int k, f32x4& a, f32x4& b) {
+    a = f32x4{0.f, 0.f, 0.f, 0.f};
+    b = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a_ok) {
+      if (A_K) {
+        if (a_vec && k + 3 < kend) a = *reinterpret_cast<const f32x4*>(ap + k);
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (k + e < kend) a[e] = ap[k + e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (k + e < kend) a[e] = ap[(size_t)(k + e) * g.lda];
+      }
+    }
+    if (b_ok) {
+      if (B_K) {
+        if (b_vec && k + 3 < kend) b = *reinterpret_cast<const f32x4*>(bp + k);
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) if (k + e < kend) b[e] = bp[k + e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) if (k + e < kend) b[e] = bp[(size_t)(k + e) * g.ldb];
+      }
+    }
+  };
+  constexpr int UB = 8;   // k-groups per batch: all of a batch's loads are in flight before its first MFMA
+  for (int k0 = kbeg; k0 < kend; k0 += 8 * UB) {
+    f32x4 a[UB], b[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) load_group(k0 + 8 * u + 4 * lh, a[u], b[u]);
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      if (do_cs) csum += (a[u][0] + a[u][1]) + (a[u][2] + a[u][3]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][e], b[u][e], acc, 0, 0, 0);
+    }
+  }
+
+  // partial tiles -> LDS; C/D layout: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
+#pragma unroll
+  for (int e = 0; e < 16; ++e) part[wave][((e & 3) + 8 * (e >> 2) + 4 * lh) * 33 + li] = acc[e];
+  if (do_cs) {
+    csum += __shfl_xor(csum, 32, 64);
+    if (lane < 32) cs_s[wave][lane] = csum;
+  }
+  __syncthreads();
+  if (do_cs && tid < 32 && m0 + tid < g.M) {
+    const float sum = (cs_s[0][tid] + cs_s[1][tid]) + (cs_s[2][tid] + cs_s[3][tid]);
+    float* dst = g.colsum_a[grp] + m0 + tid;
+    *dst = g.accumulate ? *dst + sum : sum;
+  }
+  float* C = g.C[grp];
+  const float* bias = g.bias[grp];
+  DropRT cd = drop_resolve(g.c_drop);
+  cd.site += (uint32_t)(grp * g.c_drop_group_stride);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int o = tid + 256 * q, r = o >> 5, c = o & 31;
+    const int row = m0 + r, col = n0 + c;
+    if (row >= g.M || col >= g.N) continue;
+    float v = (part[0][r * 33 + c] + part[1][r * 33 + c]) + (part[2][r * 33 + c] + part[3][r * 33 + c]);
+    v = apply_act(v + (bias ? bias[col] : 0.f), g.act);
+    if (cd.enabled) v *= drop_mask1(cd, (uint32_t)row, (uint32_t)col);
+    float* dst = C + (size_t)row * g.ldc + col;
+    if (g.accumulate) v += *dst;
+    *dst = v;
+  }
+}
+
 // ordered (deterministic) reduction of the split-K slabs + the epilogue
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const sdumc_gemm g, const int nsplit) {
   const int grp = blockIdx.y;
@@ -306,7 +413,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const sdumc_gemm g, 
 }
 
 struct GemmPlan {
-  int tile;    // 1 = 128x128, 2 = 64x64
+  int tile;    // 1 = 128x128, 2 = 64x64, 3 = small-problem kernel (32x32 tile, intra-workgroup split-K)
   int nsplit;
   int kchunk;
 };
@@ -331,6 +438,16 @@ GemmPlan plan_gemm(const sdumc_gemm& g, size_t ws_bytes) {
   const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.groups;
   const long small = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * g.groups;
   p.tile = g.tile ? g.tile : (small >= 8192 ? 1 : 2);
+  {   // launch-bound problems: at most 768 tiles of 32x32, K <= 1024, no operand-side fusions, no explicit split
+    const long t32 = (long)((g.M + 31) / 32) * ((g.N + 31) / 32) * g.groups;
+    const bool plain = !g.a_drop.enabled && !g.b_drop.enabled && g.a_row_mod == 0 && g.b_row_mod == 0;
+    if ((g.tile == 0 && g.splitk <= 1 && t32 <= 768 && g.K <= 1024 && plain) || g.tile == 3) {
+      p.tile = 3;
+      p.nsplit = 1;
+      p.kchunk = ((((g.K + 3) / 4) + 7) / 8) * 8;   // k per wave
+      return p;
+    }
+  }
   int s;
   if (g.splitk >= 1) {                                   // explicit
     s = std::min(g.splitk, ktiles);
@@ -391,11 +508,22 @@ extern "C" int sdumc_gemm_f32(const sdumc_gemm* gp, void* stream) {
   const bool prof = g_prof_on;
   if (prof) {
     if (hipEventCreate(&rec.a) != hipSuccess || hipEventCreate(&rec.b) != hipSuccess) return SDUMC_ELAUNCH;
-    rec.variant = g.layout * 2 + (tile == 1 ? 0 : 1);
+    rec.variant = tile == 3 ? 6 + g.layout : g.layout * 2 + (tile == 1 ? 0 : 1);
     rec.flops = 2.0 * g.M * (double)g.N * g.K * g.groups;
     (void)hipEventRecord(rec.a, st);
   }
-  int rc = tile == 1 ? launch<128, 128>(g, nsplit, kchunk, st) : launch<64, 64>(g, nsplit, kchunk, st);
+  int rc = SDUMC_OK;
+  if (tile == 3) {
+    if (g.tile == 3 && (g.a_drop.enabled || g.b_drop.enabled || g.a_row_mod || g.b_row_mod)) return SDUMC_EINVAL;
+    dim3 grid((g.N + 31) / 32, (g.M + 31) / 32, g.groups);
+    switch (g.layout) {
+      case SDUMC_NT: hipLaunchKernelGGL((gemm_small_kernel<true, true>), grid, dim3(256), 0, st, g, kchunk); break;
+      case SDUMC_NN: hipLaunchKernelGGL((gemm_small_kernel<true, false>), grid, dim3(256), 0, st, g, kchunk); break;
+      default: hipLaunchKernelGGL((gemm_small_kernel<false, false>), grid, dim3(256), 0, st, g, kchunk); break;
+    }
+  } else {
+    rc = tile == 1 ? launch<128, 128>(g, nsplit, kchunk, st) : launch<64, 64>(g, nsplit, kchunk, st);
+  }
   if (rc != SDUMC_OK) return rc;
   SDUMC_CHECK_LAUNCH();
   if (prof) {
@@ -425,9 +553,9 @@ extern "C" int sdumc_profile_enable(int on) {
 }
 
 extern "C" int sdumc_profile_report(sdumc_prof_entry* out, int max_entries) {
-  if (!out || max_entries < 6) return SDUMC_EINVAL;
+  if (!out || max_entries < kNumVariants) return SDUMC_EINVAL;
   std::lock_guard<std::mutex> lock(g_prof_mu);
-  for (int v = 0; v < 6; ++v) {
+  for (int v = 0; v < kNumVariants; ++v) {
     out[v].name = kVariantName[v];
     out[v].launches = 0;
     out[v].total_ms = 0.0;
@@ -441,5 +569,5 @@ extern "C" int sdumc_profile_report(sdumc_prof_entry* out, int max_entries) {
     out[r.variant].total_ms += ms;
     out[r.variant].total_flops += r.flops;
   }
-  return 6;
+  return kNumVariants;
 }

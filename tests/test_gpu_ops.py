@@ -105,6 +105,31 @@ def test_gemm_nn_tn_accumulate_splitk(ops):
     close(ops.gemm(ops.NN, dev(dY3), dev(W3), 130, 256, 3), dY3.double() @ W3.double(), 2e-5)
 
 
+@pytest.mark.parametrize("M,N,K", [(128, 256, 256), (896, 128, 256), (128, 3, 256), (128, 896, 256), (130, 70, 100),
+                                   (128, 256, 896), (128, 1, 128), (5, 64, 64), (128, 256, 7)])
+def test_gemm_small_kernel_all_layouts(ops, M, N, K):
+    """tile=3: 32x32 tile, the four waves split K; NT / NN / TN, bias + activation, accumulate, fused colsum."""
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    A, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    ref = A.double() @ W.double().T
+    close(ops.gemm(ops.NT, dev(A), dev(W), M, N, K, bias=dev(b), act=ops.ACT_RELU, tile=3), torch.relu(ref + b.double()), 2e-5)
+    auto = ops.gemm(ops.NT, dev(A), dev(W), M, N, K, bias=dev(b), splitk=0)          # planner picks it for these sizes
+    close(auto, ref + b.double(), 2e-5)
+    Wt = W.T.contiguous()
+    C0 = torch.randn(M, N, generator=g)
+    Cd = dev(C0.clone())
+    ops.gemm(ops.NN, dev(A), dev(Wt), M, N, K, C_out=Cd, accumulate=True, tile=3)
+    close(Cd, C0.double() + ref, 2e-5)
+    At = A.T.contiguous()                                                          # TN: [K, M]^T [K, N]
+    X = torch.randn(M, N, generator=g)
+    cs = dev(torch.full((K,), 1.5))
+    got = ops.gemm(ops.TN, dev(A), dev(X), K, N, M, tile=3, colsum_a=cs, accumulate=False)
+    close(got, A.double().T @ X.double(), 2e-5)
+    close(cs, A.double().sum(0), 2e-5)
+    again = ops.gemm(ops.TN, dev(A), dev(X), K, N, M, tile=3)
+    assert torch.equal(got, again)
+
+
 def test_gemm_grouped_strided_and_dropout(ops):
     from oracle import philox
     from sdumc_amd._lib import make_dropout

@@ -35,7 +35,7 @@ if __name__ == "__main__":
         bench(TN, 256, 1024, 24000, tile=1, splitk=s)
     for s in (48, 96, 0):
         bench(TN, 256, 256, 48000, tile=1, splitk=s)
-    for t, s in ((2, 1), (2, 2), (2, 4), (0, 0)):
+    for t, s in ((2, 1), (3, 1), (0, 0)):
         bench(NT, 128, 256, 256, tile=t, splitk=s)
         bench(NT, 128, 256, 896, tile=t, splitk=s)
         bench(NT, 896, 256, 256, tile=t, splitk=s)
