@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsdumc_hip.so")
+LIB_PATH = os.environ.get("SDUMC_LIB") or os.path.join(_HERE, "csrc", "libsdumc_hip.so")   # override: A/B of builds
 
 MAX_GROUPS = 8
 D, H, NQ, RNC_DIM, N_SITES = 256, 128, 7, 64, 35
