@@ -98,6 +98,10 @@ typedef struct sdumc_gemm {
                            for the launch-bound utterance-level layers; no operand-side fusions) */
   int32_t ab_drop_group_stride; /* group g draws a_drop / b_drop from site + g * stride ... */
   const uint8_t* ab_drop_bits[SDUMC_MAX_GROUPS]; /* ... or from these per-group keep-bits (NULL: a_drop.bits / b_drop.bits) */
+  const float* c_mask_y[SDUMC_MAX_GROUPS]; /* optional epilogue (selects the small-problem kernel): C = C * [Y > 0] * c_mask_scale,
+                           Y laid out like C, applied after `accumulate`.  Folds the backward of the NEXT
+                           Linear->ReLU->Dropout (dz = dy * [y > 0] / (1-p), model :264-273) into the dX GEMM */
+  float c_mask_scale;
   float* colsum_a[SDUMC_MAX_GROUPS]; /* TN only, optional: out[m] (+)= sum_k A[k,m] fused into the staging of A
                            (the bias gradient when A = dz); `accumulate` applies to it too */
   float* workspace;
@@ -201,7 +205,9 @@ int sdumc_hweight_fwd(const float* c, const float* alpha, float* h, int32_t V, v
 /* dh [V,7,128] -> dc [3][V,7,128] = alpha_m dh (+ dct [V,7,128] on m = 1, the external gradient of
  * cross_hiddens[:,1]; may be NULL), dalpha [V,3] (overwritten) */
 int sdumc_hweight_bwd(const float* c, const float* alpha, const float* dh, const float* dct, float* dc,
-                      float* dalpha, int32_t V, void* stream);
+                      float* dalpha, int32_t V, float relu_scale, void* stream);
+/* relu_scale > 0: dc is additionally multiplied by [c > 0] * relu_scale (c is the post-ReLU/dropout output of
+ * cross_*_mlp, so this is the gradient w.r.t. its pre-activation); 0: plain */
 /* z[v,:] = sum_i beta[v,i] h[v,i,:]  (model :356-358) */
 int sdumc_zpool_fwd(const float* h, const float* beta, float* z, int32_t V, void* stream);
 /* dz [V,128] -> dh [V,7,128] (overwritten), dbeta [V,7] (overwritten) */
@@ -257,6 +263,12 @@ int sdumc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
                     float grad_scale, void* stream);
 
 /* misc */
+/* n (<= 8) strided copies in one launch */
+typedef struct sdumc_copy_seg {
+  const float* src; float* dst;
+  int32_t ld_src, ld_dst, rows, cols;
+} sdumc_copy_seg;
+int sdumc_copy2d_multi(const sdumc_copy_seg* segs, int32_t n, void* stream);
 /* dst[r, 0:cols] = src[r, 0:cols] for r < rows, with leading dimensions */
 /* dst[r, 0:cols] += src[r, 0:cols] */
 int sdumc_axpy2d(const float* src, int32_t ld_src, float* dst, int32_t ld_dst, int32_t rows, int32_t cols, void* stream);
@@ -266,6 +278,10 @@ int sdumc_fill(float* p, float v, int64_t n, void* stream);
 int sdumc_rng_advance(uint32_t* dev_state, uint32_t inc, void* stream);
 /* keep-bits of a [streams*samples, rows, width] row space, one byte per 4 columns (see sdumc_dropout.bits) */
 int sdumc_dropout_bits(const sdumc_dropout* d, int32_t streams, uint8_t* bits, void* stream);
+/* the same for nsite (<= 4) sites d->site + s * site_stride that share the row space, in one launch
+ * (width must be a multiple of 16: four quads are packed per 32-bit store; bits[s] 4-byte aligned) */
+int sdumc_dropout_bits_multi(const sdumc_dropout* d, int32_t streams, int32_t nsite, int32_t site_stride,
+                             uint8_t* const* bits, void* stream);
 /* writes the dropout mask values (0 or scale) of a [streams*samples, rows, width] tensor: test hook */
 int sdumc_dropout_mask(const sdumc_dropout* d, int32_t streams, float* mask, void* stream);
 const char* sdumc_version(void);

@@ -36,6 +36,7 @@ class Gemm(C.Structure):
                 ("act", C.c_int32), ("c_drop", Dropout), ("c_drop_group_stride", C.c_int32),
                 ("accumulate", C.c_int32), ("splitk", C.c_int32), ("tile", C.c_int32),
                 ("ab_drop_group_stride", C.c_int32), ("ab_drop_bits", C.c_void_p * MAX_GROUPS),
+                ("c_mask_y", C.c_void_p * MAX_GROUPS), ("c_mask_scale", C.c_float),
                 ("colsum_a", C.c_void_p * MAX_GROUPS),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
@@ -94,7 +95,13 @@ class ProfEntry(C.Structure):
     _fields_ = [("name", C.c_char_p), ("launches", C.c_int64), ("total_ms", C.c_double), ("total_flops", C.c_double)]
 
 
+class CopySeg(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("ld_src", C.c_int32), ("ld_dst", C.c_int32),
+                ("rows", C.c_int32), ("cols", C.c_int32)]
+
+
 _SIGS = {
+    "sdumc_copy2d_multi": (C.c_int, [C.POINTER(CopySeg), C.c_int32, C.c_void_p]),
     "sdumc_profile_enable": (C.c_int, [C.c_int]),
     "sdumc_profile_report": (C.c_int, [C.POINTER(ProfEntry), C.c_int]),
     "sdumc_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(Gemm)]),
@@ -111,7 +118,7 @@ _SIGS = {
     "sdumc_fusion_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "sdumc_fusion_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "sdumc_hweight_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
-    "sdumc_hweight_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
+    "sdumc_hweight_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_void_p]),
     "sdumc_zpool_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "sdumc_zpool_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]),
     "sdumc_mse_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -132,6 +139,7 @@ _SIGS = {
     "sdumc_fill": (C.c_int, [C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
     "sdumc_rng_advance": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "sdumc_dropout_bits": (C.c_int, [C.POINTER(Dropout), C.c_int32, C.c_void_p, C.c_void_p]),
+    "sdumc_dropout_bits_multi": (C.c_int, [C.POINTER(Dropout), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.c_void_p]),
     "sdumc_dropout_mask": (C.c_int, [C.POINTER(Dropout), C.c_int32, C.c_void_p, C.c_void_p]),
     "sdumc_version": (C.c_char_p, []),
     # network level (engine.hip)

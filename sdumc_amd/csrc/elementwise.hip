@@ -1,6 +1,8 @@
 // elementwise.hip — the small fused element-wise / reduction kernels of the utterance-level
 // network (model :293-368) and of its backward.  All HBM/L2-streaming: 16-B accesses where the
 // layout allows, wave64 shuffles for the per-sample dot products.
+#include <algorithm>
+
 #include "common.h"
 
 namespace {
@@ -65,6 +67,18 @@ __global__ void axpy2d_kernel(const float* src, int ld_src, float* dst, int ld_d
   dst[(size_t)r * ld_dst + c] += src[(size_t)r * ld_src + c];
 }
 
+struct CopySegs {
+  sdumc_copy_seg s[8];
+};
+__global__ void copy2d_multi_kernel(const CopySegs cs) {
+  const sdumc_copy_seg& sg = cs.s[blockIdx.y];
+  const int64_t n = (int64_t)sg.rows * sg.cols;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / sg.cols), c = (int)(i - (int64_t)r * sg.cols);
+    sg.dst[(size_t)r * sg.ld_dst + c] = sg.src[(size_t)r * sg.ld_src + c];
+  }
+}
+
 __global__ void fill_kernel(float* p, float v, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -82,14 +96,29 @@ __global__ void dropout_mask_kernel(const sdumc_dropout d, int64_t nquads, float
   st4(mask + 4 * i, m);
 }
 
-__global__ void dropout_bits_kernel(const sdumc_dropout d, int64_t nquads, uint8_t* out) {
+// keep-bits for `nsite` dropout sites that share one row space (site, site + stride, ...): one thread packs
+// four consecutive column quads into one 32-bit store (the byte-per-thread form was store-bound: 53 us for
+// the audio tensor; this one is bound by the ~90 VALU ops of Philox per quad)
+struct BitsOut {
+  uint8_t* p[4];
+};
+__global__ void dropout_bits_kernel(const sdumc_dropout d, int64_t nwords, int nsite, int site_stride, BitsOut out) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nquads) return;
+  if (i >= nwords) return;
   DropRT r = drop_resolve(d);
   r.bits = nullptr;   // always from Philox
-  const uint32_t vrow = (uint32_t)(i / r.qwidth), cq = (uint32_t)(i - (int64_t)vrow * r.qwidth);
-  const f32x4 m = drop_mask4(r, vrow, cq);
-  out[i] = (uint8_t)((m[0] != 0.f) | ((m[1] != 0.f) << 1) | ((m[2] != 0.f) << 2) | ((m[3] != 0.f) << 3));
+  const uint32_t wpr = r.qwidth >> 2;                      // 32-bit words per row
+  const uint32_t vrow = (uint32_t)(i / wpr), w = (uint32_t)(i - (int64_t)vrow * wpr);
+  for (int s = 0; s < nsite; ++s) {
+    uint32_t word = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 m = drop_mask4(r, vrow, 4 * w + q);
+      word |= (uint32_t)((m[0] != 0.f) | ((m[1] != 0.f) << 1) | ((m[2] != 0.f) << 2) | ((m[3] != 0.f) << 3)) << (8 * q);
+    }
+    reinterpret_cast<uint32_t*>(out.p[s])[i] = word;
+    r.site += (uint32_t)site_stride;
+  }
 }
 
 // dx[b,t,:] = sum_k g_k[b,t,:] * mask_k  : one thread per 4 channels
@@ -162,7 +191,8 @@ __global__ __launch_bounds__(256) void hweight_fwd_kernel(const float* c, const 
 
 // one 256-thread workgroup per v: dc_m = alpha_m dh (+ dct on m = 1), dalpha_m = <dh, c_m>
 __global__ __launch_bounds__(256) void hweight_bwd_kernel(const float* c, const float* alpha, const float* dh,
-                                                          const float* dct, float* dc, float* dalpha, int V) {
+                                                          const float* dct, float* dc, float* dalpha, int V,
+                                                          float relu_scale) {
   __shared__ float red[3][4];
   const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   float acc[3] = {0.f, 0.f, 0.f};
@@ -171,14 +201,23 @@ __global__ __launch_bounds__(256) void hweight_bwd_kernel(const float* c, const 
     const f32x4 g = ld4(dh + (size_t)v * NQ * H + 4 * e);
     const size_t gs = (size_t)V * NQ * H;  // c, dc are [3][V,7,128]
     const size_t cb = (size_t)v * NQ * H + 4 * e;
-    acc[0] += dot4(g, ld4(c + cb));
-    acc[1] += dot4(g, ld4(c + cb + gs));
-    acc[2] += dot4(g, ld4(c + cb + 2 * gs));
-    st4(dc + cb, g * a0);
-    f32x4 g1 = g * a1;
+    const f32x4 c0 = ld4(c + cb), c1 = ld4(c + cb + gs), c2 = ld4(c + cb + 2 * gs);
+    acc[0] += dot4(g, c0);
+    acc[1] += dot4(g, c1);
+    acc[2] += dot4(g, c2);
+    f32x4 g0 = g * a0, g1 = g * a1, g2 = g * a2;
     if (dct) g1 += ld4(dct + (size_t)v * NQ * H + 4 * e);
+    if (relu_scale > 0.f) {   // gradient w.r.t. the pre-activation of cross_*_mlp.3 (ReLU + dropout backward)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        g0[j] = c0[j] > 0.f ? g0[j] * relu_scale : 0.f;
+        g1[j] = c1[j] > 0.f ? g1[j] * relu_scale : 0.f;
+        g2[j] = c2[j] > 0.f ? g2[j] * relu_scale : 0.f;
+      }
+    }
+    st4(dc + cb, g0);
     st4(dc + cb + gs, g1);
-    st4(dc + cb + 2 * gs, g * a2);
+    st4(dc + cb + 2 * gs, g2);
   }
 #pragma unroll
   for (int m = 0; m < 3; ++m) {
@@ -268,6 +307,20 @@ extern "C" int sdumc_copy2d(const float* src, int32_t ld_src, float* dst, int32_
   return SDUMC_OK;
 }
 
+extern "C" int sdumc_copy2d_multi(const sdumc_copy_seg* segs, int32_t n, void* stream) {
+  if (!segs || n < 1 || n > 8) return SDUMC_EINVAL;
+  CopySegs cs;
+  int64_t mx = 0;
+  for (int i = 0; i < n; ++i) {
+    if (!segs[i].src || !segs[i].dst || segs[i].rows <= 0 || segs[i].cols <= 0) return SDUMC_EINVAL;
+    cs.s[i] = segs[i];
+    mx = std::max<int64_t>(mx, (int64_t)segs[i].rows * segs[i].cols);
+  }
+  hipLaunchKernelGGL(copy2d_multi_kernel, dim3(std::min<unsigned>(nblk(mx), 256u), n), dim3(256), 0, as_stream(stream), cs);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
 extern "C" int sdumc_axpy2d(const float* src, int32_t ld_src, float* dst, int32_t ld_dst, int32_t rows, int32_t cols,
                             void* stream) {
   if (!src || !dst || rows <= 0 || cols <= 0 || ld_src < cols || ld_dst < cols) return SDUMC_EINVAL;
@@ -300,12 +353,24 @@ extern "C" int sdumc_dropout_mask(const sdumc_dropout* d, int32_t streams, float
   return SDUMC_OK;
 }
 
-extern "C" int sdumc_dropout_bits(const sdumc_dropout* d, int32_t streams, uint8_t* bits, void* stream) {
-  if (!d || !bits || streams < 1 || (d->width & 3) || d->width == 0) return SDUMC_EINVAL;
-  const int64_t nquads = (int64_t)streams * d->samples * (d->rows ? d->rows : 1) * (d->width / 4);
-  hipLaunchKernelGGL(dropout_bits_kernel, dim3(nblk(nquads)), dim3(256), 0, as_stream(stream), *d, nquads, bits);
+extern "C" int sdumc_dropout_bits_multi(const sdumc_dropout* d, int32_t streams, int32_t nsite, int32_t site_stride,
+                                        uint8_t* const* bits, void* stream) {
+  if (!d || !bits || streams < 1 || nsite < 1 || nsite > 4 || (d->width & 15) || d->width == 0) return SDUMC_EINVAL;
+  BitsOut out;
+  for (int s = 0; s < 4; ++s) {
+    out.p[s] = s < nsite ? bits[s] : nullptr;
+    if (s < nsite && (!bits[s] || (reinterpret_cast<uintptr_t>(bits[s]) & 3))) return SDUMC_EINVAL;
+  }
+  const int64_t nwords = (int64_t)streams * d->samples * (d->rows ? d->rows : 1) * (d->width / 16);
+  hipLaunchKernelGGL(dropout_bits_kernel, dim3(nblk(nwords)), dim3(256), 0, as_stream(stream), *d, nwords, nsite,
+                     site_stride, out);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
+}
+
+extern "C" int sdumc_dropout_bits(const sdumc_dropout* d, int32_t streams, uint8_t* bits, void* stream) {
+  uint8_t* one[1] = {bits};
+  return sdumc_dropout_bits_multi(d, streams, 1, 0, one, stream);
 }
 
 extern "C" int sdumc_dropsum_bwd(const sdumc_dropsum* p, void* stream) {
@@ -341,9 +406,10 @@ extern "C" int sdumc_hweight_fwd(const float* c, const float* alpha, float* h, i
 }
 
 extern "C" int sdumc_hweight_bwd(const float* c, const float* alpha, const float* dh, const float* dct, float* dc,
-                                 float* dalpha, int32_t V, void* stream) {
+                                 float* dalpha, int32_t V, float relu_scale, void* stream) {
   if (!c || !alpha || !dh || !dc || !dalpha || V <= 0) return SDUMC_EINVAL;
-  hipLaunchKernelGGL(hweight_bwd_kernel, dim3(V), dim3(256), 0, as_stream(stream), c, alpha, dh, dct, dc, dalpha, V);
+  hipLaunchKernelGGL(hweight_bwd_kernel, dim3(V), dim3(256), 0, as_stream(stream), c, alpha, dh, dct, dc, dalpha, V,
+                     relu_scale);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
 }

@@ -475,8 +475,10 @@ int colsum(const Ctx& c, const float* a, int64_t rows, int cols, int lda, float*
 
 // backward of y = act(x W^T + b) given dzv = gradient w.r.t. the pre-activation, [M, L.out] with ld lddz:
 //   dW = dz^T x, db = colsum(dz), dx (=|+=) dz W
+//   dx_y != nullptr: x itself is the saved output of a Linear->ReLU->Dropout layer; the dX GEMM's epilogue then
+//   multiplies dx by [dx_y > 0] * dx_scale, i.e. hands back the gradient w.r.t. that layer's PRE-activation
 int lin_bwd(const Ctx& c, const Lin& L, const float* dzv, int lddz, const float* x, int ldx, int M, float* dx, int lddx,
-            int dx_accumulate) {
+            int dx_accumulate, const float* dx_y = nullptr, float dx_scale = 1.f) {
   sdumc_gemm gw = G_(SDUMC_TN, L.out, L.in, M);
   gw.A[0] = dzv;
   gw.lda = lddz;
@@ -498,6 +500,8 @@ int lin_bwd(const Ctx& c, const Lin& L, const float* dzv, int lddz, const float*
     gx.C[0] = dx;
     gx.ldc = lddx;
     gx.accumulate = dx_accumulate;
+    gx.c_mask_y[0] = dx_y;
+    gx.c_mask_scale = dx_scale;
     RET(run(c, gx));
   }
   return SDUMC_OK;
@@ -508,6 +512,8 @@ struct GroupPtrs {
   const float* dz;  int64_t dz_gs;  int lddz;
   const float* x;   int64_t x_gs;   int ldx;
   float* dx;        int64_t dx_gs;  int lddx;
+  const float* dx_y = nullptr;   // see lin_bwd: same layout/strides as dx
+  float dx_scale = 1.f;
 };
 int lin_bwd_grouped(const Ctx& c, const Lin* L, int ng, int M, const GroupPtrs& q) {
   sdumc_gemm gw = G_(SDUMC_TN, L[0].out, L[0].in, M, ng);
@@ -520,6 +526,7 @@ int lin_bwd_grouped(const Ctx& c, const Lin* L, int ng, int M, const GroupPtrs& 
     gx.A[g] = q.dz + g * q.dz_gs;
     gx.B[g] = c.P + L[g].w;
     gx.C[g] = q.dx ? q.dx + g * q.dx_gs : nullptr;
+    gx.c_mask_y[g] = q.dx_y ? q.dx_y + g * q.dx_gs : nullptr;
   }
   gw.lda = q.lddz;
   gw.ldb = q.ldx;
@@ -529,6 +536,7 @@ int lin_bwd_grouped(const Ctx& c, const Lin* L, int ng, int M, const GroupPtrs& 
   RET(run(c, gw));
   c.use(0);
   if (q.dx) {
+    gx.c_mask_scale = q.dx_scale;
     gx.lda = q.lddz;
     gx.ldb = L[0].in;
     gx.ldc = q.lddx;
@@ -623,11 +631,12 @@ int forward(const Ctx& c) {
   for (int m = 0; m < 3; ++m) {
     c.use(LANE_OF[m]);
     if (c.d.train)   // Philox runs once per element here instead of ~10x in the kernels that stage these tiles
-      for (int k = 0; k < 2; ++k)
-        for (const Seg& sg : pl.segs[m]) {
-          sdumc_dropout d = mkdrop(c, SITE_IN[k][m], c.d.p_frame, sg.T, D, sg.s0);
-          RET(sdumc_dropout_bits(&d, sg.V / B, reinterpret_cast<uint8_t*>(c.p(pl.bits[k][m])) + sg.row0 * (D / 4), c.st));
-        }
+      for (const Seg& sg : pl.segs[m]) {   // both sites (fra2utt_m, cross_att_fra2utt_m) in one launch
+        sdumc_dropout d = mkdrop(c, SITE_IN[0][m], c.d.p_frame, sg.T, D, sg.s0);
+        uint8_t* outs[2] = {reinterpret_cast<uint8_t*>(c.p(pl.bits[0][m])) + sg.row0 * (D / 4),
+                            reinterpret_cast<uint8_t*>(c.p(pl.bits[1][m])) + sg.row0 * (D / 4)};
+        RET(sdumc_dropout_bits_multi(&d, sg.V / B, 2, SITE_IN[1][m] - SITE_IN[0][m], outs, c.st));
+      }
     for (int s = 0; s < (m == 1 ? S : 1); ++s) {
       const float* in = m == 0 ? c.io.audio : (m == 2 ? c.io.video : c.io.text[s]);
       RET(lin_fwd(c, pm.frame[m], in, din[m], B * pl.T[m][s], c.p(pl.x[m][s]), D, SDUMC_ACT_NONE, nullptr));
@@ -746,11 +755,16 @@ int forward(const Ctx& c) {
   RET(lin_fwd(c, pm.rnc0, c.p(pl.z), H, V, c.p(pl.r1), RD, SDUMC_ACT_RELU, nullptr));
   RET(lin_fwd(c, pm.rnc2, c.p(pl.r1), RD, V, c.p(pl.r), RD, SDUMC_ACT_NONE, nullptr));
   // outputs (model :370)
-  if (c.io.vals) RET(sdumc_copy2d(c.p(pl.vals), 1, c.io.vals, 1, V, 1, c.st));
-  if (c.io.fused) RET(sdumc_copy2d(c.p(pl.z), H, c.io.fused, H, V, H, c.st));
-  if (c.io.rnc) RET(sdumc_copy2d(c.p(pl.r), RD, c.io.rnc, RD, V, RD, c.st));
-  if (c.io.text_hidden) RET(sdumc_copy2d(c.p(pl.q) + 5 * D, NQ * D, c.io.text_hidden, D, V, D, c.st));
-  if (c.io.cross_text) RET(sdumc_copy2d(c.p(pl.c) + (int64_t)V * NQ * H, NQ * H, c.io.cross_text, NQ * H, V, NQ * H, c.st));
+  {
+    sdumc_copy_seg sg[5];
+    int n = 0;
+    if (c.io.vals) sg[n++] = {c.p(pl.vals), c.io.vals, 1, 1, V, 1};
+    if (c.io.fused) sg[n++] = {c.p(pl.z), c.io.fused, H, H, V, H};
+    if (c.io.rnc) sg[n++] = {c.p(pl.r), c.io.rnc, RD, RD, V, RD};
+    if (c.io.text_hidden) sg[n++] = {c.p(pl.q) + 5 * D, c.io.text_hidden, NQ * D, D, V, D};
+    if (c.io.cross_text) sg[n++] = {c.p(pl.c) + (int64_t)V * NQ * H, c.io.cross_text, NQ * H, NQ * H, V, NQ * H};
+    if (n) RET(sdumc_copy2d_multi(sg, n, c.st));
+  }
   return SDUMC_OK;
 }
 
@@ -817,13 +831,13 @@ int backward(const Ctx& c, const sdumc_net_grads& og) {
   const int B = pl.B, S = pl.S, V = pl.V;
   const int din[3] = {c.d.da, c.d.dt, c.d.dv};
   const float s_mlp = c.d.train ? 1.0f / (1.0f - (float)c.d.p_mlp) : 1.0f;
-  RET(sdumc_fill(c.G, 0.f, pm.live, c.st));
+  // every live gradient tensor is overwritten below when all five output gradients are given
+  if (!og.d_vals || !og.d_fused || !og.d_rnc || !og.d_text_hidden || !og.d_cross_text) RET(sdumc_fill(c.G, 0.f, pm.live, c.st));
 
   // 12'. heads: r = L2(relu(L0(z))), vals = fc_out_v(z), plus the external gradient of cross_fused_feat
   float* d_z = c.p(pl.d_z);
   if (og.d_rnc) {
-    RET(lin_bwd(c, pm.rnc2, og.d_rnc, RD, c.p(pl.r1), RD, V, c.p(pl.d_r1), RD, 0));
-    RET(sdumc_relu_drop_bwd(c.p(pl.d_r1), c.p(pl.r1), 1.0f, c.p(pl.d_r1), (int64_t)V * RD, c.st));
+    RET(lin_bwd(c, pm.rnc2, og.d_rnc, RD, c.p(pl.r1), RD, V, c.p(pl.d_r1), RD, 0, c.p(pl.r1), 1.0f));
     RET(lin_bwd(c, pm.rnc0, c.p(pl.d_r1), RD, c.p(pl.z), H, V, d_z, H, 0));
   } else {
     RET(sdumc_fill(d_z, 0.f, (int64_t)V * H, c.st));
@@ -832,20 +846,18 @@ int backward(const Ctx& c, const sdumc_net_grads& og) {
   if (og.d_fused) RET(sdumc_axpy2d(og.d_fused, H, d_z, H, V, H, c.st));
   RET(sdumc_zpool_bwd(c.p(pl.h), c.p(pl.beta), d_z, c.p(pl.d_h), c.p(pl.d_beta), V, c.st));
   // 11'. cross_fc_att, cross_attention_mlp
-  RET(lin_bwd(c, pm.cross_fc_att, c.p(pl.d_beta), NQ, c.p(pl.e2), H, V, c.p(pl.d_e2), H, 0));
-  RET(sdumc_relu_drop_bwd(c.p(pl.d_e2), c.p(pl.e2), s_mlp, c.p(pl.d_e2), (int64_t)V * H, c.st));
-  RET(lin_bwd(c, pm.catt3, c.p(pl.d_e2), H, c.p(pl.e1), D, V, c.p(pl.d_e1), D, 0));
-  RET(sdumc_relu_drop_bwd(c.p(pl.d_e1), c.p(pl.e1), s_mlp, c.p(pl.d_e1), (int64_t)V * D, c.st));
+  RET(lin_bwd(c, pm.cross_fc_att, c.p(pl.d_beta), NQ, c.p(pl.e2), H, V, c.p(pl.d_e2), H, 0, c.p(pl.e2), s_mlp));
+  RET(lin_bwd(c, pm.catt3, c.p(pl.d_e2), H, c.p(pl.e1), D, V, c.p(pl.d_e1), D, 0, c.p(pl.e1), s_mlp));
   RET(lin_bwd(c, pm.catt0, c.p(pl.d_e1), D, c.p(pl.h), NQ * H, V, c.p(pl.d_h), NQ * H, 1));
   // 10'. modality-weighted sum; the external gradient of cross_hiddens[:,1] joins here
-  RET(sdumc_hweight_bwd(c.p(pl.c), c.p(pl.alpha), c.p(pl.d_h), og.d_cross_text, c.p(pl.d_c), c.p(pl.d_alpha), V, c.st));
+  RET(sdumc_hweight_bwd(c.p(pl.c), c.p(pl.alpha), c.p(pl.d_h), og.d_cross_text, c.p(pl.d_c), c.p(pl.d_alpha), V, s_mlp,
+                        c.st));   // d_c comes out already masked: gradient w.r.t. the pre-activation of cross_*_mlp.3
   // 9'. cross_{audio,text,video}_mlp
   {
     const int M = V * NQ;
-    RET(sdumc_relu_drop_bwd(c.p(pl.d_c), c.p(pl.c), s_mlp, c.p(pl.d_c), 3LL * M * H, c.st));
-    GroupPtrs q3 = {c.p(pl.d_c), (int64_t)M * H, H, c.p(pl.c1), (int64_t)M * D, D, c.p(pl.d_c1), (int64_t)M * D, D};
+    GroupPtrs q3 = {c.p(pl.d_c), (int64_t)M * H, H, c.p(pl.c1), (int64_t)M * D, D, c.p(pl.d_c1), (int64_t)M * D, D,
+                    c.p(pl.c1), s_mlp};
     RET(lin_bwd_grouped(c, pm.cmlp3, 3, M, q3));
-    RET(sdumc_relu_drop_bwd(c.p(pl.d_c1), c.p(pl.c1), s_mlp, c.p(pl.d_c1), 3LL * M * D, c.st));
     GroupPtrs q0 = {c.p(pl.d_c1), (int64_t)M * D, D, c.p(pl.ca_out), (int64_t)M * D, D, c.p(pl.d_ca_out), (int64_t)M * D, D};
     RET(lin_bwd_grouped(c, pm.cmlp0, 3, M, q0));
   }
@@ -894,17 +906,15 @@ int backward(const Ctx& c, const sdumc_net_grads& og) {
   // 5'. fusion algebra (d_alpha already holds the second-level contribution)
   RET(sdumc_fusion_bwd(c.p(pl.u), c.p(pl.alpha), c.p(pl.d_qin), c.p(pl.d_u), c.p(pl.d_alpha), V, c.st));
   // 4'. fc_att, attention_mlp
-  RET(lin_bwd(c, pm.fc_att, c.p(pl.d_alpha), 3, c.p(pl.att2), D, V, c.p(pl.d_att2), D, 0));
-  RET(sdumc_relu_drop_bwd(c.p(pl.d_att2), c.p(pl.att2), s_mlp, c.p(pl.d_att2), (int64_t)V * D, c.st));
-  RET(lin_bwd(c, pm.att3, c.p(pl.d_att2), D, c.p(pl.att1), D, V, c.p(pl.d_att1), D, 0));
-  RET(sdumc_relu_drop_bwd(c.p(pl.d_att1), c.p(pl.att1), s_mlp, c.p(pl.d_att1), (int64_t)V * D, c.st));
-  RET(lin_bwd(c, pm.att0, c.p(pl.d_att1), D, c.p(pl.u), 3 * D, V, c.p(pl.d_u), 3 * D, 1));
+  RET(lin_bwd(c, pm.fc_att, c.p(pl.d_alpha), 3, c.p(pl.att2), D, V, c.p(pl.d_att2), D, 0, c.p(pl.att2), s_mlp));
+  RET(lin_bwd(c, pm.att3, c.p(pl.d_att2), D, c.p(pl.att1), D, V, c.p(pl.d_att1), D, 0, c.p(pl.att1), s_mlp));
+  //   d_u = (fusion part + att0 part) masked by u: the accumulate runs first, then the mask
+  RET(lin_bwd(c, pm.att0, c.p(pl.d_att1), D, c.p(pl.u), 3 * D, V, c.p(pl.d_u), 3 * D, 1, c.p(pl.u), s_mlp));
   // 3'. audio/text/video_mlp
   {
-    RET(sdumc_relu_drop_bwd(c.p(pl.d_u), c.p(pl.u), s_mlp, c.p(pl.d_u), 3LL * V * D, c.st));
-    GroupPtrs q3 = {c.p(pl.d_u), D, 3 * D, c.p(pl.u1), (int64_t)V * D, D, c.p(pl.d_u1), (int64_t)V * D, D};
+    GroupPtrs q3 = {c.p(pl.d_u), D, 3 * D, c.p(pl.u1), (int64_t)V * D, D, c.p(pl.d_u1), (int64_t)V * D, D,
+                    c.p(pl.u1), s_mlp};
     RET(lin_bwd_grouped(c, pm.umlp3, 3, V, q3));
-    RET(sdumc_relu_drop_bwd(c.p(pl.d_u1), c.p(pl.u1), s_mlp, c.p(pl.d_u1), 3LL * V * D, c.st));
     GroupPtrs q0 = {c.p(pl.d_u1), (int64_t)V * D, D, c.p(pl.hpre), (int64_t)V * D, D, c.p(pl.d_hpre), (int64_t)V * D, D};
     RET(lin_bwd_grouped(c, pm.umlp0, 3, V, q0));
   }

@@ -364,6 +364,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const sdumc_gemm g, con
   }
   float* C = g.C[grp];
   const float* bias = g.bias[grp];
+  const float* cy = g.c_mask_y[grp];   // optional: C = C * [Y > 0] * scale, applied last (after accumulate)
   DropRT cd = drop_resolve(g.c_drop);
   cd.site += (uint32_t)(grp * g.c_drop_group_stride);
 #pragma unroll
@@ -376,6 +377,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const sdumc_gemm g, con
     if (cd.enabled) v *= drop_mask1(cd, (uint32_t)row, (uint32_t)col);
     float* dst = C + (size_t)row * g.ldc + col;
     if (g.accumulate) v += *dst;
+    if (cy) v = cy[(size_t)row * g.ldc + col] > 0.f ? v * g.c_mask_scale : 0.f;
     *dst = v;
   }
 }
@@ -441,7 +443,9 @@ GemmPlan plan_gemm(const sdumc_gemm& g, size_t ws_bytes) {
   {   // launch-bound problems: at most 768 tiles of 32x32, K <= 1024, no operand-side fusions, no explicit split
     const long t32 = (long)((g.M + 31) / 32) * ((g.N + 31) / 32) * g.groups;
     const bool plain = !g.a_drop.enabled && !g.b_drop.enabled && g.a_row_mod == 0 && g.b_row_mod == 0;
-    if ((g.tile == 0 && g.splitk <= 1 && t32 <= 768 && g.K <= 1024 && plain) || g.tile == 3) {
+    bool masked = false;
+    for (int i = 0; i < g.groups; ++i) masked |= g.c_mask_y[i] != nullptr;   // only the small kernel implements it
+    if ((g.tile == 0 && g.splitk <= 1 && t32 <= 768 && g.K <= 1024 && plain) || g.tile == 3 || masked) {
       p.tile = 3;
       p.nsplit = 1;
       p.kchunk = ((((g.K + 3) / 4) + 7) / 8) * 8;   // k per wave

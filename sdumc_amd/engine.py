@@ -211,6 +211,7 @@ class TrainStep:
         self.graph = None
         goff = lib.sdumc_step_grads_offset(C.byref(self.dims))
         self.grads = self.workspace[goff:goff + 4 * self.layout.live].view(torch.float32)
+        self.grads.zero_()      # alignment padding between tensors is never written by the kernels
 
     def set_batch(self, audio, text, video, feat4, labels):
         """Copies one batch into the step's resident input buffers (shapes are fixed per TrainStep)."""
