@@ -243,6 +243,20 @@ size_t sdumc_rnc_workspace_bytes(int32_t n);
 int sdumc_rnc_fwd_bwd(const float* feats, const float* labels, int32_t n, int32_t dim, float temperature,
                       float weight, int32_t row0, int32_t rows_local, float* loss_out, float* dfeats,
                       float* workspace, void* stream);
+/* the same with the labels given once ([n/2]) and read as labels[j % (n/2)] (loss.py:283 labels.repeat(2, 1)) */
+int sdumc_rnc_fwd_bwd_rep(const float* feats, const float* labels_half, int32_t n, int32_t dim, float temperature,
+                          float weight, int32_t row0, int32_t rows_local, float* loss_out, float* dfeats,
+                          float* workspace, void* stream);
+/* The five batch-local terms of main :137-148 in two launches: MSELoss(vals_s, labels) for both streams and the
+ * three RMSELoss pairs (text_hidden, cross_text, fused; stream 1 vs stream 0, teacher side detached for the
+ * first two).  All tensors are the [2B, ...] stream-major network outputs; weights5 = (full_mse, missing_mse,
+ * text_feat, text_query_feat, features); denom = B_global; ssd_global = all-reduced sums or NULL (computed
+ * here).  Writes losses[1..5] (unweighted) and the four gradient buffers (every element, incl. the zeros). */
+size_t sdumc_distill_workspace_bytes(int32_t B);
+int sdumc_distill_fwd_bwd(int32_t B, float denom, const float* vals, const float* labels, const float* th,
+                          const float* ct, const float* z, const float* weights5, const float* ssd_global,
+                          float* d_vals, float* d_th, float* d_ct, float* d_z, float* losses, float* workspace,
+                          void* stream);
 /* gradient rows [row0, row0+rows) from the workspace a previous sdumc_rnc_fwd_bwd call filled
  * (a data-parallel rank owns two row ranges of the gathered matrix: its stream-0 and stream-1 rows) */
 int sdumc_rnc_dfeat_rows(const float* feats, int32_t n, int32_t dim, float temperature, float weight, int32_t row0,

@@ -129,6 +129,10 @@ _SIGS = {
     "sdumc_rnc_workspace_bytes": (C.c_size_t, [C.c_int32]),
     "sdumc_rnc_fwd_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32,
                                     C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdumc_rnc_fwd_bwd_rep": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32,
+                                        C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sdumc_distill_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "sdumc_distill_fwd_bwd": (C.c_int, [C.c_int32, C.c_float] + [C.c_void_p] * 14),
     "sdumc_rnc_dfeat_rows": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_int32, C.c_int32,
                                        C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdumc_rnc_mask": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -177,6 +181,8 @@ def _load():
             "or `make -C sdumc_amd/csrc`. sdumc_amd has no CPU or PyTorch fallback.")
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in _SIGS.items():
+        if os.environ.get("SDUMC_LIB") and not hasattr(lib, name):
+            continue             # A/B against an older build: it may lack newer entry points
         fn = getattr(lib, name)  # AttributeError (loud) if the symbol is missing
         fn.restype = res
         fn.argtypes = args

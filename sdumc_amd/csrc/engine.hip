@@ -991,7 +991,8 @@ LossScratch loss_scratch(const sdumc_net_dims& d, int B_global, float* base) {
     return o;
   };
   const int64_t o_ssd = al(4);
-  s.ssd_ws_each = (int64_t)(sdumc_ssd_workspace_bytes((int64_t)d.B * NQ * H) / sizeof(float)) + 64;
+  s.ssd_ws_each = std::max<int64_t>((int64_t)(sdumc_ssd_workspace_bytes((int64_t)d.B * NQ * H) / sizeof(float)) + 64,
+                                   (int64_t)(sdumc_distill_workspace_bytes(d.B) / sizeof(float)));
   const int64_t o_ws = al(3 * s.ssd_ws_each);
   const int64_t o_l2 = al(2LL * d.B);
   const int64_t o_rnc = al((int64_t)(sdumc_rnc_workspace_bytes(2 * Bg) / sizeof(float)));
@@ -1100,23 +1101,10 @@ extern "C" int sdumc_loss_backward(const sdumc_net_dims* d, const sdumc_net_io* 
   float* dct = const_cast<float*>(g->d_cross_text);
   float* L = cfg->losses;
   const float* w = cfg->weights;
-  // MSELoss on both streams (main :137-138)
-  RET(sdumc_mse_fwd_bwd(io->vals, cfg->labels, B, (float)Bg, w[0], L + 1, dv, st));
-  RET(sdumc_mse_fwd_bwd(io->vals + B, cfg->labels, B, (float)Bg, w[1], L + 2, dv + B, st));
-  // RMSELoss x3 (main :148): teacher side detached for text_feat / text_query_feat, not for features
-  const float* ssd = cfg->ssd_global;
-  if (!ssd) {
-    RET(loss_ssd(*d, *io, ls.ssd, ls, st));
-    ssd = ls.ssd;
-  }
-  RET(sdumc_fill(dth, 0.f, (int64_t)B * D, st));
-  RET(sdumc_rmse_bwd(io->text_hidden + (int64_t)B * D, io->text_hidden, (int64_t)B * D, ssd + 0, (double)Bg * D, w[2],
-                     L + 3, dth + (int64_t)B * D, 0, nullptr, 0, st));
-  RET(sdumc_fill(dct, 0.f, (int64_t)B * NQ * H, st));
-  RET(sdumc_rmse_bwd(io->cross_text + (int64_t)B * NQ * H, io->cross_text, (int64_t)B * NQ * H, ssd + 1,
-                     (double)Bg * NQ * H, w[3], L + 4, dct + (int64_t)B * NQ * H, 0, nullptr, 0, st));
-  RET(sdumc_rmse_bwd(io->fused + (int64_t)B * H, io->fused, (int64_t)B * H, ssd + 2, (double)Bg * H, w[4], L + 5,
-                     df + (int64_t)B * H, 0, df, 0, st));
+  // MSELoss x2 (main :137-138) + RMSELoss x3 (main :148; teacher side detached for text_feat / text_query_feat,
+  // not for features): value and gradients in two launches
+  RET(sdumc_distill_fwd_bwd(B, (float)Bg, io->vals, cfg->labels, io->text_hidden, io->cross_text, io->fused, w,
+                            cfg->ssd_global, dv, dth, dct, df, L, ls.ssd_ws, stream));
   // RnCLoss over cat(r_stream0, r_stream1) with labels repeated (main :134,:140; loss.py:282-283)
   if (cfg->rnc_feats_global) {
     if (!cfg->rnc_labels_global) return SDUMC_EINVAL;
@@ -1125,9 +1113,7 @@ extern "C" int sdumc_loss_backward(const sdumc_net_dims* d, const sdumc_net_io* 
     RET(sdumc_rnc_dfeat_rows(cfg->rnc_feats_global, 2 * Bg, RD, cfg->temperature, w[5], cfg->rnc_row0[1], B,
                              dr + (int64_t)B * RD, ls.rnc_ws, st));
   } else {
-    RET(sdumc_copy2d(cfg->labels, 1, ls.labels2, 1, B, 1, st));
-    RET(sdumc_copy2d(cfg->labels, 1, ls.labels2 + B, 1, B, 1, st));
-    RET(sdumc_rnc_fwd_bwd(io->rnc, ls.labels2, 2 * B, RD, cfg->temperature, w[5], 0, 2 * B, L + 6, dr, ls.rnc_ws, st));
+    RET(sdumc_rnc_fwd_bwd_rep(io->rnc, cfg->labels, 2 * B, RD, cfg->temperature, w[5], 0, 2 * B, L + 6, dr, ls.rnc_ws, st));
   }
   hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(1), 0, st, L, w[0], w[1], w[2], w[3], w[4], w[5]);
   SDUMC_CHECK_LAUNCH();

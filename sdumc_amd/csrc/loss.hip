@@ -82,67 +82,6 @@ __host__ __device__ inline RncWs rnc_ws(float* w, int n) {
   return r;
 }
 
-// one workgroup per anchor row i: distances, label differences, row max, exp
-__global__ __launch_bounds__(256) void rnc_pairs_kernel(const float* f, const float* y, int n, int dim, float inv_t,
-                                                        RncWs w) {
-  extern __shared__ float fi[];  // [dim]
-  __shared__ float red[4];
-  const int i = blockIdx.x;
-  for (int c = threadIdx.x; c < dim; c += 256) fi[c] = f[(size_t)i * dim + c];
-  __syncthreads();
-  const float yi = y[i];
-  float mx = -INFINITY;
-  for (int j = threadIdx.x; j < n; j += 256) {
-    float s = 0.f;
-    for (int c = 0; c < dim; ++c) {
-      const float d = fi[c] - f[(size_t)j * dim + c];
-      s += d * d;
-    }
-    const float dist = sqrtf(s);
-    w.dist[(size_t)i * n + j] = dist;
-    w.ldiff[(size_t)i * n + j] = fabsf(yi - y[j]);
-    mx = fmaxf(mx, -dist * inv_t);
-  }
-  mx = wave_max(mx);
-  __syncthreads();
-  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
-  __syncthreads();
-  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-  if (threadIdx.x == 0) w.rowmax[i] = mx;
-  for (int j = threadIdx.x; j < n; j += 256) w.e[(size_t)i * n + j] = expf(-w.dist[(size_t)i * n + j] * inv_t - mx);
-}
-
-// one workgroup per anchor i: D_ik = sum_{j != i} [ldiff_ij >= ldiff_ik - 1e-4] e_ij ; row loss
-__global__ __launch_bounds__(256) void rnc_denoms_kernel(int n, float inv_t, RncWs w) {
-  extern __shared__ float sm[];  // ld[n], e[n]
-  __shared__ float red[4];
-  float* ld = sm;
-  float* ee = sm + n;
-  const int i = blockIdx.x;
-  for (int j = threadIdx.x; j < n; j += 256) {
-    ld[j] = w.ldiff[(size_t)i * n + j];
-    ee[j] = w.e[(size_t)i * n + j];
-  }
-  __syncthreads();
-  const float mx = w.rowmax[i];
-  float acc = 0.f;
-  for (int k = threadIdx.x; k < n; k += 256) {
-    if (k == i) {
-      w.invD[(size_t)i * n + k] = 0.f;
-      continue;
-    }
-    const float thr = __fsub_rn(ld[k], 0.0001f);
-    float dsum = 0.f;
-    for (int j = 0; j < n; ++j)
-      if (j != i && ld[j] >= thr) dsum += ee[j];
-    w.invD[(size_t)i * n + k] = 1.f / dsum;
-    const float logit = -w.dist[(size_t)i * n + k] * inv_t - mx;
-    acc += logit - logf(dsum);
-  }
-  const float s = block_sum_256(acc, red);
-  if (threadIdx.x == 0) w.rowloss[i] = s;
-}
-
 __global__ __launch_bounds__(256) void rnc_loss_kernel(int n, RncWs w, float* loss_out) {
   __shared__ float red[4];
   float acc = 0.f;
@@ -151,26 +90,70 @@ __global__ __launch_bounds__(256) void rnc_loss_kernel(int n, RncWs w, float* lo
   if (threadIdx.x == 0) *loss_out = -s / ((float)n * (float)(n - 1));
 }
 
-// G_ij = dLoss/dlogit_ij = -c (1 - e_ij sum_{k != i} [ldiff_ij >= ldiff_ik - 1e-4] / D_ik)
-__global__ __launch_bounds__(256) void rnc_glogit_kernel(int n, RncWs w) {
-  extern __shared__ float sm[];  // thr[n], invD[n]
-  float* thr = sm;
-  float* iD = sm + n;
+// One workgroup per anchor i, everything that depends on row i only: distances, label differences, exp,
+// the masked denominators D_ik, the row's loss and G_i* = dLoss/dlogit_i*.  labels: y[j] = labels[j % label_mod]
+// when label_mod > 0 (the reference's labels.repeat(2, 1), loss.py:283, without materialising it).
+__global__ __launch_bounds__(256) void rnc_row_kernel(const float* f, const float* labels, int label_mod, int n,
+                                                      int dim, float inv_t, RncWs w, int want_grad) {
+  extern __shared__ float sm[];   // fi[dim] | ld[n] | ee[n] | dd[n] | thr[n] | iD[n]
+  __shared__ float red[4];
+  float* fi = sm;
+  float* ld = fi + ((dim + 3) & ~3);
+  float* ee = ld + n;
+  float* dd = ee + n;
+  float* thr = dd + n;
+  float* iD = thr + n;
   const int i = blockIdx.x;
-  for (int k = threadIdx.x; k < n; k += 256) {
-    thr[k] = __fsub_rn(w.ldiff[(size_t)i * n + k], 0.0001f);
-    iD[k] = w.invD[(size_t)i * n + k];
+  for (int c = threadIdx.x; c < dim; c += 256) fi[c] = f[(size_t)i * dim + c];
+  __syncthreads();
+  const float yi = labels[label_mod > 0 ? i % label_mod : i];
+  float mx = -INFINITY;
+  for (int j = threadIdx.x; j < n; j += 256) {
+    float s = 0.f;
+    for (int c = 0; c < dim; ++c) {
+      const float d = fi[c] - f[(size_t)j * dim + c];
+      s += d * d;
+    }
+    const float dist = sqrtf(s);
+    dd[j] = dist;
+    w.dist[(size_t)i * n + j] = dist;
+    const float l = fabsf(yi - labels[label_mod > 0 ? j % label_mod : j]);
+    ld[j] = l;
+    thr[j] = __fsub_rn(l, 0.0001f);
+    mx = fmaxf(mx, -dist * inv_t);
   }
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  for (int j = threadIdx.x; j < n; j += 256) ee[j] = expf(-dd[j] * inv_t - mx);
+  __syncthreads();
+  float acc = 0.f;
+  for (int k = threadIdx.x; k < n; k += 256) {
+    if (k == i) {
+      iD[k] = 0.f;
+      continue;
+    }
+    const float t = thr[k];
+    float dsum = 0.f;
+    for (int j = 0; j < n; ++j)
+      if (j != i && ld[j] >= t) dsum += ee[j];
+    iD[k] = 1.f / dsum;
+    acc += (-dd[k] * inv_t - mx) - logf(dsum);
+  }
+  const float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) w.rowloss[i] = s;
+  if (!want_grad) return;
   __syncthreads();
   const float c = 1.f / ((float)n * (float)(n - 1));
   for (int j = threadIdx.x; j < n; j += 256) {
     float g = 0.f;
     if (j != i) {
-      const float lj = w.ldiff[(size_t)i * n + j];
-      float s = 0.f;
+      const float lj = ld[j];
+      float sum = 0.f;
       for (int k = 0; k < n; ++k)
-        if (k != i && lj >= thr[k]) s += iD[k];
-      g = -c * (1.f - w.e[(size_t)i * n + j] * s);
+        if (k != i && lj >= thr[k]) sum += iD[k];
+      g = -c * (1.f - ee[j] * sum);
     }
     w.G[(size_t)i * n + j] = g;
   }
@@ -217,6 +200,90 @@ __global__ void rnc_mask_kernel(const float* y, int n, uint8_t* mask) {
   mask[e] = dij >= __fsub_rn(dik, 0.0001f) ? 1 : 0;
 }
 
+
+// ---- the five "small" distillation terms of main :137-148 in two launches -------------------------------
+// pass 1: per-block partial sums of squared differences of the three RMSE pairs (+ both MSE terms, block 0)
+// pass 2: every block re-reduces the (few) partials in a fixed order, then writes the gradients of its chunk
+struct DistillArgs {
+  int B;            // local samples per stream
+  float denom;      // B_global
+  const float *vals, *labels, *th, *ct, *z;   // network outputs [2B, ...]
+  float w[5];       // full_mse, missing_mse, text_feat, text_query_feat, features
+  const float* ssd_global;                      // [3] or nullptr
+  float *d_vals, *d_th, *d_ct, *d_z;
+  float* losses;    // [8]: writes 1..5
+  float* part;      // [3][nblk]
+  int nblk[3];
+};
+constexpr int DCH = 4096;   // elements per block
+__device__ __forceinline__ void distill_pair(const DistillArgs& a, int p, const float*& s1, const float*& s0, float*& g,
+                                             int64_t& n) {
+  const int64_t per = p == 0 ? SDUMC_D : (p == 1 ? SDUMC_NQ * SDUMC_H : SDUMC_H);
+  n = (int64_t)a.B * per;
+  const float* base = p == 0 ? a.th : (p == 1 ? a.ct : a.z);
+  s0 = base;
+  s1 = base + n;
+  g = p == 0 ? a.d_th : (p == 1 ? a.d_ct : a.d_z);
+}
+__global__ __launch_bounds__(256) void distill_partials_kernel(const DistillArgs a) {
+  __shared__ float red[4];
+  const int p = blockIdx.y;
+  if ((int)blockIdx.x >= a.nblk[p]) return;
+  const float *s1, *s0;
+  float* g;
+  int64_t n;
+  distill_pair(a, p, s1, s0, g, n);
+  const int64_t i0 = (int64_t)blockIdx.x * DCH, i1 = min(n, i0 + DCH);
+  float acc = 0.f;
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    const float d = s1[i] - s0[i];
+    acc += d * d;
+  }
+  const float s = block_sum_256(acc, red);
+  if (threadIdx.x == 0) a.part[p * a.nblk[1] + blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void distill_apply_kernel(const DistillArgs a) {
+  __shared__ float red[4];
+  const int p = blockIdx.y;
+  if (p == 3) {   // MSELoss on both streams (loss.py:19-33): value + gradient
+    if (blockIdx.x > 1) return;
+    const int sidx = blockIdx.x;
+    const float inv = 1.f / a.denom;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < a.B; i += 256) {
+      const float d = a.vals[sidx * a.B + i] - a.labels[i];
+      acc += d * d;
+      a.d_vals[sidx * a.B + i] = a.w[sidx] * 2.f * d * inv;
+    }
+    const float s = block_sum_256(acc, red);
+    if (threadIdx.x == 0) a.losses[1 + sidx] = s * inv;
+    return;
+  }
+  if ((int)blockIdx.x >= a.nblk[p]) return;
+  const float *s1, *s0;
+  float* g;
+  int64_t n;
+  distill_pair(a, p, s1, s0, g, n);
+  float ssd;
+  if (a.ssd_global) {
+    ssd = a.ssd_global[p];
+  } else {   // ordered re-reduction of the partials (identical in every block)
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < a.nblk[p]; i += 256) acc += a.part[p * a.nblk[1] + i];
+    ssd = block_sum_256(acc, red);
+  }
+  const float per = p == 0 ? SDUMC_D : (p == 1 ? SDUMC_NQ * SDUMC_H : SDUMC_H);
+  const float inv_numel = 1.f / (a.denom * per);
+  const float rmse = sqrtf(ssd * inv_numel);
+  if (blockIdx.x == 0 && threadIdx.x == 0) a.losses[3 + p] = rmse;
+  const float k = a.w[2 + p] * inv_numel / rmse;   // 0/0 -> NaN exactly like torch's sqrt backward
+  const int64_t i0 = (int64_t)blockIdx.x * DCH, i1 = min(n, i0 + DCH);
+  for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+    const float gr = k * (s1[i] - s0[i]);
+    g[n + i] = gr;                        // stream 1 (student)
+    g[i] = p == 2 ? -gr : 0.f;           // stream 0: detached for text_feat / text_query_feat (main :148), not for features
+  }
+}
 }  // namespace
 
 extern "C" int sdumc_mse_fwd_bwd(const float* pred, const float* target, int32_t rows, float denom, float weight,
@@ -253,28 +320,79 @@ extern "C" int sdumc_rmse_bwd(const float* a, const float* b, int64_t n_local, c
 
 extern "C" size_t sdumc_rnc_workspace_bytes(int32_t n) { return ((size_t)5 * n * n + 2 * (size_t)n) * sizeof(float); }
 
-extern "C" int sdumc_rnc_fwd_bwd(const float* feats, const float* labels, int32_t n, int32_t dim, float temperature,
-                                 float weight, int32_t row0, int32_t rows_local, float* loss_out, float* dfeats,
-                                 float* workspace, void* stream) {
+static int rnc_impl(const float* feats, const float* labels, int label_mod, int32_t n, int32_t dim, float temperature,
+                    float weight, int32_t row0, int32_t rows_local, float* loss_out, float* dfeats, float* workspace,
+                    void* stream) {
   if (!feats || !labels || !loss_out || !workspace || n < 2 || dim <= 0 || temperature <= 0.f) return SDUMC_EINVAL;
   if (row0 < 0 || rows_local < 0 || row0 + rows_local > n) return SDUMC_EINVAL;
-  if ((size_t)n * 2 * sizeof(float) + 1024 > 64 * 1024) return SDUMC_EINVAL;  // n <= ~8000
   hipStream_t st = as_stream(stream);
   const RncWs w = rnc_ws(workspace, n);
   const float inv_t = 1.f / temperature;
-  hipLaunchKernelGGL(rnc_pairs_kernel, dim3(n), dim3(256), dim * sizeof(float), st, feats, labels, n, dim, inv_t, w);
-  SDUMC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(rnc_denoms_kernel, dim3(n), dim3(256), 2 * n * sizeof(float), st, n, inv_t, w);
+  const int want_grad = dfeats && rows_local > 0;
+  const size_t lds = (((size_t)dim + 3) & ~(size_t)3) * sizeof(float) + 5 * (size_t)n * sizeof(float);
+  if (lds > 64 * 1024) return SDUMC_EINVAL;
+  hipLaunchKernelGGL(rnc_row_kernel, dim3(n), dim3(256), lds, st, feats, labels, label_mod, n, dim, inv_t, w, want_grad);
   SDUMC_CHECK_LAUNCH();
   hipLaunchKernelGGL(rnc_loss_kernel, dim3(1), dim3(256), 0, st, n, w, loss_out);
   SDUMC_CHECK_LAUNCH();
-  if (dfeats && rows_local > 0) {
-    hipLaunchKernelGGL(rnc_glogit_kernel, dim3(n), dim3(256), 2 * n * sizeof(float), st, n, w);
-    SDUMC_CHECK_LAUNCH();
+  if (want_grad) {
     hipLaunchKernelGGL(rnc_dfeat_kernel, dim3(rows_local), dim3(256), (n + 256) * sizeof(float), st, feats, n, dim,
                        inv_t, weight, row0, w, dfeats);
     SDUMC_CHECK_LAUNCH();
   }
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_rnc_fwd_bwd(const float* feats, const float* labels, int32_t n, int32_t dim, float temperature,
+                                 float weight, int32_t row0, int32_t rows_local, float* loss_out, float* dfeats,
+                                 float* workspace, void* stream) {
+  return rnc_impl(feats, labels, 0, n, dim, temperature, weight, row0, rows_local, loss_out, dfeats, workspace, stream);
+}
+
+// labels given once ([n/2]) and read as labels[j % (n/2)]: the reference's labels.repeat(2, 1) (loss.py:283)
+extern "C" int sdumc_rnc_fwd_bwd_rep(const float* feats, const float* labels_half, int32_t n, int32_t dim,
+                                     float temperature, float weight, int32_t row0, int32_t rows_local, float* loss_out,
+                                     float* dfeats, float* workspace, void* stream) {
+  if (n & 1) return SDUMC_EINVAL;
+  return rnc_impl(feats, labels_half, n / 2, n, dim, temperature, weight, row0, rows_local, loss_out, dfeats, workspace,
+                  stream);
+}
+
+extern "C" size_t sdumc_distill_workspace_bytes(int32_t B) {
+  const int64_t nb = ((int64_t)B * SDUMC_NQ * SDUMC_H + DCH - 1) / DCH;
+  return (size_t)(3 * nb + 64) * sizeof(float);
+}
+
+// MSE x2 + RMSE x3 of main :137-148 (value + gradients w.r.t. the network outputs) in two launches
+extern "C" int sdumc_distill_fwd_bwd(int32_t B, float denom, const float* vals, const float* labels, const float* th,
+                                     const float* ct, const float* z, const float* weights5, const float* ssd_global,
+                                     float* d_vals, float* d_th, float* d_ct, float* d_z, float* losses,
+                                     float* workspace, void* stream) {
+  if (B <= 0 || denom <= 0.f || !vals || !labels || !th || !ct || !z || !weights5 || !d_vals || !d_th || !d_ct || !d_z ||
+      !losses || !workspace)
+    return SDUMC_EINVAL;
+  DistillArgs a;
+  a.B = B;
+  a.denom = denom;
+  a.vals = vals; a.labels = labels; a.th = th; a.ct = ct; a.z = z;
+  for (int i = 0; i < 5; ++i) a.w[i] = weights5[i];
+  a.ssd_global = ssd_global;
+  a.d_vals = d_vals; a.d_th = d_th; a.d_ct = d_ct; a.d_z = d_z;
+  a.losses = losses;
+  a.part = workspace;
+  const int64_t per[3] = {SDUMC_D, SDUMC_NQ * SDUMC_H, SDUMC_H};
+  int mx = 1;
+  for (int p = 0; p < 3; ++p) {
+    a.nblk[p] = (int)(((int64_t)B * per[p] + DCH - 1) / DCH);
+    mx = a.nblk[p] > mx ? a.nblk[p] : mx;
+  }
+  hipStream_t st = as_stream(stream);
+  if (!ssd_global) {
+    hipLaunchKernelGGL(distill_partials_kernel, dim3(mx, 3), dim3(256), 0, st, a);
+    SDUMC_CHECK_LAUNCH();
+  }
+  hipLaunchKernelGGL(distill_apply_kernel, dim3(mx > 2 ? mx : 2, 4), dim3(256), 0, st, a);
+  SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
 }
 
