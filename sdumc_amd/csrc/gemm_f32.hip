@@ -317,20 +317,31 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdumc_gemm g, const int
         for (int j = 0; j < BM / 32; ++j) csum += ra[j];
       }
     }
+    // fragment reads are software-pipelined over two register sets: group g+1 is read from LDS while the
+    // MFMAs of group g issue (with one set the compiler emitted read -> lgkmcnt(0) -> 4 MFMA, four times,
+    // exposing the LDS latency of every group)
+    f32x4 af[2][TM], bf[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) af[0][i] = read_frag<BM, A_K>(As, wm0 + 32 * i, 0, li, lh);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) bf[0][j] = read_frag<BN, B_K>(Bs, wn0 + 32 * j, 0, li, lh);
 #pragma unroll
     for (int gq = 0; gq < BK / 8; ++gq) {
-      f32x4 af[TM], bf[TN];
+      const int cur = gq & 1, nxt = cur ^ 1;
+      if (gq + 1 < BK / 8) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = read_frag<BM, A_K>(As, wm0 + 32 * i, gq, li, lh);
+        for (int i = 0; i < TM; ++i) af[nxt][i] = read_frag<BM, A_K>(As, wm0 + 32 * i, gq + 1, li, lh);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) bf[j] = read_frag<BN, B_K>(Bs, wn0 + 32 * j, gq, li, lh);
+        for (int j = 0; j < TN; ++j) bf[nxt][j] = read_frag<BN, B_K>(Bs, wn0 + 32 * j, gq + 1, li, lh);
+      }
+      __builtin_amdgcn_sched_barrier(0);   // keep the reads above ahead of the MFMAs below (hipcc sinks them otherwise)
 #pragma unroll
       for (int s = 0; s < 4; ++s)
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][s], bf[j][s], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][s], bf[cur][j][s], acc[i][j], 0, 0, 0);
     }
   }
 
