@@ -104,6 +104,8 @@ typedef struct sdumc_gemm {
   float c_mask_scale;
   float* colsum_a[SDUMC_MAX_GROUPS]; /* TN only, optional: out[m] (+)= sum_k A[k,m] fused into the staging of A
                            (the bias gradient when A = dz); `accumulate` applies to it too */
+  int32_t bf16;         /* 1: NT only -- operands rounded to bf16 while staged, v_mfma_f32_32x32x16_bf16, fp32 accumulate
+                           and fp32 epilogue (the "bf16 compute" mode, BASELINE configs[2]); 0: exact fp32 (default) */
   float* workspace;
   size_t workspace_bytes;
 } sdumc_gemm;

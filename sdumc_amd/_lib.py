@@ -38,6 +38,7 @@ class Gemm(C.Structure):
                 ("ab_drop_group_stride", C.c_int32), ("ab_drop_bits", C.c_void_p * MAX_GROUPS),
                 ("c_mask_y", C.c_void_p * MAX_GROUPS), ("c_mask_scale", C.c_float),
                 ("colsum_a", C.c_void_p * MAX_GROUPS),
+                ("bf16", C.c_int32),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 

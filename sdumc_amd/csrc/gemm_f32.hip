@@ -36,10 +36,11 @@ struct ProfRec {
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::mutex g_prof_mu;
-constexpr int kNumVariants = 9;
+constexpr int kNumVariants = 11;
 const char* const kVariantName[kNumVariants] = {"gemm_nt_128x128", "gemm_nt_64x64",  "gemm_nn_128x128",
                                                 "gemm_nn_64x64",   "gemm_tn_128x128", "gemm_tn_64x64",
-                                                "gemm_small_nt",   "gemm_small_nn",   "gemm_small_tn"};
+                                                "gemm_small_nt",   "gemm_small_nn",   "gemm_small_tn",
+                                                "gemm_bf16_nt_128x128", "gemm_bf16_nt_64x64"};
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;
@@ -224,8 +225,16 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
-template <int BM, int BN, bool A_K, bool B_K>
+// BF16 = true (NT layout only): the staged operands are rounded to bf16 (v_cvt_pk_bf16_f32, RNE) on their way into
+// LDS and multiplied on v_mfma_f32_32x32x16_bf16 -- 16x the fp32 MFMA rate -- with fp32 accumulation and the same
+// fp32 epilogue.  This is the "bf16 compute" mode of BASELINE configs[2]; the default path is exact fp32.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int LDH = BK + 8;   // bf16 elements per LDS row (80 B): the 16-B fragment reads are conflict-free
+
+template <int BM, int BN, bool A_K, bool B_K, bool BF16 = false>
 __global__ __launch_bounds__(256) void gemm_kernel(const sdumc_gemm g, const int nsplit, const int kchunk) {
+  static_assert(!BF16 || (A_K && B_K), "the bf16 variant is built for the NT layout");
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int A_ELEMS = A_K ? BM * LDK : BK * BM;
   constexpr int B_ELEMS = B_K ? BN * LDK : BK * BN;
@@ -301,8 +310,23 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdumc_gemm g, const int
   }
   for (int k0 = kbeg; k0 < kend; k0 += BK) {
     __syncthreads();  // everyone is done reading the previous tile
-    store_tile<BM, A_K>(As, ra, tid);
-    store_tile<BN, B_K>(Bs, rb, tid);
+    if constexpr (BF16) {
+      __bf16* Ah = reinterpret_cast<__bf16*>(As);
+      __bf16* Bh = reinterpret_cast<__bf16*>(Bs);
+#pragma unroll
+      for (int j = 0; j < BM / 32; ++j) {
+        bf16x4 h = {(__bf16)ra[j][0], (__bf16)ra[j][1], (__bf16)ra[j][2], (__bf16)ra[j][3]};
+        *reinterpret_cast<bf16x4*>(Ah + ((tid >> 3) + 32 * j) * LDH + 4 * (tid & 7)) = h;
+      }
+#pragma unroll
+      for (int j = 0; j < BN / 32; ++j) {
+        bf16x4 h = {(__bf16)rb[j][0], (__bf16)rb[j][1], (__bf16)rb[j][2], (__bf16)rb[j][3]};
+        *reinterpret_cast<bf16x4*>(Bh + ((tid >> 3) + 32 * j) * LDH + 4 * (tid & 7)) = h;
+      }
+    } else {
+      store_tile<BM, A_K>(As, ra, tid);
+      store_tile<BN, B_K>(Bs, rb, tid);
+    }
     __syncthreads();
     if (k0 + BK < kend) {  // prefetch: in flight during the MFMAs below
       if (fast) {
@@ -316,6 +340,27 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdumc_gemm g, const int
 #pragma unroll
         for (int j = 0; j < BM / 32; ++j) csum += ra[j];
       }
+    }
+    if constexpr (BF16) {
+      // lane (r = lane&31, h = lane>>5) holds A[row r][k = 16 ks + 8 h .. +7] and the same k range of B's row
+      const __bf16* Ah = reinterpret_cast<const __bf16*>(As);
+      const __bf16* Bh = reinterpret_cast<const __bf16*>(Bs);
+      bf16x8 ah[BK / 16][TM], bh[BK / 16][TN];
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) ah[ks][i] = *reinterpret_cast<const bf16x8*>(Ah + (wm0 + 32 * i + li) * LDH + 16 * ks + 8 * lh);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bh[ks][j] = *reinterpret_cast<const bf16x8*>(Bh + (wn0 + 32 * j + li) * LDH + 16 * ks + 8 * lh);
+      }
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
+      continue;
     }
     // fragment reads are software-pipelined over two register sets: group g+1 is read from LDS while the
     // MFMAs of group g issue (with one set the compiler emitted read -> lgkmcnt(0) -> 4 MFMA, four times,
@@ -563,7 +608,7 @@ GemmPlan plan_gemm(const sdumc_gemm& g, size_t ws_bytes) {
     const bool plain = !g.a_drop.enabled && !g.b_drop.enabled && g.a_row_mod == 0 && g.b_row_mod == 0;
     bool masked = false;
     for (int i = 0; i < g.groups; ++i) masked |= g.c_mask_y[i] != nullptr;   // only the small kernel implements it
-    if ((g.tile == 0 && g.splitk <= 1 && t32 <= 768 && g.K <= 1024 && plain) || g.tile == 3 || masked) {
+    if (!g.bf16 && ((g.tile == 0 && g.splitk <= 1 && t32 <= 768 && g.K <= 1024 && plain) || g.tile == 3 || masked)) {
       p.tile = 3;
       p.nsplit = 1;
       p.kchunk = ((((g.K + 3) / 4) + 7) / 8) * 8;   // k per wave
@@ -593,6 +638,10 @@ GemmPlan plan_gemm(const sdumc_gemm& g, size_t ws_bytes) {
 template <int BM, int BN>
 int launch(const sdumc_gemm& g, int nsplit, int kchunk, hipStream_t st) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.groups * nsplit);
+  if (g.bf16) {   // NT only (checked by the caller)
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, true>), grid, dim3(256), 0, st, g, nsplit, kchunk);
+    return SDUMC_OK;
+  }
   switch (g.layout) {
     case SDUMC_NT: hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true>), grid, dim3(256), 0, st, g, nsplit, kchunk); break;
     case SDUMC_NN: hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false>), grid, dim3(256), 0, st, g, nsplit, kchunk); break;
@@ -622,6 +671,11 @@ extern "C" int sdumc_gemm_f32(const sdumc_gemm* gp, void* stream) {
     return SDUMC_EINVAL;
   for (int i = 0; i < g.groups; ++i)
     if (g.colsum_a[i] && g.layout != SDUMC_TN) return SDUMC_EINVAL;
+  if (g.bf16) {   // bf16 operands: NT layout, 16-byte aligned rows, k a multiple of 4
+    if (g.layout != SDUMC_NT || (g.lda & 3) || (g.ldb & 3) || (g.K & 3)) return SDUMC_EINVAL;
+    for (int i = 0; i < g.groups; ++i)
+      if ((reinterpret_cast<uintptr_t>(g.A[i]) | reinterpret_cast<uintptr_t>(g.B[i])) & 15) return SDUMC_EINVAL;
+  }
   const GemmPlan pl = plan_gemm(g, g.workspace ? g.workspace_bytes : 0);
   const int nsplit = pl.nsplit, kchunk = pl.kchunk, tile = pl.tile;
   if (nsplit > 1 && (!g.workspace || g.workspace_bytes < plan_ws_bytes(g, nsplit))) return SDUMC_ENOMEM;
@@ -630,7 +684,7 @@ extern "C" int sdumc_gemm_f32(const sdumc_gemm* gp, void* stream) {
   const bool prof = g_prof_on;
   if (prof) {
     if (hipEventCreate(&rec.a) != hipSuccess || hipEventCreate(&rec.b) != hipSuccess) return SDUMC_ELAUNCH;
-    rec.variant = tile == 3 ? 6 + g.layout : g.layout * 2 + (tile == 1 ? 0 : 1);
+    rec.variant = g.bf16 ? (tile == 1 ? 9 : 10) : tile == 3 ? 6 + g.layout : g.layout * 2 + (tile == 1 ? 0 : 1);
     rec.flops = 2.0 * g.M * (double)g.N * g.K * g.groups;
     (void)hipEventRecord(rec.a, st);
   }

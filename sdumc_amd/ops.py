@@ -18,7 +18,7 @@ def _st():
 
 def gemm(layout, A, B, M, N, K, bias=None, C_out=None, lda=None, ldb=None, ldc=None, act=ACT_NONE, a_row_mod=0,
          b_row_mod=0, a_drop=None, b_drop=None, c_drop=None, c_drop_group_stride=0, accumulate=False, splitk=1,
-         tile=0, colsum_a=None, ab_drop_group_stride=0, ab_drop_bits=None, c_mask_y=None, c_mask_scale=1.0):
+         tile=0, colsum_a=None, ab_drop_group_stride=0, ab_drop_bits=None, c_mask_y=None, c_mask_scale=1.0, bf16=False):
     """Grouped when A/B/(bias)/C_out are lists."""
     As = A if isinstance(A, (list, tuple)) else [A]
     Bs = B if isinstance(B, (list, tuple)) else [B]
@@ -46,6 +46,7 @@ def gemm(layout, A, B, M, N, K, bias=None, C_out=None, lda=None, ldb=None, ldc=N
     g.c_drop_group_stride = c_drop_group_stride
     g.act, g.accumulate, g.splitk, g.tile = act, 1 if accumulate else 0, splitk, tile
     g.ab_drop_group_stride = ab_drop_group_stride
+    g.bf16 = 1 if bf16 else 0
     if c_mask_y is not None:
         ys = c_mask_y if isinstance(c_mask_y, (list, tuple)) else [c_mask_y]
         for i in range(groups):

@@ -130,6 +130,18 @@ def test_gemm_small_kernel_all_layouts(ops, M, N, K):
     assert torch.equal(got, again)
 
 
+@pytest.mark.parametrize("M,N,K,tile", [(300, 256, 1024, 2), (2048, 256, 4096, 0), (513, 130, 96, 1), (48000, 256, 256, 0)])
+def test_gemm_bf16_operand_mode(ops, M, N, K, tile):
+    """bf16=True: operands rounded to bf16 (RNE) while staged, fp32 accumulate: must equal the fp64 product of the
+    bf16-rounded operands to fp32-accumulation accuracy, and stay within bf16 distance of the exact product."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
+    got = ops.gemm(ops.NT, dev(A), dev(W), M, N, K, bias=dev(b), act=ops.ACT_TANH, tile=tile, splitk=0, bf16=True)
+    Ab, Wb = A.bfloat16().double(), W.bfloat16().double()
+    close(got, torch.tanh(Ab @ Wb.T + b.double()), 2e-5)
+    close(got, torch.tanh(A.double() @ W.double().T + b.double()), 2e-2)
+
+
 def test_gemm_grouped_strided_and_dropout(ops):
     from oracle import philox
     from sdumc_amd._lib import make_dropout

@@ -30,6 +30,9 @@ for name, fn in [
     ("+row_mod+philox", lambda: ops.gemm(ops.NT, x, W, M, D, D, C_out=C, a_row_mod=B * T, a_drop=d, splitk=1)),
     ("+row_mod+bits", lambda: ops.gemm(ops.NT, x, W, M, D, D, C_out=C, a_row_mod=B * T, a_drop=db, splitk=1)),
     ("all (bits,tanh)", lambda: ops.gemm(ops.NT, x, W, M, D, D, bias=b, act=ops.ACT_TANH, C_out=C, a_row_mod=B * T, a_drop=db, splitk=1)),
+    ("bf16 plain NT", lambda: ops.gemm(ops.NT, x2, W, M, D, D, C_out=C, splitk=1, bf16=True)),
+    ("bf16 NT tile128", lambda: ops.gemm(ops.NT, x2, W, M, D, D, C_out=C, splitk=1, bf16=True, tile=1)),
+    ("bf16 all (bits,tanh)", lambda: ops.gemm(ops.NT, x, W, M, D, D, bias=b, act=ops.ACT_TANH, C_out=C, a_row_mod=B * T, a_drop=db, splitk=1, bf16=True)),
     ("NN plain", lambda: ops.gemm(ops.NN, x2, W, M, D, D, C_out=C, splitk=1)),
     ("NN accumulate", lambda: ops.gemm(ops.NN, x2, W, M, D, D, C_out=C, splitk=1, accumulate=True)),
     ("TN plain s=0", lambda: ops.gemm(ops.TN, x2, C, D, D, M, splitk=0)),
