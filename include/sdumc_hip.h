@@ -278,6 +278,13 @@ int sdumc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
                     float* hyper, float beta1, float beta2, float eps, float weight_decay,
                     float grad_scale, void* stream);
 
+/* Batch assembly from a device-resident packed feature store = the collater's padding
+ * (toolkit/utils/read_data.py:139-151, :223-248; toolkit/data/feat_data.py:232-253) on the GPU:
+ * out[b, t, :] = packed[start[b] + t, :] for t < len[b], zero beyond, out is [B, Tmax, d].
+ * packed [sum T, d] fp32, start int64 [B], len int32 [B] (device), d % 4 == 0. */
+int sdumc_gather_pad(const float* packed, const int64_t* start, const int32_t* len, int32_t B, int32_t Tmax, int32_t d,
+                     float* out, void* stream);
+
 /* misc */
 /* n (<= 8) strided copies in one launch */
 typedef struct sdumc_copy_seg {

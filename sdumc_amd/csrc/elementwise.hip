@@ -79,6 +79,22 @@ __global__ void copy2d_multi_kernel(const CopySegs cs) {
   }
 }
 
+// out[b, t, :] = packed[start[b] + t, :] for t < len[b], 0 beyond: the collater's right-zero-padding
+// (toolkit/utils/read_data.py:139-151, :223-248) done on the device from a packed feature store.
+// one thread per 16 bytes; d must be a multiple of 4
+__global__ void gather_pad_kernel(const float* packed, const int64_t* start, const int32_t* len, int B, int Tmax, int d4,
+                                  float* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * Tmax * d4;
+  if (i >= total) return;
+  const int c = (int)(i % d4);
+  const int64_t r = i / d4;
+  const int t = (int)(r % Tmax), b = (int)(r / Tmax);
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (t < len[b]) v = ld4(packed + ((size_t)(start[b] + t) * d4 + c) * 4);
+  st4(out + 4 * i, v);
+}
+
 __global__ void fill_kernel(float* p, float v, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -317,6 +333,17 @@ extern "C" int sdumc_copy2d_multi(const sdumc_copy_seg* segs, int32_t n, void* s
     mx = std::max<int64_t>(mx, (int64_t)segs[i].rows * segs[i].cols);
   }
   hipLaunchKernelGGL(copy2d_multi_kernel, dim3(std::min<unsigned>(nblk(mx), 256u), n), dim3(256), 0, as_stream(stream), cs);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_gather_pad(const float* packed, const int64_t* start, const int32_t* len, int32_t B, int32_t Tmax,
+                                int32_t d, float* out, void* stream) {
+  if (!packed || !start || !len || !out || B <= 0 || Tmax <= 0 || d <= 0 || (d & 3)) return SDUMC_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(out)) & 15) return SDUMC_EINVAL;
+  const int64_t total = (int64_t)B * Tmax * (d / 4);
+  hipLaunchKernelGGL(gather_pad_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), packed, start, len, B, Tmax,
+                     d / 4, out);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
 }

@@ -61,3 +61,64 @@ def unpack(data, device):
     return (b['audios'].to(device, non_blocking=True), b['texts'].to(device, non_blocking=True),
             b['videos'].to(device, non_blocking=True), b['feat4s'].to(device, non_blocking=True),
             data[-2].float().to(device, non_blocking=True), data[-1])
+
+
+class DeviceFeatureStore:
+    """All pre-extracted features of a split, packed per modality into ONE device tensor [sum T, d]
+    (MOSEI train at WavLM/Vicuna/MANet widths is tens of GB: it fits the 288 GB of one MI355X many times).
+    `batch(indices)` assembles the reference's batch tuple on the GPU with a HIP gather/pad kernel
+    (sdumc_gather_pad), so no feature bytes cross PCIe inside the training loop.  Replaces the roles of
+    Data_Feat_MOSEI_EmoVal_4F.collater + pad_to_maxlen_pre_modality_tensor_4 (feat_data.py:232-253,
+    read_data.py:223-248) for the hot path; the on-disk format is the reference's (read_feature)."""
+
+    MODS = ('audio', 'text', 'video', 'feat4')
+
+    def __init__(self, instances, device='cuda'):
+        """instances: iterable of dicts with 'audio','text','video','feat4' ([T, d] arrays), 'emo', 'val', 'name'."""
+        import ctypes as C
+        from . import _lib
+        self._C, self._lib = C, _lib
+        instances = list(instances)
+        self.device = torch.device(device)
+        self.names = [inst['name'] for inst in instances]
+        self.vals = torch.tensor([float(inst['val']) for inst in instances], dtype=torch.float32, device=self.device)
+        self.emos = torch.tensor([float(inst['emo']) for inst in instances], dtype=torch.float32, device=self.device)
+        self.packed, self.start, self.length, self.dim = {}, {}, {}, {}
+        for m in self.MODS:
+            lens = [int(inst[m].shape[0]) for inst in instances]
+            d = int(instances[0][m].shape[1])
+            if d % 4:
+                raise _lib.SdumcError(f"feature width {d} of '{m}' must be a multiple of 4")
+            starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
+            host = torch.empty(sum(lens), d, dtype=torch.float32)
+            for s, n, inst in zip(starts, lens, instances):
+                host[s:s + n] = torch.as_tensor(inst[m], dtype=torch.float32)
+            self.packed[m] = host.to(self.device)
+            self.start[m] = torch.from_numpy(starts)
+            self.length[m] = torch.tensor(lens, dtype=torch.int32)
+            self.dim[m] = d
+
+    def __len__(self):
+        return len(self.names)
+
+    def get_featdim(self):
+        return tuple(self.dim[m] for m in self.MODS)          # (adim, tdim, vdim, f4dim), feat_data.py:256-258
+
+    def batch(self, indices):
+        """-> (batch_dict, pads, emos, vals, names) with device tensors, identical to collate() of the same samples."""
+        C, _lib = self._C, self._lib
+        idx = torch.as_tensor(indices, dtype=torch.int64)
+        B = idx.numel()
+        out, pads = {}, []
+        for key, m in zip(KEYS, self.MODS):
+            lens = self.length[m][idx]
+            tmax = int(lens.max())
+            start_d = self.start[m][idx].to(self.device)
+            len_d = lens.to(self.device)
+            dst = torch.empty(B, tmax, self.dim[m], dtype=torch.float32, device=self.device)
+            _lib.check(_lib.lib.sdumc_gather_pad(_lib.ptr(self.packed[m]), _lib.ptr(start_d), _lib.ptr(len_d), B, tmax,
+                                                 self.dim[m], _lib.ptr(dst), _lib.current_stream()), "sdumc_gather_pad")
+            out[key] = dst
+            pads.append((tmax - lens).tolist())
+        idx_d = idx.to(self.device)
+        return out, pads, self.emos[idx_d], self.vals[idx_d], [self.names[i] for i in idx.tolist()]

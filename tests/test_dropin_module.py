@@ -117,3 +117,92 @@ def test_reference_training_loop_with_dropin_modules(golden):
         y1, emb = model([audio_feat[:1].contiguous(), text_feat[:1].contiguous(), visual_feat[:1].contiguous(), False])
     assert y1.shape == (1, 1) and emb[3].shape == (1, 7, 128)
     np.testing.assert_allclose(y1.cpu().numpy(), y0[:1].cpu().numpy(), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.gpu
+def test_device_feature_store_equals_reference_collater(golden):
+    """F1: batches assembled on the GPU from the packed device-resident store == the reference collater's output."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from sdumc_amd.data import DeviceFeatureStore, collate
+    g = golden("collate")
+    n = len(g["lens"])
+    inst = [{k: g[f"raw_{k}_{b}"] for k in ("audio", "text", "video", "feat4")} | {"emo": 0, "val": 0.25 * b, "name": f"u{b}"}
+            for b in range(n)]
+    # feature widths must be multiples of 4 for the 16-byte kernel: pad the golden's odd widths consistently on both sides
+    def pad4(a):
+        d = (-a.shape[1]) % 4
+        return np.pad(a, ((0, 0), (0, d))) if d else a
+    inst = [{k: (pad4(v) if isinstance(v, np.ndarray) else v) for k, v in i.items()} for i in inst]
+    store = DeviceFeatureStore(inst)
+    for order in ([0, 1, 2], [2, 0], [1]):
+        batch, pads, emos, vals, names = store.batch(order)
+        ref, rpads, remos, rvals, rnames = collate([inst[i] for i in order])
+        for k in ("audios", "texts", "videos", "feat4s"):
+            assert torch.equal(batch[k].cpu(), ref[k]), k
+        assert pads == rpads and names == rnames and torch.equal(vals.cpu(), rvals)
+    # unpadded widths: the first golden batch reproduces the reference's stacked tensors on the original columns
+    batch, *_ = store.batch([0, 1, 2])
+    for k, key in (("audio", "audios"), ("text", "texts"), ("video", "videos"), ("feat4", "feat4s")):
+        np.testing.assert_array_equal(batch[key].cpu().numpy()[:, :, :g[key].shape[2]], g[key])
+
+
+def test_checkpoint_roundtrip_in_reference_format(tmp_path):
+    """F2: {'epoch','state_dict','optimizer'} with 'model.'-prefixed keys; loads with a 'module.' prefix too;
+    torch.optim.Adam accepts the optimizer state built from the fused step's flat moments."""
+    from sdumc_amd.model import get_models
+    from sdumc_amd import checkpoint as ck
+    dims = (16, 8, 12, 8)
+    torch.manual_seed(3)
+    a = get_models(_args(dims))
+    net = a.model
+    m = torch.arange(net._layout.live, dtype=torch.float32) * 1e-6
+    v = torch.arange(net._layout.live, dtype=torch.float32) * 1e-9
+    opt_state = ck.adam_state_from_flat(net, m, v, step=7)
+    path = str(tmp_path / "mosei_mult-view_kd_full_0.5_17.pt")
+    ck.save_checkpoint(path, a, opt_state, epoch=17)
+    raw = torch.load(path, weights_only=False)
+    assert set(raw) == {"epoch", "state_dict", "optimizer"} and all(k.startswith("model.") for k in raw["state_dict"])
+    assert sum(v.numel() for v in raw["state_dict"].values()) == sum(p.numel() for p in a.parameters())
+    # DataParallel-style prefix, as the reference's inference script expects to strip
+    raw["state_dict"] = {"module." + k: v for k, v in raw["state_dict"].items()}
+    torch.save(raw, path)
+    torch.manual_seed(4)
+    b = get_models(_args(dims))
+    epoch, opt, missing, unexpected = ck.load_checkpoint(path, b)
+    assert epoch == 17 and not missing and not unexpected
+    for (ka, pa), (kb, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert ka == kb and torch.equal(pa, pb)
+    optim = torch.optim.Adam(b.parameters(), lr=1e-4, weight_decay=1e-5)
+    optim.load_state_dict(opt)                                  # torch accepts it
+    m2, v2, step = ck.flat_from_adam_state(b.model, opt, "cpu")
+    assert step == 7
+    lay = b.model._layout
+    for name in lay.live_names():                                # (alignment padding between tensors carries no state)
+        off, shape, _ = lay.entries[name]
+        n = int(np.prod(shape))
+        assert torch.equal(m2[off:off + n], m[off:off + n]) and torch.equal(v2[off:off + n], v[off:off + n]), name
+    dead = [i for i, n in enumerate(b.model._pnames) if not b.model._layout.entries[n][2]]
+    assert dead and all(i not in opt["state"] for i in dead)     # grad-None parameters carry no Adam state
+
+
+@pytest.mark.gpu
+def test_inference_export_loop(golden):
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import sdumc_oracle as O
+    from sdumc_amd.model import get_models
+    from sdumc_amd.checkpoint import run_inference
+    g = golden("forward")
+    dims = tuple(int(v) for v in g["dims"])
+    model = get_models(_args(dims))
+    model.load_state_dict({"model." + k: v for k, v in O.init_params(dims, seed=int(g["pseed"])).items()})
+    model = model.cuda()
+    T = lambda k: torch.from_numpy(g[k])
+    data = ({"audios": T("audio"), "texts": T("text"), "videos": T("video"), "feat4s": T("feat4")}, None,
+            torch.zeros(4), T("vals"), [f"u{i}" for i in range(4)])
+    res = run_inference(model, [data, data])
+    assert res["val_preds_full"].shape == (8, 1) and res["text_rep_full"].shape == (8, 7, 128) and len(res["names"]) == 8
+    np.testing.assert_allclose(res["val_preds_full"][:4], g["eval0_vals"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(res["missing_rnc"][4:], g["eval1_rnc"], rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(res["text_rep_query_full"][:4], g["eval0_text_hidden"], rtol=2e-5, atol=2e-6)
