@@ -51,7 +51,7 @@ typedef struct sdumc_dropout {
   uint32_t threshold;  /* floor(p * 2^32) */
   float scale;         /* 1/(1-p) */
   uint32_t rows;       /* rows per sample (T, NQ or 1) */
-  uint32_t width;      /* row width, multiple of 4 */
+  uint32_t width;      /* row width; a multiple of 4 wherever the mask is fused into a GEMM */
   uint32_t samples;    /* samples per stream (local batch B) */
   uint32_t sample0;    /* global index of local sample 0 (data-parallel shard offset) */
   uint32_t call0;      /* Philox call index of stream 0 (ignored when dev_state != NULL) */
@@ -108,6 +108,12 @@ typedef struct sdumc_gemm {
                            and fp32 epilogue (the "bf16 compute" mode, BASELINE configs[2]); 0: exact fp32 (default) */
   float* workspace;
   size_t workspace_bytes;
+  int32_t batch;        /* >1: strided-batched mode -- every group is `batch` products of one shape, entry z reads
+                           A + z*stride_a, B + z*stride_b and writes C + z*stride_c (the per-(sample, head) QK^T / PV
+                           products of sdumc_mha_*, multihead_attention.py:103,123: with [T, B, H*d_h] activations the
+                           head slice of (b, h) starts at (b*H + h)*d_h, so one stride walks samples and heads).
+                           Plain products only: no operand/epilogue dropout, bias, column sums or split-K */
+  int64_t stride_a, stride_b, stride_c;   /* floats */
 } sdumc_gemm;
 
 size_t sdumc_gemm_workspace_bytes(const sdumc_gemm* g);
@@ -284,6 +290,101 @@ int sdumc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
  * packed [sum T, d] fp32, start int64 [B], len int32 [B] (device), d % 4 == 0. */
 int sdumc_gather_pad(const float* packed, const int64_t* start, const int32_t* len, int32_t B, int32_t Tmax, int32_t d,
                      float* out, void* stream);
+
+/* ------------------------------------------------------------------------
+ * Generic fairseq-style multi-head attention and the pieces of the pre-LN Transformer encoder
+ * (toolkit/models/modules/transformers_encoder/, all three files).
+ * Activations are Time x Batch x Channel ([T, B, E] row-major) as in the reference (multihead_attention.py:51).
+ * Dropout descriptors on [T, B, E] tensors use samples = T, rows = B, width = E; on the attention
+ * probabilities [B*H, Tq, Tk] samples = B*H, rows = Tq, width = Tk (a width that is not a multiple of 4
+ * uses ceil(width/4) Philox calls per row).
+ * ---------------------------------------------------------------------- */
+
+/* nn.LayerNorm(E) (transformer.py:201-203): y = (x - mean) * rstd * gamma + beta over the last axis,
+ * biased variance, rstd = 1/sqrt(var + eps).  mean / rstd [rows] are saved for the backward. */
+int sdumc_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
+                        int64_t rows, int32_t width, float eps, void* stream);
+/* dx (+)= LayerNorm backward (accumulate_dx: the residual branch's gradient is already in dx);
+ * dgamma, dbeta [width] overwritten (deterministic two-stage column reduction through `workspace`). */
+size_t sdumc_layernorm_bwd_workspace_bytes(int64_t rows, int32_t width);
+int sdumc_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
+                        float* dx, float* dgamma, float* dbeta, int32_t accumulate_dx, int64_t rows, int32_t width,
+                        float* workspace, size_t workspace_bytes, void* stream);
+
+/* Softmax over the key axis of the attention scores, with the additive mask, the attention dropout and the
+ * head-averaged weights the reference returns (multihead_attention.py:104-117, :128-130). */
+typedef struct sdumc_softmax {
+  int32_t batch, heads, tq, tk;
+  float scale;            /* d_h^-0.5: the reference scales q (:84); here it multiplies S = q.k^T */
+  const float* mask;      /* optional additive [tq, tk] (attn_mask.unsqueeze(0), :108); may hold -inf */
+  float* scores;          /* in: S [batch*heads, tq, tk]; out: P = softmax(scale*S + mask) (saved for backward) */
+  float* probs_drop;      /* drop.enabled: P * keep/(1-p), what multiplies V (:117); else unused (may be NULL) */
+  float* weights;         /* optional [batch, tq, tk]: mean over heads of what multiplies V (:128-130) */
+  sdumc_dropout drop;     /* F.dropout(attn_weights, p=attn_dropout) (:117) */
+} sdumc_softmax;
+int sdumc_softmax_fwd(const sdumc_softmax* s, void* stream);
+/* dscores [batch*heads, tq, tk]: in dL/d(what multiplies V), out (in place) dL/dS.  Reads s->scores (= P). */
+int sdumc_softmax_bwd(const sdumc_softmax* s, float* dscores, void* stream);
+
+/* y = drop(alpha * x + pos) + residual over a [samples, rows, width] tensor:
+ *   the "dropout -> add residual" of TransformerEncoderLayer.forward (transformer.py:161-162, :168-172; alpha = 1),
+ *   the embedding stage of TransformerEncoder.forward (:68-71; alpha = sqrt(E), pos_table = sinusoidal table,
+ *   position of token (t, b) = t + 1 if x[t, b, 0] != 0 else 0 -- position_embedding.py:8-26 with padding_idx 0),
+ *   and the backward of both (x = dy, residual NULL). */
+typedef struct sdumc_dropadd {
+  const float* x;
+  float alpha;
+  const float* pos_table;  /* optional [samples + 1, width], row 0 = padding row */
+  const float* pos_src;    /* tensor whose first channel decides padding (the un-scaled input); NULL with pos_table NULL */
+  const float* residual;   /* optional */
+  float* y;
+  int32_t samples, rows, width;
+  sdumc_dropout drop;
+} sdumc_dropadd;
+int sdumc_drop_add(const sdumc_dropadd* d, void* stream);
+
+/* MultiheadAttention.forward (multihead_attention.py:48-131) and its backward.
+ * query [tq, B, E], key / value [tk, B, E].  Pointer equality of query / key / value selects the fused
+ * projection paths the reference selects with data_ptr() tests (:61-62); the results do not depend on it.
+ * add_bias_kv / add_zero_attn (:28-38, default off, never enabled by transformer.py) are not implemented. */
+typedef struct sdumc_mha {
+  int32_t tq, tk, batch, embed, heads;
+  const float* query;
+  const float* key;
+  const float* value;
+  const float* in_proj_weight;   /* [3E, E] rows = (q | k | v) (:24, :133-154) */
+  const float* in_proj_bias;     /* [3E] or NULL */
+  const float* out_proj_weight;  /* [E, E] (:30) */
+  const float* out_proj_bias;    /* [E] or NULL */
+  const float* attn_mask;        /* optional additive [tq, tk] */
+  sdumc_dropout attn_drop;       /* enabled = training and attn_dropout > 0 */
+  float* out;                    /* [tq, B, E] */
+  float* weights;                /* [B, tq, tk] head-averaged attention weights, or NULL */
+  /* caller-owned intermediates, saved for the backward */
+  float* q;                      /* [tq, B, E] projected queries (unscaled) */
+  float* k;                      /* [tk, B, E] */
+  float* v;                      /* [tk, B, E] */
+  float* probs;                  /* [B*H, tq, tk] softmax output */
+  float* probs_drop;             /* [B*H, tq, tk] when attn_drop.enabled, else NULL */
+  float* ctx;                    /* [tq, B, E] attention output before out_proj */
+  float* workspace;              /* >= sdumc_mha_workspace_bytes */
+  size_t workspace_bytes;
+} sdumc_mha;
+
+typedef struct sdumc_mha_grads {
+  const float* dout;             /* [tq, B, E] */
+  float* dquery;                 /* [tq, B, E] overwritten.  Where the forward inputs aliased, pass the same */
+  float* dkey;                   /* [tk, B, E] aliasing here: the contributions are then summed into one buffer */
+  float* dvalue;                 /* [tk, B, E] */
+  float* d_in_proj_weight;       /* [3E, E] overwritten */
+  float* d_in_proj_bias;         /* [3E] or NULL */
+  float* d_out_proj_weight;      /* [E, E] */
+  float* d_out_proj_bias;        /* [E] or NULL */
+} sdumc_mha_grads;
+
+size_t sdumc_mha_workspace_bytes(const sdumc_mha* m, int32_t backward);
+int sdumc_mha_forward(const sdumc_mha* m, void* stream);
+int sdumc_mha_backward(const sdumc_mha* m, const sdumc_mha_grads* g, void* stream);
 
 /* misc */
 /* n (<= 8) strided copies in one launch */

@@ -11,7 +11,7 @@ therefore defined on masks that BOTH sides can compute from
 (seed, call, site, sample, row, column) alone.
 
 Mask convention (one Philox call = 4 consecutive columns of one row):
-    ctr = ( row * (width/4) + col/4 ,  global sample index ,  site ,  call )
+    ctr = ( row * ceil(width/4) + col/4 ,  global sample index ,  site ,  call )
     key = ( seed & 0xffffffff , seed >> 32 )
     keep(col) = word[col % 4] >= floor(p * 2**32)
     value     = keep ? 1/(1-p) (computed in fp32 as 1.0f / (1.0f - p)) : 0
@@ -64,13 +64,13 @@ def drop_scale(p):
 
 
 def dropout_mask(nsamp, rows, width, p, seed, call, site, sample0=0):
-    """float32 [nsamp, rows, width] multiplicative mask (0 or 1/(1-p))."""
-    assert width % 4 == 0
-    q = width // 4
+    """float32 [nsamp, rows, width] multiplicative mask (0 or 1/(1-p)).
+    A width that is not a multiple of 4 uses ceil(width/4) Philox calls per row (the last one partly unused)."""
+    q = (width + 3) // 4
     b = (np.arange(nsamp, dtype=np.uint64) + np.uint64(sample0)).astype(np.uint32)
     rc = np.arange(rows * q, dtype=np.uint32)
     w = philox4x32_10(rc[None, :], b[:, None], np.uint32(site), np.uint32(call),
                       seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
-    words = np.stack(w, axis=-1).reshape(nsamp, rows, width)
+    words = np.stack(w, axis=-1).reshape(nsamp, rows, 4 * q)[:, :, :width]
     keep = words >= np.uint32(drop_threshold(p))
     return keep.astype(np.float32) * drop_scale(p)

@@ -39,7 +39,9 @@ class Gemm(C.Structure):
                 ("c_mask_y", C.c_void_p * MAX_GROUPS), ("c_mask_scale", C.c_float),
                 ("colsum_a", C.c_void_p * MAX_GROUPS),
                 ("bf16", C.c_int32),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("batch", C.c_int32),
+                ("stride_a", C.c_int64), ("stride_b", C.c_int64), ("stride_c", C.c_int64)]
 
 
 class AttnPool(C.Structure):
@@ -90,6 +92,36 @@ class StepCfg(C.Structure):
                 ("losses", C.c_void_p),
                 ("B_global", C.c_int32), ("ssd_global", C.c_void_p), ("rnc_feats_global", C.c_void_p),
                 ("rnc_labels_global", C.c_void_p), ("rnc_row0", C.c_int32 * 2)]
+
+
+class Softmax(C.Structure):
+    _fields_ = [("batch", C.c_int32), ("heads", C.c_int32), ("tq", C.c_int32), ("tk", C.c_int32),
+                ("scale", C.c_float), ("mask", C.c_void_p), ("scores", C.c_void_p), ("probs_drop", C.c_void_p),
+                ("weights", C.c_void_p), ("drop", Dropout)]
+
+
+class DropAdd(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("alpha", C.c_float), ("pos_table", C.c_void_p), ("pos_src", C.c_void_p),
+                ("residual", C.c_void_p), ("y", C.c_void_p),
+                ("samples", C.c_int32), ("rows", C.c_int32), ("width", C.c_int32), ("drop", Dropout)]
+
+
+class Mha(C.Structure):
+    _fields_ = [("tq", C.c_int32), ("tk", C.c_int32), ("batch", C.c_int32), ("embed", C.c_int32), ("heads", C.c_int32),
+                ("query", C.c_void_p), ("key", C.c_void_p), ("value", C.c_void_p),
+                ("in_proj_weight", C.c_void_p), ("in_proj_bias", C.c_void_p),
+                ("out_proj_weight", C.c_void_p), ("out_proj_bias", C.c_void_p),
+                ("attn_mask", C.c_void_p), ("attn_drop", Dropout),
+                ("out", C.c_void_p), ("weights", C.c_void_p),
+                ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p),
+                ("probs", C.c_void_p), ("probs_drop", C.c_void_p), ("ctx", C.c_void_p),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
+class MhaGrads(C.Structure):
+    _fields_ = [("dout", C.c_void_p), ("dquery", C.c_void_p), ("dkey", C.c_void_p), ("dvalue", C.c_void_p),
+                ("d_in_proj_weight", C.c_void_p), ("d_in_proj_bias", C.c_void_p),
+                ("d_out_proj_weight", C.c_void_p), ("d_out_proj_bias", C.c_void_p)]
 
 
 class ProfEntry(C.Structure):
@@ -148,6 +180,16 @@ _SIGS = {
     "sdumc_dropout_bits_multi": (C.c_int, [C.POINTER(Dropout), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.c_void_p]),
     "sdumc_dropout_mask": (C.c_int, [C.POINTER(Dropout), C.c_int32, C.c_void_p, C.c_void_p]),
     "sdumc_version": (C.c_char_p, []),
+    # generic MHA / Transformer-encoder pieces (transformer.hip)
+    "sdumc_layernorm_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
+    "sdumc_layernorm_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
+    "sdumc_layernorm_bwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sdumc_softmax_fwd": (C.c_int, [C.POINTER(Softmax), C.c_void_p]),
+    "sdumc_softmax_bwd": (C.c_int, [C.POINTER(Softmax), C.c_void_p, C.c_void_p]),
+    "sdumc_drop_add": (C.c_int, [C.POINTER(DropAdd), C.c_void_p]),
+    "sdumc_mha_workspace_bytes": (C.c_size_t, [C.POINTER(Mha), C.c_int32]),
+    "sdumc_mha_forward": (C.c_int, [C.POINTER(Mha), C.c_void_p]),
+    "sdumc_mha_backward": (C.c_int, [C.POINTER(Mha), C.POINTER(MhaGrads), C.c_void_p]),
     # network level (engine.hip)
     "sdumc_param_count": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "sdumc_param_live_count": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),

@@ -52,7 +52,7 @@ __device__ __forceinline__ DropRT drop_resolve(const sdumc_dropout& d) {
   r.site = d.site;
   r.threshold = d.threshold;
   r.rows = d.rows ? d.rows : 1u;
-  r.qwidth = d.width >> 2;
+  r.qwidth = (d.width + 3u) >> 2;   // ceil: a ragged last quad still costs one Philox call
   r.samples = d.samples ? d.samples : 1u;
   r.sample0 = d.sample0;
   r.stream0 = d.stream0;

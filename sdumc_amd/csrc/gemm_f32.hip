@@ -245,16 +245,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdumc_gemm g, const int
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-  const int grp = blockIdx.z / nsplit, ks = blockIdx.z - grp * nsplit;
+  // blockIdx.z = ((group * batch) + batch entry) * nsplit + k-split
+  const int gz = blockIdx.z / nsplit, ks = blockIdx.z - gz * nsplit;
+  const int nb = g.batch > 1 ? g.batch : 1;
+  const int grp = gz / nb, bz = gz - grp * nb;
   const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
   const int kbeg = ks * kchunk;
   const int kend = min(g.K, kbeg + kchunk);
 
   TileLoadCtx ca, cb;
-  ca.p = g.A[grp];
+  ca.p = g.A[grp] + (size_t)bz * g.stride_a;
   ca.ld = g.lda;
   ca.row_mod = g.a_row_mod;
-  cb.p = g.B[grp];
+  cb.p = g.B[grp] + (size_t)bz * g.stride_b;
   cb.ld = g.ldb;
   cb.row_mod = (!A_K && !B_K) ? g.b_row_mod : 0;
   // 16-byte vector loads need aligned rows and a channel extent that is a multiple of 4
@@ -410,7 +413,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdumc_gemm g, const int
   }
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-  float* C = to_slab ? g.workspace + ((size_t)blockIdx.z) * (size_t)g.M * g.N : g.C[grp];
+  float* C = to_slab ? g.workspace + ((size_t)blockIdx.z) * (size_t)g.M * g.N : g.C[grp] + (size_t)bz * g.stride_c;
   const int ldc = to_slab ? g.N : g.ldc;
   const float* bias = to_slab ? nullptr : g.bias[grp];
   DropRT cd = drop_resolve(g.c_drop);
@@ -608,7 +611,7 @@ GemmPlan plan_gemm(const sdumc_gemm& g, size_t ws_bytes) {
     const bool plain = !g.a_drop.enabled && !g.b_drop.enabled && g.a_row_mod == 0 && g.b_row_mod == 0;
     bool masked = false;
     for (int i = 0; i < g.groups; ++i) masked |= g.c_mask_y[i] != nullptr;   // only the small kernel implements it
-    if (!g.bf16 && ((g.tile == 0 && g.splitk <= 1 && t32 <= 768 && g.K <= 1024 && plain) || g.tile == 3 || masked)) {
+    if (!g.bf16 && g.batch <= 1 && ((g.tile == 0 && g.splitk <= 1 && t32 <= 768 && g.K <= 1024 && plain) || g.tile == 3 || masked)) {
       p.tile = 3;
       p.nsplit = 1;
       p.kchunk = ((((g.K + 3) / 4) + 7) / 8) * 8;   // k per wave
@@ -616,7 +619,9 @@ GemmPlan plan_gemm(const sdumc_gemm& g, size_t ws_bytes) {
     }
   }
   int s;
-  if (g.splitk >= 1) {                                   // explicit
+  if (g.batch > 1) {                                     // strided-batched: the batch dimension fills the chip
+    s = 1;
+  } else if (g.splitk >= 1) {                            // explicit
     s = std::min(g.splitk, ktiles);
   } else {                                               // auto
     const long tiles = p.tile == 1 ? big : small;
@@ -637,7 +642,7 @@ GemmPlan plan_gemm(const sdumc_gemm& g, size_t ws_bytes) {
 
 template <int BM, int BN>
 int launch(const sdumc_gemm& g, int nsplit, int kchunk, hipStream_t st) {
-  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.groups * nsplit);
+  dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.groups * (g.batch > 1 ? g.batch : 1) * nsplit);
   if (g.bf16) {   // NT only (checked by the caller)
     hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, true>), grid, dim3(256), 0, st, g, nsplit, kchunk);
     return SDUMC_OK;
@@ -671,6 +676,13 @@ extern "C" int sdumc_gemm_f32(const sdumc_gemm* gp, void* stream) {
     return SDUMC_EINVAL;
   for (int i = 0; i < g.groups; ++i)
     if (g.colsum_a[i] && g.layout != SDUMC_TN) return SDUMC_EINVAL;
+  if (g.batch > 1) {   // strided-batched mode: plain products only (the attention-core GEMMs of transformer.hip)
+    if (g.tile == 3 || g.splitk > 1 || g.a_drop.enabled || g.b_drop.enabled || g.c_drop.enabled || g.a_row_mod ||
+        g.b_row_mod || (long)g.groups * g.batch > 65535)
+      return SDUMC_EINVAL;
+    for (int i = 0; i < g.groups; ++i)
+      if (g.colsum_a[i] || g.c_mask_y[i] || g.bias[i]) return SDUMC_EINVAL;
+  }
   if (g.bf16) {   // bf16 operands: NT layout, 16-byte aligned rows, k a multiple of 4
     if (g.layout != SDUMC_NT || (g.lda & 3) || (g.ldb & 3) || (g.K & 3)) return SDUMC_EINVAL;
     for (int i = 0; i < g.groups; ++i)
@@ -685,7 +697,7 @@ extern "C" int sdumc_gemm_f32(const sdumc_gemm* gp, void* stream) {
   if (prof) {
     if (hipEventCreate(&rec.a) != hipSuccess || hipEventCreate(&rec.b) != hipSuccess) return SDUMC_ELAUNCH;
     rec.variant = g.bf16 ? (tile == 1 ? 9 : 10) : tile == 3 ? 6 + g.layout : g.layout * 2 + (tile == 1 ? 0 : 1);
-    rec.flops = 2.0 * g.M * (double)g.N * g.K * g.groups;
+    rec.flops = 2.0 * g.M * (double)g.N * g.K * g.groups * (g.batch > 1 ? g.batch : 1);
     (void)hipEventRecord(rec.a, st);
   }
   int rc = SDUMC_OK;

@@ -18,8 +18,9 @@ def _st():
 
 def gemm(layout, A, B, M, N, K, bias=None, C_out=None, lda=None, ldb=None, ldc=None, act=ACT_NONE, a_row_mod=0,
          b_row_mod=0, a_drop=None, b_drop=None, c_drop=None, c_drop_group_stride=0, accumulate=False, splitk=1,
-         tile=0, colsum_a=None, ab_drop_group_stride=0, ab_drop_bits=None, c_mask_y=None, c_mask_scale=1.0, bf16=False):
-    """Grouped when A/B/(bias)/C_out are lists."""
+         tile=0, colsum_a=None, ab_drop_group_stride=0, ab_drop_bits=None, c_mask_y=None, c_mask_scale=1.0, bf16=False,
+         batch=0, stride_a=0, stride_b=0, stride_c=0):
+    """Grouped when A/B/(bias)/C_out are lists; strided-batched when batch > 1 (C_out required)."""
     As = A if isinstance(A, (list, tuple)) else [A]
     Bs = B if isinstance(B, (list, tuple)) else [B]
     groups = len(As)
@@ -47,6 +48,7 @@ def gemm(layout, A, B, M, N, K, bias=None, C_out=None, lda=None, ldb=None, ldc=N
     g.act, g.accumulate, g.splitk, g.tile = act, 1 if accumulate else 0, splitk, tile
     g.ab_drop_group_stride = ab_drop_group_stride
     g.bf16 = 1 if bf16 else 0
+    g.batch, g.stride_a, g.stride_b, g.stride_c = batch, stride_a, stride_b, stride_c
     if c_mask_y is not None:
         ys = c_mask_y if isinstance(c_mask_y, (list, tuple)) else [c_mask_y]
         for i in range(groups):
@@ -193,3 +195,120 @@ def rnc_mask(labels):
 def adam_step(param, grad, m, v, hyper, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=1e-5, grad_scale=1.0):
     check(lib.sdumc_adam_step(ptr(param), ptr(grad), ptr(m), ptr(v), param.numel(), ptr(hyper), beta1, beta2, eps,
                               weight_decay, grad_scale, _st()), "sdumc_adam_step")
+
+
+# ---- generic MHA / Transformer-encoder pieces (transformer.hip) ------------------------------------
+def layernorm_fwd(x, gamma, beta, eps=1e-5):
+    width = x.shape[-1]
+    rows = x.numel() // width
+    y = torch.empty_like(x)
+    mean = torch.empty(rows, device=x.device)
+    rstd = torch.empty(rows, device=x.device)
+    check(lib.sdumc_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(mean), ptr(rstd), rows, width, eps,
+                                  _st()), "sdumc_layernorm_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx_accumulate_into=None, need_params=True):
+    width = x.shape[-1]
+    rows = x.numel() // width
+    dx = dx_accumulate_into if dx_accumulate_into is not None else torch.empty_like(x)
+    dg = torch.empty(width, device=x.device) if need_params else None
+    db = torch.empty(width, device=x.device) if need_params else None
+    need = lib.sdumc_layernorm_bwd_workspace_bytes(rows, width)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
+    check(lib.sdumc_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dg), ptr(db),
+                                  1 if dx_accumulate_into is not None else 0, rows, width, ptr(ws), need, _st()),
+          "sdumc_layernorm_bwd")
+    return dx, dg, db
+
+
+def softmax_desc(scores, batch, heads, scale, mask=None, drop=None, probs_drop=None, weights=None):
+    bh, tq, tk = scores.shape
+    assert bh == batch * heads
+    s = _lib.Softmax()
+    s.batch, s.heads, s.tq, s.tk, s.scale = batch, heads, tq, tk, scale
+    s.mask, s.scores, s.probs_drop, s.weights = ptr(mask), ptr(scores), ptr(probs_drop), ptr(weights)
+    if drop is not None:
+        s.drop = drop
+    return s
+
+
+def softmax_fwd(scores, batch, heads, scale, mask=None, drop=None, need_weights=True):
+    """In place on `scores` ([batch*heads, tq, tk]).  Returns (P, P_dropped or None, head-mean weights or None, desc)."""
+    bh, tq, tk = scores.shape
+    pd = torch.empty_like(scores) if drop is not None and drop.enabled else None
+    w = torch.empty(batch, tq, tk, device=scores.device) if need_weights else None
+    s = softmax_desc(scores, batch, heads, scale, mask, drop, pd, w)
+    check(lib.sdumc_softmax_fwd(C.byref(s), _st()), "sdumc_softmax_fwd")
+    return scores, pd, w, s
+
+
+def softmax_bwd(desc, dscores):
+    check(lib.sdumc_softmax_bwd(C.byref(desc), ptr(dscores), _st()), "sdumc_softmax_bwd")
+    return dscores
+
+
+def drop_add(x, residual=None, drop=None, alpha=1.0, pos_table=None, pos_src=None, out=None):
+    """y = drop(alpha * x + pos) + residual over a [samples, rows, width] tensor."""
+    samples, rows, width = x.shape
+    y = out if out is not None else torch.empty_like(x)
+    d = _lib.DropAdd()
+    d.x, d.alpha, d.pos_table, d.pos_src, d.residual, d.y = ptr(x), alpha, ptr(pos_table), ptr(pos_src), ptr(residual), ptr(y)
+    d.samples, d.rows, d.width = samples, rows, width
+    if drop is not None:
+        d.drop = drop
+    check(lib.sdumc_drop_add(C.byref(d), _st()), "sdumc_drop_add")
+    return y
+
+
+def mha_forward(query, key, value, w_in, b_in, w_out, b_out, heads, attn_mask=None, attn_drop=None, need_weights=True):
+    """MultiheadAttention.forward on [T, B, E] tensors.  Returns (out, weights, saved) where `saved` is what
+    mha_backward needs."""
+    tq, B, E = query.shape
+    tk = key.shape[0]
+    dev = query.device
+    m = _lib.Mha()
+    m.tq, m.tk, m.batch, m.embed, m.heads = tq, tk, B, E, heads
+    m.query, m.key, m.value = ptr(query), ptr(key), ptr(value)
+    m.in_proj_weight, m.in_proj_bias, m.out_proj_weight, m.out_proj_bias = ptr(w_in), ptr(b_in), ptr(w_out), ptr(b_out)
+    m.attn_mask = ptr(attn_mask)
+    drop_on = attn_drop is not None and attn_drop.enabled
+    if drop_on:
+        m.attn_drop = attn_drop
+    t = {"out": torch.empty(tq, B, E, device=dev),
+         "weights": torch.empty(B, tq, tk, device=dev) if need_weights else None,
+         "q": torch.empty(tq, B, E, device=dev), "k": torch.empty(tk, B, E, device=dev),
+         "v": torch.empty(tk, B, E, device=dev), "probs": torch.empty(B * heads, tq, tk, device=dev),
+         "probs_drop": torch.empty(B * heads, tq, tk, device=dev) if drop_on else None,
+         "ctx": torch.empty(tq, B, E, device=dev)}
+    for name, ten in t.items():
+        setattr(m, name, ptr(ten))
+    need = lib.sdumc_mha_workspace_bytes(C.byref(m), 0)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+    m.workspace, m.workspace_bytes = ptr(ws), need
+    check(lib.sdumc_mha_forward(C.byref(m), _st()), "sdumc_mha_forward")
+    t["inputs"] = (query, key, value, w_in, b_in, w_out, b_out, attn_mask)   # keep-alive
+    return t["out"], t["weights"], (m, t)
+
+
+def mha_backward(saved, dout):
+    """Returns (dquery, dkey, dvalue, dw_in, db_in, dw_out, db_out).  Inputs that aliased in the forward share ONE
+    summed gradient buffer; it is returned once (for the first of them) and the others come back as None."""
+    m, t = saved
+    query, key, value, w_in, b_in, w_out, b_out, _ = t["inputs"]
+    dev = dout.device
+    dq = torch.empty_like(query)
+    dk = dq if key.data_ptr() == query.data_ptr() else torch.empty_like(key)
+    dv = dq if value.data_ptr() == query.data_ptr() else (dk if value.data_ptr() == key.data_ptr() else torch.empty_like(value))
+    g = _lib.MhaGrads()
+    dw_in, dw_out = torch.empty_like(w_in), torch.empty_like(w_out)
+    db_in = torch.empty_like(b_in) if b_in is not None else None
+    db_out = torch.empty_like(b_out) if b_out is not None else None
+    g.dout, g.dquery, g.dkey, g.dvalue = ptr(dout), ptr(dq), ptr(dk), ptr(dv)
+    g.d_in_proj_weight, g.d_in_proj_bias, g.d_out_proj_weight, g.d_out_proj_bias = ptr(dw_in), ptr(db_in), ptr(dw_out), ptr(db_out)
+    need = lib.sdumc_mha_workspace_bytes(C.byref(m), 1)
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+    m.workspace, m.workspace_bytes = ptr(ws), need
+    check(lib.sdumc_mha_backward(C.byref(m), C.byref(g), _st()), "sdumc_mha_backward")
+    return dq, (None if dk is dq else dk), (None if dv is dq or dv is dk else dv), dw_in, db_in, dw_out, db_out

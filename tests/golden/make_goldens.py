@@ -11,6 +11,8 @@ expected outputs as small .npz files:
   step.npz        one full two-stream train step: loss, 6 terms, per-parameter gradient
                   digests, post-Adam parameter digests, LR-lambda table
   collate.npz     pad_to_maxlen_pre_modality_tensor_4 on ragged inputs
+  transformer.npz the generic transformers_encoder package (MultiheadAttention, LayerNorm,
+                  TransformerEncoderLayer, TransformerEncoder): parameters, inputs, outputs, gradients
 
 Parameters are not stored (the model has 2.7 M non-input parameters because
 general_dim=256 is hard-coded, model :191): they are regenerated from
@@ -55,14 +57,16 @@ class PhiloxDropout:
     """Context manager: replace F.dropout by a Philox replay with a scripted
     site sequence (one entry per dropout call, in call order)."""
 
-    def __init__(self, seed, call, sites, sample0=0):
-        self.seed, self.call, self.sites, self.sample0 = seed, call, list(sites), sample0
+    def __init__(self, seed, call, sites=None, sample0=0):
+        """sites = None: the k-th F.dropout call of the block uses site k (transformers_encoder convention)."""
+        self.seed, self.call, self.sample0 = seed, call, sample0
+        self.sites = None if sites is None else list(sites)
         self.i = 0
 
     def _drop(self, x, p=0.5, training=True, inplace=False):
         if not training:
             return x
-        site = self.sites[self.i]
+        site = self.i if self.sites is None else self.sites[self.i]
         self.i += 1
         nsamp, width = x.shape[0], x.shape[-1]
         rows = x.numel() // (nsamp * width)
@@ -78,7 +82,7 @@ class PhiloxDropout:
     def __exit__(self, *a):
         F.dropout = self.orig
         torch.nn.functional.dropout = self.orig
-        assert self.i == len(self.sites), (self.i, len(self.sites))
+        assert self.sites is None or self.i == len(self.sites), (self.i, len(self.sites))
 
 
 def digest(t, key):
@@ -315,6 +319,147 @@ def gen_init(ref_model, out):
                         fc_att_weight=np32(sd["fc_att.weight"]), ctx0=np32(sd["fra2utt_0.attention_context_vector"]))
 
 
+def load_reference_transformer():
+    """The reference's transformers_encoder directory has no __init__.py and uses relative imports:
+    import it as a synthetic package rooted at its own directory."""
+    import importlib
+    path = os.path.join(REF, "toolkit/models/modules/transformers_encoder")
+    pkg = types.ModuleType("ref_te")
+    pkg.__path__ = [path]
+    sys.modules["ref_te"] = pkg
+    return importlib.import_module("ref_te.transformer"), importlib.import_module("ref_te.multihead_attention")
+
+
+def gen_transformer(out):
+    ref_tr, ref_mha = load_reference_transformer()
+    d = {}
+
+    def put_params(tag, mod):
+        for k, v in mod.state_dict().items():
+            d[f"{tag}/P/{k}"] = np32(v)
+
+    def put_grads(tag, mod, **inputs):
+        for k, v in mod.named_parameters():
+            d[f"{tag}/G/{k}"] = np32(v.grad)
+            v.grad = None
+        for k, v in inputs.items():
+            d[f"{tag}/d{k}"] = np32(v.grad)
+            v.grad = None
+
+    def randomise(mod, gen):   # biases / LayerNorm affine are 0 / 1 at init: give them values
+        with torch.no_grad():
+            for k, v in mod.named_parameters():
+                if k.endswith("bias") or "layer_norm" in k:
+                    v.add_(0.2 * torch.randn(v.shape, generator=gen))
+
+    g = torch.Generator().manual_seed(2024)
+    rn = lambda *s: torch.randn(*s, generator=g)
+
+    # A: self-attention, eval
+    torch.manual_seed(1)
+    m = ref_mha.MultiheadAttention(32, 4); randomise(m, g); m.eval()
+    x = rn(6, 3, 32)
+    o, w = m(x, x, x)
+    put_params("mha_self", m)
+    d.update({"mha_self/x": np32(x), "mha_self/out": np32(o), "mha_self/weights": np32(w)})
+
+    # B: cross attention (Tk = 9: ragged quads), future mask, attention dropout, gradients
+    torch.manual_seed(2)
+    m = ref_mha.MultiheadAttention(32, 4, attn_dropout=0.25); randomise(m, g); m.train()
+    q, k, v = (rn(5, 2, 32).requires_grad_(), rn(9, 2, 32).requires_grad_(), rn(9, 2, 32).requires_grad_())
+    mask = ref_tr.buffered_future_mask(q, k)
+    R = rn(5, 2, 32)
+    with PhiloxDropout(91, 3):
+        o, w = m(q, k, v, attn_mask=mask)
+    (o * R).sum().backward()
+    put_params("mha_cross", m)
+    d.update({"mha_cross/q": np32(q), "mha_cross/k": np32(k), "mha_cross/v": np32(v), "mha_cross/mask": np32(mask),
+              "mha_cross/R": np32(R), "mha_cross/out": np32(o), "mha_cross/weights": np32(w),
+              "mha_cross/seed_call": np.array([91, 3])})
+    put_grads("mha_cross", m, q=q, k=k, v=v)
+
+    # C: head_dim 15 (unaligned head slices), key is value but not query
+    torch.manual_seed(3)
+    m = ref_mha.MultiheadAttention(30, 2); randomise(m, g); m.eval()
+    q, kv = rn(7, 2, 30).requires_grad_(), rn(4, 2, 30).requires_grad_()
+    R = rn(7, 2, 30)
+    o, w = m(q, kv, kv)
+    (o * R).sum().backward()
+    put_params("mha_odd", m)
+    d.update({"mha_odd/q": np32(q), "mha_odd/kv": np32(kv), "mha_odd/R": np32(R), "mha_odd/out": np32(o),
+              "mha_odd/weights": np32(w)})
+    put_grads("mha_odd", m, q=q, kv=kv)
+
+    # D: LayerNorm(300) (the width of the reference's own __main__ example, transformer.py:206-209)
+    ln = ref_tr.LayerNorm(300)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.3 * rn(300)); ln.bias.copy_(0.3 * rn(300))
+    x = (2.0 * rn(5, 3, 300) + 0.7).requires_grad_()
+    R = rn(5, 3, 300)
+    y = ln(x)
+    (y * R).sum().backward()
+    put_params("ln", ln)
+    d.update({"ln/x": np32(x), "ln/R": np32(R), "ln/y": np32(y)})
+    put_grads("ln", ln, x=x)
+
+    # E/F: one encoder layer, self and cross, train mode with all three dropouts and the future mask
+    torch.manual_seed(4)
+    lay = ref_tr.TransformerEncoderLayer(32, num_heads=4, attn_dropout=0.1, relu_dropout=0.2, res_dropout=0.3,
+                                         attn_mask=True)
+    randomise(lay, g); lay.train()
+    put_params("layer", lay)
+    x = rn(8, 2, 32).requires_grad_()
+    R = rn(8, 2, 32)
+    with PhiloxDropout(17, 6):
+        y = lay(x)
+    (y * R).sum().backward()
+    d.update({"layer/x": np32(x), "layer/R": np32(R), "layer/self_out": np32(y), "layer/seed_call": np.array([17, 6])})
+    put_grads("layer/self", lay, x=x)
+    xk, xv = rn(12, 2, 32).requires_grad_(), rn(12, 2, 32).requires_grad_()
+    with PhiloxDropout(17, 7):
+        y = lay(x, xk, xv)
+    (y * R).sum().backward()
+    d.update({"layer/xk": np32(xk), "layer/xv": np32(xv), "layer/cross_out": np32(y)})
+    put_grads("layer/cross", lay, x=x, xk=xk, xv=xv)
+    lay.eval()
+    d["layer/self_eval_out"] = np32(lay(x))
+
+    # G/H: two-layer encoder with sinusoidal positions (some tokens have first channel == 0 -> padding row)
+    torch.manual_seed(5)
+    enc = ref_tr.TransformerEncoder(32, 4, 2, attn_dropout=0.1, relu_dropout=0.1, res_dropout=0.2,
+                                    embed_dropout=0.15, attn_mask=True, position_embedding=True)
+    randomise(enc, g)
+    put_params("enc", enc)
+    x = rn(8, 3, 32)
+    x[2, 1, 0] = 0.0; x[5, 0, 0] = 0.0; x[7, 2, 0] = 0.0
+    x.requires_grad_()
+    R = rn(8, 3, 32)
+    enc.eval()
+    d["enc/self_eval_out"] = np32(enc(x))
+    enc.train()
+    with PhiloxDropout(23, 1):
+        y = enc(x)
+    (y * R).sum().backward()
+    d.update({"enc/x": np32(x), "enc/R": np32(R), "enc/self_out": np32(y), "enc/seed_call": np.array([23, 1])})
+    put_grads("enc/self", enc, x=x)
+    xk = rn(12, 3, 32); xk[0, 0, 0] = 0.0; xk[11, 2, 0] = 0.0
+    xv = rn(12, 3, 32); xv[3, 1, 0] = 0.0
+    xk.requires_grad_(); xv.requires_grad_()
+    with PhiloxDropout(23, 2):
+        y = enc(x, xk, xv)
+    (y * R).sum().backward()
+    d.update({"enc/xk": np32(xk), "enc/xv": np32(xv), "enc/cross_out": np32(y)})
+    put_grads("enc/cross", enc, x=x, xk=xk, xv=xv)
+    # no-position / no-mask variant, eval
+    torch.manual_seed(6)
+    enc2 = ref_tr.TransformerEncoder(32, 4, 1)
+    randomise(enc2, g); enc2.eval()
+    put_params("enc_plain", enc2)
+    x2 = rn(5, 2, 32)
+    d.update({"enc_plain/x": np32(x2), "enc_plain/out": np32(enc2(x2))})
+    np.savez_compressed(os.path.join(out, "transformer.npz"), **d)
+
+
 def main():
     torch.set_num_threads(4)
     ref_model, ref_loss = load_reference()
@@ -324,6 +469,7 @@ def main():
     gen_losses(ref_loss, HERE)
     gen_step(ref_model, ref_loss, HERE)
     gen_collate(HERE)
+    gen_transformer(HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))
