@@ -335,14 +335,22 @@ def fill_with_neg_inf(t):
     return t.float().fill_(float('-inf')).type_as(t)
 
 
-def buffered_future_mask(tensor, tensor2=None):   # transformer.py:183-190
+_future_masks = {}
+
+
+def buffered_future_mask(tensor, tensor2=None):
+    """[T_q, T_k] additive mask, -inf strictly above diagonal 1 + |T_k - T_q| (transformer.py:183-190).
+    Built once per (T_q, T_k, device) ON the device: the reference rebuilds it on the host and copies it
+    over on every layer call, which on this stack stalls the stream for tens of milliseconds."""
     dim1 = dim2 = tensor.size(0)
     if tensor2 is not None:
         dim2 = tensor2.size(0)
-    future_mask = torch.triu(fill_with_neg_inf(torch.ones(dim1, dim2)), 1 + abs(dim2 - dim1))
-    if tensor.is_cuda:
-        future_mask = future_mask.to(tensor.device)
-    return future_mask[:dim1, :dim2]
+    key = (dim1, dim2, str(tensor.device))
+    m = _future_masks.get(key)
+    if m is None:
+        m = torch.triu(torch.full((dim1, dim2), float('-inf'), device=tensor.device), 1 + abs(dim2 - dim1))
+        _future_masks[key] = m
+    return m
 
 
 def _dropout_add(x, residual, p, training):
