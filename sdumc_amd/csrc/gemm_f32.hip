@@ -146,27 +146,25 @@ struct Stager {
     }
   }
 
+  uint32_t mb[P];     // keep-bits of the tile in flight
+  int mpos;           // k position of the tile in flight (Philox fallback)
+
+  // Issues the 16-byte loads (and the keep-bits byte loads) of the next k-tile and returns WITHOUT touching the
+  // loaded values: anything that reads them here puts an s_waitcnt vmcnt right behind the load and the prefetch
+  // stops overlapping the MFMAs of the current tile.  The dropout mask is applied by apply(), just before the
+  // tile is written to LDS one iteration later.
   __device__ __forceinline__ void load(f32x4 (&reg)[P], const TileLoadCtx& c, int kend) {
 #pragma unroll
     for (int j = 0; j < P; ++j) {
       const int kk = KC ? pos : pos + RP * j;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      uint32_t b = 0;
       if (((ok >> j) & 1u) && kk < kend) {
         v = *reinterpret_cast<const f32x4*>(c.p + off[j]);
-        if (c.drop.enabled) {
-          if (c.drop.bits) {
-            const uint32_t b = c.drop.bits[boff[j]];
-            v[0] = (b & 1u) ? v[0] * c.drop.scale : 0.f;
-            v[1] = (b & 2u) ? v[1] * c.drop.scale : 0.f;
-            v[2] = (b & 4u) ? v[2] * c.drop.scale : 0.f;
-            v[3] = (b & 8u) ? v[3] * c.drop.scale : 0.f;
-          } else {
-            v *= KC ? drop_mask4(c.drop, (uint32_t)(vrow0 + 32 * j), (uint32_t)(pos >> 2))
-                    : drop_mask4(c.drop, (uint32_t)kk, (uint32_t)(vrow0 >> 2));
-          }
-        }
+        if (c.drop.enabled && c.drop.bits) b = c.drop.bits[boff[j]];
       }
       reg[j] = v;
+      mb[j] = b;
       off[j] += step;
       if (KC) {
         boff[j] += BK / 4;
@@ -181,7 +179,25 @@ struct Stager {
         }
       }
     }
+    mpos = pos;
     pos += BK;
+  }
+
+  __device__ __forceinline__ void apply(f32x4 (&reg)[P], const TileLoadCtx& c) const {
+    if (!c.drop.enabled) return;
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      if (c.drop.bits) {
+        const uint32_t b = mb[j];
+        reg[j][0] = (b & 1u) ? reg[j][0] * c.drop.scale : 0.f;
+        reg[j][1] = (b & 2u) ? reg[j][1] * c.drop.scale : 0.f;
+        reg[j][2] = (b & 4u) ? reg[j][2] * c.drop.scale : 0.f;
+        reg[j][3] = (b & 8u) ? reg[j][3] * c.drop.scale : 0.f;
+      } else {   // out-of-range elements were loaded as 0 and stay 0
+        reg[j] *= KC ? drop_mask4(c.drop, (uint32_t)(vrow0 + 32 * j), (uint32_t)(mpos >> 2))
+                     : drop_mask4(c.drop, (uint32_t)(mpos + RP * j), (uint32_t)(vrow0 >> 2));
+      }
+    }
   }
 };
 
@@ -306,12 +322,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdumc_gemm g, const int
       load_tile<BM, A_K>(ra, ca, m0, g.M, kbeg, kend, tid);
       load_tile<BN, B_K>(rb, cb, n0, g.N, kbeg, kend, tid);
     }
+  }
+  for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    // first use of the registers the prefetch of the previous iteration filled: dropout masks and the fused
+    // column sums are applied here, not at load time, so that the loads stay in flight behind the MFMAs
+    if (fast) {
+      sa.apply(ra, ca);
+      sb.apply(rb, cb);
+    }
     if (do_cs) {
 #pragma unroll
       for (int j = 0; j < BM / 32; ++j) csum += ra[j];
     }
-  }
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
     __syncthreads();  // everyone is done reading the previous tile
     if constexpr (BF16) {
       __bf16* Ah = reinterpret_cast<__bf16*>(As);
@@ -338,10 +360,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdumc_gemm g, const int
       } else {
         load_tile<BM, A_K>(ra, ca, m0, g.M, k0 + BK, kend, tid);
         load_tile<BN, B_K>(rb, cb, n0, g.N, k0 + BK, kend, tid);
-      }
-      if (do_cs) {
-#pragma unroll
-        for (int j = 0; j < BM / 32; ++j) csum += ra[j];
       }
     }
     if constexpr (BF16) {
