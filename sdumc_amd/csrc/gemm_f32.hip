@@ -44,6 +44,10 @@ const char* const kVariantName[kNumVariants] = {"gemm_nt_128x128", "gemm_nt_64x6
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;
+#ifndef SDUMC_GEMM_LDS_STAGES
+#define SDUMC_GEMM_LDS_STAGES 1
+#endif
+constexpr int kLdsStages = SDUMC_GEMM_LDS_STAGES;
 
 struct TileLoadCtx {
   const float* p;
@@ -249,14 +253,13 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int LDH = BK + 8;   // bf16 elements per LDS row (80 B): the 16-B fragment reads are conflict-free
 
 template <int BM, int BN, bool A_K, bool B_K, bool BF16 = false>
-__global__ __launch_bounds__(256) void gemm_kernel(const sdumc_gemm g, const int nsplit, const int kchunk) {
+__global__ __launch_bounds__(256, (BM == 64 ? 4 : 2)) void gemm_kernel(const sdumc_gemm g, const int nsplit, const int kchunk) {
   static_assert(!BF16 || (A_K && B_K), "the bf16 variant is built for the NT layout");
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int A_ELEMS = A_K ? BM * LDK : BK * BM;
   constexpr int B_ELEMS = B_K ? BN * LDK : BK * BN;
-  __shared__ __attribute__((aligned(16))) float lds[A_ELEMS + B_ELEMS];
-  float* As = lds;
-  float* Bs = lds + A_ELEMS;
+  constexpr int STAGE = A_ELEMS + B_ELEMS;
+  __shared__ __attribute__((aligned(16))) float lds[kLdsStages * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -265,7 +268,22 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdumc_gemm g, const int
   const int gz = blockIdx.z / nsplit, ks = blockIdx.z - gz * nsplit;
   const int nb = g.batch > 1 ? g.batch : 1;
   const int grp = gz / nb, bz = gz - grp * nb;
-  const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+  // XCD-aware tile order.  The dispatcher deals workgroups round-robin over the 8 XCDs (linear id % 8), each with
+  // its own L2: in launch order the N/BN workgroups that share one A row-panel would land on different XCDs and
+  // every one of them would pull the panel through the fabric again.  Give XCD x the x-th contiguous run of tiles
+  // instead (n fastest inside the run), so that panel sharers sit behind one L2, dispatched back to back.
+  int tile_m = blockIdx.y, tile_n = blockIdx.x;
+  {
+    const int nwg = gridDim.x * gridDim.y;
+    if (nwg >= 16 && ((nwg & 7) == 0 || gridDim.z == 1)) {
+      const int id = blockIdx.y * gridDim.x + blockIdx.x;
+      const int xcd = id & 7, j = id >> 3, q = nwg >> 3, r = nwg & 7;
+      const int t = xcd * q + min(xcd, r) + j;
+      tile_m = t / gridDim.x;
+      tile_n = t - tile_m * gridDim.x;
+    }
+  }
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kbeg = ks * kchunk;
   const int kend = min(g.K, kbeg + kchunk);
 
@@ -301,7 +319,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdumc_gemm g, const int
 
   // TN only: column sums of A (= the bias gradient when A is dz) ride along with the staging loads of
   // the first n-tile: every A element passes through exactly one thread of those workgroups.
-  const bool do_cs = !A_K && g.colsum_a[grp] != nullptr && blockIdx.x == 0;
+  const bool do_cs = !A_K && g.colsum_a[grp] != nullptr && tile_n == 0;
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 
   // 32-bit element offsets: fine for every operand below 2^32 floats (16 GiB)
@@ -314,18 +332,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdumc_gemm g, const int
     sb.init(cb, n0, g.N, kbeg, tid);
   }
   f32x4 ra[BM / 32], rb[BN / 32];
-  if (kbeg < kend) {
+  // global -> registers for the k-tile starting at k (nothing reads the registers here: the loads stay in flight)
+  auto prefetch = [&](int k) {
     if (fast) {
       sa.load(ra, ca, kend);
       sb.load(rb, cb, kend);
     } else {
-      load_tile<BM, A_K>(ra, ca, m0, g.M, kbeg, kend, tid);
-      load_tile<BN, B_K>(rb, cb, n0, g.N, kbeg, kend, tid);
+      load_tile<BM, A_K>(ra, ca, m0, g.M, k, kend, tid);
+      load_tile<BN, B_K>(rb, cb, n0, g.N, k, kend, tid);
     }
-  }
-  for (int k0 = kbeg; k0 < kend; k0 += BK) {
-    // first use of the registers the prefetch of the previous iteration filled: dropout masks and the fused
-    // column sums are applied here, not at load time, so that the loads stay in flight behind the MFMAs
+  };
+  // registers -> LDS stage.  First use of the prefetched registers: dropout masks and the fused column sums are
+  // applied here, not at load time
+  auto store_stage = [&](float* As, float* Bs) {
     if (fast) {
       sa.apply(ra, ca);
       sb.apply(rb, cb);
@@ -334,7 +353,6 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdumc_gemm g, const int
 #pragma unroll
       for (int j = 0; j < BM / 32; ++j) csum += ra[j];
     }
-    __syncthreads();  // everyone is done reading the previous tile
     if constexpr (BF16) {
       __bf16* Ah = reinterpret_cast<__bf16*>(As);
       __bf16* Bh = reinterpret_cast<__bf16*>(Bs);
@@ -352,16 +370,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdumc_gemm g, const int
       store_tile<BM, A_K>(As, ra, tid);
       store_tile<BN, B_K>(Bs, rb, tid);
     }
-    __syncthreads();
-    if (k0 + BK < kend) {  // prefetch: in flight during the MFMAs below
-      if (fast) {
-        sa.load(ra, ca, kend);
-        sb.load(rb, cb, kend);
-      } else {
-        load_tile<BM, A_K>(ra, ca, m0, g.M, k0 + BK, kend, tid);
-        load_tile<BN, B_K>(rb, cb, n0, g.N, k0 + BK, kend, tid);
-      }
-    }
+  };
+  // one k-tile of MFMAs from an LDS stage
+  auto compute = [&](const float* As, const float* Bs) {
     if constexpr (BF16) {
       // lane (r = lane&31, h = lane>>5) holds A[row r][k = 16 ks + 8 h .. +7] and the same k range of B's row
       const __bf16* Ah = reinterpret_cast<const __bf16*>(As);
@@ -381,38 +392,72 @@ __global__ __launch_bounds__(256) void gemm_kernel(const sdumc_gemm g, const int
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][i], bh[ks][j], acc[i][j], 0, 0, 0);
-      continue;
-    }
-    // fragment reads are software-pipelined over two register sets: group g+1 is read from LDS while the
-    // MFMAs of group g issue (with one set the compiler emitted read -> lgkmcnt(0) -> 4 MFMA, four times,
-    // exposing the LDS latency of every group)
-    f32x4 af[2][TM], bf[2][TN];
+    } else {
+      // fragment reads are software-pipelined over two register sets: group g+1 is read from LDS while the
+      // MFMAs of group g issue (with one set the compiler emitted read -> lgkmcnt(0) -> 4 MFMA, four times,
+      // exposing the LDS latency of every group)
+      f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
-    for (int i = 0; i < TM; ++i) af[0][i] = read_frag<BM, A_K>(As, wm0 + 32 * i, 0, li, lh);
+      for (int i = 0; i < TM; ++i) af[0][i] = read_frag<BM, A_K>(As, wm0 + 32 * i, 0, li, lh);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) bf[0][j] = read_frag<BN, B_K>(Bs, wn0 + 32 * j, 0, li, lh);
+      for (int j = 0; j < TN; ++j) bf[0][j] = read_frag<BN, B_K>(Bs, wn0 + 32 * j, 0, li, lh);
 #pragma unroll
-    for (int gq = 0; gq < BK / 8; ++gq) {
-      const int cur = gq & 1, nxt = cur ^ 1;
-      if (gq + 1 < BK / 8) {
+      for (int gq = 0; gq < BK / 8; ++gq) {
+        const int cur = gq & 1, nxt = cur ^ 1;
+        if (gq + 1 < BK / 8) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[nxt][i] = read_frag<BM, A_K>(As, wm0 + 32 * i, gq + 1, li, lh);
+          for (int i = 0; i < TM; ++i) af[nxt][i] = read_frag<BM, A_K>(As, wm0 + 32 * i, gq + 1, li, lh);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[nxt][j] = read_frag<BN, B_K>(Bs, wn0 + 32 * j, gq + 1, li, lh);
+          for (int j = 0; j < TN; ++j) bf[nxt][j] = read_frag<BN, B_K>(Bs, wn0 + 32 * j, gq + 1, li, lh);
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the reads above ahead of the MFMAs below (hipcc sinks them otherwise)
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][s], bf[cur][j][s], acc[i][j], 0, 0, 0);
       }
-      __builtin_amdgcn_sched_barrier(0);   // keep the reads above ahead of the MFMAs below (hipcc sinks them otherwise)
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][s], bf[cur][j][s], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if constexpr (kLdsStages == 2) {
+    // Two LDS stages, ONE barrier per k-tile: while the MFMAs of tile t read stage t&1, tile t+1 (prefetched one
+    // iteration earlier) is written to the other stage and tile t+2 is put in flight.  The barrier at the end of
+    // iteration t orders (writes of t+1) before (reads of t+1) and (reads of t) before (writes of t+2).
+    if (kbeg < kend) {
+      prefetch(kbeg);
+      store_stage(lds, lds + A_ELEMS);
+      if (kbeg + BK < kend) prefetch(kbeg + BK);
+    }
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      float* nxt = lds + (cur ^ 1) * STAGE;
+      if (k0 + BK < kend) {
+        store_stage(nxt, nxt + A_ELEMS);
+        if (k0 + 2 * BK < kend) prefetch(k0 + 2 * BK);
+      }
+      compute(lds + cur * STAGE, lds + cur * STAGE + A_ELEMS);
+      __syncthreads();
+      cur ^= 1;
+    }
+  } else {
+    float* As = lds;
+    float* Bs = lds + A_ELEMS;
+    if (kbeg < kend) prefetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+      __syncthreads();  // everyone is done reading the previous tile
+      store_stage(As, Bs);
+      __syncthreads();
+      if (k0 + BK < kend) prefetch(k0 + BK);   // in flight during the MFMAs below
+      compute(As, Bs);
     }
   }
 
   const bool to_slab = nsplit > 1;
-  if (!A_K && g.colsum_a[grp] != nullptr && blockIdx.x == 0) {   // block-uniform
+  if (!A_K && g.colsum_a[grp] != nullptr && tile_n == 0) {   // block-uniform
     constexpr int Q = BM / 4, RP = 256 / Q;
     __syncthreads();                                  // the last tile's fragment reads are done
     *reinterpret_cast<f32x4*>(lds + (tid / Q) * BM + 4 * (tid % Q)) = csum;
