@@ -48,6 +48,13 @@ constexpr int LDK = BK + 4;
 #define SDUMC_GEMM_LDS_STAGES 1
 #endif
 constexpr int kLdsStages = SDUMC_GEMM_LDS_STAGES;
+#ifndef SDUMC_GEMM_PREFETCH
+#define SDUMC_GEMM_PREFETCH 1
+#endif
+constexpr int kPrefetch = kLdsStages == 2 ? 1 : SDUMC_GEMM_PREFETCH;   // k-tiles in flight in registers
+#ifndef SDUMC_GEMM_WPE64
+#define SDUMC_GEMM_WPE64 4   // waves per SIMD the 64x64 variants are register-allocated for
+#endif
 
 struct TileLoadCtx {
   const float* p;
@@ -150,14 +157,16 @@ struct Stager {
     }
   }
 
-  uint32_t mb[P];     // keep-bits of the tile in flight
-  int mpos;           // k position of the tile in flight (Philox fallback)
+  struct InFlight {   // what apply() needs to know about a tile whose loads are in flight
+    uint32_t mb[P];   // its keep-bits
+    int mpos;         // its k position (Philox fallback)
+  };
 
   // Issues the 16-byte loads (and the keep-bits byte loads) of the next k-tile and returns WITHOUT touching the
   // loaded values: anything that reads them here puts an s_waitcnt vmcnt right behind the load and the prefetch
   // stops overlapping the MFMAs of the current tile.  The dropout mask is applied by apply(), just before the
   // tile is written to LDS one iteration later.
-  __device__ __forceinline__ void load(f32x4 (&reg)[P], const TileLoadCtx& c, int kend) {
+  __device__ __forceinline__ void load(f32x4 (&reg)[P], InFlight& fl, const TileLoadCtx& c, int kend) {
 #pragma unroll
     for (int j = 0; j < P; ++j) {
       const int kk = KC ? pos : pos + RP * j;
@@ -168,7 +177,7 @@ struct Stager {
         if (c.drop.enabled && c.drop.bits) b = c.drop.bits[boff[j]];
       }
       reg[j] = v;
-      mb[j] = b;
+      fl.mb[j] = b;
       off[j] += step;
       if (KC) {
         boff[j] += BK / 4;
@@ -183,23 +192,23 @@ struct Stager {
         }
       }
     }
-    mpos = pos;
+    fl.mpos = pos;
     pos += BK;
   }
 
-  __device__ __forceinline__ void apply(f32x4 (&reg)[P], const TileLoadCtx& c) const {
+  __device__ __forceinline__ void apply(f32x4 (&reg)[P], const InFlight& fl, const TileLoadCtx& c) const {
     if (!c.drop.enabled) return;
 #pragma unroll
     for (int j = 0; j < P; ++j) {
       if (c.drop.bits) {
-        const uint32_t b = mb[j];
+        const uint32_t b = fl.mb[j];
         reg[j][0] = (b & 1u) ? reg[j][0] * c.drop.scale : 0.f;
         reg[j][1] = (b & 2u) ? reg[j][1] * c.drop.scale : 0.f;
         reg[j][2] = (b & 4u) ? reg[j][2] * c.drop.scale : 0.f;
         reg[j][3] = (b & 8u) ? reg[j][3] * c.drop.scale : 0.f;
       } else {   // out-of-range elements were loaded as 0 and stay 0
-        reg[j] *= KC ? drop_mask4(c.drop, (uint32_t)(vrow0 + 32 * j), (uint32_t)(mpos >> 2))
-                     : drop_mask4(c.drop, (uint32_t)(mpos + RP * j), (uint32_t)(vrow0 >> 2));
+        reg[j] *= KC ? drop_mask4(c.drop, (uint32_t)(vrow0 + 32 * j), (uint32_t)(fl.mpos >> 2))
+                     : drop_mask4(c.drop, (uint32_t)(fl.mpos + RP * j), (uint32_t)(vrow0 >> 2));
       }
     }
   }
@@ -253,7 +262,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int LDH = BK + 8;   // bf16 elements per LDS row (80 B): the 16-B fragment reads are conflict-free
 
 template <int BM, int BN, bool A_K, bool B_K, bool BF16 = false>
-__global__ __launch_bounds__(256, (BM == 64 ? 4 : 2)) void gemm_kernel(const sdumc_gemm g, const int nsplit, const int kchunk) {
+__global__ __launch_bounds__(256, (BM == 64 ? SDUMC_GEMM_WPE64 : 2)) void gemm_kernel(const sdumc_gemm g, const int nsplit, const int kchunk) {
   static_assert(!BF16 || (A_K && B_K), "the bf16 variant is built for the NT layout");
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int A_ELEMS = A_K ? BM * LDK : BK * BM;
@@ -331,53 +340,62 @@ __global__ __launch_bounds__(256, (BM == 64 ? 4 : 2)) void gemm_kernel(const sdu
     sa.init(ca, m0, g.M, kbeg, tid);
     sb.init(cb, n0, g.N, kbeg, tid);
   }
-  f32x4 ra[BM / 32], rb[BN / 32];
+  // kPrefetch register sets: set (t % kPrefetch) carries k-tile t from its global loads to its LDS store
+  f32x4 ra[kPrefetch][BM / 32], rb[kPrefetch][BN / 32];
+  typename Stager<BM, A_K>::InFlight fa[kPrefetch];
+  typename Stager<BN, B_K>::InFlight fb[kPrefetch];
   // global -> registers for the k-tile starting at k (nothing reads the registers here: the loads stay in flight)
-  auto prefetch = [&](int k) {
+  auto prefetch = [&](int set, int k) {
     if (fast) {
-      sa.load(ra, ca, kend);
-      sb.load(rb, cb, kend);
+      sa.load(ra[set], fa[set], ca, kend);
+      sb.load(rb[set], fb[set], cb, kend);
     } else {
-      load_tile<BM, A_K>(ra, ca, m0, g.M, k, kend, tid);
-      load_tile<BN, B_K>(rb, cb, n0, g.N, k, kend, tid);
+      load_tile<BM, A_K>(ra[set], ca, m0, g.M, k, kend, tid);
+      load_tile<BN, B_K>(rb[set], cb, n0, g.N, k, kend, tid);
     }
   };
   // registers -> LDS stage.  First use of the prefetched registers: dropout masks and the fused column sums are
   // applied here, not at load time
-  auto store_stage = [&](float* As, float* Bs) {
+  auto store_stage = [&](int set, float* As, float* Bs) {
     if (fast) {
-      sa.apply(ra, ca);
-      sb.apply(rb, cb);
+      sa.apply(ra[set], fa[set], ca);
+      sb.apply(rb[set], fb[set], cb);
     }
     if (do_cs) {
 #pragma unroll
-      for (int j = 0; j < BM / 32; ++j) csum += ra[j];
+      for (int j = 0; j < BM / 32; ++j) csum += ra[set][j];
     }
     if constexpr (BF16) {
       __bf16* Ah = reinterpret_cast<__bf16*>(As);
       __bf16* Bh = reinterpret_cast<__bf16*>(Bs);
 #pragma unroll
       for (int j = 0; j < BM / 32; ++j) {
-        bf16x4 h = {(__bf16)ra[j][0], (__bf16)ra[j][1], (__bf16)ra[j][2], (__bf16)ra[j][3]};
+        bf16x4 h = {(__bf16)ra[set][j][0], (__bf16)ra[set][j][1], (__bf16)ra[set][j][2], (__bf16)ra[set][j][3]};
         *reinterpret_cast<bf16x4*>(Ah + ((tid >> 3) + 32 * j) * LDH + 4 * (tid & 7)) = h;
       }
 #pragma unroll
       for (int j = 0; j < BN / 32; ++j) {
-        bf16x4 h = {(__bf16)rb[j][0], (__bf16)rb[j][1], (__bf16)rb[j][2], (__bf16)rb[j][3]};
+        bf16x4 h = {(__bf16)rb[set][j][0], (__bf16)rb[set][j][1], (__bf16)rb[set][j][2], (__bf16)rb[set][j][3]};
         *reinterpret_cast<bf16x4*>(Bh + ((tid >> 3) + 32 * j) * LDH + 4 * (tid & 7)) = h;
       }
     } else {
-      store_tile<BM, A_K>(As, ra, tid);
-      store_tile<BN, B_K>(Bs, rb, tid);
+      store_tile<BM, A_K>(As, ra[set], tid);
+      store_tile<BN, B_K>(Bs, rb[set], tid);
     }
   };
   // one k-tile of MFMAs from an LDS stage
-  auto compute = [&](const float* As, const float* Bs) {
+  auto no_hook = [] {};
+  // after0 / after1 run right behind the MFMAs of fragment group 0 / 1 are ISSUED, i.e. they execute in the shadow
+  // of those MFMAs (a 32x32x2 MFMA occupies the pipe for 64 cycles after its issue): the two-stage loop puts the
+  // LDS store of the next tile and the global loads of the one after there.
+  auto compute = [&](const float* As, const float* Bs, auto&& after0, auto&& after1) {
     if constexpr (BF16) {
       // lane (r = lane&31, h = lane>>5) holds A[row r][k = 16 ks + 8 h .. +7] and the same k range of B's row
       const __bf16* Ah = reinterpret_cast<const __bf16*>(As);
       const __bf16* Bh = reinterpret_cast<const __bf16*>(Bs);
       bf16x8 ah[BK / 16][TM], bh[BK / 16][TN];
+      after0();
+      after1();
 #pragma unroll
       for (int ks = 0; ks < BK / 16; ++ks) {
 #pragma unroll
@@ -418,6 +436,15 @@ __global__ __launch_bounds__(256, (BM == 64 ? 4 : 2)) void gemm_kernel(const sdu
 #pragma unroll
             for (int j = 0; j < TN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][s], bf[cur][j][s], acc[i][j], 0, 0, 0);
+        if (gq == 0) {
+          __builtin_amdgcn_sched_barrier(0);
+          after0();
+          __builtin_amdgcn_sched_barrier(0);
+        } else if (gq == 1) {
+          __builtin_amdgcn_sched_barrier(0);
+          after1();
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
   };
@@ -426,33 +453,44 @@ __global__ __launch_bounds__(256, (BM == 64 ? 4 : 2)) void gemm_kernel(const sdu
     // Two LDS stages, ONE barrier per k-tile: while the MFMAs of tile t read stage t&1, tile t+1 (prefetched one
     // iteration earlier) is written to the other stage and tile t+2 is put in flight.  The barrier at the end of
     // iteration t orders (writes of t+1) before (reads of t+1) and (reads of t) before (writes of t+2).
+    // (Measured slower than the one-stage loop on MI355X: 2.47 vs 2.32 ms per step; kept as a build variant.)
     if (kbeg < kend) {
-      prefetch(kbeg);
-      store_stage(lds, lds + A_ELEMS);
-      if (kbeg + BK < kend) prefetch(kbeg + BK);
+      prefetch(0, kbeg);
+      store_stage(0, lds, lds + A_ELEMS);
+      if (kbeg + BK < kend) prefetch(0, kbeg + BK);
     }
     __syncthreads();
     int cur = 0;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
       float* nxt = lds + (cur ^ 1) * STAGE;
-      if (k0 + BK < kend) {
-        store_stage(nxt, nxt + A_ELEMS);
-        if (k0 + 2 * BK < kend) prefetch(k0 + 2 * BK);
-      }
-      compute(lds + cur * STAGE, lds + cur * STAGE + A_ELEMS);
+      const bool more1 = k0 + BK < kend, more2 = k0 + 2 * BK < kend;   // block-uniform
+      compute(
+          lds + cur * STAGE, lds + cur * STAGE + A_ELEMS,
+          [&] { if (more1) store_stage(0, nxt, nxt + A_ELEMS); },
+          [&] { if (more2) prefetch(0, k0 + 2 * BK); });
       __syncthreads();
       cur ^= 1;
     }
   } else {
     float* As = lds;
     float* Bs = lds + A_ELEMS;
-    if (kbeg < kend) prefetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-      __syncthreads();  // everyone is done reading the previous tile
-      store_stage(As, Bs);
-      __syncthreads();
-      if (k0 + BK < kend) prefetch(k0 + BK);   // in flight during the MFMAs below
-      compute(As, Bs);
+    // kPrefetch k-tiles are kept in flight: tile t is stored (and its register set refilled with tile
+    // t + kPrefetch) at the top of iteration t.  The loop is unrolled by kPrefetch so that `set` is static.
+#pragma unroll
+    for (int p = 0; p < kPrefetch; ++p)
+      if (kbeg + p * BK < kend) prefetch(p, kbeg + p * BK);
+    for (int k0 = kbeg; k0 < kend; k0 += kPrefetch * BK) {
+#pragma unroll
+      for (int p = 0; p < kPrefetch; ++p) {
+        const int k = k0 + p * BK;
+        if (k < kend) {   // block-uniform
+          __syncthreads();  // everyone is done reading the previous tile
+          store_stage(p, As, Bs);
+          __syncthreads();
+          if (k + kPrefetch * BK < kend) prefetch(p, k + kPrefetch * BK);   // in flight during the MFMAs below
+          compute(As, Bs, no_hook, no_hook);
+        }
+      }
     }
   }
 
