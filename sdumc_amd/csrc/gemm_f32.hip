@@ -21,6 +21,7 @@
 //     accumulate, deterministic split-K (slabs + ordered reduce; no float atomics).
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -44,14 +45,6 @@ const char* const kVariantName[kNumVariants] = {"gemm_nt_128x128", "gemm_nt_64x6
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;
-#ifndef SDUMC_GEMM_LDS_STAGES
-#define SDUMC_GEMM_LDS_STAGES 1
-#endif
-constexpr int kLdsStages = SDUMC_GEMM_LDS_STAGES;
-#ifndef SDUMC_GEMM_PREFETCH
-#define SDUMC_GEMM_PREFETCH 1
-#endif
-constexpr int kPrefetch = kLdsStages == 2 ? 1 : SDUMC_GEMM_PREFETCH;   // k-tiles in flight in registers
 #ifndef SDUMC_GEMM_WPE64
 #define SDUMC_GEMM_WPE64 4   // waves per SIMD the 64x64 variants are register-allocated for
 #endif
@@ -122,7 +115,7 @@ struct Stager {
   int src[P];         // !KC with row_mod: current source row (to wrap)
   int pos;            // KC: this thread's current k;  !KC: current k row of j = 0
   uint32_t ok;        // bit j: the k-invariant coordinate is in range
-  int vrow0;          // KC: first row (Philox fallback) / !KC: this thread's column
+  int vrow0;          // KC: this thread's first row / !KC: this thread's column
   uint32_t step, wrap;
 
   __device__ __forceinline__ void init(const TileLoadCtx& c, int r0, int R, int kbeg, int tid) {
@@ -157,16 +150,12 @@ struct Stager {
     }
   }
 
-  struct InFlight {   // what apply() needs to know about a tile whose loads are in flight
-    uint32_t mb[P];   // its keep-bits
-    int mpos;         // its k position (Philox fallback)
-  };
-
-  // Issues the 16-byte loads (and the keep-bits byte loads) of the next k-tile and returns WITHOUT touching the
-  // loaded values: anything that reads them here puts an s_waitcnt vmcnt right behind the load and the prefetch
-  // stops overlapping the MFMAs of the current tile.  The dropout mask is applied by apply(), just before the
-  // tile is written to LDS one iteration later.
-  __device__ __forceinline__ void load(f32x4 (&reg)[P], InFlight& fl, const TileLoadCtx& c, int kend) {
+  // Issues the 16-byte loads (and, with MASK, the keep-bits byte loads) of the next k-tile and returns WITHOUT touching
+  // the loaded values: anything that reads them here puts an s_waitcnt vmcnt right behind the load and the prefetch
+  // stops overlapping the MFMAs of the current tile.  The dropout mask is applied by apply(), just before the tile
+  // is written to LDS one iteration later.
+  template <bool MASK>
+  __device__ __forceinline__ void load(f32x4 (&reg)[P], uint32_t (&mb)[P], const TileLoadCtx& c, int kend) {
 #pragma unroll
     for (int j = 0; j < P; ++j) {
       const int kk = KC ? pos : pos + RP * j;
@@ -174,10 +163,10 @@ struct Stager {
       uint32_t b = 0;
       if (((ok >> j) & 1u) && kk < kend) {
         v = *reinterpret_cast<const f32x4*>(c.p + off[j]);
-        if (c.drop.enabled && c.drop.bits) b = c.drop.bits[boff[j]];
+        if (MASK) b = c.drop.bits[boff[j]];
       }
       reg[j] = v;
-      fl.mb[j] = b;
+      mb[j] = b;
       off[j] += step;
       if (KC) {
         boff[j] += BK / 4;
@@ -192,24 +181,18 @@ struct Stager {
         }
       }
     }
-    fl.mpos = pos;
     pos += BK;
   }
 
-  __device__ __forceinline__ void apply(f32x4 (&reg)[P], const InFlight& fl, const TileLoadCtx& c) const {
-    if (!c.drop.enabled) return;
+  // keep-bits -> the four multiplicative mask values (out-of-range elements were loaded as 0 and stay 0)
+  __device__ __forceinline__ static void apply(f32x4 (&reg)[P], const uint32_t (&mb)[P], float scale) {
 #pragma unroll
     for (int j = 0; j < P; ++j) {
-      if (c.drop.bits) {
-        const uint32_t b = fl.mb[j];
-        reg[j][0] = (b & 1u) ? reg[j][0] * c.drop.scale : 0.f;
-        reg[j][1] = (b & 2u) ? reg[j][1] * c.drop.scale : 0.f;
-        reg[j][2] = (b & 4u) ? reg[j][2] * c.drop.scale : 0.f;
-        reg[j][3] = (b & 8u) ? reg[j][3] * c.drop.scale : 0.f;
-      } else {   // out-of-range elements were loaded as 0 and stay 0
-        reg[j] *= KC ? drop_mask4(c.drop, (uint32_t)(vrow0 + 32 * j), (uint32_t)(fl.mpos >> 2))
-                     : drop_mask4(c.drop, (uint32_t)(fl.mpos + RP * j), (uint32_t)(vrow0 >> 2));
-      }
+      const uint32_t b = mb[j];
+      reg[j][0] = (b & 1u) ? reg[j][0] * scale : 0.f;
+      reg[j][1] = (b & 2u) ? reg[j][1] * scale : 0.f;
+      reg[j][2] = (b & 4u) ? reg[j][2] * scale : 0.f;
+      reg[j][3] = (b & 8u) ? reg[j][3] * scale : 0.f;
     }
   }
 };
@@ -267,8 +250,7 @@ __global__ __launch_bounds__(256, (BM == 64 ? SDUMC_GEMM_WPE64 : 2)) void gemm_k
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int A_ELEMS = A_K ? BM * LDK : BK * BM;
   constexpr int B_ELEMS = B_K ? BN * LDK : BK * BN;
-  constexpr int STAGE = A_ELEMS + B_ELEMS;
-  __shared__ __attribute__((aligned(16))) float lds[kLdsStages * STAGE];
+  __shared__ __attribute__((aligned(16))) float lds[A_ELEMS + B_ELEMS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
@@ -331,71 +313,19 @@ __global__ __launch_bounds__(256, (BM == 64 ? SDUMC_GEMM_WPE64 : 2)) void gemm_k
   const bool do_cs = !A_K && g.colsum_a[grp] != nullptr && tile_n == 0;
   f32x4 csum = {0.f, 0.f, 0.f, 0.f};
 
-  // 32-bit element offsets: fine for every operand below 2^32 floats (16 GiB)
+  // 32-bit element offsets: fine for every operand below 2^32 floats (16 GiB).  A fused dropout without precomputed
+  // keep-bits (Philox recomputed in the loader: tests, one-off calls) takes the generic path.
+  const bool mask_a = ca.drop.enabled != 0, mask_b = cb.drop.enabled != 0;
   const bool fast = ca.vec && cb.vec && BK < (ca.row_mod > 0 ? ca.row_mod : BK + 1) &&
-                    BK < (cb.row_mod > 0 ? cb.row_mod : BK + 1);
-  Stager<BM, A_K> sa;
-  Stager<BN, B_K> sb;
-  if (fast) {
-    sa.init(ca, m0, g.M, kbeg, tid);
-    sb.init(cb, n0, g.N, kbeg, tid);
-  }
-  // kPrefetch register sets: set (t % kPrefetch) carries k-tile t from its global loads to its LDS store
-  f32x4 ra[kPrefetch][BM / 32], rb[kPrefetch][BN / 32];
-  typename Stager<BM, A_K>::InFlight fa[kPrefetch];
-  typename Stager<BN, B_K>::InFlight fb[kPrefetch];
-  // global -> registers for the k-tile starting at k (nothing reads the registers here: the loads stay in flight)
-  auto prefetch = [&](int set, int k) {
-    if (fast) {
-      sa.load(ra[set], fa[set], ca, kend);
-      sb.load(rb[set], fb[set], cb, kend);
-    } else {
-      load_tile<BM, A_K>(ra[set], ca, m0, g.M, k, kend, tid);
-      load_tile<BN, B_K>(rb[set], cb, n0, g.N, k, kend, tid);
-    }
-  };
-  // registers -> LDS stage.  First use of the prefetched registers: dropout masks and the fused column sums are
-  // applied here, not at load time
-  auto store_stage = [&](int set, float* As, float* Bs) {
-    if (fast) {
-      sa.apply(ra[set], fa[set], ca);
-      sb.apply(rb[set], fb[set], cb);
-    }
-    if (do_cs) {
-#pragma unroll
-      for (int j = 0; j < BM / 32; ++j) csum += ra[set][j];
-    }
-    if constexpr (BF16) {
-      __bf16* Ah = reinterpret_cast<__bf16*>(As);
-      __bf16* Bh = reinterpret_cast<__bf16*>(Bs);
-#pragma unroll
-      for (int j = 0; j < BM / 32; ++j) {
-        bf16x4 h = {(__bf16)ra[set][j][0], (__bf16)ra[set][j][1], (__bf16)ra[set][j][2], (__bf16)ra[set][j][3]};
-        *reinterpret_cast<bf16x4*>(Ah + ((tid >> 3) + 32 * j) * LDH + 4 * (tid & 7)) = h;
-      }
-#pragma unroll
-      for (int j = 0; j < BN / 32; ++j) {
-        bf16x4 h = {(__bf16)rb[set][j][0], (__bf16)rb[set][j][1], (__bf16)rb[set][j][2], (__bf16)rb[set][j][3]};
-        *reinterpret_cast<bf16x4*>(Bh + ((tid >> 3) + 32 * j) * LDH + 4 * (tid & 7)) = h;
-      }
-    } else {
-      store_tile<BM, A_K>(As, ra[set], tid);
-      store_tile<BN, B_K>(Bs, rb[set], tid);
-    }
-  };
-  // one k-tile of MFMAs from an LDS stage
-  auto no_hook = [] {};
-  // after0 / after1 run right behind the MFMAs of fragment group 0 / 1 are ISSUED, i.e. they execute in the shadow
-  // of those MFMAs (a 32x32x2 MFMA occupies the pipe for 64 cycles after its issue): the two-stage loop puts the
-  // LDS store of the next tile and the global loads of the one after there.
-  auto compute = [&](const float* As, const float* Bs, auto&& after0, auto&& after1) {
+                    BK < (cb.row_mod > 0 ? cb.row_mod : BK + 1) && (!mask_a || ca.drop.bits) && (!mask_b || cb.drop.bits);
+
+  // One k-tile of MFMAs from the LDS stage.
+  auto compute = [&](const float* As, const float* Bs) {
     if constexpr (BF16) {
       // lane (r = lane&31, h = lane>>5) holds A[row r][k = 16 ks + 8 h .. +7] and the same k range of B's row
       const __bf16* Ah = reinterpret_cast<const __bf16*>(As);
       const __bf16* Bh = reinterpret_cast<const __bf16*>(Bs);
       bf16x8 ah[BK / 16][TM], bh[BK / 16][TN];
-      after0();
-      after1();
 #pragma unroll
       for (int ks = 0; ks < BK / 16; ++ks) {
 #pragma unroll
@@ -436,60 +366,91 @@ __global__ __launch_bounds__(256, (BM == 64 ? SDUMC_GEMM_WPE64 : 2)) void gemm_k
 #pragma unroll
             for (int j = 0; j < TN; ++j)
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][s], bf[cur][j][s], acc[i][j], 0, 0, 0);
-        if (gq == 0) {
-          __builtin_amdgcn_sched_barrier(0);
-          after0();
-          __builtin_amdgcn_sched_barrier(0);
-        } else if (gq == 1) {
-          __builtin_amdgcn_sched_barrier(0);
-          after1();
-          __builtin_amdgcn_sched_barrier(0);
-        }
       }
     }
   };
+  auto store_stage = [&](float* As, float* Bs, const f32x4 (&ra)[BM / 32], const f32x4 (&rb)[BN / 32]) {
+    if constexpr (BF16) {
+      __bf16* Ah = reinterpret_cast<__bf16*>(As);
+      __bf16* Bh = reinterpret_cast<__bf16*>(Bs);
+#pragma unroll
+      for (int j = 0; j < BM / 32; ++j) {
+        bf16x4 h = {(__bf16)ra[j][0], (__bf16)ra[j][1], (__bf16)ra[j][2], (__bf16)ra[j][3]};
+        *reinterpret_cast<bf16x4*>(Ah + ((tid >> 3) + 32 * j) * LDH + 4 * (tid & 7)) = h;
+      }
+#pragma unroll
+      for (int j = 0; j < BN / 32; ++j) {
+        bf16x4 h = {(__bf16)rb[j][0], (__bf16)rb[j][1], (__bf16)rb[j][2], (__bf16)rb[j][3]};
+        *reinterpret_cast<bf16x4*>(Bh + ((tid >> 3) + 32 * j) * LDH + 4 * (tid & 7)) = h;
+      }
+    } else {
+      store_tile<BM, A_K>(As, ra, tid);
+      store_tile<BN, B_K>(Bs, rb, tid);
+    }
+  };
 
-  if constexpr (kLdsStages == 2) {
-    // Two LDS stages, ONE barrier per k-tile: while the MFMAs of tile t read stage t&1, tile t+1 (prefetched one
-    // iteration earlier) is written to the other stage and tile t+2 is put in flight.  The barrier at the end of
-    // iteration t orders (writes of t+1) before (reads of t+1) and (reads of t) before (writes of t+2).
-    // (Measured slower than the one-stage loop on MI355X: 2.47 vs 2.32 ms per step; kept as a build variant.)
-    if (kbeg < kend) {
-      prefetch(0, kbeg);
-      store_stage(0, lds, lds + A_ELEMS);
-      if (kbeg + BK < kend) prefetch(0, kbeg + BK);
+  // The k-loop, instantiated once per combination of the block-uniform run-time switches
+  //   FAST (aligned operands, hoisted addressing), MA / MB (keep-bits mask on the A / B operand), CS (fused column sums)
+  // so that its body carries no scalar branches on them (the one loop that tested them per k-tile spent ~10 taken/not
+  // taken s_cbranch per iteration and kept every variant's registers live).
+  // Structure: global -> registers (prefetch of tile t+1 in flight during the MFMAs of tile t) -> LDS -> fragments.
+  float* const As = lds;
+  float* const Bs = lds + A_ELEMS;
+  auto k_loop = [&](auto fast_c, auto ma_c, auto mb_c, auto cs_c) {
+    constexpr bool FAST = decltype(fast_c)::value, MA = decltype(ma_c)::value, MB = decltype(mb_c)::value,
+                   CS = decltype(cs_c)::value;
+    Stager<BM, A_K> sa;
+    Stager<BN, B_K> sb;
+    if constexpr (FAST) {
+      sa.init(ca, m0, g.M, kbeg, tid);
+      sb.init(cb, n0, g.N, kbeg, tid);
     }
-    __syncthreads();
-    int cur = 0;
+    f32x4 ra[BM / 32], rb[BN / 32];
+    uint32_t ba[BM / 32], bb[BN / 32];
+    // nothing reads the registers here: the loads stay in flight
+    auto prefetch = [&](int k) {
+      if constexpr (FAST) {
+        sa.template load<MA>(ra, ba, ca, kend);
+        sb.template load<MB>(rb, bb, cb, kend);
+      } else {
+        load_tile<BM, A_K>(ra, ca, m0, g.M, k, kend, tid);
+        load_tile<BN, B_K>(rb, cb, n0, g.N, k, kend, tid);
+      }
+    };
+    if (kbeg < kend) prefetch(kbeg);
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
-      float* nxt = lds + (cur ^ 1) * STAGE;
-      const bool more1 = k0 + BK < kend, more2 = k0 + 2 * BK < kend;   // block-uniform
-      compute(
-          lds + cur * STAGE, lds + cur * STAGE + A_ELEMS,
-          [&] { if (more1) store_stage(0, nxt, nxt + A_ELEMS); },
-          [&] { if (more2) prefetch(0, k0 + 2 * BK); });
+      // first use of the prefetched registers: dropout masks and the fused column sums are applied here, not at
+      // load time
+      if constexpr (FAST && MA) Stager<BM, A_K>::apply(ra, ba, ca.drop.scale);
+      if constexpr (FAST && MB) Stager<BN, B_K>::apply(rb, bb, cb.drop.scale);
+      if constexpr (CS) {
+#pragma unroll
+        for (int j = 0; j < BM / 32; ++j) csum += ra[j];
+      }
+      __syncthreads();  // everyone is done reading the previous tile
+      store_stage(As, Bs, ra, rb);
       __syncthreads();
-      cur ^= 1;
+      if (k0 + BK < kend) prefetch(k0 + BK);   // in flight during the MFMAs below
+      compute(As, Bs);
     }
-  } else {
-    float* As = lds;
-    float* Bs = lds + A_ELEMS;
-    // kPrefetch k-tiles are kept in flight: tile t is stored (and its register set refilled with tile
-    // t + kPrefetch) at the top of iteration t.  The loop is unrolled by kPrefetch so that `set` is static.
-#pragma unroll
-    for (int p = 0; p < kPrefetch; ++p)
-      if (kbeg + p * BK < kend) prefetch(p, kbeg + p * BK);
-    for (int k0 = kbeg; k0 < kend; k0 += kPrefetch * BK) {
-#pragma unroll
-      for (int p = 0; p < kPrefetch; ++p) {
-        const int k = k0 + p * BK;
-        if (k < kend) {   // block-uniform
-          __syncthreads();  // everyone is done reading the previous tile
-          store_stage(p, As, Bs);
-          __syncthreads();
-          if (k + kPrefetch * BK < kend) prefetch(p, k + kPrefetch * BK);   // in flight during the MFMAs below
-          compute(As, Bs, no_hook, no_hook);
-        }
+  };
+  {
+    using T = std::true_type;
+    using F = std::false_type;
+    if constexpr (A_K) {          // NT / NN: optional mask on A
+      if (!fast) k_loop(F{}, F{}, F{}, F{});
+      else if (mask_a) k_loop(T{}, T{}, F{}, F{});
+      else k_loop(T{}, F{}, F{}, F{});
+    } else {                      // TN: optional mask on B, optional column sums of A
+      if (!fast) {
+        if (do_cs) k_loop(F{}, F{}, F{}, T{});
+        else k_loop(F{}, F{}, F{}, F{});
+      } else if (mask_b) {
+        if (do_cs) k_loop(T{}, F{}, T{}, T{});
+        else k_loop(T{}, F{}, T{}, F{});
+      } else {
+        if (do_cs) k_loop(T{}, F{}, F{}, T{});
+        else k_loop(T{}, F{}, F{}, F{});
       }
     }
   }
