@@ -304,11 +304,11 @@ int sdumc_gather_pad(const float* packed, const int64_t* start, const int32_t* l
  * biased variance, rstd = 1/sqrt(var + eps).  mean / rstd [rows] are saved for the backward. */
 int sdumc_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* rstd,
                         int64_t rows, int32_t width, float eps, void* stream);
-/* dx (+)= LayerNorm backward (accumulate_dx: the residual branch's gradient is already in dx);
+/* dx = LayerNorm backward (+ dx_add when not NULL: the residual branch's gradient meeting at x; dx_add may alias dx);
  * dgamma, dbeta [width] overwritten (deterministic two-stage column reduction through `workspace`). */
 size_t sdumc_layernorm_bwd_workspace_bytes(int64_t rows, int32_t width);
 int sdumc_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean, const float* rstd,
-                        float* dx, float* dgamma, float* dbeta, int32_t accumulate_dx, int64_t rows, int32_t width,
+                        float* dx, float* dgamma, float* dbeta, const float* dx_add, int64_t rows, int32_t width,
                         float* workspace, size_t workspace_bytes, void* stream);
 
 /* Softmax over the key axis of the attention scores, with the additive mask, the attention dropout and the

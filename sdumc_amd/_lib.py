@@ -183,7 +183,7 @@ _SIGS = {
     # generic MHA / Transformer-encoder pieces (transformer.hip)
     "sdumc_layernorm_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
     "sdumc_layernorm_bwd_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
-    "sdumc_layernorm_bwd": (C.c_int, [C.c_void_p] * 8 + [C.c_int32, C.c_int64, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sdumc_layernorm_bwd": (C.c_int, [C.c_void_p] * 9 + [C.c_int64, C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sdumc_softmax_fwd": (C.c_int, [C.POINTER(Softmax), C.c_void_p]),
     "sdumc_softmax_bwd": (C.c_int, [C.POINTER(Softmax), C.c_void_p, C.c_void_p]),
     "sdumc_drop_add": (C.c_int, [C.POINTER(DropAdd), C.c_void_p]),

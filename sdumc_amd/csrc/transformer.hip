@@ -122,8 +122,8 @@ template <int W, int MAXU>
 __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ mean,
-                                                               const float* __restrict__ rstd, float* __restrict__ dx,
-                                                               int accumulate, int64_t rows, int width) {
+                                                               const float* __restrict__ rstd, float* dx,
+                                                               const float* dx_add, int64_t rows, int width) {
   constexpr int NC = MAXU > 0 ? MAXU : 1;
   const int lane = threadIdx.x & 63;
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -131,6 +131,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __re
   const float* xr = x + row * width;
   const float* dr = dy + row * width;
   float* or_ = dx + row * width;
+  const float* ar = dx_add ? dx_add + row * width : nullptr;
   const int nu = width / W;
   const float mu = mean[row], rs = rstd[row];
   float xh[NC][W], dh[NC][W];   // xhat and g*dy
@@ -158,11 +159,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_dx_kernel(const float* __re
   for_units<MAXU>(nu, lane, [&](int i, int u) {
     if constexpr (MAXU == 0) fetch(0, u);
     float o[W];
-    if (accumulate) ldu<W>(o, or_ + u * W);
+    if (ar) ldu<W>(o, ar + u * W);
 #pragma unroll
     for (int e = 0; e < W; ++e) {
       const float d = rs * (dh[i][e] - m1 - xh[i][e] * m2);
-      o[e] = accumulate ? o[e] + d : d;
+      o[e] = ar ? o[e] + d : d;
     }
     stu<W>(or_ + u * W, o);
   });
@@ -202,7 +203,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_gb_stage2(const float* __re
 }
 
 int ln_chunks(int64_t rows, int* rows_per_chunk) {
-  int rpc = (int)std::max<int64_t>(32, (rows + 511) / 512);
+  // <= 128 row chunks: stage 2 walks them serially per column (512 chunks cost 124 us at 16k rows x 1024; 128: ~30 us)
+  int rpc = (int)std::max<int64_t>(64, (rows + 127) / 128);
   *rows_per_chunk = rpc;
   return (int)((rows + rpc - 1) / rpc);
 }
@@ -519,14 +521,14 @@ extern "C" size_t sdumc_layernorm_bwd_workspace_bytes(int64_t rows, int32_t widt
 }
 
 extern "C" int sdumc_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* mean,
-                                   const float* rstd, float* dx, float* dgamma, float* dbeta, int32_t accumulate_dx,
+                                   const float* rstd, float* dx, float* dgamma, float* dbeta, const float* dx_add,
                                    int64_t rows, int32_t width, float* workspace, size_t workspace_bytes, void* stream) {
   if (!dy || !x || !gamma || !mean || !rstd || rows <= 0 || width <= 0) return SDUMC_EINVAL;
   hipStream_t st = as_stream(stream);
   if (dx) {
-    const bool vec = (width & 3) == 0 && aligned16(x) && aligned16(dy) && aligned16(gamma) && aligned16(dx);
+    const bool vec = (width & 3) == 0 && aligned16(x) && aligned16(dy) && aligned16(gamma) && aligned16(dx) && aligned16(dx_add);
     const dim3 grid((unsigned)((rows + 3) / 4)), blk(256);
-#define LN_BWD(W, U) hipLaunchKernelGGL((layernorm_bwd_dx_kernel<W, U>), grid, blk, 0, st, dy, x, gamma, mean, rstd, dx, accumulate_dx, rows, width)
+#define LN_BWD(W, U) hipLaunchKernelGGL((layernorm_bwd_dx_kernel<W, U>), grid, blk, 0, st, dy, x, gamma, mean, rstd, dx, dx_add, rows, width)
     dispatch_row(vec, width, [&] { LN_BWD(4, 2); }, [&] { LN_BWD(4, 8); }, [&] { LN_BWD(4, 0); }, [&] { LN_BWD(1, 8); },
                  [&] { LN_BWD(1, 0); });
 #undef LN_BWD

@@ -209,17 +209,17 @@ def layernorm_fwd(x, gamma, beta, eps=1e-5):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x, gamma, mean, rstd, dx_accumulate_into=None, need_params=True):
+def layernorm_bwd(dy, x, gamma, mean, rstd, dx_add=None, need_params=True):
+    """dx = LayerNorm backward (+ dx_add: the residual branch's gradient at x, summed in the same kernel)."""
     width = x.shape[-1]
     rows = x.numel() // width
-    dx = dx_accumulate_into if dx_accumulate_into is not None else torch.empty_like(x)
+    dx = torch.empty_like(x)
     dg = torch.empty(width, device=x.device) if need_params else None
     db = torch.empty(width, device=x.device) if need_params else None
     need = lib.sdumc_layernorm_bwd_workspace_bytes(rows, width)
     ws = torch.empty(max(need, 16), dtype=torch.uint8, device=x.device)
     check(lib.sdumc_layernorm_bwd(ptr(dy), ptr(x), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx), ptr(dg), ptr(db),
-                                  1 if dx_accumulate_into is not None else 0, rows, width, ptr(ws), need, _st()),
-          "sdumc_layernorm_bwd")
+                                  ptr(dx_add), rows, width, ptr(ws), need, _st()), "sdumc_layernorm_bwd")
     return dx, dg, db
 
 

@@ -129,6 +129,26 @@ class _LayerNormFn(torch.autograd.Function):
         return dx, dg, db, None
 
 
+class _NormResidualFn(torch.autograd.Function):
+    """(LayerNorm(x), x): the normalised branch input and the residual passthrough of a pre-LN block as ONE node, so
+    that the two gradients meeting at x are summed by the LayerNorm backward kernel (accumulate_dx) instead of a
+    separate element-wise add."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        x, gamma, beta = _c(x), _c(gamma), _c(beta)
+        _dev(x, gamma, beta)
+        y, mean, rstd = ops.layernorm_fwd(x, gamma, beta, eps)
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dres):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dx, dg, db = ops.layernorm_bwd(_c(dy), x, gamma, mean, rstd, dx_add=_c(dres))
+        return dx, dg, db, None
+
+
 class _DropAddFn(torch.autograd.Function):
     """y = drop(alpha * x + pos) + residual."""
 
@@ -385,8 +405,15 @@ class TransformerEncoderLayer(nn.Module):
         assert before ^ after
         return self._norm(i, x, pre=before)
 
+    def _norm_split(self, i, x):
+        """(branch input, residual) of sub-block i."""
+        if self.normalize_before:
+            ln = self.layer_norms[i]
+            return _NormResidualFn.apply(x, ln.weight, ln.bias, ln.eps)
+        return x, x
+
     def _attention_block(self, x, x_k, x_v):
-        h = self._norm(0, x, pre=True)
+        h, x = self._norm_split(0, x)
         mask = buffered_future_mask(h, x_k) if self.attn_mask else None
         if x_k is None and x_v is None:
             k = v = h          # one tensor: the fused self-attention projection path
@@ -396,7 +423,7 @@ class TransformerEncoderLayer(nn.Module):
         return self._norm(0, _dropout_add(h, x, self.res_dropout, self.training), pre=False)
 
     def _ffn_block(self, x):
-        h = self._norm(1, x, pre=True)
+        h, x = self._norm_split(1, x)
         T, B, _ = h.shape
         drop = dropout_stream.draw(self.relu_dropout, T, B, 4 * self.embed_dim, self.training)
         h = _linear(h, self.fc1.weight, self.fc1.bias, relu=True, drop=drop)   # ReLU + dropout in the GEMM epilogue

@@ -74,7 +74,7 @@ def test_layernorm_fwd_bwd(ops, rows, width):
     dx, dw, db = ops.layernorm_bwd(Rg, xg, wg, mean, rstd)
     close(dx, x.grad, 2e-5, "dx"); close(dw, w.grad, 2e-5, "dw"); close(db, b.grad, 2e-5, "db")
     base = torch.randn(rows, width, generator=g).cuda()
-    acc, _, _ = ops.layernorm_bwd(Rg, xg, wg, mean, rstd, dx_accumulate_into=base.clone(), need_params=False)
+    acc, _, _ = ops.layernorm_bwd(Rg, xg, wg, mean, rstd, dx_add=base, need_params=False)
     close(acc, base.double().cpu() + x.grad, 2e-5, "dx accumulate")
 
 
