@@ -511,10 +511,10 @@ __global__ __launch_bounds__(256, (BM == 64 ? SDUMC_GEMM_WPE64 : 2)) void gemm_k
 // (no LDS staging, no barriers in the k-loop, several k-groups of loads in flight at once), then the four
 // partial tiles are summed through LDS in a fixed order and the usual fused epilogue runs.
 // ------------------------------------------------------------------------------------------------
-template <bool A_K, bool B_K>
-__global__ __launch_bounds__(256) void gemm_small_kernel(const sdumc_gemm g, const int kq /* k per wave, multiple of 8 */) {
-  __shared__ float part[4][32 * 33];
-  __shared__ float cs_s[4][32];
+template <bool A_K, bool B_K, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_small_kernel(const sdumc_gemm g, const int kq /* k per wave, multiple of 8 */) {
+  __shared__ float part[NW][32 * 33];
+  __shared__ float cs_s[NW][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int grp = blockIdx.z, m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
@@ -586,7 +586,9 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const sdumc_gemm g, con
   }
   __syncthreads();
   if (do_cs && tid < 32 && m0 + tid < g.M) {
-    const float sum = (cs_s[0][tid] + cs_s[1][tid]) + (cs_s[2][tid] + cs_s[3][tid]);
+    float sum = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) sum += cs_s[w][tid];
     float* dst = g.colsum_a[grp] + m0 + tid;
     *dst = g.accumulate ? *dst + sum : sum;
   }
@@ -596,11 +598,13 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const sdumc_gemm g, con
   DropRT cd = drop_resolve(g.c_drop);
   cd.site += (uint32_t)(grp * g.c_drop_group_stride);
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int o = tid + 256 * q, r = o >> 5, c = o & 31;
+  for (int q = 0; q < 16 / NW; ++q) {
+    const int o = tid + 64 * NW * q, r = o >> 5, c = o & 31;
     const int row = m0 + r, col = n0 + c;
     if (row >= g.M || col >= g.N) continue;
-    float v = (part[0][r * 33 + c] + part[1][r * 33 + c]) + (part[2][r * 33 + c] + part[3][r * 33 + c]);
+    float v = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) v += part[w][r * 33 + c];   // fixed order: deterministic
     v = apply_act(v + (bias ? bias[col] : 0.f), g.act);
     if (cd.enabled) v *= drop_mask1(cd, (uint32_t)row, (uint32_t)col);
     float* dst = C + (size_t)row * g.ldc + col;
@@ -642,10 +646,17 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const sdumc_gemm g, 
   *dst = v;
 }
 
+// small-problem kernel: 8 waves split K when each still gets >= 16 k (one batch of loads per wave up to K = 512)
+#ifndef SDUMC_SMALL_WAVES_MAX
+#define SDUMC_SMALL_WAVES_MAX 4   // 8 waves splitting K measured 1.5 % slower per step (2.289 vs 2.255 ms): more partial tiles to meet in LDS
+#endif
+inline int small_waves(int K) { return (SDUMC_SMALL_WAVES_MAX == 8 && K >= 128) ? 8 : 4; }
+
 struct GemmPlan {
   int tile;    // 1 = 128x128, 2 = 64x64, 3 = small-problem kernel (32x32 tile, intra-workgroup split-K)
   int nsplit;
   int kchunk;
+  int waves = 4;   // tile 3 only
 };
 
 size_t plan_ws_bytes(const sdumc_gemm& g, int nsplit) {
@@ -676,7 +687,8 @@ GemmPlan plan_gemm(const sdumc_gemm& g, size_t ws_bytes) {
     if (!g.bf16 && g.batch <= 1 && ((g.tile == 0 && g.splitk <= 1 && t32 <= 768 && g.K <= 1024 && plain) || g.tile == 3 || masked)) {
       p.tile = 3;
       p.nsplit = 1;
-      p.kchunk = ((((g.K + 3) / 4) + 7) / 8) * 8;   // k per wave
+      p.waves = small_waves(g.K);                               // waves per workgroup that split K
+      p.kchunk = ((((g.K + p.waves - 1) / p.waves) + 7) / 8) * 8;   // k per wave
       return p;
     }
   }
@@ -752,6 +764,7 @@ extern "C" int sdumc_gemm_f32(const sdumc_gemm* gp, void* stream) {
   }
   const GemmPlan pl = plan_gemm(g, g.workspace ? g.workspace_bytes : 0);
   const int nsplit = pl.nsplit, kchunk = pl.kchunk, tile = pl.tile;
+  const int small_nw = pl.waves;
   if (nsplit > 1 && (!g.workspace || g.workspace_bytes < plan_ws_bytes(g, nsplit))) return SDUMC_ENOMEM;
   hipStream_t st = as_stream(stream);
   ProfRec rec;
@@ -766,10 +779,18 @@ extern "C" int sdumc_gemm_f32(const sdumc_gemm* gp, void* stream) {
   if (tile == 3) {
     if (g.tile == 3 && (g.a_drop.enabled || g.b_drop.enabled || g.a_row_mod || g.b_row_mod)) return SDUMC_EINVAL;
     dim3 grid((g.N + 31) / 32, (g.M + 31) / 32, g.groups);
-    switch (g.layout) {
-      case SDUMC_NT: hipLaunchKernelGGL((gemm_small_kernel<true, true>), grid, dim3(256), 0, st, g, kchunk); break;
-      case SDUMC_NN: hipLaunchKernelGGL((gemm_small_kernel<true, false>), grid, dim3(256), 0, st, g, kchunk); break;
-      default: hipLaunchKernelGGL((gemm_small_kernel<false, false>), grid, dim3(256), 0, st, g, kchunk); break;
+    if (small_nw == 8) {
+      switch (g.layout) {
+        case SDUMC_NT: hipLaunchKernelGGL((gemm_small_kernel<true, true, 8>), grid, dim3(512), 0, st, g, kchunk); break;
+        case SDUMC_NN: hipLaunchKernelGGL((gemm_small_kernel<true, false, 8>), grid, dim3(512), 0, st, g, kchunk); break;
+        default: hipLaunchKernelGGL((gemm_small_kernel<false, false, 8>), grid, dim3(512), 0, st, g, kchunk); break;
+      }
+    } else {
+      switch (g.layout) {
+        case SDUMC_NT: hipLaunchKernelGGL((gemm_small_kernel<true, true, 4>), grid, dim3(256), 0, st, g, kchunk); break;
+        case SDUMC_NN: hipLaunchKernelGGL((gemm_small_kernel<true, false, 4>), grid, dim3(256), 0, st, g, kchunk); break;
+        default: hipLaunchKernelGGL((gemm_small_kernel<false, false, 4>), grid, dim3(256), 0, st, g, kchunk); break;
+      }
     }
   } else {
     rc = tile == 1 ? launch<128, 128>(g, nsplit, kchunk, st) : launch<64, 64>(g, nsplit, kchunk, st);
