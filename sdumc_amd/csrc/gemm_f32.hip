@@ -255,25 +255,29 @@ __global__ __launch_bounds__(256, (BM == 64 ? SDUMC_GEMM_WPE64 : 2)) void gemm_k
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-  // blockIdx.z = ((group * batch) + batch entry) * nsplit + k-split
-  const int gz = blockIdx.z / nsplit, ks = blockIdx.z - gz * nsplit;
-  const int nb = g.batch > 1 ? g.batch : 1;
-  const int grp = gz / nb, bz = gz - grp * nb;
-  // XCD-aware tile order.  The dispatcher deals workgroups round-robin over the 8 XCDs (linear id % 8), each with
-  // its own L2: in launch order the N/BN workgroups that share one A row-panel would land on different XCDs and
-  // every one of them would pull the panel through the fabric again.  Give XCD x the x-th contiguous run of tiles
-  // instead (n fastest inside the run), so that panel sharers sit behind one L2, dispatched back to back.
-  int tile_m = blockIdx.y, tile_n = blockIdx.x;
+  // XCD-aware work order.  The dispatcher deals workgroups round-robin over the 8 XCDs (launch-order id % 8), each
+  // with its own L2.  In launch order the workgroups that share an operand panel -- the N/BN tiles of one A row
+  // panel, the M/BM x N/BN tiles of one split-K slice or of one (sample, head) batch entry -- land on 8 different
+  // XCDs and each pulls the panel through the fabric again (rocprofv3 FETCH_SIZE: 3.6x the algorithmic bytes on the
+  // split-K dW GEMMs).  Renumber: XCD x works on the x-th contiguous run of (slice-major, n-fastest) tiles, so that
+  // sharers sit behind one L2 and run back to back.  Bijective for any grid (cdna_hip_programming.md, T1).
+  int tile_m = blockIdx.y, tile_n = blockIdx.x, slice = blockIdx.z;
   {
-    const int nwg = gridDim.x * gridDim.y;
-    if (nwg >= 16 && ((nwg & 7) == 0 || gridDim.z == 1)) {
-      const int id = blockIdx.y * gridDim.x + blockIdx.x;
-      const int xcd = id & 7, j = id >> 3, q = nwg >> 3, r = nwg & 7;
+    const int plane = gridDim.x * gridDim.y, total = plane * gridDim.z;
+    if (total >= 16) {
+      const int id = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+      const int xcd = id & 7, j = id >> 3, q = total >> 3, r = total & 7;
       const int t = xcd * q + min(xcd, r) + j;
-      tile_m = t / gridDim.x;
-      tile_n = t - tile_m * gridDim.x;
+      slice = t / plane;
+      const int rem = t - slice * plane;
+      tile_m = rem / gridDim.x;
+      tile_n = rem - tile_m * gridDim.x;
     }
   }
+  // slice = ((group * batch) + batch entry) * nsplit + k-split
+  const int gz = slice / nsplit, ks = slice - gz * nsplit;
+  const int nb = g.batch > 1 ? g.batch : 1;
+  const int grp = gz / nb, bz = gz - grp * nb;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kbeg = ks * kchunk;
   const int kend = min(g.K, kbeg + kchunk);
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(256, (BM == 64 ? SDUMC_GEMM_WPE64 : 2)) void gemm_k
 #pragma unroll
       for (int r = 0; r < RP; ++r) sum += lds[r * BM + tid];
       if (to_slab) {
-        g.workspace[(size_t)g.groups * nsplit * g.M * g.N + (size_t)blockIdx.z * g.M + m0 + tid] = sum;
+        g.workspace[(size_t)g.groups * nsplit * g.M * g.N + (size_t)slice * g.M + m0 + tid] = sum;
       } else {
         float* dst = g.colsum_a[grp] + m0 + tid;
         *dst = g.accumulate ? *dst + sum : sum;
@@ -475,7 +479,7 @@ __global__ __launch_bounds__(256, (BM == 64 ? SDUMC_GEMM_WPE64 : 2)) void gemm_k
   }
 
   // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (e&3) + 8*(e>>2) + 4*(lane>>5)
-  float* C = to_slab ? g.workspace + ((size_t)blockIdx.z) * (size_t)g.M * g.N : g.C[grp] + (size_t)bz * g.stride_c;
+  float* C = to_slab ? g.workspace + ((size_t)slice) * (size_t)g.M * g.N : g.C[grp] + (size_t)bz * g.stride_c;
   const int ldc = to_slab ? g.N : g.ldc;
   const float* bias = to_slab ? nullptr : g.bias[grp];
   DropRT cd = drop_resolve(g.c_drop);
