@@ -195,6 +195,7 @@ _SIGS = {
     "sdumc_param_live_count": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "sdumc_param_table": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]),
     "sdumc_set_concurrency": (C.c_int, [C.c_int]),
+    "sdumc_set_background_lane": (C.c_int, [C.c_int]),
     "sdumc_net_workspace_bytes": (C.c_size_t, [C.POINTER(NetDims)]),
     "sdumc_net_forward": (C.c_int, [C.POINTER(NetDims), C.POINTER(NetIO), C.c_void_p]),
     "sdumc_net_backward": (C.c_int, [C.POINTER(NetDims), C.POINTER(NetIO), C.POINTER(NetGrads), C.c_void_p]),

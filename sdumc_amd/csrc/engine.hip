@@ -16,6 +16,8 @@
 
 #include <algorithm>
 #include <map>
+#include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <string>
 #include <tuple>
@@ -184,7 +186,7 @@ struct Plan {
   int64_t dz[2][3], dxd[2][3], dx[3][2];
   int64_t d_hpre, d_u1, d_u, d_att1, d_att2, d_alpha, d_qin, d_q, d_qp, d_ca_out, d_c1, d_c, d_h, d_e1, d_e2, d_beta,
       d_z, d_r1, dq_fra;
-  int64_t scratch[3] = {0, 0, 0}, scratch_floats = 0;   // one scratch per lane (stream)
+  int64_t scratch[4] = {0, 0, 0, 0}, scratch_floats = 0;   // one scratch per lane (stream)
   int64_t alloc(int64_t n) {
     const int64_t o = cur;
     cur += (n + 63) & ~(int64_t)63;
@@ -327,7 +329,7 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
   sc = std::max<int64_t>(sc, (int64_t)8 * 4 * D * NQ * H);  // grouped utterance-level split-K upper bound
   sc = std::max<int64_t>(sc, (int64_t)13 << 20);            // auto split-K: <= ~(320 + tiles) slabs of 64 KiB
   p.scratch_floats = sc;
-  for (int l = 0; l < 3; ++l) p.scratch[l] = p.alloc(sc);
+  for (int l = 0; l < 4; ++l) p.scratch[l] = p.alloc(sc);
   return true;
 }
 
@@ -339,6 +341,7 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
 // hides the launch-bound small ones.  Each lane has its own scratch, so concurrent kernels never share slabs.
 struct SideStreams {
   hipStream_t s[2] = {nullptr, nullptr};
+  hipStream_t bg = nullptr;   // background lane: big GEMMs that may run beside the launch-bound utterance-level chain
   hipEvent_t ev[64];
   int next = 0;
   bool ok = false;
@@ -348,6 +351,7 @@ SideStreams& side_streams() {
   return S;
 }
 bool g_concurrency = true;   // sdumc_set_concurrency(0): everything on the caller's stream (profiling)
+bool g_background = false;   // sdumc_set_background_lane(1): the Cross_Attention-site GEMMs leave the grouped launches for lane 3
 // created outside any capture (called from the *_workspace_bytes queries every caller makes first)
 void ensure_side_streams() {
   static std::mutex mu;
@@ -358,6 +362,15 @@ void ensure_side_streams() {
     if (hipStreamCreateWithFlags(&S.s[i], hipStreamNonBlocking) != hipSuccess) return;
   for (int i = 0; i < 64; ++i)
     if (hipEventCreateWithFlags(&S.ev[i], hipEventDisableTiming) != hipSuccess) return;
+  {
+    // The (optional) background lane carries MFMA-bound GEMMs that run beside the launch-bound utterance-level chain.
+    // Measured on MI355X: an ordinary stream gains 0.8 % per step (2.236 vs 2.254 ms, three alternations) while the
+    // half-size launches lose 4 % of per-kernel efficiency (TN 78 vs 82 TF) -> off by default; a stream confined to 7/8 (or 1/2) of the CUs with
+    // hipExtStreamCreateWithCUMask -- meant to keep free CUs for the chain's small kernels -- made the whole step
+    // 60 % slower (3.57 vs 2.22 ms), and 128x128 tiles on this lane (2 workgroups per CU, room for a small kernel beside
+    // them) 12 % slower; the lowest stream priority made no difference.
+    if (hipStreamCreateWithFlags(&S.bg, hipStreamNonBlocking) != hipSuccess) return;
+  }
   S.ok = true;
 }
 
@@ -370,7 +383,8 @@ struct Ctx {
   float* W;     // workspace base
   float* P;     // parameters
   float* G;     // gradient bucket (backward only)
-  hipStream_t sts[3] = {nullptr, nullptr, nullptr};
+  hipStream_t sts[4] = {nullptr, nullptr, nullptr, nullptr};
+  bool bg = false;   // the Cross_Attention-site key projections are issued on lane 3 (background)
   mutable float* scr = nullptr;   // scratch of the current lane
   bool multi = false;
   float* p(int64_t off) const { return W + off; }
@@ -378,8 +392,10 @@ struct Ctx {
     const SideStreams& S = side_streams();
     sts[0] = st;
     multi = S.ok && g_concurrency;
+    bg = g_background;                    // the launch decomposition is the same with and without real streams
     sts[1] = multi ? S.s[0] : st;
     sts[2] = multi ? S.s[1] : st;
+    sts[3] = multi && bg ? S.bg : st;
     use(0);
   }
   void use(int lane) const {
@@ -396,7 +412,7 @@ hipEvent_t next_event() {
 }
 // lane `from` -> lane `to`: everything issued on `to` after this waits for what `from` has issued so far
 int link(const Ctx& c, int from, int to) {
-  if (!c.multi || from == to) return SDUMC_OK;
+  if (c.sts[from] == c.sts[to]) return SDUMC_OK;
   hipEvent_t e = next_event();
   if (hipEventRecord(e, c.sts[from]) != hipSuccess) return SDUMC_ELAUNCH;
   if (hipStreamWaitEvent(c.sts[to], e, 0) != hipSuccess) return SDUMC_ELAUNCH;
@@ -584,23 +600,23 @@ sdumc_attnpool attn_desc(const Ctx& c, int k, int m, const Seg& sg) {
   return a;
 }
 
-// keys = tanh(drop(x) W^T + b) of BOTH attention sites of modality m (FRA2UTT_new and Cross_Attention read
-// the same x with different masks and weights): one grouped launch per run -- twice the workgroups per
-// launch, so the last dispatch round of the 64x64 tiles is much fuller than with two launches.
-int keys_gemm_fwd(const Ctx& c, int m) {
+// keys = tanh(drop(x) W^T + b) of the attention sites [k0, k1) of modality m (FRA2UTT_new = 0, Cross_Attention = 1:
+// they read the same x with different masks and weights).  Both in one grouped launch fill the last dispatch round
+// of the 64x64 tiles better; one at a time lets the Cross_Attention half run on the background lane.
+int keys_gemm_fwd(const Ctx& c, int m, int k0, int k1) {
   for (const Seg& sg : c.pl.segs[m]) {
-    sdumc_gemm g = G_(SDUMC_NT, sg.V * sg.T, D, D, 2);
-    for (int k = 0; k < 2; ++k) {
+    sdumc_gemm g = G_(SDUMC_NT, sg.V * sg.T, D, D, k1 - k0);
+    for (int k = k0; k < k1; ++k) {
       const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
-      g.A[k] = c.p(sg.x_off);
-      g.B[k] = c.P + L.w;
-      g.bias[k] = c.P + L.b;
-      g.C[k] = c.p(c.pl.keys[k][m]) + sg.row0 * D;
-      g.ab_drop_bits[k] = in_drop(c, k, m, sg.T, sg.s0, sg.row0).bits;
+      g.A[k - k0] = c.p(sg.x_off);
+      g.B[k - k0] = c.P + L.w;
+      g.bias[k - k0] = c.P + L.b;
+      g.C[k - k0] = c.p(c.pl.keys[k][m]) + sg.row0 * D;
+      g.ab_drop_bits[k - k0] = in_drop(c, k, m, sg.T, sg.s0, sg.row0).bits;
     }
     g.lda = g.ldb = g.ldc = D;
     g.a_row_mod = sg.x_samples < sg.V ? sg.x_samples * sg.T : 0;
-    g.a_drop = in_drop(c, 0, m, sg.T, sg.s0, sg.row0);
+    g.a_drop = in_drop(c, k0, m, sg.T, sg.s0, sg.row0);
     g.ab_drop_group_stride = SITE_IN[1][m] - SITE_IN[0][m];
     g.act = SDUMC_ACT_TANH;
     RET(run(c, g));
@@ -641,7 +657,15 @@ int forward(const Ctx& c) {
       const float* in = m == 0 ? c.io.audio : (m == 2 ? c.io.video : c.io.text[s]);
       RET(lin_fwd(c, pm.frame[m], in, din[m], B * pl.T[m][s], c.p(pl.x[m][s]), D, SDUMC_ACT_NONE, nullptr));
     }
-    RET(keys_gemm_fwd(c, m));
+    if (c.bg) {   // the Cross_Attention keys are not needed before step 8: background lane, beside steps 2-7
+      RET(keys_gemm_fwd(c, m, 0, 1));
+      RET(link(c, LANE_OF[m], 3));
+      c.use(3);
+      RET(keys_gemm_fwd(c, m, 1, 2));
+      c.use(LANE_OF[m]);
+    } else {
+      RET(keys_gemm_fwd(c, m, 0, 2));
+    }
     RET(pool_fwd(c, 0, m));
   }
   c.use(0);
@@ -708,6 +732,7 @@ int forward(const Ctx& c) {
     RET(run(c, g));
   }
   // 8. cross_att_fra2utt_{0,1,2} (model :334-336)
+  RET(link(c, 3, 0));   // their keys
   RET(fork_all(c));
   for (int m = 0; m < 3; ++m) {
     c.use(LANE_OF[m]);
@@ -788,37 +813,37 @@ int pool_bwd(const Ctx& c, int k, int m, const float* dout_base /* [V, nq, D] */
   return SDUMC_OK;
 }
 
-// input_proj backward of BOTH sites of modality m, grouped: dW = dz^T drop(x) (+ db), dxd += dz W
-int keys_gemm_bwd(const Ctx& c, int m) {
+// input_proj backward of the sites [k0, k1) of modality m (grouped when both): dW = dz^T drop(x) (+ db), dxd += dz W
+int keys_gemm_bwd(const Ctx& c, int m, int k0, int k1) {
   const Plan& pl = c.pl;
   // dW: one grouped GEMM per run (runs differ in their x buffer), later runs accumulate
   bool first = true;
   for (const Seg& sg : pl.segs[m]) {
     const int rows = sg.V * sg.T;
-    sdumc_gemm g = G_(SDUMC_TN, D, D, rows, 2);
-    for (int k = 0; k < 2; ++k) {
+    sdumc_gemm g = G_(SDUMC_TN, D, D, rows, k1 - k0);
+    for (int k = k0; k < k1; ++k) {
       const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
-      g.A[k] = c.p(pl.dz[k][m]) + sg.row0 * D;
-      g.B[k] = c.p(sg.x_off);
-      g.C[k] = c.G + L.w;
-      g.colsum_a[k] = c.G + L.b;
-      g.ab_drop_bits[k] = in_drop(c, k, m, sg.T, sg.s0, sg.row0).bits;
+      g.A[k - k0] = c.p(pl.dz[k][m]) + sg.row0 * D;
+      g.B[k - k0] = c.p(sg.x_off);
+      g.C[k - k0] = c.G + L.w;
+      g.colsum_a[k - k0] = c.G + L.b;
+      g.ab_drop_bits[k - k0] = in_drop(c, k, m, sg.T, sg.s0, sg.row0).bits;
     }
     g.lda = g.ldb = g.ldc = D;
     g.b_row_mod = sg.x_samples < sg.V ? sg.x_samples * sg.T : 0;
-    g.b_drop = in_drop(c, 0, m, sg.T, sg.s0, sg.row0);
+    g.b_drop = in_drop(c, k0, m, sg.T, sg.s0, sg.row0);
     g.ab_drop_group_stride = SITE_IN[1][m] - SITE_IN[0][m];
     g.accumulate = first ? 0 : 1;
     RET(run(c, g));
     first = false;
   }
   // dxd += dz W (the key-projection path joins the pooling path)
-  sdumc_gemm g = G_(SDUMC_NN, (int)pl.rows[m], D, D, 2);
-  for (int k = 0; k < 2; ++k) {
+  sdumc_gemm g = G_(SDUMC_NN, (int)pl.rows[m], D, D, k1 - k0);
+  for (int k = k0; k < k1; ++k) {
     const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
-    g.A[k] = c.p(pl.dz[k][m]);
-    g.B[k] = c.P + L.w;
-    g.C[k] = c.p(pl.dxd[k][m]);
+    g.A[k - k0] = c.p(pl.dz[k][m]);
+    g.B[k - k0] = c.P + L.w;
+    g.C[k - k0] = c.p(pl.dxd[k][m]);
   }
   g.lda = g.ldb = g.ldc = D;
   g.accumulate = 1;
@@ -866,6 +891,11 @@ int backward(const Ctx& c, const sdumc_net_grads& og) {
   for (int m = 0; m < 3; ++m) {
     c.use(LANE_OF[m]);
     RET(pool_bwd(c, 1, m, c.p(pl.d_ca_out) + (int64_t)m * V * NQ * D, c.p(pl.d_qp) + (int64_t)m * V * NQ * D));
+    if (c.bg) {   // the Cross_Attention input_proj backward has everything it needs: background lane, beside 7'-3'
+      RET(link(c, LANE_OF[m], 3));
+      c.use(3);
+      RET(keys_gemm_bwd(c, m, 1, 2));
+    }
   }
   c.use(0);
   RET(join_all(c));
@@ -922,13 +952,14 @@ int backward(const Ctx& c, const sdumc_net_grads& og) {
   //   fra2utt_m pooling backward (the shared context vector's gradient = sum of the per-sample dq)
   //   -> input_proj backward of both sites (grouped) -> dx = sum of the (up to) four masked paths into the
   //   projected features -> frame_dim_reshape_m: dW = dx^T feat (split-K) with db fused
+  RET(link(c, 3, 0));   // dxd of the Cross_Attention sites
   RET(fork_all(c));
   for (int m = 0; m < 3; ++m) {
     c.use(LANE_OF[m]);
     float* dq = c.p(pl.dq_fra) + (int64_t)m * V * D;
     RET(pool_bwd(c, 0, m, c.p(pl.d_hpre) + (int64_t)m * V * D, dq));
     RET(colsum(c, dq, V, D, D, c.G + pm.fra_ctx[m], 0));
-    RET(keys_gemm_bwd(c, m));
+    RET(keys_gemm_bwd(c, m, c.bg ? 0 : 0, c.bg ? 1 : 2));
     for (int s = 0; s < (m == 1 ? S : 1); ++s) {
       const int T = pl.T[m][s];
       sdumc_dropsum ds;
@@ -1021,6 +1052,10 @@ int loss_ssd(const sdumc_net_dims& d, const sdumc_net_io& io, float* ssd_out, co
 // ==========================================================================================
 extern "C" int sdumc_set_concurrency(int on) {
   g_concurrency = on != 0;
+  return SDUMC_OK;
+}
+extern "C" int sdumc_set_background_lane(int on) {
+  g_background = on != 0;
   return SDUMC_OK;
 }
 
