@@ -66,7 +66,9 @@ __device__ __forceinline__ f32x4 rows_times_cols(const float* rowp, const float*
 }
 
 // ---- forward, pass 1: one workgroup per (chunk of 64 rows, v) -----------------------------------
-__global__ __launch_bounds__(256, 2) void attn_fwd_partial_kernel(const sdumc_attnpool p, float* ws, const int nchunk) {
+// PHILOX: the input dropout mask is recomputed per row (no precomputed keep-bits attached: tests, one-off calls)
+template <bool PHILOX>
+__global__ __launch_bounds__(256, 4) void attn_fwd_partial_kernel(const sdumc_attnpool p, float* ws, const int nchunk) {
   __shared__ __attribute__((aligned(16))) float P_s[CH * MAXQ];
   __shared__ __attribute__((aligned(16))) float red[4 * MAXQ * D];   // first the query tile, later the pooling reduce
   __shared__ float wstat[4][16];
@@ -128,15 +130,50 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_partial_kernel(const sdumc_at
   f32x4 acc[MAXQ];
 #pragma unroll
   for (int i = 0; i < MAXQ; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if constexpr (PHILOX) {
+    // row at a time
 #pragma unroll 1
-  for (int r = 0; r < 16; ++r) {
-    const int rl = 16 * wave + r, t = t0 + rl;
-    if (t >= T) break;
-    f32x4 x = ld4(p.x + ((size_t)vx * T + t) * D + 4 * lane);
-    if (xd.enabled) x *= drop_mask4(xd, (uint32_t)(v * T + t), (uint32_t)lane);
+    for (int r = 0; r < 16; ++r) {
+      const int rl = 16 * wave + r, t = t0 + rl;
+      if (t >= T) break;
+      f32x4 x = ld4(p.x + ((size_t)vx * T + t) * D + 4 * lane);
+      x *= drop_mask4(xd, (uint32_t)(v * T + t), (uint32_t)lane);
 #pragma unroll
-    for (int i = 0; i < MAXQ; ++i)
-      if (i < nq) acc[i] += x * P_s[rl * MAXQ + i];
+      for (int i = 0; i < MAXQ; ++i)
+        if (i < nq) acc[i] += x * P_s[rl * MAXQ + i];
+    }
+  } else {
+    // rows in batches of RB: all of a batch's 16-byte loads (and keep-bits bytes) are in flight before the first
+    // FMA consumes one -- the row-at-a-time loop this replaces paid one memory round trip per row (16 per wave)
+    constexpr int RB = 4;
+    const bool masked = xd.enabled != 0;
+    const float mscale = masked ? xd.scale : 1.f;
+#pragma unroll 1
+    for (int rb = 0; rb < 16; rb += RB) {
+      f32x4 xr[RB];
+      uint32_t mb[RB];
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        const int t = min(t0 + 16 * wave + rb + j, T - 1);   // rows beyond T re-read the last row; their P_s is 0
+        xr[j] = ld4(p.x + ((size_t)vx * T + t) * D + 4 * lane);
+        mb[j] = masked ? xd.bits[(size_t)(v * T + t) * xd.qwidth + lane] : 0xfu;
+      }
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        const int rl = 16 * wave + rb + j;
+        f32x4 x = xr[j];
+        {
+          const uint32_t b = mb[j];
+          x[0] = (b & 1u) ? x[0] * mscale : 0.f;
+          x[1] = (b & 2u) ? x[1] * mscale : 0.f;
+          x[2] = (b & 4u) ? x[2] * mscale : 0.f;
+          x[3] = (b & 8u) ? x[3] * mscale : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < MAXQ; ++i)
+          if (i < nq) acc[i] += x * P_s[rl * MAXQ + i];   // rows beyond T: x = 0 and P_s = 0
+      }
+    }
   }
 #pragma unroll
   for (int i = 0; i < MAXQ; ++i)
@@ -255,24 +292,36 @@ __global__ __launch_bounds__(256, 2) void attnpool_bwd_kernel(const sdumc_attnpo
       g[i] = ld4(dO_s + i * LDQ + 4 * lane);
     }
   }
-#pragma unroll 1
-  for (int r = 0; r < 16; ++r) {
-    const int rl = 16 * wave + r, t = t0 + rl;
-    if (t >= T) break;
-    const size_t row = (size_t)v * T + t;
-    const f32x4 k = ld4(p.keys + row * D + 4 * lane);
-    f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dx = {0.f, 0.f, 0.f, 0.f};
+  // rows in batches of RB: the batch's key-row loads are all in flight before the first row is processed
+  constexpr int RB = 4;
 #pragma unroll
-    for (int i = 0; i < MAXQ; ++i)
-      if (i < nq) {
-        const float dS = dS_s[rl * MAXQ + i], a = A_s[rl * MAXQ + i];
-        dk += q[i] * dS;
-        dx += g[i] * a;
-        dqa[i] += k * dS;
+  for (int rb = 0; rb < 16; rb += RB) {
+    f32x4 kr[RB];
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int t = t0 + 16 * wave + rb + j;
+      kr[j] = t < T ? ld4(p.keys + ((size_t)v * T + t) * D + 4 * lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int rl = 16 * wave + rb + j, t = t0 + rl;
+      const size_t row = (size_t)v * T + t;
+      const f32x4 k = kr[j];
+      f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < MAXQ; ++i)
+        if (i < nq) {
+          const float dS = dS_s[rl * MAXQ + i], a = A_s[rl * MAXQ + i];   // both 0 for rows beyond T
+          dk += q[i] * dS;
+          dx += g[i] * a;
+          dqa[i] += k * dS;
+        }
+      if (t < T) {
+        const f32x4 one = {1.f, 1.f, 1.f, 1.f};
+        st4(b.dz + row * D + 4 * lane, dk * (one - k * k));
+        st4(b.dxd + row * D + 4 * lane, dx);
       }
-    const f32x4 one = {1.f, 1.f, 1.f, 1.f};
-    st4(b.dz + row * D + 4 * lane, dk * (one - k * k));
-    st4(b.dxd + row * D + 4 * lane, dx);
+    }
   }
 #pragma unroll
   for (int i = 0; i < MAXQ; ++i)
@@ -320,7 +369,10 @@ extern "C" int sdumc_attnpool_fwd(const sdumc_attnpool* pp, void* stream) {
   if (!p.workspace || p.workspace_bytes < sdumc_attnpool_fwd_workspace_bytes(p.V, p.T, p.nq)) return SDUMC_ENOMEM;
   hipStream_t st = as_stream(stream);
   const int nchunk = (p.T + CH - 1) / CH;
-  hipLaunchKernelGGL(attn_fwd_partial_kernel, dim3(nchunk, p.V), dim3(256), 0, st, p, p.workspace, nchunk);
+  if (p.x_drop.enabled && !p.x_drop.bits)
+    hipLaunchKernelGGL(attn_fwd_partial_kernel<true>, dim3(nchunk, p.V), dim3(256), 0, st, p, p.workspace, nchunk);
+  else
+    hipLaunchKernelGGL(attn_fwd_partial_kernel<false>, dim3(nchunk, p.V), dim3(256), 0, st, p, p.workspace, nchunk);
   SDUMC_CHECK_LAUNCH();
   hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(p.V), dim3(256), (size_t)nchunk * MAXQ * sizeof(float), st, p,
                      p.workspace, nchunk);
