@@ -51,16 +51,41 @@ template <bool DROP>
 __device__ __forceinline__ f32x4 rows_times_cols(const float* rowp, const float* b_lds, const DropRT& d,
                                                  uint32_t vrow, int r16, int kk) {
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
-  for (int j = 0; j < 16; ++j) {
-    f32x4 a = {0.f, 0.f, 0.f, 0.f}, bq = {0.f, 0.f, 0.f, 0.f};
-    if (rowp) {
-      a = ld4(rowp + 16 * j + 4 * kk);
-      if (DROP) a *= drop_mask4(d, vrow, (uint32_t)(4 * j + kk));
-    }
-    if (r16 < MAXQ) bq = ld4(b_lds + r16 * LDQ + 16 * j + 4 * kk);
+  // two batches of 8 channel groups: a batch's row loads (and keep-bits bytes) are all issued before its first MFMA
+  const bool bits = DROP && d.bits != nullptr;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bq[e], acc, 0, 0, 0);
+  for (int jb = 0; jb < 16; jb += 8) {
+    f32x4 a[8];
+    uint32_t mb[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = jb + u;
+      a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      mb[u] = 0;
+      if (rowp) {
+        a[u] = ld4(rowp + 16 * j + 4 * kk);
+        if (bits) mb[u] = d.bits[(size_t)vrow * d.qwidth + 4 * j + kk];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int j = jb + u;
+      if (DROP) {
+        if (bits) {
+          const uint32_t m = mb[u];
+          a[u][0] = (m & 1u) ? a[u][0] * d.scale : 0.f;
+          a[u][1] = (m & 2u) ? a[u][1] * d.scale : 0.f;
+          a[u][2] = (m & 4u) ? a[u][2] * d.scale : 0.f;
+          a[u][3] = (m & 8u) ? a[u][3] * d.scale : 0.f;
+        } else if (rowp) {
+          a[u] *= drop_mask4(d, vrow, (uint32_t)(4 * j + kk));
+        }
+      }
+      f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+      if (r16 < MAXQ) bq = ld4(b_lds + r16 * LDQ + 16 * j + 4 * kk);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][e], bq[e], acc, 0, 0, 0);
+    }
   }
   return acc;
 }
