@@ -445,6 +445,10 @@ typedef struct sdumc_net_dims {
   int32_t sample0;  /* global index of local sample 0 (data-parallel shard offset) */
   double p_frame;   /* 0.5: nn.Dropout inside FRA2UTT_new / Cross_Attention (model :54,:77) */
   double p_mlp;     /* 0.3: constructor default dropout (model :187) */
+  int32_t bf16;     /* 0 (default): exact fp32 everywhere.  1: the frame-level forward projections (frame_dim_reshape_*,
+                       model :282-284, and the input_proj keys of FRA2UTT_new / Cross_Attention, model :60,:82) round
+                       their operands to bf16 and multiply on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the
+                       "bf16" configs of BASELINE.json; everything else, the whole backward included, stays fp32 */
 } sdumc_net_dims;
 
 typedef struct sdumc_net_io {

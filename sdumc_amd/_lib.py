@@ -67,7 +67,7 @@ class NetDims(C.Structure):
                 ("Ta", C.c_int32), ("Tv", C.c_int32), ("Tt", C.c_int32 * 2),
                 ("da", C.c_int32), ("dt", C.c_int32), ("dv", C.c_int32),
                 ("train", C.c_int32), ("sample0", C.c_int32),
-                ("p_frame", C.c_double), ("p_mlp", C.c_double)]
+                ("p_frame", C.c_double), ("p_mlp", C.c_double), ("bf16", C.c_int32)]
 
 
 class NetIO(C.Structure):

@@ -471,8 +471,9 @@ int run(const Ctx& c, sdumc_gemm& g) {
 
 // y = act(x W^T + b) (+ dropout), single group
 int lin_fwd(const Ctx& c, const Lin& L, const float* x, int lda, int M, float* y, int ldc, int act,
-            const sdumc_dropout* drop) {
+            const sdumc_dropout* drop, bool bf16 = false) {
   sdumc_gemm g = G_(SDUMC_NT, M, L.out, L.in);
+  g.bf16 = bf16 && (lda % 4 == 0) && (L.in % 4 == 0) ? 1 : 0;
   g.A[0] = x;
   g.lda = lda;
   g.B[0] = c.P + L.w;
@@ -619,6 +620,7 @@ int keys_gemm_fwd(const Ctx& c, int m, int k0, int k1) {
     g.a_drop = in_drop(c, k0, m, sg.T, sg.s0, sg.row0);
     g.ab_drop_group_stride = SITE_IN[1][m] - SITE_IN[0][m];
     g.act = SDUMC_ACT_TANH;
+    g.bf16 = c.d.bf16 ? 1 : 0;
     RET(run(c, g));
   }
   return SDUMC_OK;
@@ -655,7 +657,7 @@ int forward(const Ctx& c) {
       }
     for (int s = 0; s < (m == 1 ? S : 1); ++s) {
       const float* in = m == 0 ? c.io.audio : (m == 2 ? c.io.video : c.io.text[s]);
-      RET(lin_fwd(c, pm.frame[m], in, din[m], B * pl.T[m][s], c.p(pl.x[m][s]), D, SDUMC_ACT_NONE, nullptr));
+      RET(lin_fwd(c, pm.frame[m], in, din[m], B * pl.T[m][s], c.p(pl.x[m][s]), D, SDUMC_ACT_NONE, nullptr, c.d.bf16 != 0));
     }
     if (c.bg) {   // the Cross_Attention keys are not needed before step 8: background lane, beside steps 2-7
       RET(keys_gemm_fwd(c, m, 0, 1));

@@ -70,7 +70,7 @@ def _require_cuda(*tensors):
             raise _lib.SdumcError("expected contiguous float32 tensors")
 
 
-def make_dims(B, streams, Ta, Tv, Tt, dims, train, sample0=0, p_mlp=P_MLP):
+def make_dims(B, streams, Ta, Tv, Tt, dims, train, sample0=0, p_mlp=P_MLP, bf16=False):
     d = _lib.NetDims()
     d.B, d.streams, d.Ta, d.Tv = B, streams, Ta, Tv
     d.Tt[0] = Tt[0]
@@ -79,6 +79,7 @@ def make_dims(B, streams, Ta, Tv, Tt, dims, train, sample0=0, p_mlp=P_MLP):
     d.train = 1 if train else 0
     d.sample0 = sample0
     d.p_frame, d.p_mlp = P_FRAME, p_mlp
+    d.bf16 = 1 if bf16 else 0
     return d
 
 
@@ -100,7 +101,7 @@ class RngState:
 class NetCall:
     """One network invocation (1 or 2 streams): owns workspace + outputs, supports backward."""
 
-    def __init__(self, flat_params, audio, texts, video, train, rng, sample0=0, p_mlp=P_MLP):
+    def __init__(self, flat_params, audio, texts, video, train, rng, sample0=0, p_mlp=P_MLP, bf16=False):
         texts = list(texts)
         _require_cuda(flat_params, audio, video, *texts)
         S = len(texts)
@@ -112,7 +113,7 @@ class NetCall:
                 raise _lib.SdumcError("text-slot inputs must share batch and width (SURVEY §8b: feat4 width == text width)")
         if video.shape[0] != B:
             raise _lib.SdumcError("batch mismatch")
-        self.dims = make_dims(B, S, Ta, Tv, [t.shape[1] for t in texts], (da, dt, dv), train, sample0, p_mlp)
+        self.dims = make_dims(B, S, Ta, Tv, [t.shape[1] for t in texts], (da, dt, dv), train, sample0, p_mlp, bf16)
         self.layout = ParamLayout.get(da, dt, dv)
         if flat_params.numel() != self.layout.total:
             raise _lib.SdumcError("flat parameter buffer has the wrong size")
@@ -164,13 +165,13 @@ class TrainStep:
     optionally captured into a hipGraph (torch.cuda.CUDAGraph) and replayed."""
 
     def __init__(self, flat_params, B, T, dims, weights=DEFAULT_WEIGHTS, lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=1e-5, seed=0, train=True, sample0=0):
+                 weight_decay=1e-5, seed=0, train=True, sample0=0, bf16=False):
         Ta, Tt, Tv, T4 = T
         self.layout = ParamLayout.get(dims[0], dims[1], dims[2])
         dev = flat_params.device
         _require_cuda(flat_params)
         self.params = flat_params
-        self.dims = make_dims(B, 2, Ta, Tv, (Tt, T4), dims, train, sample0)
+        self.dims = make_dims(B, 2, Ta, Tv, (Tt, T4), dims, train, sample0, bf16=bf16)
         nbytes = lib.sdumc_step_workspace_bytes(C.byref(self.dims))
         if nbytes == 0:
             raise _lib.SdumcError("invalid step dimensions")

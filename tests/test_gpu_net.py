@@ -290,3 +290,32 @@ def test_large_batch_rnc_1024_rows(E):
     np.testing.assert_allclose(losses[1:7], [float(t) for t in terms], rtol=2e-4, atol=1e-6)
     np.testing.assert_allclose(losses[0], float(loss), rtol=2e-4)
     assert torch.isfinite(ts.grads).all()
+
+
+def test_bf16_operand_mode_c3(E):
+    """BASELINE configs[2] (C3: MOSEI shapes, text-missing stream + self-distillation, bf16): the frame-level forward
+    projections round their operands to bf16 (fp32 accumulate); SURVEY §8d bar for that mode: activations <= 2e-2 of
+    the fp32 oracle, loss in fp32.  B reduced to 8 so that the CPU oracle finishes in seconds."""
+    from oracle import sdumc_oracle as O
+    dims = (1024, 4096, 1024, 4096)
+    B, Tn = 8, (375, 32, 225, 32)
+    P = O.init_params(dims, seed=0)
+    flat, lay = flat_from(E, P, dims)
+    audio, text, video, feat4, vals = O.synthetic_batch(B, Tn, dims, seed=1234)
+    dev = [t.cuda() for t in (audio, text, video, feat4)]
+    f32 = [t.clone() for t in E.NetCall(flat, dev[0], [dev[1], dev[3]], dev[2], False, None).forward()]
+    b16 = [t.clone() for t in E.NetCall(flat, dev[0], [dev[1], dev[3]], dev[2], False, None, bf16=True).forward()]
+    diffs = []
+    for n, a, b in zip(NAMES, f32, b16):
+        close(b, a, 2e-2, "bf16 " + n)
+        diffs.append(float((a - b).abs().max()))
+    assert max(diffs) > 1e-6, "bf16 mode produced bit-identical outputs: the mode is not active"
+    # a complete bf16-mode optimisation step against the fp32 oracle
+    ts = E.TrainStep(flat, B, Tn, dims, seed=777, bf16=True)
+    ts.set_batch(dev[0], dev[1], dev[2], dev[3], vals.cuda())
+    losses = ts.run().cpu().numpy()
+    Pd = {k: v.clone() for k, v in P.items()}
+    loss, terms, grads, outs = O.train_step(Pd, {}, audio, text, video, feat4, vals, mode="philox", seed=777, step=0)
+    np.testing.assert_allclose(losses[0], float(loss), rtol=2e-2)
+    np.testing.assert_allclose(losses[1:7], [float(t) for t in terms], rtol=2e-2, atol=1e-4)
+    assert np.isfinite(ts.grads.cpu().numpy()).all()
