@@ -493,6 +493,13 @@ typedef struct sdumc_net_grads {
 
 /* loss.backward() through the network (main :149).  Needs the workspace of the matching forward. */
 int sdumc_net_backward(const sdumc_net_dims* d, const sdumc_net_io* io, const sdumc_net_grads* g, void* stream);
+/* The same in two calls, for a data-parallel step that overlaps its gradient all-reduce with the backward:
+ * phase 0 = the utterance-level layers; when it returns (stream-ordered) grads[0, sdumc_param_early_count) are final.
+ * phase 1 = the frame-level layers (input_proj of both attention sites, frame_dim_reshape: 0.9 of the 1.4 ms of
+ * backward GEMM time at C2), which finish grads[early, live). */
+int sdumc_net_backward_phase(const sdumc_net_dims* d, const sdumc_net_io* io, const sdumc_net_grads* g, int32_t phase,
+                             void* stream);
+int64_t sdumc_param_early_count(int32_t da, int32_t dt, int32_t dv);
 
 /* Two-stream self-distillation step (main :119-150). */
 typedef struct sdumc_step_cfg {

@@ -199,6 +199,8 @@ _SIGS = {
     "sdumc_net_workspace_bytes": (C.c_size_t, [C.POINTER(NetDims)]),
     "sdumc_net_forward": (C.c_int, [C.POINTER(NetDims), C.POINTER(NetIO), C.c_void_p]),
     "sdumc_net_backward": (C.c_int, [C.POINTER(NetDims), C.POINTER(NetIO), C.POINTER(NetGrads), C.c_void_p]),
+    "sdumc_net_backward_phase": (C.c_int, [C.POINTER(NetDims), C.POINTER(NetIO), C.POINTER(NetGrads), C.c_int32, C.c_void_p]),
+    "sdumc_param_early_count": (C.c_int64, [C.c_int32, C.c_int32, C.c_int32]),
     "sdumc_step_workspace_bytes": (C.c_size_t, [C.POINTER(NetDims)]),
     "sdumc_train_step": (C.c_int, [C.POINTER(NetDims), C.POINTER(NetIO), C.POINTER(StepCfg), C.c_void_p]),
     "sdumc_loss_workspace_bytes": (C.c_size_t, [C.POINTER(NetDims), C.c_int32]),

@@ -63,7 +63,7 @@ struct ParamMap {
   Lin frame[3], fra_proj[3], umlp0[3], umlp3[3], att0, att3, fc_att, query[7], ca_q[3], ca_in[3], cmlp0[3], cmlp3[3],
       catt0, catt3, cross_fc_att, fc_out_v, rnc0, rnc2;
   int64_t fra_ctx[3] = {0, 0, 0};
-  int64_t live = 0, total = 0;
+  int64_t early = 0, live = 0, total = 0;   // [0, early): utterance-level, [early, live): frame-level, [live, total): never trained
   std::vector<PEntry> table;
 };
 
@@ -107,12 +107,10 @@ ParamMap build_params_uncached(int da, int dt, int dv) {
   static const char* MOD[3] = {"audio", "text", "video"};
   static const char* QN[7] = {"fused", "at", "tv", "av", "audio", "text", "video"};
   const int din[3] = {da, dt, dv};
-  for (int m = 0; m < 3; ++m) pm.frame[m] = b.lin("frame_dim_reshape_" + std::to_string(m), D, din[m]);
-  for (int m = 0; m < 3; ++m) {
-    const std::string p = "fra2utt_" + std::to_string(m);
-    pm.fra_ctx[m] = b.add(p + ".attention_context_vector", 1, D);
-    pm.fra_proj[m] = b.lin(p + ".input_proj", D, D);
-  }
+  // Order inside the live block = order in which the backward FINISHES the gradients: the utterance-level layers
+  // first ("early": final once the utterance-level backward is done), then the frame-level ones ("late": input_proj of
+  // both attention sites, the FRA2UTT context vectors, frame_dim_reshape).  A data-parallel step can then all-reduce
+  // the early slice while the frame-level backward (0.9 ms of GEMMs at C2) is still running.
   for (int m = 0; m < 3; ++m) {
     pm.umlp0[m] = b.lin(std::string(MOD[m]) + "_mlp.0", D, D);
     pm.umlp3[m] = b.lin(std::string(MOD[m]) + "_mlp.3", D, D);
@@ -121,11 +119,7 @@ ParamMap build_params_uncached(int da, int dt, int dv) {
   pm.att3 = b.lin("attention_mlp.3", D, D);
   pm.fc_att = b.lin("fc_att", 3, D);
   for (int i = 0; i < 7; ++i) pm.query[i] = b.lin(std::string("cross_") + QN[i] + "_query_mlp.0", D, D);
-  for (int m = 0; m < 3; ++m) {
-    const std::string p = "cross_att_fra2utt_" + std::to_string(m);
-    pm.ca_q[m] = b.lin(p + ".query_proj", D, D);
-    pm.ca_in[m] = b.lin(p + ".input_proj", D, D);
-  }
+  for (int m = 0; m < 3; ++m) pm.ca_q[m] = b.lin("cross_att_fra2utt_" + std::to_string(m) + ".query_proj", D, D);
   for (int m = 0; m < 3; ++m) {
     pm.cmlp0[m] = b.lin(std::string("cross_") + MOD[m] + "_mlp.0", D, D);
     pm.cmlp3[m] = b.lin(std::string("cross_") + MOD[m] + "_mlp.3", H, D);
@@ -136,6 +130,14 @@ ParamMap build_params_uncached(int da, int dt, int dv) {
   pm.fc_out_v = b.lin("fc_out_v", 1, H);
   pm.rnc0 = b.lin("orgin_linear_change.0", RD, H);
   pm.rnc2 = b.lin("orgin_linear_change.2", RD, RD);
+  pm.early = b.cur;
+  for (int m = 0; m < 3; ++m) pm.ca_in[m] = b.lin("cross_att_fra2utt_" + std::to_string(m) + ".input_proj", D, D);
+  for (int m = 0; m < 3; ++m) {
+    const std::string p = "fra2utt_" + std::to_string(m);
+    pm.fra_ctx[m] = b.add(p + ".attention_context_vector", 1, D);
+    pm.fra_proj[m] = b.lin(p + ".input_proj", D, D);
+  }
+  for (int m = 0; m < 3; ++m) pm.frame[m] = b.lin("frame_dim_reshape_" + std::to_string(m), D, din[m]);
   pm.live = b.cur;
   // parameters that exist for state_dict compatibility but never receive a gradient
   // (model :202-203, :242, :244, :257, :260)
@@ -852,12 +854,14 @@ int keys_gemm_bwd(const Ctx& c, int m, int k0, int k1) {
   return run(c, g);
 }
 
-int backward(const Ctx& c, const sdumc_net_grads& og) {
+// phases: bit 0 = the utterance-level part (finishes every gradient in [0, pm.early)), bit 1 = the frame-level part
+int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   const Plan& pl = c.pl;
   const ParamMap& pm = c.pm;
   const int B = pl.B, S = pl.S, V = pl.V;
   const int din[3] = {c.d.da, c.d.dt, c.d.dv};
   const float s_mlp = c.d.train ? 1.0f / (1.0f - (float)c.d.p_mlp) : 1.0f;
+  if (phases & 1) {
   // every live gradient tensor is overwritten below when all five output gradients are given
   if (!og.d_vals || !og.d_fused || !og.d_rnc || !og.d_text_hidden || !og.d_cross_text) RET(sdumc_fill(c.G, 0.f, pm.live, c.st));
 
@@ -950,6 +954,9 @@ int backward(const Ctx& c, const sdumc_net_grads& og) {
     GroupPtrs q0 = {c.p(pl.d_u1), (int64_t)V * D, D, c.p(pl.hpre), (int64_t)V * D, D, c.p(pl.d_hpre), (int64_t)V * D, D};
     RET(lin_bwd_grouped(c, pm.umlp0, 3, V, q0));
   }
+  RET(link(c, 1, 0));   // the dW GEMMs of this part ran on lane 1: [0, pm.early) is final on the caller's stream
+  }   // phases & 1
+  if (!(phases & 2)) return SDUMC_OK;
   // 2'+1'. three independent per-modality chains, one per lane:
   //   fra2utt_m pooling backward (the shared context vector's gradient = sum of the per-sample dq)
   //   -> input_proj backward of both sites (grouped) -> dx = sum of the (up to) four masked paths into the
@@ -1107,6 +1114,21 @@ extern "C" int sdumc_net_backward(const sdumc_net_dims* d, const sdumc_net_io* i
   c.init_lanes();
   return backward(c, *g);
 }
+
+extern "C" int sdumc_net_backward_phase(const sdumc_net_dims* d, const sdumc_net_io* io, const sdumc_net_grads* g,
+                                        int32_t phase, void* stream) {
+  RET(check_io(d, io));
+  if (!g || !g->grads || (reinterpret_cast<uintptr_t>(g->grads) & 15) || phase < 0 || phase > 1) return SDUMC_EINVAL;
+  Ctx c{*d, *io, as_stream(stream), build_params(d->da, d->dt, d->dv), Plan(), nullptr, nullptr, nullptr};
+  if (!make_plan(*d, c.pl)) return SDUMC_EINVAL;
+  if (io->workspace_bytes < (size_t)c.pl.cur * sizeof(float)) return SDUMC_ENOMEM;
+  c.W = static_cast<float*>(io->workspace);
+  c.P = io->params;
+  c.G = g->grads;
+  c.init_lanes();
+  return backward(c, *g, 1 << phase);
+}
+extern "C" int64_t sdumc_param_early_count(int32_t da, int32_t dt, int32_t dv) { return build_params(da, dt, dv).early; }
 
 extern "C" size_t sdumc_loss_workspace_bytes(const sdumc_net_dims* d, int32_t B_global) {
   if (!d || d->B <= 0) return 0;

@@ -37,6 +37,8 @@ class ParamLayout:
             self.order.append(name)
         self.total = lib.sdumc_param_count(*self.dims)
         self.live = lib.sdumc_param_live_count(*self.dims)
+        # [0, early): utterance-level layers (gradients final after backward phase 0), [early, live): frame-level
+        self.early = lib.sdumc_param_early_count(*self.dims)
 
     @classmethod
     def get(cls, da, dt, dv):

@@ -57,3 +57,55 @@ def test_two_simulated_ranks_equal_full_batch():
     np.testing.assert_allclose(((bes[0].params - flat()) * 1e4).cpu().numpy(), ((full_p - flat()) * 1e4).cpu().numpy(),
                                rtol=2e-2, atol=2e-2)
     assert bes[0].rng.call == 2
+
+
+def test_backward_phases_equal_one_call_and_early_slice_is_final():
+    """sdumc_net_backward_phase(0) + (1) == sdumc_net_backward, bit for bit, and after phase 0 alone the slice
+    [0, layout.early) -- what the data-parallel step all-reduces while phase 1 runs -- already holds its final
+    values.  The early/late split is by layer: utterance-level first, frame-level (input_proj, context vectors,
+    frame_dim_reshape) last."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from oracle import sdumc_oracle as O
+    from sdumc_amd import engine
+    from sdumc_amd.trainer import HipBackend
+    dims, Tn, B, seed = (64, 32, 48, 32), (70, 6, 30, 5), 4, 7
+    P = O.init_params(dims, seed=3)
+    lay = engine.ParamLayout.get(*dims[:3])
+    late = {n for n in lay.live_names() if lay.entries[n][0] >= lay.early}
+    assert late == {n for n in lay.live_names()
+                    if n.startswith("frame_dim_reshape_") or n.startswith("fra2utt_") or ".input_proj." in n}
+    assert 0 < lay.early < lay.live and lay.early % 4 == 0
+
+    def flat():
+        f = torch.zeros(lay.total)
+        for k, v in lay.views(f).items():
+            v.copy_(P[k])
+        return f.cuda()
+
+    gb = [t.cuda() for t in O.synthetic_batch(B, Tn, dims, seed=8)]
+    used = torch.zeros(lay.live, dtype=torch.bool)          # alignment padding between tensors is never written
+    for n in lay.live_names():
+        off, shape, _ = lay.entries[n]
+        used[off:off + int(np.prod(shape))] = True
+    res = []
+    for phased in (False, True):
+        be = HipBackend(flat(), B, Tn, dims, engine.DEFAULT_WEIGHTS, 1e-4, (0.9, 0.999), 1e-8, 1e-5, seed, 0, B)
+        be.set_batch(*gb)
+        be.forward()
+        be.loss_backward()
+        if phased:
+            be.grads.fill_(float("nan"))
+            early = be.backward_phase(0)
+            torch.cuda.synchronize()
+            assert early.numel() == lay.early and torch.isfinite(early.cpu()[used[:lay.early]]).all()
+            assert not torch.isfinite(be.grads.cpu()[lay.early:][used[lay.early:]]).any()   # phase 1 has not run
+            snap = early.clone()
+            be.backward_phase(1)
+            torch.cuda.synchronize()
+            assert torch.equal(snap.cpu()[used[:lay.early]], be.grads.cpu()[:lay.early][used[:lay.early]])   # untouched by phase 1
+        else:
+            be.backward()
+        torch.cuda.synchronize()
+        res.append(be.grads.clone())
+    assert torch.equal(res[0].cpu()[used], res[1].cpu()[used])
