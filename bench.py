@@ -199,7 +199,7 @@ def main():
         run = step.run
     else:
         from sdumc_amd.trainer import DataParallelStep
-        step = DataParallelStep(flat, B_PER_GPU, T_MOSEI, DIMS, seed=2024, exact=True)
+        step = DataParallelStep(flat, B_PER_GPU, T_MOSEI, DIMS, seed=2024, exact=True, bf16=args.bf16)
         step.set_batch(*batch)
         run = step.step
 

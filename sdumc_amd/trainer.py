@@ -32,7 +32,8 @@ def _world():
 class HipBackend:
     """Per-rank compute on one MI355X through the C ABI."""
 
-    def __init__(self, flat_params, B, T, dims, weights, lr, betas, eps, weight_decay, seed, sample0, B_global):
+    def __init__(self, flat_params, B, T, dims, weights, lr, betas, eps, weight_decay, seed, sample0, B_global,
+                 bf16=False):
         from . import _lib, engine
         self._lib, self._engine = _lib, engine
         lib = _lib.lib
@@ -48,7 +49,7 @@ class HipBackend:
         self.labels = torch.empty(B, device=dev)
         self.rng = engine.RngState(seed, dev)
         self.call = engine.NetCall(flat_params, self.audio, [self.text, self.feat4], self.video, True, self.rng,
-                                   sample0=sample0)
+                                   sample0=sample0, bf16=bf16)
         V = 2 * B
         self.d_vals = torch.empty(V, 1, device=dev)
         self.d_fused = torch.empty(V, engine.H, device=dev)
@@ -143,13 +144,14 @@ class DataParallelStep:
     """
 
     def __init__(self, flat_params, B, T, dims, weights=(0.5, 0.5, 0.1, 0.7, 0.1, 0.8), lr=1e-4, betas=(0.9, 0.999),
-                 eps=1e-8, weight_decay=1e-5, seed=0, exact=True, backend_factory=None):
+                 eps=1e-8, weight_decay=1e-5, seed=0, exact=True, backend_factory=None, bf16=False):
         self.rank, self.world = _world()
         self.B, self.exact = B, exact
         self.B_global = B * self.world if exact else B
         factory = backend_factory or HipBackend
+        extra = {"bf16": True} if bf16 else {}
         self.be = factory(flat_params, B, T, dims, weights, lr, betas, eps, weight_decay, seed, self.rank * B,
-                          self.B_global)
+                          self.B_global, **extra)
         self.weights = weights
         # The early-slice all-reduce is issued asynchronously only on RCCL ("nccl"), where it is a kernel on the
         # communicator's own stream beside the frame-level backward (the pattern torch DDP uses).  Under gloo (CPU tests,
