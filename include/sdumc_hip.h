@@ -146,9 +146,15 @@ typedef struct sdumc_attnpool {
   float* out;          /* [V, nq, 256] */
   float* workspace;    /* >= sdumc_attnpool_fwd_workspace_bytes(V, T, nq): per-chunk softmax partials */
   size_t workspace_bytes;
+  int32_t dim;         /* channels per row: 0 or 256 (the model's general_dim, model :191), or 512 / 768 / 1024 for the
+                          blocks used on their own (FRA2UTT_new / Cross_Attention default to input_dim = 1024,
+                          model :47,:71).  Every "256" in the shapes above and below then reads `dim`; the dropout
+                          descriptors carry width = dim; workspaces are sized by the *_dim queries */
 } sdumc_attnpool;
 
 size_t sdumc_attnpool_fwd_workspace_bytes(int32_t V, int32_t T, int32_t nq);
+size_t sdumc_attnpool_fwd_workspace_bytes_dim(int32_t V, int32_t T, int32_t nq, int32_t dim);
+size_t sdumc_attnpool_bwd_workspace_bytes_dim(int32_t V, int32_t T, int32_t nq, int32_t dim);
 int sdumc_attnpool_fwd(const sdumc_attnpool* p, void* stream);
 
 /* backward of the above. Produces

@@ -49,7 +49,7 @@ class AttnPool(C.Structure):
                 ("x", C.c_void_p), ("keys", C.c_void_p), ("q", C.c_void_p), ("q_stride", C.c_int64),
                 ("scale", C.c_float), ("x_drop", Dropout), ("out_drop", Dropout),
                 ("attn", C.c_void_p), ("pooled", C.c_void_p), ("out", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("dim", C.c_int32)]
 
 
 class AttnPoolBwd(C.Structure):
@@ -141,6 +141,8 @@ _SIGS = {
     "sdumc_gemm_f32": (C.c_int, [C.POINTER(Gemm), C.c_void_p]),
     "sdumc_attnpool_fwd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "sdumc_attnpool_fwd": (C.c_int, [C.POINTER(AttnPool), C.c_void_p]),
+    "sdumc_attnpool_fwd_workspace_bytes_dim": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "sdumc_attnpool_bwd_workspace_bytes_dim": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "sdumc_attnpool_bwd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "sdumc_attnpool_bwd": (C.c_int, [C.POINTER(AttnPoolBwd), C.c_void_p]),
     "sdumc_relu_drop_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),

@@ -7,8 +7,8 @@
 Same constructor signatures, parameter names/shapes (`attention_context_vector[1, D]`, `input_proj`,
 `query_proj`, the `dropout_output` sub-module), inputs and return values; forward and backward run on the
 HIP kernels the full network uses (`sdumc_gemm_f32` with the input dropout and tanh fused, `sdumc_attnpool_fwd/bwd`,
-`sdumc_dropsum_bwd`).  The kernels are built for `input_dim == 256` -- the only width the model ever
-instantiates (`general_dim = 256` is hard-coded, model :191); other widths raise NotImplementedError.  CPU tensors raise.
+`sdumc_drop_add`).  `input_dim` may be 256 (what the model instantiates: `general_dim = 256` is hard-coded, model :191),
+512, 768 or 1024 (the constructors' default); other widths raise NotImplementedError.  CPU tensors raise.
 
 Dropout: the block's two `self.dropout_output(...)` calls draw Philox masks keyed by (seed, call, site) from the
 module-level `dropout_stream` (sites in call order, exactly like `sdumc_amd.transformers_encoder`).
@@ -21,7 +21,7 @@ from torch import nn
 from . import _lib, ops
 from .transformers_encoder import DropoutStream, _LinearFn, _c, _dev
 
-D = _lib.D
+DIMS = (256, 512, 768, 1024)
 
 dropout_stream = DropoutStream()
 
@@ -38,7 +38,7 @@ class _PoolFn(torch.autograd.Function):
     def forward(ctx, x, q, w, b, scale, x_drop, out_drop, q_shared):
         x, q, w, b = _c(x), _c(q), _c(w), _c(b)
         _dev(x, q, w, b)
-        B, T, _ = x.shape
+        B, T, D = x.shape
         nq = q.shape[1]
         keys = ops.gemm(ops.NT, x, w, B * T, D, D, bias=b, act=ops.ACT_TANH, a_drop=x_drop, splitk=0).view(B, T, D)
         out, attn, pooled, desc = _pool_with_scale(x, keys, q, nq, B, q_shared, x_drop, out_drop, scale)
@@ -50,7 +50,7 @@ class _PoolFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout, _dattn):
         x, keys, q, w, desc, attn, pooled, out = ctx.saved
-        B, T, _ = x.shape
+        B, T, D = x.shape
         dz, dxd, dq = ops.attnpool_bwd(desc, _c(dout), (x, keys, q))
         dw = ops.gemm(ops.TN, dz.view(-1, D), x, D, D, B * T, b_drop=ctx.x_drop, splitk=0)
         db = ops.colsum(dz.view(-1, D))
@@ -63,13 +63,13 @@ class _PoolFn(torch.autograd.Function):
 
 
 def _pool_with_scale(x, keys, q, nq, B, q_shared, x_drop, out_drop, scale):
-    V, T, _ = keys.shape
+    V, T, D = keys.shape
     dev = keys.device
     attn = torch.empty(V, T, nq, device=dev)
     pooled = torch.empty(V, nq, D, device=dev)
     out = torch.empty(V, nq, D, device=dev)
-    a = ops.attnpool_desc(x, keys, q, V, T, nq, B, 0 if q_shared else nq * D, x_drop, out_drop, attn, pooled, out, scale)
-    need = _lib.lib.sdumc_attnpool_fwd_workspace_bytes(V, T, nq)
+    a = ops.attnpool_desc(x, keys, q, V, T, nq, B, 0 if q_shared else nq * D, x_drop, out_drop, attn, pooled, out, scale, D)
+    need = _lib.lib.sdumc_attnpool_fwd_workspace_bytes_dim(V, T, nq, D)
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
     a.workspace, a.workspace_bytes = _lib.ptr(ws), need
     _lib.check(_lib.lib.sdumc_attnpool_fwd(C.byref(a), _lib.current_stream()), "sdumc_attnpool_fwd")
@@ -80,21 +80,13 @@ def _mask_apply(g, drop, B, T):
     """g * mask of the input dropout (identity in eval mode): the backward of `dropout_output(input_tensor)`."""
     if drop is None or not drop.enabled:
         return g
-    dx = torch.empty_like(g)
-    ds = _lib.DropSum()
-    ds.terms, ds.samples, ds.T = 1, B, T
-    ds.g[0] = _lib.ptr(g)
-    ds.drop[0] = drop
-    ds.stream_idx[0] = 0
-    ds.dx = _lib.ptr(dx)
-    _lib.check(_lib.lib.sdumc_dropsum_bwd(C.byref(ds), _lib.current_stream()), "sdumc_dropsum_bwd")
-    return dx
+    return ops.drop_add(g, None, drop, 1.0)
 
 
 def _check_dim(input_dim):
-    if input_dim != D:
-        raise NotImplementedError(f"the HIP attention-pooling kernels are built for input_dim == {D} "
-                                  f"(general_dim is hard-coded to 256 in the reference model, :191); got {input_dim}")
+    if input_dim not in DIMS:
+        raise NotImplementedError(f"the HIP attention-pooling kernels are built for input_dim in {DIMS} "
+                                  f"(multiples of 256, the model's general_dim); got {input_dim}")
 
 
 class FRA2UTT_new(nn.Module):
@@ -111,7 +103,7 @@ class FRA2UTT_new(nn.Module):
         self.dropout_output = nn.Dropout(0.5)
 
     def forward(self, input_tensor):
-        B, T, _ = input_tensor.shape
+        B, T, D = input_tensor.shape
         p = self.dropout_output.p
         x_drop = dropout_stream.draw(p, B, T, D, self.training)
         out_drop = dropout_stream.draw(p, B, 1, D, self.training)
@@ -135,7 +127,7 @@ class Cross_Attention(nn.Module):
         self.dropout_output = nn.Dropout(0.5)
 
     def forward(self, query_tensor, input_tensor):
-        B, T, _ = input_tensor.shape
+        B, T, D = input_tensor.shape
         nq = query_tensor.shape[1]
         if nq > 8:
             raise NotImplementedError("at most 8 queries per block (the model uses 7, :332)")

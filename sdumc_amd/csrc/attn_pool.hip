@@ -18,11 +18,13 @@
 // matrix cores as v_mfma_f32_16x16x4_f32 (queries padded to 16 columns) instead of 64-lane shuffle
 // reductions; the [rows] x [channels] parts stay on the VALU with one 16-B access per lane per row.
 // No float atomics: partials are reduced in a fixed order (bitwise reproducible).
+#include <type_traits>
+
 #include "common.h"
 
 namespace {
 
-constexpr int D = SDUMC_D;       // 256 channels = 64 lanes x 4
+constexpr int D = SDUMC_D;       // one channel block = 256 channels = 64 lanes x 4; a row holds C blocks (dim = 256 C)
 constexpr int MAXQ = 8;
 constexpr int CH = 64;           // rows of one v handled by a 4-wave workgroup (16 per wave)
 
@@ -35,26 +37,27 @@ struct FwdWs {
   float* part;
   float* stats;
 };
-__host__ __device__ inline FwdWs fwd_ws(float* w, int V, int nchunk, int nq) {
+__host__ __device__ inline FwdWs fwd_ws(float* w, int V, int nchunk, int nq, int dd) {
   FwdWs r;
   r.part = w;
-  r.stats = w + (size_t)V * nchunk * nq * D;
+  r.stats = w + (size_t)V * nchunk * nq * dd;
   return r;
 }
+__host__ __device__ inline int row_dim(const sdumc_attnpool& p) { return p.dim > 0 ? p.dim : D; }
 
 // [16 rows of this wave] x [16 query columns] = sum over 256 channels, on the matrix cores.
 // A operand: lane (r = lane&15, kk = lane>>4) supplies rows[r][16 j + 4 kk + e]; B operand: the same
 // channel of column r.  `rowp` = this lane's row pointer (or nullptr), bq[j] = this lane's B fragments.
 // The B side lives in LDS as [MAXQ][LDQ] (LDQ = 272: rows 16 banks apart -> at most 2-way conflicts).
-constexpr int LDQ = D + 16;
-template <bool DROP>
+template <bool DROP, int C>
 __device__ __forceinline__ f32x4 rows_times_cols(const float* rowp, const float* b_lds, const DropRT& d,
                                                  uint32_t vrow, int r16, int kk) {
+  constexpr int LDQ = D * C + 16;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   // two batches of 8 channel groups: a batch's row loads (and keep-bits bytes) are all issued before its first MFMA
   const bool bits = DROP && d.bits != nullptr;
 #pragma unroll
-  for (int jb = 0; jb < 16; jb += 8) {
+  for (int jb = 0; jb < 16 * C; jb += 8) {
     f32x4 a[8];
     uint32_t mb[8];
 #pragma unroll
@@ -92,10 +95,12 @@ __device__ __forceinline__ f32x4 rows_times_cols(const float* rowp, const float*
 
 // ---- forward, pass 1: one workgroup per (chunk of 64 rows, v) -----------------------------------
 // PHILOX: the input dropout mask is recomputed per row (no precomputed keep-bits attached: tests, one-off calls)
-template <bool PHILOX>
-__global__ __launch_bounds__(256, 4) void attn_fwd_partial_kernel(const sdumc_attnpool p, float* ws, const int nchunk) {
+template <bool PHILOX, int C>
+__global__ __launch_bounds__(256, C == 1 ? 4 : 2) void attn_fwd_partial_kernel(const sdumc_attnpool p, float* ws, const int nchunk) {
+  constexpr int DD = D * C, LDQ = DD + 16;
+  constexpr int RED = 4 * MAXQ * D > MAXQ * LDQ ? 4 * MAXQ * D : MAXQ * LDQ;
   __shared__ __attribute__((aligned(16))) float P_s[CH * MAXQ];
-  __shared__ __attribute__((aligned(16))) float red[4 * MAXQ * D];   // first the query tile, later the pooling reduce
+  __shared__ __attribute__((aligned(16))) float red[RED];   // first the query tile, later the pooling reduce (per channel block)
   __shared__ float wstat[4][16];
   __shared__ float cstat[16];
   const int chunk = blockIdx.x, v = blockIdx.y;
@@ -103,18 +108,18 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_partial_kernel(const sdumc_at
   const int r16 = lane & 15, kk = lane >> 4;
   const int T = p.T, nq = p.nq;
   const int t0 = chunk * CH;
-  const FwdWs w = fwd_ws(ws, p.V, nchunk, nq);
+  const FwdWs w = fwd_ws(ws, p.V, nchunk, nq, DD);
 
   // scores of this wave's 16 rows against the (<= 8) queries
   float* q_s = red;
-  for (int e = tid; e < MAXQ * (D / 4); e += 256) {
-    const int i = e / (D / 4), cq = e - i * (D / 4);
-    st4(q_s + i * LDQ + 4 * cq, i < nq ? ld4(p.q + (size_t)v * p.q_stride + (size_t)i * D + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f});
+  for (int e = tid; e < MAXQ * (DD / 4); e += 256) {
+    const int i = e / (DD / 4), cq = e - i * (DD / 4);
+    st4(q_s + i * LDQ + 4 * cq, i < nq ? ld4(p.q + (size_t)v * p.q_stride + (size_t)i * DD + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f});
   }
   __syncthreads();
   const int myrow = t0 + 16 * wave + r16;
   const DropRT nodrop = {};
-  const f32x4 s4 = rows_times_cols<false>(myrow < T ? p.keys + ((size_t)v * T + myrow) * D : nullptr, q_s, nodrop, 0u, r16, kk);
+  const f32x4 s4 = rows_times_cols<false, C>(myrow < T ? p.keys + ((size_t)v * T + myrow) * DD : nullptr, q_s, nodrop, 0u, r16, kk);
   // C layout: column (query) = lane & 15, rows = 16 wave + 4 (lane >> 4) + e
   float s[4], mx = -INFINITY;
 #pragma unroll
@@ -149,76 +154,88 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_partial_kernel(const sdumc_at
     st[tid] = cstat[tid];
     st[MAXQ + tid] = wstat[0][tid] + wstat[1][tid] + wstat[2][tid] + wstat[3][tid];
   }
-  // unnormalised pooling of this chunk: lane owns channels 4*lane..4*lane+3, wave owns 16 rows
+  // unnormalised pooling of this chunk, one 256-channel block at a time: lane owns channels 4*lane..4*lane+3 of the
+  // block, wave owns 16 rows
   const DropRT xd = drop_resolve(p.x_drop);
   const int vx = v % p.x_samples;
-  f32x4 acc[MAXQ];
+  // (a generic lambda called once per block, not a loop over blocks: ANY enclosing loop -- even one of trip count 1 --
+  // makes hipcc (ROCm 7.2) unroll the row loops inside it despite their `unroll 1` and spill ~4600 VGPRs)
+  auto pool_block = [&](auto cbc) {
+    constexpr int cb = decltype(cbc)::value;
+    const int ch = D * cb + 4 * lane;           // this lane's first channel
+    f32x4 acc[MAXQ];
 #pragma unroll
-  for (int i = 0; i < MAXQ; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if constexpr (PHILOX) {
-    // row at a time
+    for (int i = 0; i < MAXQ; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (PHILOX) {
+      // row at a time
 #pragma unroll 1
-    for (int r = 0; r < 16; ++r) {
-      const int rl = 16 * wave + r, t = t0 + rl;
-      if (t >= T) break;
-      f32x4 x = ld4(p.x + ((size_t)vx * T + t) * D + 4 * lane);
-      x *= drop_mask4(xd, (uint32_t)(v * T + t), (uint32_t)lane);
-#pragma unroll
-      for (int i = 0; i < MAXQ; ++i)
-        if (i < nq) acc[i] += x * P_s[rl * MAXQ + i];
-    }
-  } else {
-    // rows in batches of RB: all of a batch's 16-byte loads (and keep-bits bytes) are in flight before the first
-    // FMA consumes one -- the row-at-a-time loop this replaces paid one memory round trip per row (16 per wave)
-    constexpr int RB = 4;
-    const bool masked = xd.enabled != 0;
-    const float mscale = masked ? xd.scale : 1.f;
-#pragma unroll 1
-    for (int rb = 0; rb < 16; rb += RB) {
-      f32x4 xr[RB];
-      uint32_t mb[RB];
-#pragma unroll
-      for (int j = 0; j < RB; ++j) {
-        const int t = min(t0 + 16 * wave + rb + j, T - 1);   // rows beyond T re-read the last row; their P_s is 0
-        xr[j] = ld4(p.x + ((size_t)vx * T + t) * D + 4 * lane);
-        mb[j] = masked ? xd.bits[(size_t)(v * T + t) * xd.qwidth + lane] : 0xfu;
-      }
-#pragma unroll
-      for (int j = 0; j < RB; ++j) {
-        const int rl = 16 * wave + rb + j;
-        f32x4 x = xr[j];
-        {
-          const uint32_t b = mb[j];
-          x[0] = (b & 1u) ? x[0] * mscale : 0.f;
-          x[1] = (b & 2u) ? x[1] * mscale : 0.f;
-          x[2] = (b & 4u) ? x[2] * mscale : 0.f;
-          x[3] = (b & 8u) ? x[3] * mscale : 0.f;
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int rl = 16 * wave + r, t = t0 + rl;
+        if (t >= T) break;
+        f32x4 x = ld4(p.x + ((size_t)vx * T + t) * DD + ch);
+        x *= drop_mask4(xd, (uint32_t)(v * T + t), (uint32_t)(ch >> 2));
 #pragma unroll
         for (int i = 0; i < MAXQ; ++i)
-          if (i < nq) acc[i] += x * P_s[rl * MAXQ + i];   // rows beyond T: x = 0 and P_s = 0
+          if (i < nq) acc[i] += x * P_s[rl * MAXQ + i];
+      }
+    } else {
+      // rows in batches of RB: all of a batch's 16-byte loads (and keep-bits bytes) are in flight before the first
+      // FMA consumes one -- the row-at-a-time loop this replaces paid one memory round trip per row (16 per wave)
+      constexpr int RB = 4;
+      const bool masked = xd.enabled != 0;
+      const float mscale = masked ? xd.scale : 1.f;
+#pragma unroll 1
+      for (int rb = 0; rb < 16; rb += RB) {
+        f32x4 xr[RB];
+        uint32_t mb[RB];
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          const int t = min(t0 + 16 * wave + rb + j, T - 1);   // rows beyond T re-read the last row; their P_s is 0
+          xr[j] = ld4(p.x + ((size_t)vx * T + t) * DD + ch);
+          mb[j] = masked ? xd.bits[(size_t)(v * T + t) * xd.qwidth + (ch >> 2)] : 0xfu;
+        }
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          const int rl = 16 * wave + rb + j;
+          f32x4 x = xr[j];
+          {
+            const uint32_t b = mb[j];
+            x[0] = (b & 1u) ? x[0] * mscale : 0.f;
+            x[1] = (b & 2u) ? x[1] * mscale : 0.f;
+            x[2] = (b & 4u) ? x[2] * mscale : 0.f;
+            x[3] = (b & 8u) ? x[3] * mscale : 0.f;
+          }
+#pragma unroll
+          for (int i = 0; i < MAXQ; ++i)
+            if (i < nq) acc[i] += x * P_s[rl * MAXQ + i];   // rows beyond T: x = 0 and P_s = 0
+        }
       }
     }
-  }
+    if (cb > 0) __syncthreads();              // the previous block's reduce has read `red`
 #pragma unroll
-  for (int i = 0; i < MAXQ; ++i)
-    if (i < nq) st4(red + (wave * MAXQ + i) * D + 4 * lane, acc[i]);
-  __syncthreads();
-  for (int e = tid; e < nq * (D / 4); e += 256) {
-    const int i = e / (D / 4), cq = e - i * (D / 4);
-    f32x4 sum = ld4(red + i * D + 4 * cq);
+    for (int i = 0; i < MAXQ; ++i)
+      if (i < nq) st4(red + (wave * MAXQ + i) * D + 4 * lane, acc[i]);
+    __syncthreads();
+    for (int e = tid; e < nq * (D / 4); e += 256) {
+      const int i = e / (D / 4), cq = e - i * (D / 4);
+      f32x4 sum = ld4(red + i * D + 4 * cq);
 #pragma unroll
-    for (int ww = 1; ww < 4; ++ww) sum += ld4(red + (ww * MAXQ + i) * D + 4 * cq);
-    st4(w.part + (((size_t)v * nchunk + chunk) * nq + i) * D + 4 * cq, sum);
-  }
+      for (int ww = 1; ww < 4; ++ww) sum += ld4(red + (ww * MAXQ + i) * D + 4 * cq);
+      st4(w.part + (((size_t)v * nchunk + chunk) * nq + i) * DD + D * cb + 4 * cq, sum);
+    }
+  };
+  pool_block(std::integral_constant<int, 0>{});
+  if constexpr (C > 1) pool_block(std::integral_constant<int, 1>{});
+  if constexpr (C > 2) pool_block(std::integral_constant<int, 2>{});
+  if constexpr (C > 3) pool_block(std::integral_constant<int, 3>{});
 }
 
 // ---- forward, pass 2: combine the chunks of one v, normalise the weights, output dropout ---------
 __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const sdumc_attnpool p, const float* ws, const int nchunk) {
   extern __shared__ float fac[];   // [nchunk][MAXQ]: exp(m_c - m) / l
   const int v = blockIdx.x, tid = threadIdx.x;
-  const int T = p.T, nq = p.nq;
-  const FwdWs w = fwd_ws(const_cast<float*>(ws), p.V, nchunk, nq);
+  const int T = p.T, nq = p.nq, DD = row_dim(p);
+  const FwdWs w = fwd_ws(const_cast<float*>(ws), p.V, nchunk, nq, DD);
   const float* st = w.stats + (size_t)v * nchunk * 2 * MAXQ;
   if (tid < nq) {
     float m = -INFINITY;
@@ -230,11 +247,11 @@ __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const sdumc_attnp
   }
   __syncthreads();
   const DropRT od = drop_resolve(p.out_drop);
-  for (int e = tid; e < nq * (D / 4); e += 256) {
-    const int i = e / (D / 4), cq = e - i * (D / 4);
+  for (int e = tid; e < nq * (DD / 4); e += 256) {
+    const int i = e / (DD / 4), cq = e - i * (DD / 4);
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < nchunk; ++c) sum += ld4(w.part + (((size_t)v * nchunk + c) * nq + i) * D + 4 * cq) * fac[c * MAXQ + i];
-    const size_t o = ((size_t)v * nq + i) * D + 4 * cq;
+    for (int c = 0; c < nchunk; ++c) sum += ld4(w.part + (((size_t)v * nchunk + c) * nq + i) * DD + 4 * cq) * fac[c * MAXQ + i];
+    const size_t o = ((size_t)v * nq + i) * DD + 4 * cq;
     st4(p.pooled + o, sum);
     if (od.enabled) sum *= drop_mask4(od, (uint32_t)(v * nq + i), (uint32_t)cq);
     st4(p.out + o, sum);
@@ -252,8 +269,10 @@ __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const sdumc_attnp
 //   dK_t = sum_i dS_i Q_i ; dz_t = dK_t (1 - K_t^2)            -> dz
 //   dxd_t (pool path) = sum_i A_ti dO_i                         -> dxd
 //   dQ_i += dS_i K_t                                            -> per-chunk slabs (deterministic)
+template <int C>
 __global__ __launch_bounds__(256, 2) void attnpool_bwd_kernel(const sdumc_attnpool_bwd_t b, float* dq_part,
                                                            const int nchunk) {
+  constexpr int DD = D * C, LDQ = DD + 16;
   __shared__ __attribute__((aligned(16))) float dO_s[MAXQ * LDQ];
   __shared__ __attribute__((aligned(16))) float red[4 * MAXQ * D];
   __shared__ __attribute__((aligned(16))) float dS_s[CH * MAXQ];
@@ -266,11 +285,11 @@ __global__ __launch_bounds__(256, 2) void attnpool_bwd_kernel(const sdumc_attnpo
   const int T = p.T, nq = p.nq;
   const int t0 = chunk * CH;
   const DropRT od = drop_resolve(p.out_drop);
-  for (int e = tid; e < MAXQ * (D / 4); e += 256) {
-    const int i = e / (D / 4), cq = e - i * (D / 4);
+  for (int e = tid; e < MAXQ * (DD / 4); e += 256) {
+    const int i = e / (DD / 4), cq = e - i * (DD / 4);
     f32x4 g = {0.f, 0.f, 0.f, 0.f};
     if (i < nq) {
-      g = ld4(b.dout + ((size_t)v * nq + i) * D + 4 * cq);
+      g = ld4(b.dout + ((size_t)v * nq + i) * DD + 4 * cq);
       if (od.enabled) g *= drop_mask4(od, (uint32_t)(v * nq + i), (uint32_t)cq);
     }
     st4(dO_s + i * LDQ + 4 * cq, g);
@@ -278,7 +297,11 @@ __global__ __launch_bounds__(256, 2) void attnpool_bwd_kernel(const sdumc_attnpo
   if (tid < 16) delta_s[tid] = 0.f;
   __syncthreads();
   for (int i = wave; i < nq; i += 4) {
-    const float d = wave_sum(dot4(ld4(dO_s + i * LDQ + 4 * lane), ld4(p.pooled + ((size_t)v * nq + i) * D + 4 * lane)));
+    float d = 0.f;
+#pragma unroll
+    for (int cb = 0; cb < C; ++cb)
+      d += dot4(ld4(dO_s + i * LDQ + D * cb + 4 * lane), ld4(p.pooled + ((size_t)v * nq + i) * DD + D * cb + 4 * lane));
+    d = wave_sum(d);
     if (lane == 0) delta_s[i] = d;
   }
   __syncthreads();
@@ -288,10 +311,10 @@ __global__ __launch_bounds__(256, 2) void attnpool_bwd_kernel(const sdumc_attnpo
   const int vx = v % p.x_samples;
   {
     const int myrow = t0 + 16 * wave + r16;
-    const float* rowp = myrow < T ? p.x + ((size_t)vx * T + myrow) * D : nullptr;
+    const float* rowp = myrow < T ? p.x + ((size_t)vx * T + myrow) * DD : nullptr;
     const uint32_t vrow = (uint32_t)(v * T + myrow);
-    const f32x4 dA = xd.enabled ? rows_times_cols<true>(rowp, dO_s, xd, vrow, r16, kk)
-                                : rows_times_cols<false>(rowp, dO_s, xd, vrow, r16, kk);
+    const f32x4 dA = xd.enabled ? rows_times_cols<true, C>(rowp, dO_s, xd, vrow, r16, kk)
+                                : rows_times_cols<false, C>(rowp, dO_s, xd, vrow, r16, kk);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int rl = 16 * wave + 4 * kk + e, t = t0 + rl;
@@ -308,56 +331,62 @@ __global__ __launch_bounds__(256, 2) void attnpool_bwd_kernel(const sdumc_attnpo
   }
   __syncthreads();
 
-  f32x4 q[MAXQ], g[MAXQ], dqa[MAXQ];
+  // one 256-channel block at a time
+#pragma unroll 1
+  for (int cb = 0; cb < C; ++cb) {
+    const int ch = D * cb + 4 * lane;
+    f32x4 q[MAXQ], g[MAXQ], dqa[MAXQ];
 #pragma unroll
-  for (int i = 0; i < MAXQ; ++i) {
-    dqa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (i < nq) {
-      q[i] = ld4(p.q + (size_t)v * p.q_stride + (size_t)i * D + 4 * lane);
-      g[i] = ld4(dO_s + i * LDQ + 4 * lane);
-    }
-  }
-  // rows in batches of RB: the batch's key-row loads are all in flight before the first row is processed
-  constexpr int RB = 4;
-#pragma unroll
-  for (int rb = 0; rb < 16; rb += RB) {
-    f32x4 kr[RB];
-#pragma unroll
-    for (int j = 0; j < RB; ++j) {
-      const int t = t0 + 16 * wave + rb + j;
-      kr[j] = t < T ? ld4(p.keys + ((size_t)v * T + t) * D + 4 * lane) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int j = 0; j < RB; ++j) {
-      const int rl = 16 * wave + rb + j, t = t0 + rl;
-      const size_t row = (size_t)v * T + t;
-      const f32x4 k = kr[j];
-      f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dx = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int i = 0; i < MAXQ; ++i)
-        if (i < nq) {
-          const float dS = dS_s[rl * MAXQ + i], a = A_s[rl * MAXQ + i];   // both 0 for rows beyond T
-          dk += q[i] * dS;
-          dx += g[i] * a;
-          dqa[i] += k * dS;
-        }
-      if (t < T) {
-        const f32x4 one = {1.f, 1.f, 1.f, 1.f};
-        st4(b.dz + row * D + 4 * lane, dk * (one - k * k));
-        st4(b.dxd + row * D + 4 * lane, dx);
+    for (int i = 0; i < MAXQ; ++i) {
+      dqa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (i < nq) {
+        q[i] = ld4(p.q + (size_t)v * p.q_stride + (size_t)i * DD + ch);
+        g[i] = ld4(dO_s + i * LDQ + ch);
       }
     }
-  }
+    // rows in batches of RB: the batch's key-row loads are all in flight before the first row is processed
+    constexpr int RB = 4;
 #pragma unroll
-  for (int i = 0; i < MAXQ; ++i)
-    if (i < nq) st4(red + (wave * MAXQ + i) * D + 4 * lane, dqa[i]);
-  __syncthreads();
-  for (int e = tid; e < nq * (D / 4); e += 256) {
-    const int i = e / (D / 4), cq = e - i * (D / 4);
-    f32x4 s = ld4(red + i * D + 4 * cq);
+    for (int rb = 0; rb < 16; rb += RB) {
+      f32x4 kr[RB];
 #pragma unroll
-    for (int w = 1; w < 4; ++w) s += ld4(red + (w * MAXQ + i) * D + 4 * cq);
-    st4(dq_part + (((size_t)v * nchunk + chunk) * nq + i) * D + 4 * cq, s);
+      for (int j = 0; j < RB; ++j) {
+        const int t = t0 + 16 * wave + rb + j;
+        kr[j] = t < T ? ld4(p.keys + ((size_t)v * T + t) * DD + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int j = 0; j < RB; ++j) {
+        const int rl = 16 * wave + rb + j, t = t0 + rl;
+        const size_t row = (size_t)v * T + t;
+        const f32x4 k = kr[j];
+        f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < MAXQ; ++i)
+          if (i < nq) {
+            const float dS = dS_s[rl * MAXQ + i], a = A_s[rl * MAXQ + i];   // both 0 for rows beyond T
+            dk += q[i] * dS;
+            dx += g[i] * a;
+            dqa[i] += k * dS;
+          }
+        if (t < T) {
+          const f32x4 one = {1.f, 1.f, 1.f, 1.f};
+          st4(b.dz + row * DD + ch, dk * (one - k * k));
+          st4(b.dxd + row * DD + ch, dx);
+        }
+      }
+    }
+    if (cb > 0) __syncthreads();              // the previous block's reduce has read `red`
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i)
+      if (i < nq) st4(red + (wave * MAXQ + i) * D + 4 * lane, dqa[i]);
+    __syncthreads();
+    for (int e = tid; e < nq * (D / 4); e += 256) {
+      const int i = e / (D / 4), cq = e - i * (D / 4);
+      f32x4 s = ld4(red + i * D + 4 * cq);
+#pragma unroll
+      for (int w = 1; w < 4; ++w) s += ld4(red + (w * MAXQ + i) * D + 4 * cq);
+      st4(dq_part + (((size_t)v * nchunk + chunk) * nq + i) * DD + D * cb + 4 * cq, s);
+    }
   }
 }
 
@@ -374,6 +403,7 @@ __global__ __launch_bounds__(256) void dq_reduce_kernel(const float* part, float
 
 int check(const sdumc_attnpool& p) {
   if (p.V <= 0 || p.T <= 0 || p.nq < 1 || p.nq > MAXQ || p.x_samples <= 0) return SDUMC_EINVAL;
+  if (p.dim != 0 && p.dim != 256 && p.dim != 512 && p.dim != 768 && p.dim != 1024) return SDUMC_EINVAL;
   if (!p.x || !p.keys || !p.q || !p.attn || !p.pooled || !p.out) return SDUMC_EINVAL;
   if ((p.T + CH - 1) / CH > 4096) return SDUMC_EINVAL;
   return SDUMC_OK;
@@ -381,9 +411,12 @@ int check(const sdumc_attnpool& p) {
 
 }  // namespace
 
-extern "C" size_t sdumc_attnpool_fwd_workspace_bytes(int32_t V, int32_t T, int32_t nq) {
+extern "C" size_t sdumc_attnpool_fwd_workspace_bytes_dim(int32_t V, int32_t T, int32_t nq, int32_t dim) {
   const size_t nchunk = (size_t)(T + CH - 1) / CH;
-  return ((size_t)V * nchunk * nq * D + (size_t)V * nchunk * 2 * MAXQ) * sizeof(float);
+  return ((size_t)V * nchunk * nq * (dim > 0 ? dim : D) + (size_t)V * nchunk * 2 * MAXQ) * sizeof(float);
+}
+extern "C" size_t sdumc_attnpool_fwd_workspace_bytes(int32_t V, int32_t T, int32_t nq) {
+  return sdumc_attnpool_fwd_workspace_bytes_dim(V, T, nq, D);
 }
 
 extern "C" int sdumc_attnpool_fwd(const sdumc_attnpool* pp, void* stream) {
@@ -391,13 +424,19 @@ extern "C" int sdumc_attnpool_fwd(const sdumc_attnpool* pp, void* stream) {
   const sdumc_attnpool& p = *pp;
   int rc = check(p);
   if (rc) return rc;
-  if (!p.workspace || p.workspace_bytes < sdumc_attnpool_fwd_workspace_bytes(p.V, p.T, p.nq)) return SDUMC_ENOMEM;
+  if (!p.workspace || p.workspace_bytes < sdumc_attnpool_fwd_workspace_bytes_dim(p.V, p.T, p.nq, row_dim(p))) return SDUMC_ENOMEM;
   hipStream_t st = as_stream(stream);
   const int nchunk = (p.T + CH - 1) / CH;
-  if (p.x_drop.enabled && !p.x_drop.bits)
-    hipLaunchKernelGGL(attn_fwd_partial_kernel<true>, dim3(nchunk, p.V), dim3(256), 0, st, p, p.workspace, nchunk);
-  else
-    hipLaunchKernelGGL(attn_fwd_partial_kernel<false>, dim3(nchunk, p.V), dim3(256), 0, st, p, p.workspace, nchunk);
+  const bool philox = p.x_drop.enabled && !p.x_drop.bits;
+  const dim3 grid(nchunk, p.V), blk(256);
+#define FWD_PARTIAL(PH, CC) hipLaunchKernelGGL((attn_fwd_partial_kernel<PH, CC>), grid, blk, 0, st, p, p.workspace, nchunk)
+  switch (row_dim(p) / D) {
+    case 1: if (philox) FWD_PARTIAL(true, 1); else FWD_PARTIAL(false, 1); break;
+    case 2: if (philox) FWD_PARTIAL(true, 2); else FWD_PARTIAL(false, 2); break;
+    case 3: if (philox) FWD_PARTIAL(true, 3); else FWD_PARTIAL(false, 3); break;
+    default: if (philox) FWD_PARTIAL(true, 4); else FWD_PARTIAL(false, 4); break;
+  }
+#undef FWD_PARTIAL
   SDUMC_CHECK_LAUNCH();
   hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(p.V), dim3(256), (size_t)nchunk * MAXQ * sizeof(float), st, p,
                      p.workspace, nchunk);
@@ -405,9 +444,12 @@ extern "C" int sdumc_attnpool_fwd(const sdumc_attnpool* pp, void* stream) {
   return SDUMC_OK;
 }
 
-extern "C" size_t sdumc_attnpool_bwd_workspace_bytes(int32_t V, int32_t T, int32_t nq) {
+extern "C" size_t sdumc_attnpool_bwd_workspace_bytes_dim(int32_t V, int32_t T, int32_t nq, int32_t dim) {
   const size_t nchunk = (size_t)(T + CH - 1) / CH;
-  return (size_t)V * nchunk * nq * D * sizeof(float);
+  return (size_t)V * nchunk * nq * (dim > 0 ? dim : D) * sizeof(float);
+}
+extern "C" size_t sdumc_attnpool_bwd_workspace_bytes(int32_t V, int32_t T, int32_t nq) {
+  return sdumc_attnpool_bwd_workspace_bytes_dim(V, T, nq, D);
 }
 
 extern "C" int sdumc_attnpool_bwd(const sdumc_attnpool_bwd_t* bp, void* stream) {
@@ -418,13 +460,20 @@ extern "C" int sdumc_attnpool_bwd(const sdumc_attnpool_bwd_t* bp, void* stream) 
   if (!b.dout || !b.dz || !b.dxd || !b.dq || !b.workspace) return SDUMC_EINVAL;
   const sdumc_attnpool& p = b.f;
   const int nchunk = (p.T + CH - 1) / CH;
-  if (b.workspace_bytes < sdumc_attnpool_bwd_workspace_bytes(p.V, p.T, p.nq)) return SDUMC_ENOMEM;
+  const int DD = row_dim(p);
+  if (b.workspace_bytes < sdumc_attnpool_bwd_workspace_bytes_dim(p.V, p.T, p.nq, DD)) return SDUMC_ENOMEM;
   hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(attnpool_bwd_kernel, dim3(nchunk, p.V), dim3(256), 0, st, b, b.workspace, nchunk);
+  const dim3 grid(nchunk, p.V), blk(256);
+  switch (DD / D) {
+    case 1: hipLaunchKernelGGL(attnpool_bwd_kernel<1>, grid, blk, 0, st, b, b.workspace, nchunk); break;
+    case 2: hipLaunchKernelGGL(attnpool_bwd_kernel<2>, grid, blk, 0, st, b, b.workspace, nchunk); break;
+    case 3: hipLaunchKernelGGL(attnpool_bwd_kernel<3>, grid, blk, 0, st, b, b.workspace, nchunk); break;
+    default: hipLaunchKernelGGL(attnpool_bwd_kernel<4>, grid, blk, 0, st, b, b.workspace, nchunk); break;
+  }
   SDUMC_CHECK_LAUNCH();
-  const size_t total = (size_t)p.V * p.nq * D;
+  const size_t total = (size_t)p.V * p.nq * DD;
   hipLaunchKernelGGL(dq_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, b.workspace, b.dq,
-                     nchunk, p.nq * D, total);
+                     nchunk, p.nq * DD, total);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
 }

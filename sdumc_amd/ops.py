@@ -68,8 +68,9 @@ def gemm(layout, A, B, M, N, K, bias=None, C_out=None, lda=None, ldb=None, ldc=N
     return Cs if isinstance(A, (list, tuple)) else Cs[0]
 
 
-def attnpool_desc(x, keys, q, V, T, nq, x_samples, q_stride, x_drop, out_drop, attn, pooled, out, scale=0.3):
+def attnpool_desc(x, keys, q, V, T, nq, x_samples, q_stride, x_drop, out_drop, attn, pooled, out, scale=0.3, dim=0):
     a = _lib.AttnPool()
+    a.dim = dim
     a.V, a.T, a.nq, a.x_samples = V, T, nq, x_samples
     a.x, a.keys, a.q, a.q_stride, a.scale = ptr(x), ptr(keys), ptr(q), q_stride, scale
     if x_drop is not None:
@@ -99,10 +100,11 @@ def attnpool_bwd(desc, dout, keep):
     """desc: the AttnPool returned by attnpool_fwd; keep: tensors that must stay alive."""
     V, T, nq = desc.V, desc.T, desc.nq
     dev = dout.device
-    dz = torch.empty(V, T, _lib.D, device=dev)
-    dxd = torch.empty(V, T, _lib.D, device=dev)
-    dq = torch.empty(V, nq, _lib.D, device=dev)
-    need = lib.sdumc_attnpool_bwd_workspace_bytes(V, T, nq)
+    Dm = desc.dim or _lib.D
+    dz = torch.empty(V, T, Dm, device=dev)
+    dxd = torch.empty(V, T, Dm, device=dev)
+    dq = torch.empty(V, nq, Dm, device=dev)
+    need = lib.sdumc_attnpool_bwd_workspace_bytes_dim(V, T, nq, Dm)
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
     b = _lib.AttnPoolBwd()
     b.f = desc

@@ -42,8 +42,9 @@ def test_state_dict_and_constructor_contract(blocks):
     fra = blocks.FRA2UTT_new(input_dim=256)
     assert sorted(fra.state_dict()) == ["attention_context_vector", "input_proj.bias", "input_proj.weight"]
     assert tuple(fra.attention_context_vector.shape) == (1, 256) and ca.softmax_scale == 0.3
+    assert tuple(blocks.Cross_Attention().query_proj.weight.shape) == (1024, 1024)   # the reference default input_dim
     with pytest.raises(NotImplementedError):
-        blocks.Cross_Attention()          # the reference default input_dim=1024 is not built
+        blocks.Cross_Attention(input_dim=300)     # only multiples of 256 up to 1024 are built
     from sdumc_amd._lib import SdumcError
     with pytest.raises(SdumcError):
         ca(torch.randn(2, 7, 256), torch.randn(2, 5, 256))     # CPU tensors: no fallback
@@ -112,3 +113,42 @@ def test_blocks_backward_vs_oracle(blocks, golden, train):
     close(ca.query_proj.bias.grad, P["cross_att_fra2utt_2.query_proj.bias"].grad, 1e-4, "ca dbq")
     close(ca.input_proj.weight.grad, P["cross_att_fra2utt_2.input_proj.weight"].grad, 1e-4, "ca dWi")
     close(ca.input_proj.bias.grad, P["cross_att_fra2utt_2.input_proj.bias"].grad, 1e-4, "ca dbi")
+
+
+@pytest.mark.parametrize("Dm,train", [(512, True), (768, False), (1024, True)])
+def test_blocks_other_widths_vs_oracle(blocks, Dm, train):
+    """input_dim 512 / 768 / 1024 (the constructors' default; BASELINE configs[4]'s block-level variant with D = 1024):
+    forward, dropout masks and every gradient against the oracle in float64."""
+    from oracle import sdumc_oracle as O
+    torch.manual_seed(Dm)
+    fra = blocks.FRA2UTT_new(input_dim=Dm).cuda().train(train)
+    ca = blocks.Cross_Attention(input_dim=Dm).cuda().train(train)
+    gen = torch.Generator().manual_seed(Dm + 1)
+    B, Tn, nq = 3, 70, 7
+    x = torch.randn(B, Tn, Dm, generator=gen)
+    q = torch.randn(B, nq, Dm, generator=gen) / 8
+    R1, R2 = torch.randn(B, Dm, generator=gen), torch.randn(B, nq, Dm, generator=gen)
+    seed, call = 321, 4
+    P = {"fra2utt_0.attention_context_vector": fra.attention_context_vector, "fra2utt_0.input_proj.weight": fra.input_proj.weight,
+         "fra2utt_0.input_proj.bias": fra.input_proj.bias,
+         "cross_att_fra2utt_0.query_proj.weight": ca.query_proj.weight, "cross_att_fra2utt_0.query_proj.bias": ca.query_proj.bias,
+         "cross_att_fra2utt_0.input_proj.weight": ca.input_proj.weight, "cross_att_fra2utt_0.input_proj.bias": ca.input_proj.bias}
+    P = {k: v.detach().cpu().double().requires_grad_() for k, v in P.items()}
+    xo, qo = x.double().requires_grad_(), q.double().requires_grad_()
+    d = O.DropCtx("philox", seed, call) if train else O.DropCtx("eval")
+    o1, a1 = O.fra2utt(P, 0, xo, d)
+    o2, a2 = O.cross_attention(P, 0, qo, xo, d)
+    ((o1 * R1.double()).sum() + (o2 * R2.double()).sum()).backward()
+    xg, qg = x.cuda().requires_grad_(), q.cuda().requires_grad_()
+    blocks.manual_seed(seed, call, site=O.SITE_FRA_IN[0])
+    g1, b1 = fra(xg)
+    blocks.manual_seed(seed, call, site=O.SITE_CA_IN[0])
+    g2, b2 = ca(qg, xg)
+    close(g1, o1, what="fra out"); close(b1, a1, what="fra att"); close(g2, o2, what="ca out"); close(b2, a2, what="ca att")
+    if train:
+        assert torch.equal(g2.detach().cpu() == 0, o2.detach() == 0)     # output-dropout mask bit-exact
+    ((g1 * R1.cuda()).sum() + (g2 * R2.cuda()).sum()).backward()
+    close(xg.grad, xo.grad, 1e-4, "dx"); close(qg.grad, qo.grad, 1e-4, "dq")
+    for mod, pre in ((fra, "fra2utt_0."), (ca, "cross_att_fra2utt_0.")):
+        for k, v in mod.named_parameters():
+            close(v.grad, P[pre + k].grad, 1e-4, pre + k)
