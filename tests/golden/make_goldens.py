@@ -6,6 +6,7 @@ reference's own modules by path — never copies them — and records inputs and
 expected outputs as small .npz files:
 
   blocks.npz      FRA2UTT_new / Cross_Attention, eval and Philox-replayed train mode
+  blocks1024.npz  the same two blocks at the constructors' default input_dim = 1024 (weights re-drawn from a seed)
   forward.npz     full-model forward, both streams, eval and train(Philox) mode
   losses.npz      MSELoss / RMSELoss / RnCLoss (incl. tied labels) values + input grads
   step.npz        one full two-stream train step: loss, 6 terms, per-parameter gradient
@@ -139,6 +140,36 @@ def gen_blocks(ref_model, out):
               "ca64_bq": np32(ca2.query_proj.bias), "ca64_wi": np32(ca2.input_proj.weight),
               "ca64_bi": np32(ca2.input_proj.bias), "ca64_out": np32(o), "ca64_att": np32(a)})
     np.savez_compressed(os.path.join(out, "blocks.npz"), **d)
+
+
+def gen_blocks_1024(ref_model, out):
+    """The two attention blocks at their constructors' DEFAULT width (input_dim = 1024; model :47, :71).  The 1024x1024
+    weights are not stored: `torch.manual_seed(s); Block()` draws them, and a drop-in module constructed under the same
+    seed draws the same ones (same layers in the same order); digests pin the stream."""
+    d = {}
+    g = torch.Generator().manual_seed(99)
+    x = torch.randn(2, 9, 1024, generator=g)
+    q = torch.randn(2, 7, 1024, generator=g) / 8
+    torch.manual_seed(31)
+    fra = ref_model.FRA2UTT_new()
+    torch.manual_seed(32)
+    ca = ref_model.Cross_Attention()
+    d.update({"x": np32(x), "q": np32(q), "seed_fra": np.int64(31), "seed_ca": np.int64(32),
+              "fra_w_digest": digest(fra.input_proj.weight, "fra.w"), "fra_ctx_digest": digest(fra.attention_context_vector, "fra.ctx"),
+              "ca_wq_digest": digest(ca.query_proj.weight, "ca.wq"), "ca_wi_digest": digest(ca.input_proj.weight, "ca.wi")})
+    fra.eval(); ca.eval()
+    o, a = fra(x); d["fra_eval_out"], d["fra_eval_att"] = np32(o), np32(a)
+    o, a = ca(q, x); d["ca_eval_out"], d["ca_eval_att"] = np32(o), np32(a)
+    fra.train(); ca.train()
+    seed, call = 55, 2
+    with PhiloxDropout(seed, call, [O.SITE_FRA_IN[0], O.SITE_FRA_OUT[0]]):
+        o, a = fra(x)
+    d["fra_train_out"], d["fra_train_att"] = np32(o), np32(a)
+    with PhiloxDropout(seed, call, [O.SITE_CA_IN[0], O.SITE_CA_OUT[0]]):
+        o, a = ca(q, x)
+    d["ca_train_out"], d["ca_train_att"] = np32(o), np32(a)
+    d["seed"], d["call"] = np.int64(seed), np.int64(call)
+    np.savez_compressed(os.path.join(out, "blocks1024.npz"), **d)
 
 
 FWD_SITES = list(range(O.N_SITES))   # call order of one reference forward == site ids
@@ -465,6 +496,7 @@ def main():
     ref_model, ref_loss = load_reference()
     gen_init(ref_model, HERE)
     gen_blocks(ref_model, HERE)
+    gen_blocks_1024(ref_model, HERE)
     gen_forward(ref_model, HERE)
     gen_losses(ref_loss, HERE)
     gen_step(ref_model, ref_loss, HERE)

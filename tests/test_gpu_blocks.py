@@ -152,3 +152,36 @@ def test_blocks_other_widths_vs_oracle(blocks, Dm, train):
     for mod, pre in ((fra, "fra2utt_0."), (ca, "cross_att_fra2utt_0.")):
         for k, v in mod.named_parameters():
             close(v.grad, P[pre + k].grad, 1e-4, pre + k)
+
+
+def test_default_width_blocks_vs_reference_goldens(blocks, golden):
+    """input_dim = 1024, the reference constructors' default: outputs recorded from the REAL reference classes
+    (tests/golden/blocks1024.npz).  The weights are re-drawn: same seed + same constructor order = same init stream."""
+    from oracle import sdumc_oracle as O
+    from tests.golden.make_goldens import digest
+    g = golden("blocks1024")
+    torch.manual_seed(int(g["seed_fra"]))
+    fra = blocks.FRA2UTT_new()
+    torch.manual_seed(int(g["seed_ca"]))
+    ca = blocks.Cross_Attention()
+    np.testing.assert_allclose(digest(fra.input_proj.weight, "fra.w"), g["fra_w_digest"], rtol=1e-12)
+    np.testing.assert_allclose(digest(fra.attention_context_vector, "fra.ctx"), g["fra_ctx_digest"], rtol=1e-12)
+    np.testing.assert_allclose(digest(ca.query_proj.weight, "ca.wq"), g["ca_wq_digest"], rtol=1e-12)
+    np.testing.assert_allclose(digest(ca.input_proj.weight, "ca.wi"), g["ca_wi_digest"], rtol=1e-12)
+    fra, ca = fra.cuda(), ca.cuda()
+    x, q = T(g["x"]).cuda(), T(g["q"]).cuda()
+    with torch.no_grad():
+        fra.eval(); ca.eval()
+        o, a = fra(x)
+        close(o, g["fra_eval_out"], what="fra eval out"); close(a, g["fra_eval_att"], what="fra eval att")
+        o, a = ca(q, x)
+        close(o, g["ca_eval_out"], what="ca eval out"); close(a, g["ca_eval_att"], what="ca eval att")
+        fra.train(); ca.train()
+        seed, call = int(g["seed"]), int(g["call"])
+        blocks.manual_seed(seed, call, site=O.SITE_FRA_IN[0])
+        o, a = fra(x)
+        close(o, g["fra_train_out"], what="fra train out"); close(a, g["fra_train_att"], what="fra train att")
+        blocks.manual_seed(seed, call, site=O.SITE_CA_IN[0])
+        o, a = ca(q, x)
+        close(o, g["ca_train_out"], what="ca train out"); close(a, g["ca_train_att"], what="ca train att")
+        assert torch.equal(o.cpu() == 0, T(g["ca_train_out"]) == 0)

@@ -156,3 +156,34 @@ def test_collate_contract(golden):
             raw = g[f"raw_{name}_{b}"]
             np.testing.assert_array_equal(stacked[b, :len(raw)], raw)
             assert not stacked[b, len(raw):].any()
+
+
+def test_blocks_default_width_1024(golden):
+    """The oracle's block restatements at the reference constructors' default input_dim = 1024 against the real reference
+    (tests/golden/blocks1024.npz).  Weights are re-drawn from the recorded seeds through the drop-in constructors (same
+    layers, same order as the reference's), digests pin the stream."""
+    from sdumc_amd import blocks
+    from tests.golden.make_goldens import digest
+    g = golden("blocks1024")
+    torch.manual_seed(int(g["seed_fra"]))
+    fra = blocks.FRA2UTT_new()
+    torch.manual_seed(int(g["seed_ca"]))
+    ca = blocks.Cross_Attention()
+    np.testing.assert_allclose(digest(fra.input_proj.weight, "fra.w"), g["fra_w_digest"], rtol=1e-12)
+    np.testing.assert_allclose(digest(ca.input_proj.weight, "ca.wi"), g["ca_wi_digest"], rtol=1e-12)
+    P = {"fra2utt_0.attention_context_vector": fra.attention_context_vector.detach(),
+         "fra2utt_0.input_proj.weight": fra.input_proj.weight.detach(), "fra2utt_0.input_proj.bias": fra.input_proj.bias.detach(),
+         "cross_att_fra2utt_0.query_proj.weight": ca.query_proj.weight.detach(),
+         "cross_att_fra2utt_0.query_proj.bias": ca.query_proj.bias.detach(),
+         "cross_att_fra2utt_0.input_proj.weight": ca.input_proj.weight.detach(),
+         "cross_att_fra2utt_0.input_proj.bias": ca.input_proj.bias.detach()}
+    x, q = T(g["x"]), T(g["q"])
+    o, a = O.fra2utt(P, 0, x, O.DropCtx("eval"))
+    close(o, g["fra_eval_out"], 5e-6); close(a, g["fra_eval_att"], 5e-6)
+    o, a = O.cross_attention(P, 0, q, x, O.DropCtx("eval"))
+    close(o, g["ca_eval_out"], 5e-6); close(a, g["ca_eval_att"], 5e-6)
+    d = O.DropCtx("philox", int(g["seed"]), int(g["call"]))
+    o, a = O.fra2utt(P, 0, x, d)
+    close(o, g["fra_train_out"], 5e-6); close(a, g["fra_train_att"], 5e-6)
+    o, a = O.cross_attention(P, 0, q, x, d)
+    close(o, g["ca_train_out"], 5e-6); close(a, g["ca_train_att"], 5e-6)
