@@ -154,14 +154,16 @@ struct Stager {
   // the loaded values: anything that reads them here puts an s_waitcnt vmcnt right behind the load and the prefetch
   // stops overlapping the MFMAs of the current tile.  The dropout mask is applied by apply(), just before the tile
   // is written to LDS one iteration later.
-  template <bool MASK>
+  // FULL: every tile of the problem is a full tile (M, N multiples of the block tile, K of BK): no range predicates,
+  // i.e. no exec-mask save/restore around the loads
+  template <bool MASK, bool FULL>
   __device__ __forceinline__ void load(f32x4 (&reg)[P], uint32_t (&mb)[P], const TileLoadCtx& c, int kend) {
 #pragma unroll
     for (int j = 0; j < P; ++j) {
       const int kk = KC ? pos : pos + RP * j;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       uint32_t b = 0;
-      if (((ok >> j) & 1u) && kk < kend) {
+      if (FULL || (((ok >> j) & 1u) && kk < kend)) {
         v = *reinterpret_cast<const f32x4*>(c.p + off[j]);
         if (MASK) b = c.drop.bits[boff[j]];
       }
@@ -401,7 +403,8 @@ __global__ __launch_bounds__(256, (BM == 64 ? SDUMC_GEMM_WPE64 : 2)) void gemm_k
   float* const As = lds;
   float* const Bs = lds + A_ELEMS;
   auto k_loop = [&](auto fast_c, auto ma_c, auto mb_c, auto cs_c) {
-    constexpr bool FAST = decltype(fast_c)::value, MA = decltype(ma_c)::value, MB = decltype(mb_c)::value,
+    constexpr int FASTV = decltype(fast_c)::value;   // 0 generic loader, 1 hoisted addressing, 2 the same on full tiles only
+    constexpr bool FAST = FASTV > 0, FULL = FASTV == 2, MA = decltype(ma_c)::value, MB = decltype(mb_c)::value,
                    CS = decltype(cs_c)::value;
     Stager<BM, A_K> sa;
     Stager<BN, B_K> sb;
@@ -414,8 +417,8 @@ __global__ __launch_bounds__(256, (BM == 64 ? SDUMC_GEMM_WPE64 : 2)) void gemm_k
     // nothing reads the registers here: the loads stay in flight
     auto prefetch = [&](int k) {
       if constexpr (FAST) {
-        sa.template load<MA>(ra, ba, ca, kend);
-        sb.template load<MB>(rb, bb, cb, kend);
+        sa.template load<MA, FULL>(ra, ba, ca, kend);
+        sb.template load<MB, FULL>(rb, bb, cb, kend);
       } else {
         load_tile<BM, A_K>(ra, ca, m0, g.M, k, kend, tid);
         load_tile<BN, B_K>(rb, cb, n0, g.N, k, kend, tid);
@@ -441,20 +444,24 @@ __global__ __launch_bounds__(256, (BM == 64 ? SDUMC_GEMM_WPE64 : 2)) void gemm_k
   {
     using T = std::true_type;
     using F = std::false_type;
+    using G0 = std::integral_constant<int, 0>;
+    using F1 = std::integral_constant<int, 1>;
+    using F2 = std::integral_constant<int, 2>;
+    const bool full = (g.M % BM) == 0 && (g.N % BN) == 0 && (g.K % BK) == 0;   // then every k-range is whole k-tiles too
     if constexpr (A_K) {          // NT / NN: optional mask on A
-      if (!fast) k_loop(F{}, F{}, F{}, F{});
-      else if (mask_a) k_loop(T{}, T{}, F{}, F{});
-      else k_loop(T{}, F{}, F{}, F{});
+      if (!fast) k_loop(G0{}, F{}, F{}, F{});
+      else if (mask_a) { if (full) k_loop(F2{}, T{}, F{}, F{}); else k_loop(F1{}, T{}, F{}, F{}); }
+      else { if (full) k_loop(F2{}, F{}, F{}, F{}); else k_loop(F1{}, F{}, F{}, F{}); }
     } else {                      // TN: optional mask on B, optional column sums of A
       if (!fast) {
-        if (do_cs) k_loop(F{}, F{}, F{}, T{});
-        else k_loop(F{}, F{}, F{}, F{});
-      } else if (mask_b) {
-        if (do_cs) k_loop(T{}, F{}, T{}, T{});
-        else k_loop(T{}, F{}, T{}, F{});
+        if (do_cs) k_loop(G0{}, F{}, F{}, T{});
+        else k_loop(G0{}, F{}, F{}, F{});
+      } else if (full) {
+        if (mask_b) { if (do_cs) k_loop(F2{}, F{}, T{}, T{}); else k_loop(F2{}, F{}, T{}, F{}); }
+        else { if (do_cs) k_loop(F2{}, F{}, F{}, T{}); else k_loop(F2{}, F{}, F{}, F{}); }
       } else {
-        if (do_cs) k_loop(T{}, F{}, F{}, T{});
-        else k_loop(T{}, F{}, F{}, F{});
+        if (mask_b) { if (do_cs) k_loop(F1{}, F{}, T{}, T{}); else k_loop(F1{}, F{}, T{}, F{}); }
+        else { if (do_cs) k_loop(F1{}, F{}, F{}, T{}); else k_loop(F1{}, F{}, F{}, F{}); }
       }
     }
   }
