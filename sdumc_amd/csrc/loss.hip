@@ -157,8 +157,9 @@ __global__ __launch_bounds__(256) void rnc_row_kernel(const float* f, const floa
     }
     const float t = thr[k];
     float dsum = 0.f;
-    for (int j = 0; j < n; ++j)
-      if (j != i && ld[j] >= t) dsum += ee[j];
+#pragma unroll 8
+    for (int j = 0; j < n; ++j)      // unrolled: the LDS reads of 8 iterations are in flight together (same summation order)
+      dsum += (j != i && ld[j] >= t) ? ee[j] : 0.f;
     iD[k] = 1.f / dsum;
     acc += (-dd[k] * inv_t - mx) - logf(dsum);
   }
@@ -172,9 +173,201 @@ __global__ __launch_bounds__(256) void rnc_row_kernel(const float* f, const floa
     if (j != i) {
       const float lj = ld[j];
       float sum = 0.f;
+#pragma unroll 8
       for (int k = 0; k < n; ++k)
-        if (k != i && lj >= thr[k]) sum += iD[k];
+        sum += (k != i && lj >= thr[k]) ? iD[k] : 0.f;
       g = -c * (1.f - ee[j] * sum);
+    }
+    w.G[(size_t)i * n + j] = g;
+  }
+}
+
+// ---- O(n^2 log n) formulation (n <= 2048) ---------------------------------------------------------------------
+// For anchor i the reference's neg_mask row for k, {j : |y_i - y_j| >= |y_i - y_k| - 1e-4} (loss.py:303), is the
+// complement of a window around i in the order of the labels: with the labels sorted ONCE (rnc_sort_kernel) it is a
+// prefix [0, L) plus a suffix [U, n) of the sorted order, and the gradient's {k : |y_i - y_k| - 1e-4 <= |y_i - y_j|}
+// is a window [A, B] around i.  Prefix / suffix sums of exp(logit) and window sums of 1/D then replace the two
+// O(n^2) loops per anchor of rnc_row_kernel; L, U, A, B come from binary searches that evaluate the SAME fp32
+// predicate as the reference on the probed elements (fabsf(y_i - y_j) >= fsub(|y_i - y_k|, 1e-4f): monotone on either
+// side of i), so set membership stays bit-exact.  All partial sums are sums of non-negative terms taken outward from
+// the ends / from i (no prefix differences -> no cancellation), in a fixed order.
+// At n = 128 (one GPU, B = 64) this is on par with the direct loops; at n = 1024 (B_global = 512 under data
+// parallelism, where EVERY rank evaluates the full loss) it is 0.67 ms -> tens of microseconds per step.
+// sorted order of the labels by counting: rank[j] = #{k : y_k < y_j or (y_k == y_j and k < j)} (ties by index: a
+// total, deterministic order), perm = rank^-1.  n threads x n comparisons from LDS: a few microseconds at n = 1024.
+__global__ __launch_bounds__(256) void rnc_sort_kernel(const float* labels, int label_mod, int n, int* perm, int* rank) {
+  extern __shared__ float ysm[];   // [n]
+  for (int t = threadIdx.x; t < n; t += 256) ysm[t] = labels[label_mod > 0 ? t % label_mod : t];
+  __syncthreads();
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const float yj = ysm[j];
+  int r = 0;
+#pragma unroll 8
+  for (int k = 0; k < n; ++k) {
+    const float yk = ysm[k];
+    r += (yk < yj || (yk == yj && k < j)) ? 1 : 0;
+  }
+  rank[j] = r;
+  perm[r] = j;
+}
+
+// inclusive scan of a[0..n) in LDS with 256 threads (reverse: suffix sums), fixed order; tmp: >= 4 floats
+__device__ __forceinline__ void block_scan(float* a, int n, bool reverse, float* tmp) {
+  const int per = (n + 255) / 256;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int lo = t * per, hi = min(n, lo + per);
+  float s = 0.f;
+  for (int p = lo; p < hi; ++p) s += a[reverse ? n - 1 - p : p];
+  // exclusive scan of the 256 per-thread partials: shuffles inside a wave, then the four wave totals
+  float incl = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const float v = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += v;
+  }
+  __syncthreads();                 // tmp may still be read by a previous scan
+  if (lane == 63) tmp[wave] = incl;
+  __syncthreads();
+  float run = incl - s;
+  for (int w2 = 0; w2 < wave; ++w2) run += tmp[w2];
+  for (int p = lo; p < hi; ++p) {
+    const int q = reverse ? n - 1 - p : p;
+    run += a[q];
+    a[q] = run;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void rnc_row_sorted_kernel(const float* f, const float* labels, int label_mod, int n, int dim,
+                                                             float inv_t, RncWs w, const int* perm, const int* rank,
+                                                             int want_grad) {
+  extern __shared__ float sm[];   // fi[dim4] | ys[n] | dd[n] | ee[n] | pre[n] | suf[n] | iD[n] | oL[n] | oR[n] | tmp[8]
+  __shared__ float red[4];
+  const int dim4 = (dim + 3) & ~3;
+  float* fi = sm;
+  float* ys = fi + dim4;
+  float* dd = ys + n;
+  float* ee = dd + n;
+  float* pre = ee + n;
+  float* suf = pre + n;
+  float* iD = suf + n;
+  float* oL = iD + n;
+  float* oR = oL + n;
+  float* tmp = oR + n;
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const int pos_i = rank[i];
+  for (int c = tid; c < dim; c += 256) fi[c] = f[(size_t)i * dim + c];
+  for (int r = tid; r < n; r += 256) {
+    const int j = perm[r];
+    ys[r] = labels[label_mod > 0 ? j % label_mod : j];
+  }
+  __syncthreads();
+  const float yi = ys[pos_i];
+  const bool vec = (dim & 3) == 0 && (reinterpret_cast<uintptr_t>(f) & 15) == 0;
+  float mx = -INFINITY;
+  for (int r = tid; r < n; r += 256) {
+    const int j = perm[r];
+    float s = 0.f;
+    if (vec) {
+      const f32x4* fj = reinterpret_cast<const f32x4*>(f + (size_t)j * dim);
+      for (int c0 = 0; c0 < dim / 4; c0 += 8) {
+        f32x4 rr[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rr[u] = c0 + u < dim / 4 ? fj[c0 + u] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+          if (c0 + u < dim / 4) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float d = fi[4 * (c0 + u) + e] - rr[u][e];
+              s += d * d;
+            }
+          }
+      }
+    } else {
+      for (int c = 0; c < dim; ++c) {
+        const float d = fi[c] - f[(size_t)j * dim + c];
+        s += d * d;
+      }
+    }
+    const float dist = sqrtf(s);
+    dd[r] = dist;
+    w.dist[(size_t)i * n + j] = dist;
+    mx = fmaxf(mx, -dist * inv_t);
+  }
+  mx = wave_max(mx);
+  if ((tid & 63) == 0) red[tid >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  for (int r = tid; r < n; r += 256) {
+    const float e = r == pos_i ? 0.f : expf(-dd[r] * inv_t - mx);   // the anchor itself is excluded (diagonal removal, loss.py:294-296)
+    ee[r] = e;
+    pre[r] = e;
+    suf[r] = e;
+  }
+  __syncthreads();
+  block_scan(pre, n, false, tmp);   // pre[r] = sum_{p <= r} ee[p]
+  block_scan(suf, n, true, tmp);    // suf[r] = sum_{p >= r} ee[p]
+  float acc = 0.f;
+  for (int r = tid; r < n; r += 256) {
+    float inv = 0.f;
+    if (r != pos_i) {
+      const float t = __fsub_rn(fabsf(yi - ys[r]), 0.0001f);
+      // L = number of p in [0, pos_i] with fabsf(yi - ys[p]) >= t (true ... true false ... false)
+      int lo = 0, hi = pos_i + 1;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (fabsf(yi - ys[mid]) >= t) lo = mid + 1; else hi = mid;
+      }
+      const int L = lo;
+      // U = first p in [pos_i, n) with fabsf(yi - ys[p]) >= t (false ... false true ... true)
+      lo = pos_i;
+      hi = n;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (fabsf(yi - ys[mid]) >= t) hi = mid; else lo = mid + 1;
+      }
+      const int U = lo;
+      const float dsum = (L > 0 ? pre[L - 1] : 0.f) + (U < n ? suf[U] : 0.f);
+      inv = 1.f / dsum;
+      acc += (-dd[r] * inv_t - mx) - logf(dsum);
+    }
+    iD[r] = inv;
+  }
+  const float sl = block_sum_256(acc, red);
+  if (tid == 0) w.rowloss[i] = sl;
+  if (!want_grad) return;
+  __syncthreads();
+  for (int r = tid; r < n; r += 256) {
+    oL[r] = r <= pos_i ? iD[r] : 0.f;
+    oR[r] = r >= pos_i ? iD[r] : 0.f;
+  }
+  __syncthreads();
+  block_scan(oL, n, true, tmp);     // oL[p] = sum_{q = p .. pos_i} iD[q]   (p <= pos_i)
+  block_scan(oR, n, false, tmp);    // oR[p] = sum_{q = pos_i .. p} iD[q]   (p >= pos_i)
+  const float c = 1.f / ((float)n * (float)(n - 1));
+  for (int r = tid; r < n; r += 256) {
+    const int j = perm[r];
+    float g = 0.f;
+    if (r != pos_i) {
+      const float lj = fabsf(yi - ys[r]);
+      // A = first p in [0, pos_i] with thr(p) <= lj  (thr non-increasing towards pos_i: false ... false true ... true)
+      int lo = 0, hi = pos_i;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (lj >= __fsub_rn(fabsf(yi - ys[mid]), 0.0001f)) hi = mid; else lo = mid + 1;
+      }
+      const int A = lo;
+      // B = last p in [pos_i, n) with thr(p) <= lj  (true ... true false ... false)
+      lo = pos_i;
+      hi = n - 1;
+      while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (lj >= __fsub_rn(fabsf(yi - ys[mid]), 0.0001f)) lo = mid; else hi = mid - 1;
+      }
+      const int B = lo;
+      g = -c * (1.f - ee[r] * (oL[A] + oR[B]));   // iD[pos_i] = 0: counting it on both sides is harmless
     }
     w.G[(size_t)i * n + j] = g;
   }
@@ -198,7 +391,15 @@ __global__ __launch_bounds__(256) void rnc_dfeat_kernel(const float* f, int n, i
     float acc = 0.f;
     if (c < dim) {
       const float fic = f[(size_t)i * dim + c];
-      for (int j = part; j < n; j += 4) acc += coef[j] * (fic - f[(size_t)j * dim + c]);
+      int j = part;
+      for (; j + 28 < n; j += 32) {   // 8 rows of loads in flight (same summation order as the plain loop)
+        float fj[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) fj[u] = f[(size_t)(j + 4 * u) * dim + c];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += coef[j + 4 * u] * (fic - fj[u]);
+      }
+      for (; j < n; j += 4) acc += coef[j] * (fic - f[(size_t)j * dim + c]);
     }
     red[part * 64 + lane] = acc;
     __syncthreads();
@@ -350,10 +551,28 @@ static int rnc_impl(const float* feats, const float* labels, int label_mod, int3
   const RncWs w = rnc_ws(workspace, n);
   const float inv_t = 1.f / temperature;
   const int want_grad = dfeats && rows_local > 0;
-  const size_t lds = (((size_t)dim + 3) & ~(size_t)3) * sizeof(float) + 5 * (size_t)n * sizeof(float);
-  if (lds > 64 * 1024) return SDUMC_EINVAL;
-  hipLaunchKernelGGL(rnc_row_kernel, dim3(n), dim3(256), lds, st, feats, labels, label_mod, n, dim, inv_t, w, want_grad);
-  SDUMC_CHECK_LAUNCH();
+  if (n > 256 && n <= 2048) {
+    // sorted formulation; perm / rank live in the (otherwise unused) `e` region of the workspace
+    int* perm = reinterpret_cast<int*>(w.e);
+    int* rank = perm + n;
+    hipLaunchKernelGGL(rnc_sort_kernel, dim3((n + 255) / 256), dim3(256), (size_t)n * sizeof(float), st, labels, label_mod, n,
+                       perm, rank);
+    SDUMC_CHECK_LAUNCH();
+    const size_t lds = ((((size_t)dim + 3) & ~(size_t)3) + 8 * (size_t)n + 8) * sizeof(float);
+    if (lds > 160 * 1024) return SDUMC_EINVAL;
+    if (lds > 48 * 1024 &&
+        hipFuncSetAttribute(reinterpret_cast<const void*>(rnc_row_sorted_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess)
+      return SDUMC_ELAUNCH;
+    hipLaunchKernelGGL(rnc_row_sorted_kernel, dim3(n), dim3(256), lds, st, feats, labels, label_mod, n, dim, inv_t, w, perm,
+                       rank, want_grad);
+    SDUMC_CHECK_LAUNCH();
+  } else {
+    const size_t lds = (((size_t)dim + 3) & ~(size_t)3) * sizeof(float) + 5 * (size_t)n * sizeof(float);
+    if (lds > 64 * 1024) return SDUMC_EINVAL;
+    hipLaunchKernelGGL(rnc_row_kernel, dim3(n), dim3(256), lds, st, feats, labels, label_mod, n, dim, inv_t, w, want_grad);
+    SDUMC_CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(rnc_loss_kernel, dim3(1), dim3(256), 0, st, n, w, loss_out);
   SDUMC_CHECK_LAUNCH();
   if (want_grad) {

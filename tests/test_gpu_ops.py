@@ -275,6 +275,25 @@ def test_rnc_large_matches_oracle(ops):
                                   O.rnc_masks(y.repeat(2, 1)).numpy())
 
 
+@pytest.mark.parametrize("B,decimals", [(150, 1), (384, 0), (512, 3)])
+def test_rnc_sorted_formulation_matches_oracle(ops, B, decimals):
+    """n = 2B > 256 rows takes the O(n^2 log n) sorted formulation (what every rank of a data-parallel job evaluates:
+    B_global = 512 at BASELINE configs[3]); loss and gradient against the oracle's literal restatement of the
+    reference, with many tied labels (decimals 0: only 7 distinct values) and with almost none."""
+    from oracle import sdumc_oracle as O
+    g = torch.Generator().manual_seed(B + decimals)
+    f = torch.randn(B, 2, 64, generator=g).double().requires_grad_()
+    y = (torch.rand(B, 1, generator=g) * 6 - 3).round(decimals=decimals)
+    l = O.rnc_loss(f, y.double())
+    l.backward()
+    feats = dev(torch.cat([f[:, 0], f[:, 1]], dim=0).detach().float())
+    loss, df, _ = ops.rnc_fwd_bwd(feats, dev(y.repeat(2, 1).reshape(-1)), weight=0.8)
+    close(loss, l.detach().reshape(1), 2e-5)
+    ref = 0.8 * torch.cat([f.grad[:, 0], f.grad[:, 1]])
+    scale = float(ref.abs().max())
+    assert float((df.cpu().double() - ref).abs().max()) <= 1e-3 * scale
+
+
 def test_adam_matches_torch(ops):
     g = torch.Generator().manual_seed(4)
     n = 10007
