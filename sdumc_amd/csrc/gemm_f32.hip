@@ -45,6 +45,9 @@ const char* const kVariantName[kNumVariants] = {"gemm_nt_128x128", "gemm_nt_64x6
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;
+#ifndef SDUMC_GEMM_WPE128
+#define SDUMC_GEMM_WPE128 2
+#endif
 #ifndef SDUMC_GEMM_WPE64
 #define SDUMC_GEMM_WPE64 5   // waves per SIMD the 64x64 variants are register-allocated for (96 VGPRs, 1-2 spilled outside the k-loop): 2.197 vs 2.214 ms per step against 4
 #endif
@@ -247,7 +250,7 @@ typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int LDH = BK + 8;   // bf16 elements per LDS row (80 B): the 16-B fragment reads are conflict-free
 
 template <int BM, int BN, bool A_K, bool B_K, bool BF16 = false>
-__global__ __launch_bounds__(256, (BM == 64 ? SDUMC_GEMM_WPE64 : 2)) void gemm_kernel(const sdumc_gemm g, const int nsplit, const int kchunk) {
+__global__ __launch_bounds__(256, (BM == 64 ? SDUMC_GEMM_WPE64 : SDUMC_GEMM_WPE128)) void gemm_kernel(const sdumc_gemm g, const int nsplit, const int kchunk) {
   static_assert(!BF16 || (A_K && B_K), "the bf16 variant is built for the NT layout");
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int A_ELEMS = A_K ? BM * LDK : BK * BM;
