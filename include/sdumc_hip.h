@@ -94,7 +94,7 @@ typedef struct sdumc_gemm {
   int32_t accumulate;   /* C += result (requires act none, no c_drop, no bias) */
   int32_t splitk;       /* 0: auto (tile + split chosen to fill 256 CUs); 1: no split; >1: K split over workgroups.
                            Split results go through fp32 slabs in `workspace` and an ordered, deterministic reduce */
-  int32_t tile;         /* 0 auto, 1 = 128x128, 2 = 64x64, 3 = small-problem kernel (32x32 tile, the four waves split K;
+  int32_t tile;         /* 0 auto, 1 = 128x128, 2 = 64x64, 4 = 128x64, 3 = small-problem kernel (32x32 tile, the four waves split K;
                            for the launch-bound utterance-level layers; no operand-side fusions) */
   int32_t ab_drop_group_stride; /* group g draws a_drop / b_drop from site + g * stride ... */
   const uint8_t* ab_drop_bits[SDUMC_MAX_GROUPS]; /* ... or from these per-group keep-bits (NULL: a_drop.bits / b_drop.bits) */

@@ -715,7 +715,7 @@ GemmPlan plan_gemm(const sdumc_gemm& g, size_t ws_bytes) {
   } else if (g.splitk >= 1) {                            // explicit
     s = std::min(g.splitk, ktiles);
   } else {                                               // auto
-    const long tiles = p.tile == 1 ? big : small;
+    const long tiles = p.tile == 1 ? big : p.tile == 4 ? (long)((g.M + 127) / 128) * ((g.N + 63) / 64) * g.groups : small;
     const long want = p.tile == 1 ? 512 : 1024;
     const long smax = std::max(1, ktiles / 6);
     s = (int)std::min<long>(smax, want / tiles);   // floor: 900 tiles stay unsplit, 128 tiles split 8 ways
@@ -810,7 +810,8 @@ extern "C" int sdumc_gemm_f32(const sdumc_gemm* gp, void* stream) {
       }
     }
   } else {
-    rc = tile == 1 ? launch<128, 128>(g, nsplit, kchunk, st) : launch<64, 64>(g, nsplit, kchunk, st);
+    rc = tile == 1 ? launch<128, 128>(g, nsplit, kchunk, st)
+         : tile == 4 ? launch<128, 64>(g, nsplit, kchunk, st) : launch<64, 64>(g, nsplit, kchunk, st);
   }
   if (rc != SDUMC_OK) return rc;
   SDUMC_CHECK_LAUNCH();
