@@ -696,6 +696,8 @@ GemmPlan plan_gemm(const sdumc_gemm& g, size_t ws_bytes) {
   // 128x128 tiles (tools/gemm_tile_choice.py: 103 vs 93, 128 vs 117, 124 vs 114 TF); this path's N = 256 shapes stay on 64x64
   const bool wide = std::min(g.M, g.N) >= 1024 && (long)g.M * g.N >= 4096L * 1024L;
   p.tile = g.tile ? g.tile : ((small >= 8192 || wide) ? 1 : 2);
+  // (128x64 tiles, tile = 4, are +4-6 % on the K >= 1024 frame projections in isolation but cost 2 % of the step under
+  // the three-lane schedule: 2.199 vs 2.157 ms -- not selected automatically)
   {   // launch-bound problems: at most 768 tiles of 32x32, K <= 1024, no operand-side fusions, no explicit split
     const long t32 = (long)((g.M + 31) / 32) * ((g.N + 31) / 32) * g.groups;
     const bool plain = !g.a_drop.enabled && !g.b_drop.enabled && g.a_row_mod == 0 && g.b_row_mod == 0;

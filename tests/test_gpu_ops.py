@@ -52,7 +52,8 @@ def test_dropout_mask_bit_exact(ops):
 
 
 @pytest.mark.parametrize("M,N,K,tile", [(128, 256, 256, 0), (300, 256, 1024, 1), (77, 3, 256, 2), (64, 7, 128, 0),
-                                        (513, 130, 96, 1), (2048, 256, 4096, 0), (5, 1, 128, 0)])
+                                        (513, 130, 96, 1), (2048, 256, 4096, 0), (5, 1, 128, 0), (300, 256, 1024, 4),
+                                        (129, 65, 40, 4), (16384, 256, 1024, 0)])
 def test_gemm_nt_bias_act(ops, M, N, K, tile):
     g = torch.Generator().manual_seed(M * 7 + N)
     A, W, b = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g)
@@ -85,7 +86,7 @@ def test_gemm_nn_tn_accumulate_splitk(ops):
     close(acc, ref + 1, 2e-5)
     # fused column sums of A (the bias gradient), every split mode incl. auto (0), with accumulate
     for sk in (0, 1, 6):
-        for tile in (1, 2):
+        for tile in (1, 2, 4):
             cs = dev(torch.full((Mo,), 2.0))
             acc = dev(torch.ones(Mo, Ni))
             ops.gemm(ops.TN, dev(dY), dev(X), Mo, Ni, R, C_out=acc, splitk=sk, tile=tile, accumulate=True, colsum_a=cs)
