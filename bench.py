@@ -153,8 +153,8 @@ def main():
                     help="issue the Cross_Attention-site key-projection GEMMs on a fourth stream beside the utterance-level "
                          "chain instead of grouped with the FRA2UTT ones (A/B switch; measured +0.8 %% per step)")
     ap.add_argument("--bf16", action="store_true",
-                    help="BASELINE configs[2] arithmetic: bf16 operands (fp32 accumulate) in the frame-level forward "
-                         "projections; NOT the default workload (configs[1] is fp32)")
+                    help="BASELINE configs[2] arithmetic: bf16 operands (fp32 accumulate) in the frame-level projections, "
+                         "forward and backward; NOT the default workload (configs[1] is fp32)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -231,7 +231,7 @@ def main():
         "metric": "train samples/sec at MOSEI feature shapes (two-stream forward + 6-term loss + backward + Adam)",
         "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16 operands / f32 accumulate in the frame-level forward projections, f32 elsewhere" if args.bf16 else "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "bf16 operands / f32 accumulate in the frame-level projections (forward, dW, dX), f32 elsewhere" if args.bf16 else "f32", "data": "synthetic",
         "config": {"workload": ("BASELINE configs[2] arithmetic (--bf16) on the configs[1] shapes: " if args.bf16 else "") + "BASELINE configs[1]: CMU-MOSEI-shaped features, batch=64 per GPU, fp32, both streams "
                                "(text + text-missing/feat4) with self-distillation",
                    "batch_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU,

@@ -104,8 +104,9 @@ typedef struct sdumc_gemm {
   float c_mask_scale;
   float* colsum_a[SDUMC_MAX_GROUPS]; /* TN only, optional: out[m] (+)= sum_k A[k,m] fused into the staging of A
                            (the bias gradient when A = dz); `accumulate` applies to it too */
-  int32_t bf16;         /* 1: NT only -- operands rounded to bf16 while staged, v_mfma_f32_32x32x16_bf16, fp32 accumulate
-                           and fp32 epilogue (the "bf16 compute" mode, BASELINE configs[2]); 0: exact fp32 (default) */
+  int32_t bf16;         /* 1: operands rounded to bf16 while staged (row-contiguous ones transposed by their LDS stores),
+                           v_mfma_f32_32x32x16_bf16, fp32 accumulate and fp32 epilogue / column sums (the "bf16 compute" mode,
+                           BASELINE configs[2]; 64x64 and 128x128 tiles, channel extents multiples of 4); 0: exact fp32 (default) */
   float* workspace;
   size_t workspace_bytes;
   int32_t batch;        /* >1: strided-batched mode -- every group is `batch` products of one shape, entry z reads
@@ -451,10 +452,11 @@ typedef struct sdumc_net_dims {
   int32_t sample0;  /* global index of local sample 0 (data-parallel shard offset) */
   double p_frame;   /* 0.5: nn.Dropout inside FRA2UTT_new / Cross_Attention (model :54,:77) */
   double p_mlp;     /* 0.3: constructor default dropout (model :187) */
-  int32_t bf16;     /* 0 (default): exact fp32 everywhere.  1: the frame-level forward projections (frame_dim_reshape_*,
-                       model :282-284, and the input_proj keys of FRA2UTT_new / Cross_Attention, model :60,:82) round
-                       their operands to bf16 and multiply on v_mfma_f32_32x32x16_bf16 with fp32 accumulation -- the
-                       "bf16" configs of BASELINE.json; everything else, the whole backward included, stays fp32 */
+  int32_t bf16;     /* 0 (default): exact fp32 everywhere.  1: the frame-level projections (frame_dim_reshape_*,
+                       model :282-284, and the input_proj keys of FRA2UTT_new / Cross_Attention, model :60,:82), forward
+                       and backward (dW, dX), round their operands to bf16 and multiply on v_mfma_f32_32x32x16_bf16 with
+                       fp32 accumulation -- the "bf16" configs of BASELINE.json; the utterance-level layers, the
+                       attention pooling, the losses and Adam stay fp32 */
 } sdumc_net_dims;
 
 typedef struct sdumc_net_io {

@@ -838,6 +838,7 @@ int keys_gemm_bwd(const Ctx& c, int m, int k0, int k1) {
     g.b_drop = in_drop(c, k0, m, sg.T, sg.s0, sg.row0);
     g.ab_drop_group_stride = SITE_IN[1][m] - SITE_IN[0][m];
     g.accumulate = first ? 0 : 1;
+    g.bf16 = c.d.bf16 ? 1 : 0;
     RET(run(c, g));
     first = false;
   }
@@ -851,6 +852,7 @@ int keys_gemm_bwd(const Ctx& c, int m, int k0, int k1) {
   }
   g.lda = g.ldb = g.ldc = D;
   g.accumulate = 1;
+  g.bf16 = c.d.bf16 ? 1 : 0;
   return run(c, g);
 }
 
@@ -1000,6 +1002,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
       g.ldc = din[m];
       g.colsum_a[0] = c.G + pm.frame[m].b;
       g.accumulate = s > 0;
+      g.bf16 = c.d.bf16 && (din[m] % 4 == 0) ? 1 : 0;
       RET(run(c, g));
     }
   }

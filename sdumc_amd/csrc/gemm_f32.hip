@@ -37,11 +37,13 @@ struct ProfRec {
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::mutex g_prof_mu;
-constexpr int kNumVariants = 11;
+constexpr int kNumVariants = 15;
 const char* const kVariantName[kNumVariants] = {"gemm_nt_128x128", "gemm_nt_64x64",  "gemm_nn_128x128",
                                                 "gemm_nn_64x64",   "gemm_tn_128x128", "gemm_tn_64x64",
                                                 "gemm_small_nt",   "gemm_small_nn",   "gemm_small_tn",
-                                                "gemm_bf16_nt_128x128", "gemm_bf16_nt_64x64"};
+                                                "gemm_bf16_nt_128x128", "gemm_bf16_nt_64x64",
+                                                "gemm_bf16_nn_128x128", "gemm_bf16_nn_64x64",
+                                                "gemm_bf16_tn_128x128", "gemm_bf16_tn_64x64"};
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;
@@ -109,10 +111,13 @@ __device__ __forceinline__ void load_tile(f32x4 (&reg)[BR / 32], const TileLoadC
 // constant per k-tile.  The generic load_tile above costs ~25 VALU instructions per 16-byte load (64-bit
 // multiply-adds, bounds, an integer modulo for the shared-x mapping); with 4-5 waves per SIMD that filled the
 // vector-issue slots beside the MFMAs (SQ counters: 6.4 VALU per MFMA).
-template <int BR, bool KC>
+// PAIRK (row-contiguous operands only): the thread's P loads are k-consecutive rows (k = P (tid / Q) + j) instead of RP
+// apart, so that the bf16 variant can store k-pairs / k-quads of one row with one LDS write
+template <int BR, bool KC, bool PAIRK = false>
 struct Stager {
   static constexpr int P = BR / 32;
   static constexpr int Q = BR / 4, RP = 256 / Q;
+  static constexpr int KSTEP = PAIRK ? 1 : RP;   // k distance between consecutive loads of one thread
   uint32_t off[P];    // element offset of this thread's next 16 bytes
   uint32_t boff[P];   // byte offset of the matching keep-bits
   int src[P];         // !KC with row_mod: current source row (to wrap)
@@ -138,12 +143,12 @@ struct Stager {
       step = BK;
       wrap = 0;
     } else {
-      pos = kbeg + tid / Q;
+      pos = kbeg + (PAIRK ? P * (tid / Q) : tid / Q);
       vrow0 = r0 + 4 * (tid % Q);
       if (vrow0 < R) ok = (1u << P) - 1;
 #pragma unroll
       for (int j = 0; j < P; ++j) {
-        const int row = pos + RP * j;
+        const int row = pos + KSTEP * j;
         src[j] = c.row_mod > 0 ? row % c.row_mod : row;
         off[j] = (uint32_t)src[j] * (uint32_t)c.ld + (uint32_t)vrow0;
         boff[j] = (uint32_t)row * c.drop.qwidth + (uint32_t)(vrow0 >> 2);
@@ -163,7 +168,7 @@ struct Stager {
   __device__ __forceinline__ void load(f32x4 (&reg)[P], uint32_t (&mb)[P], const TileLoadCtx& c, int kend) {
 #pragma unroll
     for (int j = 0; j < P; ++j) {
-      const int kk = KC ? pos : pos + RP * j;
+      const int kk = KC ? pos : pos + KSTEP * j;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       uint32_t b = 0;
       if (FULL || (((ok >> j) & 1u) && kk < kend)) {
@@ -242,16 +247,55 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   return v;
 }
 
-// BF16 = true (NT layout only): the staged operands are rounded to bf16 (v_cvt_pk_bf16_f32, RNE) on their way into
-// LDS and multiplied on v_mfma_f32_32x32x16_bf16 -- 16x the fp32 MFMA rate -- with fp32 accumulation and the same
+// BF16 = true: the staged operands are rounded to bf16 (v_cvt_pk_bf16_f32, RNE) on their way into LDS -- always as
+// [row][k], so row-contiguous operands (NN's B, TN's A and B) are transposed by their LDS stores -- and multiplied on
+// v_mfma_f32_32x32x16_bf16 -- 16x the fp32 MFMA rate -- with fp32 accumulation and the same
 // fp32 epilogue.  This is the "bf16 compute" mode of BASELINE configs[2]; the default path is exact fp32.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int LDH = BK + 8;   // bf16 elements per LDS row (80 B): the 16-B fragment reads are conflict-free
 
+// registers -> bf16 LDS tile [row][LDH].  KC: the thread's four values are k-consecutive (one 8-byte store).
+// !KC (the transpose): PAIRK -- the thread holds P consecutive k of four rows: one 4-byte (P = 2) or 8-byte (P = 4) store
+// per row; otherwise (generic loader) four 2-byte stores per load
+template <int BR, bool KC, bool PAIRK>
+__device__ __forceinline__ void store_half(__bf16* H, const f32x4 (&reg)[BR / 32], int tid) {
+  constexpr int P = BR / 32;
+  if constexpr (KC) {
+#pragma unroll
+    for (int j = 0; j < P; ++j) {
+      bf16x4 h = {(__bf16)reg[j][0], (__bf16)reg[j][1], (__bf16)reg[j][2], (__bf16)reg[j][3]};
+      *reinterpret_cast<bf16x4*>(H + ((tid >> 3) + 32 * j) * LDH + 4 * (tid & 7)) = h;
+    }
+  } else {
+    constexpr int Q = BR / 4, RP = 256 / Q;
+    const int r = 4 * (tid % Q);
+    if constexpr (PAIRK) {
+      const int k0 = P * (tid / Q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if constexpr (P == 2) {
+          typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+          bf16x2 h = {(__bf16)reg[0][e], (__bf16)reg[1][e]};
+          *reinterpret_cast<bf16x2*>(H + (r + e) * LDH + k0) = h;
+        } else {
+          bf16x4 h = {(__bf16)reg[0][e], (__bf16)reg[1][e], (__bf16)reg[2][e], (__bf16)reg[3][e]};
+          *reinterpret_cast<bf16x4*>(H + (r + e) * LDH + k0) = h;
+        }
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < P; ++j) {
+        const int k = tid / Q + RP * j;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) H[(r + e) * LDH + k] = (__bf16)reg[j][e];
+      }
+    }
+  }
+}
+
 template <int BM, int BN, bool A_K, bool B_K, bool BF16 = false>
 __global__ __launch_bounds__(256, (BM == 64 ? SDUMC_GEMM_WPE64 : SDUMC_GEMM_WPE128)) void gemm_kernel(const sdumc_gemm g, const int nsplit, const int kchunk) {
-  static_assert(!BF16 || (A_K && B_K), "the bf16 variant is built for the NT layout");
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int A_ELEMS = A_K ? BM * LDK : BK * BM;
   constexpr int B_ELEMS = B_K ? BN * LDK : BK * BN;
@@ -378,20 +422,11 @@ __global__ __launch_bounds__(256, (BM == 64 ? SDUMC_GEMM_WPE64 : SDUMC_GEMM_WPE1
       }
     }
   };
-  auto store_stage = [&](float* As, float* Bs, const f32x4 (&ra)[BM / 32], const f32x4 (&rb)[BN / 32]) {
+  auto store_stage = [&](float* As, float* Bs, const f32x4 (&ra)[BM / 32], const f32x4 (&rb)[BN / 32], auto pair_c) {
     if constexpr (BF16) {
-      __bf16* Ah = reinterpret_cast<__bf16*>(As);
-      __bf16* Bh = reinterpret_cast<__bf16*>(Bs);
-#pragma unroll
-      for (int j = 0; j < BM / 32; ++j) {
-        bf16x4 h = {(__bf16)ra[j][0], (__bf16)ra[j][1], (__bf16)ra[j][2], (__bf16)ra[j][3]};
-        *reinterpret_cast<bf16x4*>(Ah + ((tid >> 3) + 32 * j) * LDH + 4 * (tid & 7)) = h;
-      }
-#pragma unroll
-      for (int j = 0; j < BN / 32; ++j) {
-        bf16x4 h = {(__bf16)rb[j][0], (__bf16)rb[j][1], (__bf16)rb[j][2], (__bf16)rb[j][3]};
-        *reinterpret_cast<bf16x4*>(Bh + ((tid >> 3) + 32 * j) * LDH + 4 * (tid & 7)) = h;
-      }
+      constexpr bool PAIRK = decltype(pair_c)::value;
+      store_half<BM, A_K, PAIRK>(reinterpret_cast<__bf16*>(As), ra, tid);
+      store_half<BN, B_K, PAIRK>(reinterpret_cast<__bf16*>(Bs), rb, tid);
     } else {
       store_tile<BM, A_K>(As, ra, tid);
       store_tile<BN, B_K>(Bs, rb, tid);
@@ -409,8 +444,8 @@ __global__ __launch_bounds__(256, (BM == 64 ? SDUMC_GEMM_WPE64 : SDUMC_GEMM_WPE1
     constexpr int FASTV = decltype(fast_c)::value;   // 0 generic loader, 1 hoisted addressing, 2 the same on full tiles only
     constexpr bool FAST = FASTV > 0, FULL = FASTV == 2, MA = decltype(ma_c)::value, MB = decltype(mb_c)::value,
                    CS = decltype(cs_c)::value;
-    Stager<BM, A_K> sa;
-    Stager<BN, B_K> sb;
+    Stager<BM, A_K, BF16 && !A_K> sa;     // bf16: row-contiguous operands are loaded as k-pairs (see store_half)
+    Stager<BN, B_K, BF16 && !B_K> sb;
     if constexpr (FAST) {
       sa.init(ca, m0, g.M, kbeg, tid);
       sb.init(cb, n0, g.N, kbeg, tid);
@@ -433,12 +468,13 @@ __global__ __launch_bounds__(256, (BM == 64 ? SDUMC_GEMM_WPE64 : SDUMC_GEMM_WPE1
       // load time
       if constexpr (FAST && MA) Stager<BM, A_K>::apply(ra, ba, ca.drop.scale);
       if constexpr (FAST && MB) Stager<BN, B_K>::apply(rb, bb, cb.drop.scale);
+      constexpr bool PAIR = FAST && BF16;   // the generic loader keeps the RP-apart mapping
       if constexpr (CS) {
 #pragma unroll
         for (int j = 0; j < BM / 32; ++j) csum += ra[j];
       }
       __syncthreads();  // everyone is done reading the previous tile
-      store_stage(As, Bs, ra, rb);
+      store_stage(As, Bs, ra, rb, std::integral_constant<bool, PAIR>{});
       __syncthreads();
       if (k0 + BK < kend) prefetch(k0 + BK);   // in flight during the MFMAs below
       compute(As, Bs);
@@ -736,8 +772,13 @@ GemmPlan plan_gemm(const sdumc_gemm& g, size_t ws_bytes) {
 template <int BM, int BN>
 int launch(const sdumc_gemm& g, int nsplit, int kchunk, hipStream_t st) {
   dim3 grid((g.N + BN - 1) / BN, (g.M + BM - 1) / BM, g.groups * (g.batch > 1 ? g.batch : 1) * nsplit);
-  if (g.bf16) {   // NT only (checked by the caller)
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, true>), grid, dim3(256), 0, st, g, nsplit, kchunk);
+  if (g.bf16) {
+    switch (g.layout) {
+      case SDUMC_NT: hipLaunchKernelGGL((gemm_kernel<BM, BN, true, true, true>), grid, dim3(256), 0, st, g, nsplit, kchunk); break;
+      case SDUMC_NN: hipLaunchKernelGGL((gemm_kernel<BM, BN, true, false, true>), grid, dim3(256), 0, st, g, nsplit, kchunk); break;
+      case SDUMC_TN: hipLaunchKernelGGL((gemm_kernel<BM, BN, false, false, true>), grid, dim3(256), 0, st, g, nsplit, kchunk); break;
+      default: return SDUMC_EINVAL;
+    }
     return SDUMC_OK;
   }
   switch (g.layout) {
@@ -776,8 +817,10 @@ extern "C" int sdumc_gemm_f32(const sdumc_gemm* gp, void* stream) {
     for (int i = 0; i < g.groups; ++i)
       if (g.colsum_a[i] || g.c_mask_y[i] || g.bias[i]) return SDUMC_EINVAL;
   }
-  if (g.bf16) {   // bf16 operands: NT layout, 16-byte aligned rows, k a multiple of 4
-    if (g.layout != SDUMC_NT || (g.lda & 3) || (g.ldb & 3) || (g.K & 3)) return SDUMC_EINVAL;
+  if (g.bf16) {   // bf16 operands: 16-byte aligned rows, channel extents multiples of 4, 64x64 / 128x128 tiles
+    if ((g.lda & 3) || (g.ldb & 3) || (g.K & 3) || (g.layout != SDUMC_NT && ((g.N & 3) || (g.layout == SDUMC_TN && (g.M & 3)))) ||
+        g.tile == 3 || g.tile == 4)
+      return SDUMC_EINVAL;
     for (int i = 0; i < g.groups; ++i)
       if ((reinterpret_cast<uintptr_t>(g.A[i]) | reinterpret_cast<uintptr_t>(g.B[i])) & 15) return SDUMC_EINVAL;
   }
@@ -790,7 +833,7 @@ extern "C" int sdumc_gemm_f32(const sdumc_gemm* gp, void* stream) {
   const bool prof = g_prof_on;
   if (prof) {
     if (hipEventCreate(&rec.a) != hipSuccess || hipEventCreate(&rec.b) != hipSuccess) return SDUMC_ELAUNCH;
-    rec.variant = g.bf16 ? (tile == 1 ? 9 : 10) : tile == 3 ? 6 + g.layout : g.layout * 2 + (tile == 1 ? 0 : 1);
+    rec.variant = g.bf16 ? 9 + g.layout * 2 + (tile == 1 ? 0 : 1) : tile == 3 ? 6 + g.layout : g.layout * 2 + (tile == 1 ? 0 : 1);
     rec.flops = 2.0 * g.M * (double)g.N * g.K * g.groups * (g.batch > 1 ? g.batch : 1);
     (void)hipEventRecord(rec.a, st);
   }

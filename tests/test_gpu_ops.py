@@ -131,6 +131,29 @@ def test_gemm_small_kernel_all_layouts(ops, M, N, K):
     assert torch.equal(got, again)
 
 
+@pytest.mark.parametrize("layout", ["NN", "TN"])
+@pytest.mark.parametrize("M,N,K,tile", [(300, 256, 1024, 2), (2048, 256, 256, 0), (256, 1024, 5000, 0), (512, 128, 96, 1)])
+def test_gemm_bf16_row_contiguous_layouts(ops, layout, M, N, K, tile):
+    """bf16-operand mode of the NN (dX) and TN (dW, with the fused column sums) products: the row-contiguous operands are
+    transposed by their LDS stores.  Reference: the product of the bf16-rounded operands in float64 (tight), and the fp32
+    product (bf16 tolerance)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    if layout == "NN":
+        A, B = torch.randn(M, K, generator=g), torch.randn(K, N, generator=g) / K ** 0.5
+        ref32 = A.double() @ B.double()
+        refbf = A.bfloat16().double() @ B.bfloat16().double()
+        got = ops.gemm(ops.NN, dev(A), dev(B), M, N, K, tile=tile, splitk=0, bf16=True)
+    else:
+        A, B = torch.randn(K, M, generator=g), torch.randn(K, N, generator=g) / K ** 0.5
+        ref32 = A.double().T @ B.double()
+        refbf = A.bfloat16().double().T @ B.bfloat16().double()
+        cs = dev(torch.zeros(M))
+        got = ops.gemm(ops.TN, dev(A), dev(B), M, N, K, tile=tile, splitk=0, bf16=True, colsum_a=cs)
+        close(cs, A.double().sum(0), 2e-5)          # the column sums ride on the fp32 staging registers: exact fp32
+    close(got, refbf, 2e-5)
+    close(got, ref32, 2e-2)
+
+
 @pytest.mark.parametrize("M,N,K,tile", [(300, 256, 1024, 2), (2048, 256, 4096, 0), (513, 130, 96, 1), (48000, 256, 256, 0)])
 def test_gemm_bf16_operand_mode(ops, M, N, K, tile):
     """bf16=True: operands rounded to bf16 (RNE) while staged, fp32 accumulate: must equal the fp64 product of the
