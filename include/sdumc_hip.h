@@ -376,6 +376,9 @@ typedef struct sdumc_mha {
   float* ctx;                    /* [tq, B, E] attention output before out_proj */
   float* workspace;              /* >= sdumc_mha_workspace_bytes */
   size_t workspace_bytes;
+  int32_t bf16;                  /* 1: every product (projections, q.k^T, P.v and their backward) rounds its operands to bf16,
+                                    fp32 accumulate (needs embed and head_dim multiples of 4; otherwise the call stays fp32);
+                                    softmax, dropout, bias and the stored tensors are fp32 either way.  0: exact fp32 */
 } sdumc_mha;
 
 typedef struct sdumc_mha_grads {

@@ -115,7 +115,7 @@ class Mha(C.Structure):
                 ("out", C.c_void_p), ("weights", C.c_void_p),
                 ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p),
                 ("probs", C.c_void_p), ("probs_drop", C.c_void_p), ("ctx", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("bf16", C.c_int32)]
 
 
 class MhaGrads(C.Structure):

@@ -480,15 +480,22 @@ void dw_in_desc(sdumc_gemm& g, const sdumc_mha& m, const sdumc_mha_grads& gr, co
 
 size_t align_up(size_t n) { return (n + 63) & ~(size_t)63; }
 
+// bf16-operand products need every extent that is a leading dimension, a stride or a channel count to be a multiple of 4
+int mha_bf16(const sdumc_mha& m, const MhaPlan& p) {
+  return m.bf16 && (p.E % 4 == 0) && (p.dh % 4 == 0) && (p.tq % 4 == 0) && (p.tk % 4 == 0) ? 1 : 0;
+}
+
 struct Runner {   // launches descriptors with the shared split-K scratch
   float* ws;
   size_t ws_bytes;
   hipStream_t st;
+  int bf16 = 0;
   int rc = SDUMC_OK;
   void run(sdumc_gemm& g) {
     if (rc != SDUMC_OK) return;
     g.workspace = ws;
     g.workspace_bytes = ws_bytes;
+    g.bf16 = bf16;
     rc = sdumc_gemm_f32(&g, (void*)st);
   }
 };
@@ -640,7 +647,7 @@ extern "C" int sdumc_mha_forward(const sdumc_mha* mp, void* stream) {
   if (m.attn_drop.enabled && !m.probs_drop) return SDUMC_EINVAL;
   const size_t need = sdumc_mha_workspace_bytes(mp, 0);
   if (need && (!m.workspace || m.workspace_bytes < need)) return SDUMC_ENOMEM;
-  Runner r{m.workspace, need, as_stream(stream)};
+  Runner r{m.workspace, need, as_stream(stream), mha_bf16(m, p)};
   sdumc_gemm g;
   // q, k, v = in_proj(query | key | value)   (:64-82)
   if (p.tq == p.tk) {
@@ -705,7 +712,7 @@ extern "C" int sdumc_mha_backward(const sdumc_mha* mp, const sdumc_mha_grads* gp
   float* dk = base + align_up(2 * p.n_q);
   float* dv = dk + p.n_k;
   float* dP = dk + align_up(2 * p.n_k);
-  Runner r{m.workspace, gws, as_stream(stream)};
+  Runner r{m.workspace, gws, as_stream(stream), mha_bf16(m, p)};
   sdumc_gemm g;
   const int ldx = p.B * p.E;
   const float* pv = m.attn_drop.enabled ? m.probs_drop : m.probs;

@@ -264,7 +264,8 @@ def drop_add(x, residual=None, drop=None, alpha=1.0, pos_table=None, pos_src=Non
     return y
 
 
-def mha_forward(query, key, value, w_in, b_in, w_out, b_out, heads, attn_mask=None, attn_drop=None, need_weights=True):
+def mha_forward(query, key, value, w_in, b_in, w_out, b_out, heads, attn_mask=None, attn_drop=None, need_weights=True,
+                bf16=False):
     """MultiheadAttention.forward on [T, B, E] tensors.  Returns (out, weights, saved) where `saved` is what
     mha_backward needs."""
     tq, B, E = query.shape
@@ -275,6 +276,7 @@ def mha_forward(query, key, value, w_in, b_in, w_out, b_out, heads, attn_mask=No
     m.query, m.key, m.value = ptr(query), ptr(key), ptr(value)
     m.in_proj_weight, m.in_proj_bias, m.out_proj_weight, m.out_proj_bias = ptr(w_in), ptr(b_in), ptr(w_out), ptr(b_out)
     m.attn_mask = ptr(attn_mask)
+    m.bf16 = 1 if bf16 else 0
     drop_on = attn_drop is not None and attn_drop.enabled
     if drop_on:
         m.attn_drop = attn_drop

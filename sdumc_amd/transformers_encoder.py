@@ -53,6 +53,16 @@ class DropoutStream:
 
 dropout_stream = DropoutStream()
 
+_BF16 = False
+
+
+def set_bf16(on=True):
+    """bf16-operand mode for every product of this module family (fp32 accumulate, fp32 storage): Linear / in_proj /
+    out_proj forward and backward, q.k^T and P.v.  Off by default (exact fp32).  Shapes whose extents are not multiples
+    of 4 stay on the fp32 path."""
+    global _BF16
+    _BF16 = bool(on)
+
 
 def manual_seed(seed, call=0):
     """Re-key the dropout stream (and restart the site numbering)."""
@@ -88,10 +98,12 @@ class _LinearFn(torch.autograd.Function):
         N, K = w.shape
         M = x.numel() // K
         y = torch.empty(*x.shape[:-1], N, device=x.device)
+        bf16 = _BF16 and N % 4 == 0 and K % 4 == 0 and M % 4 == 0
         ops.gemm(ops.NT, x, w, M, N, K, bias=b, C_out=y, act=ops.ACT_RELU if relu else ops.ACT_NONE, c_drop=drop,
-                 splitk=0)
+                 splitk=0, bf16=bf16)
         ctx.save_for_backward(x, w, y if relu else None)
         ctx.has_bias, ctx.relu, ctx.scale = b is not None, relu, (drop.scale if drop is not None else 1.0)
+        ctx.bf16 = bf16
         return y
 
     @staticmethod
@@ -106,10 +118,10 @@ class _LinearFn(torch.autograd.Function):
                                                     _lib.current_stream()), "sdumc_relu_drop_bwd")
             dy = dz
         dx = torch.empty_like(x)
-        ops.gemm(ops.NN, dy, w, M, K, N, C_out=dx, splitk=0)
+        ops.gemm(ops.NN, dy, w, M, K, N, C_out=dx, splitk=0, bf16=ctx.bf16)
         dw = torch.empty_like(w)
         db = torch.empty(N, device=x.device) if ctx.has_bias else None
-        ops.gemm(ops.TN, dy, x, N, K, M, C_out=dw, colsum_a=db, splitk=0)
+        ops.gemm(ops.TN, dy, x, N, K, M, C_out=dw, colsum_a=db, splitk=0, bf16=ctx.bf16)
         return dx, dw, db, None, None
 
 
@@ -182,7 +194,8 @@ class _MhaFn(torch.autograd.Function):
         value = query if same_vq else (key if same_vk else _c(value))
         w_in, b_in, w_out, b_out, attn_mask = _c(w_in), _c(b_in), _c(w_out), _c(b_out), _c(attn_mask)
         _dev(query, key, value, w_in, b_in, w_out, b_out, attn_mask)
-        out, weights, saved = ops.mha_forward(query, key, value, w_in, b_in, w_out, b_out, heads, attn_mask, drop)
+        out, weights, saved = ops.mha_forward(query, key, value, w_in, b_in, w_out, b_out, heads, attn_mask, drop,
+                                              bf16=_BF16)
         ctx.saved = saved
         ctx.mark_non_differentiable(weights)
         return out, weights

@@ -314,3 +314,38 @@ def test_mha_properties_at_c5_shape(te):
     # out is affine in value: o(v1 + 2 v2) = o(v1) + 2 o(v2) - 2 * o(0); with zero biases o(0) = 0
     assert float(b.detach().abs().max()) == 0.0 and float(bv.detach().abs().max()) == 0.0
     close(o12, o1 + 2 * o2, 1e-4, "linearity in value")
+
+
+def test_encoder_layer_bf16_operand_mode(te):
+    """bf16-operand mode of every product in the layer (BASELINE configs[4] dtype): outputs within 2e-2 of the fp32 oracle,
+    the mode is really active, gradients norm-wise within bf16 tolerance; exact fp32 is restored afterwards."""
+    from oracle import transformer_oracle as TO
+    E, H, T_, B = 256, 8, 64, 4
+    torch.manual_seed(E)
+    lay = te.TransformerEncoderLayer(E, num_heads=H, attn_dropout=0.1, relu_dropout=0.1, res_dropout=0.1, attn_mask=True).cuda().train()
+    x = torch.randn(T_, B, E)
+    R = torch.randn(T_, B, E) / math.sqrt(T_ * B * E)
+    P = _oracle_params(lay)
+    xo = x.double().requires_grad_()
+    yo = TO.encoder_layer(P, "", xo, H, TO.DropSeq(True, 99, 3), 0.1, 0.1, 0.1, True)
+    (yo * R.double()).sum().backward()
+    outs = {}
+    try:
+        for mode in (False, True):
+            te.set_bf16(mode)
+            xg = x.cuda().requires_grad_()
+            te.manual_seed(99, 3)
+            y = lay(xg)
+            (y * R.cuda()).sum().backward()
+            outs[mode] = (y.detach().clone(), xg.grad.clone(), {k: v.grad.clone() for k, v in lay.named_parameters()})
+            for v in lay.parameters():
+                v.grad = None
+    finally:
+        te.set_bf16(False)
+    close(outs[False][0], yo, what="fp32 out")
+    close(outs[True][0], yo, 2e-2, "bf16 out")
+    assert float((outs[True][0] - outs[False][0]).abs().max()) > 1e-6, "bf16 mode not active"
+    rel = lambda a, b: float((a.cpu().double() - b).norm() / (b.norm() + 1e-12))
+    assert rel(outs[True][1], xo.grad) < 3e-2
+    for k, v in outs[True][2].items():
+        assert rel(v, P[k].grad) < 5e-2, k

@@ -18,6 +18,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sdumc_amd import _lib, transformers_encoder as te  # noqa: E402
 
 PEAK_F32_TFLOPS = 157.3   # MI355X dense fp32 MFMA (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA
 
 
 def main():
@@ -29,8 +30,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-dropout", action="store_true")
+    ap.add_argument("--bf16", action="store_true", help="bf16 operands / fp32 accumulate in every product (BASELINE configs[4] dtype)")
     a = ap.parse_args()
     p = 0.0 if a.no_dropout else 0.1
+    te.set_bf16(a.bf16)
     torch.manual_seed(0)
     lay = te.TransformerEncoderLayer(a.E, num_heads=a.H, attn_dropout=p, relu_dropout=p, res_dropout=p,
                                      attn_mask=True).cuda().train()
@@ -78,8 +81,9 @@ def main():
         "what": "TransformerEncoderLayer fwd / fwd+bwd", "T": a.T, "B": a.B, "E": a.E, "H": a.H, "dropout": p,
         "fwd_ms": round(ms_f, 4), "fwd_bwd_ms": round(ms_fb, 4),
         "fwd_tflops": round(fwd_flops / (ms_f * 1e9), 2), "fwd_bwd_tflops": round(3 * fwd_flops / (ms_fb * 1e9), 2),
-        "peak_tflops": PEAK_F32_TFLOPS, "fwd_bwd_frac": round(3 * fwd_flops / (ms_fb * 1e9) / PEAK_F32_TFLOPS, 3),
-        "tokens_per_s": round(M / (ms_fb * 1e-3)), "dtype": "f32", "gemm_variants": gemms}))
+        "peak_tflops": PEAK_BF16_TFLOPS if a.bf16 else PEAK_F32_TFLOPS,
+        "fwd_bwd_frac": round(3 * fwd_flops / (ms_fb * 1e9) / (PEAK_BF16_TFLOPS if a.bf16 else PEAK_F32_TFLOPS), 3),
+        "tokens_per_s": round(M / (ms_fb * 1e-3)), "dtype": "bf16 operands / f32 accumulate, f32 storage" if a.bf16 else "f32", "gemm_variants": gemms}))
 
 
 if __name__ == "__main__":
