@@ -89,13 +89,29 @@ def roofline_leg(_lib, launch, steps):
                          "ms_per_step": e.total_ms / steps})
     rows.sort(key=lambda r: -r["ms_per_step"])
     top = rows[0]
+    traffic, traffic_src = recorded_traffic(top["kernel"])
     return {"bound": "mfma", "achieved": round(top["tflops"], 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(top["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+            "frac": round(top["tflops"] / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
             "kernel": top["kernel"], "avg_launch_us": round(top["avg_us"], 2),
             "gflop_per_launch": round(top["gflop_per_launch"], 3),
             "launches_per_step": top["launches_per_step"],
             "gemm_ms_per_step": round(sum(r["ms_per_step"] for r in rows), 4),
             "all_gemm_variants": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]}
+
+
+def recorded_traffic(kernel):
+    """HBM-side bytes per launch of `kernel` from the committed PMC summary (profiles/pmc_traffic.json, written by
+    tools/pmc_traffic_summary.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes over this same
+    command; counters cannot be read from inside the process).  None when the kernel is not in the summary."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            k = json.load(f)["kernels"].get(kernel)
+    except (OSError, ValueError, KeyError):
+        return None, None
+    if not k:
+        return None, None
+    return k["traffic_bytes"], "profiles/pmc_traffic.json (rocprofv3 PMC passes, fetch x2 gfx950 correction, average per launch)"
 
 
 def cpu_baseline_leg(steps=3):
@@ -176,7 +192,15 @@ def main():
 
     import torch.distributed as dist
     from sdumc_amd import _lib, engine
-    if world > 1:
+    # SDUMC_FORCE_DP=1 at world size 1: a one-rank RCCL communicator and the data-parallel step with every collective
+    # issued -- exercises the N > 1 code path (communicator stream ordering, async early-slice all-reduce) on one GPU.
+    force_dp = world == 1 and os.environ.get("SDUMC_FORCE_DP", "0") == "1"
+    if force_dp:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force_dp:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("SDUMC_DIST_BACKEND", "nccl")          # "nccl" is RCCL on ROCm
         if backend == "nccl":
@@ -191,7 +215,7 @@ def main():
     flat, lay = init_flat_params(engine, dev)
     batch = [t.to(dev) for t in synthetic_shard(B_PER_GPU, rank)]
 
-    if world == 1:
+    if world == 1 and not force_dp:
         step = engine.TrainStep(flat, B_PER_GPU, T_MOSEI, DIMS, seed=2024, bf16=args.bf16)
         step.set_batch(*batch)
         if args.graph:
@@ -199,30 +223,31 @@ def main():
         run = step.run
     else:
         from sdumc_amd.trainer import DataParallelStep
-        step = DataParallelStep(flat, B_PER_GPU, T_MOSEI, DIMS, seed=2024, exact=True, bf16=args.bf16)
+        step = DataParallelStep(flat, B_PER_GPU, T_MOSEI, DIMS, seed=2024, exact=True, bf16=args.bf16,
+                                force_collectives=force_dp)
         step.set_batch(*batch)
         run = step.step
 
     for _ in range(args.warmup):
         run()
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or force_dp:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         run()
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or force_dp:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if world > 1 or force_dp:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
-    losses = (step.losses if world == 1 else step.be.losses).cpu()
+    losses = (step.losses if (world == 1 and not force_dp) else step.be.losses).cpu()
     if not torch.isfinite(losses).all():
         raise SystemExit(f"non-finite loss: {losses.tolist()}")
 
@@ -236,24 +261,28 @@ def main():
                                "(text + text-missing/feat4) with self-distillation",
                    "batch_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU,
                    "T_audio_text_video_feat4": list(T_MOSEI), "feature_dims": list(DIMS),
-                   "parallelism": f"dp{world}" if world > 1 else "single",
+                   "parallelism": f"dp{world}" if world > 1 else ("dp1 (one-rank RCCL communicator, all collectives issued)" if force_dp else "single"),
                    "launch": "hipGraph replay" if (args.graph and world == 1) else ("eager, 4 lanes (caller stream + 2 modality side streams + 1 background stream)" if args.background_lane else "eager, 3 lanes (caller stream + 2 side streams)"),
                    "params": lay.total, "final_loss": round(float(losses[0]), 5)},
         "whole_step_tflops": round(value * TRAIN_FLOPS_PER_SAMPLE / 1e12, 2),
         "whole_step_frac_of_f32_mfma_peak": round(value * TRAIN_FLOPS_PER_SAMPLE / 1e12 / (world * PEAK_F32_MFMA_TFLOPS), 4),
     }
     if not args.no_roofline:     # every rank runs it (the DP step has collectives); rank 0 reports
-        roof = roofline_leg(_lib, step.launch if world == 1 else step.step, max(3, min(10, args.steps)))
+        roof = roofline_leg(_lib, step.launch if (world == 1 and not force_dp) else step.step, max(3, min(10, args.steps)))
         if rank == 0:
             out["roofline"] = roof
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg()
             out["gpu_over_cpu"] = round(value / out["cpu_baseline"]["value"], 1)
+    if world > 1 or force_dp:
+        dist.destroy_process_group()
+    # RCCL writes a version banner through C stdio, which reaches a redirected stdout only when its buffer is flushed
+    # (normally at exit, i.e. AFTER anything Python printed): flush it first so that the JSON line is the last line.
+    import ctypes
+    ctypes.CDLL(None).fflush(None)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -535,6 +535,17 @@ size_t sdumc_loss_workspace_bytes(const sdumc_net_dims* d, int32_t B_global);
 /* local sums of squared differences of the three RMSE pairs -> ssd_out float[3] (for the all-reduce) */
 int sdumc_loss_ssd(const sdumc_net_dims* d, const sdumc_net_io* io, float* ssd_out, void* scratch,
                    size_t scratch_bytes, void* stream);
+/* The data-parallel exactness exchange as ONE record per rank,
+ *   record = [ rnc features of this rank, stream-major (2*B x rd) | labels (B) | sums of squares (3) ],  n = 2*B*rd + B + 3 floats,
+ * so that one all-gather of W records replaces the three exchanges.  sdumc_dp_unpack turns the gathered [W, n] matrix into
+ * what sdumc_step_cfg takes: feats [2*W*B, rd] = (stream-0 rows of rank 0..W-1, then stream-1 rows of rank 0..W-1),
+ * labels2 [2*W*B] = the W*B labels twice, ssd[3] = the per-rank sums added in rank order (same bits on every rank).
+ * The reference has no data-parallel path: the truth these reproduce is the single-process step on the
+ * whole batch (main_frame_val_text_missing.py:119-150). */
+int sdumc_dp_pack(const float* rnc, const float* labels, const float* ssd, int32_t B, int32_t rd, float* record,
+                  void* stream);
+int sdumc_dp_unpack(const float* records, int32_t W, int32_t B, int32_t rd, float* feats, float* labels2, float* ssd,
+                    void* stream);
 /* loss values + gradients w.r.t. the five network outputs (written to the d_* buffers of `g`,
  * which here are OUTPUTS and must all be non-NULL) */
 int sdumc_loss_backward(const sdumc_net_dims* d, const sdumc_net_io* io, const sdumc_step_cfg* cfg,

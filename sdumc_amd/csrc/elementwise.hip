@@ -456,4 +456,53 @@ extern "C" int sdumc_zpool_bwd(const float* h, const float* beta, const float* d
   return SDUMC_OK;
 }
 
+namespace {
+__global__ void dp_pack_kernel(const float* __restrict__ rnc, const float* __restrict__ labels, const float* __restrict__ ssd,
+                               int nf, int B, float* __restrict__ rec) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nf) rec[i] = rnc[i];
+  else if (i < nf + B) rec[i] = labels[i - nf];
+  else if (i < nf + B + 3) rec[i] = ssd[i - nf - B];
+}
+__global__ void dp_unpack_kernel(const float* __restrict__ recs, int W, int B, int rd, float* __restrict__ feats,
+                                 float* __restrict__ labels2, float* __restrict__ ssd) {
+  const int nf = 2 * B * rd, n = nf + B + 3;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;   // over the [2*W*B, rd] feature matrix
+  const int64_t total = (int64_t)W * nf;
+  if (i < total) {
+    const int col = (int)(i % rd);
+    const int64_t row = i / rd;            // s * W * B + r * B + b
+    const int s = (int)(row / ((int64_t)W * B));
+    const int rb = (int)(row % ((int64_t)W * B));
+    const int r = rb / B, b = rb % B;
+    feats[i] = recs[(int64_t)r * n + (int64_t)(s * B + b) * rd + col];
+    if (col == 0) labels2[row] = recs[(int64_t)r * n + nf + b];
+  }
+  if (i < 3) {
+    float acc = 0.f;
+    for (int r = 0; r < W; ++r) acc += recs[(int64_t)r * n + nf + B + (int)i];   // fixed order: identical on every rank
+    ssd[i] = acc;
+  }
+}
+}  // namespace
+
+extern "C" int sdumc_dp_pack(const float* rnc, const float* labels, const float* ssd, int32_t B, int32_t rd, float* record,
+                             void* stream) {
+  if (!rnc || !labels || !ssd || !record || B <= 0 || rd <= 0) return SDUMC_EINVAL;
+  const int nf = 2 * B * rd, n = nf + B + 3;
+  hipLaunchKernelGGL(dp_pack_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(stream), rnc, labels, ssd, nf, B, record);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_dp_unpack(const float* records, int32_t W, int32_t B, int32_t rd, float* feats, float* labels2,
+                               float* ssd, void* stream) {
+  if (!records || !feats || !labels2 || !ssd || W <= 0 || B <= 0 || rd <= 0) return SDUMC_EINVAL;
+  const int64_t total = (int64_t)W * 2 * B * rd;
+  hipLaunchKernelGGL(dp_unpack_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, as_stream(stream), records, W, B,
+                     rd, feats, labels2, ssd);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
 extern "C" const char* sdumc_version(void) { return "sdumc_hip 0.1 (gfx950)"; }

@@ -360,8 +360,22 @@ void ensure_side_streams() {
   std::lock_guard<std::mutex> lock(mu);
   SideStreams& S = side_streams();
   if (S.ok) return;
+  // The side lanes are HIGH-priority streams.  The HIP runtime multiplexes the streams of one priority class onto
+  // GPU_MAX_HW_QUEUES (default 4) hardware queues, handing a new stream the least-used queue: once other components
+  // hold normal-priority streams (an RCCL communicator created before these lanes; torch's stream pool) two lanes can
+  // land on ONE hardware queue and the three modality chains serialise -- measured on MI355X: 2.59-2.63 ms per step
+  // instead of 2.18 whenever the process group had been initialised first (tools/rccl_queue_probe.py), and 2.18 again
+  // with GPU_MAX_HW_QUEUES=8 or with the lanes in their own priority class (2.17-2.20 ms in both orders).
+  // SDUMC_LANE_PRIORITY=normal|low restores / varies the class for experiments.
+  int prio = 0;
+  {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return;
+    const char* e = getenv("SDUMC_LANE_PRIORITY");
+    prio = (e && e[0] == 'n') ? 0 : ((e && e[0] == 'l') ? least : greatest);
+  }
   for (int i = 0; i < 2; ++i)
-    if (hipStreamCreateWithFlags(&S.s[i], hipStreamNonBlocking) != hipSuccess) return;
+    if (hipStreamCreateWithPriority(&S.s[i], hipStreamNonBlocking, prio) != hipSuccess) return;
   for (int i = 0; i < 64; ++i)
     if (hipEventCreateWithFlags(&S.ev[i], hipEventDisableTiming) != hipSuccess) return;
   {
@@ -370,8 +384,9 @@ void ensure_side_streams() {
     // half-size launches lose 4 % of per-kernel efficiency (TN 78 vs 82 TF) -> off by default; a stream confined to 7/8 (or 1/2) of the CUs with
     // hipExtStreamCreateWithCUMask -- meant to keep free CUs for the chain's small kernels -- made the whole step
     // 60 % slower (3.57 vs 2.22 ms), and 128x128 tiles on this lane (2 workgroups per CU, room for a small kernel beside
-    // them) 12 % slower; the lowest stream priority made no difference.
-    if (hipStreamCreateWithFlags(&S.bg, hipStreamNonBlocking) != hipSuccess) return;
+    // them) 12 % slower; the lowest stream priority made no difference.  Re-measured after the dW batches moved to this
+    // lane (r1n): 27.7 k samples/s with the option against 29.7 k without, at every priority of this stream.
+    if (hipStreamCreateWithPriority(&S.bg, hipStreamNonBlocking, prio) != hipSuccess) return;
   }
   S.ok = true;
 }
@@ -389,6 +404,8 @@ struct Ctx {
   bool bg = false;   // the Cross_Attention-site key projections are issued on lane 3 (background)
   mutable float* scr = nullptr;   // scratch of the current lane
   bool multi = false;
+  // weight-gradient GEMMs of the utterance-level layers, queued by lin_bwd* and issued in batches on lane 3 (flush_dw)
+  mutable std::vector<sdumc_gemm> deferred;
   float* p(int64_t off) const { return W + off; }
   void init_lanes() {
     const SideStreams& S = side_streams();
@@ -397,7 +414,7 @@ struct Ctx {
     bg = g_background;                    // the launch decomposition is the same with and without real streams
     sts[1] = multi ? S.s[0] : st;
     sts[2] = multi ? S.s[1] : st;
-    sts[3] = multi && bg ? S.bg : st;
+    sts[3] = multi ? S.bg : st;   // lane 3: deferred dW batches (and, with the background option, the Cross_Attention keys)
     use(0);
   }
   void use(int lane) const {
@@ -492,6 +509,29 @@ int colsum(const Ctx& c, const float* a, int64_t rows, int cols, int lda, float*
   return sdumc_colsum(a, rows, cols, lda, out, accumulate, c.scr, c.st);
 }
 
+// Issues the queued utterance-level dW GEMMs on lane 3, ordered after everything lane 0 has issued so far.
+// Why batches: every hipEventRecord on a stream costs its NEXT kernel ~12 us of bubble on this stack (kernel trace of the
+// step: the dX chain ran at one 9 us kernel per 26-30 us while each layer forked its own dW to a side lane, against
+// back-to-back kernels in the link-free forward chain), so the chain records an event at three points instead of at
+// every layer.  Every operand of a queued GEMM (dz, the saved input) is final when it is queued and is not written
+// again before the end of the backward pass, so running it later is safe.
+bool dw_batching() {   // SDUMC_DW_BATCH=0: one fork per layer (the pre-batching schedule, kept for A/B measurements)
+  static const bool on = [] {
+    const char* e = getenv("SDUMC_DW_BATCH");
+    return !(e && e[0] == '0');
+  }();
+  return on;
+}
+int flush_dw(const Ctx& c) {
+  if (c.deferred.empty()) return SDUMC_OK;
+  RET(link(c, 0, 3));
+  c.use(3);
+  for (sdumc_gemm& g : c.deferred) RET(run(c, g));
+  c.use(0);
+  c.deferred.clear();
+  return SDUMC_OK;
+}
+
 // backward of y = act(x W^T + b) given dzv = gradient w.r.t. the pre-activation, [M, L.out] with ld lddz:
 //   dW = dz^T x, db = colsum(dz), dx (=|+=) dz W
 //   dx_y != nullptr: x itself is the saved output of a Linear->ReLU->Dropout layer; the dX GEMM's epilogue then
@@ -506,10 +546,8 @@ int lin_bwd(const Ctx& c, const Lin& L, const float* dzv, int lddz, const float*
   gw.C[0] = c.G + L.w;
   gw.ldc = L.in;
   gw.colsum_a[0] = c.G + L.b;   // db rides along with the staging of dz
-  RET(link(c, 0, 1));           // dW is off the dX critical path: lane 1
-  c.use(1);
-  RET(run(c, gw));
-  c.use(0);
+  c.deferred.push_back(gw);     // dW is off the dX critical path: issued later, in a batch, on lane 3 (flush_dw)
+  if (!dw_batching()) RET(flush_dw(c));
   if (dx) {
     sdumc_gemm gx = G_(SDUMC_NN, M, L.in, L.out);
     gx.A[0] = dzv;
@@ -550,10 +588,8 @@ int lin_bwd_grouped(const Ctx& c, const Lin* L, int ng, int M, const GroupPtrs& 
   gw.lda = q.lddz;
   gw.ldb = q.ldx;
   gw.ldc = L[0].in;
-  RET(link(c, 0, 1));
-  c.use(1);
-  RET(run(c, gw));
-  c.use(0);
+  c.deferred.push_back(gw);
+  if (!dw_batching()) RET(flush_dw(c));
   if (q.dx) {
     gx.c_mask_scale = q.dx_scale;
     gx.lda = q.lddz;
@@ -894,6 +930,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     GroupPtrs q0 = {c.p(pl.d_c1), (int64_t)M * D, D, c.p(pl.ca_out), (int64_t)M * D, D, c.p(pl.d_ca_out), (int64_t)M * D, D};
     RET(lin_bwd_grouped(c, pm.cmlp0, 3, M, q0));
   }
+  RET(flush_dw(c));   // batch 1: heads, cross_attention_mlp, cross_*_mlp
   // 8'. the three Cross_Attention blocks
   RET(fork_all(c));
   for (int m = 0; m < 3; ++m) {
@@ -918,10 +955,8 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
       gw.colsum_a[m] = c.G + pm.ca_q[m].b;
     }
     gw.lda = gw.ldb = gw.ldc = D;
-    RET(link(c, 0, 1));
-    c.use(1);
-    RET(run(c, gw));
-    c.use(0);
+    c.deferred.push_back(gw);
+    if (!dw_batching()) RET(flush_dw(c));
     for (int m = 0; m < 3; ++m) {
       sdumc_gemm gx = G_(SDUMC_NN, M, D, D);
       gx.A[0] = c.p(pl.d_qp) + (int64_t)m * M * D;
@@ -941,6 +976,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     GroupPtrs qq = {c.p(pl.d_q), D, NQ * D, c.p(pl.qin), (int64_t)V * D, D, c.p(pl.d_qin), (int64_t)V * D, D};
     RET(lin_bwd_grouped(c, pm.query, 7, V, qq));
   }
+  RET(flush_dw(c));   // batch 2: query_proj, the query MLPs
   // 5'. fusion algebra (d_alpha already holds the second-level contribution)
   RET(sdumc_fusion_bwd(c.p(pl.u), c.p(pl.alpha), c.p(pl.d_qin), c.p(pl.d_u), c.p(pl.d_alpha), V, c.st));
   // 4'. fc_att, attention_mlp
@@ -956,14 +992,17 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     GroupPtrs q0 = {c.p(pl.d_u1), (int64_t)V * D, D, c.p(pl.hpre), (int64_t)V * D, D, c.p(pl.d_hpre), (int64_t)V * D, D};
     RET(lin_bwd_grouped(c, pm.umlp0, 3, V, q0));
   }
-  RET(link(c, 1, 0));   // the dW GEMMs of this part ran on lane 1: [0, pm.early) is final on the caller's stream
+  RET(flush_dw(c));   // batch 3: fc_att, attention_mlp, audio/text/video_mlp
+  // the dW GEMMs of this part ran on lane 3: after this link [0, pm.early) is final on the caller's stream.  When the
+  // frame-level part follows in the same call the link at its head does the same job.
+  if (!(phases & 2)) RET(link(c, 3, 0));
   }   // phases & 1
   if (!(phases & 2)) return SDUMC_OK;
   // 2'+1'. three independent per-modality chains, one per lane:
   //   fra2utt_m pooling backward (the shared context vector's gradient = sum of the per-sample dq)
   //   -> input_proj backward of both sites (grouped) -> dx = sum of the (up to) four masked paths into the
   //   projected features -> frame_dim_reshape_m: dW = dx^T feat (split-K) with db fused
-  RET(link(c, 3, 0));   // dxd of the Cross_Attention sites
+  if (c.bg) RET(link(c, 3, 0));   // dxd of the Cross_Attention sites (background option)
   RET(fork_all(c));
   for (int m = 0; m < 3; ++m) {
     c.use(LANE_OF[m]);
@@ -1008,6 +1047,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   }
   c.use(0);
   RET(join_all(c));
+  RET(link(c, 3, 0));   // the last dW batch of the utterance-level part
   return SDUMC_OK;
 }
 

@@ -79,6 +79,7 @@ class HipBackend:
         g.grads = _lib.ptr(self.grads)
         self.g = g
         self.betas, self.eps, self.wd = betas, eps, weight_decay
+        self._record = self._gathered = None
 
     def set_batch(self, audio, text, video, feat4, labels):
         self.audio.copy_(audio, non_blocking=True)
@@ -97,6 +98,30 @@ class HipBackend:
                                       _lib.ptr(self.loss_ws), self.loss_ws.numel(), _lib.current_stream()),
                    "sdumc_loss_ssd")
         return self.ssd[:3]
+
+    def dp_pack(self):
+        """This rank's exchange record [rnc features | labels | local sums of squares] (one kernel after local_ssd)."""
+        lib, _lib = self._lib.lib, self._lib
+        B, rd = self.B, self._engine.RNC_DIM
+        if self._record is None:
+            self._record = torch.empty(2 * B * rd + B + 3, device=self.params.device)
+        self.local_ssd()
+        _lib.check(lib.sdumc_dp_pack(_lib.ptr(self.call.rnc), _lib.ptr(self.labels), _lib.ptr(self.ssd), B, rd,
+                                     _lib.ptr(self._record), _lib.current_stream()), "sdumc_dp_pack")
+        return self._record
+
+    def dp_unpack(self, records, W):
+        """gathered records [W, n] -> (ssd[3], feats [2*W*B, 64], labels2 [2*W*B]) in the layout loss_backward takes."""
+        lib, _lib = self._lib.lib, self._lib
+        B, rd = self.B, self._engine.RNC_DIM
+        if self._gathered is None or self._gathered[1].shape[0] != 2 * W * B:
+            dev = self.params.device
+            self._gathered = (torch.empty(4, device=dev), torch.empty(2 * W * B, rd, device=dev),
+                              torch.empty(2 * W * B, device=dev))
+        ssd, feats, labels2 = self._gathered
+        _lib.check(lib.sdumc_dp_unpack(_lib.ptr(records), W, B, rd, _lib.ptr(feats), _lib.ptr(labels2), _lib.ptr(ssd),
+                                       _lib.current_stream()), "sdumc_dp_unpack")
+        return ssd, feats, labels2
 
     def loss_backward(self, ssd_global=None, feats_global=None, labels_global=None, row0=(0, 0)):
         lib, _lib = self._lib.lib, self._lib
@@ -144,8 +169,13 @@ class DataParallelStep:
     """
 
     def __init__(self, flat_params, B, T, dims, weights=(0.5, 0.5, 0.1, 0.7, 0.1, 0.8), lr=1e-4, betas=(0.9, 0.999),
-                 eps=1e-8, weight_decay=1e-5, seed=0, exact=True, backend_factory=None, bf16=False):
+                 eps=1e-8, weight_decay=1e-5, seed=0, exact=True, backend_factory=None, bf16=False,
+                 force_collectives=False):
         self.rank, self.world = _world()
+        # force_collectives: issue every collective even at world size 1 (a one-rank RCCL communicator): the only way to
+        # exercise the RCCL code path -- communicator stream ordering, the async early-slice handle -- on a 1-GPU box.
+        self._records = None
+        self.collect = self.world > 1 or (bool(force_collectives) and dist.is_initialized())
         self.B, self.exact = B, exact
         self.B_global = B * self.world if exact else B
         factory = backend_factory or HipBackend
@@ -157,7 +187,7 @@ class DataParallelStep:
         # communicator's own stream beside the frame-level backward (the pattern torch DDP uses).  Under gloo (CPU tests,
         # the two-ranks-on-one-GPU debugging aid) an in-flight collective stalls every concurrent launch of this process
         # (200 vs 11 ms per step measured), so there the bucket is reduced in one blocking call after the backward.
-        self.overlap = self.world > 1 and dist.get_backend() == "nccl"
+        self.overlap = self.collect and dist.get_backend() == "nccl"
 
     def set_batch(self, *batch):
         """The LOCAL shard: rows [rank*B, (rank+1)*B) of the global batch."""
@@ -171,23 +201,35 @@ class DataParallelStep:
     def step(self):
         be, B, W = self.be, self.B, self.world
         rnc = be.forward()
-        if W > 1 and self.exact:
-            # ONE collective carries the three exactness exchanges: every rank writes
-            # [rnc features (2B x 64) | labels (B) | 3 sums of squares] into its own row of a zeroed [W, n] buffer and the
-            # buffer is all-reduced -- an all-gather spelt as a sum with zeros (exact in floating point), because a gloo
-            # all_gather of a freshly produced device tensor blocked the host for ~240 ms per call on this stack while
-            # all_reduce does not; under RCCL either spelling is one small kernel.
-            n_f = rnc.numel()
-            pack = torch.cat([rnc.reshape(-1), be.labels.reshape(-1).to(rnc.dtype), be.local_ssd().to(rnc.dtype)])
-            buf = torch.zeros(W, pack.numel(), dtype=pack.dtype, device=pack.device)
-            buf[self.rank] = pack
-            dist.all_reduce(buf)
-            parts = list(buf)
-            fs = [p[:n_f].view(2 * B, -1) for p in parts]   # each (stream 0 rows, stream 1 rows)
-            feats = torch.cat([f[:B] for f in fs] + [f[B:] for f in fs]).contiguous()
-            lab = torch.cat([p[n_f:n_f + B] for p in parts])
-            labels2 = torch.cat([lab, lab]).contiguous()
-            ssd = torch.stack([p[n_f + B:n_f + B + 3] for p in parts]).sum(0)   # fixed rank order: same bits on every rank
+        if self.collect and self.exact:
+            # ONE collective carries the three exactness exchanges: each rank contributes one record
+            # [rnc features (2B x 64) | labels (B) | 3 sums of squares]; RCCL all-gathers the records, while under gloo
+            # each rank writes its record into its own row of a zeroed [W, n] buffer that is all-reduced -- an all-gather
+            # spelt as a sum with zeros (exact in floating point), because a gloo all_gather of a freshly produced device
+            # tensor blocked the host for ~240 ms per call on this stack while all_reduce does not.
+            if hasattr(be, "dp_pack"):      # HIP backend: one pack kernel, one collective, one unpack kernel
+                rec = be.dp_pack()
+                if self._records is None:
+                    self._records = torch.empty(W, rec.numel(), dtype=rec.dtype, device=rec.device)
+                if dist.get_backend() == "nccl":
+                    dist.all_gather_into_tensor(self._records, rec)
+                else:
+                    self._records.zero_()
+                    self._records[self.rank].copy_(rec)
+                    dist.all_reduce(self._records)
+                ssd, feats, labels2 = be.dp_unpack(self._records, W)
+            else:
+                n_f = rnc.numel()
+                pack = torch.cat([rnc.reshape(-1), be.labels.reshape(-1).to(rnc.dtype), be.local_ssd().to(rnc.dtype)])
+                buf = torch.zeros(W, pack.numel(), dtype=pack.dtype, device=pack.device)
+                buf[self.rank] = pack
+                dist.all_reduce(buf)
+                parts = list(buf)
+                fs = [p[:n_f].view(2 * B, -1) for p in parts]   # each (stream 0 rows, stream 1 rows)
+                feats = torch.cat([f[:B] for f in fs] + [f[B:] for f in fs]).contiguous()
+                lab = torch.cat([p[n_f:n_f + B] for p in parts])
+                labels2 = torch.cat([lab, lab]).contiguous()
+                ssd = torch.stack([p[n_f + B:n_f + B + 3] for p in parts]).sum(0)   # fixed rank order: same bits on every rank
             losses = be.loss_backward(ssd, feats, labels2, (self.rank * B, W * B + self.rank * B))
         else:
             losses = be.loss_backward()
@@ -199,7 +241,7 @@ class DataParallelStep:
             pending.wait()
         else:
             grads = be.backward()
-            if W > 1:
+            if self.collect:
                 dist.all_reduce(grads)                      # one flat bucket
         be.adam(1.0 if (self.exact or W == 1) else 1.0 / W)
         return losses
@@ -207,7 +249,7 @@ class DataParallelStep:
     def global_losses(self, losses):
         """[total, mse_full, mse_missing, rmse_text, rmse_query, rmse_fused, rnc] of the GLOBAL batch."""
         l = losses.clone()
-        if self.world > 1 and self.exact:
+        if self.collect and self.exact:
             mse = l[1:3].clone()
             dist.all_reduce(mse)                            # MSE terms are local sums / B_global
             l[1:3] = mse
