@@ -544,6 +544,13 @@ int sdumc_loss_ssd(const sdumc_net_dims* d, const sdumc_net_io* io, float* ssd_o
  * whole batch (main_frame_val_text_missing.py:119-150). */
 int sdumc_dp_pack(const float* rnc, const float* labels, const float* ssd, int32_t B, int32_t rd, float* record,
                   void* stream);
+/* sdumc_loss_ssd + sdumc_dp_pack in one launch: the three sums of squares (text_hidden, cross_text, fused: rows [B, 2B)
+ * minus rows [0, B) of each [2B, .] output) are reduced in a fixed order by the last block to finish.  `workspace`
+ * (>= sdumc_dp_record_workspace_bytes(B), 4-byte aligned) must be ZERO before the first call; every call leaves it
+ * ready for the next. */
+size_t sdumc_dp_record_workspace_bytes(int32_t B);
+int sdumc_dp_record(int32_t B, int32_t rd, const float* text_hidden, const float* cross_text, const float* fused,
+                    const float* rnc, const float* labels, float* record, void* workspace, void* stream);
 int sdumc_dp_unpack(const float* records, int32_t W, int32_t B, int32_t rd, float* feats, float* labels2, float* ssd,
                     void* stream);
 /* loss values + gradients w.r.t. the five network outputs (written to the d_* buffers of `g`,

@@ -210,6 +210,9 @@ _SIGS = {
     "sdumc_loss_backward": (C.c_int, [C.POINTER(NetDims), C.POINTER(NetIO), C.POINTER(StepCfg), C.POINTER(NetGrads),
                                       C.c_void_p, C.c_size_t, C.c_void_p]),
     "sdumc_dp_pack": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sdumc_dp_record_workspace_bytes": (C.c_size_t, [C.c_int32]),
+    "sdumc_dp_record": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p, C.c_void_p]),
     "sdumc_dp_unpack": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
     "sdumc_step_grads_offset": (C.c_size_t, [C.POINTER(NetDims)]),

@@ -508,6 +508,89 @@ __global__ __launch_bounds__(256) void distill_apply_kernel(const DistillArgs a)
 }
 }  // namespace
 
+namespace {
+// The whole data-parallel exchange record of one rank in ONE launch: blockIdx.y = 0..2 -> partial sums of squares of the
+// three RMSE pairs (DCH elements per block), blockIdx.y = 3 -> copies of the RnC features and the labels.  The last
+// block to finish (device-scope counter) adds the partials of each pair in index order -- the same bits whatever the
+// scheduling -- writes the three sums behind the labels and re-arms the counter.
+struct DpRecordArgs {
+  int B, rd;
+  const float *th, *ct, *z, *rnc, *labels;
+  float* rec;        // [2*B*rd | B | 3]
+  float* part;       // [3][nblk_max]
+  unsigned* counter; // zero before the first launch; left zero by every launch
+  int nblk[3], nblk_max, ncopy;
+};
+__global__ __launch_bounds__(256) void dp_record_kernel(const DpRecordArgs a) {
+  __shared__ float red[4];
+  __shared__ bool last;
+  const int p = blockIdx.y;
+  const int nf = 2 * a.B * a.rd;
+  if (p == 3) {
+    if ((int)blockIdx.x < a.ncopy) {
+      const int i0 = blockIdx.x * DCH, i1 = min(nf + a.B, i0 + DCH);
+      for (int i = i0 + threadIdx.x; i < i1; i += 256) a.rec[i] = i < nf ? a.rnc[i] : a.labels[i - nf];
+    }
+  } else if ((int)blockIdx.x < a.nblk[p]) {
+    const int64_t per = p == 0 ? SDUMC_D : (p == 1 ? SDUMC_NQ * SDUMC_H : SDUMC_H);
+    const int64_t n = (int64_t)a.B * per;
+    const float* s0 = p == 0 ? a.th : (p == 1 ? a.ct : a.z);
+    const float* s1 = s0 + n;
+    const int64_t i0 = (int64_t)blockIdx.x * DCH, i1 = min(n, i0 + DCH);
+    float acc = 0.f;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+      const float d = s1[i] - s0[i];
+      acc += d * d;
+    }
+    const float sum = block_sum_256(acc, red);
+    if (threadIdx.x == 0) a.part[p * a.nblk_max + blockIdx.x] = sum;
+  }
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = atomicAdd(a.counter, 1u) == gridDim.x * gridDim.y - 1;
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  for (int q = 0; q < 3; ++q) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < a.nblk[q]; i += 256) acc += __builtin_nontemporal_load(a.part + q * a.nblk_max + i);
+    const float sum = block_sum_256(acc, red);
+    if (threadIdx.x == 0) a.rec[nf + a.B + q] = sum;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *a.counter = 0u;
+}
+}  // namespace
+
+extern "C" size_t sdumc_dp_record_workspace_bytes(int32_t B) {
+  const int64_t nb = ((int64_t)B * SDUMC_NQ * SDUMC_H + DCH - 1) / DCH;
+  return (size_t)(3 * nb + 16) * sizeof(float);
+}
+
+extern "C" int sdumc_dp_record(int32_t B, int32_t rd, const float* text_hidden, const float* cross_text, const float* fused,
+                               const float* rnc, const float* labels, float* record, void* workspace, void* stream) {
+  if (B <= 0 || rd <= 0 || !text_hidden || !cross_text || !fused || !rnc || !labels || !record || !workspace)
+    return SDUMC_EINVAL;
+  DpRecordArgs a;
+  a.B = B; a.rd = rd;
+  a.th = text_hidden; a.ct = cross_text; a.z = fused; a.rnc = rnc; a.labels = labels;
+  a.rec = record;
+  const int64_t per[3] = {SDUMC_D, SDUMC_NQ * SDUMC_H, SDUMC_H};
+  int mx = 1;
+  for (int p = 0; p < 3; ++p) {
+    a.nblk[p] = (int)(((int64_t)B * per[p] + DCH - 1) / DCH);
+    mx = a.nblk[p] > mx ? a.nblk[p] : mx;
+  }
+  a.nblk_max = a.nblk[1];
+  a.ncopy = (2 * B * rd + B + DCH - 1) / DCH;
+  mx = a.ncopy > mx ? a.ncopy : mx;
+  a.counter = reinterpret_cast<unsigned*>(workspace);
+  a.part = static_cast<float*>(workspace) + 16;
+  hipLaunchKernelGGL(dp_record_kernel, dim3(mx, 4), dim3(256), 0, as_stream(stream), a);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
 extern "C" int sdumc_mse_fwd_bwd(const float* pred, const float* target, int32_t rows, float denom, float weight,
                                  float* loss_out, float* dpred, void* stream) {
   if (!pred || !target || !loss_out || rows <= 0 || denom <= 0.f) return SDUMC_EINVAL;

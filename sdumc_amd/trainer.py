@@ -100,14 +100,17 @@ class HipBackend:
         return self.ssd[:3]
 
     def dp_pack(self):
-        """This rank's exchange record [rnc features | labels | local sums of squares] (one kernel after local_ssd)."""
+        """This rank's exchange record [rnc features | labels | local sums of squares] in one launch."""
         lib, _lib = self._lib.lib, self._lib
         B, rd = self.B, self._engine.RNC_DIM
         if self._record is None:
-            self._record = torch.empty(2 * B * rd + B + 3, device=self.params.device)
-        self.local_ssd()
-        _lib.check(lib.sdumc_dp_pack(_lib.ptr(self.call.rnc), _lib.ptr(self.labels), _lib.ptr(self.ssd), B, rd,
-                                     _lib.ptr(self._record), _lib.current_stream()), "sdumc_dp_pack")
+            dev = self.params.device
+            self._record = torch.empty(2 * B * rd + B + 3, device=dev)
+            self._record_ws = torch.zeros(lib.sdumc_dp_record_workspace_bytes(B), dtype=torch.uint8, device=dev)
+        c = self.call
+        _lib.check(lib.sdumc_dp_record(B, rd, _lib.ptr(c.text_hidden), _lib.ptr(c.cross_text), _lib.ptr(c.fused),
+                                       _lib.ptr(c.rnc), _lib.ptr(self.labels), _lib.ptr(self._record),
+                                       _lib.ptr(self._record_ws), _lib.current_stream()), "sdumc_dp_record")
         return self._record
 
     def dp_unpack(self, records, W):

@@ -196,3 +196,36 @@ def test_dp_exchange_record_pack_and_unpack_layout(W, B):
     assert torch.equal(feats, want_f)
     assert torch.equal(labels2, torch.cat([lab, lab]))
     assert torch.equal(ssd[:3], want_s)
+
+
+@pytest.mark.parametrize("B", [3, 64, 257])
+def test_dp_record_one_launch_equals_ssd_plus_pack_and_is_deterministic(B):
+    """sdumc_dp_record (sums of squares + pack, last-block ordered reduction) == float64 sums to 1e-5 relative, the copied
+    part bit-exact, identical bits across repeated launches, workspace left re-armed."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from sdumc_amd import _lib, engine
+    lib = _lib.lib
+    rd, D, H, NQ = engine.RNC_DIM, engine.D, engine.H, engine.NQ
+    g = torch.Generator().manual_seed(B)
+    th = torch.randn(2 * B, D, generator=g).cuda()
+    ct = torch.randn(2 * B, NQ, H, generator=g).cuda()
+    z = torch.randn(2 * B, H, generator=g).cuda()
+    rnc = torch.randn(2 * B, rd, generator=g).cuda()
+    labels = torch.randn(B, generator=g).cuda()
+    ws = torch.zeros(lib.sdumc_dp_record_workspace_bytes(B), dtype=torch.uint8, device="cuda")
+    nf = 2 * B * rd
+    outs = []
+    for _ in range(3):
+        rec = torch.full((nf + B + 3,), float("nan"), device="cuda")
+        _lib.check(lib.sdumc_dp_record(B, rd, _lib.ptr(th), _lib.ptr(ct), _lib.ptr(z), _lib.ptr(rnc), _lib.ptr(labels),
+                                       _lib.ptr(rec), _lib.ptr(ws), _lib.current_stream()), "sdumc_dp_record")
+        outs.append(rec.clone())
+    torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[1], outs[2])
+    rec = outs[0]
+    assert torch.equal(rec[:nf], rnc.reshape(-1))
+    assert torch.equal(rec[nf:nf + B], labels)
+    want = [float(((x[B:].double() - x[:B].double()) ** 2).sum()) for x in (th, ct, z)]
+    np.testing.assert_allclose(rec[nf + B:].cpu().numpy(), np.array(want), rtol=1e-5)
+    assert int(ws[:4].view(torch.int32).item()) == 0
