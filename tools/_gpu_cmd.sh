@@ -1,7 +1,8 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_dp.py -x -q 2>&1 | tail -3
-for i in 1 2; do
-SDUMC_FORCE_DP=1 timeout 300 python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | cut -c100-200
-timeout 300 python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | cut -c100-200
-done
-SDUMC_DIST_BACKEND=gloo timeout 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29571 bench.py --gpus 2 --steps 20 --warmup 5 --no-roofline 2>/dev/null | tail -1 | cut -c100-200
+export TMPDIR=/tmp
+timeout 600 python bench.py > gpurun_out/bench_r1n.json 2> gpurun_out/bench_r1n.err; echo rc=$?; tail -1 gpurun_out/bench_r1n.json | cut -c1-250
+timeout 300 python bench.py --workload c5 --no-cpu-baseline > gpurun_out/bench_r1n_c5.json 2>/dev/null; tail -1 gpurun_out/bench_r1n_c5.json | cut -c100-250
+timeout 300 python bench.py --workload c5 --bf16 --no-cpu-baseline > gpurun_out/bench_r1n_c5_bf16.json 2>/dev/null; tail -1 gpurun_out/bench_r1n_c5_bf16.json | cut -c100-250
+timeout 300 python bench.py --workload c1 --no-cpu-baseline > gpurun_out/bench_r1n_c1.json 2>/dev/null; tail -1 gpurun_out/bench_r1n_c1.json | cut -c100-250
+timeout 300 python bench.py --bf16 --no-cpu-baseline > gpurun_out/bench_r1n_bf16.json 2>/dev/null; tail -1 gpurun_out/bench_r1n_bf16.json | cut -c100-250
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r1n -o p -- python3 bench.py --steps 10 --warmup 3 --serial-lanes --no-cpu-baseline --no-roofline > gpurun_out/prof_r1n.log 2>&1; echo rc=$?; ls gpurun_out/prof_r1n
