@@ -232,7 +232,7 @@ def main():
     if args.serial_lanes:
         _lib.lib.sdumc_set_concurrency(0)
     if args.background_lane:
-        _lib.lib.sdumc_set_background_lane(1)
+        _lib.lib.sdumc_set_background_lane(int(os.environ.get("SDUMC_BG_MODE", "2")))
     flat, lay = init_flat_params(engine, dev)
     batch = [t.to(dev) for t in synthetic_shard(B_PER_GPU, rank)]
 

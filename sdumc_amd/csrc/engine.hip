@@ -353,7 +353,7 @@ SideStreams& side_streams() {
   return S;
 }
 bool g_concurrency = true;   // sdumc_set_concurrency(0): everything on the caller's stream (profiling)
-bool g_background = false;   // sdumc_set_background_lane(1): the Cross_Attention-site GEMMs leave the grouped launches for lane 3
+int g_background = 0;      // 0 off, 1 forward + backward, 2 forward only;   // sdumc_set_background_lane(1): the Cross_Attention-site GEMMs leave the grouped launches for lane 3
 // created outside any capture (called from the *_workspace_bytes queries every caller makes first)
 void ensure_side_streams() {
   static std::mutex mu;
@@ -385,7 +385,10 @@ void ensure_side_streams() {
     // hipExtStreamCreateWithCUMask -- meant to keep free CUs for the chain's small kernels -- made the whole step
     // 60 % slower (3.57 vs 2.22 ms), and 128x128 tiles on this lane (2 workgroups per CU, room for a small kernel beside
     // them) 12 % slower; the lowest stream priority made no difference.  Re-measured after the dW batches moved to this
-    // lane (r1n): 27.7 k samples/s with the option against 29.7 k without, at every priority of this stream.
+    // lane (r1n): 27.7 k samples/s with the option (forward + backward, mode 1) against 29.7 k without, at every priority of
+    // this stream; forward only (mode 2) 30.0-30.2 k against 29.7-29.9 k (+0.9 %, six alternations); the same GEMMs issued at
+    // the START of the utterance-level chain, so that they can only run beside it: 29.75 k = no gain -- the small kernels
+    // slow down by as much as is hidden.
     if (hipStreamCreateWithPriority(&S.bg, hipStreamNonBlocking, prio) != hipSuccess) return;
   }
   S.ok = true;
@@ -402,6 +405,7 @@ struct Ctx {
   float* G;     // gradient bucket (backward only)
   hipStream_t sts[4] = {nullptr, nullptr, nullptr, nullptr};
   bool bg = false;   // the Cross_Attention-site key projections are issued on lane 3 (background)
+  bool bgb = false;  // ... and their backward too
   mutable float* scr = nullptr;   // scratch of the current lane
   bool multi = false;
   // weight-gradient GEMMs of the utterance-level layers, queued by lin_bwd* and issued in batches on lane 3 (flush_dw)
@@ -411,7 +415,8 @@ struct Ctx {
     const SideStreams& S = side_streams();
     sts[0] = st;
     multi = S.ok && g_concurrency;
-    bg = g_background;                    // the launch decomposition is the same with and without real streams
+    bg = g_background != 0;               // the launch decomposition is the same with and without real streams
+    bgb = g_background == 1;
     sts[1] = multi ? S.s[0] : st;
     sts[2] = multi ? S.s[1] : st;
     sts[3] = multi ? S.bg : st;   // lane 3: deferred dW batches (and, with the background option, the Cross_Attention keys)
@@ -936,7 +941,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   for (int m = 0; m < 3; ++m) {
     c.use(LANE_OF[m]);
     RET(pool_bwd(c, 1, m, c.p(pl.d_ca_out) + (int64_t)m * V * NQ * D, c.p(pl.d_qp) + (int64_t)m * V * NQ * D));
-    if (c.bg) {   // the Cross_Attention input_proj backward has everything it needs: background lane, beside 7'-3'
+    if (c.bgb) {   // the Cross_Attention input_proj backward has everything it needs: background lane, beside 7'-3'
       RET(link(c, LANE_OF[m], 3));
       c.use(3);
       RET(keys_gemm_bwd(c, m, 1, 2));
@@ -1002,14 +1007,14 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   //   fra2utt_m pooling backward (the shared context vector's gradient = sum of the per-sample dq)
   //   -> input_proj backward of both sites (grouped) -> dx = sum of the (up to) four masked paths into the
   //   projected features -> frame_dim_reshape_m: dW = dx^T feat (split-K) with db fused
-  if (c.bg) RET(link(c, 3, 0));   // dxd of the Cross_Attention sites (background option)
+  if (c.bgb) RET(link(c, 3, 0));   // dxd of the Cross_Attention sites (background option)
   RET(fork_all(c));
   for (int m = 0; m < 3; ++m) {
     c.use(LANE_OF[m]);
     float* dq = c.p(pl.dq_fra) + (int64_t)m * V * D;
     RET(pool_bwd(c, 0, m, c.p(pl.d_hpre) + (int64_t)m * V * D, dq));
     RET(colsum(c, dq, V, D, D, c.G + pm.fra_ctx[m], 0));
-    RET(keys_gemm_bwd(c, m, c.bg ? 0 : 0, c.bg ? 1 : 2));
+    RET(keys_gemm_bwd(c, m, 0, c.bgb ? 1 : 2));
     for (int s = 0; s < (m == 1 ? S : 1); ++s) {
       const int T = pl.T[m][s];
       sdumc_dropsum ds;
@@ -1107,7 +1112,7 @@ extern "C" int sdumc_set_concurrency(int on) {
   return SDUMC_OK;
 }
 extern "C" int sdumc_set_background_lane(int on) {
-  g_background = on != 0;
+  g_background = on;
   return SDUMC_OK;
 }
 
