@@ -122,6 +122,42 @@ def test_backward_vs_oracle(E, mode, equal_T):
     assert torch.equal(grads, again)
 
 
+@pytest.mark.parametrize("B,Tn,dims", [
+    (1, (1, 1, 1, 1), (4, 8, 12, 8)),          # one utterance, one frame per modality, minimal widths
+    (2, (3, 1, 2, 5), (7, 9, 5, 9)),            # widths that are not multiples of 4 (no 16-byte rows anywhere)
+    (3, (65, 1, 64, 2), (20, 36, 28, 36)),      # T straddling the 64-row pooling chunk; one text frame
+    (1, (512, 300, 257, 1), (16, 16, 16, 16)),  # long ragged sequences for a single utterance
+])
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_edge_shapes_forward_backward_vs_oracle(E, mode, B, Tn, dims):
+    """Smallest and most awkward shapes the boundary admits: B = 1 (RnC over n = 2 rows), single frames (softmax over one
+    element), odd feature widths, sequences that straddle the kernels' chunk sizes, an all-zero (fully padded) utterance."""
+    from oracle import sdumc_oracle as O
+    P = O.init_params(dims, seed=21)
+    flat, lay = flat_from(E, P, dims)
+    audio, text, video, feat4, _ = O.synthetic_batch(B, Tn, dims, seed=6)
+    if B > 1:
+        video[B - 1] = 0                      # a fully padded utterance: uniform attention over zero frames
+    seed, call0 = 7, 2
+    g = torch.Generator().manual_seed(2)
+    V = 2 * B
+    douts = [torch.randn(V, 1, generator=g), torch.randn(V, 128, generator=g), torch.randn(V, 64, generator=g),
+             torch.randn(V, 256, generator=g), torch.randn(V, 7, 128, generator=g)]
+    rng = E.RngState(seed, "cuda", call=call0)
+    call = E.NetCall(flat, audio.cuda(), [text.cuda(), feat4.cuda()], video.cuda(), mode == "train", rng)
+    outs = [o.clone() for o in call.forward()]
+    for s, tx in enumerate((text, feat4)):
+        d = O.DropCtx("eval" if mode == "eval" else "philox", seed, call0 + s)
+        y, (z, r, th, ct) = O.forward({k: v.double() for k, v in P.items()}, audio.double(), tx.double(), video.double(), d)
+        for name, got, want in zip(NAMES, outs, (y, z, r, th, ct)):
+            close(got[s * B:(s + 1) * B], want, 1e-4, f"{name} stream {s}")
+    want = _oracle_grads(P, audio, [text, feat4], video, mode, seed, call0, douts)
+    grads = call.backward(*[d.cuda().contiguous() for d in douts])
+    gv = lay.views(torch.cat([grads.cpu(), torch.zeros(lay.total - lay.live)]))
+    for k in lay.live_names():
+        close(gv[k], want[k], 2e-4, k)
+
+
 def test_train_step_vs_reference_golden(E, golden):
     from oracle import sdumc_oracle as O
     from tests.golden.make_goldens import digest
@@ -213,6 +249,33 @@ def test_mosei_shape_forward_and_step_vs_oracle(E):
     pv = lay.views(flat.cpu())
     for k in ("frame_dim_reshape_1.weight", "cross_att_fra2utt_0.input_proj.weight", "fc_out_v.weight"):
         close((pv[k] - P[k]) * 1e4, (Pd[k] - P[k]) * 1e4, 2e-2, k)
+
+
+@pytest.mark.parametrize("B", [1, 2, 3])
+def test_train_step_smallest_batches_vs_oracle(E, B):
+    """The fused step at the smallest batches: B = 1 puts n = 2 rows into the RnC loss (one positive, no negative per anchor),
+    B = 2 / 3 the first non-trivial masks; label ties included (B = 3: two equal labels)."""
+    from oracle import sdumc_oracle as O
+    dims, Tn = (24, 16, 20, 16), (9, 2, 5, 3)
+    P = O.init_params(dims, seed=4)
+    flat, lay = flat_from(E, P, dims)
+    audio, text, video, feat4, vals = O.synthetic_batch(B, Tn, dims, seed=77)
+    if B == 3:
+        vals[2] = vals[0]
+    ts = E.TrainStep(flat, B, Tn, dims, seed=5)
+    ts.set_batch(audio.cuda(), text.cuda(), video.cuda(), feat4.cuda(), vals.cuda())
+    losses = ts.run().cpu().numpy()
+    Pd = {k: v.clone() for k, v in P.items()}
+    loss, terms, grads, outs = O.train_step(Pd, {}, audio, text, video, feat4, vals, mode="philox", seed=5, step=0)
+    want = np.array([float(t) for t in terms])
+    assert np.array_equal(np.isfinite(losses[1:7]), np.isfinite(want))       # same NaN/inf pattern as the reference math
+    fin = np.isfinite(want)
+    np.testing.assert_allclose(losses[1:7][fin], want[fin], rtol=1e-4, atol=1e-6)
+    if np.isfinite(float(loss)):
+        np.testing.assert_allclose(losses[0], float(loss), rtol=1e-4)
+        gv = lay.views(torch.cat([ts.grads.cpu(), torch.zeros(lay.total - lay.live)]))
+        for k in lay.live_names():
+            close(gv[k], grads[k], 5e-4, k)
 
 
 def test_full_c2_batch_properties(E):
