@@ -151,6 +151,10 @@ typedef struct sdumc_attnpool {
                           blocks used on their own (FRA2UTT_new / Cross_Attention default to input_dim = 1024,
                           model :47,:71).  Every "256" in the shapes above and below then reads `dim`; the dropout
                           descriptors carry width = dim; workspaces are sized by the *_dim queries */
+  const int32_t* lengths; /* EXTENSION (default NULL = the reference's behaviour, where zero-padded frames take
+                          part in the softmax, read_data.py:139-151 / model :63,:90): device int32 [V], valid frames per
+                          virtual sample; frames t >= max(1, lengths[v]) get weight exactly 0 (key-padding mask) and
+                          therefore zero gradient in sdumc_attnpool_bwd, which needs no mask of its own */
 } sdumc_attnpool;
 
 size_t sdumc_attnpool_fwd_workspace_bytes(int32_t V, int32_t T, int32_t nq);
@@ -477,6 +481,10 @@ typedef struct sdumc_net_io {
   float* rnc;            /* [V, 64]     feat4rnc */
   float* text_hidden;    /* [V, 256]    text_hidden (after cross_text_query_mlp, model :329) */
   float* cross_text;     /* [V, 7, 128] cross_hiddens[:,1] */
+  /* EXTENSION, default all NULL = reference behaviour: device int32 [B] valid frame counts of audio, text, video, feat4
+   * (maxT - pad_len of toolkit/data/feat_data.py:232-253's `pads`); when given, the six attention poolings mask the
+   * padded frames (sdumc_attnpool.lengths).  All four (three when streams == 1) or none. */
+  const int32_t* lengths[4];
 } sdumc_net_io;
 
 /* The network-level calls issue independent branches (the three per-modality chains; the dW GEMMs) on up to

@@ -49,7 +49,8 @@ class AttnPool(C.Structure):
                 ("x", C.c_void_p), ("keys", C.c_void_p), ("q", C.c_void_p), ("q_stride", C.c_int64),
                 ("scale", C.c_float), ("x_drop", Dropout), ("out_drop", Dropout),
                 ("attn", C.c_void_p), ("pooled", C.c_void_p), ("out", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("dim", C.c_int32)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("dim", C.c_int32),
+                ("lengths", C.c_void_p)]
 
 
 class AttnPoolBwd(C.Structure):
@@ -76,7 +77,8 @@ class NetIO(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
                 # outputs, each [streams*B, ...]
                 ("vals", C.c_void_p), ("fused", C.c_void_p), ("rnc", C.c_void_p),
-                ("text_hidden", C.c_void_p), ("cross_text", C.c_void_p)]
+                ("text_hidden", C.c_void_p), ("cross_text", C.c_void_p),
+                ("lengths", C.c_void_p * 4)]
 
 
 class NetGrads(C.Structure):

@@ -109,6 +109,8 @@ __global__ __launch_bounds__(256, C == 1 ? 4 : 2) void attn_fwd_partial_kernel(c
   const int T = p.T, nq = p.nq;
   const int t0 = chunk * CH;
   const FwdWs w = fwd_ws(ws, p.V, nchunk, nq, DD);
+  // key-padding extension: frames at or beyond Tv get weight 0 (a chunk wholly beyond Tv reports max -inf, sum 0)
+  const int Tv = p.lengths ? min(T, max(1, p.lengths[v])) : T;
 
   // scores of this wave's 16 rows against the (<= 8) queries
   float* q_s = red;
@@ -125,7 +127,7 @@ __global__ __launch_bounds__(256, C == 1 ? 4 : 2) void attn_fwd_partial_kernel(c
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int t = t0 + 16 * wave + 4 * kk + e;
-    s[e] = t < T ? p.scale * s4[e] : -INFINITY;
+    s[e] = t < Tv ? p.scale * s4[e] : -INFINITY;
     mx = fmaxf(mx, s[e]);
   }
   mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
@@ -134,12 +136,12 @@ __global__ __launch_bounds__(256, C == 1 ? 4 : 2) void attn_fwd_partial_kernel(c
   __syncthreads();
   if (tid < 16) cstat[tid] = fmaxf(fmaxf(wstat[0][tid], wstat[1][tid]), fmaxf(wstat[2][tid], wstat[3][tid]));
   __syncthreads();
-  const float mc = cstat[r16];          // chunk max of my query column (finite: every chunk has >= 1 row)
+  const float mc = cstat[r16];          // chunk max of my query column (-inf only for a chunk wholly beyond Tv)
   float lsum = 0.f;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int rl = 16 * wave + 4 * kk + e, t = t0 + rl;
-    const float pe = t < T ? expf(s[e] - mc) : 0.f;
+    const float pe = t < Tv ? expf(s[e] - mc) : 0.f;
     lsum += pe;
     if (r16 < MAXQ) P_s[rl * MAXQ + r16] = pe;
     if (r16 < nq && t < T) p.attn[((size_t)v * T + t) * nq + r16] = pe;   // normalised by the combine kernel

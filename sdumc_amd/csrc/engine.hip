@@ -188,6 +188,7 @@ struct Plan {
   int64_t dz[2][3], dxd[2][3], dx[3][2];
   int64_t d_hpre, d_u1, d_u, d_att1, d_att2, d_alpha, d_qin, d_q, d_qp, d_ca_out, d_c1, d_c, d_h, d_e1, d_e2, d_beta,
       d_z, d_r1, dq_fra;
+  int64_t lens = 0;          // int32 [3][V]: valid frames per (modality, virtual sample) when sdumc_net_io.lengths is given
   int64_t scratch[4] = {0, 0, 0, 0}, scratch_floats = 0;   // one scratch per lane (stream)
   int64_t alloc(int64_t n) {
     const int64_t o = cur;
@@ -316,6 +317,7 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
   p.d_z = p.alloc((int64_t)V * H);
   p.d_r1 = p.alloc((int64_t)V * RD);
   p.dq_fra = p.alloc(3LL * V * D);
+  p.lens = p.alloc(3LL * V);
   // scratch shared by split-K slabs, column-sum partials and the attention-pool dq slabs
   int64_t sc = 1 << 16;
   const int din[3] = {d.da, d.dt, d.dv};
@@ -612,7 +614,22 @@ int check_io(const sdumc_net_dims* d, const sdumc_net_io* io) {
   if (d->train && !io->rng_state) return SDUMC_EINVAL;
   if (reinterpret_cast<uintptr_t>(io->workspace) & 255) return SDUMC_EINVAL;
   if (reinterpret_cast<uintptr_t>(io->params) & 15) return SDUMC_EINVAL;
+  {   // key-padding lengths: all of (audio, text, video[, feat4]) or none
+    const int need = d->streams == 2 ? 4 : 3;
+    int have = 0;
+    for (int i = 0; i < need; ++i) have += io->lengths[i] != nullptr;
+    if (have != 0 && have != need) return SDUMC_EINVAL;
+  }
   return SDUMC_OK;
+}
+
+// lens[m][s * B + b] = lengths of modality m for stream s (audio / video: the same for both streams; text: stream 1 reads feat4)
+__global__ void expand_lengths_kernel(const int32_t* la, const int32_t* lt, const int32_t* lv, const int32_t* l4, int B, int S,
+                                      int32_t* lens) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x, V = B * S;
+  if (i >= 3 * V) return;
+  const int m = i / V, v = i - m * V, s = v / B, b = v - s * B;
+  lens[i] = m == 0 ? la[b] : (m == 2 ? lv[b] : (s == 0 ? lt[b] : l4[b]));
 }
 
 // the attention-pooling descriptor of (site kind k, modality m, run sg) — shared by forward and backward
@@ -641,6 +658,8 @@ sdumc_attnpool attn_desc(const Ctx& c, int k, int m, const Seg& sg) {
   a.pooled = c.p(pl.pooled[k][m]) + (int64_t)sg.s0 * pl.B * nq * D;
   float* outbase = k == 0 ? c.p(pl.hpre) + (int64_t)m * pl.V * D : c.p(pl.ca_out) + (int64_t)m * pl.V * NQ * D;
   a.out = outbase + (int64_t)sg.s0 * pl.B * nq * D;
+  if (c.io.lengths[0])
+    a.lengths = reinterpret_cast<const int32_t*>(c.p(pl.lens)) + (int64_t)m * pl.V + (int64_t)sg.s0 * pl.B;
   return a;
 }
 
@@ -685,6 +704,12 @@ int forward(const Ctx& c) {
   const ParamMap& pm = c.pm;
   const int B = pl.B, S = pl.S, V = pl.V;
   const int din[3] = {c.d.da, c.d.dt, c.d.dv};
+  if (c.io.lengths[0]) {
+    hipLaunchKernelGGL(expand_lengths_kernel, dim3((3 * V + 255) / 256), dim3(256), 0, c.st, c.io.lengths[0], c.io.lengths[1],
+                       c.io.lengths[2], S == 2 ? c.io.lengths[3] : c.io.lengths[1], B, S,
+                       reinterpret_cast<int32_t*>(c.p(pl.lens)));
+    SDUMC_CHECK_LAUNCH();
+  }
   // 1+2. three independent per-modality chains, one per lane:
   //      keep-bits of the two frame-level input dropouts -> frame_dim_reshape_m (model :282-284; audio/video once
   //      for both streams) -> keys of fra2utt_m AND cross_att_fra2utt_m -> FRA2UTT pooling (model :288-290)

@@ -55,6 +55,13 @@ def collate(instances):
     return batch, pads, emos, vals, names
 
 
+def lengths_from_pads(data):
+    """Valid frame counts (audio, text, video, feat4) of one batch tuple = maxT_m - pad_len (the `pads` the reference's
+    collater returns and never uses, feat_data.py:244-253): what `lengths=` of the key-padding extension takes."""
+    b, pads = data[0], data[1]
+    return tuple(torch.tensor([b[k].shape[1] - int(p) for p in pad], dtype=torch.int32) for k, pad in zip(KEYS, pads))
+
+
 def unpack(data, device):
     """What train_or_eval_model reads from one batch tuple (main :94-109), moved to `device`."""
     b = data[0]

@@ -100,10 +100,29 @@ class RngState:
         return int(self.t[2].item()) & 0xFFFFFFFF
 
 
-class NetCall:
-    """One network invocation (1 or 2 streams): owns workspace + outputs, supports backward."""
+def _lengths_arg(lengths, B, n, device):
+    """(audio, text, video[, feat4]) valid-frame counts -> n contiguous cuda int32 tensors of B entries."""
+    if lengths is None:
+        return None
+    lengths = list(lengths)
+    if len(lengths) != n:
+        raise _lib.SdumcError(f"lengths: expected {n} per-modality tensors (audio, text, video" + (", feat4)" if n == 4 else ")"))
+    out = []
+    for l in lengths:
+        t = torch.as_tensor(l, dtype=torch.int32).reshape(-1).to(device).contiguous()
+        if t.numel() != B:
+            raise _lib.SdumcError("lengths: one entry per sample of the batch")
+        out.append(t)
+    return out
 
-    def __init__(self, flat_params, audio, texts, video, train, rng, sample0=0, p_mlp=P_MLP, bf16=False):
+
+class NetCall:
+    """One network invocation (1 or 2 streams): owns workspace + outputs, supports backward.
+    `lengths` (extension, default None = the reference's behaviour): per-modality valid frame counts
+    (audio, text[, feat4 when two streams], video -> given as (audio, text, video) or (audio, text, video, feat4));
+    padded frames are then masked out of the six attention poolings."""
+
+    def __init__(self, flat_params, audio, texts, video, train, rng, sample0=0, p_mlp=P_MLP, bf16=False, lengths=None):
         texts = list(texts)
         _require_cuda(flat_params, audio, video, *texts)
         S = len(texts)
@@ -141,6 +160,10 @@ class NetCall:
         io.workspace, io.workspace_bytes = ptr(self.workspace), nbytes
         io.vals, io.fused, io.rnc = ptr(self.vals), ptr(self.fused), ptr(self.rnc)
         io.text_hidden, io.cross_text = ptr(self.text_hidden), ptr(self.cross_text)
+        self._lengths = _lengths_arg(lengths, B, 4 if S == 2 else 3, dev)
+        if self._lengths is not None:
+            for i, t in enumerate(self._lengths):
+                io.lengths[i] = ptr(t)
         self.io = io
 
     def forward(self):
@@ -223,6 +246,22 @@ class TrainStep:
         self.video.copy_(video, non_blocking=True)
         self.feat4.copy_(feat4, non_blocking=True)
         self.labels.copy_(labels.reshape(-1), non_blocking=True)
+
+    def set_lengths(self, lengths):
+        """Key-padding extension: (audio, text, video, feat4) valid frame counts of the current batch, or None to go back
+        to the reference's behaviour (padded frames take part in the softmax)."""
+        new = _lengths_arg(lengths, self.B, 4, self.params.device)
+        if new is None:
+            self._lengths = None
+            for i in range(4):
+                self.io.lengths[i] = None
+            return
+        if getattr(self, "_lengths", None) is None:
+            self._lengths = [torch.empty(self.B, dtype=torch.int32, device=self.params.device) for _ in range(4)]
+            for i, t in enumerate(self._lengths):
+                self.io.lengths[i] = ptr(t)
+        for dst, src in zip(self._lengths, new):
+            dst.copy_(src, non_blocking=True)      # resident buffers: a captured graph keeps reading the same addresses
 
     def set_lr(self, lr):
         self.hyper[0] = lr

@@ -24,10 +24,10 @@ class _NetFn(torch.autograd.Function):
     """One reference forward call (one stream) = sdumc_net_forward; backward = sdumc_net_backward."""
 
     @staticmethod
-    def forward(ctx, module, audio, text, video, call_index, *live_params):
+    def forward(ctx, module, audio, text, video, call_index, lengths, *live_params):
         rng = engine.RngState(module.seed, audio.device, call=call_index)
         call = engine.NetCall(module._flat, audio, [text], video, True, rng, sample0=module.sample0,
-                              p_mlp=module.dropout_p)
+                              p_mlp=module.dropout_p, lengths=lengths)
         outs = call.forward()
         ctx.call, ctx.module = call, module
         return tuple(outs)
@@ -46,7 +46,7 @@ class _NetFn(torch.autograd.Function):
                 n *= s
             out.append(grads[off:off + n].view(shape))
         ctx.call = None
-        return (None, None, None, None, None) + tuple(out)
+        return (None, None, None, None, None, None) + tuple(out)
 
 
 class WengnetMOSEIMultViewsTextMissing(nn.Module):
@@ -115,7 +115,9 @@ class WengnetMOSEIMultViewsTextMissing(nn.Module):
                 self._reflatten()
                 return
 
-    def forward(self, batch):
+    def forward(self, batch, lengths=None):
+        """`lengths` is an extension (default None = the reference's behaviour): (audio, text, video) valid frame counts
+        per sample; padded frames are then masked out of the attention poolings instead of joining the softmax."""
         audio, text, video = batch[0], batch[1], batch[2]       # batch[-1] = missing_flag: read and ignored (model :278)
         self._check_flat()
         if not audio.is_cuda:
@@ -126,14 +128,15 @@ class WengnetMOSEIMultViewsTextMissing(nn.Module):
             self._calls += 1
             if torch.is_grad_enabled():
                 live = [self._get(n) for n in self._live_names]
-                vals, fused, rnc, th, ct = _NetFn.apply(self, audio, text, video, call_index, *live)
+                vals, fused, rnc, th, ct = _NetFn.apply(self, audio, text, video, call_index, lengths, *live)
             else:
                 rng = engine.RngState(self.seed, audio.device, call=call_index)
                 vals, fused, rnc, th, ct = engine.NetCall(self._flat, audio, [text], video, True, rng,
-                                                          sample0=self.sample0, p_mlp=self.dropout_p).forward()
+                                                          sample0=self.sample0, p_mlp=self.dropout_p,
+                                                          lengths=lengths).forward()
         else:
             vals, fused, rnc, th, ct = engine.NetCall(self._flat, audio, [text], video, False, None,
-                                                      p_mlp=self.dropout_p).forward()
+                                                      p_mlp=self.dropout_p, lengths=lengths).forward()
         return vals, [fused, rnc, th, ct]
 
 

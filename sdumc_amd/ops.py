@@ -68,9 +68,11 @@ def gemm(layout, A, B, M, N, K, bias=None, C_out=None, lda=None, ldb=None, ldc=N
     return Cs if isinstance(A, (list, tuple)) else Cs[0]
 
 
-def attnpool_desc(x, keys, q, V, T, nq, x_samples, q_stride, x_drop, out_drop, attn, pooled, out, scale=0.3, dim=0):
+def attnpool_desc(x, keys, q, V, T, nq, x_samples, q_stride, x_drop, out_drop, attn, pooled, out, scale=0.3, dim=0,
+                  lengths=None):
     a = _lib.AttnPool()
     a.dim = dim
+    a.lengths = ptr(lengths)   # int32 [V] key-padding extension, or None = the reference's behaviour
     a.V, a.T, a.nq, a.x_samples = V, T, nq, x_samples
     a.x, a.keys, a.q, a.q_stride, a.scale = ptr(x), ptr(keys), ptr(q), q_stride, scale
     if x_drop is not None:
@@ -81,14 +83,17 @@ def attnpool_desc(x, keys, q, V, T, nq, x_samples, q_stride, x_drop, out_drop, a
     return a
 
 
-def attnpool_fwd(x, keys, q, nq, x_samples=None, q_shared=False, x_drop=None, out_drop=None):
+def attnpool_fwd(x, keys, q, nq, x_samples=None, q_shared=False, x_drop=None, out_drop=None, lengths=None):
     V, T, Dm = keys.shape
     dev = keys.device
     attn = torch.empty(V, T, nq, device=dev)
     pooled = torch.empty(V, nq, Dm, device=dev)
     out = torch.empty(V, nq, Dm, device=dev)
+    if lengths is not None and (lengths.dtype != torch.int32 or not lengths.is_cuda or lengths.numel() != V):
+        raise _lib.SdumcError("lengths must be a cuda int32 tensor with one entry per virtual sample")
     a = attnpool_desc(x, keys, q, V, T, nq, x_samples or x.shape[0], 0 if q_shared else nq * Dm, x_drop, out_drop,
-                      attn, pooled, out)
+                      attn, pooled, out, lengths=lengths)
+    a._keep_lengths = lengths
     need = lib.sdumc_attnpool_fwd_workspace_bytes(V, T, nq)
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
     a.workspace, a.workspace_bytes = ptr(ws), need

@@ -1,2 +1,4 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_gpu_net.py -x -q -k smallest_batches 2>&1 | tail -30
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -4
+timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+for i in 1 2; do timeout 300 python bench.py --steps 100 --warmup 20 --no-cpu-baseline --no-roofline 2>/dev/null | tail -1 | cut -c100-200; done
