@@ -21,7 +21,7 @@ __global__ void adam_hyper_kernel(float* hyper, double beta1, double beta2) {
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n4,
                                                    int64_t n, const float* hyper, float beta1, float beta2, float eps,
-                                                   float wd, float gscale) {
+                                                   float wd, float gscale, uint32_t* rng, uint32_t rng_inc) {
   const float step_size = hyper[2], bc2_sqrt = hyper[3];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n4) {
@@ -40,8 +40,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
     reinterpret_cast<f32x4*>(m)[i] = mm;
     reinterpret_cast<f32x4*>(v)[i] = vv;
   }
-  // scalar tail
+  // scalar tail (+ the dropout call counter: every reader of this step is ordered before this launch)
   if (i == 0) {
+    if (rng) rng[2] += rng_inc;
     for (int64_t t = n4 * 4; t < n; ++t) {
       const float ge = g[t] * gscale + wd * p[t];
       m[t] = m[t] + (ge - m[t]) * (1.f - beta1);
@@ -53,20 +54,34 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
 
 }  // namespace
 
-extern "C" int sdumc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
-                               float* hyper, float beta1, float beta2, float eps, float weight_decay,
-                               float grad_scale, void* stream) {
+extern "C" int sdumc_adam_hyper_(float* hyper, float beta1, float beta2, void* stream) {
+  if (!hyper) return SDUMC_EINVAL;
+  hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(1), 0, as_stream(stream), hyper, (double)beta1, (double)beta2);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_adam_apply_(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                                 const float* hyper, float beta1, float beta2, float eps, float weight_decay,
+                                 float grad_scale, uint32_t* rng_state, uint32_t rng_inc, void* stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper || n <= 0) return SDUMC_EINVAL;
   if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
        reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15)
     return SDUMC_EINVAL;
-  hipStream_t st = as_stream(stream);
-  hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(1), 0, st, hyper, (double)beta1, (double)beta2);
-  SDUMC_CHECK_LAUNCH();
   const int64_t n4 = n / 4;
   const int64_t threads = n4 > 0 ? n4 : 1;
-  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, param, grad, exp_avg,
-                     exp_avg_sq, n4, n, hyper, beta1, beta2, eps, weight_decay, grad_scale);
+  hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), param, grad,
+                     exp_avg, exp_avg_sq, n4, n, hyper, beta1, beta2, eps, weight_decay, grad_scale, rng_state, rng_inc);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
+}
+
+extern "C" int sdumc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                               float* hyper, float beta1, float beta2, float eps, float weight_decay,
+                               float grad_scale, void* stream) {
+  if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper || n <= 0) return SDUMC_EINVAL;
+  int rc = sdumc_adam_hyper_(hyper, beta1, beta2, stream);
+  if (rc) return rc;
+  return sdumc_adam_apply_(param, grad, exp_avg, exp_avg_sq, n, hyper, beta1, beta2, eps, weight_decay, grad_scale, nullptr,
+                           0u, stream);
 }

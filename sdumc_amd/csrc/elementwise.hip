@@ -19,6 +19,16 @@ __global__ void relu_drop_bwd_kernel(const float* dy, const float* y, float scal
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dz[i] = y[i] > 0.f ? dy[i] * scale : 0.f;
 }
+__global__ void relu_drop_bwd_add_kernel(const float* dy, const float* y, float scale, float* dz, int64_t n,
+                                         const float* add, int row_len, int col0, int width) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float g = dy[i];
+  const int64_t row = i / row_len;
+  const int col = (int)(i - row * row_len) - col0;
+  if (col >= 0 && col < width) g += add[row * width + col];
+  dz[i] = y[i] > 0.f ? g * scale : 0.f;
+}
 
 // ---- column sums -------------------------------------------------------------------------
 constexpr int CS_ROWS = 512;  // rows per first-stage chunk
@@ -256,13 +266,14 @@ __global__ void zpool_fwd_kernel(const float* h, const float* beta, float* z, in
 }
 
 // one wave per v (lanes 0..31 hold 4 channels each): dh_i = beta_i dz ; dbeta_i = <dz, h_i>
-__global__ __launch_bounds__(256) void zpool_bwd_kernel(const float* h, const float* beta, const float* dz, float* dh,
-                                                        float* dbeta, int V) {
+__global__ __launch_bounds__(256) void zpool_bwd_kernel(const float* h, const float* beta, const float* dz,
+                                                        const float* dz_add, float* dh, float* dbeta, int V) {
   const int v = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (v >= V) return;
   const bool on = lane < H / 4;
   f32x4 g = {0.f, 0.f, 0.f, 0.f};
   if (on) g = ld4(dz + (size_t)v * H + 4 * lane);
+  if (on && dz_add) g += ld4(dz_add + (size_t)v * H + 4 * lane);
 #pragma unroll
   for (int i = 0; i < NQ; ++i) {
     float d = 0.f;
@@ -451,7 +462,24 @@ extern "C" int sdumc_zpool_fwd(const float* h, const float* beta, float* z, int3
 extern "C" int sdumc_zpool_bwd(const float* h, const float* beta, const float* dz, float* dh, float* dbeta, int32_t V,
                                void* stream) {
   if (!h || !beta || !dz || !dh || !dbeta || V <= 0) return SDUMC_EINVAL;
-  hipLaunchKernelGGL(zpool_bwd_kernel, dim3((V + 3) / 4), dim3(256), 0, as_stream(stream), h, beta, dz, dh, dbeta, V);
+  return sdumc_zpool_bwd_add_(h, beta, dz, nullptr, dh, dbeta, V, stream);
+}
+
+extern "C" int sdumc_zpool_bwd_add_(const float* h, const float* beta, const float* dz, const float* dz_add, float* dh,
+                                    float* dbeta, int32_t V, void* stream) {
+  if (!h || !beta || !dz || !dh || !dbeta || V <= 0) return SDUMC_EINVAL;
+  hipLaunchKernelGGL(zpool_bwd_kernel, dim3((V + 3) / 4), dim3(256), 0, as_stream(stream), h, beta, dz, dz_add, dh, dbeta, V);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_relu_drop_bwd_add_(const float* dy, const float* y, float scale, float* dz, int64_t n, const float* add,
+                                        int32_t row_len, int32_t col0, int32_t width, void* stream) {
+  if (!dy || !y || !dz || n < 0 || row_len <= 0) return SDUMC_EINVAL;
+  if (n == 0) return SDUMC_OK;
+  if (!add) return sdumc_relu_drop_bwd(dy, y, scale, dz, n, stream);
+  hipLaunchKernelGGL(relu_drop_bwd_add_kernel, dim3(nblk(n)), dim3(256), 0, as_stream(stream), dy, y, scale, dz, n, add,
+                     row_len, col0, width);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
 }

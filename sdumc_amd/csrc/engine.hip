@@ -942,8 +942,8 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     RET(sdumc_fill(d_z, 0.f, (int64_t)V * H, c.st));
   }
   if (og.d_vals) RET(lin_bwd(c, pm.fc_out_v, og.d_vals, 1, c.p(pl.z), H, V, d_z, H, 1));
-  if (og.d_fused) RET(sdumc_axpy2d(og.d_fused, H, d_z, H, V, H, c.st));
-  RET(sdumc_zpool_bwd(c.p(pl.h), c.p(pl.beta), d_z, c.p(pl.d_h), c.p(pl.d_beta), V, c.st));
+  //      (d_z + the external gradient of cross_fused_feat, added inside the kernel instead of by an axpy launch)
+  RET(sdumc_zpool_bwd_add_(c.p(pl.h), c.p(pl.beta), d_z, og.d_fused, c.p(pl.d_h), c.p(pl.d_beta), V, c.st));
   // 11'. cross_fc_att, cross_attention_mlp
   RET(lin_bwd(c, pm.cross_fc_att, c.p(pl.d_beta), NQ, c.p(pl.e2), H, V, c.p(pl.d_e2), H, 0, c.p(pl.e2), s_mlp));
   RET(lin_bwd(c, pm.catt3, c.p(pl.d_e2), H, c.p(pl.e1), D, V, c.p(pl.d_e1), D, 0, c.p(pl.e1), s_mlp));
@@ -998,11 +998,12 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
       gx.accumulate = m > 0;
       RET(run(c, gx));
     }
-    if (og.d_text_hidden) RET(sdumc_axpy2d(og.d_text_hidden, D, c.p(pl.d_q) + 5 * D, NQ * D, V, D, c.st));
   }
   // 6'. the 7 query MLPs
   {
-    RET(sdumc_relu_drop_bwd(c.p(pl.d_q), c.p(pl.q), s_mlp, c.p(pl.d_q), 7LL * V * D, c.st));
+    //   the external gradient of text_hidden (= q[:, 5]) joins d_q inside the same launch
+    RET(sdumc_relu_drop_bwd_add_(c.p(pl.d_q), c.p(pl.q), s_mlp, c.p(pl.d_q), 7LL * V * D, og.d_text_hidden, NQ * D, 5 * D, D,
+                                 c.st));
     GroupPtrs qq = {c.p(pl.d_q), D, NQ * D, c.p(pl.qin), (int64_t)V * D, D, c.p(pl.d_qin), (int64_t)V * D, D};
     RET(lin_bwd_grouped(c, pm.query, 7, V, qq));
   }
@@ -1081,9 +1082,18 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   return SDUMC_OK;
 }
 
-__global__ void total_loss_kernel(float* losses, float w0, float w1, float w2, float w3, float w4, float w5) {
+// hyper != nullptr: also the Adam bias-correction update of this step (adam.hip's adam_hyper_kernel, same double
+// arithmetic) -- it depends on nothing the step computes, so it rides here instead of as a launch of its own
+__global__ void total_loss_kernel(float* losses, float w0, float w1, float w2, float w3, float w4, float w5, float* hyper,
+                                  double beta1, double beta2) {
   losses[0] = w0 * losses[1] + w1 * losses[2] + w2 * losses[3] + w3 * losses[4] + w4 * losses[5] + w5 * losses[6];
   losses[7] = 0.f;
+  if (hyper) {
+    const double t = (double)hyper[1] + 1.0;
+    hyper[1] = (float)t;
+    hyper[2] = (float)((double)hyper[0] / (1.0 - pow(beta1, t)));
+    hyper[3] = (float)sqrt(1.0 - pow(beta2, t));
+  }
 }
 
 struct LossScratch {
@@ -1216,8 +1226,17 @@ extern "C" int sdumc_loss_ssd(const sdumc_net_dims* d, const sdumc_net_io* io, f
   return loss_ssd(*d, *io, ssd_out, ls, as_stream(stream));
 }
 
+namespace {
+int loss_backward_impl(const sdumc_net_dims* d, const sdumc_net_io* io, const sdumc_step_cfg* cfg, const sdumc_net_grads* g,
+                       void* scratch, size_t scratch_bytes, void* stream, float* hyper);
+}
 extern "C" int sdumc_loss_backward(const sdumc_net_dims* d, const sdumc_net_io* io, const sdumc_step_cfg* cfg,
                                    const sdumc_net_grads* g, void* scratch, size_t scratch_bytes, void* stream) {
+  return loss_backward_impl(d, io, cfg, g, scratch, scratch_bytes, stream, nullptr);
+}
+namespace {
+int loss_backward_impl(const sdumc_net_dims* d, const sdumc_net_io* io, const sdumc_step_cfg* cfg, const sdumc_net_grads* g,
+                       void* scratch, size_t scratch_bytes, void* stream, float* hyper) {
   if (!d || !io || !cfg || !g || !scratch || d->streams != 2) return SDUMC_EINVAL;
   if (!io->vals || !io->fused || !io->rnc || !io->text_hidden || !io->cross_text) return SDUMC_EINVAL;
   if (!g->d_vals || !g->d_fused || !g->d_rnc || !g->d_text_hidden || !g->d_cross_text) return SDUMC_EINVAL;
@@ -1247,10 +1266,12 @@ extern "C" int sdumc_loss_backward(const sdumc_net_dims* d, const sdumc_net_io* 
   } else {
     RET(sdumc_rnc_fwd_bwd_rep(io->rnc, cfg->labels, 2 * B, RD, cfg->temperature, w[5], 0, 2 * B, L + 6, dr, ls.rnc_ws, st));
   }
-  hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(1), 0, st, L, w[0], w[1], w[2], w[3], w[4], w[5]);
+  hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(1), 0, st, L, w[0], w[1], w[2], w[3], w[4], w[5], hyper,
+                     (double)cfg->beta1, (double)cfg->beta2);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
 }
+}  // namespace
 
 namespace {
 struct StepLayout {
@@ -1302,11 +1323,12 @@ extern "C" int sdumc_train_step(const sdumc_net_dims* d, const sdumc_net_io* io,
   g.d_text_hidden = g.d_rnc + RD * V;
   g.d_cross_text = g.d_text_hidden + D * V;
   g.grads = reinterpret_cast<float*>(base + sl.grads);
-  RET(sdumc_loss_backward(d, &nio, cfg, &g, base + sl.loss, sl.total - sl.loss, stream));
+  // the Adam bias-correction update rides in the loss's last launch, the dropout call counter in the Adam launch
+  RET(loss_backward_impl(d, &nio, cfg, &g, base + sl.loss, sl.total - sl.loss, stream, cfg->hyper));
   RET(sdumc_net_backward(d, &nio, &g, stream));
-  RET(sdumc_adam_step(io->params, g.grads, cfg->adam_m, cfg->adam_v, (int64_t)sl.live, cfg->hyper, cfg->beta1,
-                      cfg->beta2, cfg->eps, cfg->weight_decay, 1.0f, stream));
-  if (d->train) RET(sdumc_rng_advance(const_cast<uint32_t*>(io->rng_state), 2, stream));
+  RET(sdumc_adam_apply_(io->params, g.grads, cfg->adam_m, cfg->adam_v, (int64_t)sl.live, cfg->hyper, cfg->beta1, cfg->beta2,
+                        cfg->eps, cfg->weight_decay, 1.0f, d->train ? const_cast<uint32_t*>(io->rng_state) : nullptr, 2u,
+                        stream));
   return SDUMC_OK;
 }
 
