@@ -43,6 +43,9 @@ WORKLOADS = {   # name: (batch per GPU, T, dims, algorithmic train FLOPs per sam
     "c5": (32, (512, 512, 512, 512), (1024, 1024, 1024, 1024), 4696.9e6,
            "BASELINE configs[4] per-GPU slice: synthetic long sequences T=512, d=1024, batch=32 per GPU, both streams "
            "with self-distillation"),
+    "c5g": (256, (512, 512, 512, 512), (1024, 1024, 1024, 1024), 4696.9e6,
+            "BASELINE configs[4] at its GLOBAL batch on every GPU: synthetic long sequences T=512, d=1024, batch=256 per GPU, "
+            "both streams with self-distillation"),
 }
 WORKLOAD_TEXT = WORKLOADS["c2"][4]
 
@@ -189,7 +192,7 @@ def main():
                     help="BASELINE configs[2] arithmetic: bf16 operands (fp32 accumulate) in the frame-level projections, "
                          "forward and backward; NOT the default workload (configs[1] is fp32)")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
-                    help="c2 = BASELINE configs[1], the configuration the metric is quoted on (default); c1 / c5 = side measurements")
+                    help="c2 = BASELINE configs[1], the configuration the metric is quoted on (default); c1 / c5 / c5g = side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()

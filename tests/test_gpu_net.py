@@ -316,6 +316,51 @@ def test_full_c2_batch_properties(E):
     assert not torch.equal(flat[:lay.live], before[:lay.live])
 
 
+def test_c5_global_batch_on_one_gpu_properties(E):
+    """BASELINE configs[4] at its GLOBAL batch (256 x T 512 x d 1024 = 2 x 131072 rows per modality, the largest
+    configuration in the list) on one GPU: size-independent properties -- the batch equals its two halves (eval), a shard
+    with sample0 reproduces the full batch's rows (train), the fused step is finite, deterministic bit for bit, and the RnC
+    loss runs its sorted formulation at n = 512."""
+    dims = (1024, 1024, 1024, 1024)
+    B, Tn = 256, (512, 512, 512, 512)
+    from oracle import sdumc_oracle as O
+    P = O.init_params(dims, seed=2)
+    flat, lay = flat_from(E, P, dims)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    audio, text, video, feat4 = [torch.randn(B, Tn[i], dims[i], device="cuda", generator=g) for i in range(4)]
+    vals = torch.rand(B, device="cuda", generator=g) * 6 - 3
+    full = [t.clone() for t in E.NetCall(flat, audio, [text, feat4], video, False, None).forward()]
+    h = B // 2
+    for lo in (0, h):
+        part = E.NetCall(flat, audio[lo:lo + h].contiguous(), [text[lo:lo + h].contiguous(), feat4[lo:lo + h].contiguous()],
+                         video[lo:lo + h].contiguous(), False, None).forward()
+        for n, f, p in zip(NAMES, full, part):
+            for s in range(2):
+                close(p[s * h:(s + 1) * h], f[s * B + lo:s * B + lo + h], 1e-5, n)
+    rng = E.RngState(9, audio.device, call=0)
+    full = [t.clone() for t in E.NetCall(flat, audio, [text, feat4], video, True, rng).forward()]
+    part = E.NetCall(flat, audio[h:].contiguous(), [text[h:].contiguous(), feat4[h:].contiguous()],
+                     video[h:].contiguous(), True, rng, sample0=h).forward()
+    for n, f, p in zip(NAMES, full, part):
+        for s in range(2):
+            close(p[s * h:(s + 1) * h], f[s * B + h:s * B + B], 1e-5, n)
+    del full, part
+    results = []
+    for _ in range(2):
+        fl = flat.clone()
+        ts = E.TrainStep(fl, B, Tn, dims, seed=3)
+        ts.set_batch(audio, text, video, feat4, vals)
+        losses = ts.run().clone()
+        results.append((losses, ts.grads.clone(), fl))
+        del ts
+    assert torch.isfinite(results[0][0]).all() and float(results[0][0][0]) > 0
+    for a, b in zip(results[0], results[1]):
+        assert torch.equal(a, b)
+    gv = lay.views(torch.cat([results[0][1].cpu(), torch.zeros(lay.total - lay.live)]))
+    for k in lay.live_names():
+        assert torch.isfinite(gv[k]).all() and gv[k].abs().sum() > 0, k
+
+
 def test_long_sequence_c5_shapes_vs_oracle(E):
     """BASELINE configs[4] shape family: T_t = T_a = T_v = 512 (8 row chunks per sample in the pooling kernels),
     d = 1024 for every modality; one train step against the oracle (B reduced so the CPU side takes seconds)."""
