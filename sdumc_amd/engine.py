@@ -190,7 +190,10 @@ class TrainStep:
     optionally captured into a hipGraph (torch.cuda.CUDAGraph) and replayed."""
 
     def __init__(self, flat_params, B, T, dims, weights=DEFAULT_WEIGHTS, lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=1e-5, seed=0, train=True, sample0=0, bf16=False):
+                 weight_decay=1e-5, seed=0, train=True, sample0=0, bf16=False, share=None):
+        """share: an object with .params .rng .adam_m .adam_v .hyper .losses (another TrainStep over the SAME flat_params, or
+        FusedTrainer's run state) whose optimiser state this step uses instead of allocating its own -- steps of different
+        (B, T) shapes then continue one training run."""
         Ta, Tt, Tv, T4 = T
         self.layout = ParamLayout.get(dims[0], dims[1], dims[2])
         dev = flat_params.device
@@ -201,7 +204,9 @@ class TrainStep:
         if nbytes == 0:
             raise _lib.SdumcError("invalid step dimensions")
         self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-        self.rng = RngState(seed, dev)
+        if share is not None and share.params.data_ptr() != flat_params.data_ptr():
+            raise _lib.SdumcError("share: both steps must update the same flat parameter buffer")
+        self.rng = share.rng if share is not None else RngState(seed, dev)
         V = 2 * B
         self.B, self.V = B, V
         self.audio = torch.empty(B, Ta, dims[0], device=dev)
@@ -214,10 +219,13 @@ class TrainStep:
         self.rnc = torch.empty(V, RNC_DIM, device=dev)
         self.text_hidden = torch.empty(V, D, device=dev)
         self.cross_text = torch.empty(V, NQ, H, device=dev)
-        self.adam_m = torch.zeros(self.layout.live, device=dev)
-        self.adam_v = torch.zeros(self.layout.live, device=dev)
-        self.hyper = torch.tensor([lr, 0.0, 0.0, 0.0], device=dev)
-        self.losses = torch.zeros(8, device=dev)
+        if share is not None:
+            self.adam_m, self.adam_v, self.hyper, self.losses = share.adam_m, share.adam_v, share.hyper, share.losses
+        else:
+            self.adam_m = torch.zeros(self.layout.live, device=dev)
+            self.adam_v = torch.zeros(self.layout.live, device=dev)
+            self.hyper = torch.tensor([lr, 0.0, 0.0, 0.0], device=dev)
+            self.losses = torch.zeros(8, device=dev)
         io = _lib.NetIO()
         io.audio, io.video = ptr(self.audio), ptr(self.video)
         io.text[0], io.text[1] = ptr(self.text), ptr(self.feat4)
@@ -287,3 +295,53 @@ class TrainStep:
         else:
             self.launch()
         return self.losses
+
+
+class _RunState:
+    """Optimiser state of one training run, shared by the per-shape TrainSteps of a FusedTrainer."""
+
+    def __init__(self, flat_params, live, lr, seed):
+        dev = flat_params.device
+        self.params = flat_params
+        self.rng = RngState(seed, dev)
+        self.adam_m = torch.zeros(live, device=dev)
+        self.adam_v = torch.zeros(live, device=dev)
+        self.hyper = torch.tensor([lr, 0.0, 0.0, 0.0], device=dev)
+        self.losses = torch.zeros(8, device=dev)
+
+
+class FusedTrainer:
+    """The fused step for the reference's REAL batches, whose (B, T_audio, T_text, T_video, T_feat4) change from batch to
+    batch (every modality is padded to its batch maximum, read_data.py:223-248; the last batch of an epoch is short):
+    one TrainStep per shape, created on first use, all sharing one optimiser state, so `step()` over a data loader is one
+    continuous run of main_frame_val_text_missing.py:119-150.  At most `max_cached` shapes keep their workspace (least
+    recently used first out); a shape seen again after eviction is simply rebuilt."""
+
+    def __init__(self, flat_params, dims, max_cached=8, lr=1e-4, seed=0, **step_kwargs):
+        _require_cuda(flat_params)
+        self.params, self.dims, self.max_cached = flat_params, tuple(dims), max(1, int(max_cached))
+        self.kw = dict(step_kwargs, lr=lr, seed=seed)
+        lay = ParamLayout.get(dims[0], dims[1], dims[2])
+        self.state = _RunState(flat_params, lay.live, lr, seed)     # (params, rng, adam_m, adam_v, hyper, losses)
+        self._steps = {}          # shape -> TrainStep, insertion order = recency
+
+    def _get(self, B, T):
+        key = (B,) + tuple(T)
+        ts = self._steps.pop(key, None)
+        if ts is None:
+            while len(self._steps) >= self.max_cached:
+                del self._steps[next(iter(self._steps))]
+            ts = TrainStep(self.params, B, T, self.dims, share=self.state, **self.kw)
+        self._steps[key] = ts
+        return ts
+
+    def set_lr(self, lr):
+        self.state.hyper[0] = lr
+
+    def step(self, audio, text, video, feat4, labels, lengths=None):
+        """One optimisation step on one batch of any shape; returns the device loss vector
+        [total, mse_full, mse_missing, rmse_text, rmse_query, rmse_fused, rnc, 0]."""
+        ts = self._get(audio.shape[0], (audio.shape[1], text.shape[1], video.shape[1], feat4.shape[1]))
+        ts.set_batch(audio, text, video, feat4, labels)
+        ts.set_lengths(lengths)
+        return ts.run()

@@ -439,3 +439,27 @@ def test_bf16_operand_mode_c3(E):
         ref = grads[k].double()
         errs.append(float((gv[k].double() - ref).norm() / (ref.norm() + 1e-12)))
     assert float(np.median(errs)) < 4e-2 and max(errs) < 0.2, (float(np.median(errs)), max(errs))
+
+
+def test_fused_trainer_over_changing_batch_shapes_vs_oracle(E):
+    """The reference's batches change shape from one to the next (per-batch padding, short last batch): FusedTrainer runs
+    each through a per-shape fused step while ONE optimiser state (Adam moments, step count, dropout call counter)
+    continues -- four steps over three shapes (one evicted and rebuilt) against the oracle's train_step sequence."""
+    from oracle import sdumc_oracle as O
+    dims = (24, 16, 20, 16)
+    shapes = [(4, (9, 2, 5, 3)), (3, (7, 4, 6, 1)), (4, (9, 2, 5, 3)), (2, (12, 3, 2, 2))]
+    P = O.init_params(dims, seed=8)
+    flat, lay = flat_from(E, P, dims)
+    tr = E.FusedTrainer(flat, dims, max_cached=2, lr=1e-3, seed=17)
+    Pd, state = {k: v.clone() for k, v in P.items()}, {}
+    for step, (B, Tn) in enumerate(shapes):
+        audio, text, video, feat4, vals = O.synthetic_batch(B, Tn, dims, seed=100 + step)
+        losses = tr.step(audio.cuda(), text.cuda(), video.cuda(), feat4.cuda(), vals.cuda()).cpu().numpy()
+        loss, terms, grads, outs = O.train_step(Pd, state, audio, text, video, feat4, vals, mode="philox", seed=17, step=step,
+                                                lr=1e-3)
+        np.testing.assert_allclose(losses[1:7], [float(t) for t in terms], rtol=2e-4, atol=1e-6, err_msg=f"step {step}")
+    assert len(tr._steps) == 2
+    pv = lay.views(flat.cpu())
+    for k in lay.live_names():
+        close((pv[k] - P[k]) * 1e2, (Pd[k] - P[k]) * 1e2, 2e-2, k)       # four Adam steps of lr 1e-3
+    assert tr.state.rng.call == 2 * len(shapes) and int(tr.state.hyper[1].item()) == len(shapes)
