@@ -243,6 +243,7 @@ class TrainStep:
         cfg.hyper, cfg.losses = ptr(self.hyper), ptr(self.losses)
         self.cfg = cfg
         self.graph = None
+        self._lengths = None      # key-padding extension off (set_lengths)
         goff = lib.sdumc_step_grads_offset(C.byref(self.dims))
         self.grads = self.workspace[goff:goff + 4 * self.layout.live].view(torch.float32)
         self.grads.zero_()      # alignment padding between tensors is never written by the kernels
@@ -264,7 +265,7 @@ class TrainStep:
             for i in range(4):
                 self.io.lengths[i] = None
             return
-        if getattr(self, "_lengths", None) is None:
+        if self._lengths is None:
             self._lengths = [torch.empty(self.B, dtype=torch.int32, device=self.params.device) for _ in range(4)]
             for i, t in enumerate(self._lengths):
                 self.io.lengths[i] = ptr(t)
