@@ -260,6 +260,9 @@ class TrainStep:
         """Key-padding extension: (audio, text, video, feat4) valid frame counts of the current batch, or None to go back
         to the reference's behaviour (padded frames take part in the softmax)."""
         new = _lengths_arg(lengths, self.B, 4, self.params.device)
+        if self.graph is not None and (new is None) != (self._lengths is None):
+            raise _lib.SdumcError("the captured hipGraph was recorded with the key-padding extension "
+                                  + ("on" if self._lengths is not None else "off") + ": switch it before capture()")
         if new is None:
             self._lengths = None
             for i in range(4):
