@@ -376,8 +376,14 @@ void ensure_side_streams() {
     const char* e = getenv("SDUMC_LANE_PRIORITY");
     prio = (e && e[0] == 'n') ? 0 : ((e && e[0] == 'l') ? least : greatest);
   }
+  int lane_prio[2] = {prio, prio};
+  if (const char* e = getenv("SDUMC_LANE_PRIORITIES")) {   // experiment knob: one letter (h/n/l) per side lane
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return;
+    for (int i = 0; i < 2 && e[i]; ++i) lane_prio[i] = e[i] == 'n' ? 0 : (e[i] == 'l' ? least : greatest);
+  }
   for (int i = 0; i < 2; ++i)
-    if (hipStreamCreateWithPriority(&S.s[i], hipStreamNonBlocking, prio) != hipSuccess) return;
+    if (hipStreamCreateWithPriority(&S.s[i], hipStreamNonBlocking, lane_prio[i]) != hipSuccess) return;
   for (int i = 0; i < 64; ++i)
     if (hipEventCreateWithFlags(&S.ev[i], hipEventDisableTiming) != hipSuccess) return;
   {
