@@ -732,19 +732,35 @@ int forward(const Ctx& c) {
   //      keep-bits of the two frame-level input dropouts -> frame_dim_reshape_m (model :282-284; audio/video once
   //      for both streams) -> keys of fra2utt_m AND cross_att_fra2utt_m -> FRA2UTT pooling (model :288-290)
   RET(fork_all(c));
-  for (int m = 0; m < 3; ++m) {
-    c.use(LANE_OF[m]);
-    if (c.d.train)   // Philox runs once per element here instead of ~10x in the kernels that stage these tiles
+  // The keep-bits (Philox once per element instead of ~10x in the kernels that stage these tiles; VALU-bound) are generated
+  // on lane 3 in the shadow of the MFMA-bound frame projections, which read no mask; each modality's lane waits for its
+  // own bits before the key projections.  Heaviest modality first.
+  hipEvent_t bits_done[3] = {nullptr, nullptr, nullptr};
+  if (c.d.train) {
+    RET(link(c, 0, 3));
+    c.use(3);
+    const int order[3] = {0, 2, 1};
+    for (int oi = 0; oi < 3; ++oi) {
+      const int m = order[oi];
       for (const Seg& sg : pl.segs[m]) {   // both sites (fra2utt_m, cross_att_fra2utt_m) in one launch
         sdumc_dropout d = mkdrop(c, SITE_IN[0][m], c.d.p_frame, sg.T, D, sg.s0);
         uint8_t* outs[2] = {reinterpret_cast<uint8_t*>(c.p(pl.bits[0][m])) + sg.row0 * (D / 4),
                             reinterpret_cast<uint8_t*>(c.p(pl.bits[1][m])) + sg.row0 * (D / 4)};
         RET(sdumc_dropout_bits_multi(&d, sg.V / B, 2, SITE_IN[1][m] - SITE_IN[0][m], outs, c.st));
       }
+      if (c.sts[3] != c.sts[LANE_OF[m]]) {
+        bits_done[m] = next_event();
+        if (hipEventRecord(bits_done[m], c.st) != hipSuccess) return SDUMC_ELAUNCH;
+      }
+    }
+  }
+  for (int m = 0; m < 3; ++m) {
+    c.use(LANE_OF[m]);
     for (int s = 0; s < (m == 1 ? S : 1); ++s) {
       const float* in = m == 0 ? c.io.audio : (m == 2 ? c.io.video : c.io.text[s]);
       RET(lin_fwd(c, pm.frame[m], in, din[m], B * pl.T[m][s], c.p(pl.x[m][s]), D, SDUMC_ACT_NONE, nullptr, c.d.bf16 != 0));
     }
+    if (bits_done[m] && hipStreamWaitEvent(c.st, bits_done[m], 0) != hipSuccess) return SDUMC_ELAUNCH;
     if (c.bg) {   // the Cross_Attention keys are not needed before step 8: background lane, beside steps 2-7
       RET(keys_gemm_fwd(c, m, 0, 1));
       RET(link(c, LANE_OF[m], 3));
