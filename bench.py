@@ -234,7 +234,7 @@ def main():
 
     if args.serial_lanes:
         _lib.lib.sdumc_set_concurrency(0)
-    if args.background_lane:
+    if args.background_lane or "SDUMC_BG_MODE" in os.environ:   # experiment knob; the library default is mode 2 (forward only)
         _lib.lib.sdumc_set_background_lane(int(os.environ.get("SDUMC_BG_MODE", "2")))
     flat, lay = init_flat_params(engine, dev)
     batch = [t.to(dev) for t in synthetic_shard(B_PER_GPU, rank)]
@@ -285,7 +285,7 @@ def main():
                    "batch_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU,
                    "T_audio_text_video_feat4": list(T_MOSEI), "feature_dims": list(DIMS),
                    "parallelism": f"dp{world}" if world > 1 else ("dp1 (one-rank RCCL communicator, all collectives issued)" if force_dp else "single"),
-                   "launch": "hipGraph replay" if (args.graph and world == 1) else ("eager, 4 lanes (caller stream + 2 modality side streams + 1 background stream)" if args.background_lane else "eager, 3 lanes (caller stream + 2 side streams)"),
+                   "launch": "hipGraph replay" if (args.graph and world == 1) else "eager, 4 lanes (caller stream + 2 high-priority modality side streams + 1 side stream for dW batches, keep-bits and the forward Cross_Attention key GEMMs)",
                    "params": lay.total, "final_loss": round(float(losses[0]), 5)},
         "whole_step_tflops": round(value * TRAIN_FLOPS_PER_SAMPLE / 1e12, 2),
         "whole_step_frac_of_f32_mfma_peak": round(value * TRAIN_FLOPS_PER_SAMPLE / 1e12 / (world * PEAK_F32_MFMA_TFLOPS), 4),

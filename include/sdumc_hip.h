@@ -495,8 +495,8 @@ int sdumc_set_concurrency(int on);
 /* The Cross_Attention-site key projections (forward, dW, dX: ~0.4 ms of MFMA-bound GEMMs per step at C2) are not on
  * the critical path of the launch-bound utterance-level chain (model :293-332 forward, its mirror backward).  1 = issue
  * them on a fourth internal stream beside that chain instead of grouped with the FRA2UTT-site ones, 2 = the forward
- * ones only (default 0: the grouped launches are 4 % more efficient per kernel; measured on MI355X mode 2 gains 0.9 %
- * per step and mode 1 loses 7 %). */
+ * ones only (the default: measured on MI355X mode 2 gains 1.0 % per step over mode 0 -- the HBM-bound FRA2UTT pooling
+ * then overlaps the MFMA-bound Cross_Attention key GEMM -- and mode 1 loses 7 %). */
 int sdumc_set_background_lane(int on);
 size_t sdumc_net_workspace_bytes(const sdumc_net_dims* d);
 int sdumc_net_forward(const sdumc_net_dims* d, const sdumc_net_io* io, void* stream);

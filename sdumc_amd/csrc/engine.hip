@@ -355,7 +355,7 @@ SideStreams& side_streams() {
   return S;
 }
 bool g_concurrency = true;   // sdumc_set_concurrency(0): everything on the caller's stream (profiling)
-int g_background = 0;      // 0 off, 1 forward + backward, 2 forward only;   // sdumc_set_background_lane(1): the Cross_Attention-site GEMMs leave the grouped launches for lane 3
+int g_background = 2;      // 0 off, 1 forward + backward, 2 forward only (default: +1.0 % per step, four alternations);   // sdumc_set_background_lane(1): the Cross_Attention-site GEMMs leave the grouped launches for lane 3
 // created outside any capture (called from the *_workspace_bytes queries every caller makes first)
 void ensure_side_streams() {
   static std::mutex mu;
@@ -425,6 +425,11 @@ struct Ctx {
     multi = S.ok && g_concurrency;
     bg = g_background != 0;               // the launch decomposition is the same with and without real streams
     bgb = g_background == 1;
+    {   // under hipGraph capture the extra lane-3 dependencies (three lanes -> lane 3 -> lane 0) make hipStreamEndCapture
+        // segfault on this stack (ROCm 7.0 runtime inside torch 2.10): captured steps keep the grouped launches
+      hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) bg = bgb = false;
+    }
     sts[1] = multi ? S.s[0] : st;
     sts[2] = multi ? S.s[1] : st;
     sts[3] = multi ? S.bg : st;   // lane 3: deferred dW batches (and, with the background option, the Cross_Attention keys)
