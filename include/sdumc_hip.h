@@ -495,8 +495,9 @@ int sdumc_set_concurrency(int on);
 /* The Cross_Attention-site key projections (forward, dW, dX: ~0.4 ms of MFMA-bound GEMMs per step at C2) are not on
  * the critical path of the launch-bound utterance-level chain (model :293-332 forward, its mirror backward).  1 = issue
  * them on a fourth internal stream beside that chain instead of grouped with the FRA2UTT-site ones, 2 = the forward
- * ones only (the default: measured on MI355X mode 2 gains 1.0 % per step over mode 0 -- the HBM-bound FRA2UTT pooling
- * then overlaps the MFMA-bound Cross_Attention key GEMM -- and mode 1 loses 7 %). */
+ * ones only (+1.0 % per step over mode 0 on MI355X: the HBM-bound FRA2UTT pooling then overlaps the MFMA-bound
+ * Cross_Attention key GEMM), 3 (the default) = 2 plus the audio modality's backward ones (+0.6 % over 2: the longest
+ * frame-level chain gets shorter), 4 = audio and video (+0.4 %); mode 1 loses 1.6 % against mode 2. */
 int sdumc_set_background_lane(int on);
 size_t sdumc_net_workspace_bytes(const sdumc_net_dims* d);
 int sdumc_net_forward(const sdumc_net_dims* d, const sdumc_net_io* io, void* stream);

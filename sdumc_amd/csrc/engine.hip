@@ -355,7 +355,9 @@ SideStreams& side_streams() {
   return S;
 }
 bool g_concurrency = true;   // sdumc_set_concurrency(0): everything on the caller's stream (profiling)
-int g_background = 2;      // 0 off, 1 forward + backward, 2 forward only (default: +1.0 % per step, four alternations);   // sdumc_set_background_lane(1): the Cross_Attention-site GEMMs leave the grouped launches for lane 3
+int g_background = 3;      // 0 off; 2 forward only (+1.0 % per step over 0); 3 (default) = 2 + the AUDIO Cross_Attention key-projection
+                           // backward early on lane 3 (+0.6 % over 2: it shortens the longest frame-level chain); 4 = audio + video (+0.4 %);
+                           // 1 = all three (-1.6 %);   // sdumc_set_background_lane(1): the Cross_Attention-site GEMMs leave the grouped launches for lane 3
 // created outside any capture (called from the *_workspace_bytes queries every caller makes first)
 void ensure_side_streams() {
   static std::mutex mu;
@@ -413,7 +415,7 @@ struct Ctx {
   float* G;     // gradient bucket (backward only)
   hipStream_t sts[4] = {nullptr, nullptr, nullptr, nullptr};
   bool bg = false;   // the Cross_Attention-site key projections are issued on lane 3 (background)
-  bool bgb = false;  // ... and their backward too
+  int bgb = 0;       // bit m: the Cross_Attention key-projection BACKWARD of modality m runs early, on lane 3, beside steps 7'-3'
   mutable float* scr = nullptr;   // scratch of the current lane
   bool multi = false;
   // weight-gradient GEMMs of the utterance-level layers, queued by lin_bwd* and issued in batches on lane 3 (flush_dw)
@@ -424,11 +426,11 @@ struct Ctx {
     sts[0] = st;
     multi = S.ok && g_concurrency;
     bg = g_background != 0;               // the launch decomposition is the same with and without real streams
-    bgb = g_background == 1;
+    bgb = g_background == 1 ? 7 : (g_background == 3 ? 1 : (g_background == 4 ? 5 : 0));   // 3: audio only, 4: audio + video
     {   // under hipGraph capture the extra lane-3 dependencies (three lanes -> lane 3 -> lane 0) make hipStreamEndCapture
         // segfault on this stack (ROCm 7.0 runtime inside torch 2.10): captured steps keep the grouped launches
       hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-      if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) bg = bgb = false;
+      if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) { bg = false; bgb = 0; }
     }
     sts[1] = multi ? S.s[0] : st;
     sts[2] = multi ? S.s[1] : st;
@@ -968,6 +970,8 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   const int B = pl.B, S = pl.S, V = pl.V;
   const int din[3] = {c.d.da, c.d.dt, c.d.dv};
   const float s_mlp = c.d.train ? 1.0f / (1.0f - (float)c.d.p_mlp) : 1.0f;
+  // (phased calls -- the data-parallel step -- end phase 0 by waiting for lane 3, so nothing frame-level is parked there)
+  const int bgb = phases == 3 ? c.bgb : 0;
   if (phases & 1) {
   // every live gradient tensor is overwritten below when all five output gradients are given
   if (!og.d_vals || !og.d_fused || !og.d_rnc || !og.d_text_hidden || !og.d_cross_text) RET(sdumc_fill(c.G, 0.f, pm.live, c.st));
@@ -1005,7 +1009,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   for (int m = 0; m < 3; ++m) {
     c.use(LANE_OF[m]);
     RET(pool_bwd(c, 1, m, c.p(pl.d_ca_out) + (int64_t)m * V * NQ * D, c.p(pl.d_qp) + (int64_t)m * V * NQ * D));
-    if (c.bgb) {   // the Cross_Attention input_proj backward has everything it needs: background lane, beside 7'-3'
+    if (bgb & (1 << m)) {   // the Cross_Attention input_proj backward has everything it needs: background lane, beside 7'-3'
       RET(link(c, LANE_OF[m], 3));
       c.use(3);
       RET(keys_gemm_bwd(c, m, 1, 2));
@@ -1072,14 +1076,14 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   //   fra2utt_m pooling backward (the shared context vector's gradient = sum of the per-sample dq)
   //   -> input_proj backward of both sites (grouped) -> dx = sum of the (up to) four masked paths into the
   //   projected features -> frame_dim_reshape_m: dW = dx^T feat (split-K) with db fused
-  if (c.bgb) RET(link(c, 3, 0));   // dxd of the Cross_Attention sites (background option)
   RET(fork_all(c));
   for (int m = 0; m < 3; ++m) {
     c.use(LANE_OF[m]);
     float* dq = c.p(pl.dq_fra) + (int64_t)m * V * D;
     RET(pool_bwd(c, 0, m, c.p(pl.d_hpre) + (int64_t)m * V * D, dq));
     RET(colsum(c, dq, V, D, D, c.G + pm.fra_ctx[m], 0));
-    RET(keys_gemm_bwd(c, m, 0, c.bgb ? 1 : 2));
+    RET(keys_gemm_bwd(c, m, 0, (bgb & (1 << m)) ? 1 : 2));
+    if (bgb & (1 << m)) RET(link(c, 3, LANE_OF[m]));   // dxd of this modality's Cross_Attention site (issued early on lane 3)
     for (int s = 0; s < (m == 1 ? S : 1); ++s) {
       const int T = pl.T[m][s];
       sdumc_dropsum ds;
