@@ -415,6 +415,7 @@ struct Ctx {
   float* G;     // gradient bucket (backward only)
   hipStream_t sts[4] = {nullptr, nullptr, nullptr, nullptr};
   bool bg = false;   // the Cross_Attention-site key projections are issued on lane 3 (background)
+  bool capturing = false;   // the caller's stream is under hipGraph capture: only the plain three-lane fork/join pattern is used
   int bgb = 0;       // bit m: the Cross_Attention key-projection BACKWARD of modality m runs early, on lane 3, beside steps 7'-3'
   mutable float* scr = nullptr;   // scratch of the current lane
   bool multi = false;
@@ -430,7 +431,7 @@ struct Ctx {
     {   // under hipGraph capture the extra lane-3 dependencies (three lanes -> lane 3 -> lane 0) make hipStreamEndCapture
         // segfault on this stack (ROCm 7.0 runtime inside torch 2.10): captured steps keep the grouped launches
       hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-      if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) { bg = false; bgb = 0; }
+      if (hipStreamIsCapturing(st, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) { bg = false; bgb = 0; capturing = true; }
     }
     sts[1] = multi ? S.s[0] : st;
     sts[2] = multi ? S.s[1] : st;
@@ -925,10 +926,12 @@ int pool_bwd(const Ctx& c, int k, int m, const float* dout_base /* [V, nq, D] */
 }
 
 // input_proj backward of the sites [k0, k1) of modality m (grouped when both): dW = dz^T drop(x) (+ db), dxd += dz W
-int keys_gemm_bwd(const Ctx& c, int m, int k0, int k1) {
+// parts: bit 0 = dW (off every critical path: feeds only the gradient bucket), bit 1 = dX
+int keys_gemm_bwd(const Ctx& c, int m, int k0, int k1, int parts = 3) {
   const Plan& pl = c.pl;
   // dW: one grouped GEMM per run (runs differ in their x buffer), later runs accumulate
   bool first = true;
+  if (parts & 1)
   for (const Seg& sg : pl.segs[m]) {
     const int rows = sg.V * sg.T;
     sdumc_gemm g = G_(SDUMC_TN, D, D, rows, k1 - k0);
@@ -949,6 +952,7 @@ int keys_gemm_bwd(const Ctx& c, int m, int k0, int k1) {
     RET(run(c, g));
     first = false;
   }
+  if (!(parts & 2)) return SDUMC_OK;
   // dxd += dz W (the key-projection path joins the pooling path)
   sdumc_gemm g = G_(SDUMC_NN, (int)pl.rows[m], D, D, k1 - k0);
   for (int k = k0; k < k1; ++k) {
@@ -1082,7 +1086,21 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     float* dq = c.p(pl.dq_fra) + (int64_t)m * V * D;
     RET(pool_bwd(c, 0, m, c.p(pl.d_hpre) + (int64_t)m * V * D, dq));
     RET(colsum(c, dq, V, D, D, c.G + pm.fra_ctx[m], 0));
-    RET(keys_gemm_bwd(c, m, 0, (bgb & (1 << m)) ? 1 : 2));
+    {
+      const int k1 = (bgb & (1 << m)) ? 1 : 2;
+      // bit m: modality m's key-projection dW (off the dz -> dX -> mask-sum -> frame dW chain) runs on lane 3.  Default: audio
+      // only, the longest chain (30.84 vs 30.51 k samples/s, five alternations; audio + video 30.8, all three 30.8).
+      static const int dw_off = [] { const char* e = getenv("SDUMC_KEYS_DW_LANE3"); return e ? atoi(e) : 1; }();
+      if (c.multi && !c.capturing && (dw_off & (1 << m))) {
+        RET(link(c, LANE_OF[m], 3));
+        c.use(3);
+        RET(keys_gemm_bwd(c, m, 0, k1, 1));
+        c.use(LANE_OF[m]);
+        RET(keys_gemm_bwd(c, m, 0, k1, 2));
+      } else {
+        RET(keys_gemm_bwd(c, m, 0, k1));
+      }
+    }
     if (bgb & (1 << m)) RET(link(c, 3, LANE_OF[m]));   // dxd of this modality's Cross_Attention site (issued early on lane 3)
     for (int s = 0; s < (m == 1 ? S : 1); ++s) {
       const int T = pl.T[m][s];
