@@ -974,8 +974,15 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   const int B = pl.B, S = pl.S, V = pl.V;
   const int din[3] = {c.d.da, c.d.dt, c.d.dv};
   const float s_mlp = c.d.train ? 1.0f / (1.0f - (float)c.d.p_mlp) : 1.0f;
-  // (phased calls -- the data-parallel step -- end phase 0 by waiting for lane 3, so nothing frame-level is parked there)
-  const int bgb = phases == 3 ? c.bgb : 0;
+  // Early Cross_Attention key-projection backward (bit m of c.bgb): a modality that owns a side lane keeps going on that lane --
+  // the caller's stream waits only for the pooling backward before it, so the GEMMs run beside steps 7'-3' and, in phased
+  // calls (the data-parallel step), beside whatever the caller does between the phases; a modality on the caller's stream
+  // goes through lane 3, which phased calls cannot use for frame-level work (phase 0 ends by waiting for lane 3).
+  int own_lane = 0;
+  for (int m = 0; m < 3; ++m)
+    if (phases != 3 && (c.bgb & (1 << m)) && c.multi && LANE_OF[m] != 0) own_lane |= 1 << m;
+  // (in a single call the lane-3 route measured 0.15 % faster than the own-lane route; phased calls gain 0.6 % from the latter)
+  const int bgb = phases == 3 ? c.bgb : own_lane;
   if (phases & 1) {
   // every live gradient tensor is overwritten below when all five output gradients are given
   if (!og.d_vals || !og.d_fused || !og.d_rnc || !og.d_text_hidden || !og.d_cross_text) RET(sdumc_fill(c.G, 0.f, pm.live, c.st));
@@ -1010,17 +1017,28 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   RET(flush_dw(c));   // batch 1: heads, cross_attention_mlp, cross_*_mlp
   // 8'. the three Cross_Attention blocks
   RET(fork_all(c));
+  hipEvent_t pooled[3] = {nullptr, nullptr, nullptr};   // per side lane: its pooling backward is done (partial join)
   for (int m = 0; m < 3; ++m) {
     c.use(LANE_OF[m]);
     RET(pool_bwd(c, 1, m, c.p(pl.d_ca_out) + (int64_t)m * V * NQ * D, c.p(pl.d_qp) + (int64_t)m * V * NQ * D));
-    if (bgb & (1 << m)) {   // the Cross_Attention input_proj backward has everything it needs: background lane, beside 7'-3'
+    if (own_lane & bgb & (1 << m)) {   // the input_proj backward has everything it needs: stay on this lane, beside 7'-3'
+      pooled[LANE_OF[m]] = next_event();
+      if (hipEventRecord(pooled[LANE_OF[m]], c.st) != hipSuccess) return SDUMC_ELAUNCH;
+      RET(keys_gemm_bwd(c, m, 1, 2));
+    } else if (bgb & (1 << m)) {       // same, through the background lane
       RET(link(c, LANE_OF[m], 3));
       c.use(3);
       RET(keys_gemm_bwd(c, m, 1, 2));
     }
   }
   c.use(0);
-  RET(join_all(c));
+  for (int lane = 1; lane <= 2; ++lane) {
+    if (pooled[lane]) {
+      if (hipStreamWaitEvent(c.sts[0], pooled[lane], 0) != hipSuccess) return SDUMC_ELAUNCH;
+    } else {
+      RET(link(c, lane, 0));
+    }
+  }
   // 7'. query_proj: dW/db per modality, d_q = sum_m d_qp[m] W_q[m]
   {
     const int M = V * NQ;
@@ -1101,7 +1119,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
         RET(keys_gemm_bwd(c, m, 0, k1));
       }
     }
-    if (bgb & (1 << m)) RET(link(c, 3, LANE_OF[m]));   // dxd of this modality's Cross_Attention site (issued early on lane 3)
+    if (bgb & ~own_lane & (1 << m)) RET(link(c, 3, LANE_OF[m]));   // dxd of this modality's Cross_Attention site (issued early on lane 3)
     for (int s = 0; s < (m == 1 ? S : 1); ++s) {
       const int T = pl.T[m][s];
       sdumc_dropsum ds;

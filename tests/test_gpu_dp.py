@@ -99,7 +99,14 @@ def test_backward_phases_equal_one_call_and_early_slice_is_final():
             early = be.backward_phase(0)
             torch.cuda.synchronize()
             assert early.numel() == lay.early and torch.isfinite(early.cpu()[used[:lay.early]]).all()
-            assert not torch.isfinite(be.grads.cpu()[lay.early:][used[lay.early:]]).any()   # phase 1 has not run
+            # phase 1 has not run: the late slice is untouched, except the audio Cross_Attention input_proj gradients, whose
+            # GEMMs the engine issues early on the audio lane (they run beside whatever follows phase 0)
+            pending = used.clone()
+            for n in lay.live_names():
+                if n.startswith("cross_att_fra2utt_0.input_proj."):
+                    off, shape, _ = lay.entries[n]
+                    pending[off:off + int(np.prod(shape))] = False
+            assert not torch.isfinite(be.grads.cpu()[lay.early:][pending[lay.early:]]).any()
             snap = early.clone()
             be.backward_phase(1)
             torch.cuda.synchronize()
