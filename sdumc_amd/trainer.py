@@ -18,6 +18,7 @@ The compute backend is injectable: the product default is HipBackend (no fallbac
 a CPU backend to check the collective algebra under gloo.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.distributed as dist
@@ -190,7 +191,9 @@ class DataParallelStep:
         # communicator's own stream beside the frame-level backward (the pattern torch DDP uses).  Under gloo (CPU tests,
         # the two-ranks-on-one-GPU debugging aid) an in-flight collective stalls every concurrent launch of this process
         # (200 vs 11 ms per step measured), so there the bucket is reduced in one blocking call after the backward.
-        self.overlap = self.collect and dist.get_backend() == "nccl"
+        # SDUMC_DP_OVERLAP=0: one flat all-reduce after a single backward call instead (on one rank the phase split + the
+        # asynchronous hand-off cost 0.075 ms per step, tools/dp_rccl_probe.py; what the overlap hides depends on the fabric)
+        self.overlap = (self.collect and dist.get_backend() == "nccl" and os.environ.get("SDUMC_DP_OVERLAP", "1") != "0")
 
     def set_batch(self, *batch):
         """The LOCAL shard: rows [rank*B, (rank+1)*B) of the global batch."""
