@@ -191,9 +191,11 @@ class DataParallelStep:
         # communicator's own stream beside the frame-level backward (the pattern torch DDP uses).  Under gloo (CPU tests,
         # the two-ranks-on-one-GPU debugging aid) an in-flight collective stalls every concurrent launch of this process
         # (200 vs 11 ms per step measured), so there the bucket is reduced in one blocking call after the backward.
-        # SDUMC_DP_OVERLAP=0: one flat all-reduce after a single backward call instead (on one rank the phase split + the
-        # asynchronous hand-off cost 0.075 ms per step, tools/dp_rccl_probe.py; what the overlap hides depends on the fabric)
-        self.overlap = (self.collect and dist.get_backend() == "nccl" and os.environ.get("SDUMC_DP_OVERLAP", "1") != "0")
+        # Default: ONE flat all-reduce after a single backward call.  SDUMC_DP_OVERLAP=1 selects the two-slice variant above.
+        # On one rank the phase split + the asynchronous hand-off cost 0.075 ms per step (tools/dp_rccl_probe.py), about what
+        # the whole 15.4 MB all-reduce should take on an 8 x MI355X xGMI mesh (7 links x ~100 GB/s achievable per GPU), so
+        # until it is measured on a multi-GPU node the variant with fewer collectives and no asynchronous hand-off is the default.
+        self.overlap = (self.collect and dist.get_backend() == "nccl" and os.environ.get("SDUMC_DP_OVERLAP", "0") == "1")
 
     def set_batch(self, *batch):
         """The LOCAL shard: rows [rank*B, (rank+1)*B) of the global batch."""

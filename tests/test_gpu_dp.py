@@ -139,7 +139,7 @@ p_ref = flat()
 ts = engine.TrainStep(p_ref, B, Tn, dims, seed=seed); ts.set_batch(*gb)
 p_dp = flat()
 dp = DataParallelStep(p_dp, B, Tn, dims, seed=seed, exact=True, force_collectives=True); dp.set_batch(*gb)
-assert dp.collect and dp.overlap
+assert dp.collect and dp.overlap == (os.environ.get('SDUMC_DP_OVERLAP') == '1')
 ok = True
 for it in range(3):
     l_ref = ts.run().cpu().clone()
@@ -152,9 +152,11 @@ dist.destroy_process_group()
 """
 
 
-def test_rccl_one_rank_communicator_runs_every_collective_and_matches_fused_step(tmp_path):
+@pytest.mark.parametrize("overlap", ["0", "1"])
+def test_rccl_one_rank_communicator_runs_every_collective_and_matches_fused_step(tmp_path, overlap):
     """The N > 1 code path with a real RCCL communicator (world size 1, `force_collectives`): the merged exactness
-    exchange, the asynchronous early-slice all-reduce beside the frame-level backward, the late-slice all-reduce.
+    exchange and the gradient all-reduce -- one flat bucket (overlap 0, the default), or the asynchronous early-slice
+    all-reduce beside the frame-level backward followed by the late slice (overlap 1).
     Three steps must reproduce the fused single-GPU TrainStep."""
     if not torch.cuda.is_available():
         pytest.skip("needs a GPU")
@@ -162,7 +164,8 @@ def test_rccl_one_rank_communicator_runs_every_collective_and_matches_fused_step
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     script = tmp_path / "rccl_one_rank.py"
     script.write_text(_RCCL_ONE_RANK)
-    env = dict(os.environ, SDUMC_REPO=repo, SDUMC_PORT="29547", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, SDUMC_REPO=repo, SDUMC_PORT=str(29547 + int(overlap)), HSA_ENABLE_IPC_MODE_LEGACY="0",
+               SDUMC_DP_OVERLAP=overlap)
     r = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     out = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])   # RCCL prints a banner on stdout
