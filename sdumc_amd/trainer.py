@@ -2,15 +2,15 @@
 
 One process per GPU, plain batch sharding, weights replicated.  Per step:
   1. local forward of both streams                                   (HIP, sdumc_net_forward)
-  2. exactness exchanges so that DP(N x B) == single process(N*B):
-       - all-reduce of the three RMSE sums of squared differences (RMSELoss is the sqrt of a GLOBAL
-         mean, toolkit/utils/loss.py:37-51)
-       - all-gather of the RnC embeddings and labels (RnCLoss uses in-batch negatives over n = 2*B_global,
+  2. exactness exchange so that DP(N x B) == single process(N*B), ONE all-gather of a per-rank record holding
+       - the three RMSE sums of squared differences (RMSELoss is the sqrt of a GLOBAL mean,
+         toolkit/utils/loss.py:37-51), added in rank order on every rank
+       - the RnC embeddings and labels (RnCLoss uses in-batch negatives over n = 2*B_global,
          loss.py:271-315); every rank evaluates the full loss and keeps the gradient of its own rows
   3. loss gradients w.r.t. the local outputs, backward                (HIP)
-  4. all-reduce (sum) of the flat gradient bucket over RCCL/xGMI (15.4 MB fp32) in two slices: the utterance-level
-     layers' 6.2 MB asynchronously as soon as backward phase 0 has produced them (it then overlaps the frame-level
-     backward, 0.9 ms of GEMMs), the frame-level 9.2 MB at the end
+  4. all-reduce (sum) of the flat gradient bucket over RCCL/xGMI (15.4 MB fp32): one call after the backward (default),
+     or, with SDUMC_DP_OVERLAP=1, in two slices -- the utterance-level layers' slice asynchronously as soon as backward
+     phase 0 has produced it (it then overlaps the frame-level backward, 0.9 ms of GEMMs), the frame-level slice at the end
   5. fused Adam on the flat bucket                                    (HIP)
 Dropout masks are keyed by the GLOBAL sample index, so results do not depend on N.
 
