@@ -50,6 +50,47 @@ WORKLOADS = {   # name: (batch per GPU, T, dims, algorithmic train FLOPs per sam
 WORKLOAD_TEXT = WORKLOADS["c2"][4]
 
 
+def source_sha():
+    """sha1 over the kernel sources the shipped libsdumc_hip.so is built from: ties a committed PMC summary to the code
+    it was collected on (tools/pmc_traffic_summary.py records the same value)."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    files = sorted(glob.glob(os.path.join(ROOT, "sdumc_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "sdumc_amd", "csrc", "*.h"))
+                   + glob.glob(os.path.join(ROOT, "include", "*.h")))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def spawn_ranks(n):
+    """`python3 bench.py --gpus N` without a launcher: start the N rank processes ourselves.  This parent makes NO GPU call
+    (torch is imported, nothing under torch.cuda is touched) and never exec()s: the ranks are ordinary children, rank 0's
+    stdout is relayed, and the exit code is non-zero if any rank fails."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out0, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out0.decode(errors="replace"))
+    sys.stdout.flush()
+    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
+    if bad:
+        sys.stderr.write(f"bench.py: rank(s) failed: {bad}\n")
+        return next(rc for _, rc in bad) or 1
+    return 0
+
+
 def synthetic_shard(B, rank, seed=1234):
     """SURVEY §8(d) synthetic inputs (features ~N(0,1), labels ~U(-3,3)); one generator per rank."""
     g = torch.Generator().manual_seed(seed + rank)
@@ -126,12 +167,15 @@ def recorded_traffic(kernel):
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            k = json.load(f)["kernels"].get(kernel)
+            doc = json.load(f)
+        k = doc["kernels"].get(kernel)
     except (OSError, ValueError, KeyError):
         return None, None
     if not k:
         return None, None
-    return k["traffic_bytes"], "profiles/pmc_traffic.json (rocprofv3 PMC passes, fetch x2 gfx950 correction, average per launch)"
+    if doc.get("source_sha") != source_sha():     # collected on other kernel sources: stale, not reported
+        return None, f"profiles/pmc_traffic.json is stale (collected on sources {doc.get('source_sha')}, this build is {source_sha()})"
+    return k["traffic_bytes"], "profiles/pmc_traffic.json (rocprofv3 PMC passes on these sources, fetch x2 gfx950 correction, average per launch)"
 
 
 def cpu_baseline_leg(steps=3):
@@ -202,9 +246,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus))      # no launcher: this process becomes the parent of N rank processes
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: sdumc_amd has no CPU fallback")
@@ -266,10 +310,26 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    dp_extra = None
     if world > 1 or force_dp:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        mine = torch.tensor([dt], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [float(t.item()) for t in every]
+        dt = max(per_rank)                                   # MAX over ranks, as the contract says
+        # the gradient all-reduce on its own (the flat 15.4 MB bucket, same call the step makes), outside the timed region
+        bucket = step.be.grads
+        torch.cuda.synchronize()
+        dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(20):
+            dist.all_reduce(bucket)
+        torch.cuda.synchronize()
+        ar_ms = 1e3 * (time.perf_counter() - t1) / 20
+        bucket.zero_()
+        dp_extra = {"per_rank_ms_per_step": [round(1e3 * t / args.steps, 4) for t in per_rank],
+                    "allreduce_ms": round(ar_ms, 4), "allreduce_bytes": bucket.numel() * 4,
+                    "backend": dist.get_backend(), "overlap": bool(step.overlap)}
 
     losses = (step.losses if (world == 1 and not force_dp) else step.be.losses).cpu()
     if not torch.isfinite(losses).all():
@@ -290,6 +350,8 @@ def main():
         "whole_step_tflops": round(value * TRAIN_FLOPS_PER_SAMPLE / 1e12, 2),
         "whole_step_frac_of_f32_mfma_peak": round(value * TRAIN_FLOPS_PER_SAMPLE / 1e12 / (world * PEAK_F32_MFMA_TFLOPS), 4),
     }
+    if dp_extra is not None:
+        out["data_parallel"] = dp_extra
     if not args.no_roofline:     # every rank runs it (the DP step has collectives); rank 0 reports
         roof = roofline_leg(_lib, step.launch if (world == 1 and not force_dp) else step.step, max(3, min(10, args.steps)),
                             traffic_ok=(args.workload == "c2" and not args.bf16))

@@ -37,7 +37,8 @@ def adam_state_from_flat(net, adam_m, adam_v, step, lr=1e-4, betas=(0.9, 0.999),
 
 
 def flat_from_adam_state(net, opt_state, device):
-    """Inverse of adam_state_from_flat: (adam_m, adam_v, step) flat buffers [live] for engine.TrainStep."""
+    """Inverse of adam_state_from_flat: (adam_m, adam_v, step) flat buffers [live]; hand them to
+    TrainStep / FusedTrainer / DataParallelStep .load_optimizer_state(m, v, step) to continue the run."""
     lay = net._layout
     m = torch.zeros(lay.live, device=device)
     v = torch.zeros(lay.live, device=device)
@@ -63,9 +64,12 @@ def save_checkpoint(path, model, optimizer_state, epoch):
                path)
 
 
-def load_checkpoint(path, model, strict=False):
-    """Loads like the reference's inference script: strips a leading 'module.', strict=False by default."""
-    ck = torch.load(path, map_location="cpu", weights_only=False)
+def load_checkpoint(path, model, strict=False, legacy_pickle=False):
+    """Loads like the reference's inference script: strips a leading 'module.', strict=False by default.
+    The format holds only tensors and plain containers, so it is read with torch's restricted unpickler
+    (weights_only=True); `legacy_pickle=True` opts into full pickle for files that carry other Python objects --
+    only for files you trust (the reference's own torch.load, ..._inference.py:341, executes arbitrary pickles)."""
+    ck = torch.load(path, map_location="cpu", weights_only=not legacy_pickle)
     if "state_dict" not in ck:
         raise SdumcError(f"{path}: not a reference-format checkpoint (keys {list(ck)})")
     sd = {k.replace("module.", ""): v for k, v in ck["state_dict"].items()}

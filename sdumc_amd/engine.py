@@ -166,6 +166,22 @@ class NetCall:
                 io.lengths[i] = ptr(t)
         self.io = io
 
+    def set_lengths(self, lengths):
+        """Key-padding extension for the next forward: per-modality valid frame counts, or None = the reference's behaviour."""
+        n = 4 if self.S == 2 else 3
+        new = _lengths_arg(lengths, self.B, n, self.vals.device)
+        if new is None:
+            self._lengths = None
+            for i in range(4):
+                self.io.lengths[i] = None
+            return
+        if self._lengths is None:
+            self._lengths = [torch.empty(self.B, dtype=torch.int32, device=self.vals.device) for _ in range(n)]
+            for i, t in enumerate(self._lengths):
+                self.io.lengths[i] = ptr(t)
+        for dst, src in zip(self._lengths, new):
+            dst.copy_(src, non_blocking=True)
+
     def forward(self):
         check(lib.sdumc_net_forward(C.byref(self.dims), C.byref(self.io), _lib.current_stream()), "sdumc_net_forward")
         return self.vals, self.fused, self.rnc, self.text_hidden, self.cross_text
@@ -184,7 +200,28 @@ class NetCall:
         return grads
 
 
-class TrainStep:
+class _OptStateMixin:
+    """Optimiser / RNG state of one training run: .adam_m .adam_v [live], .hyper = device {lr, step count t, lr/(1-b1^t),
+    sqrt(1-b2^t)} (the last two are recomputed from t by every step), .rng = device Philox {seed, call}."""
+
+    def optimizer_state(self):
+        """(exp_avg, exp_avg_sq, step) -- what checkpoint.adam_state_from_flat takes."""
+        return self.adam_m, self.adam_v, int(round(float(self.hyper[1].item())))
+
+    def load_optimizer_state(self, adam_m, adam_v, step):
+        """Resume (main_frame_val_text_missing.py:375 saves 'optimizer'; checkpoint.flat_from_adam_state gives the flat
+        moments): installs the Adam moments, the step count that drives the bias correction, and the dropout call
+        counter (two forward calls per step), so that the next step continues the interrupted run exactly."""
+        if adam_m.numel() != self.adam_m.numel() or adam_v.numel() != self.adam_v.numel():
+            raise _lib.SdumcError("load_optimizer_state: moment buffers must have layout.live elements")
+        step = int(step)
+        self.adam_m.copy_(adam_m.reshape(-1).to(self.adam_m.device))
+        self.adam_v.copy_(adam_v.reshape(-1).to(self.adam_v.device))
+        self.hyper[1] = float(step)
+        self.rng.set_call(2 * step)
+
+
+class TrainStep(_OptStateMixin):
     """The fused two-stream self-distillation step (main :119-150) on one GPU:
     forward(both streams) -> 6 losses -> backward -> Adam, ~150 launches on one stream,
     optionally captured into a hipGraph (torch.cuda.CUDAGraph) and replayed."""
@@ -301,8 +338,9 @@ class TrainStep:
         return self.losses
 
 
-class _RunState:
-    """Optimiser state of one training run, shared by the per-shape TrainSteps of a FusedTrainer."""
+class _RunState(_OptStateMixin):
+    """Optimiser state of one training run, shared by the per-shape TrainSteps of a FusedTrainer (and by the per-shape
+    backends of trainer.DataParallelStep)."""
 
     def __init__(self, flat_params, live, lr, seed):
         dev = flat_params.device
@@ -341,6 +379,12 @@ class FusedTrainer:
 
     def set_lr(self, lr):
         self.state.hyper[0] = lr
+
+    def load_optimizer_state(self, adam_m, adam_v, step):
+        self.state.load_optimizer_state(adam_m, adam_v, step)
+
+    def optimizer_state(self):
+        return self.state.optimizer_state()
 
     def step(self, audio, text, video, feat4, labels, lengths=None):
         """One optimisation step on one batch of any shape; returns the device loss vector

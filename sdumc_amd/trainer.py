@@ -34,7 +34,11 @@ class HipBackend:
     """Per-rank compute on one MI355X through the C ABI."""
 
     def __init__(self, flat_params, B, T, dims, weights, lr, betas, eps, weight_decay, seed, sample0, B_global,
-                 bf16=False):
+                 bf16=False, share=None):
+        """share: the run state (engine._RunState: rng, Adam moments, hyper, losses, gradient bucket) of the training run
+        this backend belongs to.  The reference's loader pads every batch to its own max T and ends an epoch on a short
+        batch (read_data.py:223-248), so a run needs one backend per (B, T) shape; they must all continue ONE optimiser
+        state, step count and dropout call counter (DataParallelStep keeps them in an LRU and passes the same `share`)."""
         from . import _lib, engine
         self._lib, self._engine = _lib, engine
         lib = _lib.lib
@@ -48,7 +52,11 @@ class HipBackend:
         self.video = torch.empty(B, Tv, dims[2], device=dev)
         self.feat4 = torch.empty(B, T4, dims[1], device=dev)
         self.labels = torch.empty(B, device=dev)
-        self.rng = engine.RngState(seed, dev)
+        st = share if share is not None else engine._RunState(flat_params, self.layout.live, lr, seed)
+        if st.params.data_ptr() != flat_params.data_ptr():
+            raise _lib.SdumcError("share: the run state belongs to another parameter buffer")
+        self.state = st
+        self.rng = st.rng
         self.call = engine.NetCall(flat_params, self.audio, [self.text, self.feat4], self.video, True, self.rng,
                                    sample0=sample0, bf16=bf16)
         V = 2 * B
@@ -57,11 +65,10 @@ class HipBackend:
         self.d_rnc = torch.empty(V, engine.RNC_DIM, device=dev)
         self.d_text_hidden = torch.empty(V, engine.D, device=dev)
         self.d_cross_text = torch.empty(V, engine.NQ, engine.H, device=dev)
-        self.grads = torch.zeros(self.layout.live, device=dev)
-        self.adam_m = torch.zeros(self.layout.live, device=dev)
-        self.adam_v = torch.zeros(self.layout.live, device=dev)
-        self.hyper = torch.tensor([lr, 0.0, 0.0, 0.0], device=dev)
-        self.losses = torch.zeros(8, device=dev)
+        if getattr(st, "grads", None) is None:
+            st.grads = torch.zeros(self.layout.live, device=dev)     # the all-reduce bucket: one per run, not per shape
+        self.grads = st.grads
+        self.adam_m, self.adam_v, self.hyper, self.losses = st.adam_m, st.adam_v, st.hyper, st.losses
         self.ssd = torch.zeros(4, device=dev)
         nb = lib.sdumc_loss_workspace_bytes(C.byref(self.call.dims), B_global)
         self.loss_ws = torch.empty(nb, dtype=torch.uint8, device=dev)
@@ -88,6 +95,13 @@ class HipBackend:
         self.video.copy_(video, non_blocking=True)
         self.feat4.copy_(feat4, non_blocking=True)
         self.labels.copy_(labels.reshape(-1), non_blocking=True)
+
+    def set_lengths(self, lengths):
+        """Key-padding extension (default None = the reference's behaviour): (audio, text, video, feat4) valid frame counts."""
+        self.call.set_lengths(lengths)
+
+    def load_optimizer_state(self, adam_m, adam_v, step):
+        self.state.load_optimizer_state(adam_m, adam_v, step)
 
     def forward(self):
         self.call.forward()
@@ -175,6 +189,8 @@ class DataParallelStep:
     def __init__(self, flat_params, B, T, dims, weights=(0.5, 0.5, 0.1, 0.7, 0.1, 0.8), lr=1e-4, betas=(0.9, 0.999),
                  eps=1e-8, weight_decay=1e-5, seed=0, exact=True, backend_factory=None, bf16=False,
                  force_collectives=False):
+        import collections
+        import inspect
         self.rank, self.world = _world()
         # force_collectives: issue every collective even at world size 1 (a one-rank RCCL communicator): the only way to
         # exercise the RCCL code path -- communicator stream ordering, the async early-slice handle -- on a 1-GPU box.
@@ -184,8 +200,22 @@ class DataParallelStep:
         self.B_global = B * self.world if exact else B
         factory = backend_factory or HipBackend
         extra = {"bf16": True} if bf16 else {}
-        self.be = factory(flat_params, B, T, dims, weights, lr, betas, eps, weight_decay, seed, self.rank * B,
-                          self.B_global, **extra)
+        # One backend per batch shape (B, T_audio, T_text, T_video, T_feat4), least recently used first out, all continuing
+        # ONE run state: the reference pads every batch to its own maximum and ends an epoch on a short batch.
+        self._shares = "share" in inspect.signature(factory).parameters
+        self.state = None
+        if self._shares:
+            from . import engine
+            lay = engine.ParamLayout.get(dims[0], dims[1], dims[2])
+            self.state = engine._RunState(flat_params, lay.live, lr, seed)
+            extra["share"] = self.state
+
+        def make(Bl, Tl):
+            Bg = Bl * self.world if exact else Bl
+            return factory(flat_params, Bl, tuple(Tl), dims, weights, lr, betas, eps, weight_decay, seed, self.rank * Bl,
+                           Bg, **extra)
+        self._make, self._bes, self.max_cached = make, collections.OrderedDict(), 8
+        self.be = self._backend(B, T)
         self.weights = weights
         # The early-slice all-reduce is issued asynchronously only on RCCL ("nccl"), where it is a kernel on the
         # communicator's own stream beside the frame-level backward (the pattern torch DDP uses).  Under gloo (CPU tests,
@@ -197,9 +227,50 @@ class DataParallelStep:
         # until it is measured on a multi-GPU node the variant with fewer collectives and no asynchronous hand-off is the default.
         self.overlap = (self.collect and dist.get_backend() == "nccl" and os.environ.get("SDUMC_DP_OVERLAP", "0") == "1")
 
-    def set_batch(self, *batch):
-        """The LOCAL shard: rows [rank*B, (rank+1)*B) of the global batch."""
-        self.be.set_batch(*batch)
+    def _backend(self, B, T):
+        key = (int(B),) + tuple(int(t) for t in T)
+        be = self._bes.pop(key, None)
+        if be is None:
+            if self._bes and not self._shares:
+                raise RuntimeError("this compute backend keeps its own optimiser state: one batch shape per run")
+            while len(self._bes) >= self.max_cached:
+                del self._bes[next(iter(self._bes))]
+            be = self._make(B, T)
+        self._bes[key] = be
+        return be
+
+    def set_batch(self, audio, text, video, feat4, labels, lengths=None):
+        """The LOCAL shard: rows [rank*B, (rank+1)*B) of the global batch.  Shapes may change from batch to batch; every
+        rank must hold the same local B, and -- for DP(N x B) to equal one process on N*B samples, where the collater pads
+        each modality to the GLOBAL batch maximum (read_data.py:223-248) -- the same padded T (`pad_to_global_max`).
+        lengths: key-padding extension, forwarded to the kernels (default None = the reference's behaviour)."""
+        B, T = audio.shape[0], (audio.shape[1], text.shape[1], video.shape[1], feat4.shape[1])
+        self.be = self._backend(B, T)
+        self.B, self.B_global = B, (B * self.world if self.exact else B)
+        self.be.set_batch(audio, text, video, feat4, labels)
+        if lengths is not None or hasattr(self.be, "set_lengths"):
+            if hasattr(self.be, "set_lengths"):
+                self.be.set_lengths(lengths)
+            elif lengths is not None:
+                raise RuntimeError("this compute backend has no key-padding extension")
+
+    def pad_to_global_max(self, audio, text, video, feat4):
+        """Right-zero-pads the four local feature tensors to the per-modality maximum over all ranks (one tiny MAX
+        all-reduce): what the reference's collater does for the whole batch."""
+        t = torch.tensor([audio.shape[1], text.shape[1], video.shape[1], feat4.shape[1]], dtype=torch.int64,
+                         device=audio.device if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu")
+        if self.collect:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        out = []
+        for x, T in zip((audio, text, video, feat4), t.tolist()):
+            out.append(x if x.shape[1] == T else torch.nn.functional.pad(x, (0, 0, 0, T - x.shape[1])))
+        return out
+
+    def load_optimizer_state(self, adam_m, adam_v, step):
+        """Resume: Adam moments, step count and dropout call counter of an interrupted run (checkpoint.flat_from_adam_state)."""
+        if self.state is None:
+            raise RuntimeError("this compute backend keeps its own optimiser state")
+        self.state.load_optimizer_state(adam_m, adam_v, step)
 
     def _gather(self, t):
         parts = [torch.empty_like(t) for _ in range(self.world)]
@@ -217,7 +288,7 @@ class DataParallelStep:
             # tensor blocked the host for ~240 ms per call on this stack while all_reduce does not.
             if hasattr(be, "dp_pack"):      # HIP backend: one pack kernel, one collective, one unpack kernel
                 rec = be.dp_pack()
-                if self._records is None:
+                if self._records is None or self._records.shape[1] != rec.numel():
                     self._records = torch.empty(W, rec.numel(), dtype=rec.dtype, device=rec.device)
                 if dist.get_backend() == "nccl":
                     dist.all_gather_into_tensor(self._records, rec)

@@ -6,6 +6,7 @@ import re
 import subprocess
 
 import numpy as np
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -101,3 +102,19 @@ def test_schedule_and_metric(golden):
     np.testing.assert_allclose(m["mae"], mean_absolute_error(y, p))
     np.testing.assert_allclose(m["acc2"], accuracy_score(y[nz] > 0, p[nz] > 0))
     np.testing.assert_allclose(m["f1"], f1_score(y[nz] > 0, p[nz] > 0, average="weighted"))
+
+
+def test_run_state_resume_installs_step_count_and_dropout_counter():
+    """engine._RunState.load_optimizer_state (host logic, no kernel call): moments copied, hyper[1] = step (drives the Adam
+    bias correction in the fused step), Philox call counter = 2 * step (two forward calls per optimisation step)."""
+    import torch
+    from sdumc_amd import engine
+    st = engine._RunState(torch.zeros(16), 8, 1e-3, seed=(7 << 32) | 5)
+    m, v = torch.arange(8.0), torch.arange(8.0) * 2
+    st.load_optimizer_state(m, v, 11)
+    assert torch.equal(st.adam_m, m) and torch.equal(st.adam_v, v)
+    assert float(st.hyper[0]) == pytest.approx(1e-3) and float(st.hyper[1]) == 11.0
+    assert st.rng.call == 22 and st.rng.t[:2].tolist() == [5, 7]
+    assert st.optimizer_state()[2] == 11
+    with pytest.raises(Exception):
+        st.load_optimizer_state(torch.zeros(4), v, 1)

@@ -1,0 +1,240 @@
+"""GPU parity tests at the shapes BASELINE.json's `configs` name, beyond the C2 cases of
+test_gpu_net.py:
+  configs[0]  C1  CMU-MOSI-shaped, B = 16, T = (200, 16, 120, 16): one full step against the oracle
+  configs[3]  C4  CMU-MOSEI-shaped, global batch 512: on ONE GPU (the truth the data-parallel run must reproduce:
+                  main_frame_val_text_missing.py:119-150 on the whole batch) + two simulated ranks of 256
+  configs[4]  C5  long sequences T = 512, d = 1024 in its stated bf16 arithmetic against the fp32 oracle (2e-2)
+plus the run-state plumbing of the data-parallel trainer (changing batch shapes, resume)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NAMES = ("vals", "fused", "rnc", "text_hidden", "cross_text")
+
+
+@pytest.fixture(scope="module")
+def E():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from sdumc_amd import engine
+    return engine
+
+
+def close(got, want, tol=1e-4, msg=""):
+    got = got.detach().cpu().double().numpy()
+    want = want.detach().cpu().double().numpy() if isinstance(want, torch.Tensor) else np.asarray(want, dtype=np.float64)
+    scale = max(1.0, np.abs(want).max())
+    np.testing.assert_allclose(got, want.reshape(got.shape), rtol=tol, atol=tol * scale, err_msg=msg)
+
+
+def flat_from(E, P, dims):
+    lay = E.ParamLayout.get(*dims[:3])
+    flat = torch.zeros(lay.total)
+    for k, v in lay.views(flat).items():
+        v.copy_(P[k])
+    return flat.cuda(), lay
+
+
+def test_c1_mosi_shapes_full_step_vs_oracle(E):
+    """BASELINE configs[0] (C1): B = 16, T = (200, 16, 120, 16), full feature widths, train mode with Philox masks:
+    loss, the six terms, the five outputs of both streams, every gradient and the Adam update against the oracle."""
+    from oracle import sdumc_oracle as O
+    dims = (1024, 4096, 1024, 4096)
+    B, Tn = 16, (200, 16, 120, 16)
+    P = O.init_params(dims, seed=0)
+    flat, lay = flat_from(E, P, dims)
+    audio, text, video, feat4, vals = O.synthetic_batch(B, Tn, dims, seed=1234)
+    ts = E.TrainStep(flat, B, Tn, dims, seed=31)
+    ts.set_batch(audio.cuda(), text.cuda(), video.cuda(), feat4.cuda(), vals.cuda())
+    losses = ts.run().cpu().numpy()
+    Pd = {k: v.clone() for k, v in P.items()}
+    loss, terms, grads, outs = O.train_step(Pd, {}, audio, text, video, feat4, vals, mode="philox", seed=31, step=0)
+    np.testing.assert_allclose(losses[0], float(loss), rtol=1e-3)
+    np.testing.assert_allclose(losses[1:7], [float(t) for t in terms], rtol=1e-3, atol=1e-5)
+    for s in range(2):
+        for n, got, want in zip(NAMES, (ts.vals, ts.fused, ts.rnc, ts.text_hidden, ts.cross_text), outs[s]):
+            close(got[s * B:(s + 1) * B], want, 1e-3, f"{n} stream {s}")
+    gv = lay.views(torch.cat([ts.grads.cpu(), torch.zeros(lay.total - lay.live)]))
+    for k in lay.live_names():
+        close(gv[k], grads[k], 1e-3, k)
+    pv = lay.views(flat.cpu())
+    for k in ("frame_dim_reshape_0.weight", "cross_att_fra2utt_2.input_proj.weight", "cross_attention_mlp.0.weight"):
+        close((pv[k] - P[k]) * 1e4, (Pd[k] - P[k]) * 1e4, 2e-2, k)
+
+
+def test_c4_global_batch_512_on_one_gpu_and_two_simulated_ranks(E):
+    """BASELINE configs[3] (C4) at its size: the global batch of 512 MOSEI-shaped samples as ONE process on one GPU (what
+    the 8-GPU data-parallel run has to equal), size-independent properties, and two simulated ranks of 256 whose summed
+    gradients, exchanged losses and Adam update reproduce it."""
+    from oracle import sdumc_oracle as O
+    from sdumc_amd.trainer import HipBackend
+    dims = (1024, 4096, 1024, 4096)
+    B, Tn, W, seed = 512, (375, 32, 225, 32), 2, 5
+    P = O.init_params(dims, seed=0)
+    flat, lay = flat_from(E, P, dims)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    audio, text, video, feat4 = [torch.randn(B, Tn[i], dims[i], device="cuda", generator=g) for i in range(4)]
+    vals = torch.rand(B, device="cuda", generator=g) * 6 - 3
+    # eval: the batch equals its two halves (samples are independent)
+    full = [t.clone() for t in E.NetCall(flat, audio, [text, feat4], video, False, None).forward()]
+    h = B // W
+    for lo in (0, h):
+        part = E.NetCall(flat, audio[lo:lo + h].contiguous(), [text[lo:lo + h].contiguous(), feat4[lo:lo + h].contiguous()],
+                         video[lo:lo + h].contiguous(), False, None).forward()
+        for n, f, p in zip(NAMES, full, part):
+            for s in range(2):
+                close(p[s * h:(s + 1) * h], f[s * B + lo:s * B + lo + h], 1e-5, n)
+    del full, part
+    # the single-process step on all 512 samples (RnC over n = 1024 rows: the sorted formulation)
+    p_full = flat.clone()
+    ts = E.TrainStep(p_full, B, Tn, dims, seed=seed)
+    ts.set_batch(audio, text, video, feat4, vals)
+    ref_losses = ts.run().cpu().clone()
+    ref_grads = ts.grads.clone()
+    assert torch.isfinite(ref_losses).all() and torch.isfinite(ref_grads).all()
+    del ts
+    # two ranks of 256 (collectives spelt out), B_global = 512
+    bes = []
+    for r in range(W):
+        be = HipBackend(flat.clone(), h, Tn, dims, E.DEFAULT_WEIGHTS, 1e-4, (0.9, 0.999), 1e-8, 1e-5, seed, r * h, B)
+        be.set_batch(*[t[r * h:(r + 1) * h].contiguous() for t in (audio, text, video, feat4, vals)])
+        bes.append(be)
+    rncs = [be.forward().clone() for be in bes]
+    ssd = sum(be.local_ssd().clone() for be in bes)
+    feats = torch.cat([p[:h] for p in rncs] + [p[h:] for p in rncs]).contiguous()
+    lab = torch.cat([be.labels for be in bes])
+    labels2 = torch.cat([lab, lab]).contiguous()
+    ls = [be.loss_backward(ssd, feats, labels2, (r * h, W * h + r * h)).cpu().clone() for r, be in enumerate(bes)]
+    gsum = sum(be.backward().clone() for be in bes)
+    np.testing.assert_allclose((ls[0][1:3] + ls[1][1:3]).numpy(), ref_losses[1:3].numpy(), rtol=1e-4)
+    for l in ls:
+        np.testing.assert_allclose(l[3:7].numpy(), ref_losses[3:7].numpy(), rtol=1e-4)
+    gv, rv = gsum.cpu(), ref_grads.cpu()
+    for k in lay.live_names():
+        off, shape, _ = lay.entries[k]
+        n = int(np.prod(shape))
+        close(gv[off:off + n], rv[off:off + n], 1e-3, k)
+    for be in bes:
+        be.grads.copy_(gsum)
+        be.adam(1.0)
+    torch.cuda.synchronize()
+    assert torch.equal(bes[0].params, bes[1].params)
+    np.testing.assert_allclose(((bes[0].params - flat) * 1e4).cpu().numpy(), ((p_full - flat) * 1e4).cpu().numpy(),
+                               rtol=5e-2, atol=5e-2)
+
+
+def test_c5_long_sequence_shapes_in_bf16_vs_fp32_oracle(E):
+    """BASELINE configs[4] (C5) in its stated arithmetic: T = 512 for every modality, d = 1024, bf16 mode, one full
+    train step against the fp32 oracle at the bf16 bar of SURVEY §8(d) (2e-2), gradients norm-wise."""
+    from oracle import sdumc_oracle as O
+    dims = (1024, 1024, 1024, 1024)
+    B, Tn = 4, (512, 512, 512, 512)
+    P = O.init_params(dims, seed=4)
+    flat, lay = flat_from(E, P, dims)
+    batch = O.synthetic_batch(B, Tn, dims, seed=21)
+    dev = [t.cuda() for t in batch]
+    f32 = [t.clone() for t in E.NetCall(flat, dev[0], [dev[1], dev[3]], dev[2], False, None).forward()]
+    b16 = [t.clone() for t in E.NetCall(flat, dev[0], [dev[1], dev[3]], dev[2], False, None, bf16=True).forward()]
+    for n, a, b in zip(NAMES, f32, b16):
+        close(b, a, 2e-2, "bf16 " + n)
+    assert max(float((a - b).abs().max()) for a, b in zip(f32, b16)) > 1e-6, "bf16 mode is not active"
+    ts = E.TrainStep(flat, B, Tn, dims, seed=11, bf16=True)
+    ts.set_batch(*dev)
+    losses = ts.run().cpu().numpy()
+    loss, terms, grads, outs = O.train_step({k: v.clone() for k, v in P.items()}, {}, *batch, mode="philox", seed=11, step=0)
+    np.testing.assert_allclose(losses[0], float(loss), rtol=2e-2)
+    np.testing.assert_allclose(losses[1:7], [float(t) for t in terms], rtol=2e-2, atol=1e-4)
+    gv = lay.views(torch.cat([ts.grads.cpu(), torch.zeros(lay.total - lay.live)]))
+    errs = []
+    for k in lay.live_names():
+        if k == "orgin_linear_change.2.bias":
+            continue
+        ref = grads[k].double()
+        errs.append(float((gv[k].double() - ref).norm() / (ref.norm() + 1e-12)))
+    assert float(np.median(errs)) < 4e-2 and max(errs) < 0.2, (float(np.median(errs)), max(errs))
+
+
+def test_data_parallel_step_over_changing_shapes_and_resume(E):
+    """trainer.DataParallelStep on real loader behaviour: batch shapes change from step to step (per-batch padding, short last
+    batch) while ONE optimiser state / step count / dropout counter continues (compared with engine.FusedTrainer over the
+    same batches), the key-padding lengths are forwarded, and a run resumed through load_optimizer_state equals the
+    uninterrupted one bit for bit."""
+    from oracle import sdumc_oracle as O
+    from sdumc_amd.trainer import DataParallelStep
+    dims = (24, 16, 20, 16)
+    shapes = [(4, (9, 2, 5, 3)), (3, (7, 4, 6, 1)), (4, (9, 2, 5, 3)), (2, (12, 3, 2, 2))]
+    P = O.init_params(dims, seed=8)
+    batches = [[t.cuda() for t in O.synthetic_batch(B, Tn, dims, seed=100 + i)] for i, (B, Tn) in enumerate(shapes)]
+    lens = [[torch.randint(1, T + 1, (B,)) for T in Tn] for (B, Tn) in shapes]
+
+    def run(steps, with_lengths, resume_at=None):
+        flat, lay = flat_from(E, P, dims)
+        dp = DataParallelStep(flat, shapes[0][0], shapes[0][1], dims, lr=1e-3, seed=17)
+        out = []
+        for i in steps:
+            if resume_at is not None and i == resume_at:
+                m, v, t = dp.state.optimizer_state()
+                m, v, params = m.clone(), v.clone(), flat.clone()
+                flat2 = params                                   # a fresh process: new trainer, restored state
+                dp = DataParallelStep(flat2, shapes[i][0], shapes[i][1], dims, lr=1e-3, seed=17)
+                dp.load_optimizer_state(m, v, t)
+                flat = flat2
+            dp.set_batch(*batches[i], lengths=lens[i] if with_lengths else None)
+            out.append(dp.step().clone())
+        return flat, out, dp
+
+    flat_dp, l_dp, dp = run(range(4), False)
+    flat_ft, lay = flat_from(E, P, dims)
+    ft = E.FusedTrainer(flat_ft, dims, lr=1e-3, seed=17)
+    for i, b in enumerate(batches):
+        l = ft.step(*b)
+        np.testing.assert_allclose(l_dp[i].cpu().numpy()[1:7], l.cpu().numpy()[1:7], rtol=1e-5, atol=1e-7, err_msg=f"step {i}")
+    np.testing.assert_allclose(flat_dp.cpu().numpy(), flat_ft.cpu().numpy(), rtol=0, atol=2e-6)
+    assert dp.state.rng.call == 8 and int(dp.state.hyper[1].item()) == 4 and len(dp._bes) == 3
+    # resume after two steps == uninterrupted
+    flat_rs, l_rs, _ = run(range(4), False, resume_at=2)
+    assert torch.equal(flat_rs, flat_dp)
+    for a, b in zip(l_dp, l_rs):
+        assert torch.equal(a, b)
+    # lengths reach the kernels: same batches with the key-padding mask differ from the unmasked run and equal FusedTrainer's
+    flat_m, l_m, _ = run(range(4), True)
+    flat_f2, _ = flat_from(E, P, dims)
+    ft2 = E.FusedTrainer(flat_f2, dims, lr=1e-3, seed=17)
+    for i, b in enumerate(batches):
+        l = ft2.step(*b, lengths=lens[i])
+        np.testing.assert_allclose(l_m[i].cpu().numpy()[1:7], l.cpu().numpy()[1:7], rtol=1e-5, atol=1e-7)
+    assert not torch.equal(l_m[0], l_dp[0])
+
+
+def test_fused_trainer_resume_equals_uninterrupted_run(E):
+    """save -> load -> continue through checkpoint.adam_state_from_flat / flat_from_adam_state and
+    FusedTrainer.load_optimizer_state: Adam moments, bias-correction step count and dropout counter all continue."""
+    from oracle import sdumc_oracle as O
+    from sdumc_amd import checkpoint as ck
+    dims = (24, 16, 20, 16)
+    B, Tn = 4, (9, 2, 5, 3)
+    P = O.init_params(dims, seed=9)
+    batches = [[t.cuda() for t in O.synthetic_batch(B, Tn, dims, seed=200 + i)] for i in range(4)]
+    flat_a, lay = flat_from(E, P, dims)
+    tr = E.FusedTrainer(flat_a, dims, lr=1e-3, seed=3)
+    la = [tr.step(*b).clone() for b in batches]
+    flat_b, _ = flat_from(E, P, dims)
+    tr1 = E.FusedTrainer(flat_b, dims, lr=1e-3, seed=3)
+    lb = [tr1.step(*b).clone() for b in batches[:2]]
+    m, v, t = tr1.optimizer_state()
+    assert t == 2
+
+    class _Net:        # what checkpoint.* needs of the module: the layout and the parameter order
+        _layout = lay
+        _pnames = lay.order
+    opt = ck.adam_state_from_flat(_Net, m, v, t, lr=1e-3)
+    m2, v2, t2 = ck.flat_from_adam_state(_Net, opt, "cuda")
+    flat_c = flat_b.clone()
+    tr2 = E.FusedTrainer(flat_c, dims, lr=1e-3, seed=3)
+    tr2.load_optimizer_state(m2, v2, t2)
+    lb += [tr2.step(*b).clone() for b in batches[2:]]
+    for a, b in zip(la, lb):
+        assert torch.equal(a, b)
+    assert torch.equal(flat_a, flat_c)

@@ -42,7 +42,11 @@ def main():
     fetch = load(sys.argv[1], "FETCH_SIZE")
     write = load(sys.argv[2], "WRITE_SIZE")
     steps = int(sys.argv[4]) if len(sys.argv) > 4 else None
-    out = {"units": "bytes per launch (average over the launches of the profiled run)",
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import source_sha
+    out = {"source_sha": source_sha(),
+           "units": "bytes per launch (average over the launches of the profiled run)",
            "corrections": "KiB -> bytes; FETCH_SIZE x2 (gfx950: 128-byte requests tallied at 64 bytes); WRITE_SIZE as read",
            "caveat": "L2 <-> fabric requests: Infinity-Cache hits are included, so this bounds HBM bytes from above",
            "kernels": {}}
