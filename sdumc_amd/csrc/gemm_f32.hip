@@ -37,13 +37,14 @@ struct ProfRec {
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::mutex g_prof_mu;
-constexpr int kNumVariants = 15;
+constexpr int kNumVariants = 17;
 const char* const kVariantName[kNumVariants] = {"gemm_nt_128x128", "gemm_nt_64x64",  "gemm_nn_128x128",
                                                 "gemm_nn_64x64",   "gemm_tn_128x128", "gemm_tn_64x64",
                                                 "gemm_small_nt",   "gemm_small_nn",   "gemm_small_tn",
                                                 "gemm_bf16_nt_128x128", "gemm_bf16_nt_64x64",
                                                 "gemm_bf16_nn_128x128", "gemm_bf16_nn_64x64",
-                                                "gemm_bf16_tn_128x128", "gemm_bf16_tn_64x64"};
+                                                "gemm_bf16_tn_128x128", "gemm_bf16_tn_64x64",
+                                                "gemm_wide_nt", "gemm_wide_tn"};
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;
@@ -703,7 +704,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const sdumc_gemm g, 
 inline int small_waves(int K) { return (SDUMC_SMALL_WAVES_MAX == 8 && K >= 128) ? 8 : 4; }
 
 struct GemmPlan {
-  int tile;    // 1 = 128x128, 2 = 64x64, 3 = small-problem kernel (32x32 tile, intra-workgroup split-K)
+  int tile;    // 1 = 128x128, 2 = 64x64, 3 = small-problem kernel (32x32 tile, intra-workgroup split-K),
+               // 11..14 = gemm_wide.hip's LDS-DMA kernels (64x256, 128x256, 128x128, 64x128)
   int nsplit;
   int kchunk;
   int waves = 4;   // tile 3 only
@@ -725,6 +727,21 @@ size_t plan_ws_bytes(const sdumc_gemm& g, int nsplit) {
 // per workgroup -- below that the extra reduce launch costs more than the shorter k-loop saves.
 GemmPlan plan_gemm(const sdumc_gemm& g, size_t ws_bytes) {
   GemmPlan p;
+  if (g.tile >= 11 && g.tile <= 14) {     // wide kernels: NT unsplit, TN split K over ~2 workgroups per CU
+    p.tile = g.tile;
+    const int bm = (g.tile == 12 || g.tile == 13) ? 128 : 64, bn = (g.tile == 11 || g.tile == 12) ? 256 : 128;
+    const long tiles = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * g.groups;
+    const int kt = (g.K + 15) / 16;
+    int s = 1;
+    if (g.splitk >= 1) s = std::min(g.splitk, kt);
+    else if (g.layout == SDUMC_TN) s = (int)std::max<long>(1, std::min<long>(kt / 8, 512 / std::max<long>(1, tiles)));
+    while (s > 1 && plan_ws_bytes(g, s) > ws_bytes) --s;
+    p.nsplit = s;
+    p.kchunk = ((kt + s - 1) / s) * 16;
+    p.nsplit = (kt * 16 + p.kchunk - 1) / p.kchunk;
+    if (p.nsplit <= 1) { p.nsplit = 1; p.kchunk = ((g.K + 15) / 16) * 16; }
+    return p;
+  }
   const int ktiles = (g.K + BK - 1) / BK;
   const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.groups;
   const long small = (long)((g.M + 63) / 64) * ((g.N + 63) / 64) * g.groups;
@@ -792,6 +809,8 @@ int launch(const sdumc_gemm& g, int nsplit, int kchunk, hipStream_t st) {
 
 }  // namespace
 
+extern "C" int sdumc_gemm_wide_(const sdumc_gemm* gp, int cfg, int nsplit, int kchunk, void* stream);   // gemm_wide.hip
+
 extern "C" size_t sdumc_gemm_workspace_bytes(const sdumc_gemm* g) {
   if (!g || g->M <= 0 || g->N <= 0 || g->K <= 0 || g->groups < 1) return 0;
   return plan_ws_bytes(*g, plan_gemm(*g, (size_t)-1).nsplit);
@@ -824,11 +843,42 @@ extern "C" int sdumc_gemm_f32(const sdumc_gemm* gp, void* stream) {
     for (int i = 0; i < g.groups; ++i)
       if ((reinterpret_cast<uintptr_t>(g.A[i]) | reinterpret_cast<uintptr_t>(g.B[i])) & 15) return SDUMC_EINVAL;
   }
-  const GemmPlan pl = plan_gemm(g, g.workspace ? g.workspace_bytes : 0);
+  GemmPlan pl = plan_gemm(g, g.workspace ? g.workspace_bytes : 0);
+  hipStream_t st = as_stream(stream);
+  if (pl.tile >= 11) {
+    if (pl.nsplit > 1 && (!g.workspace || g.workspace_bytes < plan_ws_bytes(g, pl.nsplit))) return SDUMC_ENOMEM;
+    ProfRec wrec;
+    const bool wprof = g_prof_on;
+    if (wprof) {
+      if (hipEventCreate(&wrec.a) != hipSuccess || hipEventCreate(&wrec.b) != hipSuccess) return SDUMC_ELAUNCH;
+      wrec.variant = g.layout == SDUMC_TN ? 16 : 15;
+      wrec.flops = 2.0 * g.M * (double)g.N * g.K * g.groups;
+      (void)hipEventRecord(wrec.a, st);
+    }
+    const int wrc = sdumc_gemm_wide_(&g, pl.tile - 10, pl.nsplit, pl.kchunk, stream);
+    if (wrc < 0) return wrc;
+    if (wrc == SDUMC_OK) {
+      if (wprof) {
+        (void)hipEventRecord(wrec.b, st);
+        std::lock_guard<std::mutex> lock(g_prof_mu);
+        g_prof.push_back(wrec);
+      }
+      if (pl.nsplit > 1) {
+        const size_t mn = (size_t)g.M * g.N + (size_t)g.M;
+        dim3 grid((unsigned)((mn + 255) / 256), g.groups);
+        hipLaunchKernelGGL(splitk_reduce_kernel, grid, dim3(256), 0, st, g, pl.nsplit);
+        SDUMC_CHECK_LAUNCH();
+      }
+      return SDUMC_OK;
+    }
+    if (wprof) { (void)hipEventDestroy(wrec.a); (void)hipEventDestroy(wrec.b); }
+    sdumc_gemm g2 = g;           // not a problem the wide kernels take: the generic plan
+    g2.tile = 0;
+    return sdumc_gemm_f32(&g2, stream);
+  }
   const int nsplit = pl.nsplit, kchunk = pl.kchunk, tile = pl.tile;
   const int small_nw = pl.waves;
   if (nsplit > 1 && (!g.workspace || g.workspace_bytes < plan_ws_bytes(g, nsplit))) return SDUMC_ENOMEM;
-  hipStream_t st = as_stream(stream);
   ProfRec rec;
   const bool prof = g_prof_on;
   if (prof) {

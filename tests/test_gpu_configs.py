@@ -121,8 +121,11 @@ def test_c4_global_batch_512_on_one_gpu_and_two_simulated_ranks(E):
         be.adam(1.0)
     torch.cuda.synchronize()
     assert torch.equal(bes[0].params, bes[1].params)
-    np.testing.assert_allclose(((bes[0].params - flat) * 1e4).cpu().numpy(), ((p_full - flat) * 1e4).cpu().numpy(),
-                               rtol=5e-2, atol=5e-2)
+    # the first Adam step is lr * g / (|g| + eps): ill-conditioned where g is rounding noise (|g| ~ eps = 1e-8)
+    ok = torch.zeros(lay.total, dtype=torch.bool)
+    ok[:lay.live] = rv.abs() > 1e-5
+    np.testing.assert_allclose(((bes[0].params - flat) * 1e4).cpu().numpy()[ok.numpy()],
+                               ((p_full - flat) * 1e4).cpu().numpy()[ok.numpy()], rtol=5e-2, atol=5e-2)
 
 
 def test_c5_long_sequence_shapes_in_bf16_vs_fp32_oracle(E):
@@ -147,13 +150,14 @@ def test_c5_long_sequence_shapes_in_bf16_vs_fp32_oracle(E):
     np.testing.assert_allclose(losses[0], float(loss), rtol=2e-2)
     np.testing.assert_allclose(losses[1:7], [float(t) for t in terms], rtol=2e-2, atol=1e-4)
     gv = lay.views(torch.cat([ts.grads.cpu(), torch.zeros(lay.total - lay.live)]))
-    errs = []
-    for k in lay.live_names():
-        if k == "orgin_linear_change.2.bias":
-            continue
-        ref = grads[k].double()
-        errs.append(float((gv[k].double() - ref).norm() / (ref.norm() + 1e-12)))
-    assert float(np.median(errs)) < 4e-2 and max(errs) < 0.2, (float(np.median(errs)), max(errs))
+    # norm-wise per tensor; tensors whose gradient is (analytically or numerically) negligible next to the largest one --
+    # orgin_linear_change.2.bias is exactly zero by the translation invariance of RnC -- carry no signal to compare
+    norms = {k: float(grads[k].double().norm()) for k in lay.live_names()}
+    floor = 1e-4 * max(norms.values())
+    errs = {k: float((gv[k].double() - grads[k].double()).norm() / (norms[k] + 1e-30)) for k in lay.live_names() if norms[k] > floor}
+    worst = max(errs, key=errs.get)
+    assert len(errs) >= len(norms) - 4, sorted(set(norms) - set(errs))
+    assert float(np.median(list(errs.values()))) < 4e-2 and errs[worst] < 0.2, (float(np.median(list(errs.values()))), worst, errs[worst])
 
 
 def test_data_parallel_step_over_changing_shapes_and_resume(E):
