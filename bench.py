@@ -132,8 +132,8 @@ def roofline_leg(_lib, launch, steps, traffic_ok=True):
     for _ in range(steps):
         launch()
     torch.cuda.synchronize()
-    arr = (_lib.ProfEntry * 16)()
-    n = lib.sdumc_profile_report(arr, 16)
+    arr = (_lib.ProfEntry * 32)()
+    n = lib.sdumc_profile_report(arr, 32)
     lib.sdumc_profile_enable(0)
     lib.sdumc_set_concurrency(1)
     rows = []

@@ -727,9 +727,10 @@ size_t plan_ws_bytes(const sdumc_gemm& g, int nsplit) {
 // per workgroup -- below that the extra reduce launch costs more than the shorter k-loop saves.
 GemmPlan plan_gemm(const sdumc_gemm& g, size_t ws_bytes) {
   GemmPlan p;
-  if (g.tile >= 11 && g.tile <= 14) {     // wide kernels: NT unsplit, TN split K over ~2 workgroups per CU
+  if (g.tile >= 11 && g.tile <= 18) {     // wide kernels (15..18: persistent NT variants): NT unsplit, TN split K over ~2 workgroups per CU
     p.tile = g.tile;
-    const int bm = (g.tile == 12 || g.tile == 13) ? 128 : 64, bn = (g.tile == 11 || g.tile == 12) ? 256 : 128;
+    const int wt = g.tile > 14 ? g.tile - 4 : g.tile;
+    const int bm = (wt == 12 || wt == 13) ? 128 : 64, bn = (wt == 11 || wt == 12) ? 256 : 128;
     const long tiles = (long)((g.M + bm - 1) / bm) * ((g.N + bn - 1) / bn) * g.groups;
     const int kt = (g.K + 15) / 16;
     int s = 1;
@@ -741,6 +742,22 @@ GemmPlan plan_gemm(const sdumc_gemm& g, size_t ws_bytes) {
     p.nsplit = (kt * 16 + p.kchunk - 1) / p.kchunk;
     if (p.nsplit <= 1) { p.nsplit = 1; p.kchunk = ((g.K + 15) / 16) * 16; }
     return p;
+  }
+  // Automatic use of gemm_wide.hip's LDS-DMA kernels where they measured faster than the 64x64 register-staged loop
+  // (tools/gemm_wide_check.py on MI355X, profiles/README.md r2): skinny NT problems with N a multiple of 128 --
+  // the frame projections (K >= 512: 64x128 tiles, 118 vs 95 TF at M = 24000, 104 vs 96 at M = 14400) and the key projections
+  // of the long modality (K = 256, M >= 32768: 128x128 tiles, 88 vs 76 TF; 93 vs 82 grouped).  sdumc_gemm_wide_ itself
+  // declines what it cannot take (ragged K, unaligned operands, epilogue dropout ...) and the call falls back to the plan below.
+  if (g.tile == 0 && g.layout == SDUMC_NT && !g.bf16 && g.batch <= 1 && g.splitk <= 1 && (g.N % 128) == 0 && (g.K % 16) == 0 &&
+      g.N <= 1024 && !g.c_drop.enabled) {
+    int wide = 0;
+    if (g.K >= 512 && g.M >= 8192) wide = 14;
+    else if (g.K >= 128 && g.K < 512 && (long)g.M * g.groups >= 32768) wide = 13;
+    if (wide) {
+      sdumc_gemm g2 = g;
+      g2.tile = wide;
+      return plan_gemm(g2, ws_bytes);
+    }
   }
   const int ktiles = (g.K + BK - 1) / BK;
   const long big = (long)((g.M + 127) / 128) * ((g.N + 127) / 128) * g.groups;
@@ -872,8 +889,9 @@ extern "C" int sdumc_gemm_f32(const sdumc_gemm* gp, void* stream) {
       return SDUMC_OK;
     }
     if (wprof) { (void)hipEventDestroy(wrec.a); (void)hipEventDestroy(wrec.b); }
-    sdumc_gemm g2 = g;           // not a problem the wide kernels take: the generic plan
-    g2.tile = 0;
+    sdumc_gemm g2 = g;           // not a problem the wide kernels take: the generic kernels
+    g2.tile = 2;
+    g2.splitk = 0;
     return sdumc_gemm_f32(&g2, stream);
   }
   const int nsplit = pl.nsplit, kchunk = pl.kchunk, tile = pl.tile;

@@ -1,6 +1,6 @@
 """gemm_wide.hip against gemm_f32.hip on the shapes of the SDUMC step: results (max relative difference) and time per launch,
 all tile configurations, in ONE process (interleaved rounds).  tile: 0 = the old plan, 11 = 64x256, 12 = 128x256,
-13 = 128x128, 14 = 64x128."""
+13 = 128x128, 14 = 64x128, 15..18 = the persistent NT variants of 11..14."""
 import os
 import sys
 
@@ -72,8 +72,9 @@ def case(name, layout, M, N, K, tiles, groups=1, **kw):
     flops = 2.0 * M * N * K * groups
     ref = None
     out = []
+    Cinit = [mk(M, N) for _ in range(groups)] if accumulate else None
     for t in tiles:
-        C0 = [mk(M, N) for _ in range(groups)] if accumulate else [torch.empty(M, N, device=dev) for _ in range(groups)]
+        C0 = [c.clone() for c in Cinit] if accumulate else [torch.empty(M, N, device=dev) for _ in range(groups)]
         cs = [torch.zeros(M, device=dev) for _ in range(groups)] if colsum else None
 
         def run(Cs=None):
@@ -101,7 +102,7 @@ def case(name, layout, M, N, K, tiles, groups=1, **kw):
 
 
 if __name__ == "__main__":
-    NTT = (0, 11, 12, 13, 14)
+    NTT = (0, 11, 12, 13, 14, 15, 16, 17, 18)
     TNT = (0, 11, 13, 14)
     case("frame proj audio", NT, 24000, 256, 1024, NTT, bias=True)
     case("frame proj video", NT, 14400, 256, 1024, NTT, bias=True)
@@ -120,4 +121,4 @@ if __name__ == "__main__":
     case("keys dW audio 2 sites", TN, 256, 256, 48000, TNT, groups=2, colsum=True, drop=True, row_mod=24000)
     case("keys dW video 1 site", TN, 256, 256, 28800, TNT, colsum=True, drop=True, row_mod=14400)
     case("ragged K", TN, 256, 1024, 24007, TNT, colsum=True)
-    case("square 4096", NT, 4096, 4096, 4096, (1, 12, 13))
+    case("square 4096", NT, 4096, 4096, 4096, (1, 12, 13, 16, 17))

@@ -71,8 +71,8 @@ def main():
     _lib.lib.sdumc_profile_enable(1)
     fwd_bwd()
     torch.cuda.synchronize()
-    ent = (_lib.ProfEntry * 16)()
-    n = _lib.lib.sdumc_profile_report(ent, 16)
+    ent = (_lib.ProfEntry * 32)()
+    n = _lib.lib.sdumc_profile_report(ent, 32)
     gemms = {ent[i].name.decode(): {"launches": ent[i].launches, "ms": round(ent[i].total_ms, 4),
                                     "tflops": round(ent[i].total_flops / (ent[i].total_ms * 1e9), 2)}
              for i in range(n) if ent[i].launches}
