@@ -34,6 +34,39 @@ int sdumc_adam_apply_(float* param, const float* grad, float* exp_avg, float* ex
 }
 
 // ---------------------------------------------------------------------------
+// chain.hip: the utterance-level network in four launches.  Arguments = device pointers into the flat parameter buffer
+// (backward), its transposed mirror (forward) and the engine's workspace.
+// ---------------------------------------------------------------------------
+struct sdumc_chain_args {
+  int32_t V, B;                 // virtual samples (streams * B), samples per stream
+  sdumc_dropout drop;           // template: enabled, threshold / scale of p_mlp, samples, sample0, dev_state (site, rows, width per layer)
+  float relu_scale;             // 1 / (1 - p_mlp) in train mode, 1 in eval mode (backward masks)
+  // transposed weights (forward) / weights as stored (backward), biases
+  const float *umlp0_w[3], *umlp0_b[3], *umlp3_w[3], *umlp3_b[3];
+  const float *att0_w, *att0_b, *att3_w, *att3_b, *fc_att_w, *fc_att_b;       // fc_att_w always as stored [3][256]
+  const float *query_w[7], *query_b[7], *caq_w[3], *caq_b[3];
+  const float *cmlp0_w[3], *cmlp0_b[3], *cmlp3_w[3], *cmlp3_b[3];
+  const float *catt0_w, *catt0_b, *catt3_w, *catt3_b, *cfa_w, *cfa_b;        // cfa_w as stored [7][128]
+  const float *fcv_w, *fcv_b, *rnc0_w, *rnc0_b, *rnc2_w, *rnc2_b;             // fcv_w as stored [1][128]
+  // activations (engine Plan offsets)
+  float *hpre, *u1, *u, *att1, *att2, *alpha, *qin, *q, *qp, *ca_out, *c1, *c, *h, *e1, *e2, *beta, *z, *vals, *r1, *r;
+  // outputs of the network (may be null)
+  float *o_vals, *o_fused, *o_rnc, *o_text_hidden, *o_cross_text;
+  // backward: external gradients (may be null) and gradient buffers
+  const float *g_vals, *g_fused, *g_rnc, *g_text_hidden, *g_cross_text;
+  float *d_r1, *d_z, *d_beta, *d_e2, *d_e1, *d_h, *d_c, *d_c1, *d_ca_out, *d_alpha;
+  float *d_qp, *d_q, *d_qin, *d_u, *d_att2, *d_att1, *d_u1, *d_hpre;
+};
+
+extern "C" {
+// which: 0 = stage A forward, 1 = stage B forward, 2 = stage B backward, 3 = stage A backward
+int sdumc_chain_launch_(const sdumc_chain_args* a, int which, void* stream);
+// dst[off ..] = transpose of the n listed [out][in] matrices of src (same offsets in both buffers)
+int sdumc_chain_transpose_(const float* src, float* dst, const int64_t* offs, const int32_t* outs, const int32_t* ins, int n,
+                           void* stream);
+}
+
+// ---------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. SC'11).  Bit-identical to oracle/philox.py.
 // ---------------------------------------------------------------------------
 struct Philox4 {

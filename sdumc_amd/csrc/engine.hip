@@ -189,6 +189,7 @@ struct Plan {
   int64_t d_hpre, d_u1, d_u, d_att1, d_att2, d_alpha, d_qin, d_q, d_qp, d_ca_out, d_c1, d_c, d_h, d_e1, d_e2, d_beta,
       d_z, d_r1, dq_fra;
   int64_t lens = 0;          // int32 [3][V]: valid frames per (modality, virtual sample) when sdumc_net_io.lengths is given
+  int64_t wt = 0;            // transposed mirror of the utterance-level weights [0, early): chain.hip's forward layout
   int64_t scratch[4] = {0, 0, 0, 0}, scratch_floats = 0;   // one scratch per lane (stream)
   int64_t alloc(int64_t n) {
     const int64_t o = cur;
@@ -318,6 +319,7 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
   p.d_r1 = p.alloc((int64_t)V * RD);
   p.dq_fra = p.alloc(3LL * V * D);
   p.lens = p.alloc(3LL * V);
+  p.wt = p.alloc(build_params(d.da, d.dt, d.dv).early);
   // scratch shared by split-K slabs, column-sum partials and the attention-pool dq slabs
   int64_t sc = 1 << 16;
   const int din[3] = {d.da, d.dt, d.dv};
@@ -725,6 +727,90 @@ int pool_fwd(const Ctx& c, int k, int m) {
   return SDUMC_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// chain.hip: the utterance-level network (model :293-332, :338-368) in one launch per stage and direction instead of one
+// launch per layer.  Taken when the virtual batch is small enough that those layers are launch-bound (V <= 512: up to
+// B = 256 per GPU); larger batches keep the per-layer MFMA GEMMs, which are then compute-bound.  SDUMC_CHAIN=0 / 1 forces
+// either path (A/B measurements, parity tests of both).
+// ------------------------------------------------------------------------------------------
+bool use_chain(const Ctx& c) {
+  static const int forced = [] { const char* e = getenv("SDUMC_CHAIN"); return e ? atoi(e) : -1; }();
+  if (forced >= 0) return forced != 0;
+  return c.pl.V <= 512;
+}
+
+// the Linear layers of both stages, in one list (transposed once per forward call)
+std::vector<const Lin*> chain_lins(const ParamMap& pm) {
+  std::vector<const Lin*> v;
+  for (int m = 0; m < 3; ++m) { v.push_back(&pm.umlp0[m]); v.push_back(&pm.umlp3[m]); }
+  v.push_back(&pm.att0); v.push_back(&pm.att3);
+  for (int i = 0; i < 7; ++i) v.push_back(&pm.query[i]);
+  for (int m = 0; m < 3; ++m) v.push_back(&pm.ca_q[m]);
+  for (int m = 0; m < 3; ++m) { v.push_back(&pm.cmlp0[m]); v.push_back(&pm.cmlp3[m]); }
+  v.push_back(&pm.catt0); v.push_back(&pm.catt3);
+  v.push_back(&pm.rnc0); v.push_back(&pm.rnc2);
+  return v;
+}
+
+int chain_transpose(const Ctx& c) {
+  const std::vector<const Lin*> ls = chain_lins(c.pm);
+  int64_t offs[40];
+  int32_t outs[40], ins[40];
+  int n = 0;
+  for (const Lin* L : ls) { offs[n] = L->w; outs[n] = L->out; ins[n] = L->in; ++n; }
+  return sdumc_chain_transpose_(c.P, c.p(c.pl.wt), offs, outs, ins, n, c.st);
+}
+
+// fwd: weights from the transposed mirror; bwd: as stored
+sdumc_chain_args chain_args(const Ctx& c, bool fwd, const sdumc_net_grads* og) {
+  const Plan& pl = c.pl;
+  const ParamMap& pm = c.pm;
+  sdumc_chain_args a;
+  memset(&a, 0, sizeof(a));
+  a.V = pl.V;
+  a.B = pl.B;
+  a.drop = mkdrop(c, 0, c.d.p_mlp, 1, D);
+  a.relu_scale = c.d.train ? 1.0f / (1.0f - (float)c.d.p_mlp) : 1.0f;
+  const float* WB = fwd ? c.p(pl.wt) : c.P;
+  auto W = [&](const Lin& L) { return WB + L.w; };
+  auto Bs = [&](const Lin& L) { return c.P + L.b; };
+  for (int m = 0; m < 3; ++m) {
+    a.umlp0_w[m] = W(pm.umlp0[m]); a.umlp0_b[m] = Bs(pm.umlp0[m]);
+    a.umlp3_w[m] = W(pm.umlp3[m]); a.umlp3_b[m] = Bs(pm.umlp3[m]);
+    a.caq_w[m] = W(pm.ca_q[m]); a.caq_b[m] = Bs(pm.ca_q[m]);
+    a.cmlp0_w[m] = W(pm.cmlp0[m]); a.cmlp0_b[m] = Bs(pm.cmlp0[m]);
+    a.cmlp3_w[m] = W(pm.cmlp3[m]); a.cmlp3_b[m] = Bs(pm.cmlp3[m]);
+  }
+  for (int i = 0; i < 7; ++i) { a.query_w[i] = W(pm.query[i]); a.query_b[i] = Bs(pm.query[i]); }
+  a.att0_w = W(pm.att0); a.att0_b = Bs(pm.att0);
+  a.att3_w = W(pm.att3); a.att3_b = Bs(pm.att3);
+  a.fc_att_w = c.P + pm.fc_att.w; a.fc_att_b = Bs(pm.fc_att);
+  a.catt0_w = W(pm.catt0); a.catt0_b = Bs(pm.catt0);
+  a.catt3_w = W(pm.catt3); a.catt3_b = Bs(pm.catt3);
+  a.cfa_w = c.P + pm.cross_fc_att.w; a.cfa_b = Bs(pm.cross_fc_att);
+  a.fcv_w = c.P + pm.fc_out_v.w; a.fcv_b = Bs(pm.fc_out_v);
+  a.rnc0_w = W(pm.rnc0); a.rnc0_b = Bs(pm.rnc0);
+  a.rnc2_w = W(pm.rnc2); a.rnc2_b = Bs(pm.rnc2);
+  a.hpre = c.p(pl.hpre); a.u1 = c.p(pl.u1); a.u = c.p(pl.u); a.att1 = c.p(pl.att1); a.att2 = c.p(pl.att2);
+  a.alpha = c.p(pl.alpha); a.qin = c.p(pl.qin); a.q = c.p(pl.q); a.qp = c.p(pl.qp); a.ca_out = c.p(pl.ca_out);
+  a.c1 = c.p(pl.c1); a.c = c.p(pl.c); a.h = c.p(pl.h); a.e1 = c.p(pl.e1); a.e2 = c.p(pl.e2); a.beta = c.p(pl.beta);
+  a.z = c.p(pl.z); a.vals = c.p(pl.vals); a.r1 = c.p(pl.r1); a.r = c.p(pl.r);
+  if (fwd) {
+    a.o_vals = c.io.vals; a.o_fused = c.io.fused; a.o_rnc = c.io.rnc; a.o_text_hidden = c.io.text_hidden;
+    a.o_cross_text = c.io.cross_text;
+  }
+  if (og) {
+    a.g_vals = og->d_vals; a.g_fused = og->d_fused; a.g_rnc = og->d_rnc; a.g_text_hidden = og->d_text_hidden;
+    a.g_cross_text = og->d_cross_text;
+  }
+  a.d_r1 = c.p(pl.d_r1); a.d_z = c.p(pl.d_z); a.d_beta = c.p(pl.d_beta); a.d_e2 = c.p(pl.d_e2); a.d_e1 = c.p(pl.d_e1);
+  a.d_h = c.p(pl.d_h); a.d_c = c.p(pl.d_c); a.d_c1 = c.p(pl.d_c1); a.d_ca_out = c.p(pl.d_ca_out); a.d_alpha = c.p(pl.d_alpha);
+  a.d_qp = c.p(pl.d_qp); a.d_q = c.p(pl.d_q); a.d_qin = c.p(pl.d_qin); a.d_u = c.p(pl.d_u); a.d_att2 = c.p(pl.d_att2);
+  a.d_att1 = c.p(pl.d_att1); a.d_u1 = c.p(pl.d_u1); a.d_hpre = c.p(pl.d_hpre);
+  return a;
+}
+
 int forward(const Ctx& c) {
   const Plan& pl = c.pl;
   const ParamMap& pm = c.pm;
@@ -740,6 +826,18 @@ int forward(const Ctx& c) {
   //      keep-bits of the two frame-level input dropouts -> frame_dim_reshape_m (model :282-284; audio/video once
   //      for both streams) -> keys of fra2utt_m AND cross_att_fra2utt_m -> FRA2UTT pooling (model :288-290)
   RET(fork_all(c));
+  const bool chain = use_chain(c);
+  hipEvent_t wt_done = nullptr;
+  if (chain) {   // transposed mirror of the utterance-level weights (7 MB, first needed after the frame-level part): lane 3
+    RET(link(c, 0, 3));
+    c.use(3);
+    RET(chain_transpose(c));
+    if (c.sts[3] != c.sts[0]) {
+      wt_done = next_event();
+      if (hipEventRecord(wt_done, c.st) != hipSuccess) return SDUMC_ELAUNCH;
+    }
+    c.use(0);
+  }
   // The keep-bits (Philox once per element instead of ~10x in the kernels that stage these tiles; VALU-bound) are generated
   // on lane 3 in the shadow of the MFMA-bound frame projections, which read no mask; each modality's lane waits for its
   // own bits before the key projections.  Heaviest modality first.
@@ -782,6 +880,11 @@ int forward(const Ctx& c) {
   }
   c.use(0);
   RET(join_all(c));
+  if (chain) {   // steps 3-7 in one launch
+    if (wt_done && hipStreamWaitEvent(c.st, wt_done, 0) != hipSuccess) return SDUMC_ELAUNCH;
+    const sdumc_chain_args ca = chain_args(c, true, nullptr);
+    RET(sdumc_chain_launch_(&ca, 0, c.st));
+  } else {
   // 3. audio/text/video_mlp (model :293-295), grouped over the modality
   {
     sdumc_gemm g = G_(SDUMC_NT, V, D, D, 3);
@@ -843,6 +946,7 @@ int forward(const Ctx& c) {
     g.lda = g.ldb = g.ldc = D;
     RET(run(c, g));
   }
+  }   // !chain
   // 8. cross_att_fra2utt_{0,1,2} (model :334-336)
   RET(link(c, 3, 0));   // their keys
   RET(fork_all(c));
@@ -852,6 +956,10 @@ int forward(const Ctx& c) {
   }
   c.use(0);
   RET(join_all(c));
+  if (chain) {   // steps 9-12 and the outputs in one launch
+    const sdumc_chain_args ca = chain_args(c, true, nullptr);
+    return sdumc_chain_launch_(&ca, 1, c.st);
+  }
   // 9. cross_{audio,text,video}_mlp (model :338-340)
   {
     sdumc_gemm g = G_(SDUMC_NT, V * NQ, D, D, 3);
@@ -987,6 +1095,25 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   // every live gradient tensor is overwritten below when all five output gradients are given
   if (!og.d_vals || !og.d_fused || !og.d_rnc || !og.d_text_hidden || !og.d_cross_text) RET(sdumc_fill(c.G, 0.f, pm.live, c.st));
 
+  const bool chain = use_chain(c);
+  if (chain) {
+    // 12'-9' in one launch (chain.hip); the weight gradients of these layers are queued for lane 3 as before
+    const sdumc_chain_args ca = chain_args(c, false, &og);
+    RET(sdumc_chain_launch_(&ca, 2, c.st));
+    const int M7 = V * NQ;
+    if (og.d_rnc) {
+      RET(lin_bwd(c, pm.rnc2, og.d_rnc, RD, c.p(pl.r1), RD, V, nullptr, 0, 0));
+      RET(lin_bwd(c, pm.rnc0, c.p(pl.d_r1), RD, c.p(pl.z), H, V, nullptr, 0, 0));
+    }
+    if (og.d_vals) RET(lin_bwd(c, pm.fc_out_v, og.d_vals, 1, c.p(pl.z), H, V, nullptr, 0, 0));
+    RET(lin_bwd(c, pm.cross_fc_att, c.p(pl.d_beta), NQ, c.p(pl.e2), H, V, nullptr, 0, 0));
+    RET(lin_bwd(c, pm.catt3, c.p(pl.d_e2), H, c.p(pl.e1), D, V, nullptr, 0, 0));
+    RET(lin_bwd(c, pm.catt0, c.p(pl.d_e1), D, c.p(pl.h), NQ * H, V, nullptr, 0, 0));
+    GroupPtrs q3 = {c.p(pl.d_c), (int64_t)M7 * H, H, c.p(pl.c1), (int64_t)M7 * D, D, nullptr, 0, 0};
+    RET(lin_bwd_grouped(c, pm.cmlp3, 3, M7, q3));
+    GroupPtrs q0 = {c.p(pl.d_c1), (int64_t)M7 * D, D, c.p(pl.ca_out), (int64_t)M7 * D, D, nullptr, 0, 0};
+    RET(lin_bwd_grouped(c, pm.cmlp0, 3, M7, q0));
+  } else {
   // 12'. heads: r = L2(relu(L0(z))), vals = fc_out_v(z), plus the external gradient of cross_fused_feat
   float* d_z = c.p(pl.d_z);
   if (og.d_rnc) {
@@ -1014,6 +1141,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     GroupPtrs q0 = {c.p(pl.d_c1), (int64_t)M * D, D, c.p(pl.ca_out), (int64_t)M * D, D, c.p(pl.d_ca_out), (int64_t)M * D, D};
     RET(lin_bwd_grouped(c, pm.cmlp0, 3, M, q0));
   }
+  }   // !chain
   RET(flush_dw(c));   // batch 1: heads, cross_attention_mlp, cross_*_mlp
   // 8'. the three Cross_Attention blocks
   RET(fork_all(c));
@@ -1039,6 +1167,32 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
       RET(link(c, lane, 0));
     }
   }
+  if (chain) {
+    // 7'-3' in one launch; dW of these layers queued for lane 3
+    const sdumc_chain_args ca = chain_args(c, false, &og);
+    RET(sdumc_chain_launch_(&ca, 3, c.st));
+    const int M7 = V * NQ;
+    {
+      sdumc_gemm gw = G_(SDUMC_TN, D, D, M7, 3);
+      for (int m = 0; m < 3; ++m) {
+        gw.A[m] = c.p(pl.d_qp) + (int64_t)m * M7 * D;
+        gw.B[m] = c.p(pl.q);
+        gw.C[m] = c.G + pm.ca_q[m].w;
+        gw.colsum_a[m] = c.G + pm.ca_q[m].b;
+      }
+      gw.lda = gw.ldb = gw.ldc = D;
+      c.deferred.push_back(gw);
+    }
+    GroupPtrs qq = {c.p(pl.d_q), D, NQ * D, c.p(pl.qin), (int64_t)V * D, D, nullptr, 0, 0};
+    RET(lin_bwd_grouped(c, pm.query, 7, V, qq));
+    RET(lin_bwd(c, pm.fc_att, c.p(pl.d_alpha), 3, c.p(pl.att2), D, V, nullptr, 0, 0));
+    RET(lin_bwd(c, pm.att3, c.p(pl.d_att2), D, c.p(pl.att1), D, V, nullptr, 0, 0));
+    RET(lin_bwd(c, pm.att0, c.p(pl.d_att1), D, c.p(pl.u), 3 * D, V, nullptr, 0, 0));
+    GroupPtrs q3 = {c.p(pl.d_u), D, 3 * D, c.p(pl.u1), (int64_t)V * D, D, nullptr, 0, 0};
+    RET(lin_bwd_grouped(c, pm.umlp3, 3, V, q3));
+    GroupPtrs q0 = {c.p(pl.d_u1), (int64_t)V * D, D, c.p(pl.hpre), (int64_t)V * D, D, nullptr, 0, 0};
+    RET(lin_bwd_grouped(c, pm.umlp0, 3, V, q0));
+  } else {
   // 7'. query_proj: dW/db per modality, d_q = sum_m d_qp[m] W_q[m]
   {
     const int M = V * NQ;
@@ -1088,6 +1242,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     GroupPtrs q0 = {c.p(pl.d_u1), (int64_t)V * D, D, c.p(pl.hpre), (int64_t)V * D, D, c.p(pl.d_hpre), (int64_t)V * D, D};
     RET(lin_bwd_grouped(c, pm.umlp0, 3, V, q0));
   }
+  }   // !chain
   RET(flush_dw(c));   // batch 3: fc_att, attention_mlp, audio/text/video_mlp
   // the dW GEMMs of this part ran on lane 3: after this link [0, pm.early) is final on the caller's stream.  When the
   // frame-level part follows in the same call the link at its head does the same job.
