@@ -48,6 +48,9 @@ WORKLOADS = {   # name: (batch per GPU, T, dims, algorithmic train FLOPs per sam
             "both streams with self-distillation"),
 }
 WORKLOAD_TEXT = WORKLOADS["c2"][4]
+EPOCH_TEXT = ("ragged epoch at BASELINE configs[1] widths: 200 batches of 64 utterances with per-sample lengths U{ceil(T/4)..T}, assembled "
+              "on the device by DeviceFeatureStore.batch_into (right-zero-padded to the batch maximum like read_data.py:223-248) and "
+              "stepped through engine.FusedTrainer inside one capacity-sized arena")
 
 
 def source_sha():
@@ -218,6 +221,54 @@ def cpu_baseline_leg(steps=3):
             "sec_per_step": round(best, 4)}
 
 
+def epoch_leg(args, engine, flat, lay, dev):
+    """Side measurement (never the driver's default line): one epoch of REAL loader behaviour -- every batch has its own
+    padded shape -- against the static-shape step at the same mean padded frame counts."""
+    from sdumc_amd.data import DeviceFeatureStore
+    nb, B = max(args.steps, 1), B_PER_GPU
+    store = DeviceFeatureStore.synthetic(2048, T_MOSEI, DIMS, seed=1234, device=dev)
+    g = torch.Generator().manual_seed(7)
+    batches = [torch.randperm(len(store), generator=g)[:B] for _ in range(nb + args.warmup)]
+    tr = engine.FusedTrainer(flat, DIMS, capacity=(B, T_MOSEI), seed=2024, bf16=args.bf16)
+    shapes = [store.batch_shape(ix)[1] for ix in batches]
+    for ix in batches[:args.warmup]:
+        tr.step_from_store(store, ix)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for ix in batches[args.warmup:]:
+        tr.step_from_store(store, ix)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    losses = tr.state.losses.cpu()
+    if not torch.isfinite(losses).all():
+        raise SystemExit(f"non-finite loss: {losses.tolist()}")
+    # the static-shape step at the epoch's mean padded shape (rounded up)
+    timed = shapes[args.warmup:]
+    mean_T = tuple(int(-(-sum(s[i] for s in timed) // len(timed))) for i in range(4))
+    flat2 = flat.clone()
+    st = engine.TrainStep(flat2, B, mean_T, DIMS, seed=2024, bf16=args.bf16)
+    gg = torch.Generator(device=dev).manual_seed(3)
+    st.set_batch(*[torch.randn(B, mean_T[i], DIMS[i], device=dev, generator=gg) for i in range(4)],
+                 torch.rand(B, device=dev, generator=gg) * 6 - 3)
+    for _ in range(args.warmup):
+        st.run()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(nb):
+        st.run()
+    torch.cuda.synchronize()
+    ds = time.perf_counter() - t1
+    ev, sv = B * nb / dt, B * nb / ds
+    return {"metric": "train samples/sec over a ragged epoch (side measurement)", "value": round(ev, 2), "unit": "samples/s",
+            "n_gpus": 1, "steps": nb, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / nb, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if args.bf16 else "f32", "data": "synthetic",
+            "config": {"workload": EPOCH_TEXT, "batch_per_gpu": B, "distinct_batch_shapes": len(set(shapes)),
+                       "mean_padded_T": list(mean_T), "capacity_T": list(T_MOSEI), "feature_dims": list(DIMS),
+                       "store_utterances": len(store), "cached_steps": len(tr._steps)},
+            "static_shape_at_mean_T": {"value": round(sv, 2), "ms_per_step": round(1e3 * ds / nb, 4)},
+            "epoch_over_static": round(ev / sv, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -235,13 +286,14 @@ def main():
     ap.add_argument("--bf16", action="store_true",
                     help="BASELINE configs[2] arithmetic: bf16 operands (fp32 accumulate) in the frame-level projections, "
                          "forward and backward; NOT the default workload (configs[1] is fp32)")
-    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c2",
+    ap.add_argument("--workload", choices=sorted(WORKLOADS) + ["epoch"], default="c2",
                     help="c2 = BASELINE configs[1], the configuration the metric is quoted on (default); c1 / c5 / c5g = side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
     global B_PER_GPU, T_MOSEI, DIMS, TRAIN_FLOPS_PER_SAMPLE, WORKLOAD_TEXT
-    B_PER_GPU, T_MOSEI, DIMS, TRAIN_FLOPS_PER_SAMPLE, WORKLOAD_TEXT = WORKLOADS[args.workload]
+    epoch = args.workload == "epoch"
+    B_PER_GPU, T_MOSEI, DIMS, TRAIN_FLOPS_PER_SAMPLE, WORKLOAD_TEXT = WORKLOADS["c2" if epoch else args.workload]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -281,6 +333,11 @@ def main():
     if args.background_lane or "SDUMC_BG_MODE" in os.environ:   # experiment knob; the library default is mode 2 (forward only)
         _lib.lib.sdumc_set_background_lane(int(os.environ.get("SDUMC_BG_MODE", "2")))
     flat, lay = init_flat_params(engine, dev)
+    if epoch:
+        if world != 1:
+            raise SystemExit("--workload epoch is a single-GPU side measurement")
+        print(json.dumps(epoch_leg(args, engine, flat, lay, dev)), flush=True)
+        return
     batch = [t.to(dev) for t in synthetic_shard(B_PER_GPU, rank)]
 
     if world == 1 and not force_dp:

@@ -301,6 +301,12 @@ int sdumc_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
  * packed [sum T, d] fp32, start int64 [B], len int32 [B] (device), d % 4 == 0. */
 int sdumc_gather_pad(const float* packed, const int64_t* start, const int32_t* len, int32_t B, int32_t Tmax, int32_t d,
                      float* out, void* stream);
+/* The same from store-wide tables: start_all int64 [N], len_all int32 [N] (device, one entry per stored utterance) and a
+ * device index vector idx int64 [B] naming the batch's utterances -- an epoch then assembles its batches without copying
+ * per-batch tables to the device.  len_out (optional, int32 [B]): min(len, Tmax) of the batch = the `lengths` the
+ * key-padding extension takes (maxT - pad_len of feat_data.py:244-253). */
+int sdumc_gather_pad_idx(const float* packed, const int64_t* start_all, const int32_t* len_all, const int64_t* idx, int32_t B,
+                         int32_t Tmax, int32_t d, float* out, int32_t* len_out, void* stream);
 
 /* ------------------------------------------------------------------------
  * Generic fairseq-style multi-head attention and the pieces of the pre-LN Transformer encoder

@@ -178,6 +178,8 @@ _SIGS = {
     "sdumc_copy2d": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sdumc_axpy2d": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sdumc_gather_pad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sdumc_gather_pad_idx": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                       C.c_void_p, C.c_void_p]),
     "sdumc_fill": (C.c_int, [C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
     "sdumc_rng_advance": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "sdumc_dropout_bits": (C.c_int, [C.POINTER(Dropout), C.c_int32, C.c_void_p, C.c_void_p]),

@@ -105,6 +105,24 @@ __global__ void gather_pad_kernel(const float* packed, const int64_t* start, con
   st4(out + 4 * i, v);
 }
 
+// the same with store-wide start / len tables and a device index vector: sample b of the batch = store entry idx[b]
+// (no per-batch host -> device copies of the tables); len_out (optional) receives the valid frame counts of the batch
+__global__ void gather_pad_idx_kernel(const float* packed, const int64_t* start_all, const int32_t* len_all, const int64_t* idx,
+                                      int B, int Tmax, int d4, float* out, int32_t* len_out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)B * Tmax * d4;
+  if (i >= total) return;
+  const int c = (int)(i % d4);
+  const int64_t r = i / d4;
+  const int t = (int)(r % Tmax), b = (int)(r / Tmax);
+  const int64_t e = idx[b];
+  const int n = len_all[e];
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (t < n) v = ld4(packed + ((size_t)(start_all[e] + t) * d4 + c) * 4);
+  st4(out + 4 * i, v);
+  if (len_out && t == 0 && c == 0) len_out[b] = n < Tmax ? n : Tmax;
+}
+
 __global__ void fill_kernel(float* p, float v, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -344,6 +362,17 @@ extern "C" int sdumc_copy2d_multi(const sdumc_copy_seg* segs, int32_t n, void* s
     mx = std::max<int64_t>(mx, (int64_t)segs[i].rows * segs[i].cols);
   }
   hipLaunchKernelGGL(copy2d_multi_kernel, dim3(std::min<unsigned>(nblk(mx), 256u), n), dim3(256), 0, as_stream(stream), cs);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_gather_pad_idx(const float* packed, const int64_t* start_all, const int32_t* len_all, const int64_t* idx,
+                                    int32_t B, int32_t Tmax, int32_t d, float* out, int32_t* len_out, void* stream) {
+  if (!packed || !start_all || !len_all || !idx || !out || B <= 0 || Tmax <= 0 || d <= 0 || (d & 3)) return SDUMC_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(packed) | reinterpret_cast<uintptr_t>(out)) & 15) return SDUMC_EINVAL;
+  const int64_t total = (int64_t)B * Tmax * (d / 4);
+  hipLaunchKernelGGL(gather_pad_idx_kernel, dim3(nblk(total)), dim3(256), 0, as_stream(stream), packed, start_all, len_all, idx, B,
+                     Tmax, d / 4, out, len_out);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
 }

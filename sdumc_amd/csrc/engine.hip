@@ -1513,18 +1513,22 @@ struct StepLayout {
   size_t live;
 };
 StepLayout step_layout(const sdumc_net_dims& d) {
+  // [gradient bucket | output gradients | loss scratch | network workspace]: the bucket comes FIRST so that it sits at the
+  // same address for every batch shape a run goes through inside one capacity-sized workspace (engine.FusedTrainer) --
+  // its alignment padding is zeroed once and stays zero, and a data-parallel all-reduce always finds it in one place.
   StepLayout s;
   auto up = [](size_t n) { return (n + 255) & ~(size_t)255; };
   s.live = (size_t)build_params(d.da, d.dt, d.dv).live;
   const size_t V = (size_t)d.B * 2;
-  s.net = 0;
-  size_t cur = up(sdumc_net_workspace_bytes(&d));
+  size_t cur = 0;
   s.grads = cur;
   cur += up(s.live * sizeof(float));
   s.dout = cur;
   cur += up(V * (64 + H + RD + D + NQ * H) * sizeof(float));
   s.loss = cur;
   cur += up(sdumc_loss_workspace_bytes(&d, 0));
+  s.net = cur;
+  cur += up(sdumc_net_workspace_bytes(&d));
   s.total = cur;
   return s;
 }
@@ -1546,7 +1550,7 @@ extern "C" int sdumc_train_step(const sdumc_net_dims* d, const sdumc_net_io* io,
   char* base = static_cast<char*>(io->workspace);
   sdumc_net_io nio = *io;
   nio.workspace = base + sl.net;
-  nio.workspace_bytes = sl.grads - sl.net;
+  nio.workspace_bytes = sl.total - sl.net;
   RET(sdumc_net_forward(d, &nio, stream));
   const size_t V = (size_t)d->B * 2;
   float* dout = reinterpret_cast<float*>(base + sl.dout);
@@ -1558,7 +1562,7 @@ extern "C" int sdumc_train_step(const sdumc_net_dims* d, const sdumc_net_io* io,
   g.d_cross_text = g.d_text_hidden + D * V;
   g.grads = reinterpret_cast<float*>(base + sl.grads);
   // the Adam bias-correction update rides in the loss's last launch, the dropout call counter in the Adam launch
-  RET(loss_backward_impl(d, &nio, cfg, &g, base + sl.loss, sl.total - sl.loss, stream, cfg->hyper));
+  RET(loss_backward_impl(d, &nio, cfg, &g, base + sl.loss, sl.net - sl.loss, stream, cfg->hyper));
   RET(sdumc_net_backward(d, &nio, &g, stream));
   RET(sdumc_adam_apply_(io->params, g.grads, cfg->adam_m, cfg->adam_v, (int64_t)sl.live, cfg->hyper, cfg->beta1, cfg->beta2,
                         cfg->eps, cfg->weight_decay, 1.0f, d->train ? const_cast<uint32_t*>(io->rng_state) : nullptr, 2u,

@@ -104,6 +104,61 @@ class DeviceFeatureStore:
             self.start[m] = torch.from_numpy(starts)
             self.length[m] = torch.tensor(lens, dtype=torch.int32)
             self.dim[m] = d
+        self._device_tables()
+
+    def _device_tables(self):
+        # store-wide tables on the device: a batch is then named by its index vector alone (sdumc_gather_pad_idx)
+        self.start_d = {m: self.start[m].to(self.device) for m in self.MODS}
+        self.length_d = {m: self.length[m].to(self.device) for m in self.MODS}
+
+    @classmethod
+    def synthetic(cls, n, T, dims, seed=1234, device='cuda', min_frac=0.25):
+        """n utterances with per-sample lengths ~ U{ceil(min_frac * T_m) .. T_m} and N(0, 1) features, generated on the device
+        (SURVEY §8d's variable-length synthetic inputs; no host copy of the tens of GB a real split holds)."""
+        import ctypes as C
+        from . import _lib
+        self = cls.__new__(cls)
+        self._C, self._lib = C, _lib
+        self.device = torch.device(device)
+        g = torch.Generator().manual_seed(seed)
+        gd = torch.Generator(device=self.device).manual_seed(seed)
+        self.names = [f"utt{i:06d}" for i in range(n)]
+        self.vals = (torch.rand(n, generator=g) * 6 - 3).to(self.device)
+        self.emos = torch.zeros(n, device=self.device)
+        self.packed, self.start, self.length, self.dim = {}, {}, {}, {}
+        for m, Tm, d in zip(self.MODS, T, dims):
+            lo = max(1, int(np.ceil(Tm * min_frac)))
+            lens = torch.randint(lo, Tm + 1, (n,), generator=g, dtype=torch.int32)
+            starts = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(lens.to(torch.int64), 0)[:-1]])
+            self.packed[m] = torch.randn(int(lens.sum()), d, device=self.device, generator=gd)
+            self.start[m], self.length[m], self.dim[m] = starts, lens, int(d)
+        self._device_tables()
+        return self
+
+    def batch_shape(self, indices):
+        """(B, (T_audio, T_text, T_video, T_feat4)) of the padded batch -- host-side table lookups only."""
+        idx = torch.as_tensor(indices, dtype=torch.int64)
+        return int(idx.numel()), tuple(int(self.length[m][idx].max()) for m in self.MODS)
+
+    def batch_into(self, indices, outs, labels_out, lengths_out=None):
+        """Assembles the batch `indices` into caller-owned buffers: outs = 4 device tensors [B, Tmax_m, d_m] (e.g. the input
+        buffers of an engine.TrainStep), labels_out [B]; lengths_out = optional 4 int32 device tensors (>= B) that receive the
+        valid frame counts.  One index-vector upload, four gather/pad launches, nothing else."""
+        _lib = self._lib
+        idx = torch.as_tensor(indices, dtype=torch.int64)
+        B = idx.numel()
+        idx_d = idx.to(self.device, non_blocking=True)
+        for k, m in enumerate(self.MODS):
+            dst = outs[k]
+            if dst.shape[0] != B or dst.shape[2] != self.dim[m] or not dst.is_contiguous():
+                raise _lib.SdumcError("batch_into: output buffer does not match the batch")
+            _lib.check(_lib.lib.sdumc_gather_pad_idx(_lib.ptr(self.packed[m]), _lib.ptr(self.start_d[m]), _lib.ptr(self.length_d[m]),
+                                                     _lib.ptr(idx_d), B, dst.shape[1], self.dim[m], _lib.ptr(dst),
+                                                     _lib.ptr(lengths_out[k]) if lengths_out is not None else None,
+                                                     _lib.current_stream()), "sdumc_gather_pad_idx")
+        torch.index_select(self.vals, 0, idx_d, out=labels_out)
+        self._keep_idx = idx_d
+        return lengths_out
 
     def __len__(self):
         return len(self.names)

@@ -227,10 +227,12 @@ class TrainStep(_OptStateMixin):
     optionally captured into a hipGraph (torch.cuda.CUDAGraph) and replayed."""
 
     def __init__(self, flat_params, B, T, dims, weights=DEFAULT_WEIGHTS, lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=1e-5, seed=0, train=True, sample0=0, bf16=False, share=None):
+                 weight_decay=1e-5, seed=0, train=True, sample0=0, bf16=False, share=None, arena=None):
         """share: an object with .params .rng .adam_m .adam_v .hyper .losses (another TrainStep over the SAME flat_params, or
         FusedTrainer's run state) whose optimiser state this step uses instead of allocating its own -- steps of different
-        (B, T) shapes then continue one training run."""
+        (B, T) shapes then continue one training run.
+        arena: a _StepArena sized for the largest batch of the run: workspace, input and output buffers are views into it
+        instead of fresh allocations (a C2 step owns ~1.2 GB of workspace: one arena per run, not one per batch shape)."""
         Ta, Tt, Tv, T4 = T
         self.layout = ParamLayout.get(dims[0], dims[1], dims[2])
         dev = flat_params.device
@@ -240,22 +242,38 @@ class TrainStep(_OptStateMixin):
         nbytes = lib.sdumc_step_workspace_bytes(C.byref(self.dims))
         if nbytes == 0:
             raise _lib.SdumcError("invalid step dimensions")
-        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         if share is not None and share.params.data_ptr() != flat_params.data_ptr():
             raise _lib.SdumcError("share: both steps must update the same flat parameter buffer")
         self.rng = share.rng if share is not None else RngState(seed, dev)
         V = 2 * B
         self.B, self.V = B, V
-        self.audio = torch.empty(B, Ta, dims[0], device=dev)
-        self.text = torch.empty(B, Tt, dims[1], device=dev)
-        self.video = torch.empty(B, Tv, dims[2], device=dev)
-        self.feat4 = torch.empty(B, T4, dims[1], device=dev)
-        self.labels = torch.empty(B, device=dev)
-        self.vals = torch.empty(V, 1, device=dev)
-        self.fused = torch.empty(V, H, device=dev)
-        self.rnc = torch.empty(V, RNC_DIM, device=dev)
-        self.text_hidden = torch.empty(V, D, device=dev)
-        self.cross_text = torch.empty(V, NQ, H, device=dev)
+        if arena is not None:
+            if not arena.fits(B, T, nbytes):
+                raise _lib.SdumcError("arena too small for this batch shape")
+            self.workspace = arena.workspace
+            nbytes = arena.workspace.numel()
+            self.audio = arena.inputs[0][:B * Ta * dims[0]].view(B, Ta, dims[0])
+            self.text = arena.inputs[1][:B * Tt * dims[1]].view(B, Tt, dims[1])
+            self.video = arena.inputs[2][:B * Tv * dims[2]].view(B, Tv, dims[2])
+            self.feat4 = arena.inputs[3][:B * T4 * dims[1]].view(B, T4, dims[1])
+            self.labels = arena.labels[:B]
+            self.vals = arena.outs[0][:V].view(V, 1)
+            self.fused = arena.outs[1][:V * H].view(V, H)
+            self.rnc = arena.outs[2][:V * RNC_DIM].view(V, RNC_DIM)
+            self.text_hidden = arena.outs[3][:V * D].view(V, D)
+            self.cross_text = arena.outs[4][:V * NQ * H].view(V, NQ, H)
+        else:
+            self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            self.audio = torch.empty(B, Ta, dims[0], device=dev)
+            self.text = torch.empty(B, Tt, dims[1], device=dev)
+            self.video = torch.empty(B, Tv, dims[2], device=dev)
+            self.feat4 = torch.empty(B, T4, dims[1], device=dev)
+            self.labels = torch.empty(B, device=dev)
+            self.vals = torch.empty(V, 1, device=dev)
+            self.fused = torch.empty(V, H, device=dev)
+            self.rnc = torch.empty(V, RNC_DIM, device=dev)
+            self.text_hidden = torch.empty(V, D, device=dev)
+            self.cross_text = torch.empty(V, NQ, H, device=dev)
         if share is not None:
             self.adam_m, self.adam_v, self.hyper, self.losses = share.adam_m, share.adam_v, share.hyper, share.losses
         else:
@@ -281,9 +299,10 @@ class TrainStep(_OptStateMixin):
         self.cfg = cfg
         self.graph = None
         self._lengths = None      # key-padding extension off (set_lengths)
-        goff = lib.sdumc_step_grads_offset(C.byref(self.dims))
+        goff = lib.sdumc_step_grads_offset(C.byref(self.dims))      # the same for every shape: the bucket leads the workspace
         self.grads = self.workspace[goff:goff + 4 * self.layout.live].view(torch.float32)
-        self.grads.zero_()      # alignment padding between tensors is never written by the kernels
+        if arena is None:
+            self.grads.zero_()      # alignment padding between tensors is never written by the kernels (an arena zeroes it once)
 
     def set_batch(self, audio, text, video, feat4, labels):
         """Copies one batch into the step's resident input buffers (shapes are fixed per TrainStep)."""
@@ -352,6 +371,33 @@ class _RunState(_OptStateMixin):
         self.losses = torch.zeros(8, device=dev)
 
 
+class _StepArena:
+    """Device memory of one training run, sized once for its largest batch (B, T_audio, T_text, T_video, T_feat4):
+    the step workspace (whose leading gradient bucket is zeroed here, once), the four input buffers the batches are
+    assembled in -- DeviceFeatureStore.batch_into gathers straight into them -- the labels and the five outputs."""
+
+    def __init__(self, flat_params, B, T, dims, bf16=False):
+        dev = flat_params.device
+        self.B, self.T, self.dims = int(B), tuple(int(t) for t in T), tuple(dims)
+        d = make_dims(self.B, 2, self.T[0], self.T[2], (self.T[1], self.T[3]), dims, True, 0, bf16=bf16)
+        nbytes = lib.sdumc_step_workspace_bytes(C.byref(d))
+        if nbytes == 0:
+            raise _lib.SdumcError("invalid arena dimensions")
+        self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        lay = ParamLayout.get(dims[0], dims[1], dims[2])
+        goff = lib.sdumc_step_grads_offset(C.byref(d))
+        self.workspace[goff:goff + 4 * lay.live].zero_()
+        n = [self.B * self.T[0] * dims[0], self.B * self.T[1] * dims[1], self.B * self.T[2] * dims[2], self.B * self.T[3] * dims[1]]
+        self.inputs = [torch.empty(k, device=dev) for k in n]
+        self.labels = torch.empty(self.B, device=dev)
+        V = 2 * self.B
+        self.outs = [torch.empty(V * k, device=dev) for k in (1, H, RNC_DIM, D, NQ * H)]
+        self.lengths = [torch.empty(self.B, dtype=torch.int32, device=dev) for _ in range(4)]
+
+    def fits(self, B, T, nbytes):
+        return B <= self.B and all(t <= c for t, c in zip(T, self.T)) and nbytes <= self.workspace.numel()
+
+
 class FusedTrainer:
     """The fused step for the reference's REAL batches, whose (B, T_audio, T_text, T_video, T_feat4) change from batch to
     batch (every modality is padded to its batch maximum, read_data.py:223-248; the last batch of an epoch is short):
@@ -359,13 +405,20 @@ class FusedTrainer:
     continuous run of main_frame_val_text_missing.py:119-150.  At most `max_cached` shapes keep their workspace (least
     recently used first out); a shape seen again after eviction is simply rebuilt."""
 
-    def __init__(self, flat_params, dims, max_cached=8, lr=1e-4, seed=0, **step_kwargs):
+    def __init__(self, flat_params, dims, max_cached=8, lr=1e-4, seed=0, capacity=None, **step_kwargs):
+        """capacity = (B_max, (T_audio, T_text, T_video, T_feat4) maxima) of the run: ONE arena then backs every batch shape
+        (no per-shape workspace, the per-shape step is a few ctypes structs and tensor views: cache as many as you like) and
+        `step_from_store` assembles batches straight into it.  Without it every cached shape owns its workspace."""
         _require_cuda(flat_params)
         self.params, self.dims, self.max_cached = flat_params, tuple(dims), max(1, int(max_cached))
         self.kw = dict(step_kwargs, lr=lr, seed=seed)
         lay = ParamLayout.get(dims[0], dims[1], dims[2])
         self.state = _RunState(flat_params, lay.live, lr, seed)     # (params, rng, adam_m, adam_v, hyper, losses)
         self._steps = {}          # shape -> TrainStep, insertion order = recency
+        self.arena = None
+        if capacity is not None:
+            self.arena = _StepArena(flat_params, capacity[0], capacity[1], dims, bf16=bool(step_kwargs.get("bf16", False)))
+            self.max_cached = max(self.max_cached, 4096)
 
     def _get(self, B, T):
         key = (B,) + tuple(T)
@@ -373,7 +426,12 @@ class FusedTrainer:
         if ts is None:
             while len(self._steps) >= self.max_cached:
                 del self._steps[next(iter(self._steps))]
-            ts = TrainStep(self.params, B, T, self.dims, share=self.state, **self.kw)
+            if self.arena is not None and not (B <= self.arena.B and all(t <= c for t, c in zip(T, self.arena.T))):
+                # a batch beyond the declared capacity: grow the arena (every cached step pointed into the old one)
+                cap_T = tuple(max(t, c) for t, c in zip(T, self.arena.T))
+                self.arena = _StepArena(self.params, max(B, self.arena.B), cap_T, self.dims, bf16=bool(self.kw.get("bf16", False)))
+                self._steps.clear()
+            ts = TrainStep(self.params, B, T, self.dims, share=self.state, arena=self.arena, **self.kw)
         self._steps[key] = ts
         return ts
 
@@ -385,6 +443,19 @@ class FusedTrainer:
 
     def optimizer_state(self):
         return self.state.optimizer_state()
+
+    def step_from_store(self, store, indices, key_padding=False):
+        """One optimisation step on the batch `indices` of a data.DeviceFeatureStore: the padded batch is assembled by the
+        gather/pad kernel DIRECTLY in the step's input buffers (no intermediate batch tensors, no 224 MB device copy);
+        key_padding=True also hands the valid frame counts to the kernels (extension, default off = the reference)."""
+        if self.arena is None:
+            raise _lib.SdumcError("step_from_store needs FusedTrainer(capacity=...)")
+        B, T = store.batch_shape(indices)
+        ts = self._get(B, T)
+        lens = store.batch_into(indices, (ts.audio, ts.text, ts.video, ts.feat4), ts.labels,
+                                self.arena.lengths if key_padding else None)
+        ts.set_lengths([l[:B] for l in lens] if key_padding else None)
+        return ts.run()
 
     def step(self, audio, text, video, feat4, labels, lengths=None):
         """One optimisation step on one batch of any shape; returns the device loss vector

@@ -246,3 +246,40 @@ def test_fused_trainer_resume_equals_uninterrupted_run(E):
     for a, b in zip(la, lb):
         assert torch.equal(a, b)
     assert torch.equal(flat_a, flat_c)
+
+
+def test_ragged_epoch_through_store_and_arena_equals_plain_batches(E):
+    """F1 + the ragged-epoch path: batches assembled by DeviceFeatureStore.batch_into straight into the arena of a
+    capacity-mode FusedTrainer (one workspace for every batch shape, gradient bucket at a fixed offset) reproduce, bit for
+    bit, the same epoch run batch by batch through store.batch() + FusedTrainer.step with per-shape workspaces; the
+    key-padding lengths produced by the gather kernel equal the host table."""
+    from oracle import sdumc_oracle as O
+    from sdumc_amd.data import DeviceFeatureStore
+    dims = (24, 16, 20, 16)
+    Tcap = (19, 6, 11, 5)
+    P = O.init_params(dims, seed=8)
+    store = DeviceFeatureStore.synthetic(40, Tcap, dims, seed=5)
+    g = torch.Generator().manual_seed(1)
+    batches = [torch.randperm(40, generator=g)[:B] for B in (6, 6, 4, 6, 3, 6)]
+    assert len({store.batch_shape(ix) for ix in batches}) >= 4
+    res = []
+    for mode in ("arena", "plain", "arena_kp", "plain_kp"):
+        flat, lay = flat_from(E, P, dims)
+        kp = mode.endswith("_kp")
+        tr = E.FusedTrainer(flat, dims, lr=1e-3, seed=11, capacity=(6, Tcap) if mode.startswith("arena") else None)
+        ls = []
+        for ix in batches:
+            if mode.startswith("arena"):
+                ls.append(tr.step_from_store(store, ix, key_padding=kp).clone())
+            else:
+                b, pads, emos, vals, names = store.batch(ix)
+                lens = [torch.tensor([b[k].shape[1] - p for p in pad], dtype=torch.int32) for k, pad in zip(("audios", "texts", "videos", "feat4s"), pads)]
+                ls.append(tr.step(b["audios"], b["texts"], b["videos"], b["feat4s"], vals, lengths=lens if kp else None).clone())
+        res.append((flat.clone(), ls))
+        if mode == "arena":
+            assert len(tr._steps) == len({store.batch_shape(ix) for ix in batches})
+    for a, b in ((0, 1), (2, 3)):
+        for x, y in zip(res[a][1], res[b][1]):
+            assert torch.equal(x, y)
+        assert torch.equal(res[a][0], res[b][0])
+    assert not torch.equal(res[0][1][0], res[2][1][0])       # the key-padding mask changes the result
