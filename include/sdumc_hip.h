@@ -12,6 +12,9 @@
  *   - every function enqueues work on `stream` (a hipStream_t passed as void*)
  *     and returns immediately: no allocation, no synchronisation, no host
  *     copies -> every call is hipGraph-capturable;
+ *   - `stream` must belong to the CURRENT device (hipSetDevice) of the calling thread, like any HIP launch; the
+ *     network-level calls keep their internal streams per device (or per caller context, sdumc_net_io.ctx), so calls
+ *     on different devices or with different contexts share no state and may run from different host threads;
  *   - return value: 0 = ok, <0 = SDUMC_E* (never throws across the ABI);
  *   - scratch memory is caller-owned; *_workspace_bytes() says how much.
  */
@@ -491,7 +494,17 @@ typedef struct sdumc_net_io {
    * (maxT - pad_len of toolkit/data/feat_data.py:232-253's `pads`); when given, the six attention poolings mask the
    * padded frames (sdumc_attnpool.lengths).  All four (three when streams == 1) or none. */
   const int32_t* lengths[4];
+  /* Optional caller-owned execution context (sdumc_ctx_create): the internal side streams and the event ring the call forks
+   * its branches on.  NULL = the default context of the current device (one per device, created on first use).  Two host
+   * threads that run steps concurrently -- on distinct streams of one device, or on two devices -- give each its own
+   * context; a context is used by one thread at a time and only on the device it was created on (else SDUMC_EINVAL). */
+  void* ctx;
 } sdumc_net_io;
+
+/* Execution contexts (see sdumc_net_io.ctx).  Create / destroy outside stream capture; destroy only when no work issued
+ * through the context is pending. */
+int sdumc_ctx_create(void** ctx);
+int sdumc_ctx_destroy(void* ctx);
 
 /* The network-level calls issue independent branches (the three per-modality chains; the dW GEMMs) on up to
  * two internal side streams forked from / joined to `stream` with events: the call stays stream-ordered

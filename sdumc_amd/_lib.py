@@ -78,7 +78,8 @@ class NetIO(C.Structure):
                 # outputs, each [streams*B, ...]
                 ("vals", C.c_void_p), ("fused", C.c_void_p), ("rnc", C.c_void_p),
                 ("text_hidden", C.c_void_p), ("cross_text", C.c_void_p),
-                ("lengths", C.c_void_p * 4)]
+                ("lengths", C.c_void_p * 4),
+                ("ctx", C.c_void_p)]          # optional caller-owned execution context (sdumc_ctx_create); None = device default
 
 
 class NetGrads(C.Structure):
@@ -178,6 +179,8 @@ _SIGS = {
     "sdumc_copy2d": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sdumc_axpy2d": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sdumc_gather_pad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sdumc_ctx_create": (C.c_int, [C.POINTER(C.c_void_p)]),
+    "sdumc_ctx_destroy": (C.c_int, [C.c_void_p]),
     "sdumc_gather_pad_idx": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     "sdumc_fill": (C.c_int, [C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),

@@ -15,6 +15,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <cstdlib>
 #include <cstring>
@@ -345,66 +346,75 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
 // path) are issued on different lanes: eagerly they overlap on the GPU, under hipGraph capture they become
 // parallel branches of the graph.  That fills the partially empty last dispatch round of the big kernels and
 // hides the launch-bound small ones.  Each lane has its own scratch, so concurrent kernels never share slabs.
-struct SideStreams {
+// A lane set = the internal streams and the event ring one caller context issues its branches on.  There is one default set
+// per DEVICE (created on first use, under a lock), and callers that drive several steps from several host threads create
+// their own with sdumc_ctx_create and pass it in sdumc_net_io.ctx: nothing here is shared between two lane sets, and the
+// event ring hands its entries out atomically, so two threads on distinct contexts (or distinct devices) never see each
+// other's events.  (One context is still for one thread at a time: its lanes are ordered streams.)
+struct LaneSet {
   hipStream_t s[2] = {nullptr, nullptr};
-  hipStream_t bg = nullptr;   // background lane: big GEMMs that may run beside the launch-bound utterance-level chain
-  hipEvent_t ev[64];
-  int next = 0;
+  hipStream_t bg = nullptr;   // lane 3: dW batches, keep-bits, the forward Cross_Attention key GEMMs
+  static constexpr unsigned NEV = 256;
+  hipEvent_t ev[NEV];
+  std::atomic<unsigned> next{0};
+  int device = -1;
   bool ok = false;
 };
-SideStreams& side_streams() {
-  static SideStreams S;
-  return S;
-}
 bool g_concurrency = true;   // sdumc_set_concurrency(0): everything on the caller's stream (profiling)
 int g_background = 3;      // 0 off; 2 forward only (+1.0 % per step over 0); 3 (default) = 2 + the AUDIO Cross_Attention key-projection
                            // backward early on lane 3 (+0.6 % over 2: it shortens the longest frame-level chain); 4 = audio + video (+0.4 %);
-                           // 1 = all three (-1.6 %);   // sdumc_set_background_lane(1): the Cross_Attention-site GEMMs leave the grouped launches for lane 3
-// created outside any capture (called from the *_workspace_bytes queries every caller makes first)
-void ensure_side_streams() {
-  static std::mutex mu;
-  std::lock_guard<std::mutex> lock(mu);
-  SideStreams& S = side_streams();
-  if (S.ok) return;
-  // The side lanes are HIGH-priority streams.  The HIP runtime multiplexes the streams of one priority class onto
-  // GPU_MAX_HW_QUEUES (default 4) hardware queues, handing a new stream the least-used queue: once other components
-  // hold normal-priority streams (an RCCL communicator created before these lanes; torch's stream pool) two lanes can
-  // land on ONE hardware queue and the three modality chains serialise -- measured on MI355X: 2.59-2.63 ms per step
-  // instead of 2.18 whenever the process group had been initialised first (tools/rccl_queue_probe.py), and 2.18 again
-  // with GPU_MAX_HW_QUEUES=8 or with the lanes in their own priority class (2.17-2.20 ms in both orders).
-  // SDUMC_LANE_PRIORITY=normal|low restores / varies the class for experiments.
-  int prio = 0;
-  {
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return;
-    const char* e = getenv("SDUMC_LANE_PRIORITY");
-    prio = (e && e[0] == 'n') ? 0 : ((e && e[0] == 'l') ? least : greatest);
-  }
+                           // 1 = all three (-1.6 %)
+
+// The side lanes are HIGH-priority streams.  The HIP runtime multiplexes the streams of one priority class onto
+// GPU_MAX_HW_QUEUES (default 4) hardware queues, handing a new stream the least-used queue: once other components
+// hold normal-priority streams (an RCCL communicator created before these lanes; torch's stream pool) two lanes can
+// land on ONE hardware queue and the three modality chains serialise -- measured on MI355X: 2.59-2.63 ms per step
+// instead of 2.18 whenever the process group had been initialised first (tools/rccl_queue_probe.py), and 2.18 again
+// with GPU_MAX_HW_QUEUES=8 or with the lanes in their own priority class (2.17-2.20 ms in both orders).
+// SDUMC_LANE_PRIORITY=normal|low restores / varies the class for experiments.
+// (Measured and rejected for lane 3: a stream confined to 7/8 or 1/2 of the CUs with hipExtStreamCreateWithCUMask, 128x128
+// tiles on it, the lowest priority, a fourth side stream of the same class: profiles/README.md.)
+bool create_lanes(LaneSet& S) {
+  if (hipGetDevice(&S.device) != hipSuccess) return false;
+  int least = 0, greatest = 0;
+  if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return false;
+  const char* e = getenv("SDUMC_LANE_PRIORITY");
+  const int prio = (e && e[0] == 'n') ? 0 : ((e && e[0] == 'l') ? least : greatest);
   int lane_prio[2] = {prio, prio};
-  if (const char* e = getenv("SDUMC_LANE_PRIORITIES")) {   // experiment knob: one letter (h/n/l) per side lane
-    int least = 0, greatest = 0;
-    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return;
-    for (int i = 0; i < 2 && e[i]; ++i) lane_prio[i] = e[i] == 'n' ? 0 : (e[i] == 'l' ? least : greatest);
-  }
+  if (const char* e2 = getenv("SDUMC_LANE_PRIORITIES"))    // experiment knob: one letter (h/n/l) per side lane
+    for (int i = 0; i < 2 && e2[i]; ++i) lane_prio[i] = e2[i] == 'n' ? 0 : (e2[i] == 'l' ? least : greatest);
   for (int i = 0; i < 2; ++i)
-    if (hipStreamCreateWithPriority(&S.s[i], hipStreamNonBlocking, lane_prio[i]) != hipSuccess) return;
-  for (int i = 0; i < 64; ++i)
-    if (hipEventCreateWithFlags(&S.ev[i], hipEventDisableTiming) != hipSuccess) return;
-  {
-    // The (optional) background lane carries MFMA-bound GEMMs that run beside the launch-bound utterance-level chain.
-    // Measured on MI355X: an ordinary stream gains 0.8 % per step (2.236 vs 2.254 ms, three alternations) while the
-    // half-size launches lose 4 % of per-kernel efficiency (TN 78 vs 82 TF) -> off by default; a stream confined to 7/8 (or 1/2) of the CUs with
-    // hipExtStreamCreateWithCUMask -- meant to keep free CUs for the chain's small kernels -- made the whole step
-    // 60 % slower (3.57 vs 2.22 ms), and 128x128 tiles on this lane (2 workgroups per CU, room for a small kernel beside
-    // them) 12 % slower; the lowest stream priority made no difference.  Re-measured after the dW batches moved to this
-    // lane (r1n): 27.7 k samples/s with the option (forward + backward, mode 1) against 29.7 k without, at every priority of
-    // this stream; forward only (mode 2) 30.0-30.2 k against 29.7-29.9 k (+0.9 %, six alternations); the same GEMMs issued at
-    // the START of the utterance-level chain, so that they can only run beside it: 29.75 k = no gain -- the small kernels
-    // slow down by as much as is hidden.
-    if (hipStreamCreateWithPriority(&S.bg, hipStreamNonBlocking, prio) != hipSuccess) return;
-  }
+    if (hipStreamCreateWithPriority(&S.s[i], hipStreamNonBlocking, lane_prio[i]) != hipSuccess) return false;
+  for (unsigned i = 0; i < LaneSet::NEV; ++i)
+    if (hipEventCreateWithFlags(&S.ev[i], hipEventDisableTiming) != hipSuccess) return false;
+  if (hipStreamCreateWithPriority(&S.bg, hipStreamNonBlocking, prio) != hipSuccess) return false;
   S.ok = true;
+  return true;
 }
+void destroy_lanes(LaneSet& S) {
+  for (int i = 0; i < 2; ++i)
+    if (S.s[i]) (void)hipStreamDestroy(S.s[i]);
+  if (S.bg) (void)hipStreamDestroy(S.bg);
+  if (S.ok)
+    for (unsigned i = 0; i < LaneSet::NEV; ++i) (void)hipEventDestroy(S.ev[i]);
+  S.ok = false;
+}
+// the default lane set of the CURRENT device; created outside any capture (the *_workspace_bytes queries every caller
+// makes first call this)
+LaneSet* default_lanes() {
+  static std::mutex mu;
+  static std::map<int, LaneSet*> per_device;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = per_device.find(dev);
+  if (it != per_device.end()) return it->second;
+  LaneSet* S = new LaneSet();
+  if (!create_lanes(*S)) { destroy_lanes(*S); delete S; S = nullptr; }
+  per_device[dev] = S;
+  return S;
+}
+void ensure_side_streams() { (void)default_lanes(); }
 
 struct Ctx {
   const sdumc_net_dims& d;
@@ -416,6 +426,7 @@ struct Ctx {
   float* P;     // parameters
   float* G;     // gradient bucket (backward only)
   hipStream_t sts[4] = {nullptr, nullptr, nullptr, nullptr};
+  LaneSet* lanes = nullptr;   // io.ctx (caller-owned) or the device's default set
   bool bg = false;   // the Cross_Attention-site key projections are issued on lane 3 (background)
   bool capturing = false;   // the caller's stream is under hipGraph capture: only the plain three-lane fork/join pattern is used
   int bgb = 0;       // bit m: the Cross_Attention key-projection BACKWARD of modality m runs early, on lane 3, beside steps 7'-3'
@@ -425,7 +436,9 @@ struct Ctx {
   mutable std::vector<sdumc_gemm> deferred;
   float* p(int64_t off) const { return W + off; }
   void init_lanes() {
-    const SideStreams& S = side_streams();
+    lanes = io.ctx ? static_cast<LaneSet*>(io.ctx) : default_lanes();
+    static LaneSet none;
+    const LaneSet& S = lanes ? *lanes : none;
     sts[0] = st;
     multi = S.ok && g_concurrency;
     bg = g_background != 0;               // the launch decomposition is the same with and without real streams
@@ -446,16 +459,14 @@ struct Ctx {
   }
 };
 
-hipEvent_t next_event() {
-  SideStreams& S = side_streams();
-  hipEvent_t e = S.ev[S.next];
-  S.next = (S.next + 1) & 63;
-  return e;
+hipEvent_t next_event(const Ctx& c) {
+  LaneSet& S = *c.lanes;       // only reached when lanes exist (every caller is behind a sts[a] != sts[b] test)
+  return S.ev[S.next.fetch_add(1, std::memory_order_relaxed) % LaneSet::NEV];
 }
 // lane `from` -> lane `to`: everything issued on `to` after this waits for what `from` has issued so far
 int link(const Ctx& c, int from, int to) {
   if (c.sts[from] == c.sts[to]) return SDUMC_OK;
-  hipEvent_t e = next_event();
+  hipEvent_t e = next_event(c);
   if (hipEventRecord(e, c.sts[from]) != hipSuccess) return SDUMC_ELAUNCH;
   if (hipStreamWaitEvent(c.sts[to], e, 0) != hipSuccess) return SDUMC_ELAUNCH;
   return SDUMC_OK;
@@ -642,6 +653,10 @@ int check_io(const sdumc_net_dims* d, const sdumc_net_io* io) {
   if (d->train && !io->rng_state) return SDUMC_EINVAL;
   if (reinterpret_cast<uintptr_t>(io->workspace) & 255) return SDUMC_EINVAL;
   if (reinterpret_cast<uintptr_t>(io->params) & 15) return SDUMC_EINVAL;
+  if (io->ctx) {   // a caller-owned context belongs to the device it was created on
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || static_cast<const LaneSet*>(io->ctx)->device != dev) return SDUMC_EINVAL;
+  }
   {   // key-padding lengths: all of (audio, text, video[, feat4]) or none
     const int need = d->streams == 2 ? 4 : 3;
     int have = 0;
@@ -833,7 +848,7 @@ int forward(const Ctx& c) {
     c.use(3);
     RET(chain_transpose(c));
     if (c.sts[3] != c.sts[0]) {
-      wt_done = next_event();
+      wt_done = next_event(c);
       if (hipEventRecord(wt_done, c.st) != hipSuccess) return SDUMC_ELAUNCH;
     }
     c.use(0);
@@ -855,7 +870,7 @@ int forward(const Ctx& c) {
         RET(sdumc_dropout_bits_multi(&d, sg.V / B, 2, SITE_IN[1][m] - SITE_IN[0][m], outs, c.st));
       }
       if (c.sts[3] != c.sts[LANE_OF[m]]) {
-        bits_done[m] = next_event();
+        bits_done[m] = next_event(c);
         if (hipEventRecord(bits_done[m], c.st) != hipSuccess) return SDUMC_ELAUNCH;
       }
     }
@@ -1150,7 +1165,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     c.use(LANE_OF[m]);
     RET(pool_bwd(c, 1, m, c.p(pl.d_ca_out) + (int64_t)m * V * NQ * D, c.p(pl.d_qp) + (int64_t)m * V * NQ * D));
     if (own_lane & bgb & (1 << m)) {   // the input_proj backward has everything it needs: stay on this lane, beside 7'-3'
-      pooled[LANE_OF[m]] = next_event();
+      pooled[LANE_OF[m]] = next_event(c);
       if (hipEventRecord(pooled[LANE_OF[m]], c.st) != hipSuccess) return SDUMC_ELAUNCH;
       RET(keys_gemm_bwd(c, m, 1, 2));
     } else if (bgb & (1 << m)) {       // same, through the background lane
@@ -1376,6 +1391,25 @@ int loss_ssd(const sdumc_net_dims& d, const sdumc_net_io& io, float* ssd_out, co
 // ==========================================================================================
 // C ABI
 // ==========================================================================================
+extern "C" int sdumc_ctx_create(void** ctx) {
+  if (!ctx) return SDUMC_EINVAL;
+  LaneSet* S = new LaneSet();
+  if (!create_lanes(*S)) {
+    destroy_lanes(*S);
+    delete S;
+    return SDUMC_ELAUNCH;
+  }
+  *ctx = S;
+  return SDUMC_OK;
+}
+extern "C" int sdumc_ctx_destroy(void* ctx) {
+  if (!ctx) return SDUMC_EINVAL;
+  LaneSet* S = static_cast<LaneSet*>(ctx);
+  destroy_lanes(*S);
+  delete S;
+  return SDUMC_OK;
+}
+
 extern "C" int sdumc_set_concurrency(int on) {
   g_concurrency = on != 0;
   return SDUMC_OK;

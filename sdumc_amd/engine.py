@@ -85,6 +85,28 @@ def make_dims(B, streams, Ta, Tv, Tt, dims, train, sample0=0, p_mlp=P_MLP, bf16=
     return d
 
 
+class ExecContext:
+    """A caller-owned execution context of the C ABI (sdumc_ctx_create): its own internal side streams and event ring.
+    Steps driven concurrently from several host threads (each on its own torch stream) take one context each; without one,
+    every call on a device shares that device's default context and must come from one thread at a time."""
+
+    def __init__(self):
+        h = C.c_void_p()
+        check(lib.sdumc_ctx_create(C.byref(h)), "sdumc_ctx_create")
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            lib.sdumc_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class RngState:
     """Device-resident {seed_lo, seed_hi, call}: lets captured graphs draw fresh masks per replay."""
 
@@ -122,7 +144,8 @@ class NetCall:
     (audio, text[, feat4 when two streams], video -> given as (audio, text, video) or (audio, text, video, feat4));
     padded frames are then masked out of the six attention poolings."""
 
-    def __init__(self, flat_params, audio, texts, video, train, rng, sample0=0, p_mlp=P_MLP, bf16=False, lengths=None):
+    def __init__(self, flat_params, audio, texts, video, train, rng, sample0=0, p_mlp=P_MLP, bf16=False, lengths=None,
+                 ctx=None):
         texts = list(texts)
         _require_cuda(flat_params, audio, video, *texts)
         S = len(texts)
@@ -164,6 +187,8 @@ class NetCall:
         if self._lengths is not None:
             for i, t in enumerate(self._lengths):
                 io.lengths[i] = ptr(t)
+        self._ctx = ctx
+        io.ctx = ctx.handle if ctx is not None else None
         self.io = io
 
     def set_lengths(self, lengths):
@@ -227,7 +252,7 @@ class TrainStep(_OptStateMixin):
     optionally captured into a hipGraph (torch.cuda.CUDAGraph) and replayed."""
 
     def __init__(self, flat_params, B, T, dims, weights=DEFAULT_WEIGHTS, lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=1e-5, seed=0, train=True, sample0=0, bf16=False, share=None, arena=None):
+                 weight_decay=1e-5, seed=0, train=True, sample0=0, bf16=False, share=None, arena=None, ctx=None):
         """share: an object with .params .rng .adam_m .adam_v .hyper .losses (another TrainStep over the SAME flat_params, or
         FusedTrainer's run state) whose optimiser state this step uses instead of allocating its own -- steps of different
         (B, T) shapes then continue one training run.
@@ -288,6 +313,8 @@ class TrainStep(_OptStateMixin):
         io.workspace, io.workspace_bytes = ptr(self.workspace), nbytes
         io.vals, io.fused, io.rnc = ptr(self.vals), ptr(self.fused), ptr(self.rnc)
         io.text_hidden, io.cross_text = ptr(self.text_hidden), ptr(self.cross_text)
+        self._ctx = ctx       # ExecContext or None (= the device's default lanes)
+        io.ctx = ctx.handle if ctx is not None else None
         self.io = io
         cfg = _lib.StepCfg()
         for i, w in enumerate(weights):

@@ -283,3 +283,44 @@ def test_ragged_epoch_through_store_and_arena_equals_plain_batches(E):
             assert torch.equal(x, y)
         assert torch.equal(res[a][0], res[b][0])
     assert not torch.equal(res[0][1][0], res[2][1][0])       # the key-padding mask changes the result
+
+
+def test_two_host_threads_with_their_own_contexts_match_the_sequential_run(E):
+    """C-ABI: no state is shared between execution contexts (sdumc_ctx_create / sdumc_net_io.ctx) -- two host threads, each
+    with its own context and its own torch stream, run three fused steps concurrently on separate parameter copies; both
+    end bit-identical to the same steps run alone on the default context."""
+    import threading
+    from oracle import sdumc_oracle as O
+    dims = (64, 32, 48, 32)
+    B, Tn = 6, (70, 6, 30, 5)
+    P = O.init_params(dims, seed=3)
+    batch = [t.cuda() for t in O.synthetic_batch(B, Tn, dims, seed=8)]
+
+    def run(ctx, stream, out, k):
+        with torch.cuda.stream(stream):
+            flat, _ = flat_from(E, P, dims)
+            ts = E.TrainStep(flat, B, Tn, dims, seed=5, ctx=ctx)
+            ts.set_batch(*batch)
+            ls = [ts.run().clone() for _ in range(3)]
+            stream.synchronize()
+        out[k] = (flat, ls)
+
+    ref = {}
+    run(None, torch.cuda.current_stream(), ref, 0)
+    torch.cuda.synchronize()
+    for _ in range(3):
+        res, ths = {}, []
+        ctxs = [E.ExecContext(), E.ExecContext()]
+        for k in range(2):
+            th = threading.Thread(target=run, args=(ctxs[k], torch.cuda.Stream(), res, k))
+            th.start()
+            ths.append(th)
+        for th in ths:
+            th.join()
+        torch.cuda.synchronize()
+        for k in range(2):
+            assert torch.equal(res[k][0], ref[0][0])
+            for a, b in zip(res[k][1], ref[0][1]):
+                assert torch.equal(a, b)
+        for c in ctxs:
+            c.close()
