@@ -124,6 +124,34 @@ size_t sdumc_gemm_workspace_bytes(const sdumc_gemm* g);
 int sdumc_gemm_f32(const sdumc_gemm* g, void* stream);
 
 /* ------------------------------------------------------------------------
+ * GEMM on bf16 STORAGE (BASELINE configs[2], configs[4]): A and B are bf16 in HBM, products accumulate in fp32 on
+ * v_mfma_f32_32x32x16_bf16, C is fp32 or bf16.  The frame-level products of the step in bf16 mode
+ * (sdumc_net_dims.bf16 = 2): frame_dim_reshape (model :282-284), input_proj of FRA2UTT_new / Cross_Attention
+ * (model :60, :82) and their autograd (main :149).
+ *   SDUMC_NT: C[M,N] = A[M,K] . B[N,K]^T (+ bias, tanh / ReLU; accumulate: C += ...);  K a multiple of 64
+ *   SDUMC_TN: C[M,N] = A[K,M]^T . B[K,N]  (fp32 C; split-K through fp32 slabs, ordered reduce; colsum_a = column sums of A)
+ * Leading dimensions and the contiguous extents are multiples of 8 elements (16-byte rows), pointers 16-byte aligned.
+ * No dropout descriptor: in bf16 mode the masked frames xd = drop(x) are materialised once (sdumc_mask_apply_bf16).
+ * ---------------------------------------------------------------------- */
+typedef struct sdumc_gemm_bf16 {
+  int32_t layout, M, N, K, groups;
+  const void* A[SDUMC_MAX_GROUPS];      /* bf16 */
+  const void* B[SDUMC_MAX_GROUPS];      /* bf16 */
+  void* C[SDUMC_MAX_GROUPS];            /* fp32, or bf16 when c_bf16 */
+  const float* bias[SDUMC_MAX_GROUPS];  /* [N] fp32 or NULL */
+  float* colsum_a[SDUMC_MAX_GROUPS];    /* TN only, optional: out[m] (+)= sum_k A[k, m] */
+  int32_t lda, ldb, ldc;
+  int32_t a_row_mod;                    /* NT: A's source row = m % a_row_mod (both streams share x in eval mode) */
+  int32_t b_row_mod;                    /* TN: B's source row = k % b_row_mod */
+  int32_t act, accumulate, c_bf16;
+  int32_t splitk;                       /* TN: 0 auto, >= 1 explicit */
+  float* workspace;
+  size_t workspace_bytes;
+} sdumc_gemm_bf16;
+size_t sdumc_gemm_bf16_workspace_bytes(const sdumc_gemm_bf16* g);
+int sdumc_gemm_bf16_run(const sdumc_gemm_bf16* g, void* stream);
+
+/* ------------------------------------------------------------------------
  * Attention pooling over the time axis = the body shared by
  *   FRA2UTT_new.forward     (model :56-68; nq = 1, query = attention_context_vector, q_stride 0)
  *   Cross_Attention.forward (model :79-95; nq = 7, query = query_proj(multi_query))
@@ -158,6 +186,9 @@ typedef struct sdumc_attnpool {
                           part in the softmax, read_data.py:139-151 / model :63,:90): device int32 [V], valid frames per
                           virtual sample; frames t >= max(1, lengths[v]) get weight exactly 0 (key-padding mask) and
                           therefore zero gradient in sdumc_attnpool_bwd, which needs no mask of its own */
+  int32_t bf16;        /* 1: x and keys (and, in sdumc_attnpool_bwd, dz and dxd) are bf16 tensors of the same shapes (the engine's
+                          bf16-storage mode, BASELINE configs[2] / [4]); scores, softmax, pooling, attn, pooled, out, dq stay
+                          fp32.  dim must be 256; a fused x_drop needs precomputed keep-bits.  0 (default): fp32 */
 } sdumc_attnpool;
 
 size_t sdumc_attnpool_fwd_workspace_bytes(int32_t V, int32_t T, int32_t nq);
@@ -211,8 +242,15 @@ typedef struct sdumc_dropsum {
   int32_t stream_idx[8];
   int32_t samples, T;
   float* dx;                     /* [samples, T, 256] */
+  int32_t bf16;                  /* 1: g[k] and dx are bf16 tensors (the engine's bf16-storage mode); 0: fp32 */
 } sdumc_dropsum;
 int sdumc_dropsum_bwd(const sdumc_dropsum* p, void* stream);
+
+/* bf16-storage mode: out[row, :] = bf16(x[row % x_rows, :] * keep * scale) -- the masked frames drop(x) of one attention site
+ * (nn.Dropout inside FRA2UTT_new / Cross_Attention, model :59, :81) materialised once, from keep-bits produced by
+ * sdumc_dropout_bits (byte [row * width/4 + q], bit e = keep column 4q + e).  x, out: bf16 [.., width], width % 8 == 0. */
+int sdumc_mask_apply_bf16(const void* x, const uint8_t* bits, void* out, int64_t rows, int64_t x_rows, int32_t width, float scale,
+                          void* stream);
 
 /* Modality fusion (model :301-332 algebra).  u [V,3,256], alpha [V,3]
  *   qin [7][V,256] = (f, f_at, f_tv, f_av, u_a, u_t, u_v)                         */
@@ -468,11 +506,14 @@ typedef struct sdumc_net_dims {
   int32_t sample0;  /* global index of local sample 0 (data-parallel shard offset) */
   double p_frame;   /* 0.5: nn.Dropout inside FRA2UTT_new / Cross_Attention (model :54,:77) */
   double p_mlp;     /* 0.3: constructor default dropout (model :187) */
-  int32_t bf16;     /* 0 (default): exact fp32 everywhere.  1: the frame-level projections (frame_dim_reshape_*,
-                       model :282-284, and the input_proj keys of FRA2UTT_new / Cross_Attention, model :60,:82), forward
-                       and backward (dW, dX), round their operands to bf16 and multiply on v_mfma_f32_32x32x16_bf16 with
-                       fp32 accumulation -- the "bf16" configs of BASELINE.json; the utterance-level layers, the
-                       attention pooling, the losses and Adam stay fp32 */
+  int32_t bf16;     /* 0 (default): exact fp32 everywhere.
+                       1: fp32 storage; the frame-level projections (frame_dim_reshape_*, model :282-284, and the input_proj
+                       keys of FRA2UTT_new / Cross_Attention, model :60,:82), forward and backward, round their operands to bf16
+                       on the way to v_mfma_f32_32x32x16_bf16 (fp32 accumulation).
+                       2: bf16 STORAGE (BASELINE configs[2], configs[4]): the input features (sdumc_net_io.audio / video /
+                       text are then bf16 tensors), the projected frames, the masked frames, the tanh keys and the frame-level
+                       gradients live in HBM as bf16; products accumulate in fp32, bias / tanh / softmax / pooling / the
+                       utterance-level network / losses / Adam (fp32 master weights) stay fp32.  Needs da, dt, dv % 64 == 0. */
 } sdumc_net_dims;
 
 typedef struct sdumc_net_io {

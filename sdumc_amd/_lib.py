@@ -44,13 +44,23 @@ class Gemm(C.Structure):
                 ("stride_a", C.c_int64), ("stride_b", C.c_int64), ("stride_c", C.c_int64)]
 
 
+class GemmBf16(C.Structure):
+    _fields_ = [("layout", C.c_int32), ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("groups", C.c_int32),
+                ("A", C.c_void_p * MAX_GROUPS), ("B", C.c_void_p * MAX_GROUPS), ("C", C.c_void_p * MAX_GROUPS),
+                ("bias", C.c_void_p * MAX_GROUPS), ("colsum_a", C.c_void_p * MAX_GROUPS),
+                ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
+                ("a_row_mod", C.c_int32), ("b_row_mod", C.c_int32),
+                ("act", C.c_int32), ("accumulate", C.c_int32), ("c_bf16", C.c_int32), ("splitk", C.c_int32),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
 class AttnPool(C.Structure):
     _fields_ = [("V", C.c_int32), ("T", C.c_int32), ("nq", C.c_int32), ("x_samples", C.c_int32),
                 ("x", C.c_void_p), ("keys", C.c_void_p), ("q", C.c_void_p), ("q_stride", C.c_int64),
                 ("scale", C.c_float), ("x_drop", Dropout), ("out_drop", Dropout),
                 ("attn", C.c_void_p), ("pooled", C.c_void_p), ("out", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("dim", C.c_int32),
-                ("lengths", C.c_void_p)]
+                ("lengths", C.c_void_p), ("bf16", C.c_int32)]
 
 
 class AttnPoolBwd(C.Structure):
@@ -60,7 +70,8 @@ class AttnPoolBwd(C.Structure):
 
 class DropSum(C.Structure):
     _fields_ = [("terms", C.c_int32), ("g", C.c_void_p * 8), ("drop", Dropout * 8),
-                ("stream_idx", C.c_int32 * 8), ("samples", C.c_int32), ("T", C.c_int32), ("dx", C.c_void_p)]
+                ("stream_idx", C.c_int32 * 8), ("samples", C.c_int32), ("T", C.c_int32), ("dx", C.c_void_p),
+                ("bf16", C.c_int32)]
 
 
 class NetDims(C.Structure):
@@ -179,6 +190,9 @@ _SIGS = {
     "sdumc_copy2d": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sdumc_axpy2d": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sdumc_gather_pad": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "sdumc_mask_apply_bf16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_float, C.c_void_p]),
+    "sdumc_gemm_bf16_workspace_bytes": (C.c_size_t, [C.POINTER(GemmBf16)]),
+    "sdumc_gemm_bf16_run": (C.c_int, [C.POINTER(GemmBf16), C.c_void_p]),
     "sdumc_ctx_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "sdumc_ctx_destroy": (C.c_int, [C.c_void_p]),
     "sdumc_gather_pad_idx": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,

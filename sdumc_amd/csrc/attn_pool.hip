@@ -31,6 +31,28 @@ constexpr int CH = 64;           // rows of one v handled by a 4-wave workgroup 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
+// Frame tensors (x, keys, dz, dxd) are fp32, or bf16 in the engine's bf16-storage mode (sdumc_attnpool.bf16): `base` is the
+// tensor's address as float*, `off` an ELEMENT offset; 4 consecutive channels either way (16 or 8 bytes).
+template <bool HF>
+__device__ __forceinline__ f32x4 ldx(const float* base, size_t off) {
+  if constexpr (HF) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off);
+    return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                 __uint_as_float(u.y & 0xffff0000u)};
+  } else {
+    return ld4(base + off);
+  }
+}
+template <bool HF>
+__device__ __forceinline__ void stx(float* base, size_t off, f32x4 v) {
+  if constexpr (HF) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    const bf16x4 h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};      // round to nearest even
+    *reinterpret_cast<bf16x4*>(reinterpret_cast<unsigned short*>(base) + off) = h;
+  } else {
+    st4(base + off, v);
+  }
+}
 
 // workspace layout of the forward: part [V][nchunk][nq][256], then stats [V][nchunk][2][MAXQ]
 struct FwdWs {
@@ -49,9 +71,9 @@ __host__ __device__ inline int row_dim(const sdumc_attnpool& p) { return p.dim >
 // A operand: lane (r = lane&15, kk = lane>>4) supplies rows[r][16 j + 4 kk + e]; B operand: the same
 // channel of column r.  `rowp` = this lane's row pointer (or nullptr), bq[j] = this lane's B fragments.
 // The B side lives in LDS as [MAXQ][LDQ] (LDQ = 272: rows 16 banks apart -> at most 2-way conflicts).
-template <bool DROP, int C>
+template <bool DROP, int C, bool HF = false>
 __device__ __forceinline__ f32x4 rows_times_cols(const float* rowp, const float* b_lds, const DropRT& d,
-                                                 uint32_t vrow, int r16, int kk) {
+                                                 uint32_t vrow, int r16, int kk, size_t rowoff = 0) {
   constexpr int LDQ = D * C + 16;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   // two batches of 8 channel groups: a batch's row loads (and keep-bits bytes) are all issued before its first MFMA
@@ -66,7 +88,7 @@ __device__ __forceinline__ f32x4 rows_times_cols(const float* rowp, const float*
       a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
       mb[u] = 0;
       if (rowp) {
-        a[u] = ld4(rowp + 16 * j + 4 * kk);
+        a[u] = ldx<HF>(rowp, rowoff + 16 * j + 4 * kk);
         if (bits) mb[u] = d.bits[(size_t)vrow * d.qwidth + 4 * j + kk];
       }
     }
@@ -95,7 +117,7 @@ __device__ __forceinline__ f32x4 rows_times_cols(const float* rowp, const float*
 
 // ---- forward, pass 1: one workgroup per (chunk of 64 rows, v) -----------------------------------
 // PHILOX: the input dropout mask is recomputed per row (no precomputed keep-bits attached: tests, one-off calls)
-template <bool PHILOX, int C>
+template <bool PHILOX, int C, bool HF = false>
 __global__ __launch_bounds__(256, C == 1 ? 4 : 2) void attn_fwd_partial_kernel(const sdumc_attnpool p, float* ws, const int nchunk) {
   constexpr int DD = D * C, LDQ = DD + 16;
   constexpr int RED = 4 * MAXQ * D > MAXQ * LDQ ? 4 * MAXQ * D : MAXQ * LDQ;
@@ -121,7 +143,7 @@ __global__ __launch_bounds__(256, C == 1 ? 4 : 2) void attn_fwd_partial_kernel(c
   __syncthreads();
   const int myrow = t0 + 16 * wave + r16;
   const DropRT nodrop = {};
-  const f32x4 s4 = rows_times_cols<false, C>(myrow < T ? p.keys + ((size_t)v * T + myrow) * DD : nullptr, q_s, nodrop, 0u, r16, kk);
+  const f32x4 s4 = rows_times_cols<false, C, HF>(myrow < T ? p.keys : nullptr, q_s, nodrop, 0u, r16, kk, ((size_t)v * T + myrow) * DD);
   // C layout: column (query) = lane & 15, rows = 16 wave + 4 (lane >> 4) + e
   float s[4], mx = -INFINITY;
 #pragma unroll
@@ -174,7 +196,7 @@ __global__ __launch_bounds__(256, C == 1 ? 4 : 2) void attn_fwd_partial_kernel(c
       for (int r = 0; r < 16; ++r) {
         const int rl = 16 * wave + r, t = t0 + rl;
         if (t >= T) break;
-        f32x4 x = ld4(p.x + ((size_t)vx * T + t) * DD + ch);
+        f32x4 x = ldx<HF>(p.x, ((size_t)vx * T + t) * DD + ch);
         x *= drop_mask4(xd, (uint32_t)(v * T + t), (uint32_t)(ch >> 2));
 #pragma unroll
         for (int i = 0; i < MAXQ; ++i)
@@ -193,7 +215,7 @@ __global__ __launch_bounds__(256, C == 1 ? 4 : 2) void attn_fwd_partial_kernel(c
 #pragma unroll
         for (int j = 0; j < RB; ++j) {
           const int t = min(t0 + 16 * wave + rb + j, T - 1);   // rows beyond T re-read the last row; their P_s is 0
-          xr[j] = ld4(p.x + ((size_t)vx * T + t) * DD + ch);
+          xr[j] = ldx<HF>(p.x, ((size_t)vx * T + t) * DD + ch);
           mb[j] = masked ? xd.bits[(size_t)(v * T + t) * xd.qwidth + (ch >> 2)] : 0xfu;
         }
 #pragma unroll
@@ -271,7 +293,7 @@ __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const sdumc_attnp
 //   dK_t = sum_i dS_i Q_i ; dz_t = dK_t (1 - K_t^2)            -> dz
 //   dxd_t (pool path) = sum_i A_ti dO_i                         -> dxd
 //   dQ_i += dS_i K_t                                            -> per-chunk slabs (deterministic)
-template <int C>
+template <int C, bool HF = false>
 __global__ __launch_bounds__(256, 2) void attnpool_bwd_kernel(const sdumc_attnpool_bwd_t b, float* dq_part,
                                                            const int nchunk) {
   constexpr int DD = D * C, LDQ = DD + 16;
@@ -313,10 +335,11 @@ __global__ __launch_bounds__(256, 2) void attnpool_bwd_kernel(const sdumc_attnpo
   const int vx = v % p.x_samples;
   {
     const int myrow = t0 + 16 * wave + r16;
-    const float* rowp = myrow < T ? p.x + ((size_t)vx * T + myrow) * DD : nullptr;
+    const float* rowp = myrow < T ? p.x : nullptr;
+    const size_t rowoff = ((size_t)vx * T + myrow) * DD;
     const uint32_t vrow = (uint32_t)(v * T + myrow);
-    const f32x4 dA = xd.enabled ? rows_times_cols<true, C>(rowp, dO_s, xd, vrow, r16, kk)
-                                : rows_times_cols<false, C>(rowp, dO_s, xd, vrow, r16, kk);
+    const f32x4 dA = xd.enabled ? rows_times_cols<true, C, HF>(rowp, dO_s, xd, vrow, r16, kk, rowoff)
+                                : rows_times_cols<false, C, HF>(rowp, dO_s, xd, vrow, r16, kk, rowoff);
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const int rl = 16 * wave + 4 * kk + e, t = t0 + rl;
@@ -354,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void attnpool_bwd_kernel(const sdumc_attnpo
 #pragma unroll
       for (int j = 0; j < RB; ++j) {
         const int t = t0 + 16 * wave + rb + j;
-        kr[j] = t < T ? ld4(p.keys + ((size_t)v * T + t) * DD + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+        kr[j] = t < T ? ldx<HF>(p.keys, ((size_t)v * T + t) * DD + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int j = 0; j < RB; ++j) {
@@ -372,8 +395,8 @@ __global__ __launch_bounds__(256, 2) void attnpool_bwd_kernel(const sdumc_attnpo
           }
         if (t < T) {
           const f32x4 one = {1.f, 1.f, 1.f, 1.f};
-          st4(b.dz + row * DD + ch, dk * (one - k * k));
-          st4(b.dxd + row * DD + ch, dx);
+          stx<HF>(b.dz, row * DD + ch, dk * (one - k * k));
+          stx<HF>(b.dxd, row * DD + ch, dx);
         }
       }
     }
@@ -432,6 +455,10 @@ extern "C" int sdumc_attnpool_fwd(const sdumc_attnpool* pp, void* stream) {
   const bool philox = p.x_drop.enabled && !p.x_drop.bits;
   const dim3 grid(nchunk, p.V), blk(256);
 #define FWD_PARTIAL(PH, CC) hipLaunchKernelGGL((attn_fwd_partial_kernel<PH, CC>), grid, blk, 0, st, p, p.workspace, nchunk)
+  if (p.bf16) {      // bf16 frames: the engine's bf16-storage mode (256 channels, masks pre-applied or keep-bits attached)
+    if (row_dim(p) != D || philox) return SDUMC_EINVAL;
+    hipLaunchKernelGGL((attn_fwd_partial_kernel<false, 1, true>), grid, blk, 0, st, p, p.workspace, nchunk);
+  } else
   switch (row_dim(p) / D) {
     case 1: if (philox) FWD_PARTIAL(true, 1); else FWD_PARTIAL(false, 1); break;
     case 2: if (philox) FWD_PARTIAL(true, 2); else FWD_PARTIAL(false, 2); break;
@@ -466,6 +493,10 @@ extern "C" int sdumc_attnpool_bwd(const sdumc_attnpool_bwd_t* bp, void* stream) 
   if (b.workspace_bytes < sdumc_attnpool_bwd_workspace_bytes_dim(p.V, p.T, p.nq, DD)) return SDUMC_ENOMEM;
   hipStream_t st = as_stream(stream);
   const dim3 grid(nchunk, p.V), blk(256);
+  if (p.bf16) {
+    if (DD != D || (p.x_drop.enabled && !p.x_drop.bits)) return SDUMC_EINVAL;
+    hipLaunchKernelGGL((attnpool_bwd_kernel<1, true>), grid, blk, 0, st, b, b.workspace, nchunk);
+  } else
   switch (DD / D) {
     case 1: hipLaunchKernelGGL(attnpool_bwd_kernel<1>, grid, blk, 0, st, b, b.workspace, nchunk); break;
     case 2: hipLaunchKernelGGL(attnpool_bwd_kernel<2>, grid, blk, 0, st, b, b.workspace, nchunk); break;

@@ -62,6 +62,9 @@ extern "C" {
 // which: 0 = stage A forward, 1 = stage B forward, 2 = stage B backward, 3 = stage A backward
 int sdumc_chain_launch_(const sdumc_chain_args* a, int which, void* stream);
 // dst[off ..] = transpose of the n listed [out][in] matrices of src (same offsets in both buffers)
+// fp32 parameters -> bf16 copies as stored (dst) and, where want_t[i], transposed (dst_t); same element offsets as in src
+int sdumc_weights_to_bf16_(const float* src, void* dst, void* dst_t, const int64_t* offs, const int32_t* outs, const int32_t* ins,
+                           const int32_t* want_t, int n, void* stream);
 int sdumc_chain_transpose_(const float* src, float* dst, const int64_t* offs, const int32_t* outs, const int32_t* ins, int n,
                            void* stream);
 }

@@ -123,6 +123,79 @@ __global__ void gather_pad_idx_kernel(const float* packed, const int64_t* start_
   if (len_out && t == 0 && c == 0) len_out[b] = n < Tmax ? n : Tmax;
 }
 
+// ---- bf16-storage mode helpers ---------------------------------------------------------------------------------------
+// xd[row, :] = bf16( x[row % x_rows, :] * keep * scale ): the masked frames of one (site, stream set), materialised once so
+// that every consumer (key projection, pooling, their backward) reads plain bf16 rows.  One thread per 8 channels.
+__global__ void mask_apply_bf16_kernel(const unsigned short* __restrict__ x, const uint8_t* __restrict__ bits, unsigned short* __restrict__ out,
+                                       int64_t rows, int64_t x_rows, int width8, float scale) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * width8) return;
+  const int64_t row = i / width8;
+  const int c8 = (int)(i - row * width8);
+  const uint4 u = *reinterpret_cast<const uint4*>(x + ((row % x_rows) * width8 + c8) * 8);
+  const unsigned m = *reinterpret_cast<const unsigned short*>(bits + (row * width8 + c8) * 2);   // 2 bytes = 8 keep-bits
+  const unsigned w[4] = {u.x, u.y, u.z, u.w};
+  unsigned o[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    // byte (k >> 1) of m covers channels 4 (k >> 1) .. +3; word k holds channels 2k (low half) and 2k + 1 (high half)
+    const unsigned b0 = (m >> (8 * (k >> 1) + 2 * (k & 1))) & 1u, b1 = (m >> (8 * (k >> 1) + 2 * (k & 1) + 1)) & 1u;
+    const float lo = b0 ? __uint_as_float(w[k] << 16) * scale : 0.f, hi = b1 ? __uint_as_float(w[k] & 0xffff0000u) * scale : 0.f;
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    const bf16x2 h = {(__bf16)lo, (__bf16)hi};
+    o[k] = *reinterpret_cast<const unsigned*>(&h);
+  }
+  *reinterpret_cast<uint4*>(out + i * 8) = uint4{o[0], o[1], o[2], o[3]};
+}
+
+// fp32 parameters -> bf16 copies: as stored ([out][in], dst) and, optionally, transposed ([in][out], dst_t), same element
+// offsets as in the flat parameter buffer; up to 16 matrices per launch
+struct CvtList {
+  int n;
+  struct { int64_t off; int32_t out, in, want_t; } e[16];
+};
+__global__ __launch_bounds__(256) void weights_to_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                              unsigned short* __restrict__ dst_t, const CvtList cl) {
+  __shared__ float t[32][33];
+  const auto& e = cl.e[blockIdx.z];
+  const int o0 = blockIdx.y * 32, i0 = blockIdx.x * 32;
+  if (o0 >= e.out || i0 >= e.in) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8)
+    if (o0 + k < e.out && i0 + tx < e.in) {
+      const float v = src[e.off + (int64_t)(o0 + k) * e.in + i0 + tx];
+      t[k][tx] = v;
+      __bf16 h = (__bf16)v;
+      dst[e.off + (int64_t)(o0 + k) * e.in + i0 + tx] = *reinterpret_cast<unsigned short*>(&h);
+    }
+  if (!e.want_t) return;
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8)
+    if (i0 + k < e.in && o0 + tx < e.out) {
+      __bf16 h = (__bf16)t[tx][k];
+      dst_t[e.off + (int64_t)(i0 + k) * e.out + o0 + tx] = *reinterpret_cast<unsigned short*>(&h);
+    }
+}
+
+// dropsum on bf16 gradients: dx = sum_k g_k * mask_k, bf16 in and out (one thread per 4 channels, keep-bits or Philox as the
+// fp32 kernel)
+__global__ void dropsum_bwd_bf16_kernel(const sdumc_dropsum p, int64_t nquads) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nquads) return;
+  const uint32_t row = (uint32_t)(i / (D / 4)), cq = (uint32_t)(i - (int64_t)row * (D / 4));
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < p.terms; ++k) {
+    const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.g[k]) + 4 * i);
+    f32x4 g = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+    const DropRT d = drop_resolve(p.drop[k]);
+    if (d.enabled) g *= drop_mask4(d, (uint32_t)p.stream_idx[k] * (uint32_t)(p.samples * p.T) + row, cq);
+    acc += g;
+  }
+  typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+  const bf16x4 h = {(__bf16)acc[0], (__bf16)acc[1], (__bf16)acc[2], (__bf16)acc[3]};
+  *reinterpret_cast<bf16x4*>(reinterpret_cast<unsigned short*>(p.dx) + 4 * i) = h;
+}
+
 __global__ void fill_kernel(float* p, float v, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) p[i] = v;
@@ -440,11 +513,48 @@ extern "C" int sdumc_dropout_bits(const sdumc_dropout* d, int32_t streams, uint8
   return sdumc_dropout_bits_multi(d, streams, 1, 0, one, stream);
 }
 
+extern "C" int sdumc_mask_apply_bf16(const void* x, const uint8_t* bits, void* out, int64_t rows, int64_t x_rows, int32_t width,
+                                     float scale, void* stream) {
+  if (!x || !bits || !out || rows <= 0 || x_rows <= 0 || width <= 0 || (width & 7)) return SDUMC_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) & 15 || (reinterpret_cast<uintptr_t>(bits) & 1)) return SDUMC_EINVAL;
+  const int64_t n = rows * (width / 8);
+  hipLaunchKernelGGL(mask_apply_bf16_kernel, dim3(nblk(n)), dim3(256), 0, as_stream(stream), static_cast<const unsigned short*>(x), bits,
+                     static_cast<unsigned short*>(out), rows, x_rows, width / 8, scale);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_weights_to_bf16_(const float* src, void* dst, void* dst_t, const int64_t* offs, const int32_t* outs,
+                                      const int32_t* ins, const int32_t* want_t, int n, void* stream) {
+  if (!src || !dst || n <= 0 || n > 16) return SDUMC_EINVAL;
+  CvtList cl;
+  cl.n = n;
+  int mo = 0, mi = 0;
+  for (int i = 0; i < n; ++i) {
+    cl.e[i].off = offs[i];
+    cl.e[i].out = outs[i];
+    cl.e[i].in = ins[i];
+    cl.e[i].want_t = want_t[i];
+    if (want_t[i] && !dst_t) return SDUMC_EINVAL;
+    mo = outs[i] > mo ? outs[i] : mo;
+    mi = ins[i] > mi ? ins[i] : mi;
+  }
+  hipLaunchKernelGGL(weights_to_bf16_kernel, dim3((mi + 31) / 32, (mo + 31) / 32, n), dim3(256), 0, as_stream(stream), src,
+                     static_cast<unsigned short*>(dst), static_cast<unsigned short*>(dst_t), cl);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
 extern "C" int sdumc_dropsum_bwd(const sdumc_dropsum* p, void* stream) {
   if (!p || p->terms < 1 || p->terms > 8 || !p->dx || p->samples <= 0 || p->T <= 0) return SDUMC_EINVAL;
   for (int k = 0; k < p->terms; ++k)
     if (!p->g[k]) return SDUMC_EINVAL;
   const int64_t nquads = (int64_t)p->samples * p->T * (D / 4);
+  if (p->bf16) {
+    hipLaunchKernelGGL(dropsum_bwd_bf16_kernel, dim3(nblk(nquads)), dim3(256), 0, as_stream(stream), *p, nquads);
+    SDUMC_CHECK_LAUNCH();
+    return SDUMC_OK;
+  }
   hipLaunchKernelGGL(dropsum_bwd_kernel, dim3(nblk(nquads)), dim3(256), 0, as_stream(stream), *p, nquads);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;

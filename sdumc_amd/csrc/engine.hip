@@ -191,6 +191,11 @@ struct Plan {
       d_z, d_r1, dq_fra;
   int64_t lens = 0;          // int32 [3][V]: valid frames per (modality, virtual sample) when sdumc_net_io.lengths is given
   int64_t wt = 0;            // transposed mirror of the utterance-level weights [0, early): chain.hip's forward layout
+  // bf16-storage mode (sdumc_net_dims.bf16 == 2): x, keys, dz, dxd, dx are bf16 (their offsets above stay in FLOATS, the
+  // buffers are half as long); plus the masked frames xd of each attention site and bf16 copies of the frame-level weights
+  bool hf = false;
+  int64_t xd[2][3] = {{0, 0, 0}, {0, 0, 0}};
+  int64_t wh = 0, wht = 0;   // [live] bf16 each: weights as stored / transposed (input_proj only), parameter offsets
   int64_t scratch[4] = {0, 0, 0, 0}, scratch_floats = 0;   // one scratch per lane (stream)
   int64_t alloc(int64_t n) {
     const int64_t o = cur;
@@ -214,23 +219,26 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
   if (d.B <= 0 || (d.streams != 1 && d.streams != 2) || d.Ta <= 0 || d.Tv <= 0 || d.Tt[0] <= 0) return false;
   if (d.streams == 2 && d.Tt[1] <= 0) return false;
   if (d.da <= 0 || d.dt <= 0 || d.dv <= 0) return false;
+  if (d.bf16 == 2 && ((d.da | d.dt | d.dv) & 63)) return false;     // bf16 storage: feature widths in whole 64-element k-tiles
   p.B = d.B;
   p.S = d.streams;
   p.V = d.B * d.streams;
+  p.hf = d.bf16 == 2;
   const int B = p.B, S = p.S, V = p.V;
+  const int HS = p.hf ? 2 : 1;          // bf16 frame tensors take half the floats
   for (int s = 0; s < 2; ++s) {
     p.T[0][s] = d.Ta;
     p.T[1][s] = d.Tt[s < S ? s : 0];
     p.T[2][s] = d.Tv;
   }
   // x buffers; the text buffers of the two streams are adjacent so that equal T merges them
-  p.x[0][0] = p.alloc((int64_t)B * d.Ta * D);
+  p.x[0][0] = p.alloc((int64_t)B * d.Ta * D / HS);
   p.x[0][1] = p.x[0][0];
-  p.x[2][0] = p.alloc((int64_t)B * d.Tv * D);
+  p.x[2][0] = p.alloc((int64_t)B * d.Tv * D / HS);
   p.x[2][1] = p.x[2][0];
   {
-    const int64_t n0 = (int64_t)B * p.T[1][0] * D;
-    const int64_t n1 = S == 2 ? (int64_t)B * p.T[1][1] * D : 0;
+    const int64_t n0 = (int64_t)B * p.T[1][0] * D / HS;
+    const int64_t n1 = S == 2 ? (int64_t)B * p.T[1][1] * D / HS : 0;
     p.x[1][0] = p.alloc(n0 + n1);
     p.x[1][1] = p.x[1][0] + n0;
   }
@@ -265,7 +273,8 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
   const int nq[2] = {1, NQ};
   for (int k = 0; k < 2; ++k)
     for (int m = 0; m < 3; ++m) {
-      p.keys[k][m] = p.alloc(p.rows[m] * D);
+      p.keys[k][m] = p.alloc(p.rows[m] * D / HS);
+      if (p.hf && d.train) p.xd[k][m] = p.alloc(p.rows[m] * D / 2);
       p.bits[k][m] = p.alloc(p.rows[m] * (D / 4) / 4 + 1);
       p.attn[k][m] = p.alloc(p.rows[m] * nq[k]);
       p.pooled[k][m] = p.alloc((int64_t)V * nq[k] * D);
@@ -293,13 +302,13 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
   // backward
   for (int k = 0; k < 2; ++k)
     for (int m = 0; m < 3; ++m) {
-      p.dz[k][m] = p.alloc(p.rows[m] * D);
-      p.dxd[k][m] = p.alloc(p.rows[m] * D);
+      p.dz[k][m] = p.alloc(p.rows[m] * D / HS);
+      p.dxd[k][m] = p.alloc(p.rows[m] * D / HS);
     }
-  p.dx[0][0] = p.dx[0][1] = p.alloc((int64_t)B * d.Ta * D);
-  p.dx[2][0] = p.dx[2][1] = p.alloc((int64_t)B * d.Tv * D);
-  p.dx[1][0] = p.alloc((int64_t)B * p.T[1][0] * D);
-  p.dx[1][1] = S == 2 ? p.alloc((int64_t)B * p.T[1][1] * D) : p.dx[1][0];
+  p.dx[0][0] = p.dx[0][1] = p.alloc((int64_t)B * d.Ta * D / HS);
+  p.dx[2][0] = p.dx[2][1] = p.alloc((int64_t)B * d.Tv * D / HS);
+  p.dx[1][0] = p.alloc((int64_t)B * p.T[1][0] * D / HS);
+  p.dx[1][1] = S == 2 ? p.alloc((int64_t)B * p.T[1][1] * D / HS) : p.dx[1][0];
   p.d_hpre = p.alloc(3LL * V * D);
   p.d_u1 = p.alloc(3LL * V * D);
   p.d_u = p.alloc(3LL * V * D);
@@ -321,6 +330,11 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
   p.dq_fra = p.alloc(3LL * V * D);
   p.lens = p.alloc(3LL * V);
   p.wt = p.alloc(build_params(d.da, d.dt, d.dv).early);
+  if (p.hf) {
+    const int64_t live = build_params(d.da, d.dt, d.dv).live;
+    p.wh = p.alloc(live / 2 + 8);
+    p.wht = p.alloc(live / 2 + 8);
+  }
   // scratch shared by split-K slabs, column-sum partials and the attention-pool dq slabs
   int64_t sc = 1 << 16;
   const int din[3] = {d.da, d.dt, d.dv};
@@ -435,6 +449,9 @@ struct Ctx {
   // weight-gradient GEMMs of the utterance-level layers, queued by lin_bwd* and issued in batches on lane 3 (flush_dw)
   mutable std::vector<sdumc_gemm> deferred;
   float* p(int64_t off) const { return W + off; }
+  // bf16 buffers: `off` is the buffer's offset in floats, `elems` an element offset inside it
+  unsigned short* ph(int64_t off, int64_t elems = 0) const { return reinterpret_cast<unsigned short*>(W + off) + elems; }
+  bool h() const { return pl.hf; }
   void init_lanes() {
     lanes = io.ctx ? static_cast<LaneSet*>(io.ctx) : default_lanes();
     static LaneSet none;
@@ -687,6 +704,14 @@ sdumc_attnpool attn_desc(const Ctx& c, int k, int m, const Seg& sg) {
   a.x_samples = sg.x_samples;
   a.x = c.p(sg.x_off);
   a.keys = c.p(pl.keys[k][m]) + sg.row0 * D;
+  if (c.h()) {     // bf16 frames; in train mode the masked frames xd of this site stand in for (x, input dropout)
+    a.bf16 = 1;
+    a.keys = reinterpret_cast<const float*>(c.ph(pl.keys[k][m], sg.row0 * D));
+    if (c.d.train) {
+      a.x = reinterpret_cast<const float*>(c.ph(pl.xd[k][m], sg.row0 * D));
+      a.x_samples = sg.V;
+    }
+  }
   if (k == 0) {
     a.q = c.P + c.pm.fra_ctx[m];
     a.q_stride = 0;
@@ -696,6 +721,7 @@ sdumc_attnpool attn_desc(const Ctx& c, int k, int m, const Seg& sg) {
   }
   a.scale = 0.3f;
   a.x_drop = in_drop(c, k, m, sg.T, sg.s0, sg.row0);
+  if (c.h()) a.x_drop.enabled = 0;
   a.out_drop = mkdrop(c, SITE_OUT[k][m], c.d.p_frame, nq, D, sg.s0);
   a.attn = c.p(pl.attn[k][m]) + sg.row0 * nq;
   a.pooled = c.p(pl.pooled[k][m]) + (int64_t)sg.s0 * pl.B * nq * D;
@@ -709,7 +735,53 @@ sdumc_attnpool attn_desc(const Ctx& c, int k, int m, const Seg& sg) {
 // keys = tanh(drop(x) W^T + b) of the attention sites [k0, k1) of modality m (FRA2UTT_new = 0, Cross_Attention = 1:
 // they read the same x with different masks and weights).  Both in one grouped launch fill the last dispatch round
 // of the 64x64 tiles better; one at a time lets the Cross_Attention half run on the background lane.
+int run_h(const Ctx& c, sdumc_gemm_bf16& g) {
+  g.workspace = c.scr;
+  g.workspace_bytes = (size_t)c.pl.scratch_floats * sizeof(float);
+  return sdumc_gemm_bf16_run(&g, c.st);
+}
+sdumc_gemm_bf16 GH_(int layout, int M, int N, int K, int groups = 1) {
+  sdumc_gemm_bf16 g;
+  memset(&g, 0, sizeof(g));
+  g.layout = layout;
+  g.M = M;
+  g.N = N;
+  g.K = K;
+  g.groups = groups;
+  return g;
+}
+
+// bf16-storage mode: xd = drop(x) of the sites [k0, k1) materialised from the keep-bits, then keys = tanh(xd W^T + b)
+int keys_gemm_fwd_h(const Ctx& c, int m, int k0, int k1) {
+  const Plan& pl = c.pl;
+  for (const Seg& sg : pl.segs[m]) {
+    const int64_t rows = (int64_t)sg.V * sg.T;
+    sdumc_gemm_bf16 g = GH_(SDUMC_NT, (int)rows, D, D, k1 - k0);
+    for (int k = k0; k < k1; ++k) {
+      const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
+      if (c.d.train) {
+        const sdumc_dropout dd = in_drop(c, k, m, sg.T, sg.s0, sg.row0);
+        RET(sdumc_mask_apply_bf16(c.ph(sg.x_off), dd.bits, c.ph(pl.xd[k][m], sg.row0 * D), rows, (int64_t)sg.x_samples * sg.T, D,
+                                  dd.scale, c.st));
+        g.A[k - k0] = c.ph(pl.xd[k][m], sg.row0 * D);
+      } else {
+        g.A[k - k0] = c.ph(sg.x_off);
+      }
+      g.B[k - k0] = c.ph(pl.wh, L.w);
+      g.bias[k - k0] = c.P + L.b;
+      g.C[k - k0] = c.ph(pl.keys[k][m], sg.row0 * D);
+    }
+    g.lda = g.ldb = g.ldc = D;
+    g.a_row_mod = (!c.d.train && sg.x_samples < sg.V) ? sg.x_samples * sg.T : 0;
+    g.act = SDUMC_ACT_TANH;
+    g.c_bf16 = 1;
+    RET(run_h(c, g));
+  }
+  return SDUMC_OK;
+}
+
 int keys_gemm_fwd(const Ctx& c, int m, int k0, int k1) {
+  if (c.h()) return keys_gemm_fwd_h(c, m, k0, k1);
   for (const Seg& sg : c.pl.segs[m]) {
     sdumc_gemm g = G_(SDUMC_NT, sg.V * sg.T, D, D, k1 - k0);
     for (int k = k0; k < k1; ++k) {
@@ -843,6 +915,18 @@ int forward(const Ctx& c) {
   RET(fork_all(c));
   const bool chain = use_chain(c);
   hipEvent_t wt_done = nullptr;
+  if (c.h()) {   // bf16 copies of the frame-level weights (+ the transposed input_proj copies the dX products read)
+    int64_t offs[16];
+    int32_t outs[16], ins[16], wantt[16];
+    int n = 0;
+    for (int m = 0; m < 3; ++m) { offs[n] = pm.frame[m].w; outs[n] = D; ins[n] = din[m]; wantt[n] = 0; ++n; }
+    for (int m = 0; m < 3; ++m) {
+      offs[n] = pm.fra_proj[m].w; outs[n] = D; ins[n] = D; wantt[n] = 1; ++n;
+      offs[n] = pm.ca_in[m].w; outs[n] = D; ins[n] = D; wantt[n] = 1; ++n;
+    }
+    RET(sdumc_weights_to_bf16_(c.P, c.ph(pl.wh), c.ph(pl.wht), offs, outs, ins, wantt, n, c.st));
+    RET(fork_all(c));      // (the lanes forked above did not see this launch)
+  }
   if (chain) {   // transposed mirror of the utterance-level weights (7 MB, first needed after the frame-level part): lane 3
     RET(link(c, 0, 3));
     c.use(3);
@@ -879,6 +963,19 @@ int forward(const Ctx& c) {
     c.use(LANE_OF[m]);
     for (int s = 0; s < (m == 1 ? S : 1); ++s) {
       const float* in = m == 0 ? c.io.audio : (m == 2 ? c.io.video : c.io.text[s]);
+      if (c.h()) {    // features and projected frames in bf16
+        sdumc_gemm_bf16 g = GH_(SDUMC_NT, B * pl.T[m][s], D, din[m]);
+        g.A[0] = in;
+        g.lda = din[m];
+        g.B[0] = c.ph(pl.wh, pm.frame[m].w);
+        g.ldb = din[m];
+        g.bias[0] = c.P + pm.frame[m].b;
+        g.C[0] = c.ph(pl.x[m][s]);
+        g.ldc = D;
+        g.c_bf16 = 1;
+        RET(run_h(c, g));
+        continue;
+      }
       RET(lin_fwd(c, pm.frame[m], in, din[m], B * pl.T[m][s], c.p(pl.x[m][s]), D, SDUMC_ACT_NONE, nullptr, c.d.bf16 != 0));
     }
     if (bits_done[m] && hipStreamWaitEvent(c.st, bits_done[m], 0) != hipSuccess) return SDUMC_ELAUNCH;
@@ -1040,6 +1137,10 @@ int pool_bwd(const Ctx& c, int k, int m, const float* dout_base /* [V, nq, D] */
     b.dout = dout_base + voff;
     b.dz = c.p(pl.dz[k][m]) + sg.row0 * D;
     b.dxd = c.p(pl.dxd[k][m]) + sg.row0 * D;
+    if (c.h()) {
+      b.dz = reinterpret_cast<float*>(c.ph(pl.dz[k][m], sg.row0 * D));
+      b.dxd = reinterpret_cast<float*>(c.ph(pl.dxd[k][m], sg.row0 * D));
+    }
     b.dq = dq_base + voff;
     b.workspace = c.scr;
     b.workspace_bytes = (size_t)pl.scratch_floats * sizeof(float);
@@ -1050,7 +1151,43 @@ int pool_bwd(const Ctx& c, int k, int m, const float* dout_base /* [V, nq, D] */
 
 // input_proj backward of the sites [k0, k1) of modality m (grouped when both): dW = dz^T drop(x) (+ db), dxd += dz W
 // parts: bit 0 = dW (off every critical path: feeds only the gradient bucket), bit 1 = dX
+int keys_gemm_bwd_h(const Ctx& c, int m, int k0, int k1, int parts) {
+  const Plan& pl = c.pl;
+  if (parts & 1) {
+    bool first = true;
+    for (const Seg& sg : pl.segs[m]) {
+      const int rows = sg.V * sg.T;
+      sdumc_gemm_bf16 g = GH_(SDUMC_TN, D, D, rows, k1 - k0);
+      for (int k = k0; k < k1; ++k) {
+        const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
+        g.A[k - k0] = c.ph(pl.dz[k][m], sg.row0 * D);
+        g.B[k - k0] = c.d.train ? c.ph(pl.xd[k][m], sg.row0 * D) : c.ph(sg.x_off);
+        g.C[k - k0] = c.G + L.w;
+        g.colsum_a[k - k0] = c.G + L.b;
+      }
+      g.lda = g.ldb = g.ldc = D;
+      g.b_row_mod = (!c.d.train && sg.x_samples < sg.V) ? sg.x_samples * sg.T : 0;
+      g.accumulate = first ? 0 : 1;
+      RET(run_h(c, g));
+      first = false;
+    }
+  }
+  if (!(parts & 2)) return SDUMC_OK;
+  sdumc_gemm_bf16 g = GH_(SDUMC_NT, (int)pl.rows[m], D, D, k1 - k0);      // dxd += dz W: NT on the transposed weight copy
+  for (int k = k0; k < k1; ++k) {
+    const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
+    g.A[k - k0] = c.ph(pl.dz[k][m]);
+    g.B[k - k0] = c.ph(pl.wht, L.w);
+    g.C[k - k0] = c.ph(pl.dxd[k][m]);
+  }
+  g.lda = g.ldb = g.ldc = D;
+  g.accumulate = 1;
+  g.c_bf16 = 1;
+  return run_h(c, g);
+}
+
 int keys_gemm_bwd(const Ctx& c, int m, int k0, int k1, int parts = 3) {
+  if (c.h()) return keys_gemm_bwd_h(c, m, k0, k1, parts);
   const Plan& pl = c.pl;
   // dW: one grouped GEMM per run (runs differ in their x buffer), later runs accumulate
   bool first = true;
@@ -1303,15 +1440,29 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
           if (m == 1 && ss != s) continue;
           int64_t roff = 0;  // virtual-row offset of stream ss inside modality m
           for (int q = 0; q < ss; ++q) roff += (int64_t)B * pl.T[m][q];
-          ds.g[nt] = c.p(pl.dxd[k][m]) + roff * D;
+          ds.g[nt] = c.h() ? reinterpret_cast<const float*>(c.ph(pl.dxd[k][m], roff * D)) : c.p(pl.dxd[k][m]) + roff * D;
           ds.drop[nt] = in_drop(c, k, m, T, ss, roff);   // row space of this term = stream ss alone
           ds.stream_idx[nt] = 0;
           ++nt;
         }
       ds.terms = nt;
+      if (c.h()) ds.bf16 = 1;          // (dx is a half-length buffer: its float offset is its start either way)
       RET(sdumc_dropsum_bwd(&ds, c.st));
       const float* in = m == 0 ? c.io.audio : (m == 2 ? c.io.video : c.io.text[s]);
       const int rows = B * T;
+      if (c.h()) {     // dW_frame = dx^T features on bf16 storage
+        sdumc_gemm_bf16 gh = GH_(SDUMC_TN, D, din[m], rows);
+        gh.A[0] = c.ph(pl.dx[m][s]);
+        gh.lda = D;
+        gh.B[0] = in;
+        gh.ldb = din[m];
+        gh.C[0] = c.G + pm.frame[m].w;
+        gh.ldc = din[m];
+        gh.colsum_a[0] = c.G + pm.frame[m].b;
+        gh.accumulate = s > 0;
+        RET(run_h(c, gh));
+        continue;
+      }
       sdumc_gemm g = G_(SDUMC_TN, D, din[m], rows);
       g.A[0] = c.p(pl.dx[m][s]);
       g.lda = D;

@@ -80,8 +80,9 @@ class DeviceFeatureStore:
 
     MODS = ('audio', 'text', 'video', 'feat4')
 
-    def __init__(self, instances, device='cuda'):
-        """instances: iterable of dicts with 'audio','text','video','feat4' ([T, d] arrays), 'emo', 'val', 'name'."""
+    def __init__(self, instances, device='cuda', bf16=False):
+        """instances: iterable of dicts with 'audio','text','video','feat4' ([T, d] arrays), 'emo', 'val', 'name'.
+        bf16=True holds the features as bf16 (half the HBM; what the engine's bf16-storage mode reads; widths % 8 == 0)."""
         import ctypes as C
         from . import _lib
         self._C, self._lib = C, _lib
@@ -100,7 +101,9 @@ class DeviceFeatureStore:
             host = torch.empty(sum(lens), d, dtype=torch.float32)
             for s, n, inst in zip(starts, lens, instances):
                 host[s:s + n] = torch.as_tensor(inst[m], dtype=torch.float32)
-            self.packed[m] = host.to(self.device)
+            self.packed[m] = host.to(self.device).to(torch.bfloat16 if bf16 else torch.float32)
+            if bf16 and d % 8:
+                raise _lib.SdumcError(f"bf16 feature width {d} of '{m}' must be a multiple of 8")
             self.start[m] = torch.from_numpy(starts)
             self.length[m] = torch.tensor(lens, dtype=torch.int32)
             self.dim[m] = d
@@ -112,7 +115,7 @@ class DeviceFeatureStore:
         self.length_d = {m: self.length[m].to(self.device) for m in self.MODS}
 
     @classmethod
-    def synthetic(cls, n, T, dims, seed=1234, device='cuda', min_frac=0.25):
+    def synthetic(cls, n, T, dims, seed=1234, device='cuda', min_frac=0.25, bf16=False):
         """n utterances with per-sample lengths ~ U{ceil(min_frac * T_m) .. T_m} and N(0, 1) features, generated on the device
         (SURVEY §8d's variable-length synthetic inputs; no host copy of the tens of GB a real split holds)."""
         import ctypes as C
@@ -130,7 +133,7 @@ class DeviceFeatureStore:
             lo = max(1, int(np.ceil(Tm * min_frac)))
             lens = torch.randint(lo, Tm + 1, (n,), generator=g, dtype=torch.int32)
             starts = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(lens.to(torch.int64), 0)[:-1]])
-            self.packed[m] = torch.randn(int(lens.sum()), d, device=self.device, generator=gd)
+            self.packed[m] = torch.randn(int(lens.sum()), d, device=self.device, generator=gd).to(torch.bfloat16 if bf16 else torch.float32)
             self.start[m], self.length[m], self.dim[m] = starts, lens, int(d)
         self._device_tables()
         return self
@@ -150,10 +153,12 @@ class DeviceFeatureStore:
         idx_d = idx.to(self.device, non_blocking=True)
         for k, m in enumerate(self.MODS):
             dst = outs[k]
-            if dst.shape[0] != B or dst.shape[2] != self.dim[m] or not dst.is_contiguous():
-                raise _lib.SdumcError("batch_into: output buffer does not match the batch")
+            if dst.shape[0] != B or dst.shape[2] != self.dim[m] or not dst.is_contiguous() or dst.dtype != self.packed[m].dtype:
+                raise _lib.SdumcError("batch_into: output buffer does not match the batch (shape / dtype)")
+            # the kernel moves 16-byte units: a bf16 row of d elements is a row of d / 2 "floats"
+            dw = self.dim[m] if dst.dtype == torch.float32 else self.dim[m] // 2
             _lib.check(_lib.lib.sdumc_gather_pad_idx(_lib.ptr(self.packed[m]), _lib.ptr(self.start_d[m]), _lib.ptr(self.length_d[m]),
-                                                     _lib.ptr(idx_d), B, dst.shape[1], self.dim[m], _lib.ptr(dst),
+                                                     _lib.ptr(idx_d), B, dst.shape[1], dw, _lib.ptr(dst),
                                                      _lib.ptr(lengths_out[k]) if lengths_out is not None else None,
                                                      _lib.current_stream()), "sdumc_gather_pad_idx")
         torch.index_select(self.vals, 0, idx_d, out=labels_out)
@@ -177,9 +182,10 @@ class DeviceFeatureStore:
             tmax = int(lens.max())
             start_d = self.start[m][idx].to(self.device)
             len_d = lens.to(self.device)
-            dst = torch.empty(B, tmax, self.dim[m], dtype=torch.float32, device=self.device)
+            dst = torch.empty(B, tmax, self.dim[m], dtype=self.packed[m].dtype, device=self.device)
+            dw = self.dim[m] if dst.dtype == torch.float32 else self.dim[m] // 2
             _lib.check(_lib.lib.sdumc_gather_pad(_lib.ptr(self.packed[m]), _lib.ptr(start_d), _lib.ptr(len_d), B, tmax,
-                                                 self.dim[m], _lib.ptr(dst), _lib.current_stream()), "sdumc_gather_pad")
+                                                 dw, _lib.ptr(dst), _lib.current_stream()), "sdumc_gather_pad")
             out[key] = dst
             pads.append((tmax - lens).tolist())
         idx_d = idx.to(self.device)

@@ -62,14 +62,25 @@ class ParamLayout:
         return [n for n in self.order if self.entries[n][2]]
 
 
-def _require_cuda(*tensors):
+def _require_cuda(*tensors, dtypes=(torch.float32,)):
     for t in tensors:
         if t is None:
             continue
         if not t.is_cuda:
             raise _lib.SdumcError("sdumc_amd runs on the GPU only: got a CPU tensor (there is no CPU fallback)")
-        if t.dtype != torch.float32 or not t.is_contiguous():
-            raise _lib.SdumcError("expected contiguous float32 tensors")
+        if t.dtype not in dtypes or not t.is_contiguous():
+            raise _lib.SdumcError("expected contiguous " + " / ".join(str(d).replace("torch.", "") for d in dtypes) + " tensors")
+
+
+def bf16_mode(bf16, dims):
+    """sdumc_net_dims.bf16 for the Python-level switch: False -> 0 (fp32); True -> 2 = bf16 STORAGE of features, projected
+    frames, keys and frame-level gradients (BASELINE configs[2] / [4]) when the feature widths are whole 64-element k-tiles,
+    else 1; "operands" -> 1 = fp32 storage, frame-level GEMM operands rounded to bf16 on their way to the matrix cores."""
+    if not bf16:
+        return 0
+    if bf16 == "operands" or (not isinstance(bf16, bool) and bf16 == 1):
+        return 1
+    return 2 if all(int(d) % 64 == 0 for d in dims[:3]) else 1
 
 
 def make_dims(B, streams, Ta, Tv, Tt, dims, train, sample0=0, p_mlp=P_MLP, bf16=False):
@@ -81,7 +92,7 @@ def make_dims(B, streams, Ta, Tv, Tt, dims, train, sample0=0, p_mlp=P_MLP, bf16=
     d.train = 1 if train else 0
     d.sample0 = sample0
     d.p_frame, d.p_mlp = P_FRAME, p_mlp
-    d.bf16 = 1 if bf16 else 0
+    d.bf16 = bf16_mode(bf16, dims)
     return d
 
 
@@ -147,9 +158,15 @@ class NetCall:
     def __init__(self, flat_params, audio, texts, video, train, rng, sample0=0, p_mlp=P_MLP, bf16=False, lengths=None,
                  ctx=None):
         texts = list(texts)
-        _require_cuda(flat_params, audio, video, *texts)
+        _require_cuda(flat_params)
+        _require_cuda(audio, video, *texts, dtypes=(torch.float32, torch.bfloat16))
         S = len(texts)
         B, Ta, da = audio.shape
+        store = torch.bfloat16 if bf16_mode(bf16, (da, texts[0].shape[2], video.shape[2])) == 2 else torch.float32
+        # bf16-storage mode reads bf16 features (a DeviceFeatureStore(bf16=True) hands them over as such; fp32 inputs are
+        # converted once, here); the other modes read fp32
+        audio, video = audio.to(store), video.to(store)
+        texts = [t.to(store) for t in texts]
         Tv, dv = video.shape[1], video.shape[2]
         dt = texts[0].shape[2]
         for t in texts:
@@ -272,7 +289,11 @@ class TrainStep(_OptStateMixin):
         self.rng = share.rng if share is not None else RngState(seed, dev)
         V = 2 * B
         self.B, self.V = B, V
+        fdt = torch.bfloat16 if self.dims.bf16 == 2 else torch.float32      # dtype the features are held in
+        self.feature_dtype = fdt
         if arena is not None:
+            if arena.feature_dtype != fdt:
+                raise _lib.SdumcError("arena and step disagree on the feature dtype")
             if not arena.fits(B, T, nbytes):
                 raise _lib.SdumcError("arena too small for this batch shape")
             self.workspace = arena.workspace
@@ -289,10 +310,10 @@ class TrainStep(_OptStateMixin):
             self.cross_text = arena.outs[4][:V * NQ * H].view(V, NQ, H)
         else:
             self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-            self.audio = torch.empty(B, Ta, dims[0], device=dev)
-            self.text = torch.empty(B, Tt, dims[1], device=dev)
-            self.video = torch.empty(B, Tv, dims[2], device=dev)
-            self.feat4 = torch.empty(B, T4, dims[1], device=dev)
+            self.audio = torch.empty(B, Ta, dims[0], device=dev, dtype=fdt)
+            self.text = torch.empty(B, Tt, dims[1], device=dev, dtype=fdt)
+            self.video = torch.empty(B, Tv, dims[2], device=dev, dtype=fdt)
+            self.feat4 = torch.empty(B, T4, dims[1], device=dev, dtype=fdt)
             self.labels = torch.empty(B, device=dev)
             self.vals = torch.empty(V, 1, device=dev)
             self.fused = torch.empty(V, H, device=dev)
@@ -332,7 +353,8 @@ class TrainStep(_OptStateMixin):
             self.grads.zero_()      # alignment padding between tensors is never written by the kernels (an arena zeroes it once)
 
     def set_batch(self, audio, text, video, feat4, labels):
-        """Copies one batch into the step's resident input buffers (shapes are fixed per TrainStep)."""
+        """Copies one batch into the step's resident input buffers (shapes are fixed per TrainStep); in bf16-storage mode the
+        buffers are bf16 and fp32 inputs are rounded by the copy."""
         self.audio.copy_(audio, non_blocking=True)
         self.text.copy_(text, non_blocking=True)
         self.video.copy_(video, non_blocking=True)
@@ -415,7 +437,8 @@ class _StepArena:
         goff = lib.sdumc_step_grads_offset(C.byref(d))
         self.workspace[goff:goff + 4 * lay.live].zero_()
         n = [self.B * self.T[0] * dims[0], self.B * self.T[1] * dims[1], self.B * self.T[2] * dims[2], self.B * self.T[3] * dims[1]]
-        self.inputs = [torch.empty(k, device=dev) for k in n]
+        self.feature_dtype = torch.bfloat16 if d.bf16 == 2 else torch.float32
+        self.inputs = [torch.empty(k, device=dev, dtype=self.feature_dtype) for k in n]
         self.labels = torch.empty(self.B, device=dev)
         V = 2 * self.B
         self.outs = [torch.empty(V * k, device=dev) for k in (1, H, RNC_DIM, D, NQ * H)]

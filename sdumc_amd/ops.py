@@ -68,6 +68,38 @@ def gemm(layout, A, B, M, N, K, bias=None, C_out=None, lda=None, ldb=None, ldc=N
     return Cs if isinstance(A, (list, tuple)) else Cs[0]
 
 
+def gemm_bf16(layout, A, B, M, N, K, bias=None, C_out=None, lda=None, ldb=None, ldc=None, act=ACT_NONE, a_row_mod=0,
+              b_row_mod=0, accumulate=False, c_bf16=False, splitk=0, colsum_a=None):
+    """GEMM on bf16 storage (sdumc_gemm_bf16_run): A, B torch.bfloat16 device tensors (lists = grouped); C fp32 or bf16."""
+    As = A if isinstance(A, (list, tuple)) else [A]
+    Bs = B if isinstance(B, (list, tuple)) else [B]
+    groups = len(As)
+    dev = As[0].device
+    if C_out is None:
+        Cs = [torch.empty(M, N, device=dev, dtype=torch.bfloat16 if c_bf16 else torch.float32) for _ in range(groups)]
+    else:
+        Cs = C_out if isinstance(C_out, (list, tuple)) else [C_out]
+    biases = bias if isinstance(bias, (list, tuple)) else [bias] * groups
+    g = _lib.GemmBf16()
+    g.layout, g.M, g.N, g.K, g.groups = layout, M, N, K, groups
+    for i in range(groups):
+        g.A[i], g.B[i], g.C[i], g.bias[i] = ptr(As[i]), ptr(Bs[i]), ptr(Cs[i]), ptr(biases[i])
+    g.lda = lda if lda is not None else (K if layout == NT else M)
+    g.ldb = ldb if ldb is not None else (K if layout == NT else N)
+    g.ldc = ldc if ldc is not None else N
+    g.a_row_mod, g.b_row_mod = a_row_mod, b_row_mod
+    g.act, g.accumulate, g.c_bf16, g.splitk = act, 1 if accumulate else 0, 1 if c_bf16 else 0, splitk
+    if colsum_a is not None:
+        cs = colsum_a if isinstance(colsum_a, (list, tuple)) else [colsum_a]
+        for i in range(groups):
+            g.colsum_a[i] = ptr(cs[i])
+    need = lib.sdumc_gemm_bf16_workspace_bytes(C.byref(g))
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+    g.workspace, g.workspace_bytes = ptr(ws), need
+    check(lib.sdumc_gemm_bf16_run(C.byref(g), _st()), "sdumc_gemm_bf16_run")
+    return Cs if isinstance(A, (list, tuple)) else Cs[0]
+
+
 def attnpool_desc(x, keys, q, V, T, nq, x_samples, q_stride, x_drop, out_drop, attn, pooled, out, scale=0.3, dim=0,
                   lengths=None):
     a = _lib.AttnPool()

@@ -47,10 +47,11 @@ class HipBackend:
         self.B, self.B_global = B, B_global
         self.layout = engine.ParamLayout.get(dims[0], dims[1], dims[2])
         self.params = flat_params
-        self.audio = torch.empty(B, Ta, dims[0], device=dev)
-        self.text = torch.empty(B, Tt, dims[1], device=dev)
-        self.video = torch.empty(B, Tv, dims[2], device=dev)
-        self.feat4 = torch.empty(B, T4, dims[1], device=dev)
+        fdt = torch.bfloat16 if engine.bf16_mode(bf16, dims) == 2 else torch.float32     # bf16-storage mode holds bf16 features
+        self.audio = torch.empty(B, Ta, dims[0], device=dev, dtype=fdt)
+        self.text = torch.empty(B, Tt, dims[1], device=dev, dtype=fdt)
+        self.video = torch.empty(B, Tv, dims[2], device=dev, dtype=fdt)
+        self.feat4 = torch.empty(B, T4, dims[1], device=dev, dtype=fdt)
         self.labels = torch.empty(B, device=dev)
         st = share if share is not None else engine._RunState(flat_params, self.layout.live, lr, seed)
         if st.params.data_ptr() != flat_params.data_ptr():
