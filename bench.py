@@ -152,7 +152,7 @@ def roofline_leg(_lib, launch, steps, traffic_ok=True):
     top = rows[0]
     # the committed PMC summary was collected on the default workload in fp32: it describes no other configuration
     traffic, traffic_src = recorded_traffic(top["kernel"]) if traffic_ok else (None, None)
-    bf16_kernel = top["kernel"].startswith("gemm_bf16")
+    bf16_kernel = top["kernel"].startswith("gemm_bf16")      # bf16-operand (gemm_bf16_*) and bf16-storage (gemm_bf16s_*) kernels
     peak = PEAK_BF16_MFMA_TFLOPS if bf16_kernel else PEAK_F32_MFMA_TFLOPS
     return {"bound": "mfma", "achieved": round(top["tflops"], 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(top["tflops"] / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -397,8 +397,8 @@ def main():
         "metric": "train samples/sec at MOSEI feature shapes (two-stream forward + 6-term loss + backward + Adam)",
         "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True, "scaling": "weak",
-        "vs_baseline": None, "dtype": "bf16 operands / f32 accumulate in the frame-level projections (forward, dW, dX), f32 elsewhere" if args.bf16 else "f32", "data": "synthetic",
-        "config": {"workload": ("bf16-operand arithmetic (--bf16, the dtype of BASELINE configs[2]/[4]) on: " if args.bf16 else "") + WORKLOAD_TEXT,
+        "vs_baseline": None, "dtype": "bf16 storage of features / frames / keys / frame-level gradients with f32 accumulation; f32 softmax, utterance-level layers, losses and Adam (f32 master weights)" if args.bf16 else "f32", "data": "synthetic",
+        "config": {"workload": ("bf16 storage (--bf16, the dtype of BASELINE configs[2]/[4]) on: " if args.bf16 else "") + WORKLOAD_TEXT,
                    "batch_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU,
                    "T_audio_text_video_feat4": list(T_MOSEI), "feature_dims": list(DIMS),
                    "parallelism": f"dp{world}" if world > 1 else ("dp1 (one-rank RCCL communicator, all collectives issued)" if force_dp else "single"),

@@ -55,79 +55,101 @@ __device__ __forceinline__ DropRT mkdrop_rt(const DropRT& base, uint32_t site, u
 // layer's reduction, epilogue and barriers instead of at the head of the next one: the chain is a sequence of ~20 dependent
 // layers per stage and that head latency was half of its time.
 // ------------------------------------------------------------------------------------------------------------------
-template <int I, int O>
+// WT = float, or unsigned short for bf16 weights (the engine's bf16-storage mode streams bf16 copies of the utterance-level
+// weights: half the bytes of the stream this chain is bound by; accumulation stays fp32)
+template <int I, int O, class WT>
 struct RxmGeom {
-  static constexpr int OG = O / 4;                      // groups of 4 output columns
+  static constexpr int EPL = 16 / (int)sizeof(WT);      // weight elements (output columns) per lane per 16-byte load
+  static constexpr int QPL = EPL / 4;                   // f32x4 accumulators per lane per block
+  static constexpr int OG = O / EPL;                    // lane-groups of output columns
   static constexpr int OGW = OG >= 64 ? 64 : OG;        // lanes that cover one row of M
   static constexpr int S = 64 / OGW;                    // rows of M covered by one wave-load (1, 2 or 4)
-  static constexpr int NB = (OG + 63) / 64;             // 256-column blocks
+  static constexpr int NB = (OG + 63) / 64;             // column blocks of 64 lanes
+  static constexpr int BW = 64 * EPL;                   // columns per block
   static constexpr int WAVES = (I / (4 * S)) >= NWV ? NWV : (I / (4 * S));
   static constexpr int IW = I / WAVES;                  // rows of M per wave
   static constexpr int ITER = IW / (4 * S);
-  static constexpr int DEP = (ITER % 4 == 0 && NB == 1) ? 4 : ((ITER % 2 == 0) ? 2 : 1);
+  // ring depth: 4 for fp32 single-block layers; bf16 lanes carry two accumulator quads per row, so their ring stays 2 deep
+  // (deeper spilled at 14 rows)
+  static constexpr int DEP = (ITER % 4 == 0 && NB == 1 && EPL == 4) ? 4 : ((ITER % 2 == 0) ? 2 : 1);
   static_assert(I % (4 * S * WAVES) == 0 && ITER >= 1, "k range must split evenly");
+  static_assert(S <= 4 && O % EPL == 0, "at least 16 lane-groups of output columns");
 };
-template <int NB, int DEP>
+template <int NB>
 struct WRing {
-  f32x4 w[DEP][4][NB];
+  uint4 w[4][4][NB];          // raw 16-byte loads (4 fp32 or 8 bf16), expanded when they are multiplied; a layer uses the first
+                              // DEP (1, 2 or 4) slots, so that layers of different depth can hand one ring on to each other
 };
-template <int I, int O>
-using RingOf = WRing<RxmGeom<I, O>::NB, RxmGeom<I, O>::DEP>;
+template <int I, int O, class WT>
+using RingOf = WRing<RxmGeom<I, O, WT>::NB>;
 
-template <int I, int O, int NBv>
-__device__ __forceinline__ void rxm_load(f32x4 (&dst)[4][NBv], const float* mp, int j, int ldm, int cg) {
-  using G = RxmGeom<I, O>;
+template <int I, int O, class WT, int NBv>
+__device__ __forceinline__ void rxm_load(uint4 (&dst)[4][NBv], const WT* mp, int j, int ldm, int cg) {
+  using G = RxmGeom<I, O, WT>;
 #pragma unroll
   for (int e = 0; e < 4; ++e)
 #pragma unroll
     for (int b = 0; b < G::NB; ++b) {
-      if (b * 64 + cg < G::OG) dst[e][b] = ld4(mp + (size_t)(j * 4 * G::S + e) * ldm + b * 256);
-      else dst[e][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (b * 64 + cg < G::OG) dst[e][b] = *reinterpret_cast<const uint4*>(mp + (size_t)(j * 4 * G::S + e) * ldm + b * G::BW);
+      else dst[e][b] = uint4{0u, 0u, 0u, 0u};
     }
 }
 
-template <int I, int O>
-__device__ __forceinline__ void rxm_prefetch(RingOf<I, O>& ring, const float* __restrict__ M, int ldm) {
-  using G = RxmGeom<I, O>;
+template <int I, int O, class WT>
+__device__ __forceinline__ void rxm_prefetch(RingOf<I, O, WT>& ring, const void* __restrict__ Mv, int ldm) {
+  using G = RxmGeom<I, O, WT>;
   if constexpr (G::DEP > 1) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (wave < G::WAVES) {
       const int sq = lane / G::OGW, cg = lane % G::OGW;
-      const float* mp = M + (size_t)(wave * G::IW + 4 * sq) * ldm + 4 * cg;
+      const WT* mp = static_cast<const WT*>(Mv) + (size_t)(wave * G::IW + 4 * sq) * ldm + G::EPL * cg;
 #pragma unroll
-      for (int d = 0; d < G::DEP - 1; ++d) rxm_load<I, O, G::NB>(ring.w[d], mp, d, ldm, cg);
+      for (int d = 0; d < G::DEP - 1; ++d) rxm_load<I, O, WT, G::NB>(ring.w[d], mp, d, ldm, cg);
     }
   }
 }
 
-template <int ROWS, int I, int O, class Epi, class Hook>
-__device__ __forceinline__ void rxm_run(RingOf<I, O>& ring, const float* in_lds, int ld_in, const float* __restrict__ M, int ldm,
+template <int ROWS, int I, int O, class WT, class Epi, class Hook>
+__device__ __forceinline__ void rxm_run(RingOf<I, O, WT>& ring, const float* in_lds, int ld_in, const void* __restrict__ Mv, int ldm,
                                         float* part, Epi&& epi, Hook&& hook) {
-  using G = RxmGeom<I, O>;
+  using G = RxmGeom<I, O, WT>;
   constexpr int OG = G::OG, OGW = G::OGW, S = G::S, NB = G::NB, WAVES = G::WAVES, IW = G::IW, ITER = G::ITER, DEP = G::DEP;
+  constexpr int EPL = G::EPL, QPL = G::QPL, BW = G::BW;
   constexpr int RC = ROWS > 7 ? 7 : ROWS;        // rows per reduction round
   static_assert(NWV * RC * O <= PART_FLOATS, "partial-sum area too small");
   static_assert(ROWS % RC == 0, "rows per round");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int sq = lane / OGW, cg = lane % OGW;
 
-  f32x4 acc[ROWS][NB];
+  f32x4 acc[ROWS][NB][QPL];
 #pragma unroll
   for (int r = 0; r < ROWS; ++r)
 #pragma unroll
-    for (int b = 0; b < NB; ++b) acc[r][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+      for (int q = 0; q < QPL; ++q) acc[r][b][q] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   if (wave < WAVES) {
     const int i0 = wave * IW + 4 * sq;
-    const float* mp = M + (size_t)i0 * ldm + 4 * cg;
-    auto fma = [&](int j, const f32x4 (&ws)[4][NB]) {
+    const WT* mp = static_cast<const WT*>(Mv) + (size_t)i0 * ldm + EPL * cg;
+    auto fma = [&](int j, const uint4 (&ws)[4][NB]) {
 #pragma unroll
       for (int r = 0; r < ROWS; ++r) {
         const f32x4 x = ld4(in_lds + r * ld_in + i0 + j * 4 * S);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-          for (int b = 0; b < NB; ++b) acc[r][b] += ws[e][b] * x[e];
+          for (int b = 0; b < NB; ++b) {
+            const uint4 u = ws[e][b];
+            if constexpr (QPL == 1) {
+              acc[r][b][0] += f32x4{__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)} * x[e];
+            } else {        // 8 bf16: low halves are the even columns
+              acc[r][b][0] += f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                                    __uint_as_float(u.y & 0xffff0000u)} * x[e];
+              acc[r][b][1] += f32x4{__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16),
+                                    __uint_as_float(u.w & 0xffff0000u)} * x[e];
+            }
+          }
         // (keeps the scheduler from hoisting every row's LDS read of several iterations to the top: with 14 rows that
         // alone is 56 live registers per iteration in flight, and the kernel spilled)
         if ((r & 3) == 3) __builtin_amdgcn_sched_barrier(0);
@@ -137,7 +159,7 @@ __device__ __forceinline__ void rxm_run(RingOf<I, O>& ring, const float* in_lds,
     if constexpr (DEP == 1) {
 #pragma unroll
       for (int j = 0; j < ITER; ++j) {
-        rxm_load<I, O, G::NB>(ring.w[0], mp, j, ldm, cg);
+        rxm_load<I, O, WT, NB>(ring.w[0], mp, j, ldm, cg);
         fma(j, ring.w[0]);
       }
     } else {
@@ -147,7 +169,7 @@ __device__ __forceinline__ void rxm_run(RingOf<I, O>& ring, const float* in_lds,
         for (int d = 0; d < DEP; ++d) {
           const int j = jb + d;
           const int jn = j + DEP - 1 < ITER ? j + DEP - 1 : ITER - 1;     // past the end: a harmless re-load, no branch
-          rxm_load<I, O, G::NB>(ring.w[(d + DEP - 1) % DEP], mp, jn, ldm, cg);
+          rxm_load<I, O, WT, NB>(ring.w[(d + DEP - 1) % DEP], mp, jn, ldm, cg);
           fma(j, ring.w[d]);
         }
       }
@@ -158,10 +180,12 @@ __device__ __forceinline__ void rxm_run(RingOf<I, O>& ring, const float* in_lds,
 #pragma unroll
         for (int b = 0; b < NB; ++b)
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            acc[r][b][c] += __shfl_xor(acc[r][b][c], 32, 64);
-            if constexpr (S == 4) acc[r][b][c] += __shfl_xor(acc[r][b][c], 16, 64);
-          }
+          for (int q = 0; q < QPL; ++q)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              acc[r][b][q][c] += __shfl_xor(acc[r][b][q][c], 32, 64);
+              if constexpr (S == 4) acc[r][b][q][c] += __shfl_xor(acc[r][b][q][c], 16, 64);
+            }
     }
   }
   hook();        // the next layer's first weight rows start moving here
@@ -172,11 +196,14 @@ __device__ __forceinline__ void rxm_run(RingOf<I, O>& ring, const float* in_lds,
       for (int r = 0; r < RC; ++r)
 #pragma unroll
         for (int b = 0; b < NB; ++b)
-          if (b * 64 + cg < OG) st4(part + (wave * RC + r) * O + b * 256 + 4 * cg, acc[r0 + r][b]);
+          if (b * 64 + cg < OG) {
+#pragma unroll
+            for (int q = 0; q < QPL; ++q) st4(part + (wave * RC + r) * O + b * BW + EPL * cg + 4 * q, acc[r0 + r][b][q]);
+          }
     }
     __syncthreads();
-    for (int u = tid; u < RC * OG; u += NTHR) {
-      const int r = u / OG, cq = u - r * OG;
+    for (int u = tid; u < RC * (O / 4); u += NTHR) {
+      const int r = u / (O / 4), cq = u - r * (O / 4);
       f32x4 v = ld4(part + r * O + 4 * cq);
 #pragma unroll
       for (int ww = 1; ww < WAVES; ++ww) v += ld4(part + (ww * RC + r) * O + 4 * cq);
@@ -186,13 +213,13 @@ __device__ __forceinline__ void rxm_run(RingOf<I, O>& ring, const float* in_lds,
   }
 }
 
-// stand-alone form: prefetch + run, nothing chained behind it
+// stand-alone form (fp32 weights): prefetch + run, nothing chained behind it
 template <int ROWS, int I, int O, class Epi>
 __device__ __forceinline__ void rows_x_matrix(const float* in_lds, int ld_in, const float* __restrict__ M, int ldm, float* part,
                                               Epi&& epi) {
-  RingOf<I, O> ring;
-  rxm_prefetch<I, O>(ring, M, ldm);
-  rxm_run<ROWS, I, O>(ring, in_lds, ld_in, M, ldm, part, epi, [] {});
+  RingOf<I, O, float> ring;
+  rxm_prefetch<I, O, float>(ring, M, ldm);
+  rxm_run<ROWS, I, O, float>(ring, in_lds, ld_in, M, ldm, part, epi, [] {});
 }
 
 // y = drop(relu(v + bias)) -> LDS and HBM (forward layer epilogue)
@@ -252,7 +279,7 @@ namespace {
 // ------------------------------------------------------------------------------------------------------------------
 // stage A forward (model :293-332 + :85)
 // ------------------------------------------------------------------------------------------------------------------
-template <int R>
+template <int R, class WT>
 __global__ __launch_bounds__(NTHR) void chain_fwd_a_kernel(const sdumc_chain_args a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* part = sm;                              // PART_FLOATS
@@ -264,43 +291,50 @@ __global__ __launch_bounds__(NTHR) void chain_fwd_a_kernel(const sdumc_chain_arg
   float* s_alpha = s_att2 + R * D;               // [R][4]
   float* s_qin = s_alpha + R * 4;                // [7][R][256]
   float* s_q = s_qin + 7 * R * D;                // [R][7][256]
+  float* s_bias = s_q + 7 * R * D;               // [18][256]: every bias of the stage (an epilogue then waits on no global load)
   const int V = a.V, v0 = blockIdx.x * R, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t VD = (int64_t)V * D;
+  {
+    const float* bsrc[18] = {a.umlp0_b[0], a.umlp0_b[1], a.umlp0_b[2], a.umlp3_b[0], a.umlp3_b[1], a.umlp3_b[2], a.att0_b, a.att3_b,
+                             a.query_b[0], a.query_b[1], a.query_b[2], a.query_b[3], a.query_b[4], a.query_b[5], a.query_b[6],
+                             a.caq_b[0], a.caq_b[1], a.caq_b[2]};
+    for (int u = tid; u < 18 * (D / 4); u += NTHR) st4(s_bias + 4 * u, ld4(bsrc[u / (D / 4)] + 4 * (u % (D / 4))));
+  }
 
   const DropRT dbase = drop_resolve(a.drop);
-  RingOf<D, D> ring;          // every layer of this stage streams through the same ring type (NB = 1, 4 deep)
-  rxm_prefetch<D, D>(ring, a.umlp0_w[0], D);
+  RingOf<D, D, WT> ring;          // every layer of this stage streams through the same ring type (NB = 1, 4 deep)
+  rxm_prefetch<D, D, WT>(ring, a.umlp0_w[0], D);
   for (int m = 0; m < 3; ++m) load_rows<R>(s_hpre + m * R * D, a.hpre + m * VD, D, D, v0, V);
   __syncthreads();
   // audio / text / video_mlp (model :293-295)
 #pragma unroll 1
   for (int m = 0; m < 3; ++m) {
-    FwdEpi e{a.umlp0_b[m], s_u1 + m * R * D, D, a.u1 + m * VD + (int64_t)v0 * D, D, true,
+    FwdEpi e{s_bias + m * D, s_u1 + m * R * D, D, a.u1 + m * VD + (int64_t)v0 * D, D, true,
              mkdrop_rt(dbase, 6 + 2 * m, 1, D), (uint32_t)v0, 1u};
     auto epi = [&](int r, int col, f32x4 v) { if (v0 + r < V) e(r, col, v); };
-    rxm_run<R, D, D>(ring, s_hpre + m * R * D, D, a.umlp0_w[m], D, part, epi,
-                     [&] { rxm_prefetch<D, D>(ring, m < 2 ? a.umlp0_w[m + 1] : a.umlp3_w[0], D); });
+    rxm_run<R, D, D, WT>(ring, s_hpre + m * R * D, D, a.umlp0_w[m], D, part, epi,
+                     [&] { rxm_prefetch<D, D, WT>(ring, m < 2 ? a.umlp0_w[m + 1] : a.umlp3_w[0], D); });
   }
 #pragma unroll 1
   for (int m = 0; m < 3; ++m) {
-    FwdEpi e{a.umlp3_b[m], s_u + m * D, 3 * D, a.u + (int64_t)v0 * 3 * D + m * D, 3 * D, true,
+    FwdEpi e{s_bias + (3 + m) * D, s_u + m * D, 3 * D, a.u + (int64_t)v0 * 3 * D + m * D, 3 * D, true,
              mkdrop_rt(dbase, 7 + 2 * m, 1, D), (uint32_t)v0, 1u};
     auto epi = [&](int r, int col, f32x4 v) { if (v0 + r < V) e(r, col, v); else st4(s_u + r * 3 * D + m * D + col, f32x4{0.f, 0.f, 0.f, 0.f}); };
-    rxm_run<R, D, D>(ring, s_u1 + m * R * D, D, a.umlp3_w[m], D, part, epi, [&] {
-      if (m < 2) rxm_prefetch<D, D>(ring, a.umlp3_w[m + 1], D);
-      else rxm_prefetch<3 * D, D>(ring, a.att0_w, D);
+    rxm_run<R, D, D, WT>(ring, s_u1 + m * R * D, D, a.umlp3_w[m], D, part, epi, [&] {
+      if (m < 2) rxm_prefetch<D, D, WT>(ring, a.umlp3_w[m + 1], D);
+      else rxm_prefetch<3 * D, D, WT>(ring, a.att0_w, D);
     });
   }
   // attention_mlp + fc_att (model :301-303)
   {
-    FwdEpi e{a.att0_b, s_att1, D, a.att1 + (int64_t)v0 * D, D, true, mkdrop_rt(dbase, 12, 1, D), (uint32_t)v0, 1u};
+    FwdEpi e{s_bias + 6 * D, s_att1, D, a.att1 + (int64_t)v0 * D, D, true, mkdrop_rt(dbase, 12, 1, D), (uint32_t)v0, 1u};
     auto epi = [&](int r, int col, f32x4 v) { if (v0 + r < V) e(r, col, v); else st4(s_att1 + r * D + col, f32x4{0.f, 0.f, 0.f, 0.f}); };
-    rxm_run<R, 3 * D, D>(ring, s_u, 3 * D, a.att0_w, D, part, epi, [&] { rxm_prefetch<D, D>(ring, a.att3_w, D); });
+    rxm_run<R, 3 * D, D, WT>(ring, s_u, 3 * D, a.att0_w, D, part, epi, [&] { rxm_prefetch<D, D, WT>(ring, a.att3_w, D); });
   }
   {
-    FwdEpi e{a.att3_b, s_att2, D, a.att2 + (int64_t)v0 * D, D, true, mkdrop_rt(dbase, 13, 1, D), (uint32_t)v0, 1u};
+    FwdEpi e{s_bias + 7 * D, s_att2, D, a.att2 + (int64_t)v0 * D, D, true, mkdrop_rt(dbase, 13, 1, D), (uint32_t)v0, 1u};
     auto epi = [&](int r, int col, f32x4 v) { if (v0 + r < V) e(r, col, v); else st4(s_att2 + r * D + col, f32x4{0.f, 0.f, 0.f, 0.f}); };
-    rxm_run<R, D, D>(ring, s_att1, D, a.att3_w, D, part, epi, [&] { rxm_prefetch<D, D>(ring, a.query_w[0], D); });
+    rxm_run<R, D, D, WT>(ring, s_att1, D, a.att3_w, D, part, epi, [&] { rxm_prefetch<D, D, WT>(ring, a.query_w[0], D); });
   }
   for (int p = wave; p < 3 * R; p += NWV) {          // alpha[r][j] = att2[r] . W[j] + b[j]
     const int r = p / 3, j = p - 3 * r;
@@ -328,7 +362,7 @@ __global__ __launch_bounds__(NTHR) void chain_fwd_a_kernel(const sdumc_chain_arg
   // the 7 query MLPs -> multi_query [V, 7, 256] (model :324-332); text_hidden = query 5 (model :329, :370)
 #pragma unroll 1
   for (int i = 0; i < 7; ++i) {
-    FwdEpi e{a.query_b[i], s_q + i * D, NQ * D, a.q + (int64_t)v0 * NQ * D + i * D, (int64_t)NQ * D, true,
+    FwdEpi e{s_bias + (8 + i) * D, s_q + i * D, NQ * D, a.q + (int64_t)v0 * NQ * D + i * D, (int64_t)NQ * D, true,
              mkdrop_rt(dbase, 14 + i, 1, D), (uint32_t)v0, 1u};
     float* th = (i == 5 && a.o_text_hidden) ? a.o_text_hidden + (int64_t)v0 * D : nullptr;
     auto epi = [&](int r, int col, f32x4 v) {
@@ -339,22 +373,22 @@ __global__ __launch_bounds__(NTHR) void chain_fwd_a_kernel(const sdumc_chain_arg
         st4(s_q + r * NQ * D + i * D + col, f32x4{0.f, 0.f, 0.f, 0.f});
       }
     };
-    rxm_run<R, D, D>(ring, s_qin + i * R * D, D, a.query_w[i], D, part, epi,
-                     [&] { rxm_prefetch<D, D>(ring, i < 6 ? a.query_w[i + 1] : a.caq_w[0], D); });
+    rxm_run<R, D, D, WT>(ring, s_qin + i * R * D, D, a.query_w[i], D, part, epi,
+                     [&] { rxm_prefetch<D, D, WT>(ring, i < 6 ? a.query_w[i + 1] : a.caq_w[0], D); });
   }
   // query_proj of the three Cross_Attention blocks (model :85): rows = (sample, query)
 #pragma unroll 1
   for (int m = 0; m < 3; ++m) {
-    FwdEpi e{a.caq_b[m], nullptr, 0, a.qp + ((int64_t)m * V + v0) * NQ * D, D, false, DropRT{}, 0u, 0u};
+    FwdEpi e{s_bias + (15 + m) * D, nullptr, 0, a.qp + ((int64_t)m * V + v0) * NQ * D, D, false, DropRT{}, 0u, 0u};
     auto epi = [&](int r, int col, f32x4 v) { if (v0 + r / NQ < V) e(r, col, v); };
-    rxm_run<NQ * R, D, D>(ring, s_q, D, a.caq_w[m], D, part, epi, [&] { if (m < 2) rxm_prefetch<D, D>(ring, a.caq_w[m + 1], D); });
+    rxm_run<NQ * R, D, D, WT>(ring, s_q, D, a.caq_w[m], D, part, epi, [&] { if (m < 2) rxm_prefetch<D, D, WT>(ring, a.caq_w[m + 1], D); });
   }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // stage B forward (model :338-368)
 // ------------------------------------------------------------------------------------------------------------------
-template <int R>
+template <int R, class WT>
 __global__ __launch_bounds__(NTHR) void chain_fwd_b_kernel(const sdumc_chain_args a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* part = sm;
@@ -367,12 +401,23 @@ __global__ __launch_bounds__(NTHR) void chain_fwd_b_kernel(const sdumc_chain_arg
   float* s_z = s_e2 + R * H;                     // [R][128]
   float* s_r1 = s_z + R * H;                     // [R][64]
   float* s_small = s_r1 + R * RD;                // alpha [R][4], beta [R][8]
+  float* s_bias = s_small + 12 * R;              // cmlp0 [3][256], cmlp3 [3][128], catt0 [256], catt3 [128], rnc0 [64], rnc2 [64]
   const int V = a.V, v0 = blockIdx.x * R, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t VQ = (int64_t)V * NQ;
+  {
+    for (int u = tid; u < 3 * (D / 4); u += NTHR) st4(s_bias + 4 * u, ld4(a.cmlp0_b[u / (D / 4)] + 4 * (u % (D / 4))));
+    for (int u = tid; u < 3 * (H / 4); u += NTHR) st4(s_bias + 3 * D + 4 * u, ld4(a.cmlp3_b[u / (H / 4)] + 4 * (u % (H / 4))));
+    for (int u = tid; u < D / 4; u += NTHR) st4(s_bias + 3 * D + 3 * H + 4 * u, ld4(a.catt0_b + 4 * u));
+    for (int u = tid; u < H / 4; u += NTHR) st4(s_bias + 4 * D + 3 * H + 4 * u, ld4(a.catt3_b + 4 * u));
+    for (int u = tid; u < RD / 4; u += NTHR) {
+      st4(s_bias + 4 * D + 4 * H + 4 * u, ld4(a.rnc0_b + 4 * u));
+      st4(s_bias + 4 * D + 4 * H + RD + 4 * u, ld4(a.rnc2_b + 4 * u));
+    }
+  }
 
   const DropRT dbase = drop_resolve(a.drop);
-  RingOf<D, D> ring;
-  rxm_prefetch<D, D>(ring, a.cmlp0_w[0], D);
+  RingOf<D, D, WT> ring;
+  rxm_prefetch<D, D, WT>(ring, a.cmlp0_w[0], D);
   for (int u = tid; u < R * 3; u += NTHR) {
     const int r = u / 3, j = u - 3 * r;
     s_small[r * 4 + j] = v0 + r < V ? a.alpha[(int64_t)(v0 + r) * 3 + j] : 0.f;
@@ -384,13 +429,13 @@ __global__ __launch_bounds__(NTHR) void chain_fwd_b_kernel(const sdumc_chain_arg
     load_rows<NQ * R>(s_x, a.ca_out + (int64_t)m * VQ * D, D, D, v0 * NQ, V * NQ);
     __syncthreads();
     {
-      FwdEpi e{a.cmlp0_b[m], s_c1, D, a.c1 + ((int64_t)m * VQ + (int64_t)v0 * NQ) * D, D, true,
+      FwdEpi e{s_bias + m * D, s_c1, D, a.c1 + ((int64_t)m * VQ + (int64_t)v0 * NQ) * D, D, true,
                mkdrop_rt(dbase, 27 + 2 * m, NQ, D), (uint32_t)(v0 * NQ), 1u};
       auto epi = [&](int r, int col, f32x4 v) { if (v0 * NQ + r < V * NQ) e(r, col, v); else st4(s_c1 + r * D + col, f32x4{0.f, 0.f, 0.f, 0.f}); };
-      rxm_run<NQ * R, D, D>(ring, s_x, D, a.cmlp0_w[m], D, part, epi, [&] { rxm_prefetch<D, H>(ring, a.cmlp3_w[m], H); });
+      rxm_run<NQ * R, D, D, WT>(ring, s_x, D, a.cmlp0_w[m], D, part, epi, [&] { rxm_prefetch<D, H, WT>(ring, a.cmlp3_w[m], H); });
     }
     {
-      FwdEpi e{a.cmlp3_b[m], s_c + m * NQ * R * H, H, a.c + ((int64_t)m * VQ + (int64_t)v0 * NQ) * H, H, true,
+      FwdEpi e{s_bias + 3 * D + m * H, s_c + m * NQ * R * H, H, a.c + ((int64_t)m * VQ + (int64_t)v0 * NQ) * H, H, true,
                mkdrop_rt(dbase, 28 + 2 * m, NQ, H), (uint32_t)(v0 * NQ), 1u};
       float* ct = (m == 1 && a.o_cross_text) ? a.o_cross_text + (int64_t)v0 * NQ * H : nullptr;
       auto epi = [&](int r, int col, f32x4 v) {
@@ -401,9 +446,9 @@ __global__ __launch_bounds__(NTHR) void chain_fwd_b_kernel(const sdumc_chain_arg
           st4(s_c + (m * NQ * R + r) * H + col, f32x4{0.f, 0.f, 0.f, 0.f});
         }
       };
-      rxm_run<NQ * R, D, H>(ring, s_c1, D, a.cmlp3_w[m], H, part, epi, [&] {
-        if (m < 2) rxm_prefetch<D, D>(ring, a.cmlp0_w[m + 1], D);
-        else rxm_prefetch<NQ * H, D>(ring, a.catt0_w, D);
+      rxm_run<NQ * R, D, H, WT>(ring, s_c1, D, a.cmlp3_w[m], H, part, epi, [&] {
+        if (m < 2) rxm_prefetch<D, D, WT>(ring, a.cmlp0_w[m + 1], D);
+        else rxm_prefetch<NQ * H, D, WT>(ring, a.catt0_w, D);
       });
     }
   }
@@ -418,14 +463,14 @@ __global__ __launch_bounds__(NTHR) void chain_fwd_b_kernel(const sdumc_chain_arg
   __syncthreads();
   // cross_attention_mlp + cross_fc_att (model :352-354)
   {
-    FwdEpi e{a.catt0_b, s_e1, D, a.e1 + (int64_t)v0 * D, D, true, mkdrop_rt(dbase, 33, 1, D), (uint32_t)v0, 1u};
+    FwdEpi e{s_bias + 3 * D + 3 * H, s_e1, D, a.e1 + (int64_t)v0 * D, D, true, mkdrop_rt(dbase, 33, 1, D), (uint32_t)v0, 1u};
     auto epi = [&](int r, int col, f32x4 v) { if (v0 + r < V) e(r, col, v); else st4(s_e1 + r * D + col, f32x4{0.f, 0.f, 0.f, 0.f}); };
-    rxm_run<R, NQ * H, D>(ring, s_h, NQ * H, a.catt0_w, D, part, epi, [&] { rxm_prefetch<D, H>(ring, a.catt3_w, H); });
+    rxm_run<R, NQ * H, D, WT>(ring, s_h, NQ * H, a.catt0_w, D, part, epi, [&] { rxm_prefetch<D, H, WT>(ring, a.catt3_w, H); });
   }
   {
-    FwdEpi e{a.catt3_b, s_e2, H, a.e2 + (int64_t)v0 * H, H, true, mkdrop_rt(dbase, 34, 1, H), (uint32_t)v0, 1u};
+    FwdEpi e{s_bias + 4 * D + 3 * H, s_e2, H, a.e2 + (int64_t)v0 * H, H, true, mkdrop_rt(dbase, 34, 1, H), (uint32_t)v0, 1u};
     auto epi = [&](int r, int col, f32x4 v) { if (v0 + r < V) e(r, col, v); else st4(s_e2 + r * H + col, f32x4{0.f, 0.f, 0.f, 0.f}); };
-    rxm_run<R, D, H>(ring, s_e1, D, a.catt3_w, H, part, epi, [] {});
+    rxm_run<R, D, H, WT>(ring, s_e1, D, a.catt3_w, H, part, epi, [] {});
   }
   for (int p = wave; p < NQ * R; p += NWV) {          // beta[r][i] = e2[r] . W[i] + b[i]
     const int r = p / NQ, i = p - NQ * r;
@@ -462,14 +507,14 @@ __global__ __launch_bounds__(NTHR) void chain_fwd_b_kernel(const sdumc_chain_arg
   }
   // orgin_linear_change (model :246-250, :368): Linear -> ReLU -> Linear
   {
-    FwdEpi e{a.rnc0_b, s_r1, RD, a.r1 + (int64_t)v0 * RD, RD, true, DropRT{}, 0u, 0u};
+    FwdEpi e{s_bias + 4 * D + 4 * H, s_r1, RD, a.r1 + (int64_t)v0 * RD, RD, true, DropRT{}, 0u, 0u};
     auto epi = [&](int r, int col, f32x4 v) { if (v0 + r < V) e(r, col, v); else st4(s_r1 + r * RD + col, f32x4{0.f, 0.f, 0.f, 0.f}); };
     rows_x_matrix<R, H, RD>(s_z, H, a.rnc0_w, RD, part, epi);
   }
   {
-    FwdEpi e{a.rnc2_b, nullptr, 0, a.r + (int64_t)v0 * RD, RD, false, DropRT{}, 0u, 0u};
+    FwdEpi e{s_bias + 4 * D + 4 * H + RD, nullptr, 0, a.r + (int64_t)v0 * RD, RD, false, DropRT{}, 0u, 0u};
     float* ro = a.o_rnc ? a.o_rnc + (int64_t)v0 * RD : nullptr;
-    const float* b2 = a.rnc2_b;
+    const float* b2 = s_bias + 4 * D + 4 * H + RD;
     auto epi = [&](int r, int col, f32x4 v) {
       if (v0 + r < V) {
         e(r, col, v);
@@ -484,7 +529,7 @@ __global__ __launch_bounds__(NTHR) void chain_fwd_b_kernel(const sdumc_chain_arg
 // stage B backward: d(vals, fused, rnc, cross_text) -> d_ca_out [3][V,7,256], d_alpha (second-level part), and every
 // pre-activation gradient the dW GEMMs need (d_rnc is the caller's; d_r1, d_z, d_beta, d_e2, d_e1, d_c, d_c1)
 // ------------------------------------------------------------------------------------------------------------------
-template <int R>
+template <int R, class WT>
 __global__ __launch_bounds__(NTHR) void chain_bwd_b_kernel(const sdumc_chain_args a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* part = sm;
@@ -506,9 +551,9 @@ __global__ __launch_bounds__(NTHR) void chain_bwd_b_kernel(const sdumc_chain_arg
   float* s_alpha = s_small + 16 * R;
   float* s_dvals = s_small + 20 * R;
 
-  RingOf<H, D> ring;           // catt3 / cmlp3 / cmlp0 backward: NB = 1, 4 deep
-  RingOf<D, NQ * H> ring4;     // catt0 backward: 896 output columns = 4 blocks, 2 deep
-  rxm_prefetch<H, D>(ring, a.catt3_w, D);
+  RingOf<H, D, WT> ring;           // catt3 / cmlp3 / cmlp0 backward: NB = 1, 4 deep
+  RingOf<D, NQ * H, WT> ring4;     // catt0 backward: 896 output columns = 4 blocks, 2 deep
+  rxm_prefetch<H, D, WT>(ring, a.catt3_w, D);
   if (a.g_rnc) load_rows<R>(s_g, a.g_rnc, RD, RD, v0, V);
   else for (int u = tid; u < R * RD; u += NTHR) s_g[u] = 0.f;
   load_rows<R>(s_r1, a.r1, RD, RD, v0, V);
@@ -573,12 +618,12 @@ __global__ __launch_bounds__(NTHR) void chain_bwd_b_kernel(const sdumc_chain_arg
   {
     BwdEpi e{nullptr, 0, s_e1, D, sc, s_e1, D, a.d_e1 + (int64_t)v0 * D, D};
     auto epi = [&](int r, int col, f32x4 v) { if (v0 + r < V) e(r, col, v); else st4(s_e1 + r * D + col, f32x4{0.f, 0.f, 0.f, 0.f}); };
-    rxm_run<R, H, D>(ring, s_dz, H, a.catt3_w, D, part, epi, [&] { rxm_prefetch<D, NQ * H>(ring4, a.catt0_w, NQ * H); });
+    rxm_run<R, H, D, WT>(ring, s_dz, H, a.catt3_w, D, part, epi, [&] { rxm_prefetch<D, NQ * H, WT>(ring4, a.catt0_w, NQ * H); });
   }
   {
     BwdEpi e{s_dh, NQ * H, nullptr, 0, 1.f, s_dh, NQ * H, nullptr, 0};
     auto epi = [&](int r, int col, f32x4 v) { e(r, col, v); };
-    rxm_run<R, D, NQ * H>(ring4, s_e1, D, a.catt0_w, NQ * H, part, epi, [&] { rxm_prefetch<H, D>(ring, a.cmlp3_w[0], D); });
+    rxm_run<R, D, NQ * H, WT>(ring4, s_e1, D, a.catt0_w, NQ * H, part, epi, [&] { rxm_prefetch<H, D, WT>(ring, a.cmlp3_w[0], D); });
   }
   // 10'. modality-weighted sum backward, then 9'. cross_*_mlp, one modality at a time
 #pragma unroll 1
@@ -610,12 +655,12 @@ __global__ __launch_bounds__(NTHR) void chain_bwd_b_kernel(const sdumc_chain_arg
     {
       BwdEpi e{nullptr, 0, s_c1, D, sc, s_c1, D, a.d_c1 + ((int64_t)m * VQ + (int64_t)v0 * NQ) * D, D};
       auto epi = [&](int r, int col, f32x4 v) { if (v0 * NQ + r < V * NQ) e(r, col, v); else st4(s_c1 + r * D + col, f32x4{0.f, 0.f, 0.f, 0.f}); };
-      rxm_run<NQ * R, H, D>(ring, s_dc, H, a.cmlp3_w[m], D, part, epi, [&] { rxm_prefetch<D, D>(ring, a.cmlp0_w[m], D); });
+      rxm_run<NQ * R, H, D, WT>(ring, s_dc, H, a.cmlp3_w[m], D, part, epi, [&] { rxm_prefetch<D, D, WT>(ring, a.cmlp0_w[m], D); });
     }
     {
       BwdEpi e{nullptr, 0, nullptr, 0, 1.f, nullptr, 0, a.d_ca_out + ((int64_t)m * VQ + (int64_t)v0 * NQ) * D, D};
       auto epi = [&](int r, int col, f32x4 v) { if (v0 * NQ + r < V * NQ) e(r, col, v); };
-      rxm_run<NQ * R, D, D>(ring, s_c1, D, a.cmlp0_w[m], D, part, epi, [&] { if (m < 2) rxm_prefetch<H, D>(ring, a.cmlp3_w[m + 1], D); });
+      rxm_run<NQ * R, D, D, WT>(ring, s_c1, D, a.cmlp0_w[m], D, part, epi, [&] { if (m < 2) rxm_prefetch<H, D, WT>(ring, a.cmlp3_w[m + 1], D); });
     }
   }
 }
@@ -624,7 +669,7 @@ __global__ __launch_bounds__(NTHR) void chain_bwd_b_kernel(const sdumc_chain_arg
 // stage A backward: d_qp [3][V,7,256] (+ d text_hidden, + d_alpha from stage B) -> d_hpre [3][V,256] and the
 // pre-activation gradients d_q, d_qin (as d of the query MLP inputs), d_att2, d_att1, d_u, d_u1
 // ------------------------------------------------------------------------------------------------------------------
-template <int R>
+template <int R, class WT>
 __global__ __launch_bounds__(NTHR) void chain_bwd_a_kernel(const sdumc_chain_args a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* part = sm;
@@ -643,9 +688,9 @@ __global__ __launch_bounds__(NTHR) void chain_bwd_a_kernel(const sdumc_chain_arg
   float* s_alpha = s_small;
   float* s_dalpha = s_small + 4 * R;
 
-  RingOf<D, D> ring;
-  RingOf<D, 3 * D> ring3;      // att0 backward: 768 output columns = 3 blocks, 2 deep
-  rxm_prefetch<D, D>(ring, a.caq_w[0], D);
+  RingOf<D, D, WT> ring;
+  RingOf<D, 3 * D, WT> ring3;      // att0 backward: 768 output columns = 3 blocks, 2 deep
+  rxm_prefetch<D, D, WT>(ring, a.caq_w[0], D);
   load_rows<R>(s_u, a.u, 3 * D, 3 * D, v0, V);
   load_rows<R>(s_a2, a.att2, D, D, v0, V);
   load_rows<R>(s_a1, a.att1, D, D, v0, V);
@@ -663,8 +708,8 @@ __global__ __launch_bounds__(NTHR) void chain_bwd_a_kernel(const sdumc_chain_arg
     __syncthreads();
     BwdEpi e{m > 0 ? s_dq : nullptr, D, nullptr, 0, 1.f, s_dq, D, nullptr, 0};
     auto epi = [&](int r, int col, f32x4 v) { e(r, col, v); };
-    rxm_run<NQ * R, D, D>(ring, s_x, D, a.caq_w[m], D, part, epi,
-                          [&] { rxm_prefetch<D, D>(ring, m < 2 ? a.caq_w[m + 1] : a.query_w[0], D); });
+    rxm_run<NQ * R, D, D, WT>(ring, s_x, D, a.caq_w[m], D, part, epi,
+                          [&] { rxm_prefetch<D, D, WT>(ring, m < 2 ? a.caq_w[m + 1] : a.query_w[0], D); });
   }
   // 6'. + the external gradient of text_hidden (= query 5), ReLU/dropout mask of q -> d_q (pre-activation); query MLPs
   for (int u = tid; u < R * NQ * (D / 4); u += NTHR) {
@@ -684,8 +729,8 @@ __global__ __launch_bounds__(NTHR) void chain_bwd_a_kernel(const sdumc_chain_arg
   for (int i = 0; i < 7; ++i) {
     BwdEpi e{nullptr, 0, nullptr, 0, 1.f, s_dqin + i * R * D, D, a.d_qin + i * VD + (int64_t)v0 * D, D};
     auto epi = [&](int r, int col, f32x4 v) { if (v0 + r < V) e(r, col, v); else st4(s_dqin + (i * R + r) * D + col, f32x4{0.f, 0.f, 0.f, 0.f}); };
-    rxm_run<R, D, D>(ring, s_dq + i * D, NQ * D, a.query_w[i], D, part, epi,
-                     [&] { rxm_prefetch<D, D>(ring, i < 6 ? a.query_w[i + 1] : a.att3_w, D); });
+    rxm_run<R, D, D, WT>(ring, s_dq + i * D, NQ * D, a.query_w[i], D, part, epi,
+                     [&] { rxm_prefetch<D, D, WT>(ring, i < 6 ? a.query_w[i + 1] : a.att3_w, D); });
   }
   // 5'. fusion algebra backward: d_u (fusion part), d_alpha += <g_m, u_m>
   for (int u = tid; u < R * (D / 4); u += NTHR) {
@@ -728,12 +773,12 @@ __global__ __launch_bounds__(NTHR) void chain_bwd_a_kernel(const sdumc_chain_arg
   {
     BwdEpi e{nullptr, 0, s_a1, D, sc, s_a1, D, a.d_att1 + (int64_t)v0 * D, D};
     auto epi = [&](int r, int col, f32x4 v) { if (v0 + r < V) e(r, col, v); else st4(s_a1 + r * D + col, f32x4{0.f, 0.f, 0.f, 0.f}); };
-    rxm_run<R, D, D>(ring, s_a2, D, a.att3_w, D, part, epi, [&] { rxm_prefetch<D, 3 * D>(ring3, a.att0_w, 3 * D); });
+    rxm_run<R, D, D, WT>(ring, s_a2, D, a.att3_w, D, part, epi, [&] { rxm_prefetch<D, 3 * D, WT>(ring3, a.att0_w, 3 * D); });
   }
   {
     BwdEpi e{s_du, 3 * D, s_u, 3 * D, sc, s_du, 3 * D, a.d_u + (int64_t)v0 * 3 * D, 3 * D};
     auto epi = [&](int r, int col, f32x4 v) { if (v0 + r < V) e(r, col, v); else st4(s_du + r * 3 * D + col, f32x4{0.f, 0.f, 0.f, 0.f}); };
-    rxm_run<R, D, 3 * D>(ring3, s_a1, D, a.att0_w, 3 * D, part, epi, [&] { rxm_prefetch<D, D>(ring, a.umlp3_w[0], D); });
+    rxm_run<R, D, 3 * D, WT>(ring3, s_a1, D, a.att0_w, 3 * D, part, epi, [&] { rxm_prefetch<D, D, WT>(ring, a.umlp3_w[0], D); });
   }
   // 3'. audio / text / video_mlp: d_u1 = (d_u_m W3) [u1 > 0] s ; d_hpre = d_u1 W0
 #pragma unroll 1
@@ -741,12 +786,12 @@ __global__ __launch_bounds__(NTHR) void chain_bwd_a_kernel(const sdumc_chain_arg
     {
       BwdEpi e{nullptr, 0, s_u1 + m * R * D, D, sc, s_u1 + m * R * D, D, a.d_u1 + m * VD + (int64_t)v0 * D, D};
       auto epi = [&](int r, int col, f32x4 v) { if (v0 + r < V) e(r, col, v); else st4(s_u1 + (m * R + r) * D + col, f32x4{0.f, 0.f, 0.f, 0.f}); };
-      rxm_run<R, D, D>(ring, s_du + m * D, 3 * D, a.umlp3_w[m], D, part, epi, [&] { rxm_prefetch<D, D>(ring, a.umlp0_w[m], D); });
+      rxm_run<R, D, D, WT>(ring, s_du + m * D, 3 * D, a.umlp3_w[m], D, part, epi, [&] { rxm_prefetch<D, D, WT>(ring, a.umlp0_w[m], D); });
     }
     {
       BwdEpi e{nullptr, 0, nullptr, 0, 1.f, nullptr, 0, a.d_hpre + m * VD + (int64_t)v0 * D, D};
       auto epi = [&](int r, int col, f32x4 v) { if (v0 + r < V) e(r, col, v); };
-      rxm_run<R, D, D>(ring, s_u1 + m * R * D, D, a.umlp0_w[m], D, part, epi, [&] { if (m < 2) rxm_prefetch<D, D>(ring, a.umlp3_w[m + 1], D); });
+      rxm_run<R, D, D, WT>(ring, s_u1 + m * R * D, D, a.umlp0_w[m], D, part, epi, [&] { if (m < 2) rxm_prefetch<D, D, WT>(ring, a.umlp3_w[m + 1], D); });
     }
   }
 }
@@ -769,8 +814,8 @@ __global__ __launch_bounds__(256) void transpose_params_kernel(const float* __re
     if (i0 + k < e.in && o0 + tx < e.out) dst[e.off + (int64_t)(i0 + k) * e.out + o0 + tx] = t[tx][k];
 }
 
-template <int R> constexpr size_t smem_fwd_a() { return sizeof(float) * (PART_FLOATS + 3 * R * D * 3 + 2 * R * D + 4 * R + 14 * R * D); }
-template <int R> constexpr size_t smem_fwd_b() { return sizeof(float) * (PART_FLOATS + 2 * NQ * R * D + 3 * NQ * R * H + R * NQ * H + R * D + 2 * R * H + R * RD + 12 * R); }
+template <int R> constexpr size_t smem_fwd_a() { return sizeof(float) * (PART_FLOATS + 3 * R * D * 3 + 2 * R * D + 4 * R + 14 * R * D + 18 * D); }
+template <int R> constexpr size_t smem_fwd_b() { return sizeof(float) * (PART_FLOATS + 2 * NQ * R * D + 3 * NQ * R * H + R * NQ * H + R * D + 2 * R * H + R * RD + 12 * R + 4 * D + 4 * H + 2 * RD); }
 template <int R> constexpr size_t smem_bwd_b() { return sizeof(float) * (PART_FLOATS + 2 * R * RD + R * H + 2 * R * NQ * H + R * H + R * D + NQ * R * H + NQ * R * D + 24 * R); }
 template <int R> constexpr size_t smem_bwd_a() { return sizeof(float) * (PART_FLOATS + 3 * NQ * R * D + 6 * R * D + 2 * R * D + 3 * R * D + 8 * R); }
 
@@ -786,20 +831,32 @@ int set_smem(K kernel, size_t bytes) {
 extern "C" int sdumc_chain_launch_(const sdumc_chain_args* a, int which, void* stream) {
   if (!a || a->V <= 0 || which < 0 || which > 3) return SDUMC_EINVAL;
   constexpr int R = 2;
+  typedef unsigned short bf;
   static bool attr = false;
   if (!attr) {
-    if (set_smem(chain_fwd_a_kernel<R>, smem_fwd_a<R>()) || set_smem(chain_fwd_b_kernel<R>, smem_fwd_b<R>()) ||
-        set_smem(chain_bwd_b_kernel<R>, smem_bwd_b<R>()) || set_smem(chain_bwd_a_kernel<R>, smem_bwd_a<R>()))
+    if (set_smem(chain_fwd_a_kernel<R, float>, smem_fwd_a<R>()) || set_smem(chain_fwd_b_kernel<R, float>, smem_fwd_b<R>()) ||
+        set_smem(chain_bwd_b_kernel<R, float>, smem_bwd_b<R>()) || set_smem(chain_bwd_a_kernel<R, float>, smem_bwd_a<R>()) ||
+        set_smem(chain_fwd_a_kernel<R, bf>, smem_fwd_a<R>()) || set_smem(chain_fwd_b_kernel<R, bf>, smem_fwd_b<R>()) ||
+        set_smem(chain_bwd_b_kernel<R, bf>, smem_bwd_b<R>()) || set_smem(chain_bwd_a_kernel<R, bf>, smem_bwd_a<R>()))
       return SDUMC_ELAUNCH;
     attr = true;
   }
   const dim3 grid((a->V + R - 1) / R), blk(NTHR);
   hipStream_t st = as_stream(stream);
-  switch (which) {
-    case 0: hipLaunchKernelGGL(chain_fwd_a_kernel<R>, grid, blk, smem_fwd_a<R>(), st, *a); break;
-    case 1: hipLaunchKernelGGL(chain_fwd_b_kernel<R>, grid, blk, smem_fwd_b<R>(), st, *a); break;
-    case 2: hipLaunchKernelGGL(chain_bwd_b_kernel<R>, grid, blk, smem_bwd_b<R>(), st, *a); break;
-    default: hipLaunchKernelGGL(chain_bwd_a_kernel<R>, grid, blk, smem_bwd_a<R>(), st, *a); break;
+  if (a->w_bf16) {
+    switch (which) {
+      case 0: hipLaunchKernelGGL((chain_fwd_a_kernel<R, bf>), grid, blk, smem_fwd_a<R>(), st, *a); break;
+      case 1: hipLaunchKernelGGL((chain_fwd_b_kernel<R, bf>), grid, blk, smem_fwd_b<R>(), st, *a); break;
+      case 2: hipLaunchKernelGGL((chain_bwd_b_kernel<R, bf>), grid, blk, smem_bwd_b<R>(), st, *a); break;
+      default: hipLaunchKernelGGL((chain_bwd_a_kernel<R, bf>), grid, blk, smem_bwd_a<R>(), st, *a); break;
+    }
+  } else {
+    switch (which) {
+      case 0: hipLaunchKernelGGL((chain_fwd_a_kernel<R, float>), grid, blk, smem_fwd_a<R>(), st, *a); break;
+      case 1: hipLaunchKernelGGL((chain_fwd_b_kernel<R, float>), grid, blk, smem_fwd_b<R>(), st, *a); break;
+      case 2: hipLaunchKernelGGL((chain_bwd_b_kernel<R, float>), grid, blk, smem_bwd_b<R>(), st, *a); break;
+      default: hipLaunchKernelGGL((chain_bwd_a_kernel<R, float>), grid, blk, smem_bwd_a<R>(), st, *a); break;
+    }
   }
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;

@@ -850,7 +850,10 @@ int chain_transpose(const Ctx& c) {
 }
 
 // fwd: weights from the transposed mirror; bwd: as stored
-sdumc_chain_args chain_args(const Ctx& c, bool fwd, const sdumc_net_grads* og) {
+// stage_a: the launch is one of the stage-A kernels.  In bf16-storage mode only those stream bf16 weights: their layers are
+// 2-row products bound by the weight stream (fwd 104 -> 82 us, bwd 100 -> 86 us at C2), while stage B's 14-row layers are bound
+// by their FMAs and the bf16 unpacking made them slower (69 -> 85 us), so stage B keeps reading the fp32 weights.
+sdumc_chain_args chain_args(const Ctx& c, bool fwd, const sdumc_net_grads* og, bool stage_a) {
   const Plan& pl = c.pl;
   const ParamMap& pm = c.pm;
   sdumc_chain_args a;
@@ -860,7 +863,14 @@ sdumc_chain_args chain_args(const Ctx& c, bool fwd, const sdumc_net_grads* og) {
   a.drop = mkdrop(c, 0, c.d.p_mlp, 1, D);
   a.relu_scale = c.d.train ? 1.0f / (1.0f - (float)c.d.p_mlp) : 1.0f;
   const float* WB = fwd ? c.p(pl.wt) : c.P;
-  auto W = [&](const Lin& L) { return WB + L.w; };
+  // bf16-storage mode: the streamed matrices are read from the bf16 copies (transposed for the forward, as stored for the
+  // backward: sdumc_weights_to_bf16_ in forward()); orgin_linear_change stays fp32 (64 columns: too narrow for 8-column lanes)
+  const bool wb = c.h() && stage_a;
+  a.w_bf16 = wb ? 1 : 0;
+  auto W = [&](const Lin& L) -> const float* {
+    if (wb) return reinterpret_cast<const float*>(c.ph(fwd ? pl.wht : pl.wh, L.w));
+    return WB + L.w;
+  };
   auto Bs = [&](const Lin& L) { return c.P + L.b; };
   for (int m = 0; m < 3; ++m) {
     a.umlp0_w[m] = W(pm.umlp0[m]); a.umlp0_b[m] = Bs(pm.umlp0[m]);
@@ -877,8 +887,8 @@ sdumc_chain_args chain_args(const Ctx& c, bool fwd, const sdumc_net_grads* og) {
   a.catt3_w = W(pm.catt3); a.catt3_b = Bs(pm.catt3);
   a.cfa_w = c.P + pm.cross_fc_att.w; a.cfa_b = Bs(pm.cross_fc_att);
   a.fcv_w = c.P + pm.fc_out_v.w; a.fcv_b = Bs(pm.fc_out_v);
-  a.rnc0_w = W(pm.rnc0); a.rnc0_b = Bs(pm.rnc0);
-  a.rnc2_w = W(pm.rnc2); a.rnc2_b = Bs(pm.rnc2);
+  a.rnc0_w = WB + pm.rnc0.w; a.rnc0_b = Bs(pm.rnc0);
+  a.rnc2_w = WB + pm.rnc2.w; a.rnc2_b = Bs(pm.rnc2);
   a.hpre = c.p(pl.hpre); a.u1 = c.p(pl.u1); a.u = c.p(pl.u); a.att1 = c.p(pl.att1); a.att2 = c.p(pl.att2);
   a.alpha = c.p(pl.alpha); a.qin = c.p(pl.qin); a.q = c.p(pl.q); a.qp = c.p(pl.qp); a.ca_out = c.p(pl.ca_out);
   a.c1 = c.p(pl.c1); a.c = c.p(pl.c); a.h = c.p(pl.h); a.e1 = c.p(pl.e1); a.e2 = c.p(pl.e2); a.beta = c.p(pl.beta);
@@ -925,7 +935,18 @@ int forward(const Ctx& c) {
       offs[n] = pm.ca_in[m].w; outs[n] = D; ins[n] = D; wantt[n] = 1; ++n;
     }
     RET(sdumc_weights_to_bf16_(c.P, c.ph(pl.wh), c.ph(pl.wht), offs, outs, ins, wantt, n, c.st));
-    RET(fork_all(c));      // (the lanes forked above did not see this launch)
+    if (chain) {           // + the utterance-level matrices chain.hip streams (both layouts: forward and backward)
+      const std::vector<const Lin*> ls = chain_lins(pm);
+      n = 0;
+      for (size_t i = 0; i <= ls.size(); ++i) {
+        if (n == 16 || (i == ls.size() && n > 0)) {
+          RET(sdumc_weights_to_bf16_(c.P, c.ph(pl.wh), c.ph(pl.wht), offs, outs, ins, wantt, n, c.st));
+          n = 0;
+        }
+        if (i < ls.size()) { offs[n] = ls[i]->w; outs[n] = ls[i]->out; ins[n] = ls[i]->in; wantt[n] = 1; ++n; }
+      }
+    }
+    RET(fork_all(c));      // (the lanes forked above did not see these launches)
   }
   if (chain) {   // transposed mirror of the utterance-level weights (7 MB, first needed after the frame-level part): lane 3
     RET(link(c, 0, 3));
@@ -994,7 +1015,7 @@ int forward(const Ctx& c) {
   RET(join_all(c));
   if (chain) {   // steps 3-7 in one launch
     if (wt_done && hipStreamWaitEvent(c.st, wt_done, 0) != hipSuccess) return SDUMC_ELAUNCH;
-    const sdumc_chain_args ca = chain_args(c, true, nullptr);
+    const sdumc_chain_args ca = chain_args(c, true, nullptr, true);
     RET(sdumc_chain_launch_(&ca, 0, c.st));
   } else {
   // 3. audio/text/video_mlp (model :293-295), grouped over the modality
@@ -1069,7 +1090,7 @@ int forward(const Ctx& c) {
   c.use(0);
   RET(join_all(c));
   if (chain) {   // steps 9-12 and the outputs in one launch
-    const sdumc_chain_args ca = chain_args(c, true, nullptr);
+    const sdumc_chain_args ca = chain_args(c, true, nullptr, false);
     return sdumc_chain_launch_(&ca, 1, c.st);
   }
   // 9. cross_{audio,text,video}_mlp (model :338-340)
@@ -1250,7 +1271,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   const bool chain = use_chain(c);
   if (chain) {
     // 12'-9' in one launch (chain.hip); the weight gradients of these layers are queued for lane 3 as before
-    const sdumc_chain_args ca = chain_args(c, false, &og);
+    const sdumc_chain_args ca = chain_args(c, false, &og, false);
     RET(sdumc_chain_launch_(&ca, 2, c.st));
     const int M7 = V * NQ;
     if (og.d_rnc) {
@@ -1321,7 +1342,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   }
   if (chain) {
     // 7'-3' in one launch; dW of these layers queued for lane 3
-    const sdumc_chain_args ca = chain_args(c, false, &og);
+    const sdumc_chain_args ca = chain_args(c, false, &og, true);
     RET(sdumc_chain_launch_(&ca, 3, c.st));
     const int M7 = V * NQ;
     {

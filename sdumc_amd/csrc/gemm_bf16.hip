@@ -413,6 +413,9 @@ int launch(const sdumc_gemm_bf16& g, const Plan& p, bool cs, hipStream_t st) {
 
 }  // namespace sdumc_bf16
 
+extern "C" int sdumc_prof_begin_(int variant, double flops, void* stream);     // gemm_f32.hip: bench.py's per-launch HIP events
+extern "C" void sdumc_prof_end_(int token, void* stream);
+
 extern "C" size_t sdumc_gemm_bf16_workspace_bytes(const sdumc_gemm_bf16* g) {
   if (!g || g->M <= 0 || g->N <= 0 || g->K <= 0 || g->groups < 1) return 0;
   return sdumc_bf16::ws_bytes(*g, sdumc_bf16::plan(*g, (size_t)-1).nsplit);
@@ -446,6 +449,7 @@ extern "C" int sdumc_gemm_bf16_run(const sdumc_gemm_bf16* gp, void* stream) {
   const Plan p = plan(g, g.workspace ? g.workspace_bytes : 0);
   if (p.nsplit > 1 && (!g.workspace || g.workspace_bytes < ws_bytes(g, p.nsplit))) return SDUMC_ENOMEM;
   hipStream_t st = as_stream(stream);
+  const int tok = sdumc_prof_begin_(nt ? 17 : 18, 2.0 * g.M * (double)g.N * g.K * g.groups, stream);
   int rc;
   if (nt) rc = nt_small(g) ? launch<NT64>(g, p, false, st) : launch<NT128>(g, p, false, st);
   else {
@@ -457,6 +461,7 @@ extern "C" int sdumc_gemm_bf16_run(const sdumc_gemm_bf16* gp, void* stream) {
   }
   if (rc != SDUMC_OK) return rc;
   SDUMC_CHECK_LAUNCH();
+  sdumc_prof_end_(tok, stream);
   if (p.nsplit > 1) {
     const size_t mn = (size_t)g.M * g.N + (size_t)g.M;
     hipLaunchKernelGGL(bf16_splitk_reduce_kernel, dim3((unsigned)((mn + 255) / 256), g.groups), dim3(256), 0, st, g, p.nsplit);

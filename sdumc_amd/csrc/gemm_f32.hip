@@ -37,14 +37,15 @@ struct ProfRec {
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::mutex g_prof_mu;
-constexpr int kNumVariants = 17;
+constexpr int kNumVariants = 19;
 const char* const kVariantName[kNumVariants] = {"gemm_nt_128x128", "gemm_nt_64x64",  "gemm_nn_128x128",
                                                 "gemm_nn_64x64",   "gemm_tn_128x128", "gemm_tn_64x64",
                                                 "gemm_small_nt",   "gemm_small_nn",   "gemm_small_tn",
                                                 "gemm_bf16_nt_128x128", "gemm_bf16_nt_64x64",
                                                 "gemm_bf16_nn_128x128", "gemm_bf16_nn_64x64",
                                                 "gemm_bf16_tn_128x128", "gemm_bf16_tn_64x64",
-                                                "gemm_wide_nt", "gemm_wide_tn"};
+                                                "gemm_wide_nt", "gemm_wide_tn",
+                                                "gemm_bf16s_nt", "gemm_bf16s_tn"};   // gemm_bf16.hip (bf16 storage)
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;
@@ -825,6 +826,24 @@ int launch(const sdumc_gemm& g, int nsplit, int kchunk, hipStream_t st) {
 }
 
 }  // namespace
+
+// per-launch timing hooks for the other GEMM files (gemm_bf16.hip): begin returns a token (or -1 when profiling is off)
+extern "C" int sdumc_prof_begin_(int variant, double flops, void* stream) {
+  if (!g_prof_on) return -1;
+  ProfRec r;
+  if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return -1;
+  r.variant = variant;
+  r.flops = flops;
+  (void)hipEventRecord(r.a, as_stream(stream));
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  g_prof.push_back(r);
+  return (int)g_prof.size() - 1;
+}
+extern "C" void sdumc_prof_end_(int token, void* stream) {
+  if (token < 0) return;
+  std::lock_guard<std::mutex> lock(g_prof_mu);
+  if (token < (int)g_prof.size()) (void)hipEventRecord(g_prof[token].b, as_stream(stream));
+}
 
 extern "C" int sdumc_gemm_wide_(const sdumc_gemm* gp, int cfg, int nsplit, int kchunk, void* stream);   // gemm_wide.hip
 
