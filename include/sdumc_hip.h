@@ -215,6 +215,12 @@ typedef struct sdumc_attnpool_bwd {
 
 size_t sdumc_attnpool_bwd_workspace_bytes(int32_t V, int32_t T, int32_t nq);
 int sdumc_attnpool_bwd(const sdumc_attnpool_bwd_t* p, void* stream);
+/* Up to four pooling sites in ONE launch pair (forward: partial + combine; backward: rows + dq reduce) -- what the step uses for
+ * its three Cross_Attention blocks, which are independent and too short to be worth a stream fork.  Every site: 256-channel
+ * rows, keep-bits attached or no input mask, the same `bf16` flag, its OWN workspace.  Results are bit-identical to n single
+ * calls.  Replaces the three Cross_Attention.forward calls of models/wengnet_mosei_multviews_text_missing.py:334-336. */
+int sdumc_attnpool_fwd_multi(const sdumc_attnpool* sites, int32_t n, void* stream);
+int sdumc_attnpool_bwd_multi(const sdumc_attnpool_bwd_t* sites, int32_t n, void* stream);
 
 /* ------------------------------------------------------------------------
  * Small fused element-wise / reduction kernels of the utterance-level network.
@@ -559,6 +565,12 @@ int sdumc_set_concurrency(int on);
  * Cross_Attention key GEMM), 3 (the default) = 2 plus the audio modality's backward ones (+0.6 % over 2: the longest
  * frame-level chain gets shorter), 4 = audio and video (+0.4 %); mode 1 loses 1.6 % against mode 2. */
 int sdumc_set_background_lane(int on);
+/* Debug timeline: with marks on, sdumc_train_step records an event on the caller's stream at fixed points (0 start, 1/2 around
+ * the first utterance-level launch, 3/4 the second, 5 after the losses, 6 after the first backward utterance-level launch, 7/8
+ * around the second, 9 before Adam, 10 end); _read returns their times in ms since mark 0 (-1 = not recorded) once the caller
+ * has synchronised.  Process-wide and single-threaded: a measurement aid (tools/step_marks.py), not part of the data path. */
+int sdumc_debug_marks(int on);
+int sdumc_debug_marks_read(float* ms, int n);
 size_t sdumc_net_workspace_bytes(const sdumc_net_dims* d);
 int sdumc_net_forward(const sdumc_net_dims* d, const sdumc_net_io* io, void* stream);
 

@@ -159,6 +159,8 @@ _SIGS = {
     "sdumc_attnpool_bwd_workspace_bytes_dim": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "sdumc_attnpool_bwd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "sdumc_attnpool_bwd": (C.c_int, [C.POINTER(AttnPoolBwd), C.c_void_p]),
+    "sdumc_attnpool_fwd_multi": (C.c_int, [C.POINTER(AttnPool), C.c_int32, C.c_void_p]),
+    "sdumc_attnpool_bwd_multi": (C.c_int, [C.POINTER(AttnPoolBwd), C.c_int32, C.c_void_p]),
     "sdumc_relu_drop_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "sdumc_colsum_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),
     "sdumc_colsum": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
@@ -219,6 +221,8 @@ _SIGS = {
     "sdumc_param_table": (C.c_int32, [C.c_int32, C.c_int32, C.c_int32, C.c_char_p, C.c_size_t]),
     "sdumc_set_concurrency": (C.c_int, [C.c_int]),
     "sdumc_set_background_lane": (C.c_int, [C.c_int]),
+    "sdumc_debug_marks": (C.c_int, [C.c_int]),
+    "sdumc_debug_marks_read": (C.c_int, [C.POINTER(C.c_float), C.c_int]),
     "sdumc_net_workspace_bytes": (C.c_size_t, [C.POINTER(NetDims)]),
     "sdumc_net_forward": (C.c_int, [C.POINTER(NetDims), C.POINTER(NetIO), C.c_void_p]),
     "sdumc_net_backward": (C.c_int, [C.POINTER(NetDims), C.POINTER(NetIO), C.POINTER(NetGrads), C.c_void_p]),

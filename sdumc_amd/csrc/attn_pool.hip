@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include <cstring>
 
 namespace {
 
@@ -118,14 +119,13 @@ __device__ __forceinline__ f32x4 rows_times_cols(const float* rowp, const float*
 // ---- forward, pass 1: one workgroup per (chunk of 64 rows, v) -----------------------------------
 // PHILOX: the input dropout mask is recomputed per row (no precomputed keep-bits attached: tests, one-off calls)
 template <bool PHILOX, int C, bool HF = false>
-__global__ __launch_bounds__(256, C == 1 ? 4 : 2) void attn_fwd_partial_kernel(const sdumc_attnpool p, float* ws, const int nchunk) {
+__device__ __forceinline__ void attn_fwd_partial_body(const sdumc_attnpool p, float* ws, const int nchunk, const int chunk, const int v) {
   constexpr int DD = D * C, LDQ = DD + 16;
   constexpr int RED = 4 * MAXQ * D > MAXQ * LDQ ? 4 * MAXQ * D : MAXQ * LDQ;
   __shared__ __attribute__((aligned(16))) float P_s[CH * MAXQ];
   __shared__ __attribute__((aligned(16))) float red[RED];   // first the query tile, later the pooling reduce (per channel block)
   __shared__ float wstat[4][16];
   __shared__ float cstat[16];
-  const int chunk = blockIdx.x, v = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, kk = lane >> 4;
   const int T = p.T, nq = p.nq;
@@ -254,10 +254,49 @@ __global__ __launch_bounds__(256, C == 1 ? 4 : 2) void attn_fwd_partial_kernel(c
   if constexpr (C > 3) pool_block(std::integral_constant<int, 3>{});
 }
 
+template <bool PHILOX, int C, bool HF = false>
+__global__ __launch_bounds__(256, C == 1 ? 4 : 2) void attn_fwd_partial_kernel(const sdumc_attnpool p, float* ws, const int nchunk) {
+  attn_fwd_partial_body<PHILOX, C, HF>(p, ws, nchunk, blockIdx.x, blockIdx.y);
+}
+
+// Several pooling sites in ONE launch (the three Cross_Attention blocks of a step: sdumc_attnpool_fwd_multi): a flat grid, the
+// heaviest site first; workgroup -> (site, chunk, v).  256-channel rows with keep-bits (or no mask) only.
+constexpr int MAXSITES = 4;
+struct MultiFwd {
+  sdumc_attnpool p[MAXSITES];
+  int32_t wg_end[MAXSITES];     // exclusive prefix ends of the partial kernel's flat grid
+  int32_t v_end[MAXSITES];      // same for the combine kernel (one workgroup per v)
+  int32_t nchunk[MAXSITES];
+};
+struct MultiBwd {
+  sdumc_attnpool_bwd_t b[MAXSITES];
+  int32_t wg_end[MAXSITES];
+  int32_t nchunk[MAXSITES];
+  unsigned long long dq_end[MAXSITES];   // prefix ends of the dq reduce (elements)
+};
+__device__ __forceinline__ int site_of(const int32_t* ends, const int bid) {
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < MAXSITES - 1; ++i) s += bid >= ends[i] ? 1 : 0;
+  return s;
+}
+
+template <bool HF>
+__global__ __launch_bounds__(256, 4) void attn_fwd_partial_multi_kernel(const MultiFwd m) {
+  const int s = site_of(m.wg_end, blockIdx.x);
+  const int local = blockIdx.x - (s ? m.wg_end[s - 1] : 0);
+  const int nchunk = m.nchunk[s];
+  sdumc_attnpool p = m.p[0];   // uniform select, by value (see attnpool_bwd_multi_kernel)
+  if (s == 1) p = m.p[1];
+  if (s == 2) p = m.p[2];
+  if (s == 3) p = m.p[3];
+  attn_fwd_partial_body<false, 1, HF>(p, static_cast<float*>(p.workspace), nchunk, local % nchunk, local / nchunk);
+}
+
 // ---- forward, pass 2: combine the chunks of one v, normalise the weights, output dropout ---------
-__global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const sdumc_attnpool p, const float* ws, const int nchunk) {
-  extern __shared__ float fac[];   // [nchunk][MAXQ]: exp(m_c - m) / l
-  const int v = blockIdx.x, tid = threadIdx.x;
+__device__ __forceinline__ void attn_fwd_combine_body(const sdumc_attnpool& p, const float* ws, const int nchunk, const int v,
+                                                      float* fac /* LDS [nchunk][MAXQ]: exp(m_c - m) / l */) {
+  const int tid = threadIdx.x;
   const int T = p.T, nq = p.nq, DD = row_dim(p);
   const FwdWs w = fwd_ws(const_cast<float*>(ws), p.V, nchunk, nq, DD);
   const float* st = w.stats + (size_t)v * nchunk * 2 * MAXQ;
@@ -287,6 +326,17 @@ __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const sdumc_attnp
   }
 }
 
+__global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const sdumc_attnpool p, const float* ws, const int nchunk) {
+  extern __shared__ float fac[];
+  attn_fwd_combine_body(p, ws, nchunk, blockIdx.x, fac);
+}
+__global__ __launch_bounds__(256) void attn_fwd_combine_multi_kernel(const MultiFwd m) {
+  extern __shared__ float fac[];
+  const int s = site_of(m.v_end, blockIdx.x);
+  const sdumc_attnpool& p = m.p[s];
+  attn_fwd_combine_body(p, static_cast<const float*>(p.workspace), m.nchunk[s], blockIdx.x - (s ? m.v_end[s - 1] : 0), fac);
+}
+
 // ---- backward: one workgroup per (chunk, v) ----------------------------------------------------
 // dO = dout * out_mask ; delta_i = dO_i . O_i ; per row t:
 //   dA_i = xd_t . dO_i (matrix cores) ; dS_i = 0.3 A_ti (dA_i - delta_i)
@@ -294,8 +344,8 @@ __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const sdumc_attnp
 //   dxd_t (pool path) = sum_i A_ti dO_i                         -> dxd
 //   dQ_i += dS_i K_t                                            -> per-chunk slabs (deterministic)
 template <int C, bool HF = false>
-__global__ __launch_bounds__(256, 2) void attnpool_bwd_kernel(const sdumc_attnpool_bwd_t b, float* dq_part,
-                                                           const int nchunk) {
+__device__ __forceinline__ void attnpool_bwd_body(const sdumc_attnpool_bwd_t b, float* dq_part, const int nchunk, const int chunk,
+                                                  const int v) {
   constexpr int DD = D * C, LDQ = DD + 16;
   __shared__ __attribute__((aligned(16))) float dO_s[MAXQ * LDQ];
   __shared__ __attribute__((aligned(16))) float red[4 * MAXQ * D];
@@ -303,7 +353,6 @@ __global__ __launch_bounds__(256, 2) void attnpool_bwd_kernel(const sdumc_attnpo
   __shared__ __attribute__((aligned(16))) float A_s[CH * MAXQ];
   __shared__ float delta_s[16];
   const sdumc_attnpool& p = b.f;
-  const int chunk = blockIdx.x, v = blockIdx.y;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int r16 = lane & 15, kk = lane >> 4;
   const int T = p.T, nq = p.nq;
@@ -415,6 +464,25 @@ __global__ __launch_bounds__(256, 2) void attnpool_bwd_kernel(const sdumc_attnpo
   }
 }
 
+template <int C, bool HF = false>
+__global__ __launch_bounds__(256, 2) void attnpool_bwd_kernel(const sdumc_attnpool_bwd_t b, float* dq_part,
+                                                           const int nchunk) {
+  attnpool_bwd_body<C, HF>(b, dq_part, nchunk, blockIdx.x, blockIdx.y);
+}
+template <bool HF>
+__global__ __launch_bounds__(256, 2) void attnpool_bwd_multi_kernel(const MultiBwd m) {
+  const int s = site_of(m.wg_end, blockIdx.x);
+  const int local = blockIdx.x - (s ? m.wg_end[s - 1] : 0);
+  const int nchunk = m.nchunk[s];
+  // (the descriptor reaches the body BY VALUE through a uniform select: handed over as a reference into the kernel argument --
+  //  indexed or not -- hipcc (ROCm 7.2) compiled the same body to 256 VGPRs + 6500 spilled dwords instead of 136 VGPRs)
+  sdumc_attnpool_bwd_t b = m.b[0];
+  if (s == 1) b = m.b[1];
+  if (s == 2) b = m.b[2];
+  if (s == 3) b = m.b[3];
+  attnpool_bwd_body<1, HF>(b, static_cast<float*>(b.workspace), nchunk, local % nchunk, local / nchunk);
+}
+
 __global__ __launch_bounds__(256) void dq_reduce_kernel(const float* part, float* dq, const int nchunk,
                                                         const int per_v /* nq*256 */, const size_t total) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -424,6 +492,22 @@ __global__ __launch_bounds__(256) void dq_reduce_kernel(const float* part, float
   float a = 0.f;
   for (int c = 0; c < nchunk; ++c) a += s[(size_t)c * per_v];
   dq[idx] = a;
+}
+
+__global__ __launch_bounds__(256) void dq_reduce_multi_kernel(const MultiBwd m) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  int s = 0;
+#pragma unroll
+  for (int i = 0; i < MAXSITES - 1; ++i) s += idx >= m.dq_end[i] ? 1 : 0;
+  if (idx >= m.dq_end[MAXSITES - 1]) return;
+  const sdumc_attnpool_bwd_t& b = m.b[s];
+  const size_t local = idx - (s ? m.dq_end[s - 1] : 0);
+  const int nchunk = m.nchunk[s], per_v = b.f.nq * D;
+  const size_t v = local / per_v, e = local - v * per_v;
+  const float* src = static_cast<const float*>(b.workspace) + v * nchunk * per_v + e;
+  float a = 0.f;
+  for (int c = 0; c < nchunk; ++c) a += src[(size_t)c * per_v];
+  b.dq[local] = a;
 }
 
 int check(const sdumc_attnpool& p) {
@@ -507,6 +591,72 @@ extern "C" int sdumc_attnpool_bwd(const sdumc_attnpool_bwd_t* bp, void* stream) 
   const size_t total = (size_t)p.V * p.nq * DD;
   hipLaunchKernelGGL(dq_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, b.workspace, b.dq,
                      nchunk, p.nq * DD, total);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+// ---- several sites in one launch -----------------------------------------------------------------
+// The three Cross_Attention blocks of a step are independent, small (17-42 us each at C2) and sit between two utterance-level
+// launches on the caller's stream: forking them onto side streams costs ~20 us of cross-queue event latency on the way out and
+// ~12 us on the way back (tools/step_marks.py), one grouped launch costs neither.
+extern "C" int sdumc_attnpool_fwd_multi(const sdumc_attnpool* ps, int32_t n, void* stream) {
+  if (!ps || n < 1 || n > MAXSITES) return SDUMC_EINVAL;
+  MultiFwd m;
+  memset(&m, 0, sizeof(m));
+  int wg = 0, vs = 0, max_chunk = 0;
+  for (int i = 0; i < MAXSITES; ++i) {
+    if (i < n) {
+      const sdumc_attnpool& p = ps[i];
+      int rc = check(p);
+      if (rc) return rc;
+      if (row_dim(p) != D || (p.x_drop.enabled && !p.x_drop.bits) || p.bf16 != ps[0].bf16) return SDUMC_EINVAL;
+      if (!p.workspace || p.workspace_bytes < sdumc_attnpool_fwd_workspace_bytes_dim(p.V, p.T, p.nq, D)) return SDUMC_ENOMEM;
+      m.p[i] = p;
+      m.nchunk[i] = (p.T + CH - 1) / CH;
+      wg += m.nchunk[i] * p.V;
+      vs += p.V;
+      max_chunk = m.nchunk[i] > max_chunk ? m.nchunk[i] : max_chunk;
+    }
+    m.wg_end[i] = wg;
+    m.v_end[i] = vs;
+  }
+  hipStream_t st = as_stream(stream);
+  if (ps[0].bf16) hipLaunchKernelGGL(attn_fwd_partial_multi_kernel<true>, dim3(wg), dim3(256), 0, st, m);
+  else hipLaunchKernelGGL(attn_fwd_partial_multi_kernel<false>, dim3(wg), dim3(256), 0, st, m);
+  SDUMC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(attn_fwd_combine_multi_kernel, dim3(vs), dim3(256), (size_t)max_chunk * MAXQ * sizeof(float), st, m);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_attnpool_bwd_multi(const sdumc_attnpool_bwd_t* bs, int32_t n, void* stream) {
+  if (!bs || n < 1 || n > MAXSITES) return SDUMC_EINVAL;
+  MultiBwd m;
+  memset(&m, 0, sizeof(m));
+  int wg = 0;
+  unsigned long long dq = 0;
+  for (int i = 0; i < MAXSITES; ++i) {
+    if (i < n) {
+      const sdumc_attnpool_bwd_t& b = bs[i];
+      const sdumc_attnpool& p = b.f;
+      int rc = check(p);
+      if (rc) return rc;
+      if (!b.dout || !b.dz || !b.dxd || !b.dq || !b.workspace) return SDUMC_EINVAL;
+      if (row_dim(p) != D || (p.x_drop.enabled && !p.x_drop.bits) || p.bf16 != bs[0].f.bf16) return SDUMC_EINVAL;
+      if (b.workspace_bytes < sdumc_attnpool_bwd_workspace_bytes_dim(p.V, p.T, p.nq, D)) return SDUMC_ENOMEM;
+      m.b[i] = b;
+      m.nchunk[i] = (p.T + CH - 1) / CH;
+      wg += m.nchunk[i] * p.V;
+      dq += (unsigned long long)p.V * p.nq * D;
+    }
+    m.wg_end[i] = wg;
+    m.dq_end[i] = dq;
+  }
+  hipStream_t st = as_stream(stream);
+  if (bs[0].f.bf16) hipLaunchKernelGGL(attnpool_bwd_multi_kernel<true>, dim3(wg), dim3(256), 0, st, m);
+  else hipLaunchKernelGGL(attnpool_bwd_multi_kernel<false>, dim3(wg), dim3(256), 0, st, m);
+  SDUMC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(dq_reduce_multi_kernel, dim3((unsigned)((dq + 255) / 256)), dim3(256), 0, st, m);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
 }

@@ -347,6 +347,13 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
     for (const Seg& sg : p.segs[m]) sc = std::max<int64_t>(sc, (int64_t)attnpool_bwd_ws_floats(sg.V, sg.T, NQ));
     sc = std::max<int64_t>(sc, (int64_t)((p.rows[m] + 511) / 512 + 1) * D);
   }
+  {   // the grouped Cross_Attention launches carve ONE lane's scratch into per-site workspaces
+    int64_t sum = 0;
+    for (int m = 0; m < 3; ++m)
+      for (const Seg& sg : p.segs[m])
+        sum += ((int64_t)(sdumc_attnpool_fwd_workspace_bytes(sg.V, sg.T, NQ) / sizeof(float)) + 63) / 64 * 64;
+    sc = std::max<int64_t>(sc, sum);
+  }
   sc = std::max<int64_t>(sc, (int64_t)8 * 4 * D * NQ * H);  // grouped utterance-level split-K upper bound
   sc = std::max<int64_t>(sc, (int64_t)13 << 20);            // auto split-K: <= ~(320 + tiles) slabs of 64 KiB
   p.scratch_floats = sc;
@@ -374,6 +381,17 @@ struct LaneSet {
   int device = -1;
   bool ok = false;
 };
+// Debug timeline (tools/step_marks.py): sdumc_debug_marks(1) makes the step record an event on the caller's stream at a few
+// fixed points; sdumc_debug_marks_read returns their times since mark 0.  Process-wide, single-threaded use only.
+constexpr int kMarks = 12;
+bool g_marks_on = false;
+hipEvent_t g_marks[kMarks] = {};
+bool g_mark_set[kMarks] = {};
+inline void mark(hipStream_t st, int id) {
+  if (!g_marks_on) return;
+  if (!g_marks[id] && hipEventCreate(&g_marks[id]) != hipSuccess) return;
+  g_mark_set[id] = hipEventRecord(g_marks[id], st) == hipSuccess;
+}
 bool g_concurrency = true;   // sdumc_set_concurrency(0): everything on the caller's stream (profiling)
 int g_background = 3;      // 0 off; 2 forward only (+1.0 % per step over 0); 3 (default) = 2 + the AUDIO Cross_Attention key-projection
                            // backward early on lane 3 (+0.6 % over 2: it shortens the longest frame-level chain); 4 = audio + video (+0.4 %);
@@ -804,6 +822,32 @@ int keys_gemm_fwd(const Ctx& c, int m, int k0, int k1) {
 }
 
 // softmax-over-time pooling of site (k, m) given its keys (and, for k = 1, the projected queries)
+// Sites (k, m = 0..2) in one launch on the current lane (sdumc_attnpool_fwd_multi / _bwd_multi); false = take the per-lane path
+// (SDUMC_ATTN_MULTI=0, or more than four runs).
+bool attn_multi_ok(const Ctx& c) {
+  static const int on = [] { const char* e = getenv("SDUMC_ATTN_MULTI"); return e ? atoi(e) : 1; }();
+  size_t n = 0;
+  for (int m = 0; m < 3; ++m) n += c.pl.segs[m].size();
+  return on && n <= 4;
+}
+
+int pool_fwd_multi(const Ctx& c, int k) {
+  sdumc_attnpool a[4];
+  int n = 0;
+  float* ws = c.scr;
+  const int order[3] = {0, 2, 1};            // heaviest first
+  for (int oi = 0; oi < 3; ++oi)
+    for (const Seg& sg : c.pl.segs[order[oi]]) {
+      a[n] = attn_desc(c, k, order[oi], sg);
+      const size_t bytes = sdumc_attnpool_fwd_workspace_bytes(sg.V, sg.T, a[n].nq);
+      a[n].workspace = ws;
+      a[n].workspace_bytes = bytes;
+      ws += (bytes / sizeof(float) + 63) / 64 * 64;
+      ++n;
+    }
+  return sdumc_attnpool_fwd_multi(a, n, c.st);
+}
+
 int pool_fwd(const Ctx& c, int k, int m) {
   for (const Seg& sg : c.pl.segs[m]) {
     sdumc_attnpool a = attn_desc(c, k, m, sg);
@@ -1016,7 +1060,9 @@ int forward(const Ctx& c) {
   if (chain) {   // steps 3-7 in one launch
     if (wt_done && hipStreamWaitEvent(c.st, wt_done, 0) != hipSuccess) return SDUMC_ELAUNCH;
     const sdumc_chain_args ca = chain_args(c, true, nullptr, true);
+    mark(c.st, 1);
     RET(sdumc_chain_launch_(&ca, 0, c.st));
+    mark(c.st, 2);
   } else {
   // 3. audio/text/video_mlp (model :293-295), grouped over the modality
   {
@@ -1080,18 +1126,26 @@ int forward(const Ctx& c) {
     RET(run(c, g));
   }
   }   // !chain
-  // 8. cross_att_fra2utt_{0,1,2} (model :334-336)
+  // 8. cross_att_fra2utt_{0,1,2} (model :334-336): one grouped launch on the caller's stream (a fork/join around three 17-30 us
+  //    kernels cost 86-91 us between the two utterance-level launches, of which ~35 us were cross-queue event latency)
   RET(link(c, 3, 0));   // their keys
-  RET(fork_all(c));
-  for (int m = 0; m < 3; ++m) {
-    c.use(LANE_OF[m]);
-    RET(pool_fwd(c, 1, m));
+  if (attn_multi_ok(c)) {
+    RET(pool_fwd_multi(c, 1));
+  } else {
+    RET(fork_all(c));
+    for (int m = 0; m < 3; ++m) {
+      c.use(LANE_OF[m]);
+      RET(pool_fwd(c, 1, m));
+    }
+    c.use(0);
+    RET(join_all(c));
   }
-  c.use(0);
-  RET(join_all(c));
   if (chain) {   // steps 9-12 and the outputs in one launch
     const sdumc_chain_args ca = chain_args(c, true, nullptr, false);
-    return sdumc_chain_launch_(&ca, 1, c.st);
+    mark(c.st, 3);
+    RET(sdumc_chain_launch_(&ca, 1, c.st));
+    mark(c.st, 4);
+    return SDUMC_OK;
   }
   // 9. cross_{audio,text,video}_mlp (model :338-340)
   {
@@ -1273,6 +1327,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     // 12'-9' in one launch (chain.hip); the weight gradients of these layers are queued for lane 3 as before
     const sdumc_chain_args ca = chain_args(c, false, &og, false);
     RET(sdumc_chain_launch_(&ca, 2, c.st));
+    mark(c.st, 6);
     const int M7 = V * NQ;
     if (og.d_rnc) {
       RET(lin_bwd(c, pm.rnc2, og.d_rnc, RD, c.p(pl.r1), RD, V, nullptr, 0, 0));
@@ -1317,9 +1372,47 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   }   // !chain
   RET(flush_dw(c));   // batch 1: heads, cross_attention_mlp, cross_*_mlp
   // 8'. the three Cross_Attention blocks
-  RET(fork_all(c));
+  const bool grouped = attn_multi_ok(c);
+  if (grouped) {   // one grouped launch on the caller's stream, then the early key-projection backwards leave for their lanes
+    sdumc_attnpool_bwd_t bb[4];
+    int n = 0;
+    float* ws = c.scr;
+    const int order[3] = {0, 2, 1};
+    for (int oi = 0; oi < 3; ++oi) {
+      const int m = order[oi];
+      for (const Seg& sg : pl.segs[m]) {
+        sdumc_attnpool_bwd_t& b = bb[n++];
+        memset(&b, 0, sizeof(b));
+        b.f = attn_desc(c, 1, m, sg);
+        const int64_t voff = (int64_t)sg.s0 * pl.B * NQ * D;
+        b.dout = c.p(pl.d_ca_out) + (int64_t)m * V * NQ * D + voff;
+        b.dq = c.p(pl.d_qp) + (int64_t)m * V * NQ * D + voff;
+        if (c.h()) {
+          b.dz = reinterpret_cast<float*>(c.ph(pl.dz[1][m], sg.row0 * D));
+          b.dxd = reinterpret_cast<float*>(c.ph(pl.dxd[1][m], sg.row0 * D));
+        } else {
+          b.dz = c.p(pl.dz[1][m]) + sg.row0 * D;
+          b.dxd = c.p(pl.dxd[1][m]) + sg.row0 * D;
+        }
+        const size_t bytes = sdumc_attnpool_bwd_workspace_bytes(sg.V, sg.T, NQ);
+        b.workspace = ws;
+        b.workspace_bytes = bytes;
+        ws += (bytes / sizeof(float) + 63) / 64 * 64;
+      }
+    }
+    RET(sdumc_attnpool_bwd_multi(bb, n, c.st));
+    for (int m = 0; m < 3; ++m) {
+      if (!(bgb & (1 << m))) continue;
+      const int lane = (own_lane & (1 << m)) ? LANE_OF[m] : 3;
+      RET(link(c, 0, lane));
+      c.use(lane);
+      RET(keys_gemm_bwd(c, m, 1, 2));
+      c.use(0);
+    }
+  }
+  if (!grouped) RET(fork_all(c));
   hipEvent_t pooled[3] = {nullptr, nullptr, nullptr};   // per side lane: its pooling backward is done (partial join)
-  for (int m = 0; m < 3; ++m) {
+  for (int m = 0; !grouped && m < 3; ++m) {
     c.use(LANE_OF[m]);
     RET(pool_bwd(c, 1, m, c.p(pl.d_ca_out) + (int64_t)m * V * NQ * D, c.p(pl.d_qp) + (int64_t)m * V * NQ * D));
     if (own_lane & bgb & (1 << m)) {   // the input_proj backward has everything it needs: stay on this lane, beside 7'-3'
@@ -1333,7 +1426,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     }
   }
   c.use(0);
-  for (int lane = 1; lane <= 2; ++lane) {
+  for (int lane = 1; !grouped && lane <= 2; ++lane) {
     if (pooled[lane]) {
       if (hipStreamWaitEvent(c.sts[0], pooled[lane], 0) != hipSuccess) return SDUMC_ELAUNCH;
     } else {
@@ -1343,7 +1436,9 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   if (chain) {
     // 7'-3' in one launch; dW of these layers queued for lane 3
     const sdumc_chain_args ca = chain_args(c, false, &og, true);
+    mark(c.st, 7);
     RET(sdumc_chain_launch_(&ca, 3, c.st));
+    mark(c.st, 8);
     const int M7 = V * NQ;
     {
       sdumc_gemm gw = G_(SDUMC_TN, D, D, M7, 3);
@@ -1757,6 +1852,7 @@ extern "C" int sdumc_train_step(const sdumc_net_dims* d, const sdumc_net_io* io,
   sdumc_net_io nio = *io;
   nio.workspace = base + sl.net;
   nio.workspace_bytes = sl.total - sl.net;
+  mark(static_cast<hipStream_t>(stream), 0);
   RET(sdumc_net_forward(d, &nio, stream));
   const size_t V = (size_t)d->B * 2;
   float* dout = reinterpret_cast<float*>(base + sl.dout);
@@ -1769,10 +1865,29 @@ extern "C" int sdumc_train_step(const sdumc_net_dims* d, const sdumc_net_io* io,
   g.grads = reinterpret_cast<float*>(base + sl.grads);
   // the Adam bias-correction update rides in the loss's last launch, the dropout call counter in the Adam launch
   RET(loss_backward_impl(d, &nio, cfg, &g, base + sl.loss, sl.net - sl.loss, stream, cfg->hyper));
+  mark(static_cast<hipStream_t>(stream), 5);
   RET(sdumc_net_backward(d, &nio, &g, stream));
+  mark(static_cast<hipStream_t>(stream), 9);
   RET(sdumc_adam_apply_(io->params, g.grads, cfg->adam_m, cfg->adam_v, (int64_t)sl.live, cfg->hyper, cfg->beta1, cfg->beta2,
                         cfg->eps, cfg->weight_decay, 1.0f, d->train ? const_cast<uint32_t*>(io->rng_state) : nullptr, 2u,
                         stream));
+  mark(static_cast<hipStream_t>(stream), 10);
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_debug_marks(int on) {
+  g_marks_on = on != 0;
+  return SDUMC_OK;
+}
+// ms since mark 0 of every mark recorded by the last step (-1 where none); the caller synchronises first
+extern "C" int sdumc_debug_marks_read(float* ms, int n) {
+  for (int i = 0; i < n; ++i) {
+    ms[i] = -1.f;
+    if (i < kMarks && g_mark_set[i] && g_mark_set[0]) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, g_marks[0], g_marks[i]) == hipSuccess) ms[i] = t;
+    }
+  }
   return SDUMC_OK;
 }
 

@@ -151,6 +151,51 @@ def attnpool_bwd(desc, dout, keep):
     return dz, dxd, dq
 
 
+def attnpool_fwd_multi(sites):
+    """sites: list of dicts with the keyword arguments of attnpool_fwd (x, keys, q, nq, ...); ONE launch pair for all of them
+    (sdumc_attnpool_fwd_multi).  -> list of (out, attn, pooled, desc)."""
+    arr = (_lib.AttnPool * len(sites))()
+    res, keep = [], []
+    for i, kw in enumerate(sites):
+        x, keys, q, nq = kw["x"], kw["keys"], kw["q"], kw["nq"]
+        V, T, Dm = keys.shape
+        dev = keys.device
+        attn, pooled, out = torch.empty(V, T, nq, device=dev), torch.empty(V, nq, Dm, device=dev), torch.empty(V, nq, Dm, device=dev)
+        a = attnpool_desc(x, keys, q, V, T, nq, kw.get("x_samples") or x.shape[0], 0 if kw.get("q_shared") else nq * Dm,
+                          kw.get("x_drop"), kw.get("out_drop"), attn, pooled, out, lengths=kw.get("lengths"))
+        need = lib.sdumc_attnpool_fwd_workspace_bytes(V, T, nq)
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        a.workspace, a.workspace_bytes = ptr(ws), need
+        arr[i] = a
+        keep.append(ws)
+        res.append((out, attn, pooled, a))
+    check(lib.sdumc_attnpool_fwd_multi(arr, len(sites), _st()), "sdumc_attnpool_fwd_multi")
+    torch.cuda.current_stream().synchronize()      # (the workspaces die with this frame)
+    return res
+
+
+def attnpool_bwd_multi(descs, douts):
+    """One launch pair for the backward of several sites (sdumc_attnpool_bwd_multi) -> list of (dz, dxd, dq)."""
+    arr = (_lib.AttnPoolBwd * len(descs))()
+    res, keep = [], []
+    for i, (desc, dout) in enumerate(zip(descs, douts)):
+        V, T, nq, Dm = desc.V, desc.T, desc.nq, _lib.D
+        dev = dout.device
+        dz, dxd, dq = torch.empty(V, T, Dm, device=dev), torch.empty(V, T, Dm, device=dev), torch.empty(V, nq, Dm, device=dev)
+        need = lib.sdumc_attnpool_bwd_workspace_bytes(V, T, nq)
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        b = _lib.AttnPoolBwd()
+        b.f = desc
+        b.dout, b.dz, b.dxd, b.dq = ptr(dout), ptr(dz), ptr(dxd), ptr(dq)
+        b.workspace, b.workspace_bytes = ptr(ws), need
+        arr[i] = b
+        keep.append(ws)
+        res.append((dz, dxd, dq))
+    check(lib.sdumc_attnpool_bwd_multi(arr, len(descs), _st()), "sdumc_attnpool_bwd_multi")
+    torch.cuda.current_stream().synchronize()
+    return res
+
+
 def dropout_mask(d, streams):
     n = streams * d.samples * max(d.rows, 1) * d.width
     dev = torch.device("cuda")

@@ -257,6 +257,36 @@ def test_attnpool_fwd_bwd(ops, nq, T, shared_q):
     close(dq.sum(0, keepdim=True) if shared_q else dq, dq_ref, 1e-4)
 
 
+def test_attnpool_multi_equals_single_calls(ops):
+    """sdumc_attnpool_fwd_multi / _bwd_multi (the step's three Cross_Attention blocks in one launch pair) against one call per
+    site: bit-identical, ragged T, keep-bits masks, key-padding lengths on one site."""
+    from sdumc_amd._lib import make_dropout
+    g = torch.Generator().manual_seed(5)
+    B, S, Dm, nq = 3, 2, 256, 7
+    V = B * S
+    sites, singles, douts = [], [], []
+    for i, T in enumerate((130, 64, 37)):
+        x = dev(torch.randn(B, T, Dm, generator=g))
+        keys = dev(torch.tanh(torch.randn(V, T, Dm, generator=g)))
+        q = dev(torch.randn(V, nq, Dm, generator=g) / 4)
+        xdrop = make_dropout(True, 23 + 2 * i, 0.5, T, Dm, B, call0=4, seed=9)
+        bits = ops.dropout_bits(xdrop, S)
+        odrop = make_dropout(True, 24 + 2 * i, 0.5, nq, Dm, B, call0=4, seed=9)
+        lengths = dev(torch.tensor([T, T - 3, 5, 1, T, 7], dtype=torch.int32)) if i == 1 else None
+        kw = dict(x=x, keys=keys, q=q, nq=nq, x_samples=B, x_drop=xdrop, out_drop=odrop, lengths=lengths, _bits=bits)
+        sites.append(kw)
+        singles.append(ops.attnpool_fwd(x, keys, q, nq, x_samples=B, x_drop=xdrop, out_drop=odrop, lengths=lengths))
+        douts.append(dev(torch.randn(V, nq, Dm, generator=g)))
+    multi = ops.attnpool_fwd_multi(sites)
+    for (o1, a1, p1, _), (o2, a2, p2, _) in zip(singles, multi):
+        assert torch.equal(o1, o2) and torch.equal(a1, a2) and torch.equal(p1, p2)
+    back1 = [ops.attnpool_bwd(s[3], d, ()) for s, d in zip(singles, douts)]
+    back2 = ops.attnpool_bwd_multi([m[3] for m in multi], douts)
+    for r1, r2 in zip(back1, back2):
+        for t1, t2 in zip(r1, r2):
+            assert torch.equal(t1, t2)
+
+
 def test_losses_against_reference_goldens(ops, golden):
     g = golden("losses")
     T = lambda k: dev(torch.from_numpy(g[k]))

@@ -1,0 +1,37 @@
+"""Where the wall time of one C2 train step goes WITHOUT a profiler attached: the engine's debug marks (events on the caller's
+stream, include/sdumc_hip.h sdumc_debug_marks) averaged over a few steps.  usage: python tools/step_marks.py [--bf16]"""
+import ctypes as C
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from sdumc_amd import engine, _lib
+
+bf16 = "--bf16" in sys.argv
+dev = torch.device("cuda:0")
+flat, lay = bench.init_flat_params(engine, dev)
+step = engine.TrainStep(flat, bench.B_PER_GPU, bench.T_MOSEI, bench.DIMS, seed=2024, bf16=bf16)
+step.set_batch(*[t.to(dev) for t in bench.synthetic_shard(bench.B_PER_GPU, 0)])
+for _ in range(10):
+    step.run()
+torch.cuda.synchronize()
+_lib.lib.sdumc_debug_marks(1)
+names = ["start", "frame-level fwd done (chain A launch)", "chain fwd A done", "site-1 attention done (chain B launch)",
+         "chain fwd B done", "losses done", "chain bwd B done", "site-1 pooling bwd done (chain bwd A launch)",
+         "chain bwd A done", "frame-level bwd done (before Adam)", "Adam done"]
+acc = [0.0] * 11
+N = 20
+for _ in range(N):
+    step.run()
+    torch.cuda.synchronize()
+    ms = (C.c_float * 11)()
+    _lib.lib.sdumc_debug_marks_read(ms, 11)
+    for i in range(11):
+        acc[i] += ms[i]
+prev = 0.0
+for i, n in enumerate(names):
+    t = acc[i] / N * 1e3
+    print(f"{i:2d} {t:8.1f} us  (+{t - prev:7.1f})  {n}")
+    prev = t
