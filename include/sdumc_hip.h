@@ -569,6 +569,12 @@ int sdumc_set_background_lane(int on);
  * the first utterance-level launch, 3/4 the second, 5 after the losses, 6 after the first backward utterance-level launch, 7/8
  * around the second, 9 before Adam, 10 end); _read returns their times in ms since mark 0 (-1 = not recorded) once the caller
  * has synchronised.  Process-wide and single-threaded: a measurement aid (tools/step_marks.py), not part of the data path. */
+/* The utterance-level stages run as clustered kernels (four workgroups split every layer's columns and exchange their slices
+ * through HBM + a flag, csrc/chain_cluster.hip) whenever all their workgroups fit the device at once (2 x streams x B <= 128
+ * on MI355X) and the stream is not being captured; 0 keeps the one-workgroup-per-sample-pair kernels of csrc/chain.hip.
+ * sdumc_chain_cluster_error_() synchronises the device and returns 0 unless a cluster spin ever ran into its cap. */
+int sdumc_set_chain_cluster(int on);
+int sdumc_chain_cluster_error_(void);
 int sdumc_debug_marks(int on);
 int sdumc_debug_marks_read(float* ms, int n);
 size_t sdumc_net_workspace_bytes(const sdumc_net_dims* d);

@@ -1,0 +1,1077 @@
+// chain_cluster.hip — the four utterance-level stages of chain.hip with every layer's OUTPUT COLUMNS split over a cluster of
+// four workgroups.
+//
+// Why: in chain.hip one workgroup owns R samples and streams every weight matrix of a stage through one CU; the stage then
+// takes (bytes of weights) / (what one CU pulls out of L2, ~100 GB/s measured) whatever R is -- 104 / 69 / 66 / 100 us at C2
+// with 64 of the 256 CUs busy, a fifth of the 2.0 ms step and the part of it during which the chip idles.  Here the R samples
+// belong to a cluster of CL = 4 workgroups on 4 CUs; member j computes columns [64 j, 64 j + 64) of every 256-wide layer
+// (32-column slices of the 128-wide ones, 64-column blocks j, j + 4, .. of the 768- and 896-wide backward products), so each
+// CU streams a quarter of the weights and does a quarter of the FMAs.  After a layer (or a group of independent layers) the
+// members swap their slices:
+//
+//   * the slices go to the activation / gradient tensors in HBM that the stage writes anyway (the backward and the dW GEMMs read
+//     them), with agent-scope (sc1, write-through) stores;
+//   * s_waitcnt vmcnt(0), workgroup barrier, one agent-scope atomic add on the cluster's arrival counter, spin until it reads
+//     CL x (exchanges so far), barrier;
+//   * every member reloads the full rows into LDS with agent-scope loads.
+//
+// tools/probes/cluster_sync_probe.hip measured that hand-shake on MI355X: 1.3 us per exchange when the members share an XCD
+// (blockIdx = cluster + member * nclusters, equal modulo 8 whenever nclusters % 8 == 0), 1.6 us across XCDs, 0 stale elements
+// in 1.3e8 checked reads with and without a bandwidth-heavy kernel on another stream.  17 exchanges per step.
+//
+// Co-residency: members spin on each other, so all nclusters x CL workgroups must be resident at once: the launch refuses
+// shapes with more workgroups than CUs (V <= 128 on MI355X; sdumc_chain_cluster_ok_), and cluster launches of different
+// streams of one device are serialised with an event (two half-resident cluster kernels would deadlock each other).  A spin
+// that exceeds its cap sets an error word and lets the kernel run to its end (wrong results, no hang).
+// fp32 weights only (a 64-column slice of a bf16 row is half a cache line per lane group; the stream is no longer the bound).
+#include <mutex>
+
+#include "chain_common.h"
+
+namespace {
+
+constexpr int CL = 4;             // workgroups per cluster
+constexpr int OC = D / CL;        // column slice of a 256-wide layer
+constexpr int HC = H / CL;        // column slice of a 128-wide layer
+constexpr int PARTC = NWV * 7 * OC;   // partial-sum area of the split layers (also covers the un-split 2 x 128 tail layers)
+constexpr int SPIN_CAP = 400000;
+static_assert(PARTC >= NWV * 2 * H, "tail layers");
+
+struct Cl {
+  uint32_t* arrive;
+  uint32_t* depart;
+  int32_t* err;
+  uint32_t round;
+};
+
+__device__ __forceinline__ void st4_dev(float* p, f32x4 v) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) __hip_atomic_store(p + j, v[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ f32x4 ld4_dev(const float* p) {
+  f32x4 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = __hip_atomic_load(p + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return v;
+}
+
+// rows [row0, row0 + ROWS) of a global [.., width] tensor (written by the cluster's members in this launch) -> LDS
+template <int ROWS>
+__device__ __forceinline__ void reload_rows(float* dst_lds, int ld_dst, const float* src, int64_t ld_src, int width, int row0, int nrows) {
+  const int q = width >> 2;
+  for (int u = threadIdx.x; u < ROWS * q; u += NTHR) {
+    const int r = u / q, c = u - r * q;
+    st4(dst_lds + r * ld_dst + 4 * c, row0 + r < nrows ? ld4_dev(src + (int64_t)(row0 + r) * ld_src + 4 * c) : f32x4{0.f, 0.f, 0.f, 0.f});
+  }
+}
+
+// every member's stores of the phase are complete and every member has arrived; ends with a workgroup barrier
+__device__ __forceinline__ void cl_sync(Cl& cl, int* s_bail) {
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0 && !*s_bail) {
+    __hip_atomic_fetch_add(cl.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t want = (uint32_t)CL * (cl.round + 1u);
+    int spins = 0;
+    while (__hip_atomic_load(cl.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+      if (++spins > SPIN_CAP) {
+        *s_bail = 1;
+        __hip_atomic_store(cl.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  ++cl.round;
+  __syncthreads();
+}
+// after a member's last cl_sync: the last one to leave zeroes the counters for the next launch
+__device__ __forceinline__ void cl_exit(Cl& cl) {
+  if (threadIdx.x == 0) {
+    const uint32_t n = __hip_atomic_fetch_add(cl.depart, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (n == (uint32_t)CL - 1u) {
+      __hip_atomic_store(cl.arrive, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(cl.depart, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+// y = drop(relu(v + bias)): `col` is the layer's global output column, bias_lds the layer's staged bias row
+__device__ __forceinline__ f32x4 fwd_val(f32x4 v, const float* bias_lds, int col, bool relu, const DropRT& drop, uint32_t vrow) {
+  v += ld4(bias_lds + col);
+  if (relu) {
+    v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f);
+  }
+  if (drop.enabled) v *= drop_mask4(drop, vrow, (uint32_t)(col >> 2));
+  return v;
+}
+__device__ __forceinline__ f32x4 mask_val(f32x4 v, f32x4 y, float sc) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = y[j] > 0.f ? v[j] * sc : 0.f;
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// rows x matrix-slice for the clustered kernels.  Same contract as rxm_run (chain_common.h) for O = 32 or 64 fp32 columns,
+// re-cut for what bounds a SLICE: not the weight stream (16-64 KB per layer and member) but the chain of latencies per layer
+// (measured 1.5 us for a 2-row layer, 6 us for a 14-row one with rxm_run: half of each wave's weight rows were loaded inside
+// the k-loop with their L2 / Infinity-Cache latency exposed, and every row added shuffles and reduction rounds):
+//   * the 8 waves form RS = 2 groups; a group owns half of the rows and splits K over its 4 waves, so each wave walks
+//     twice as many weight rows (4 iterations at I = 256) and the register ring runs 4 deep: 3 iterations are issued by the
+//     previous layer's hook, the 4th under the first FMAs;
+//   * 7 (or 1) rows per wave instead of 14 (2): half the shuffles, ONE reduction round instead of two.
+// ------------------------------------------------------------------------------------------------------------------
+// RSv = 1: the 8 waves split K (2-row layers).  RSv = 2 (14-row layers): two groups of 4 waves, each owns 7 rows and splits K
+// 4 ways -- half the shuffles per wave and ONE reduction round, at the price of both groups streaming the slice.
+// The ring holds 4 iterations: a layer of <= 4 iterations per wave (every 256-deep one) is loaded WHOLE by the prefetch, which
+// the previous layer issues from its hook, so that a k-loop starts on data that has been in flight during the previous
+// layer's reduction, epilogue and barriers; longer layers (768 / 896 deep) refill a slot as soon as it has been consumed.
+template <int I, int O, int RSv>
+struct CGeom {
+  static constexpr int OG = O / 4;                 // lane groups across the slice's columns (8 or 16)
+  static constexpr int S = 64 / OG;                // rows of M covered by one wave-load (8 or 4)
+  static constexpr int MW = NWV / RSv;             // waves that split K
+  static constexpr int UNITS = I / (4 * S);
+  static constexpr int WAVES = UNITS >= MW ? MW : UNITS;
+  static constexpr int IW = I / WAVES;
+  static constexpr int ITER = IW / (4 * S);
+  static constexpr int PRE = ITER >= 4 ? 4 : ITER;   // iterations issued by the prefetch
+  static_assert(O == 32 || O == 64, "slice width");
+  static_assert(I % (4 * S * WAVES) == 0 && ITER >= 1, "k range must split evenly");
+};
+// (every index into the ring is a compile-time constant in the SOURCE -- static_for, not an unrolled loop variable: with loop
+//  indices hipcc (ROCm 7.2) kept the 16-register ring in scratch memory as soon as a hook prefetched more than two slots)
+struct CRing {
+  uint4 w[16];      // [slot][e]
+};
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (N > 0) {
+    static_for<N - 1>(f);
+    f(std::integral_constant<int, N - 1>{});
+  }
+}
+
+template <int I, int O, int RSv, int SLOT>
+__device__ __forceinline__ void cxm_load(CRing& ring, const float* mp, int j, int ldm) {
+  using G = CGeom<I, O, RSv>;
+  static_for<4>([&](auto ec) {
+    constexpr int e = decltype(ec)::value;
+    ring.w[SLOT * 4 + e] = *reinterpret_cast<const uint4*>(mp + (size_t)(j * 4 * G::S + e) * ldm);
+  });
+}
+
+template <int I, int O, int RSv>
+__device__ __forceinline__ void cxm_prefetch(CRing& ring, const float* __restrict__ M, int ldm) {
+  using G = CGeom<I, O, RSv>;
+  const int lane = threadIdx.x & 63, wg = (threadIdx.x >> 6) % G::MW;
+  if (wg < G::WAVES) {
+    const int sq = lane / G::OG, cg = lane % G::OG;
+    const float* mp = M + (size_t)(wg * G::IW + 4 * sq) * ldm + 4 * cg;
+    static_for<G::PRE>([&](auto dc) { cxm_load<I, O, RSv, decltype(dc)::value>(ring, mp, decltype(dc)::value, ldm); });
+    // every prefetch writes all 16 registers: a hook that picks between two layer shapes (`if (m < 2) PF(..) else PF14(..)`)
+    // otherwise ends in stores to DIFFERENT ring slots, SimplifyCFG sinks them into one store through a phi of two addresses,
+    // and the ring can no longer leave scratch memory (measured: every layer then took ~8 us instead of ~2)
+    static_for<16 - 4 * G::PRE>([&](auto kc) { ring.w[4 * G::PRE + decltype(kc)::value] = uint4{0u, 0u, 0u, 0u}; });
+  }
+}
+
+// in_lds: [ROWS][ld_in]; M: this member's column slice of a row-major [I][ldm] matrix; epi(r, col, v) with col in [0, O).
+// The matching prefetch is cxm_prefetch<I, O, ROWS >= 14 ? 2 : 1> (macros PF / PF14 below).
+template <int ROWS, int I, int O, class Epi, class Hook>
+__device__ __forceinline__ void cxm_run(CRing& ring, const float* in_lds, int ld_in, const float* __restrict__ M, int ldm, float* part,
+                                        Epi&& epi, Hook&& hook) {
+  constexpr int RSv = ROWS >= 14 ? 2 : 1;
+  using G = CGeom<I, O, RSv>;
+  constexpr int OG = G::OG, S = G::S, MW = G::MW, WAVES = G::WAVES, IW = G::IW, ITER = G::ITER;
+  constexpr int RG = ROWS / RSv;                   // rows per wave group
+  static_assert(ROWS % RSv == 0 && RG <= 7, "rows per group");
+  static_assert(RSv * WAVES * RG * O <= PARTC, "partial-sum area too small");
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int grp = wave / MW, wg = wave % MW;
+  const int sq = lane / OG, cg = lane % OG;
+  f32x4 acc[RG];
+#pragma unroll
+  for (int r = 0; r < RG; ++r) acc[r] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (wg < WAVES) {
+    const int i0 = wg * IW + 4 * sq;
+    const float* mp = M + (size_t)i0 * ldm + 4 * cg;
+    const float* xin = in_lds + grp * RG * ld_in + i0;
+    static_for<ITER>([&](auto jc) {
+      constexpr int j = decltype(jc)::value, sl = (j % 4) * 4;
+#pragma unroll
+      for (int r = 0; r < RG; ++r) {
+        const f32x4 x = ld4(xin + r * ld_in + j * 4 * S);
+        static_for<4>([&](auto ec) {
+          constexpr int e = decltype(ec)::value;
+          const uint4 u = ring.w[sl + e];
+          acc[r] += f32x4{__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w)} * x[e];
+        });
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (j + 4 < ITER) cxm_load<I, O, RSv, j % 4>(ring, mp, j + 4, ldm);
+    });
+#pragma unroll
+    for (int r = 0; r < RG; ++r)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        acc[r][c] += __shfl_xor(acc[r][c], 32, 64);
+        acc[r][c] += __shfl_xor(acc[r][c], 16, 64);
+        if constexpr (S == 8) acc[r][c] += __shfl_xor(acc[r][c], 8, 64);
+      }
+  }
+  hook();        // the next layer's weight rows start moving here
+  if (wg < WAVES && sq == 0) {
+#pragma unroll
+    for (int r = 0; r < RG; ++r) st4(part + ((grp * WAVES + wg) * RG + r) * O + 4 * cg, acc[r]);
+  }
+  __syncthreads();
+  for (int u = tid; u < ROWS * (O / 4); u += NTHR) {
+    const int r = u / (O / 4), cq = u - r * (O / 4);          // r = grp * RG + row within the group
+    const int g = r / RG, rr = r - g * RG;
+    f32x4 v = ld4(part + ((g * WAVES) * RG + rr) * O + 4 * cq);
+#pragma unroll
+    for (int ww = 1; ww < WAVES; ++ww) v += ld4(part + ((g * WAVES + ww) * RG + rr) * O + 4 * cq);
+    epi(r, 4 * cq, v);
+  }
+  __syncthreads();
+}
+
+// optional phase trace (sdumc_chain_cluster_trace_): workgroup 0 stamps the 100 MHz wall clock at every phase boundary
+#define TR(k) do { if (a.cl_trace && blockIdx.x == 0 && threadIdx.x == 0) a.cl_trace[k] = wall_clock64(); } while (0)
+
+#define CL_PROLOGUE()                                                                                          \
+  __shared__ int s_bail;                                                                                       \
+  const int cluster = blockIdx.x % ncl, member = blockIdx.x / ncl;                                             \
+  const int V = a.V, v0 = cluster * R, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;                    \
+  const int coff = member * OC;                                                                                \
+  Cl cl{a.cl_flags + cluster * 64, a.cl_flags + cluster * 64 + 32, a.cl_err, 0u};                              \
+  if (tid == 0) s_bail = 0;                                                                                    \
+  (void)lane; (void)wave
+
+typedef float WT;   // weights stream as fp32
+#define PF(I_, O_, ptr, ldm) cxm_prefetch<I_, O_, 1>(ring, ptr, ldm)       /* the next layer has 2 rows */
+#define PF14(I_, O_, ptr, ldm) cxm_prefetch<I_, O_, 2>(ring, ptr, ldm)     /* the next layer has 14 rows */
+
+// ------------------------------------------------------------------------------------------------------------------
+// stage A forward (model :293-332 + :85); 5 exchanges: u1, u, att1, att2, q
+// ------------------------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(NTHR) void chain_fwd_a_cl_kernel(const sdumc_chain_args a, const int ncl) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* part = sm;                              // PARTC
+  float* s_hpre = part + PARTC;                  // [3][R][256]
+  float* s_u1 = s_hpre + 3 * R * D;              // [3][R][256]
+  float* s_u = s_u1 + 3 * R * D;                 // [R][768]
+  float* s_att1 = s_u + 3 * R * D;               // [R][256]
+  float* s_att2 = s_att1 + R * D;                // [R][256]
+  float* s_alpha = s_att2 + R * D;               // [R][4]
+  float* s_qin = s_alpha + R * 4;                // [7][R][256]
+  float* s_q = s_qin + 7 * R * D;                // [R][7][256]
+  float* s_bias = s_q + 7 * R * D;               // [18][256]
+  CL_PROLOGUE();
+  TR(0);
+  const int64_t VD = (int64_t)V * D;
+  {
+    const float* bsrc[18] = {a.umlp0_b[0], a.umlp0_b[1], a.umlp0_b[2], a.umlp3_b[0], a.umlp3_b[1], a.umlp3_b[2], a.att0_b, a.att3_b,
+                             a.query_b[0], a.query_b[1], a.query_b[2], a.query_b[3], a.query_b[4], a.query_b[5], a.query_b[6],
+                             a.caq_b[0], a.caq_b[1], a.caq_b[2]};
+    for (int u = tid; u < 18 * (D / 4); u += NTHR) st4(s_bias + 4 * u, ld4(bsrc[u / (D / 4)] + 4 * (u % (D / 4))));
+  }
+  const DropRT dbase = drop_resolve(a.drop);
+  CRing ring;
+  PF(D, OC, a.umlp0_w[0] + coff, D);
+  for (int m = 0; m < 3; ++m) load_rows<R>(s_hpre + m * R * D, a.hpre + m * VD, D, D, v0, V);
+  __syncthreads();
+  // audio / text / video_mlp (model :293-295)
+#pragma unroll 1
+  for (int m = 0; m < 3; ++m) {
+    const DropRT dr = mkdrop_rt(dbase, 6 + 2 * m, 1, D);
+    float* dst = a.u1 + m * VD + (int64_t)v0 * D;
+    auto epi = [&](int r, int col, f32x4 v) {
+      col += coff;
+      if (v0 + r < V) st4_dev(dst + (int64_t)r * D + col, fwd_val(v, s_bias + m * D, col, true, dr, (uint32_t)(v0 + r)));
+    };
+    cxm_run<R, D, OC>(ring, s_hpre + m * R * D, D, a.umlp0_w[m] + coff, D, part, epi,
+                                [&] { PF(D, OC, (m < 2 ? a.umlp0_w[m + 1] : a.umlp3_w[0]) + coff, D); });
+  }
+  TR(1);
+  cl_sync(cl, &s_bail);
+  TR(2);
+  for (int m = 0; m < 3; ++m) reload_rows<R>(s_u1 + m * R * D, D, a.u1 + m * VD, D, D, v0, V);
+  __syncthreads();
+#pragma unroll 1
+  for (int m = 0; m < 3; ++m) {
+    const DropRT dr = mkdrop_rt(dbase, 7 + 2 * m, 1, D);
+    float* dst = a.u + (int64_t)v0 * 3 * D + m * D;
+    auto epi = [&](int r, int col, f32x4 v) {
+      col += coff;
+      if (v0 + r < V) st4_dev(dst + (int64_t)r * 3 * D + col, fwd_val(v, s_bias + (3 + m) * D, col, true, dr, (uint32_t)(v0 + r)));
+    };
+    cxm_run<R, D, OC>(ring, s_u1 + m * R * D, D, a.umlp3_w[m] + coff, D, part, epi, [&] {
+      if (m < 2) PF(D, OC, a.umlp3_w[m + 1] + coff, D);
+      else PF(3 * D, OC, a.att0_w + coff, D);
+    });
+  }
+  TR(3);
+  cl_sync(cl, &s_bail);
+  TR(4);
+  reload_rows<R>(s_u, 3 * D, a.u, 3 * D, 3 * D, v0, V);
+  __syncthreads();
+  // attention_mlp + fc_att (model :301-303)
+  {
+    const DropRT dr = mkdrop_rt(dbase, 12, 1, D);
+    float* dst = a.att1 + (int64_t)v0 * D;
+    auto epi = [&](int r, int col, f32x4 v) {
+      col += coff;
+      if (v0 + r < V) st4_dev(dst + (int64_t)r * D + col, fwd_val(v, s_bias + 6 * D, col, true, dr, (uint32_t)(v0 + r)));
+    };
+    cxm_run<R, 3 * D, OC>(ring, s_u, 3 * D, a.att0_w + coff, D, part, epi, [&] { PF(D, OC, a.att3_w + coff, D); });
+  }
+  TR(5);
+  cl_sync(cl, &s_bail);
+  TR(6);
+  reload_rows<R>(s_att1, D, a.att1, D, D, v0, V);
+  __syncthreads();
+  {
+    const DropRT dr = mkdrop_rt(dbase, 13, 1, D);
+    float* dst = a.att2 + (int64_t)v0 * D;
+    auto epi = [&](int r, int col, f32x4 v) {
+      col += coff;
+      if (v0 + r < V) st4_dev(dst + (int64_t)r * D + col, fwd_val(v, s_bias + 7 * D, col, true, dr, (uint32_t)(v0 + r)));
+    };
+    cxm_run<R, D, OC>(ring, s_att1, D, a.att3_w + coff, D, part, epi, [&] { PF(D, OC, a.query_w[0] + coff, D); });
+  }
+  TR(7);
+  cl_sync(cl, &s_bail);
+  TR(8);
+  reload_rows<R>(s_att2, D, a.att2, D, D, v0, V);
+  __syncthreads();
+  for (int p = wave; p < 3 * R; p += NWV) {          // alpha[r][j] = att2[r] . W[j] + b[j]   (every member, redundantly)
+    const int r = p / 3, j = p - 3 * r;
+    const float s = wave_sum(dot4(ld4(s_att2 + r * D + 4 * lane), ld4(a.fc_att_w + j * D + 4 * lane)));
+    if (lane == 0) {
+      const float al = s + a.fc_att_b[j];
+      s_alpha[r * 4 + j] = al;
+      if (v0 + r < V && member == 0) a.alpha[(int64_t)(v0 + r) * 3 + j] = al;
+    }
+  }
+  __syncthreads();
+  // fusion algebra (model :305-320): fused, a+t, t+v, a+v, a, t, v   (LDS: every member; HBM: the owner of the column slice)
+  for (int u = tid; u < R * (D / 4); u += NTHR) {
+    const int r = u / (D / 4), c = 4 * (u - r * (D / 4));
+    const f32x4 ua = ld4(s_u + r * 3 * D + c), ut = ld4(s_u + r * 3 * D + D + c), uv = ld4(s_u + r * 3 * D + 2 * D + c);
+    const float aa = s_alpha[r * 4], at = s_alpha[r * 4 + 1], av = s_alpha[r * 4 + 2];
+    f32x4 o[7] = {ua * aa + ut * at + uv * av, ua * aa + ut * at, ut * at + uv * av, ua * aa + uv * av, ua, ut, uv};
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      st4(s_qin + (i * R + r) * D + c, o[i]);
+      if (v0 + r < V && c / OC == member) st4(a.qin + i * VD + (int64_t)(v0 + r) * D + c, o[i]);
+    }
+  }
+  __syncthreads();
+  // the 7 query MLPs -> multi_query [V, 7, 256] (model :324-332); text_hidden = query 5 (model :329, :370)
+#pragma unroll 1
+  for (int i = 0; i < 7; ++i) {
+    const DropRT dr = mkdrop_rt(dbase, 14 + i, 1, D);
+    float* dst = a.q + (int64_t)v0 * NQ * D + i * D;
+    float* th = (i == 5 && a.o_text_hidden) ? a.o_text_hidden + (int64_t)v0 * D : nullptr;
+    auto epi = [&](int r, int col, f32x4 v) {
+      col += coff;
+      if (v0 + r < V) {
+        const f32x4 y = fwd_val(v, s_bias + (8 + i) * D, col, true, dr, (uint32_t)(v0 + r));
+        st4_dev(dst + (int64_t)r * NQ * D + col, y);
+        if (th) st4(th + (int64_t)r * D + col, y);
+      }
+    };
+    cxm_run<R, D, OC>(ring, s_qin + i * R * D, D, a.query_w[i] + coff, D, part, epi,
+                                [&] { if (i < 6) PF(D, OC, a.query_w[i + 1] + coff, D); else PF14(D, OC, a.caq_w[0] + coff, D); });
+  }
+  TR(9);
+  cl_sync(cl, &s_bail);
+  TR(10);
+  reload_rows<R>(s_q, NQ * D, a.q, NQ * D, NQ * D, v0, V);
+  __syncthreads();
+  cl_exit(cl);
+  // query_proj of the three Cross_Attention blocks (model :85): rows = (sample, query)
+#pragma unroll 1
+  for (int m = 0; m < 3; ++m) {
+    float* dst = a.qp + ((int64_t)m * V + v0) * NQ * D;
+    auto epi = [&](int r, int col, f32x4 v) {
+      col += coff;
+      if (v0 + r / NQ < V) st4(dst + (int64_t)r * D + col, v + ld4(s_bias + (15 + m) * D + col));
+    };
+    cxm_run<NQ * R, D, OC>(ring, s_q, D, a.caq_w[m] + coff, D, part, epi, [&] { if (m < 2) PF14(D, OC, a.caq_w[m + 1] + coff, D); });
+  }
+  TR(31);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// stage B forward (model :338-368); 4 exchanges: c1, c, e1, e2.  The tail (beta, cross_fused_feat, fc_out_v,
+// orgin_linear_change: 2 x <= 128 columns) is member 0's alone.
+// ------------------------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(NTHR) void chain_fwd_b_cl_kernel(const sdumc_chain_args a, const int ncl) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* part = sm;
+  float* s_x = part + PARTC;                     // [3][7R][256]  ca_out, then c1
+  float* s_c = s_x + 3 * NQ * R * D;             // [3][7R][128]
+  float* s_h = s_c + 3 * NQ * R * H;             // [R][896]
+  float* s_e1 = s_h + R * NQ * H;                // [R][256]
+  float* s_e2 = s_e1 + R * D;                    // [R][128]
+  float* s_z = s_e2 + R * H;                     // [R][128]
+  float* s_r1 = s_z + R * H;                     // [R][64]
+  float* s_small = s_r1 + R * RD;                // alpha [R][4], beta [R][8]
+  float* s_bias = s_small + 12 * R;              // cmlp0 [3][256], cmlp3 [3][128], catt0 [256], catt3 [128], rnc0 [64], rnc2 [64]
+  CL_PROLOGUE();
+  TR(0);
+  const int64_t VQ = (int64_t)V * NQ;
+  const int hoff = member * HC;
+  {
+    for (int u = tid; u < 3 * (D / 4); u += NTHR) st4(s_bias + 4 * u, ld4(a.cmlp0_b[u / (D / 4)] + 4 * (u % (D / 4))));
+    for (int u = tid; u < 3 * (H / 4); u += NTHR) st4(s_bias + 3 * D + 4 * u, ld4(a.cmlp3_b[u / (H / 4)] + 4 * (u % (H / 4))));
+    for (int u = tid; u < D / 4; u += NTHR) st4(s_bias + 3 * D + 3 * H + 4 * u, ld4(a.catt0_b + 4 * u));
+    for (int u = tid; u < H / 4; u += NTHR) st4(s_bias + 4 * D + 3 * H + 4 * u, ld4(a.catt3_b + 4 * u));
+    for (int u = tid; u < RD / 4; u += NTHR) {
+      st4(s_bias + 4 * D + 4 * H + 4 * u, ld4(a.rnc0_b + 4 * u));
+      st4(s_bias + 4 * D + 4 * H + RD + 4 * u, ld4(a.rnc2_b + 4 * u));
+    }
+  }
+  const DropRT dbase = drop_resolve(a.drop);
+  CRing ring;
+  PF14(D, OC, a.cmlp0_w[0] + coff, D);
+  for (int u = tid; u < R * 3; u += NTHR) {
+    const int r = u / 3, j = u - 3 * r;
+    s_small[r * 4 + j] = v0 + r < V ? a.alpha[(int64_t)(v0 + r) * 3 + j] : 0.f;
+  }
+  for (int m = 0; m < 3; ++m) load_rows<NQ * R>(s_x + m * NQ * R * D, a.ca_out + (int64_t)m * VQ * D, D, D, v0 * NQ, V * NQ);
+  __syncthreads();
+  // cross_{audio,text,video}_mlp (model :338-340), rows = (sample, query)
+#pragma unroll 1
+  for (int m = 0; m < 3; ++m) {
+    const DropRT dr = mkdrop_rt(dbase, 27 + 2 * m, NQ, D);
+    float* dst = a.c1 + ((int64_t)m * VQ + (int64_t)v0 * NQ) * D;
+    auto epi = [&](int r, int col, f32x4 v) {
+      col += coff;
+      if (v0 * NQ + r < V * NQ) st4_dev(dst + (int64_t)r * D + col, fwd_val(v, s_bias + m * D, col, true, dr, (uint32_t)(v0 * NQ + r)));
+    };
+    cxm_run<NQ * R, D, OC>(ring, s_x + m * NQ * R * D, D, a.cmlp0_w[m] + coff, D, part, epi, [&] {
+      if (m < 2) PF14(D, OC, a.cmlp0_w[m + 1] + coff, D);
+      else PF14(D, HC, a.cmlp3_w[0] + hoff, H);
+    });
+  }
+  TR(1);
+  cl_sync(cl, &s_bail);
+  TR(2);
+  for (int m = 0; m < 3; ++m) reload_rows<NQ * R>(s_x + m * NQ * R * D, D, a.c1 + (int64_t)m * VQ * D, D, D, v0 * NQ, V * NQ);
+  __syncthreads();
+#pragma unroll 1
+  for (int m = 0; m < 3; ++m) {
+    const DropRT dr = mkdrop_rt(dbase, 28 + 2 * m, NQ, H);
+    float* dst = a.c + ((int64_t)m * VQ + (int64_t)v0 * NQ) * H;
+    float* ct = (m == 1 && a.o_cross_text) ? a.o_cross_text + (int64_t)v0 * NQ * H : nullptr;
+    auto epi = [&](int r, int col, f32x4 v) {
+      col += hoff;
+      if (v0 * NQ + r < V * NQ) {
+        const f32x4 y = fwd_val(v, s_bias + 3 * D + m * H, col, true, dr, (uint32_t)(v0 * NQ + r));
+        st4_dev(dst + (int64_t)r * H + col, y);
+        if (ct) st4(ct + (int64_t)r * H + col, y);
+      }
+    };
+    cxm_run<NQ * R, D, HC>(ring, s_x + m * NQ * R * D, D, a.cmlp3_w[m] + hoff, H, part, epi, [&] {
+      if (m < 2) PF14(D, HC, a.cmlp3_w[m + 1] + hoff, H);
+      else PF(NQ * H, OC, a.catt0_w + coff, D);
+    });
+  }
+  TR(3);
+  cl_sync(cl, &s_bail);
+  TR(4);
+  for (int m = 0; m < 3; ++m) reload_rows<NQ * R>(s_c + m * NQ * R * H, H, a.c + (int64_t)m * VQ * H, H, H, v0 * NQ, V * NQ);
+  __syncthreads();
+  // modality-weighted sum (model :346-349): h[r][i][:] = sum_m alpha[r][m] c_m[r][i][:]
+  for (int u = tid; u < R * NQ * (H / 4); u += NTHR) {
+    const int ri = u / (H / 4), c = 4 * (u - ri * (H / 4)), r = ri / NQ;
+    const f32x4 hv = ld4(s_c + ri * H + c) * s_small[r * 4] + ld4(s_c + (NQ * R + ri) * H + c) * s_small[r * 4 + 1] +
+                     ld4(s_c + (2 * NQ * R + ri) * H + c) * s_small[r * 4 + 2];
+    st4(s_h + ri * H + c, hv);
+    if (v0 + r < V && member == 0) st4(a.h + ((int64_t)v0 * NQ + ri) * H + c, hv);
+  }
+  __syncthreads();
+  // cross_attention_mlp + cross_fc_att (model :352-354)
+  {
+    const DropRT dr = mkdrop_rt(dbase, 33, 1, D);
+    float* dst = a.e1 + (int64_t)v0 * D;
+    auto epi = [&](int r, int col, f32x4 v) {
+      col += coff;
+      if (v0 + r < V) st4_dev(dst + (int64_t)r * D + col, fwd_val(v, s_bias + 3 * D + 3 * H, col, true, dr, (uint32_t)(v0 + r)));
+    };
+    cxm_run<R, NQ * H, OC>(ring, s_h, NQ * H, a.catt0_w + coff, D, part, epi, [&] { PF(D, HC, a.catt3_w + hoff, H); });
+  }
+  TR(5);
+  cl_sync(cl, &s_bail);
+  TR(6);
+  reload_rows<R>(s_e1, D, a.e1, D, D, v0, V);
+  __syncthreads();
+  {
+    const DropRT dr = mkdrop_rt(dbase, 34, 1, H);
+    float* dst = a.e2 + (int64_t)v0 * H;
+    auto epi = [&](int r, int col, f32x4 v) {
+      col += hoff;
+      if (v0 + r < V) st4_dev(dst + (int64_t)r * H + col, fwd_val(v, s_bias + 4 * D + 3 * H, col, true, dr, (uint32_t)(v0 + r)));
+    };
+    cxm_run<R, D, HC>(ring, s_e1, D, a.catt3_w + hoff, H, part, epi, [] {});
+  }
+  TR(7);
+  cl_sync(cl, &s_bail);
+  TR(8);
+  cl_exit(cl);
+  if (member != 0) return;
+  TR(30);
+  reload_rows<R>(s_e2, H, a.e2, H, H, v0, V);
+  __syncthreads();
+  for (int p = wave; p < NQ * R; p += NWV) {          // beta[r][i] = e2[r] . W[i] + b[i]
+    const int r = p / NQ, i = p - NQ * r;
+    float s = lane < H / 4 ? dot4(ld4(s_e2 + r * H + 4 * lane), ld4(a.cfa_w + i * H + 4 * lane)) : 0.f;
+    s = wave_sum(s);
+    if (lane == 0) {
+      const float bt = s + a.cfa_b[i];
+      s_small[4 * R + r * 8 + i] = bt;
+      if (v0 + r < V) a.beta[(int64_t)(v0 + r) * NQ + i] = bt;
+    }
+  }
+  __syncthreads();
+  // cross_fused_feat (model :356-358), fc_out_v (model :364)
+  for (int u = tid; u < R * (H / 4); u += NTHR) {
+    const int r = u / (H / 4), c = 4 * (u - r * (H / 4));
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) acc += ld4(s_h + (r * NQ + i) * H + c) * s_small[4 * R + r * 8 + i];
+    st4(s_z + r * H + c, acc);
+    if (v0 + r < V) {
+      st4(a.z + (int64_t)(v0 + r) * H + c, acc);
+      if (a.o_fused) st4(a.o_fused + (int64_t)(v0 + r) * H + c, acc);
+    }
+  }
+  __syncthreads();
+  for (int r = wave; r < R; r += NWV) {
+    float s = lane < H / 4 ? dot4(ld4(s_z + r * H + 4 * lane), ld4(a.fcv_w + 4 * lane)) : 0.f;
+    s = wave_sum(s);
+    if (lane == 0 && v0 + r < V) {
+      const float y = s + a.fcv_b[0];
+      a.vals[v0 + r] = y;
+      if (a.o_vals) a.o_vals[v0 + r] = y;
+    }
+  }
+  // orgin_linear_change (model :246-250, :368): Linear -> ReLU -> Linear
+  {
+    FwdEpi e{s_bias + 4 * D + 4 * H, s_r1, RD, a.r1 + (int64_t)v0 * RD, RD, true, DropRT{}, 0u, 0u};
+    auto epi = [&](int r, int col, f32x4 v) { if (v0 + r < V) e(r, col, v); else st4(s_r1 + r * RD + col, f32x4{0.f, 0.f, 0.f, 0.f}); };
+    rows_x_matrix<R, H, RD>(s_z, H, a.rnc0_w, RD, part, epi);
+  }
+  {
+    FwdEpi e{s_bias + 4 * D + 4 * H + RD, nullptr, 0, a.r + (int64_t)v0 * RD, RD, false, DropRT{}, 0u, 0u};
+    float* ro = a.o_rnc ? a.o_rnc + (int64_t)v0 * RD : nullptr;
+    const float* b2 = s_bias + 4 * D + 4 * H + RD;
+    auto epi = [&](int r, int col, f32x4 v) {
+      if (v0 + r < V) {
+        e(r, col, v);
+        if (ro) st4(ro + (int64_t)r * RD + col, v + ld4(b2 + col));
+      }
+    };
+    rows_x_matrix<R, RD, RD>(s_r1, RD, a.rnc2_w, RD, part, epi);
+  }
+  TR(31);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// stage B backward; 3 exchanges: d_e1, d_h, d_c1.  The head (orgin_linear_change, zpool, cross_fc_att backward: <= 128
+// columns) is computed by every member, written by member 0.
+// ------------------------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(NTHR) void chain_bwd_b_cl_kernel(const sdumc_chain_args a, const int ncl) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* part = sm;
+  float* s_g = part + PARTC;                     // [R][64]   d_rnc
+  float* s_r1 = s_g + R * RD;                    // [R][64]   saved r1, then d_r1
+  float* s_dz = s_r1 + R * RD;                   // [R][128]  d_z, then d_e2
+  float* s_h = s_dz + R * H;                     // [R][896]  saved h
+  float* s_dh = s_h + R * NQ * H;                // [R][896]
+  float* s_e2 = s_dh + R * NQ * H;               // [R][128]  saved e2
+  float* s_e1 = s_e2 + R * H;                    // [R][256]  saved e1, then d_e1
+  float* s_dc = s_e1 + R * D;                    // [3][7R][128] d_c
+  float* s_c1 = s_dc + 3 * NQ * R * H;           // [3][7R][256] saved c1, then d_c1
+  float* s_small = s_c1 + 3 * NQ * R * D;        // beta [R][8], d_beta [R][8], alpha [R][4], d_vals [R]
+  CL_PROLOGUE();
+  TR(0);
+  const int64_t VQ = (int64_t)V * NQ;
+  const float sc = a.relu_scale;
+  const bool wr = member == 0;
+  float* s_beta = s_small;
+  float* s_dbeta = s_small + 8 * R;
+  float* s_alpha = s_small + 16 * R;
+  float* s_dvals = s_small + 20 * R;
+
+  CRing ring;
+  PF(H, OC, a.catt3_w + coff, D);
+  if (a.g_rnc) load_rows<R>(s_g, a.g_rnc, RD, RD, v0, V);
+  else for (int u = tid; u < R * RD; u += NTHR) s_g[u] = 0.f;
+  load_rows<R>(s_r1, a.r1, RD, RD, v0, V);
+  load_rows<R>(s_h, a.h, NQ * H, NQ * H, v0, V);
+  load_rows<R>(s_e2, a.e2, H, H, v0, V);
+  load_rows<R>(s_e1, a.e1, D, D, v0, V);
+  for (int m = 0; m < 3; ++m) load_rows<NQ * R>(s_c1 + m * NQ * R * D, a.c1 + (int64_t)m * VQ * D, D, D, v0 * NQ, V * NQ);
+  for (int u = tid; u < R * 8; u += NTHR) {
+    const int r = u >> 3, i = u & 7;
+    s_beta[u] = (i < NQ && v0 + r < V) ? a.beta[(int64_t)(v0 + r) * NQ + i] : 0.f;
+    if (i < 3) s_alpha[r * 4 + i] = v0 + r < V ? a.alpha[(int64_t)(v0 + r) * 3 + i] : 0.f;
+    if (i == 0) s_dvals[r] = (a.g_vals && v0 + r < V) ? a.g_vals[v0 + r] : 0.f;
+  }
+  __syncthreads();
+  // 12'. orgin_linear_change backward: d_r1 = (d_rnc W2) [r1 > 0] ; d_z = d_r1 W0 + d_vals w_v + d_fused
+  {
+    BwdEpi e{nullptr, 0, s_r1, RD, 1.0f, s_r1, RD, wr ? a.d_r1 + (int64_t)v0 * RD : nullptr, RD};
+    auto epi = [&](int r, int col, f32x4 v) { if (v0 + r < V) e(r, col, v); else st4(s_r1 + r * RD + col, f32x4{0.f, 0.f, 0.f, 0.f}); };
+    rows_x_matrix<R, RD, RD>(s_g, RD, a.rnc2_w, RD, part, epi);
+  }
+  {
+    const float* gf = a.g_fused;
+    const float* wv = a.fcv_w;
+    float* dzg = a.d_z;
+    auto epi = [&](int r, int col, f32x4 v) {
+      v += ld4(wv + col) * s_dvals[r];
+      if (gf && v0 + r < V) v += ld4(gf + (int64_t)(v0 + r) * H + col);
+      if (v0 + r >= V) v = f32x4{0.f, 0.f, 0.f, 0.f};
+      st4(s_dz + r * H + col, v);
+      if (v0 + r < V && wr) st4(dzg + (int64_t)(v0 + r) * H + col, v);
+    };
+    rows_x_matrix<R, RD, H>(s_r1, RD, a.rnc0_w, H, part, epi);
+  }
+  // zpool backward: d_h[i] = beta_i d_z ; d_beta_i = <d_z, h_i>
+  for (int u = tid; u < R * NQ * (H / 4); u += NTHR) {
+    const int ri = u / (H / 4), c = 4 * (u - ri * (H / 4)), r = ri / NQ, i = ri - r * NQ;
+    st4(s_dh + ri * H + c, ld4(s_dz + r * H + c) * s_beta[r * 8 + i]);
+  }
+  for (int p = wave; p < NQ * R; p += NWV) {
+    const int r = p / NQ, i = p - NQ * r;
+    float s = lane < H / 4 ? dot4(ld4(s_dz + r * H + 4 * lane), ld4(s_h + (r * NQ + i) * H + 4 * lane)) : 0.f;
+    s = wave_sum(s);
+    if (lane == 0) {
+      s_dbeta[r * 8 + i] = s;
+      if (v0 + r < V && wr) a.d_beta[(int64_t)(v0 + r) * NQ + i] = s;
+    }
+  }
+  __syncthreads();
+  // 11'. cross_fc_att: d_e2 = (d_beta W_cfa) [e2 > 0] s
+  for (int u = tid; u < R * (H / 4); u += NTHR) {
+    const int r = u / (H / 4), c = 4 * (u - r * (H / 4));
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) g += ld4(a.cfa_w + i * H + c) * s_dbeta[r * 8 + i];
+    g = mask_val(g, ld4(s_e2 + r * H + c), sc);
+    if (v0 + r < V && wr) st4(a.d_e2 + (int64_t)(v0 + r) * H + c, g);
+    st4(s_dz + r * H + c, g);        // d_z is no longer needed in LDS: the slot now holds d_e2
+  }
+  __syncthreads();
+  // cross_attention_mlp.3: d_e1 = (d_e2 W) [e1 > 0] s
+  {
+    float* dst = a.d_e1 + (int64_t)v0 * D;
+    auto epi = [&](int r, int col, f32x4 v) {
+      col += coff;
+      if (v0 + r < V) st4_dev(dst + (int64_t)r * D + col, mask_val(v, ld4(s_e1 + r * D + col), sc));
+    };
+    cxm_run<R, H, OC>(ring, s_dz, H, a.catt3_w + coff, D, part, epi, [&] { PF(D, OC, a.catt0_w + member * OC, NQ * H); });
+  }
+  TR(1);
+  cl_sync(cl, &s_bail);
+  TR(2);
+  reload_rows<R>(s_e1, D, a.d_e1, D, D, v0, V);
+  __syncthreads();
+  // .0: d_h += d_e1 W   (896 columns = 14 blocks of 64: member j takes blocks j, j + 4, ..)
+#pragma unroll 1
+  for (int blk = member; blk < 14; blk += CL) {
+    float* dst = a.d_h + (int64_t)v0 * NQ * H;
+    const int boff = blk * OC;
+    auto epi = [&](int r, int col, f32x4 v) {
+      col += boff;
+      if (v0 + r < V) st4_dev(dst + (int64_t)r * NQ * H + col, v + ld4(s_dh + r * NQ * H + col));
+    };
+    cxm_run<R, D, OC>(ring, s_e1, D, a.catt0_w + boff, NQ * H, part, epi, [&] {
+      if (blk + CL < 14) PF(D, OC, a.catt0_w + boff + CL * OC, NQ * H);
+      else PF14(H, OC, a.cmlp3_w[0] + coff, D);
+    });
+  }
+  TR(3);
+  cl_sync(cl, &s_bail);
+  TR(4);
+  reload_rows<R>(s_dh, NQ * H, a.d_h, NQ * H, NQ * H, v0, V);
+  __syncthreads();
+  // 10'. modality-weighted sum backward (every member; HBM by member 0)
+#pragma unroll 1
+  for (int m = 0; m < 3; ++m) {
+    float* s_dcm = s_dc + m * NQ * R * H;
+    for (int u = tid; u < R * NQ * (H / 4); u += NTHR) {
+      const int ri = u / (H / 4), c = 4 * (u - ri * (H / 4)), r = ri / NQ;
+      const bool live = v0 + r < V;
+      f32x4 cm = {0.f, 0.f, 0.f, 0.f}, g = ld4(s_dh + ri * H + c);
+      if (live) cm = ld4(a.c + ((int64_t)m * VQ + (int64_t)v0 * NQ + ri) * H + c);
+      part[u] = dot4(g, cm);
+      g = g * s_alpha[r * 4 + m];
+      if (m == 1 && a.g_cross_text && live) g += ld4(a.g_cross_text + ((int64_t)v0 * NQ + ri) * H + c);
+      g = mask_val(g, cm, sc);
+      st4(s_dcm + ri * H + c, g);
+      if (live && wr) st4(a.d_c + ((int64_t)m * VQ + (int64_t)v0 * NQ + ri) * H + c, g);
+    }
+    __syncthreads();
+    for (int r = wave; r < R; r += NWV) {
+      float s = 0.f;
+      for (int k = lane; k < NQ * (H / 4); k += 64) s += part[r * NQ * (H / 4) + k];
+      s = wave_sum(s);
+      if (lane == 0 && v0 + r < V && wr) a.d_alpha[(int64_t)(v0 + r) * 3 + m] = s;
+    }
+    __syncthreads();
+  }
+  // 9'. cross_*_mlp.3: d_c1 = (d_c W3) [c1 > 0] s
+#pragma unroll 1
+  for (int m = 0; m < 3; ++m) {
+    float* dst = a.d_c1 + ((int64_t)m * VQ + (int64_t)v0 * NQ) * D;
+    const float* y = s_c1 + m * NQ * R * D;
+    auto epi = [&](int r, int col, f32x4 v) {
+      col += coff;
+      if (v0 * NQ + r < V * NQ) st4_dev(dst + (int64_t)r * D + col, mask_val(v, ld4(y + r * D + col), sc));
+    };
+    cxm_run<NQ * R, H, OC>(ring, s_dc + m * NQ * R * H, H, a.cmlp3_w[m] + coff, D, part, epi, [&] {
+      if (m < 2) PF14(H, OC, a.cmlp3_w[m + 1] + coff, D);
+      else PF14(D, OC, a.cmlp0_w[0] + coff, D);
+    });
+  }
+  TR(5);
+  cl_sync(cl, &s_bail);
+  TR(6);
+  cl_exit(cl);
+  for (int m = 0; m < 3; ++m) reload_rows<NQ * R>(s_c1 + m * NQ * R * D, D, a.d_c1 + (int64_t)m * VQ * D, D, D, v0 * NQ, V * NQ);
+  __syncthreads();
+  //     .0: d_ca_out = d_c1 W0
+#pragma unroll 1
+  for (int m = 0; m < 3; ++m) {
+    float* dst = a.d_ca_out + ((int64_t)m * VQ + (int64_t)v0 * NQ) * D;
+    auto epi = [&](int r, int col, f32x4 v) {
+      col += coff;
+      if (v0 * NQ + r < V * NQ) st4(dst + (int64_t)r * D + col, v);
+    };
+    cxm_run<NQ * R, D, OC>(ring, s_c1 + m * NQ * R * D, D, a.cmlp0_w[m] + coff, D, part, epi,
+                                     [&] { if (m < 2) PF14(D, OC, a.cmlp0_w[m + 1] + coff, D); });
+  }
+  TR(31);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// stage A backward; 6 exchanges: d_q, d_qin, d_att1, d_u, d_u1 (+ none for d_hpre, the stage's output)
+// ------------------------------------------------------------------------------------------------------------------
+template <int R>
+__global__ __launch_bounds__(NTHR) void chain_bwd_a_cl_kernel(const sdumc_chain_args a, const int ncl) {
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* part = sm;
+  float* s_x = part + PARTC;                     // [3][7R][256]  d_qp
+  float* s_dq = s_x + 3 * NQ * R * D;            // [R][7][256]
+  float* s_dqin = s_dq + NQ * R * D;             // [7][R][256]
+  float* s_u = s_dqin + NQ * R * D;              // [R][768]  saved u
+  float* s_du = s_u + 3 * R * D;                 // [R][768]
+  float* s_a2 = s_du + 3 * R * D;                // [R][256]  saved att2, then d_att2
+  float* s_a1 = s_a2 + R * D;                    // [R][256]  saved att1, then d_att1
+  float* s_u1 = s_a1 + R * D;                    // [3][R][256] saved u1, then d_u1
+  float* s_small = s_u1 + 3 * R * D;             // alpha [R][4], d_alpha [R][4]
+  CL_PROLOGUE();
+  TR(0);
+  const int64_t VD = (int64_t)V * D, VQ = (int64_t)V * NQ;
+  const float sc = a.relu_scale;
+  const bool wr = member == 0;
+  float* s_alpha = s_small;
+  float* s_dalpha = s_small + 4 * R;
+
+  CRing ring;
+  PF14(D, OC, a.caq_w[0] + coff, D);
+  load_rows<R>(s_u, a.u, 3 * D, 3 * D, v0, V);
+  load_rows<R>(s_a2, a.att2, D, D, v0, V);
+  load_rows<R>(s_a1, a.att1, D, D, v0, V);
+  for (int m = 0; m < 3; ++m) load_rows<R>(s_u1 + m * R * D, a.u1 + m * VD, D, D, v0, V);
+  for (int m = 0; m < 3; ++m) load_rows<NQ * R>(s_x + m * NQ * R * D, a.d_qp + (int64_t)m * VQ * D, D, D, v0 * NQ, V * NQ);
+  for (int u = tid; u < R * 3; u += NTHR) {
+    const int r = u / 3, j = u - 3 * r;
+    s_alpha[r * 4 + j] = v0 + r < V ? a.alpha[(int64_t)(v0 + r) * 3 + j] : 0.f;
+    s_dalpha[r * 4 + j] = v0 + r < V ? a.d_alpha[(int64_t)(v0 + r) * 3 + j] : 0.f;
+  }
+  __syncthreads();
+  // 7'. query_proj: d_q = sum_m d_qp_m W_q[m]  (this member's columns, accumulated in LDS over the three modalities)
+#pragma unroll 1
+  for (int m = 0; m < 3; ++m) {
+    auto epi = [&](int r, int col, f32x4 v) {
+      col += coff;
+      if (m > 0) v += ld4(s_dq + r * D + col);
+      st4(s_dq + r * D + col, v);
+    };
+    cxm_run<NQ * R, D, OC>(ring, s_x + m * NQ * R * D, D, a.caq_w[m] + coff, D, part, epi,
+                                     [&] { if (m < 2) PF14(D, OC, a.caq_w[m + 1] + coff, D); else PF(D, OC, a.query_w[0] + coff, D); });
+  }
+  // 6'. + the external gradient of text_hidden (= query 5), ReLU/dropout mask of q -> d_q (pre-activation)
+  for (int u = tid; u < R * NQ * (OC / 4); u += NTHR) {
+    const int ri = u / (OC / 4), c = coff + 4 * (u - ri * (OC / 4)), r = ri / NQ, i = ri - r * NQ;
+    f32x4 g = ld4(s_dq + ri * D + c);
+    const bool live = v0 + r < V;
+    if (i == 5 && a.g_text_hidden && live) g += ld4(a.g_text_hidden + (int64_t)(v0 + r) * D + c);
+    f32x4 y = {0.f, 0.f, 0.f, 0.f};
+    if (live) y = ld4(a.q + ((int64_t)(v0 + r) * NQ + i) * D + c);
+    g = mask_val(g, y, sc);
+    if (live) st4_dev(a.d_q + ((int64_t)(v0 + r) * NQ + i) * D + c, g);
+  }
+  TR(1);
+  cl_sync(cl, &s_bail);
+  TR(2);
+  reload_rows<R>(s_dq, NQ * D, a.d_q, NQ * D, NQ * D, v0, V);
+  __syncthreads();
+#pragma unroll 1
+  for (int i = 0; i < 7; ++i) {
+    float* dst = a.d_qin + i * VD + (int64_t)v0 * D;
+    auto epi = [&](int r, int col, f32x4 v) {
+      col += coff;
+      if (v0 + r < V) st4_dev(dst + (int64_t)r * D + col, v);
+    };
+    cxm_run<R, D, OC>(ring, s_dq + i * D, NQ * D, a.query_w[i] + coff, D, part, epi,
+                                [&] { PF(D, OC, (i < 6 ? a.query_w[i + 1] : a.att3_w) + coff, D); });
+  }
+  TR(3);
+  cl_sync(cl, &s_bail);
+  TR(4);
+  for (int i = 0; i < 7; ++i) reload_rows<R>(s_dqin + i * R * D, D, a.d_qin + i * VD, D, D, v0, V);
+  __syncthreads();
+  // 5'. fusion algebra backward: d_u (fusion part), d_alpha += <g_m, u_m>   (every member; HBM by member 0)
+  for (int u = tid; u < R * (D / 4); u += NTHR) {
+    const int r = u / (D / 4), c = 4 * (u - r * (D / 4));
+    const f32x4 df = ld4(s_dqin + (0 * R + r) * D + c), dfat = ld4(s_dqin + (1 * R + r) * D + c),
+                dftv = ld4(s_dqin + (2 * R + r) * D + c), dfav = ld4(s_dqin + (3 * R + r) * D + c);
+    const f32x4 ga = df + dfat + dfav, gt = df + dfat + dftv, gv = df + dftv + dfav;
+    const float aa = s_alpha[r * 4], at = s_alpha[r * 4 + 1], av = s_alpha[r * 4 + 2];
+    st4(s_du + r * 3 * D + c, ga * aa + ld4(s_dqin + (4 * R + r) * D + c));
+    st4(s_du + r * 3 * D + D + c, gt * at + ld4(s_dqin + (5 * R + r) * D + c));
+    st4(s_du + r * 3 * D + 2 * D + c, gv * av + ld4(s_dqin + (6 * R + r) * D + c));
+    part[(r * 3 + 0) * (D / 4) + (c >> 2)] = dot4(ga, ld4(s_u + r * 3 * D + c));
+    part[(r * 3 + 1) * (D / 4) + (c >> 2)] = dot4(gt, ld4(s_u + r * 3 * D + D + c));
+    part[(r * 3 + 2) * (D / 4) + (c >> 2)] = dot4(gv, ld4(s_u + r * 3 * D + 2 * D + c));
+  }
+  __syncthreads();
+  for (int p = wave; p < 3 * R; p += NWV) {
+    const float s = wave_sum(part[p * (D / 4) + lane]);
+    if (lane == 0) {
+      const int r = p / 3, j = p - 3 * r;
+      const float da = s_dalpha[r * 4 + j] + s;
+      s_dalpha[r * 4 + j] = da;
+      if (v0 + r < V && wr) a.d_alpha[(int64_t)(v0 + r) * 3 + j] = da;      // final d_alpha: what the fc_att dW GEMM reads
+    }
+  }
+  __syncthreads();
+  // 4'. fc_att: d_att2 = (d_alpha W_fc) [att2 > 0] s
+  for (int u = tid; u < R * (D / 4); u += NTHR) {
+    const int r = u / (D / 4), c = 4 * (u - r * (D / 4));
+    f32x4 g = ld4(a.fc_att_w + c) * s_dalpha[r * 4] + ld4(a.fc_att_w + D + c) * s_dalpha[r * 4 + 1] +
+              ld4(a.fc_att_w + 2 * D + c) * s_dalpha[r * 4 + 2];
+    g = mask_val(g, ld4(s_a2 + r * D + c), sc);
+    st4(s_a2 + r * D + c, g);
+    if (v0 + r < V && wr) st4(a.d_att2 + (int64_t)(v0 + r) * D + c, g);
+  }
+  __syncthreads();
+  //     attention_mlp.3: d_att1 = (d_att2 W) [att1 > 0] s
+  {
+    float* dst = a.d_att1 + (int64_t)v0 * D;
+    auto epi = [&](int r, int col, f32x4 v) {
+      col += coff;
+      if (v0 + r < V) st4_dev(dst + (int64_t)r * D + col, mask_val(v, ld4(s_a1 + r * D + col), sc));
+    };
+    cxm_run<R, D, OC>(ring, s_a2, D, a.att3_w + coff, D, part, epi, [&] { PF(D, OC, a.att0_w + member * OC, 3 * D); });
+  }
+  TR(5);
+  cl_sync(cl, &s_bail);
+  TR(6);
+  reload_rows<R>(s_a1, D, a.d_att1, D, D, v0, V);
+  __syncthreads();
+  //     .0: d_u = (d_u + d_att1 W) [u > 0] s   (768 columns = 12 blocks of 64: member j takes blocks j, j + 4, j + 8)
+#pragma unroll 1
+  for (int blk = member; blk < 12; blk += CL) {
+    float* dst = a.d_u + (int64_t)v0 * 3 * D;
+    const int boff = blk * OC;
+    auto epi = [&](int r, int col, f32x4 v) {
+      col += boff;
+      if (v0 + r < V) st4_dev(dst + (int64_t)r * 3 * D + col, mask_val(v + ld4(s_du + r * 3 * D + col), ld4(s_u + r * 3 * D + col), sc));
+    };
+    cxm_run<R, D, OC>(ring, s_a1, D, a.att0_w + boff, 3 * D, part, epi, [&] {
+      if (blk + CL < 12) PF(D, OC, a.att0_w + boff + CL * OC, 3 * D);
+      else PF(D, OC, a.umlp3_w[0] + coff, D);
+    });
+  }
+  TR(7);
+  cl_sync(cl, &s_bail);
+  TR(8);
+  reload_rows<R>(s_du, 3 * D, a.d_u, 3 * D, 3 * D, v0, V);
+  __syncthreads();
+  // 3'. audio / text / video_mlp: d_u1 = (d_u_m W3) [u1 > 0] s ; d_hpre = d_u1 W0
+#pragma unroll 1
+  for (int m = 0; m < 3; ++m) {
+    float* dst = a.d_u1 + m * VD + (int64_t)v0 * D;
+    const float* y = s_u1 + m * R * D;
+    auto epi = [&](int r, int col, f32x4 v) {
+      col += coff;
+      if (v0 + r < V) st4_dev(dst + (int64_t)r * D + col, mask_val(v, ld4(y + r * D + col), sc));
+    };
+    cxm_run<R, D, OC>(ring, s_du + m * D, 3 * D, a.umlp3_w[m] + coff, D, part, epi,
+                                [&] { PF(D, OC, (m < 2 ? a.umlp3_w[m + 1] : a.umlp0_w[0]) + coff, D); });
+  }
+  TR(9);
+  cl_sync(cl, &s_bail);
+  TR(10);
+  cl_exit(cl);
+  for (int m = 0; m < 3; ++m) reload_rows<R>(s_u1 + m * R * D, D, a.d_u1 + m * VD, D, D, v0, V);
+  __syncthreads();
+#pragma unroll 1
+  for (int m = 0; m < 3; ++m) {
+    float* dst = a.d_hpre + m * VD + (int64_t)v0 * D;
+    auto epi = [&](int r, int col, f32x4 v) {
+      col += coff;
+      if (v0 + r < V) st4(dst + (int64_t)r * D + col, v);
+    };
+    cxm_run<R, D, OC>(ring, s_u1 + m * R * D, D, a.umlp0_w[m] + coff, D, part, epi,
+                                [&] { if (m < 2) PF(D, OC, a.umlp0_w[m + 1] + coff, D); });
+  }
+  TR(31);
+}
+
+#undef PF
+#undef PF14
+#undef CL_PROLOGUE
+
+template <int R> constexpr size_t smem_fwd_a() { return sizeof(float) * (PARTC + 11 * R * D + 4 * R + 14 * R * D + 18 * D); }
+template <int R> constexpr size_t smem_fwd_b() { return sizeof(float) * (PARTC + 3 * NQ * R * D + 3 * NQ * R * H + R * NQ * H + R * D + 2 * R * H + R * RD + 12 * R + 4 * D + 4 * H + 2 * RD); }
+template <int R> constexpr size_t smem_bwd_b() { return sizeof(float) * (PARTC + 2 * R * RD + R * H + 2 * R * NQ * H + R * H + R * D + 3 * NQ * R * H + 3 * NQ * R * D + 24 * R); }
+template <int R> constexpr size_t smem_bwd_a() { return sizeof(float) * (PARTC + 3 * NQ * R * D + 2 * NQ * R * D + 6 * R * D + 2 * R * D + 3 * R * D + 8 * R); }
+
+template <class K>
+int set_smem(K kernel, size_t bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess
+             ? SDUMC_OK : SDUMC_ELAUNCH;
+}
+
+// per device: the clusters' counters (zero between launches), the error word, and the event that serialises cluster launches
+// of different streams
+struct ClusterDev {
+  std::mutex mu;
+  uint32_t* flags = nullptr;     // [128 clusters][64 words]: arrival counter at +0, departure counter at +32 (own 128-byte lines)
+  int32_t* err = nullptr;
+  unsigned long long* trace = nullptr;   // 4 x 32 time stamps, written only while tracing is on
+  bool tracing = false;
+  hipEvent_t done = nullptr;
+  hipStream_t last = nullptr;
+  bool any = false;
+  int cus = 0;
+};
+ClusterDev g_cl[16];
+constexpr int kMaxClusters = 128;
+
+ClusterDev* cluster_dev() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  ClusterDev& d = g_cl[dev];
+  std::lock_guard<std::mutex> lk(d.mu);
+  if (!d.flags) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return nullptr;
+    uint32_t* f = nullptr;
+    if (hipMalloc(&f, (kMaxClusters * 64 + 64 + 256) * sizeof(uint32_t)) != hipSuccess) return nullptr;
+    if (hipMemset(f, 0, (kMaxClusters * 64 + 64 + 256) * sizeof(uint32_t)) != hipSuccess) return nullptr;
+    d.trace = reinterpret_cast<unsigned long long*>(f + kMaxClusters * 64 + 64);
+    if (hipEventCreateWithFlags(&d.done, hipEventDisableTiming) != hipSuccess) return nullptr;
+    d.err = reinterpret_cast<int32_t*>(f + kMaxClusters * 64);
+    d.cus = cus;
+    d.flags = f;
+  }
+  return &d;
+}
+
+}  // namespace
+
+// 1 = V samples qualify for the cluster kernels on the current device (every workgroup resident at once)
+namespace { int g_cluster_on = -1; }
+// experiment / test knob (also SDUMC_CHAIN_CLUSTER=0|1 at start-up): 0 keeps chain.hip's one-workgroup-per-sample-pair kernels
+extern "C" int sdumc_set_chain_cluster(int on) {
+  g_cluster_on = on ? 1 : 0;
+  return SDUMC_OK;
+}
+extern "C" int sdumc_chain_cluster_ok_(int V) {
+  if (g_cluster_on < 0) { const char* e = getenv("SDUMC_CHAIN_CLUSTER"); g_cluster_on = e ? (atoi(e) ? 1 : 0) : 1; }
+  if (!g_cluster_on || V <= 0) return 0;
+  ClusterDev* d = cluster_dev();
+  if (!d) return 0;
+  const int ncl = (V + 1) / 2;
+  return ncl <= kMaxClusters && ncl * CL <= d->cus ? 1 : 0;
+}
+
+// which: 0 = stage A forward, 1 = stage B forward, 2 = stage B backward, 3 = stage A backward; 1 = shape does not qualify
+extern "C" int sdumc_chain_cluster_launch_(const sdumc_chain_args* ap, int which, void* stream) {
+  if (!ap || ap->V <= 0 || which < 0 || which > 3) return SDUMC_EINVAL;
+  if (!sdumc_chain_cluster_ok_(ap->V)) return 1;
+  constexpr int R = 2;
+  static bool attr = false;
+  if (!attr) {
+    if (set_smem(chain_fwd_a_cl_kernel<R>, smem_fwd_a<R>()) || set_smem(chain_fwd_b_cl_kernel<R>, smem_fwd_b<R>()) ||
+        set_smem(chain_bwd_b_cl_kernel<R>, smem_bwd_b<R>()) || set_smem(chain_bwd_a_cl_kernel<R>, smem_bwd_a<R>()))
+      return SDUMC_ELAUNCH;
+    attr = true;
+  }
+  ClusterDev* d = cluster_dev();
+  if (!d) return SDUMC_ELAUNCH;
+  sdumc_chain_args a = *ap;
+  a.cl_flags = d->flags;
+  a.cl_err = d->err;
+  a.cl_trace = d->tracing ? d->trace + 32 * which : nullptr;
+  a.w_bf16 = 0;
+  const int ncl = (a.V + R - 1) / R;
+  const dim3 grid(ncl * CL), blk(NTHR);
+  hipStream_t st = as_stream(stream);
+  std::lock_guard<std::mutex> lk(d->mu);
+  // one cluster kernel at a time per device: a second one on another stream waits for the first
+  if (d->any && d->last != st && hipStreamWaitEvent(st, d->done, 0) != hipSuccess) return SDUMC_ELAUNCH;
+  switch (which) {
+    case 0: hipLaunchKernelGGL(chain_fwd_a_cl_kernel<R>, grid, blk, smem_fwd_a<R>(), st, a, ncl); break;
+    case 1: hipLaunchKernelGGL(chain_fwd_b_cl_kernel<R>, grid, blk, smem_fwd_b<R>(), st, a, ncl); break;
+    case 2: hipLaunchKernelGGL(chain_bwd_b_cl_kernel<R>, grid, blk, smem_bwd_b<R>(), st, a, ncl); break;
+    default: hipLaunchKernelGGL(chain_bwd_a_cl_kernel<R>, grid, blk, smem_bwd_a<R>(), st, a, ncl); break;
+  }
+  SDUMC_CHECK_LAUNCH();
+  if (hipEventRecord(d->done, st) != hipSuccess) return SDUMC_ELAUNCH;
+  d->last = st;
+  d->any = true;
+  return SDUMC_OK;
+}
+
+// 0 = no cluster spin ever exceeded its cap on the current device (synchronises the device; tests)
+extern "C" int sdumc_chain_cluster_error_() {
+  ClusterDev* d = cluster_dev();
+  if (!d) return -1;
+  int32_t e = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpy(&e, d->err, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return e;
+}
+
+// debug: on = 1 makes workgroup 0 of every cluster kernel stamp its phase boundaries; out (4 x 32 doubles, may be null) receives
+// the stamps of the last launches in microseconds since each kernel's first stamp (synchronises the device)
+extern "C" int sdumc_chain_cluster_trace_(int on, double* out) {
+  ClusterDev* d = cluster_dev();
+  if (!d) return SDUMC_ELAUNCH;
+  if (out) {
+    unsigned long long h[128];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h, d->trace, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) return SDUMC_ELAUNCH;
+    for (int k = 0; k < 4; ++k)
+      for (int i = 0; i < 32; ++i) out[k * 32 + i] = h[k * 32 + i] ? (double)(h[k * 32 + i] - h[k * 32]) * 0.01 : -1.0;
+    if (hipMemset(d->trace, 0, sizeof(h)) != hipSuccess) return SDUMC_ELAUNCH;
+  }
+  std::lock_guard<std::mutex> lk(d->mu);
+  d->tracing = on != 0;
+  return SDUMC_OK;
+}

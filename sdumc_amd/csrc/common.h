@@ -57,11 +57,19 @@ struct sdumc_chain_args {
   const float *g_vals, *g_fused, *g_rnc, *g_text_hidden, *g_cross_text;
   float *d_r1, *d_z, *d_beta, *d_e2, *d_e1, *d_h, *d_c, *d_c1, *d_ca_out, *d_alpha;
   float *d_qp, *d_q, *d_qin, *d_u, *d_att2, *d_att1, *d_u1, *d_hpre;
+  // chain_cluster.hip only (filled by sdumc_chain_cluster_launch_): per-cluster arrival / departure counters, error word
+  uint32_t* cl_flags;
+  int32_t* cl_err;
+  unsigned long long* cl_trace;   // null, or 32 timestamps of workgroup 0 (debug)
 };
 
 extern "C" {
 // which: 0 = stage A forward, 1 = stage B forward, 2 = stage B backward, 3 = stage A backward
 int sdumc_chain_launch_(const sdumc_chain_args* a, int which, void* stream);
+// the same four stages with every layer's output columns split over clusters of 4 workgroups (chain_cluster.hip);
+// returns 1 when the shape does not qualify (the caller then takes sdumc_chain_launch_)
+int sdumc_chain_cluster_launch_(const sdumc_chain_args* a, int which, void* stream);
+int sdumc_chain_cluster_ok_(int V);
 // dst[off ..] = transpose of the n listed [out][in] matrices of src (same offsets in both buffers)
 // fp32 parameters -> bf16 copies as stored (dst) and, where want_t[i], transposed (dst_t); same element offsets as in src
 int sdumc_weights_to_bf16_(const float* src, void* dst, void* dst_t, const int64_t* offs, const int32_t* outs, const int32_t* ins,

@@ -871,6 +871,18 @@ bool use_chain(const Ctx& c) {
   return c.pl.V <= 512;
 }
 
+// chain_cluster.hip instead of chain.hip: every workgroup of the clustered kernels must be resident at once (V <= 128 on
+// MI355X) and their launches wait on a per-device event, which a stream capture cannot contain
+bool use_cluster(const Ctx& c) { return use_chain(c) && !c.capturing && sdumc_chain_cluster_ok_(c.pl.V) == 1; }
+
+int chain_launch(const Ctx& c, const sdumc_chain_args& ca, int which) {
+  if (use_cluster(c)) {
+    const int rc = sdumc_chain_cluster_launch_(&ca, which, c.st);
+    if (rc != 1) return rc;
+  }
+  return sdumc_chain_launch_(&ca, which, c.st);
+}
+
 // the Linear layers of both stages, in one list (transposed once per forward call)
 std::vector<const Lin*> chain_lins(const ParamMap& pm) {
   std::vector<const Lin*> v;
@@ -909,7 +921,7 @@ sdumc_chain_args chain_args(const Ctx& c, bool fwd, const sdumc_net_grads* og, b
   const float* WB = fwd ? c.p(pl.wt) : c.P;
   // bf16-storage mode: the streamed matrices are read from the bf16 copies (transposed for the forward, as stored for the
   // backward: sdumc_weights_to_bf16_ in forward()); orgin_linear_change stays fp32 (64 columns: too narrow for 8-column lanes)
-  const bool wb = c.h() && stage_a;
+  const bool wb = c.h() && stage_a && !use_cluster(c);
   a.w_bf16 = wb ? 1 : 0;
   auto W = [&](const Lin& L) -> const float* {
     if (wb) return reinterpret_cast<const float*>(c.ph(fwd ? pl.wht : pl.wh, L.w));
@@ -979,7 +991,7 @@ int forward(const Ctx& c) {
       offs[n] = pm.ca_in[m].w; outs[n] = D; ins[n] = D; wantt[n] = 1; ++n;
     }
     RET(sdumc_weights_to_bf16_(c.P, c.ph(pl.wh), c.ph(pl.wht), offs, outs, ins, wantt, n, c.st));
-    if (chain) {           // + the utterance-level matrices chain.hip streams (both layouts: forward and backward)
+    if (chain && !use_cluster(c)) {   // + the utterance-level matrices chain.hip streams (both layouts: forward and backward)
       const std::vector<const Lin*> ls = chain_lins(pm);
       n = 0;
       for (size_t i = 0; i <= ls.size(); ++i) {
@@ -1061,7 +1073,7 @@ int forward(const Ctx& c) {
     if (wt_done && hipStreamWaitEvent(c.st, wt_done, 0) != hipSuccess) return SDUMC_ELAUNCH;
     const sdumc_chain_args ca = chain_args(c, true, nullptr, true);
     mark(c.st, 1);
-    RET(sdumc_chain_launch_(&ca, 0, c.st));
+    RET(chain_launch(c, ca, 0));
     mark(c.st, 2);
   } else {
   // 3. audio/text/video_mlp (model :293-295), grouped over the modality
@@ -1143,7 +1155,7 @@ int forward(const Ctx& c) {
   if (chain) {   // steps 9-12 and the outputs in one launch
     const sdumc_chain_args ca = chain_args(c, true, nullptr, false);
     mark(c.st, 3);
-    RET(sdumc_chain_launch_(&ca, 1, c.st));
+    RET(chain_launch(c, ca, 1));
     mark(c.st, 4);
     return SDUMC_OK;
   }
@@ -1326,7 +1338,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   if (chain) {
     // 12'-9' in one launch (chain.hip); the weight gradients of these layers are queued for lane 3 as before
     const sdumc_chain_args ca = chain_args(c, false, &og, false);
-    RET(sdumc_chain_launch_(&ca, 2, c.st));
+    RET(chain_launch(c, ca, 2));
     mark(c.st, 6);
     const int M7 = V * NQ;
     if (og.d_rnc) {
@@ -1437,7 +1449,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     // 7'-3' in one launch; dW of these layers queued for lane 3
     const sdumc_chain_args ca = chain_args(c, false, &og, true);
     mark(c.st, 7);
-    RET(sdumc_chain_launch_(&ca, 3, c.st));
+    RET(chain_launch(c, ca, 3));
     mark(c.st, 8);
     const int M7 = V * NQ;
     {

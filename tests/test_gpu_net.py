@@ -206,6 +206,8 @@ def test_graph_replay_equals_eager_and_advances_state(E):
     P = O.init_params(dims, seed=2)
     batch = O.synthetic_batch(B, Tn, dims, seed=3)
     res = []
+    from sdumc_amd import _lib
+    _lib.lib.sdumc_set_chain_cluster(0)      # a capture takes chain.hip's kernels: compare like with like
     for use_graph in (False, True):
         flat, lay = flat_from(E, P, dims)
         ts = E.TrainStep(flat, B, Tn, dims, seed=5)
@@ -217,6 +219,7 @@ def test_graph_replay_equals_eager_and_advances_state(E):
             ls.append(ts.run().cpu().clone())
         torch.cuda.synchronize()
         res.append((flat.cpu().clone(), ls, ts.rng.call, float(ts.hyper[1])))
+    _lib.lib.sdumc_set_chain_cluster(1)
     assert torch.equal(res[0][0], res[1][0]), "graph replay must equal eager launches bit for bit"
     for a, b in zip(res[0][1], res[1][1]):
         assert torch.equal(a, b)
@@ -463,3 +466,32 @@ def test_fused_trainer_over_changing_batch_shapes_vs_oracle(E):
     for k in lay.live_names():
         close((pv[k] - P[k]) * 1e2, (Pd[k] - P[k]) * 1e2, 2e-2, k)       # four Adam steps of lr 1e-3
     assert tr.state.rng.call == 2 * len(shapes) and int(tr.state.hyper[1].item()) == len(shapes)
+
+
+def test_clustered_utterance_level_kernels_equal_the_plain_ones(E):
+    """csrc/chain_cluster.hip (columns of every utterance-level layer split over 4 workgroups that exchange slices through HBM)
+    against csrc/chain.hip on the same inputs: three optimisation steps with fresh masks each, ragged V (B = 7: the last
+    cluster holds rows beyond V).  Same arithmetic, different summation order -> 1e-5; a stale exchange would be O(1)."""
+    from oracle import sdumc_oracle as O
+    from sdumc_amd import _lib
+    dims = (64, 32, 64, 32)
+    B, Tn = 7, (40, 6, 20, 6)
+    P = O.init_params(dims, seed=4)
+    batch = O.synthetic_batch(B, Tn, dims, seed=6)
+    res = []
+    for cluster in (0, 1):
+        _lib.lib.sdumc_set_chain_cluster(cluster)
+        flat, lay = flat_from(E, P, dims)
+        ts = E.TrainStep(flat, B, Tn, dims, seed=9)
+        ts.set_batch(*[t.cuda() for t in batch])
+        ls = [ts.run().cpu().clone() for _ in range(3)]
+        torch.cuda.synchronize()
+        res.append((flat.cpu().clone(), ls, ts.grads.cpu().clone()))
+    _lib.lib.sdumc_set_chain_cluster(1)
+    assert _lib.lib.sdumc_chain_cluster_error_() == 0
+    for a, b in zip(res[0][1], res[1][1]):
+        np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=2e-5, atol=1e-6)
+    gscale = float(res[0][2].abs().max())
+    assert float((res[0][2] - res[1][2]).abs().max()) < 2e-5 * gscale
+    assert not torch.equal(res[0][2], res[1][2])            # (the clustered path really ran)
+    assert float((res[0][0] - res[1][0]).abs().max()) < 1e-4

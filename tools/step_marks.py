@@ -35,3 +35,17 @@ for i, n in enumerate(names):
     t = acc[i] / N * 1e3
     print(f"{i:2d} {t:8.1f} us  (+{t - prev:7.1f})  {n}")
     prev = t
+
+# phase stamps of workgroup 0 inside the clustered utterance-level kernels (chain_cluster.hip), when they are in use
+try:
+    _lib.lib.sdumc_chain_cluster_trace_.argtypes = [C.c_int, C.POINTER(C.c_double)]
+    _lib.lib.sdumc_chain_cluster_trace_(1, None)
+    step.run()
+    torch.cuda.synchronize()
+    out = (C.c_double * 128)()
+    _lib.lib.sdumc_chain_cluster_trace_(0, out)
+    for k, nm in enumerate(("fwd A", "fwd B", "bwd B", "bwd A")):
+        ts = [(i, out[k * 32 + i]) for i in range(32) if out[k * 32 + i] >= 0]
+        print(nm, " ".join(f"{i}:{t:.1f}" for i, t in ts))
+except AttributeError:
+    pass
