@@ -189,6 +189,11 @@ typedef struct sdumc_attnpool {
   int32_t bf16;        /* 1: x and keys (and, in sdumc_attnpool_bwd, dz and dxd) are bf16 tensors of the same shapes (the engine's
                           bf16-storage mode, BASELINE configs[2] / [4]); scores, softmax, pooling, attn, pooled, out, dq stay
                           fp32.  dim must be 256; a fused x_drop needs precomputed keep-bits.  0 (default): fp32 */
+  uint32_t* tickets;   /* NULL, or 2 * V device counters that are ZERO when the call starts (and again when it ends): the
+                          per-sample second passes then run inside the first kernels -- the last 64-frame chunk of a sample to
+                          finish combines that sample's softmax partials (forward, counters [0, V)) / sums its dq slabs
+                          (backward, counters [V, 2V)) -- instead of in a second launch.  Same arithmetic in the same order.
+                          (The engine leaves this NULL: at the MOSEI shapes the second launch measured cheaper, see engine.hip.) */
 } sdumc_attnpool;
 
 size_t sdumc_attnpool_fwd_workspace_bytes(int32_t V, int32_t T, int32_t nq);

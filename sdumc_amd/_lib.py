@@ -60,7 +60,7 @@ class AttnPool(C.Structure):
                 ("scale", C.c_float), ("x_drop", Dropout), ("out_drop", Dropout),
                 ("attn", C.c_void_p), ("pooled", C.c_void_p), ("out", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("dim", C.c_int32),
-                ("lengths", C.c_void_p), ("bf16", C.c_int32)]
+                ("lengths", C.c_void_p), ("bf16", C.c_int32), ("tickets", C.c_void_p)]
 
 
 class AttnPoolBwd(C.Structure):

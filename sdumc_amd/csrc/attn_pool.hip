@@ -31,6 +31,33 @@ constexpr int CH = 64;           // rows of one v handled by a 4-wave workgroup 
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+// agent-scope (write-through / L2-bypassing) accesses for data that another workgroup of the SAME launch reads after a ticket
+// hand-shake (descriptor field `tickets`): the chunks of one sample may run on different XCDs, whose L2s are not coherent
+__device__ __forceinline__ void stf_dev(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ float ldf_dev(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st4_dev(float* p, f32x4 v) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) stf_dev(p + j, v[j]);
+}
+__device__ __forceinline__ f32x4 ld4_dev(const float* p) {
+  f32x4 v;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = ldf_dev(p + j);
+  return v;
+}
+// true in exactly one workgroup per ticket: the last of `n` to arrive (which also re-arms the ticket).  Every thread calls it,
+// after the workgroup's agent-scope stores; ends with a barrier.
+__device__ __forceinline__ bool last_arrival(uint32_t* ticket, uint32_t n, int* s_flag) {
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *s_flag = t == n - 1u;
+    if (t == n - 1u) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
 __device__ __forceinline__ float dot4(f32x4 a, f32x4 b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3]; }
 // Frame tensors (x, keys, dz, dxd) are fp32, or bf16 in the engine's bf16-storage mode (sdumc_attnpool.bf16): `base` is the
 // tensor's address as float*, `off` an ELEMENT offset; 4 consecutive channels either way (16 or 8 bytes).
@@ -116,6 +143,45 @@ __device__ __forceinline__ f32x4 rows_times_cols(const float* rowp, const float*
   return acc;
 }
 
+// ---- forward, pass 2: combine the chunks of one v, normalise the weights, output dropout ---------
+// DEV: called by the last chunk workgroup of v inside the partial kernel: the other chunks' results are read at agent scope
+template <bool DEV>
+__device__ __forceinline__ void attn_fwd_combine_body(const sdumc_attnpool& p, const float* ws, const int nchunk, const int v,
+                                                      float* fac /* LDS [nchunk][MAXQ]: exp(m_c - m) / l */) {
+  const int tid = threadIdx.x;
+  const int T = p.T, nq = p.nq, DD = row_dim(p);
+  const FwdWs w = fwd_ws(const_cast<float*>(ws), p.V, nchunk, nq, DD);
+  const float* st = w.stats + (size_t)v * nchunk * 2 * MAXQ;
+  if (tid < nq) {
+    float m = -INFINITY;
+    auto ldst = [&](int k) { return DEV ? ldf_dev(st + k) : st[k]; };
+    for (int c = 0; c < nchunk; ++c) m = fmaxf(m, ldst(c * 2 * MAXQ + tid));
+    float l = 0.f;
+    for (int c = 0; c < nchunk; ++c) l += ldst(c * 2 * MAXQ + MAXQ + tid) * expf(ldst(c * 2 * MAXQ + tid) - m);
+    const float inv = 1.f / l;
+    for (int c = 0; c < nchunk; ++c) fac[c * MAXQ + tid] = expf(ldst(c * 2 * MAXQ + tid) - m) * inv;
+  }
+  __syncthreads();
+  const DropRT od = drop_resolve(p.out_drop);
+  for (int e = tid; e < nq * (DD / 4); e += 256) {
+    const int i = e / (DD / 4), cq = e - i * (DD / 4);
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < nchunk; ++c) {
+      const float* src = w.part + (((size_t)v * nchunk + c) * nq + i) * DD + 4 * cq;
+      sum += (DEV ? ld4_dev(src) : ld4(src)) * fac[c * MAXQ + i];
+    }
+    const size_t o = ((size_t)v * nq + i) * DD + 4 * cq;
+    st4(p.pooled + o, sum);
+    if (od.enabled) sum *= drop_mask4(od, (uint32_t)(v * nq + i), (uint32_t)cq);
+    st4(p.out + o, sum);
+  }
+  float* attn = p.attn + (size_t)v * T * nq;
+  for (int e = tid; e < T * nq; e += 256) {
+    const int t = e / nq, i = e - t * nq;
+    attn[e] = (DEV ? ldf_dev(attn + e) : attn[e]) * fac[(t / CH) * MAXQ + i];
+  }
+}
+
 // ---- forward, pass 1: one workgroup per (chunk of 64 rows, v) -----------------------------------
 // PHILOX: the input dropout mask is recomputed per row (no precomputed keep-bits attached: tests, one-off calls)
 template <bool PHILOX, int C, bool HF = false>
@@ -131,6 +197,7 @@ __device__ __forceinline__ void attn_fwd_partial_body(const sdumc_attnpool p, fl
   const int T = p.T, nq = p.nq;
   const int t0 = chunk * CH;
   const FwdWs w = fwd_ws(ws, p.V, nchunk, nq, DD);
+  const bool fuse = p.tickets != nullptr;     // the last chunk of v to finish also combines (no second launch)
   // key-padding extension: frames at or beyond Tv get weight 0 (a chunk wholly beyond Tv reports max -inf, sum 0)
   const int Tv = p.lengths ? min(T, max(1, p.lengths[v])) : T;
 
@@ -166,7 +233,10 @@ __device__ __forceinline__ void attn_fwd_partial_body(const sdumc_attnpool p, fl
     const float pe = t < Tv ? expf(s[e] - mc) : 0.f;
     lsum += pe;
     if (r16 < MAXQ) P_s[rl * MAXQ + r16] = pe;
-    if (r16 < nq && t < T) p.attn[((size_t)v * T + t) * nq + r16] = pe;   // normalised by the combine kernel
+    if (r16 < nq && t < T) {                                               // normalised by the combine step
+      if (fuse) stf_dev(p.attn + ((size_t)v * T + t) * nq + r16, pe);
+      else p.attn[((size_t)v * T + t) * nq + r16] = pe;
+    }
   }
   lsum += __shfl_xor(lsum, 16, 64);
   lsum += __shfl_xor(lsum, 32, 64);
@@ -175,8 +245,9 @@ __device__ __forceinline__ void attn_fwd_partial_body(const sdumc_attnpool p, fl
   __syncthreads();
   if (tid < nq) {
     float* st = w.stats + ((size_t)v * nchunk + chunk) * 2 * MAXQ;
-    st[tid] = cstat[tid];
-    st[MAXQ + tid] = wstat[0][tid] + wstat[1][tid] + wstat[2][tid] + wstat[3][tid];
+    const float l = wstat[0][tid] + wstat[1][tid] + wstat[2][tid] + wstat[3][tid];
+    if (fuse) { stf_dev(st + tid, cstat[tid]); stf_dev(st + MAXQ + tid, l); }
+    else { st[tid] = cstat[tid]; st[MAXQ + tid] = l; }
   }
   // unnormalised pooling of this chunk, one 256-channel block at a time: lane owns channels 4*lane..4*lane+3 of the
   // block, wave owns 16 rows
@@ -245,13 +316,19 @@ __device__ __forceinline__ void attn_fwd_partial_body(const sdumc_attnpool p, fl
       f32x4 sum = ld4(red + i * D + 4 * cq);
 #pragma unroll
       for (int ww = 1; ww < 4; ++ww) sum += ld4(red + (ww * MAXQ + i) * D + 4 * cq);
-      st4(w.part + (((size_t)v * nchunk + chunk) * nq + i) * DD + D * cb + 4 * cq, sum);
+      float* dst = w.part + (((size_t)v * nchunk + chunk) * nq + i) * DD + D * cb + 4 * cq;
+      if (fuse) st4_dev(dst, sum);
+      else st4(dst, sum);
     }
   };
   pool_block(std::integral_constant<int, 0>{});
   if constexpr (C > 1) pool_block(std::integral_constant<int, 1>{});
   if constexpr (C > 2) pool_block(std::integral_constant<int, 2>{});
   if constexpr (C > 3) pool_block(std::integral_constant<int, 3>{});
+  if (fuse) {
+    __shared__ int s_last;
+    if (last_arrival(p.tickets + v, (uint32_t)nchunk, &s_last)) attn_fwd_combine_body<true>(p, ws, nchunk, v, red);
+  }
 }
 
 template <bool PHILOX, int C, bool HF = false>
@@ -293,48 +370,15 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_partial_multi_kernel(const Mu
   attn_fwd_partial_body<false, 1, HF>(p, static_cast<float*>(p.workspace), nchunk, local % nchunk, local / nchunk);
 }
 
-// ---- forward, pass 2: combine the chunks of one v, normalise the weights, output dropout ---------
-__device__ __forceinline__ void attn_fwd_combine_body(const sdumc_attnpool& p, const float* ws, const int nchunk, const int v,
-                                                      float* fac /* LDS [nchunk][MAXQ]: exp(m_c - m) / l */) {
-  const int tid = threadIdx.x;
-  const int T = p.T, nq = p.nq, DD = row_dim(p);
-  const FwdWs w = fwd_ws(const_cast<float*>(ws), p.V, nchunk, nq, DD);
-  const float* st = w.stats + (size_t)v * nchunk * 2 * MAXQ;
-  if (tid < nq) {
-    float m = -INFINITY;
-    for (int c = 0; c < nchunk; ++c) m = fmaxf(m, st[c * 2 * MAXQ + tid]);
-    float l = 0.f;
-    for (int c = 0; c < nchunk; ++c) l += st[c * 2 * MAXQ + MAXQ + tid] * expf(st[c * 2 * MAXQ + tid] - m);
-    const float inv = 1.f / l;
-    for (int c = 0; c < nchunk; ++c) fac[c * MAXQ + tid] = expf(st[c * 2 * MAXQ + tid] - m) * inv;
-  }
-  __syncthreads();
-  const DropRT od = drop_resolve(p.out_drop);
-  for (int e = tid; e < nq * (DD / 4); e += 256) {
-    const int i = e / (DD / 4), cq = e - i * (DD / 4);
-    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < nchunk; ++c) sum += ld4(w.part + (((size_t)v * nchunk + c) * nq + i) * DD + 4 * cq) * fac[c * MAXQ + i];
-    const size_t o = ((size_t)v * nq + i) * DD + 4 * cq;
-    st4(p.pooled + o, sum);
-    if (od.enabled) sum *= drop_mask4(od, (uint32_t)(v * nq + i), (uint32_t)cq);
-    st4(p.out + o, sum);
-  }
-  float* attn = p.attn + (size_t)v * T * nq;
-  for (int e = tid; e < T * nq; e += 256) {
-    const int t = e / nq, i = e - t * nq;
-    attn[e] *= fac[(t / CH) * MAXQ + i];
-  }
-}
-
 __global__ __launch_bounds__(256) void attn_fwd_combine_kernel(const sdumc_attnpool p, const float* ws, const int nchunk) {
   extern __shared__ float fac[];
-  attn_fwd_combine_body(p, ws, nchunk, blockIdx.x, fac);
+  attn_fwd_combine_body<false>(p, ws, nchunk, blockIdx.x, fac);
 }
 __global__ __launch_bounds__(256) void attn_fwd_combine_multi_kernel(const MultiFwd m) {
   extern __shared__ float fac[];
   const int s = site_of(m.v_end, blockIdx.x);
   const sdumc_attnpool& p = m.p[s];
-  attn_fwd_combine_body(p, static_cast<const float*>(p.workspace), m.nchunk[s], blockIdx.x - (s ? m.v_end[s - 1] : 0), fac);
+  attn_fwd_combine_body<false>(p, static_cast<const float*>(p.workspace), m.nchunk[s], blockIdx.x - (s ? m.v_end[s - 1] : 0), fac);
 }
 
 // ---- backward: one workgroup per (chunk, v) ----------------------------------------------------
@@ -357,6 +401,7 @@ __device__ __forceinline__ void attnpool_bwd_body(const sdumc_attnpool_bwd_t b, 
   const int r16 = lane & 15, kk = lane >> 4;
   const int T = p.T, nq = p.nq;
   const int t0 = chunk * CH;
+  const bool fuse = p.tickets != nullptr;
   const DropRT od = drop_resolve(p.out_drop);
   for (int e = tid; e < MAXQ * (DD / 4); e += 256) {
     const int i = e / (DD / 4), cq = e - i * (DD / 4);
@@ -459,7 +504,21 @@ __device__ __forceinline__ void attnpool_bwd_body(const sdumc_attnpool_bwd_t b, 
       f32x4 s = ld4(red + i * D + 4 * cq);
 #pragma unroll
       for (int w = 1; w < 4; ++w) s += ld4(red + (w * MAXQ + i) * D + 4 * cq);
-      st4(dq_part + (((size_t)v * nchunk + chunk) * nq + i) * DD + D * cb + 4 * cq, s);
+      float* dst = dq_part + (((size_t)v * nchunk + chunk) * nq + i) * DD + D * cb + 4 * cq;
+      if (fuse) st4_dev(dst, s);
+      else st4(dst, s);
+    }
+  }
+  if (fuse) {   // the last chunk of v to finish sums the per-chunk slabs (fixed order: deterministic)
+    __shared__ int s_last;
+    if (last_arrival(p.tickets + p.V + v, (uint32_t)nchunk, &s_last)) {
+      const int per_v = nq * DD;
+      for (int e = tid; e < per_v / 4; e += 256) {
+        const float* src = dq_part + (size_t)v * nchunk * per_v + 4 * e;
+        f32x4 a = ld4_dev(src);
+        for (int c = 1; c < nchunk; ++c) a += ld4_dev(src + (size_t)c * per_v);
+        st4(b.dq + (size_t)v * per_v + 4 * e, a);
+      }
     }
   }
 }
@@ -551,6 +610,7 @@ extern "C" int sdumc_attnpool_fwd(const sdumc_attnpool* pp, void* stream) {
   }
 #undef FWD_PARTIAL
   SDUMC_CHECK_LAUNCH();
+  if (p.tickets) return SDUMC_OK;          // the combine ran inside the partial kernel
   hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(p.V), dim3(256), (size_t)nchunk * MAXQ * sizeof(float), st, p,
                      p.workspace, nchunk);
   SDUMC_CHECK_LAUNCH();
@@ -588,6 +648,7 @@ extern "C" int sdumc_attnpool_bwd(const sdumc_attnpool_bwd_t* bp, void* stream) 
     default: hipLaunchKernelGGL(attnpool_bwd_kernel<4>, grid, blk, 0, st, b, b.workspace, nchunk); break;
   }
   SDUMC_CHECK_LAUNCH();
+  if (p.tickets) return SDUMC_OK;          // the slabs were summed inside the kernel
   const size_t total = (size_t)p.V * p.nq * DD;
   hipLaunchKernelGGL(dq_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, b.workspace, b.dq,
                      nchunk, p.nq * DD, total);
@@ -610,6 +671,7 @@ extern "C" int sdumc_attnpool_fwd_multi(const sdumc_attnpool* ps, int32_t n, voi
       int rc = check(p);
       if (rc) return rc;
       if (row_dim(p) != D || (p.x_drop.enabled && !p.x_drop.bits) || p.bf16 != ps[0].bf16) return SDUMC_EINVAL;
+      if ((p.tickets != nullptr) != (ps[0].tickets != nullptr)) return SDUMC_EINVAL;
       if (!p.workspace || p.workspace_bytes < sdumc_attnpool_fwd_workspace_bytes_dim(p.V, p.T, p.nq, D)) return SDUMC_ENOMEM;
       m.p[i] = p;
       m.nchunk[i] = (p.T + CH - 1) / CH;
@@ -624,6 +686,7 @@ extern "C" int sdumc_attnpool_fwd_multi(const sdumc_attnpool* ps, int32_t n, voi
   if (ps[0].bf16) hipLaunchKernelGGL(attn_fwd_partial_multi_kernel<true>, dim3(wg), dim3(256), 0, st, m);
   else hipLaunchKernelGGL(attn_fwd_partial_multi_kernel<false>, dim3(wg), dim3(256), 0, st, m);
   SDUMC_CHECK_LAUNCH();
+  if (ps[0].tickets) return SDUMC_OK;
   hipLaunchKernelGGL(attn_fwd_combine_multi_kernel, dim3(vs), dim3(256), (size_t)max_chunk * MAXQ * sizeof(float), st, m);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
@@ -643,6 +706,7 @@ extern "C" int sdumc_attnpool_bwd_multi(const sdumc_attnpool_bwd_t* bs, int32_t 
       if (rc) return rc;
       if (!b.dout || !b.dz || !b.dxd || !b.dq || !b.workspace) return SDUMC_EINVAL;
       if (row_dim(p) != D || (p.x_drop.enabled && !p.x_drop.bits) || p.bf16 != bs[0].f.bf16) return SDUMC_EINVAL;
+      if ((p.tickets != nullptr) != (bs[0].f.tickets != nullptr)) return SDUMC_EINVAL;
       if (b.workspace_bytes < sdumc_attnpool_bwd_workspace_bytes_dim(p.V, p.T, p.nq, D)) return SDUMC_ENOMEM;
       m.b[i] = b;
       m.nchunk[i] = (p.T + CH - 1) / CH;
@@ -656,6 +720,7 @@ extern "C" int sdumc_attnpool_bwd_multi(const sdumc_attnpool_bwd_t* bs, int32_t 
   if (bs[0].f.bf16) hipLaunchKernelGGL(attnpool_bwd_multi_kernel<true>, dim3(wg), dim3(256), 0, st, m);
   else hipLaunchKernelGGL(attnpool_bwd_multi_kernel<false>, dim3(wg), dim3(256), 0, st, m);
   SDUMC_CHECK_LAUNCH();
+  if (bs[0].f.tickets) return SDUMC_OK;
   hipLaunchKernelGGL(dq_reduce_multi_kernel, dim3((unsigned)((dq + 255) / 256)), dim3(256), 0, st, m);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;

@@ -196,6 +196,7 @@ struct Plan {
   bool hf = false;
   int64_t xd[2][3] = {{0, 0, 0}, {0, 0, 0}};
   int64_t wh = 0, wht = 0;   // [live] bf16 each: weights as stored / transposed (input_proj only), parameter offsets
+  int64_t tickets = 0;   // per-sample arrival counters of the attention kernels
   int64_t scratch[4] = {0, 0, 0, 0}, scratch_floats = 0;   // one scratch per lane (stream)
   int64_t alloc(int64_t n) {
     const int64_t o = cur;
@@ -329,6 +330,7 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
   p.d_r1 = p.alloc((int64_t)V * RD);
   p.dq_fra = p.alloc(3LL * V * D);
   p.lens = p.alloc(3LL * V);
+  p.tickets = p.alloc(12LL * V + 16);    // attention sites [2][3] x 2V counters (sdumc_attnpool.tickets), zeroed by forward()
   p.wt = p.alloc(build_params(d.da, d.dt, d.dv).early);
   if (p.hf) {
     const int64_t live = build_params(d.da, d.dt, d.dv).live;
@@ -738,6 +740,13 @@ sdumc_attnpool attn_desc(const Ctx& c, int k, int m, const Seg& sg) {
     a.q_stride = (int64_t)NQ * D;
   }
   a.scale = 0.3f;
+  {   // counters of this (site, run): 2 x sg.V words
+    // OFF by default: measured at C2 on MI355X the fused second passes LOSE 11 us per step fp32 / 18 us bf16 (1.993 vs 1.982 ms,
+    // 1.204 vs 1.186 ms) -- the agent-scope dword stores of the partials and the serial tail of the last chunk cost more than
+    // the launch they save.  SDUMC_ATTN_TICKETS=1 turns them on.
+    static const int fuse = [] { const char* e = getenv("SDUMC_ATTN_TICKETS"); return e ? atoi(e) : 0; }();
+    if (fuse) a.tickets = reinterpret_cast<uint32_t*>(c.p(pl.tickets)) + ((int64_t)(k * 3 + m) * 2 * pl.V) + 2 * (int64_t)sg.s0 * pl.B;
+  }
   a.x_drop = in_drop(c, k, m, sg.T, sg.s0, sg.row0);
   if (c.h()) a.x_drop.enabled = 0;
   a.out_drop = mkdrop(c, SITE_OUT[k][m], c.d.p_frame, nq, D, sg.s0);
@@ -975,6 +984,7 @@ int forward(const Ctx& c) {
                        reinterpret_cast<int32_t*>(c.p(pl.lens)));
     SDUMC_CHECK_LAUNCH();
   }
+  RET(sdumc_fill(c.p(pl.tickets), 0.f, 12LL * V + 16, c.st));   // (self-resetting; this guards a workspace's first use)
   // 1+2. three independent per-modality chains, one per lane:
   //      keep-bits of the two frame-level input dropouts -> frame_dim_reshape_m (model :282-284; audio/video once
   //      for both streams) -> keys of fra2utt_m AND cross_att_fra2utt_m -> FRA2UTT pooling (model :288-290)

@@ -101,8 +101,11 @@ def gemm_bf16(layout, A, B, M, N, K, bias=None, C_out=None, lda=None, ldb=None, 
 
 
 def attnpool_desc(x, keys, q, V, T, nq, x_samples, q_stride, x_drop, out_drop, attn, pooled, out, scale=0.3, dim=0,
-                  lengths=None):
+                  lengths=None, tickets=True):
     a = _lib.AttnPool()
+    if tickets:      # zeroed per-sample counters: the combine / dq reduction run inside the first kernels
+        a._keep_tickets = torch.zeros(2 * V, dtype=torch.int32, device=keys.device)
+        a.tickets = ptr(a._keep_tickets)
     a.dim = dim
     a.lengths = ptr(lengths)   # int32 [V] key-padding extension, or None = the reference's behaviour
     a.V, a.T, a.nq, a.x_samples = V, T, nq, x_samples
@@ -115,7 +118,7 @@ def attnpool_desc(x, keys, q, V, T, nq, x_samples, q_stride, x_drop, out_drop, a
     return a
 
 
-def attnpool_fwd(x, keys, q, nq, x_samples=None, q_shared=False, x_drop=None, out_drop=None, lengths=None):
+def attnpool_fwd(x, keys, q, nq, x_samples=None, q_shared=False, x_drop=None, out_drop=None, lengths=None, tickets=True):
     V, T, Dm = keys.shape
     dev = keys.device
     attn = torch.empty(V, T, nq, device=dev)
@@ -124,7 +127,7 @@ def attnpool_fwd(x, keys, q, nq, x_samples=None, q_shared=False, x_drop=None, ou
     if lengths is not None and (lengths.dtype != torch.int32 or not lengths.is_cuda or lengths.numel() != V):
         raise _lib.SdumcError("lengths must be a cuda int32 tensor with one entry per virtual sample")
     a = attnpool_desc(x, keys, q, V, T, nq, x_samples or x.shape[0], 0 if q_shared else nq * Dm, x_drop, out_drop,
-                      attn, pooled, out, lengths=lengths)
+                      attn, pooled, out, lengths=lengths, tickets=tickets)
     a._keep_lengths = lengths
     need = lib.sdumc_attnpool_fwd_workspace_bytes(V, T, nq)
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
@@ -162,7 +165,8 @@ def attnpool_fwd_multi(sites):
         dev = keys.device
         attn, pooled, out = torch.empty(V, T, nq, device=dev), torch.empty(V, nq, Dm, device=dev), torch.empty(V, nq, Dm, device=dev)
         a = attnpool_desc(x, keys, q, V, T, nq, kw.get("x_samples") or x.shape[0], 0 if kw.get("q_shared") else nq * Dm,
-                          kw.get("x_drop"), kw.get("out_drop"), attn, pooled, out, lengths=kw.get("lengths"))
+                          kw.get("x_drop"), kw.get("out_drop"), attn, pooled, out, lengths=kw.get("lengths"),
+                          tickets=kw.get("tickets", True))
         need = lib.sdumc_attnpool_fwd_workspace_bytes(V, T, nq)
         ws = torch.empty(need, dtype=torch.uint8, device=dev)
         a.workspace, a.workspace_bytes = ptr(ws), need

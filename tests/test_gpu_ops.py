@@ -275,7 +275,8 @@ def test_attnpool_multi_equals_single_calls(ops):
         lengths = dev(torch.tensor([T, T - 3, 5, 1, T, 7], dtype=torch.int32)) if i == 1 else None
         kw = dict(x=x, keys=keys, q=q, nq=nq, x_samples=B, x_drop=xdrop, out_drop=odrop, lengths=lengths, _bits=bits)
         sites.append(kw)
-        singles.append(ops.attnpool_fwd(x, keys, q, nq, x_samples=B, x_drop=xdrop, out_drop=odrop, lengths=lengths))
+        # the single calls take the two-launch path (tickets=False), the grouped call the fused second passes (tickets)
+        singles.append(ops.attnpool_fwd(x, keys, q, nq, x_samples=B, x_drop=xdrop, out_drop=odrop, lengths=lengths, tickets=False))
         douts.append(dev(torch.randn(V, nq, Dm, generator=g)))
     multi = ops.attnpool_fwd_multi(sites)
     for (o1, a1, p1, _), (o2, a2, p2, _) in zip(singles, multi):
@@ -285,6 +286,8 @@ def test_attnpool_multi_equals_single_calls(ops):
     for r1, r2 in zip(back1, back2):
         for t1, t2 in zip(r1, r2):
             assert torch.equal(t1, t2)
+    for m in multi:                                   # the counters re-armed themselves
+        assert int(m[3]._keep_tickets.abs().sum()) == 0
 
 
 def test_losses_against_reference_goldens(ops, golden):
