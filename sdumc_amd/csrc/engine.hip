@@ -1340,6 +1340,15 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     if (phases != 3 && (c.bgb & (1 << m)) && c.multi && LANE_OF[m] != 0) own_lane |= 1 << m;
   // (in a single call the lane-3 route measured 0.15 % faster than the own-lane route; phased calls gain 0.6 % from the latter)
   const int bgb = phases == 3 ? c.bgb : own_lane;
+  // early_done[m]: lane 3 has finished modality m's early key-projection backward (dxd of its Cross_Attention site).  The
+  // modality's own lane waits for exactly this event before its mask-sum -- not for whatever else lane 3 has been handed by
+  // then (the utterance-level dW batches, the other key-projection dW GEMMs: ~0.25 ms of work that only feeds the bucket).
+  hipEvent_t early_done[3] = {nullptr, nullptr, nullptr};
+  auto record_early = [&](int m) -> int {
+    if (c.sts[3] == c.sts[LANE_OF[m]]) return SDUMC_OK;
+    early_done[m] = next_event(c);
+    return hipEventRecord(early_done[m], c.sts[3]) == hipSuccess ? SDUMC_OK : SDUMC_ELAUNCH;
+  };
   if (phases & 1) {
   // every live gradient tensor is overwritten below when all five output gradients are given
   if (!og.d_vals || !og.d_fused || !og.d_rnc || !og.d_text_hidden || !og.d_cross_text) RET(sdumc_fill(c.G, 0.f, pm.live, c.st));
@@ -1429,6 +1438,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
       RET(link(c, 0, lane));
       c.use(lane);
       RET(keys_gemm_bwd(c, m, 1, 2));
+      if (lane == 3) RET(record_early(m));
       c.use(0);
     }
   }
@@ -1445,6 +1455,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
       RET(link(c, LANE_OF[m], 3));
       c.use(3);
       RET(keys_gemm_bwd(c, m, 1, 2));
+      RET(record_early(m));
     }
   }
   c.use(0);
@@ -1564,7 +1575,13 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
         RET(keys_gemm_bwd(c, m, 0, k1));
       }
     }
-    if (bgb & ~own_lane & (1 << m)) RET(link(c, 3, LANE_OF[m]));   // dxd of this modality's Cross_Attention site (issued early on lane 3)
+    if (bgb & ~own_lane & (1 << m)) {   // dxd of this modality's Cross_Attention site (issued early on lane 3)
+      if (early_done[m]) {
+        if (hipStreamWaitEvent(c.st, early_done[m], 0) != hipSuccess) return SDUMC_ELAUNCH;
+      } else {
+        RET(link(c, 3, LANE_OF[m]));
+      }
+    }
     for (int s = 0; s < (m == 1 ? S : 1); ++s) {
       const int T = pl.T[m][s];
       sdumc_dropsum ds;
