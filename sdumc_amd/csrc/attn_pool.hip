@@ -464,6 +464,7 @@ __device__ __forceinline__ void attnpool_bwd_body(const sdumc_attnpool_bwd_t b, 
       }
     }
     // rows in batches of RB: the batch's key-row loads are all in flight before the first row is processed
+    // (bf16 rows: 8 per batch measured SLOWER -- 1.156 vs 1.128 ms per bf16 step -- although they are half as long)
     constexpr int RB = 4;
 #pragma unroll
     for (int rb = 0; rb < 16; rb += RB) {

@@ -1564,7 +1564,10 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
       const int k1 = (bgb & (1 << m)) ? 1 : 2;
       // bit m: modality m's key-projection dW (off the dz -> dX -> mask-sum -> frame dW chain) runs on lane 3.  Default: audio
       // only, the longest chain (30.84 vs 30.51 k samples/s, five alternations; audio + video 30.8, all three 30.8).
-      static const int dw_off = [] { const char* e = getenv("SDUMC_KEYS_DW_LANE3"); return e ? atoi(e) : 1; }();
+      // (re-measured with the clustered utterance-level kernels: fp32 1.923 ms with none on lane 3 vs 1.930 with audio's;
+      //  bf16 storage 1.148 vs 1.128 -- so the default follows the mode)
+      static const int dw_env = [] { const char* e = getenv("SDUMC_KEYS_DW_LANE3"); return e ? atoi(e) : -1; }();
+      const int dw_off = dw_env >= 0 ? dw_env : (c.h() ? 1 : 0);
       if (c.multi && !c.capturing && (dw_off & (1 << m))) {
         RET(link(c, LANE_OF[m], 3));
         c.use(3);
