@@ -79,6 +79,18 @@ int sdumc_chain_transpose_(const float* src, float* dst, const int64_t* offs, co
 }
 
 // ---------------------------------------------------------------------------
+// XCD-aware tile order.  Workgroups are dispatched round-robin over the 8 XCDs (linear workgroup id % 8) and every XCD has its
+// own 4 MB L2, so tiles that read the same operand panel should sit behind ONE L2 at about the same time: XCD x walks the
+// contiguous tile range [x T/8, (x+1) T/8) in dispatch order.  L = linear workgroup id inside one z-plane of the grid (a
+// constant offset of the real id only renames the XCDs), total = tiles in the plane; bijective for any total.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int xcd_tile(int L, int total) {
+  const int q = total >> 3, r = total & 7;
+  const int x = L & 7, s = L >> 3;
+  return x * q + (x < r ? x : r) + s;
+}
+
+// ---------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. SC'11).  Bit-identical to oracle/philox.py.
 // ---------------------------------------------------------------------------
 struct Philox4 {

@@ -78,7 +78,9 @@ __global__ __launch_bounds__(CF::NTHR, CF::OCC) void gemm_bf16_kernel(const sdum
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   const int wm0 = (wave / CF::WGN) * CF::WM, wn0 = (wave % CF::WGN) * CF::WN;
-  const int tile_n = blockIdx.x, tile_m = blockIdx.y;
+  // (tile order: see xcd_tile in common.h -- the n-tiles of an m panel behind one XCD's L2)
+  const int tlin = xcd_tile(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int tile_m = tlin / (int)gridDim.x, tile_n = tlin - tile_m * (int)gridDim.x;
   const int grp = blockIdx.z / nsplit, ks_ = blockIdx.z - grp * nsplit;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int kbeg = ks_ * kchunk, kend = min(g.K, kbeg + kchunk);

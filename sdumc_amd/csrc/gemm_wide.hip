@@ -78,8 +78,12 @@ __global__ __launch_bounds__(CF::NTHR, CF::OCC) void gemm_wide_kernel(const sdum
   const int li = lane & 31, lh = lane >> 5;
   const int wm0 = (wave / CF::WGN) * CF::WM, wn0 = (wave % CF::WGN) * CF::WN;
 
-  // work order: n fastest inside an m panel, k-slices of one tile adjacent (they share nothing but finish together)
-  const int tile_n = blockIdx.x, tile_m = blockIdx.y;
+  // work order: the n-tiles of an m panel (they read the same A rows) are consecutive tiles of ONE XCD (xcd_tile): with
+  // blockIdx.x = n fastest they alternated between XCDs and every L2 fetched the panel again (FETCH_SIZE of the frame
+  // projections: 163 MB per launch against 79 MB of operands)
+  const int tiles_n_ = gridDim.x;
+  const int tlin = xcd_tile(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+  const int tile_m = tlin / tiles_n_, tile_n = tlin - tile_m * tiles_n_;
   const int gz = blockIdx.z / nsplit, ks = blockIdx.z - gz * nsplit;
   const int grp = gz;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
