@@ -220,6 +220,19 @@ typedef struct sdumc_attnpool_bwd {
 
 size_t sdumc_attnpool_bwd_workspace_bytes(int32_t V, int32_t T, int32_t nq);
 int sdumc_attnpool_bwd(const sdumc_attnpool_bwd_t* p, void* stream);
+/* K3, the fused UMCA forward (Cross_Attention model :79-95, FRA2UTT_new :56-68 = the nq = 1 case): key
+ * projection + scores + softmax partials + pooling of one 64-frame chunk in ONE kernel -- K = tanh(drop(x) W_in^T + b) is
+ * computed on the matrix cores into an LDS tile and consumed there; it goes to HBM only if a.keys != NULL (training keeps the
+ * keys for sdumc_attnpool_bwd; inference passes NULL and the [V, T, 256] tensor never exists).  Takes the place of
+ * sdumc_gemm(NT, tanh, input dropout) + sdumc_attnpool_fwd on the same descriptor; same results (same arithmetic, same order).
+ * fp32, 256 channels, input mask as keep-bits (x_drop.bits) or none, a.tickets NULL. */
+typedef struct sdumc_umca {
+  sdumc_attnpool a;      /* as for sdumc_attnpool_fwd; a.keys = OUTPUT [V, T, 256] or NULL */
+  const float* w_in;     /* input_proj.weight [256, 256] as stored (model :60 / :82) */
+  const float* b_in;     /* input_proj.bias [256] */
+} sdumc_umca;
+int sdumc_umca_fwd(const sdumc_umca* p, void* stream);
+
 /* Up to four pooling sites in ONE launch pair (forward: partial + combine; backward: rows + dq reduce) -- what the step uses for
  * its three Cross_Attention blocks, which are independent and too short to be worth a stream fork.  Every site: 256-channel
  * rows, keep-bits attached or no input mask, the same `bf16` flag, its OWN workspace.  Results are bit-identical to n single

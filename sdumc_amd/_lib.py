@@ -63,6 +63,10 @@ class AttnPool(C.Structure):
                 ("lengths", C.c_void_p), ("bf16", C.c_int32), ("tickets", C.c_void_p)]
 
 
+class Umca(C.Structure):
+    _fields_ = [("a", AttnPool), ("w_in", C.c_void_p), ("b_in", C.c_void_p)]
+
+
 class AttnPoolBwd(C.Structure):
     _fields_ = [("f", AttnPool), ("dout", C.c_void_p), ("dz", C.c_void_p), ("dxd", C.c_void_p),
                 ("dq", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
@@ -160,6 +164,7 @@ _SIGS = {
     "sdumc_attnpool_bwd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "sdumc_attnpool_bwd": (C.c_int, [C.POINTER(AttnPoolBwd), C.c_void_p]),
     "sdumc_attnpool_fwd_multi": (C.c_int, [C.POINTER(AttnPool), C.c_int32, C.c_void_p]),
+    "sdumc_umca_fwd": (C.c_int, [C.POINTER(Umca), C.c_void_p]),
     "sdumc_attnpool_bwd_multi": (C.c_int, [C.POINTER(AttnPoolBwd), C.c_int32, C.c_void_p]),
     "sdumc_relu_drop_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
     "sdumc_colsum_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int32]),

@@ -184,12 +184,23 @@ __device__ __forceinline__ void attn_fwd_combine_body(const sdumc_attnpool& p, c
 
 // ---- forward, pass 1: one workgroup per (chunk of 64 rows, v) -----------------------------------
 // PHILOX: the input dropout mask is recomputed per row (no precomputed keep-bits attached: tests, one-off calls)
-template <bool PHILOX, int C, bool HF = false>
-__device__ __forceinline__ void attn_fwd_partial_body(const sdumc_attnpool p, float* ws, const int nchunk, const int chunk, const int v) {
+// KLDS (the fused UMCA kernel, umca_fwd_kernel below): the chunk's tanh keys are NOT read from p.keys but from the LDS tile
+// k_lds [CH][UMCA_LDK] the key projection has just left there; q_ext / red_ext are the caller's LDS buffers for the query tile
+// and for the pooling reduce (the latter may overlay k_lds: it is first written after the last score has been computed).
+constexpr int UMCA_LDK = D + 4;
+template <bool PHILOX, int C, bool HF = false, bool KLDS = false>
+__device__ __forceinline__ void attn_fwd_partial_body(const sdumc_attnpool p, float* ws, const int nchunk, const int chunk, const int v,
+                                                      const float* k_lds = nullptr, float* q_ext = nullptr, float* red_ext = nullptr) {
   constexpr int DD = D * C, LDQ = DD + 16;
   constexpr int RED = 4 * MAXQ * D > MAXQ * LDQ ? 4 * MAXQ * D : MAXQ * LDQ;
   __shared__ __attribute__((aligned(16))) float P_s[CH * MAXQ];
-  __shared__ __attribute__((aligned(16))) float red[RED];   // first the query tile, later the pooling reduce (per channel block)
+  float* red;                                                // first the query tile, later the pooling reduce (per channel block)
+  if constexpr (KLDS) {
+    red = red_ext;
+  } else {
+    __shared__ __attribute__((aligned(16))) float red_s[RED];
+    red = red_s;
+  }
   __shared__ float wstat[4][16];
   __shared__ float cstat[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -202,7 +213,7 @@ __device__ __forceinline__ void attn_fwd_partial_body(const sdumc_attnpool p, fl
   const int Tv = p.lengths ? min(T, max(1, p.lengths[v])) : T;
 
   // scores of this wave's 16 rows against the (<= 8) queries
-  float* q_s = red;
+  float* q_s = KLDS ? q_ext : red;
   for (int e = tid; e < MAXQ * (DD / 4); e += 256) {
     const int i = e / (DD / 4), cq = e - i * (DD / 4);
     st4(q_s + i * LDQ + 4 * cq, i < nq ? ld4(p.q + (size_t)v * p.q_stride + (size_t)i * DD + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f});
@@ -210,7 +221,8 @@ __device__ __forceinline__ void attn_fwd_partial_body(const sdumc_attnpool p, fl
   __syncthreads();
   const int myrow = t0 + 16 * wave + r16;
   const DropRT nodrop = {};
-  const f32x4 s4 = rows_times_cols<false, C, HF>(myrow < T ? p.keys : nullptr, q_s, nodrop, 0u, r16, kk, ((size_t)v * T + myrow) * DD);
+  const f32x4 s4 = KLDS ? rows_times_cols<false, C, false>(k_lds, q_s, nodrop, 0u, r16, kk, (size_t)(16 * wave + r16) * UMCA_LDK)
+                        : rows_times_cols<false, C, HF>(myrow < T ? p.keys : nullptr, q_s, nodrop, 0u, r16, kk, ((size_t)v * T + myrow) * DD);
   // C layout: column (query) = lane & 15, rows = 16 wave + 4 (lane >> 4) + e
   float s[4], mx = -INFINITY;
 #pragma unroll
@@ -723,6 +735,210 @@ extern "C" int sdumc_attnpool_bwd_multi(const sdumc_attnpool_bwd_t* bs, int32_t 
   SDUMC_CHECK_LAUNCH();
   if (bs[0].f.tickets) return SDUMC_OK;
   hipLaunchKernelGGL(dq_reduce_multi_kernel, dim3((unsigned)((dq + 255) / 256)), dim3(256), 0, st, m);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+// ====================================================================================================================
+// K3 -- the UMCA forward as ONE kernel per (64-frame chunk, virtual sample)   (Cross_Attention, model :79-95;
+// FRA2UTT_new, model :56-68, is the nq = 1 case):
+//     xd = drop(x)                       the frames, masked by the keep-bits, staged ONCE per k-tile through LDS (LDS-DMA ring)
+//     K  = tanh(xd W_in^T + b)           fp32 MFMA 32x32x2, the whole 64 x 256 key tile of the chunk stays on chip
+//     S  = 0.3 K Q'^T, softmax partials  MFMA 16x16x4 on the LDS key tile, chunk max / sum (flash-style partials)
+//     O_c = P^T xd                       the chunk's unnormalised pooled rows; sdumc's per-sample combine finishes the softmax
+// The keys never travel to HBM and back between the projection and the scores; they are WRITTEN (p.a.keys) only when the caller
+// wants them for the backward (training), and not at all in inference.
+// Main loop = gemm_wide.hip's NT loop at its 64 x 256 x 16 configuration (3-deep LDS-DMA ring, XOR-swizzled 16-byte chunks,
+// counted vmcnt, one raw barrier per k-tile); epilogue = attn_fwd_partial_body on the LDS key tile.
+// LDS: max(ring 62 208 B, key tile 66 560 B) + query tile 8 704 B + 2.4 KB of statistics = 77.7 KB -> two workgroups per CU.
+// ====================================================================================================================
+namespace sdumc_k3 {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+constexpr int waitcnt_vm(int n) { return (n & 0xF) | ((n >> 4) << 14) | (0x7 << 4) | (0xF << 8); }
+constexpr int BM = 64, BN = 256, BK = 16, NST = 3, NW = 4;
+constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 4, BITS_LDS = 256;
+constexpr int A_CH = A_BYTES / 1024, B_CH = B_BYTES / 1024, NI = (A_CH + B_CH) / NW;
+constexpr int STAGE_BYTES = A_BYTES + B_BYTES + BITS_LDS, RING_BYTES = NST * STAGE_BYTES;
+constexpr int K_BYTES = BM * UMCA_LDK * 4;
+constexpr int TOP_BYTES = K_BYTES > RING_BYTES ? K_BYTES : RING_BYTES;
+constexpr int LDQ = D + 16, Q_BYTES = MAXQ * LDQ * 4;
+constexpr int LDS_BYTES = TOP_BYTES + Q_BYTES;
+static_assert(4 * MAXQ * D * 4 <= TOP_BYTES, "the pooling reduce overlays the key tile");
+
+__device__ __forceinline__ int swz16(int row) { return (row >> 2) & 3; }   // gemm_wide.hip swz<16>
+__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }   // = gemm_wide.hip
+
+template <bool MASK>
+__global__ __launch_bounds__(256, 2) void umca_fwd_kernel(const sdumc_umca u, const int nchunk) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const sdumc_attnpool& p = u.a;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int wn0 = wave * 64;
+  const int chunk = blockIdx.x, v = blockIdx.y;
+  const int T = p.T, t0 = chunk * CH, vx = v % p.x_samples;
+
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0,
+      (int)min((size_t)p.x_samples * T * D * 4, (size_t)0xFFFFFFF0u), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(u.w_in), 0, D * D * 4, 0x00020000);
+  uint32_t voff[NI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i) {
+    const int piece = wave + i * NW;
+    const int q = ((piece < A_CH ? piece : piece - A_CH) << 6) + lane;       // 16-byte chunk index inside the tile
+    const int row = q >> 2, cp = q & 3, c = cp ^ swz16(row);
+    if (piece < A_CH) voff[i] = ((uint32_t)(vx * T + min(t0 + row, T - 1)) * (uint32_t)D + (uint32_t)(4 * c)) * 4u;   // rows beyond T: the last row
+    else voff[i] = ((uint32_t)row * (uint32_t)D + (uint32_t)(4 * c)) * 4u;
+  }
+  const uint8_t* bitsp = MASK ? p.x_drop.bits : nullptr;
+  const uint32_t qw = (p.x_drop.width + 3u) >> 2;
+  const float mscale = MASK ? p.x_drop.scale : 1.f;
+  const __amdgpu_buffer_rsrc_t rbits = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(MASK ? bitsp : (const uint8_t*)p.x), 0,
+      MASK ? (int)min((size_t)p.V * T * qw, (size_t)0xFFFFFFF0u) : 0, 0x00020000);
+  uint32_t bvoff = 0;
+  if constexpr (MASK) bvoff = (uint32_t)(v * T + min(t0 + lane, T - 1)) * qw;     // one dword (16 channels) per row and k-tile
+
+  auto issue = [&](int buf) {
+    char* base = lds + buf * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+      const int piece = wave + i * NW;
+      const bool isA = piece < A_CH;
+      char* dst = isA ? base + piece * 1024 : base + A_BYTES + (piece - A_CH) * 1024;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? ra : rb, (lds_void_t*)dst, 16, voff[i], 0, 0, 0);
+      voff[i] += BK * 4;
+    }
+    if constexpr (MASK) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rbits, (lds_void_t*)(base + A_BYTES + B_BYTES), 4, bvoff, 0, 0, 0);
+      bvoff += BK / 4;
+    }
+  };
+  constexpr int PER = NI + (MASK ? 1 : 0);
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  auto read_a = [&](const char* base, int gq, f32x4 (&af)[2]) {
+    const float* As = reinterpret_cast<const float*>(base);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = 32 * i + li;
+      af[i] = *reinterpret_cast<const f32x4*>(As + row * BK + 4 * ((2 * gq + lh) ^ swz16(row)));
+      if constexpr (MASK) {
+        const uint32_t b = reinterpret_cast<const uint8_t*>(base + A_BYTES + B_BYTES)[row * (BK / 4) + 2 * gq + lh];
+        af[i][0] = (b & 1u) ? af[i][0] * mscale : 0.f;
+        af[i][1] = (b & 2u) ? af[i][1] * mscale : 0.f;
+        af[i][2] = (b & 4u) ? af[i][2] * mscale : 0.f;
+        af[i][3] = (b & 8u) ? af[i][3] * mscale : 0.f;
+      }
+    }
+  };
+  auto read_b = [&](const char* base, int gq, f32x4 (&bf)[2]) {
+    const float* Bs = reinterpret_cast<const float*>(base + A_BYTES);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = wn0 + 32 * j + li;
+      bf[j] = *reinterpret_cast<const f32x4*>(Bs + row * BK + 4 * ((2 * gq + lh) ^ swz16(row)));
+    }
+  };
+  auto compute = [&](const char* base) {
+    f32x4 af[2][2], bf[2][2];
+    read_a(base, 0, af[0]);
+    read_b(base, 0, bf[0]);
+#pragma unroll
+    for (int gq = 0; gq < BK / 8; ++gq) {
+      const int cur = gq & 1, nxt = cur ^ 1;
+      if (gq + 1 < BK / 8) {
+        read_a(base, gq + 1, af[nxt]);
+        read_b(base, gq + 1, bf[nxt]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][s], bf[cur][j][s], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  // ---- key projection: 16 k-tiles through the ring ----
+  constexpr int nk = D / BK;
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s) issue(s);
+  int buf = 0, ibuf = NST - 1;
+  for (int t = 0; t < nk; ++t) {
+    if (t + NST - 2 < nk) __builtin_amdgcn_s_waitcnt(waitcnt_vm((NST - 2) * PER));
+    else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+    __builtin_amdgcn_s_barrier();
+    if (t + NST - 1 < nk) issue(ibuf);
+    compute(lds + buf * STAGE_BYTES);
+    buf = buf + 1 == NST ? 0 : buf + 1;
+    ibuf = ibuf + 1 == NST ? 0 : ibuf + 1;
+  }
+  __syncthreads();      // every wave has read its last fragments: the ring's memory becomes the key tile
+
+  // ---- K = tanh(acc + b): to the LDS key tile (and to HBM when the caller keeps the keys for the backward) ----
+  float* K_s = reinterpret_cast<float*>(lds);
+  float* q_s = reinterpret_cast<float*>(lds + TOP_BYTES);
+  float* keys_out = const_cast<float*>(p.keys);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = wn0 + 32 * j + li;
+      const float bv = u.b_in[col];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const float kv = fast_tanh(acc[i][j][e] + bv);
+        K_s[row * UMCA_LDK + col] = kv;
+        if (keys_out && t0 + row < T) keys_out[((size_t)v * T + t0 + row) * D + col] = kv;
+      }
+    }
+  __syncthreads();
+  attn_fwd_partial_body<false, 1, false, true>(p, static_cast<float*>(p.workspace), nchunk, chunk, v, K_s, q_s, K_s);
+#endif
+}
+
+}  // namespace sdumc_k3
+
+extern "C" int sdumc_umca_fwd(const sdumc_umca* up, void* stream) {
+  if (!up) return SDUMC_EINVAL;
+  sdumc_umca u = *up;
+  const sdumc_attnpool& p = u.a;
+  if (p.V <= 0 || p.T <= 0 || p.nq < 1 || p.nq > MAXQ || p.x_samples <= 0) return SDUMC_EINVAL;
+  if ((p.dim != 0 && p.dim != D) || p.bf16 || p.tickets) return SDUMC_EINVAL;       // 256-channel fp32 rows, two-pass combine
+  if (!p.x || !p.q || !p.attn || !p.pooled || !p.out || !u.w_in || !u.b_in) return SDUMC_EINVAL;
+  if (p.x_drop.enabled && !p.x_drop.bits) return SDUMC_EINVAL;                       // the input mask comes as keep-bits
+  if ((p.T + CH - 1) / CH > 4096) return SDUMC_EINVAL;
+  if (!p.workspace || p.workspace_bytes < sdumc_attnpool_fwd_workspace_bytes_dim(p.V, p.T, p.nq, D)) return SDUMC_ENOMEM;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sdumc_k3::umca_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            sdumc_k3::LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&sdumc_k3::umca_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            sdumc_k3::LDS_BYTES) != hipSuccess)
+      return SDUMC_ELAUNCH;
+    attr = true;
+  }
+  hipStream_t st = as_stream(stream);
+  const int nchunk = (p.T + CH - 1) / CH;
+  const dim3 grid(nchunk, p.V), blk(256);
+  if (p.x_drop.enabled) hipLaunchKernelGGL(sdumc_k3::umca_fwd_kernel<true>, grid, blk, sdumc_k3::LDS_BYTES, st, u, nchunk);
+  else hipLaunchKernelGGL(sdumc_k3::umca_fwd_kernel<false>, grid, blk, sdumc_k3::LDS_BYTES, st, u, nchunk);
+  SDUMC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(p.V), dim3(256), (size_t)nchunk * MAXQ * sizeof(float), st, p,
+                     static_cast<const float*>(p.workspace), nchunk);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
 }

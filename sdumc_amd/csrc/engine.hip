@@ -857,6 +857,40 @@ int pool_fwd_multi(const Ctx& c, int k) {
   return sdumc_attnpool_fwd_multi(a, n, c.st);
 }
 
+// K3 (sdumc_umca_fwd): key projection + pooling of site (k, m) in one kernel per run; the keys also go to HBM (`keep`: the
+// backward reads them, and a backward may follow an eval-mode forward too).  fp32 storage only.
+// Used for the FRA2UTT site (k = 0) of the modalities with more than one 64-frame chunk per sample.  Measured at C2
+// (tools/umca_bench.py, tools/infer_bench.py, bench.py; SDUMC_K3=0 restores the two-kernel path):
+//   * one site alone: audio 95 vs 97 us (GEMM + pooling), video 59 vs 69 us, C5's T = 512 68 vs 84 us; text's single 50-frame
+//     chunk 39 vs 33 us (22 % of its 64-row tile is padding and 128 workgroups do not fill the chip) -> text keeps the pair;
+//   * training step: 1.903 vs 1.914 ms (two alternations);
+//   * the Cross_Attention site (k = 1) does NOT use it: its projected queries exist only after the first utterance-level
+//     stage, so fusing would pull the key projection out of that stage's shadow -- an inference forward with all six sites
+//     fused measured 570 vs 544 us (one stream), 716 vs 706 us (two).
+bool k3_ok(const Ctx& c, int m) {
+  static const int on = [] { const char* e = getenv("SDUMC_K3"); return e ? atoi(e) : 1; }();
+  if (!on || c.h() || c.d.bf16) return false;
+  for (const Seg& sg : c.pl.segs[m])
+    if (sg.T < 96) return false;
+  return true;
+}
+int umca_site(const Ctx& c, int k, int m, bool keep) {
+  for (const Seg& sg : c.pl.segs[m]) {
+    sdumc_umca u;
+    memset(&u, 0, sizeof(u));
+    u.a = attn_desc(c, k, m, sg);
+    u.a.tickets = nullptr;
+    if (!keep) u.a.keys = nullptr;
+    u.a.workspace = c.scr;
+    u.a.workspace_bytes = (size_t)c.pl.scratch_floats * sizeof(float);
+    const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
+    u.w_in = c.P + L.w;
+    u.b_in = c.P + L.b;
+    RET(sdumc_umca_fwd(&u, c.st));
+  }
+  return SDUMC_OK;
+}
+
 int pool_fwd(const Ctx& c, int k, int m) {
   for (const Seg& sg : c.pl.segs[m]) {
     sdumc_attnpool a = attn_desc(c, k, m, sg);
@@ -1066,16 +1100,22 @@ int forward(const Ctx& c) {
       RET(lin_fwd(c, pm.frame[m], in, din[m], B * pl.T[m][s], c.p(pl.x[m][s]), D, SDUMC_ACT_NONE, nullptr, c.d.bf16 != 0));
     }
     if (bits_done[m] && hipStreamWaitEvent(c.st, bits_done[m], 0) != hipSuccess) return SDUMC_ELAUNCH;
+    const bool k3_site0 = k3_ok(c, m);
     if (c.bg) {   // the Cross_Attention keys are not needed before step 8: background lane, beside steps 2-7
-      RET(keys_gemm_fwd(c, m, 0, 1));
+      if (k3_site0) RET(umca_site(c, 0, m, true));
+      else RET(keys_gemm_fwd(c, m, 0, 1));
       RET(link(c, LANE_OF[m], 3));
       c.use(3);
       RET(keys_gemm_fwd(c, m, 1, 2));
       c.use(LANE_OF[m]);
+      if (!k3_site0) RET(pool_fwd(c, 0, m));
+    } else if (k3_site0) {
+      RET(umca_site(c, 0, m, true));
+      RET(keys_gemm_fwd(c, m, 1, 2));
     } else {
       RET(keys_gemm_fwd(c, m, 0, 2));
+      RET(pool_fwd(c, 0, m));
     }
-    RET(pool_fwd(c, 0, m));
   }
   c.use(0);
   RET(join_all(c));

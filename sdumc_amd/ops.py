@@ -104,7 +104,7 @@ def attnpool_desc(x, keys, q, V, T, nq, x_samples, q_stride, x_drop, out_drop, a
                   lengths=None, tickets=True):
     a = _lib.AttnPool()
     if tickets:      # zeroed per-sample counters: the combine / dq reduction run inside the first kernels
-        a._keep_tickets = torch.zeros(2 * V, dtype=torch.int32, device=keys.device)
+        a._keep_tickets = torch.zeros(2 * V, dtype=torch.int32, device=attn.device)
         a.tickets = ptr(a._keep_tickets)
     a.dim = dim
     a.lengths = ptr(lengths)   # int32 [V] key-padding extension, or None = the reference's behaviour
@@ -152,6 +152,31 @@ def attnpool_bwd(desc, dout, keep):
     b.workspace, b.workspace_bytes = ptr(ws), need
     check(lib.sdumc_attnpool_bwd(C.byref(b), _st()), "sdumc_attnpool_bwd")
     return dz, dxd, dq
+
+
+def umca_fwd(x, W, b, q, nq, x_samples=None, q_shared=False, x_drop=None, out_drop=None, lengths=None, want_keys=True, V=None):
+    """K3 (sdumc_umca_fwd): key projection + scores + softmax partials + pooling in one kernel.  x [x_samples, T, 256] fp32,
+    W [256, 256], b [256]; x_drop must carry keep-bits (dropout_bits).  -> (out, attn, pooled, keys or None, desc); the desc
+    (with keys attached) is what attnpool_bwd takes."""
+    xs, T, Dm = x.shape
+    V = V or (q.shape[0] if not q_shared else xs)
+    dev = x.device
+    attn = torch.empty(V, T, nq, device=dev)
+    pooled = torch.empty(V, nq, Dm, device=dev)
+    out = torch.empty(V, nq, Dm, device=dev)
+    keys = torch.empty(V, T, Dm, device=dev) if want_keys else None
+    a = attnpool_desc(x, keys, q, V, T, nq, x_samples or xs, 0 if q_shared else nq * Dm, x_drop, out_drop, attn, pooled, out,
+                      lengths=lengths, tickets=False)
+    need = lib.sdumc_attnpool_fwd_workspace_bytes(V, T, nq)
+    ws = torch.empty(need, dtype=torch.uint8, device=dev)
+    a.workspace, a.workspace_bytes = ptr(ws), need
+    u = _lib.Umca()
+    u.a = a
+    u.w_in, u.b_in = ptr(W), ptr(b)
+    check(lib.sdumc_umca_fwd(C.byref(u), _st()), "sdumc_umca_fwd")
+    torch.cuda.current_stream().synchronize()
+    a._keep = (ws, keys, x, q, W, b, lengths)
+    return out, attn, pooled, keys, a
 
 
 def attnpool_fwd_multi(sites):

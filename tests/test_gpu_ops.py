@@ -257,6 +257,54 @@ def test_attnpool_fwd_bwd(ops, nq, T, shared_q):
     close(dq.sum(0, keepdim=True) if shared_q else dq, dq_ref, 1e-4)
 
 
+@pytest.mark.parametrize("nq,T,shared_q,mask", [(7, 130, False, True), (1, 375, True, True), (7, 37, False, False), (7, 64, False, True)])
+def test_umca_fused_forward_k3(ops, nq, T, shared_q, mask):
+    """K3 (sdumc_umca_fwd: projection + scores + softmax + pooling in one kernel) against the fp64 restatement of
+    Cross_Attention / FRA2UTT_new (model :79-95, :56-68) and against the two-kernel composition it replaces; with and
+    without keeping the keys; its keys then drive the ordinary backward."""
+    from oracle import philox
+    from sdumc_amd._lib import make_dropout
+    g = torch.Generator().manual_seed(nq * 100 + T)
+    B, S, Dm = 3, 2, 256
+    V = B * S
+    x = torch.randn(B, T, Dm, generator=g)
+    W, b = torch.randn(Dm, Dm, generator=g) / 16, torch.randn(Dm, generator=g) * 0.1
+    q = torch.randn(1 if shared_q else V, nq, Dm, generator=g) / 4
+    seed, call = 31, 6
+    xdrop = make_dropout(mask, 23, 0.5, T, Dm, B, call0=call, seed=seed)
+    odrop = make_dropout(True, 24, 0.5, nq, Dm, B, call0=call, seed=seed)
+    ones = torch.ones(V, T, Dm, dtype=torch.float64)
+    xm = torch.from_numpy(np.concatenate([philox.dropout_mask(B, T, Dm, 0.5, seed, call + s, 23) for s in range(S)])) if mask else ones
+    om = torch.from_numpy(np.concatenate([philox.dropout_mask(B, nq, Dm, 0.5, seed, call + s, 24) for s in range(S)]))
+    xx = torch.cat([x] * S).double()
+    out_ref, a_ref, pooled_ref, keys_ref = _attn_ref(xx, W.double(), b.double(), q.double().expand(V, nq, Dm), xm, om)
+    xg, Wg, bg, qg = dev(x), dev(W), dev(b), dev(q)
+    bits = ops.dropout_bits(xdrop, S) if mask else None
+    out, attn, pooled, keys, desc = ops.umca_fwd(xg, Wg, bg, qg, nq, x_samples=B, q_shared=shared_q, x_drop=xdrop if mask else None,
+                                                 out_drop=odrop, V=V)
+    close(keys, keys_ref, 2e-5)
+    close(attn, a_ref, 2e-5)
+    close(pooled, pooled_ref, 2e-5)
+    close(out, out_ref, 2e-5)
+    # the composition K3 replaces: wide NT GEMM (same tile arithmetic) + the pooling pair
+    keys2 = ops.gemm(ops.NT, xg, Wg, V * T, Dm, Dm, bias=bg, act=ops.ACT_TANH, a_row_mod=B * T,
+                     a_drop=xdrop if mask else None).view(V, T, Dm)
+    out2, attn2, pooled2, _ = ops.attnpool_fwd(xg, keys2, qg, nq, x_samples=B, q_shared=shared_q, x_drop=xdrop if mask else None,
+                                               out_drop=odrop, tickets=False)
+    close(keys, keys2, 1e-6)
+    close(out, out2, 2e-6)
+    close(attn, attn2, 2e-6)
+    # inference form: no keys tensor at all, same outputs
+    out3, attn3, pooled3, none, _ = ops.umca_fwd(xg, Wg, bg, qg, nq, x_samples=B, q_shared=shared_q, x_drop=xdrop if mask else None,
+                                                 out_drop=odrop, want_keys=False, V=V)
+    assert none is None and torch.equal(out3, out) and torch.equal(attn3, attn) and torch.equal(pooled3, pooled)
+    # K3's keys feed the ordinary backward
+    dout = dev(torch.randn(V, nq, Dm, generator=g))
+    dz, dxd, dq = ops.attnpool_bwd(desc, dout, ())
+    assert bool(torch.isfinite(dz).all()) and bool(torch.isfinite(dxd).all()) and bool(torch.isfinite(dq).all())
+    del bits
+
+
 def test_attnpool_multi_equals_single_calls(ops):
     """sdumc_attnpool_fwd_multi / _bwd_multi (the step's three Cross_Attention blocks in one launch pair) against one call per
     site: bit-identical, ragged T, keep-bits masks, key-padding lengths on one site."""
