@@ -224,7 +224,7 @@ int sdumc_attnpool_bwd(const sdumc_attnpool_bwd_t* p, void* stream);
  * projection + scores + softmax partials + pooling of one 64-frame chunk in ONE kernel -- K = tanh(drop(x) W_in^T + b) is
  * computed on the matrix cores into an LDS tile and consumed there; it goes to HBM only if a.keys != NULL (training keeps the
  * keys for sdumc_attnpool_bwd; inference passes NULL and the [V, T, 256] tensor never exists).  Takes the place of
- * sdumc_gemm(NT, tanh, input dropout) + sdumc_attnpool_fwd on the same descriptor; same results (same arithmetic, same order).
+ * the NT key-projection GEMM (fused input dropout, bias, tanh) followed by sdumc_attnpool_fwd on the same descriptor; same results.
  * fp32, 256 channels, input mask as keep-bits (x_drop.bits) or none, a.tickets NULL. */
 typedef struct sdumc_umca {
   sdumc_attnpool a;      /* as for sdumc_attnpool_fwd; a.keys = OUTPUT [V, T, 256] or NULL */
