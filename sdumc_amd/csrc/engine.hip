@@ -331,7 +331,7 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
   p.dq_fra = p.alloc(3LL * V * D);
   p.lens = p.alloc(3LL * V);
   p.tickets = p.alloc(12LL * V + 16);    // attention sites [2][3] x 2V counters (sdumc_attnpool.tickets), zeroed by forward()
-  p.wt = p.alloc(build_params(d.da, d.dt, d.dv).early);
+  p.wt = p.alloc(build_params(d.da, d.dt, d.dv).live);   // transposed mirror: utterance-level layers (chain) + the six input_proj
   if (p.hf) {
     const int64_t live = build_params(d.da, d.dt, d.dv).live;
     p.wh = p.alloc(live / 2 + 8);
@@ -939,12 +939,30 @@ std::vector<const Lin*> chain_lins(const ParamMap& pm) {
   return v;
 }
 
+// SDUMC_KEYS_DX_NT=1: the key-projection dX product dxd += dz W as NT on a transposed weight mirror through the wide LDS-DMA
+// kernel instead of as NN through the 64x64 kernel.  Alone the wide kernel is faster (96-98 vs 70 TF); inside the step it
+// LOSES -- 1.952 vs 1.925 ms in two alternations, bit-identical results: its 60 KB LDS rings co-reside badly with the other
+// lanes' kernels -- so the default stays NN.
+int keys_dx_nt() {
+  static const int v = [] { const char* e = getenv("SDUMC_KEYS_DX_NT"); return e ? atoi(e) : 0; }();
+  return v;
+}
+// transposed fp32 mirror, refreshed once per forward: the utterance-level weights (the chain kernels stream W^T forward) and,
+// for SDUMC_KEYS_DX_NT, the six input_proj weights
 int chain_transpose(const Ctx& c) {
-  const std::vector<const Lin*> ls = chain_lins(c.pm);
   int64_t offs[40];
   int32_t outs[40], ins[40];
   int n = 0;
-  for (const Lin* L : ls) { offs[n] = L->w; outs[n] = L->out; ins[n] = L->in; ++n; }
+  if (use_chain(c)) {
+    const std::vector<const Lin*> ls = chain_lins(c.pm);
+    for (const Lin* L : ls) { offs[n] = L->w; outs[n] = L->out; ins[n] = L->in; ++n; }
+  }
+  if (!c.h() && keys_dx_nt())
+    for (int m = 0; m < 3; ++m) {
+      offs[n] = c.pm.fra_proj[m].w; outs[n] = D; ins[n] = D; ++n;
+      offs[n] = c.pm.ca_in[m].w; outs[n] = D; ins[n] = D; ++n;
+    }
+  if (n == 0) return SDUMC_OK;
   return sdumc_chain_transpose_(c.P, c.p(c.pl.wt), offs, outs, ins, n, c.st);
 }
 
@@ -1048,7 +1066,7 @@ int forward(const Ctx& c) {
     }
     RET(fork_all(c));      // (the lanes forked above did not see these launches)
   }
-  if (chain) {   // transposed mirror of the utterance-level weights (7 MB, first needed after the frame-level part): lane 3
+  if (chain || (!c.h() && keys_dx_nt())) {   // transposed mirrors (first needed after the frame-level part / in the backward): lane 3
     RET(link(c, 0, 3));
     c.use(3);
     RET(chain_transpose(c));
@@ -1350,12 +1368,13 @@ int keys_gemm_bwd(const Ctx& c, int m, int k0, int k1, int parts = 3) {
     first = false;
   }
   if (!(parts & 2)) return SDUMC_OK;
-  // dxd += dz W (the key-projection path joins the pooling path)
-  sdumc_gemm g = G_(SDUMC_NN, (int)pl.rows[m], D, D, k1 - k0);
+  // dxd += dz W (the key-projection path joins the pooling path): NT on the transposed mirror (chain_transpose)
+  const int as_nt = keys_dx_nt();
+  sdumc_gemm g = G_(as_nt ? SDUMC_NT : SDUMC_NN, (int)pl.rows[m], D, D, k1 - k0);
   for (int k = k0; k < k1; ++k) {
     const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
     g.A[k - k0] = c.p(pl.dz[k][m]);
-    g.B[k - k0] = c.P + L.w;
+    g.B[k - k0] = as_nt ? c.p(pl.wt) + L.w : c.P + L.w;
     g.C[k - k0] = c.p(pl.dxd[k][m]);
   }
   g.lda = g.ldb = g.ldc = D;
