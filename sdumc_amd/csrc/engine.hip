@@ -385,7 +385,7 @@ struct LaneSet {
 };
 // Debug timeline (tools/step_marks.py): sdumc_debug_marks(1) makes the step record an event on the caller's stream at a few
 // fixed points; sdumc_debug_marks_read returns their times since mark 0.  Process-wide, single-threaded use only.
-constexpr int kMarks = 12;
+constexpr int kMarks = 32;
 bool g_marks_on = false;
 hipEvent_t g_marks[kMarks] = {};
 bool g_mark_set[kMarks] = {};
@@ -1619,6 +1619,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     float* dq = c.p(pl.dq_fra) + (int64_t)m * V * D;
     RET(pool_bwd(c, 0, m, c.p(pl.d_hpre) + (int64_t)m * V * D, dq));
     RET(colsum(c, dq, V, D, D, c.G + pm.fra_ctx[m], 0));
+    mark(c.st, 12 + 5 * m);      // (debug marks 12..26: this modality's lane, frame-level backward)
     {
       const int k1 = (bgb & (1 << m)) ? 1 : 2;
       // bit m: modality m's key-projection dW (off the dz -> dX -> mask-sum -> frame dW chain) runs on lane 3.  Default: audio
@@ -1637,6 +1638,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
         RET(keys_gemm_bwd(c, m, 0, k1));
       }
     }
+    mark(c.st, 13 + 5 * m);
     if (bgb & ~own_lane & (1 << m)) {   // dxd of this modality's Cross_Attention site (issued early on lane 3)
       if (early_done[m]) {
         if (hipStreamWaitEvent(c.st, early_done[m], 0) != hipSuccess) return SDUMC_ELAUNCH;
@@ -1664,7 +1666,9 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
         }
       ds.terms = nt;
       if (c.h()) ds.bf16 = 1;          // (dx is a half-length buffer: its float offset is its start either way)
+      if (s == 0) mark(c.st, 14 + 5 * m);     // (after the wait for the early key-projection backward)
       RET(sdumc_dropsum_bwd(&ds, c.st));
+      if (s == 0) mark(c.st, 15 + 5 * m);
       const float* in = m == 0 ? c.io.audio : (m == 2 ? c.io.video : c.io.text[s]);
       const int rows = B * T;
       if (c.h()) {     // dW_frame = dx^T features on bf16 storage
@@ -1694,6 +1698,8 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     }
   }
   c.use(0);
+  for (int m = 0; m < 3; ++m) mark(c.sts[LANE_OF[m]], 16 + 5 * m);
+  mark(c.sts[3], 27);
   RET(join_all(c));
   RET(link(c, 3, 0));   // the last dW batch of the utterance-level part
   return SDUMC_OK;

@@ -30,11 +30,24 @@ for _ in range(N):
     _lib.lib.sdumc_debug_marks_read(ms, 11)
     for i in range(11):
         acc[i] += ms[i]
+ms2 = [0.0] * 32
+for _ in range(N):
+    step.run()
+    torch.cuda.synchronize()
+    buf = (C.c_float * 32)()
+    _lib.lib.sdumc_debug_marks_read(buf, 32)
+    for i in range(32):
+        ms2[i] += buf[i]
 prev = 0.0
 for i, n in enumerate(names):
     t = acc[i] / N * 1e3
     print(f"{i:2d} {t:8.1f} us  (+{t - prev:7.1f})  {n}")
     prev = t
+
+lane_names = ["pooling bwd + colsum done", "key-projection dX done", "early Cross_Attention dxd awaited", "mask-sum done", "frame dW done"]
+for m, mod in enumerate(("audio", "text", "video")):
+    print(f"  {mod} lane (frame-level backward):", "  ".join(f"{lane_names[j]} {ms2[12 + 5 * m + j] / N * 1e3:7.1f}" for j in range(5)))
+print(f"  lane 3 drained at {ms2[27] / N * 1e3:7.1f} us")
 
 # phase stamps of workgroup 0 inside the clustered utterance-level kernels (chain_cluster.hip), when they are in use
 try:
