@@ -64,6 +64,10 @@ struct sdumc_chain_args {
 };
 
 extern "C" {
+// loss.hip: the six loss launches of a single-GPU step in two (1 = shape not taken)
+int sdumc_losses_fused_(int32_t B, const float* vals, const float* labels, const float* th, const float* ct, const float* z,
+                        const float* rnc_feats, int32_t rd, float temperature, const float* weights6, float* d_vals, float* d_th,
+                        float* d_ct, float* d_z, float* d_rnc, float* losses, float* distill_ws, float* rnc_workspace, void* stream);
 // which: 0 = stage A forward, 1 = stage B forward, 2 = stage B backward, 3 = stage A backward
 int sdumc_chain_launch_(const sdumc_chain_args* a, int which, void* stream);
 // the same four stages with every layer's output columns split over clusters of 4 workgroups (chain_cluster.hip);

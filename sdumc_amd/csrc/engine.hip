@@ -1894,6 +1894,16 @@ int loss_backward_impl(const sdumc_net_dims* d, const sdumc_net_io* io, const sd
   float* dct = const_cast<float*>(g->d_cross_text);
   float* L = cfg->losses;
   const float* w = cfg->weights;
+  // single GPU (no global sums / features handed in): the distillation terms and RnC share their two passes (loss.hip)
+  static const int fused = [] { const char* e = getenv("SDUMC_LOSS_FUSED"); return e ? atoi(e) : 1; }();
+  bool done = false;
+  if (fused && !cfg->rnc_feats_global && !cfg->ssd_global && Bg == B) {
+    const int rc = sdumc_losses_fused_(B, io->vals, cfg->labels, io->text_hidden, io->cross_text, io->fused, io->rnc, RD,
+                                       cfg->temperature, w, dv, dth, dct, df, dr, L, ls.ssd_ws, ls.rnc_ws, stream);
+    if (rc < 0) return rc;
+    done = rc == 0;
+  }
+  if (!done) {
   // MSELoss x2 (main :137-138) + RMSELoss x3 (main :148; teacher side detached for text_feat / text_query_feat,
   // not for features): value and gradients in two launches
   RET(sdumc_distill_fwd_bwd(B, (float)Bg, io->vals, cfg->labels, io->text_hidden, io->cross_text, io->fused, w,
@@ -1908,6 +1918,7 @@ int loss_backward_impl(const sdumc_net_dims* d, const sdumc_net_io* io, const sd
   } else {
     RET(sdumc_rnc_fwd_bwd_rep(io->rnc, cfg->labels, 2 * B, RD, cfg->temperature, w[5], 0, 2 * B, L + 6, dr, ls.rnc_ws, st));
   }
+  }   // !done
   hipLaunchKernelGGL(total_loss_kernel, dim3(1), dim3(1), 0, st, L, w[0], w[1], w[2], w[3], w[4], w[5], hyper,
                      (double)cfg->beta1, (double)cfg->beta2);
   SDUMC_CHECK_LAUNCH();

@@ -82,20 +82,20 @@ __host__ __device__ inline RncWs rnc_ws(float* w, int n) {
   return r;
 }
 
-__global__ __launch_bounds__(256) void rnc_loss_kernel(int n, RncWs w, float* loss_out) {
+__device__ __forceinline__ void rnc_loss_body(int n, RncWs w, float* loss_out) {
   __shared__ float red[4];
   float acc = 0.f;
   for (int i = threadIdx.x; i < n; i += 256) acc += w.rowloss[i];
   const float s = block_sum_256(acc, red);
   if (threadIdx.x == 0) *loss_out = -s / ((float)n * (float)(n - 1));
 }
+__global__ __launch_bounds__(256) void rnc_loss_kernel(int n, RncWs w, float* loss_out) { rnc_loss_body(n, w, loss_out); }
 
 // One workgroup per anchor i, everything that depends on row i only: distances, label differences, exp,
 // the masked denominators D_ik, the row's loss and G_i* = dLoss/dlogit_i*.  labels: y[j] = labels[j % label_mod]
 // when label_mod > 0 (the reference's labels.repeat(2, 1), loss.py:283, without materialising it).
-__global__ __launch_bounds__(256) void rnc_row_kernel(const float* f, const float* labels, int label_mod, int n,
-                                                      int dim, float inv_t, RncWs w, int want_grad) {
-  extern __shared__ float sm[];   // fi[dim] | ld[n] | ee[n] | dd[n] | thr[n] | iD[n]
+__device__ __forceinline__ void rnc_row_body(const float* f, const float* labels, int label_mod, int n, int dim, float inv_t,
+                                             RncWs w, int want_grad, const int i, float* sm /* fi[dim] | ld[n] | ee[n] | dd[n] | thr[n] | iD[n] */) {
   __shared__ float red[4];
   float* fi = sm;
   float* ld = fi + ((dim + 3) & ~3);
@@ -103,7 +103,6 @@ __global__ __launch_bounds__(256) void rnc_row_kernel(const float* f, const floa
   float* dd = ee + n;
   float* thr = dd + n;
   float* iD = thr + n;
-  const int i = blockIdx.x;
   for (int c = threadIdx.x; c < dim; c += 256) fi[c] = f[(size_t)i * dim + c];
   __syncthreads();
   const float yi = labels[label_mod > 0 ? i % label_mod : i];
@@ -180,6 +179,11 @@ __global__ __launch_bounds__(256) void rnc_row_kernel(const float* f, const floa
     }
     w.G[(size_t)i * n + j] = g;
   }
+}
+__global__ __launch_bounds__(256) void rnc_row_kernel(const float* f, const float* labels, int label_mod, int n,
+                                                      int dim, float inv_t, RncWs w, int want_grad) {
+  extern __shared__ float sm[];
+  rnc_row_body(f, labels, label_mod, n, dim, inv_t, w, want_grad, blockIdx.x, sm);
 }
 
 // ---- O(n^2 log n) formulation (n <= 2048) ---------------------------------------------------------------------
@@ -374,12 +378,11 @@ __global__ __launch_bounds__(256) void rnc_row_sorted_kernel(const float* f, con
 }
 
 // df_i = -(1/t) sum_j (G_ij + G_ji) (f_i - f_j) / dist_ij ; one workgroup per local row
-__global__ __launch_bounds__(256) void rnc_dfeat_kernel(const float* f, int n, int dim, float inv_t, float weight,
-                                                        int row0, RncWs w, float* df) {
-  extern __shared__ float sm[];  // coef[n], then red[4][dim]
+__device__ __forceinline__ void rnc_dfeat_body(const float* f, int n, int dim, float inv_t, float weight, int row0, RncWs w, float* df,
+                                               const int bx, float* sm /* coef[n], then red[4][64] */) {
   float* coef = sm;
   float* red = sm + n;
-  const int i = row0 + blockIdx.x;
+  const int i = row0 + bx;
   for (int j = threadIdx.x; j < n; j += 256) {
     const float d = w.dist[(size_t)i * n + j];
     coef[j] = (j != i && d > 0.f) ? (w.G[(size_t)i * n + j] + w.G[(size_t)j * n + i]) / d : 0.f;
@@ -404,9 +407,14 @@ __global__ __launch_bounds__(256) void rnc_dfeat_kernel(const float* f, int n, i
     red[part * 64 + lane] = acc;
     __syncthreads();
     if (part == 0 && c < dim)
-      df[(size_t)blockIdx.x * dim + c] = -weight * inv_t * (red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane]);
+      df[(size_t)bx * dim + c] = -weight * inv_t * (red[lane] + red[64 + lane] + red[128 + lane] + red[192 + lane]);
     __syncthreads();
   }
+}
+__global__ __launch_bounds__(256) void rnc_dfeat_kernel(const float* f, int n, int dim, float inv_t, float weight,
+                                                        int row0, RncWs w, float* df) {
+  extern __shared__ float sm[];
+  rnc_dfeat_body(f, n, dim, inv_t, weight, row0, w, df, blockIdx.x, sm);
 }
 
 __global__ void rnc_mask_kernel(const float* y, int n, uint8_t* mask) {
@@ -447,29 +455,28 @@ __device__ __forceinline__ void distill_pair(const DistillArgs& a, int p, const 
   s1 = base + n;
   g = p == 0 ? a.d_th : (p == 1 ? a.d_ct : a.d_z);
 }
-__global__ __launch_bounds__(256) void distill_partials_kernel(const DistillArgs a) {
+__device__ __forceinline__ void distill_partials_body(const DistillArgs a, const int bx, const int p) {
   __shared__ float red[4];
-  const int p = blockIdx.y;
-  if ((int)blockIdx.x >= a.nblk[p]) return;
+  if (bx >= a.nblk[p]) return;
   const float *s1, *s0;
   float* g;
   int64_t n;
   distill_pair(a, p, s1, s0, g, n);
-  const int64_t i0 = (int64_t)blockIdx.x * DCH, i1 = min(n, i0 + DCH);
+  const int64_t i0 = (int64_t)bx * DCH, i1 = min(n, i0 + DCH);
   float acc = 0.f;
   for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
     const float d = s1[i] - s0[i];
     acc += d * d;
   }
   const float s = block_sum_256(acc, red);
-  if (threadIdx.x == 0) a.part[p * a.nblk[1] + blockIdx.x] = s;
+  if (threadIdx.x == 0) a.part[p * a.nblk[1] + bx] = s;
 }
-__global__ __launch_bounds__(256) void distill_apply_kernel(const DistillArgs a) {
+__global__ __launch_bounds__(256) void distill_partials_kernel(const DistillArgs a) { distill_partials_body(a, blockIdx.x, blockIdx.y); }
+__device__ __forceinline__ void distill_apply_body(const DistillArgs a, const int bx, const int p) {
   __shared__ float red[4];
-  const int p = blockIdx.y;
   if (p == 3) {   // MSELoss on both streams (loss.py:19-33): value + gradient
-    if (blockIdx.x > 1) return;
-    const int sidx = blockIdx.x;
+    if (bx > 1) return;
+    const int sidx = bx;
     const float inv = 1.f / a.denom;
     float acc = 0.f;
     for (int i = threadIdx.x; i < a.B; i += 256) {
@@ -481,7 +488,7 @@ __global__ __launch_bounds__(256) void distill_apply_kernel(const DistillArgs a)
     if (threadIdx.x == 0) a.losses[1 + sidx] = s * inv;
     return;
   }
-  if ((int)blockIdx.x >= a.nblk[p]) return;
+  if (bx >= a.nblk[p]) return;
   const float *s1, *s0;
   float* g;
   int64_t n;
@@ -497,13 +504,50 @@ __global__ __launch_bounds__(256) void distill_apply_kernel(const DistillArgs a)
   const float per = p == 0 ? SDUMC_D : (p == 1 ? SDUMC_NQ * SDUMC_H : SDUMC_H);
   const float inv_numel = 1.f / (a.denom * per);
   const float rmse = sqrtf(ssd * inv_numel);
-  if (blockIdx.x == 0 && threadIdx.x == 0) a.losses[3 + p] = rmse;
+  if (bx == 0 && threadIdx.x == 0) a.losses[3 + p] = rmse;
   const float k = a.w[2 + p] * inv_numel / rmse;   // 0/0 -> NaN exactly like torch's sqrt backward
-  const int64_t i0 = (int64_t)blockIdx.x * DCH, i1 = min(n, i0 + DCH);
+  const int64_t i0 = (int64_t)bx * DCH, i1 = min(n, i0 + DCH);
   for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
     const float gr = k * (s1[i] - s0[i]);
     g[n + i] = gr;                        // stream 1 (student)
     g[i] = p == 2 ? -gr : 0.f;           // stream 0: detached for text_feat / text_query_feat (main :148), not for features
+  }
+}
+__global__ __launch_bounds__(256) void distill_apply_kernel(const DistillArgs a) { distill_apply_body(a, blockIdx.x, blockIdx.y); }
+
+// ---- the six loss launches of a single-GPU step as TWO (+ the one-thread total): the distillation terms and Rank-N-Contrast
+// are independent, so their first passes share a launch (workgroups [0, n): one RnC anchor each; the rest: partial sums of
+// squares) and so do their second passes (RnC feature gradients | distillation values + gradients | the RnC mean).  No
+// atomics, no change in any summation order: same bits as the separate launches.
+struct RncArgs {
+  const float* f;
+  const float* labels;
+  int label_mod, n, dim;
+  float inv_t, weight;
+  RncWs w;
+  float* loss_out;
+  float* df;
+};
+__global__ __launch_bounds__(256) void loss_stage1_kernel(const DistillArgs a, const RncArgs r, const int mx) {
+  extern __shared__ float sm[];
+  const int bid = blockIdx.x;
+  if (bid < r.n) {
+    rnc_row_body(r.f, r.labels, r.label_mod, r.n, r.dim, r.inv_t, r.w, 1, bid, sm);
+  } else {
+    const int q = bid - r.n;
+    distill_partials_body(a, q % mx, q / mx);
+  }
+}
+__global__ __launch_bounds__(256) void loss_stage2_kernel(const DistillArgs a, const RncArgs r, const int amx) {
+  extern __shared__ float sm[];
+  const int bid = blockIdx.x;
+  if (bid < r.n) {
+    rnc_dfeat_body(r.f, r.n, r.dim, r.inv_t, r.weight, 0, r.w, r.df, bid, sm);
+  } else if (bid < r.n + 4 * amx) {
+    const int q = bid - r.n;
+    distill_apply_body(a, q % amx, q / amx);
+  } else {
+    rnc_loss_body(r.n, r.w, r.loss_out);
   }
 }
 }  // namespace
@@ -715,6 +759,47 @@ extern "C" int sdumc_distill_fwd_bwd(int32_t B, float denom, const float* vals, 
     SDUMC_CHECK_LAUNCH();
   }
   hipLaunchKernelGGL(distill_apply_kernel, dim3(mx > 2 ? mx : 2, 4), dim3(256), 0, st, a);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+// MSE x2 + RMSE x3 + RnC over cat(stream 0, stream 1) with the labels repeated (main :134-148): values and every gradient
+// w.r.t. the network outputs in two launches.  Returns 1 when the shape is not one it takes (n = 2B > 256: the sorted RnC form).
+extern "C" int sdumc_losses_fused_(int32_t B, const float* vals, const float* labels, const float* th, const float* ct,
+                                   const float* z, const float* rnc_feats, int32_t rd, float temperature, const float* weights6,
+                                   float* d_vals, float* d_th, float* d_ct, float* d_z, float* d_rnc, float* losses,
+                                   float* distill_ws, float* rnc_workspace, void* stream) {
+  const int n = 2 * B;
+  if (B <= 0 || n > 256 || rd <= 0 || temperature <= 0.f) return 1;
+  const size_t lds1 = (((size_t)rd + 3) & ~(size_t)3) * sizeof(float) + 5 * (size_t)n * sizeof(float);
+  const size_t lds2 = ((size_t)n + 256) * sizeof(float);
+  if (lds1 > 64 * 1024) return 1;
+  DistillArgs a;
+  a.B = B;
+  a.denom = (float)B;
+  a.vals = vals; a.labels = labels; a.th = th; a.ct = ct; a.z = z;
+  for (int i = 0; i < 5; ++i) a.w[i] = weights6[i];
+  a.ssd_global = nullptr;
+  a.d_vals = d_vals; a.d_th = d_th; a.d_ct = d_ct; a.d_z = d_z;
+  a.losses = losses;
+  a.part = distill_ws;
+  const int64_t per[3] = {SDUMC_D, SDUMC_NQ * SDUMC_H, SDUMC_H};
+  int mx = 1;
+  for (int p = 0; p < 3; ++p) {
+    a.nblk[p] = (int)(((int64_t)B * per[p] + DCH - 1) / DCH);
+    mx = a.nblk[p] > mx ? a.nblk[p] : mx;
+  }
+  const int amx = mx > 2 ? mx : 2;
+  RncArgs r;
+  r.f = rnc_feats; r.labels = labels; r.label_mod = B; r.n = n; r.dim = rd;
+  r.inv_t = 1.f / temperature; r.weight = weights6[5];
+  r.w = rnc_ws(rnc_workspace, n);
+  r.loss_out = losses + 6;
+  r.df = d_rnc;
+  hipStream_t st = as_stream(stream);
+  hipLaunchKernelGGL(loss_stage1_kernel, dim3(n + 3 * mx), dim3(256), lds1, st, a, r, mx);
+  SDUMC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(loss_stage2_kernel, dim3(n + 4 * amx + 1), dim3(256), lds2, st, a, r, amx);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
 }
