@@ -21,7 +21,8 @@ __global__ void adam_hyper_kernel(float* hyper, double beta1, double beta2) {
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, int64_t n4,
                                                    int64_t n, const float* hyper, float beta1, float beta2, float eps,
-                                                   float wd, float gscale, uint32_t* rng, uint32_t rng_inc) {
+                                                   float wd, float gscale, uint32_t* rng, uint32_t rng_inc,
+                                                   const sdumc_total_loss tl) {
   const float step_size = hyper[2], bc2_sqrt = hyper[3];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n4) {
@@ -43,6 +44,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
   // scalar tail (+ the dropout call counter: every reader of this step is ordered before this launch)
   if (i == 0) {
     if (rng) rng[2] += rng_inc;
+    if (tl.losses) {     // the step's weighted total (main :149), for the caller's read-back: the six terms were final long ago
+      float* L = tl.losses;
+      L[0] = tl.w[0] * L[1] + tl.w[1] * L[2] + tl.w[2] * L[3] + tl.w[3] * L[4] + tl.w[4] * L[5] + tl.w[5] * L[6];
+      L[7] = 0.f;
+    }
     for (int64_t t = n4 * 4; t < n; ++t) {
       const float ge = g[t] * gscale + wd * p[t];
       m[t] = m[t] + (ge - m[t]) * (1.f - beta1);
@@ -63,15 +69,20 @@ extern "C" int sdumc_adam_hyper_(float* hyper, float beta1, float beta2, void* s
 
 extern "C" int sdumc_adam_apply_(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                                  const float* hyper, float beta1, float beta2, float eps, float weight_decay,
-                                 float grad_scale, uint32_t* rng_state, uint32_t rng_inc, void* stream) {
+                                 float grad_scale, uint32_t* rng_state, uint32_t rng_inc, const sdumc_total_loss* total,
+                                 void* stream) {
   if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper || n <= 0) return SDUMC_EINVAL;
+  sdumc_total_loss tl;
+  tl.losses = nullptr;
+  for (int i = 0; i < 6; ++i) tl.w[i] = 0.f;
+  if (total) tl = *total;
   if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
        reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15)
     return SDUMC_EINVAL;
   const int64_t n4 = n / 4;
   const int64_t threads = n4 > 0 ? n4 : 1;
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, as_stream(stream), param, grad,
-                     exp_avg, exp_avg_sq, n4, n, hyper, beta1, beta2, eps, weight_decay, grad_scale, rng_state, rng_inc);
+                     exp_avg, exp_avg_sq, n4, n, hyper, beta1, beta2, eps, weight_decay, grad_scale, rng_state, rng_inc, tl);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
 }
@@ -83,5 +94,5 @@ extern "C" int sdumc_adam_step(float* param, const float* grad, float* exp_avg, 
   int rc = sdumc_adam_hyper_(hyper, beta1, beta2, stream);
   if (rc) return rc;
   return sdumc_adam_apply_(param, grad, exp_avg, exp_avg_sq, n, hyper, beta1, beta2, eps, weight_decay, grad_scale, nullptr,
-                           0u, stream);
+                           0u, nullptr, stream);
 }

@@ -18,6 +18,11 @@ static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 // Internal entry points (not part of include/sdumc_hip.h): fused variants the engine's train step uses to take
 // ~6.6 us dependent launches off its critical chain (measured: five such launches removed = 2.152 -> 2.119 ms).
 // ---------------------------------------------------------------------------
+// the fused step's weighted total loss (losses[0]) is written by the Adam launch instead of by a one-thread kernel of its own
+struct sdumc_total_loss {
+  float* losses;   // [8] or nullptr
+  float w[6];
+};
 extern "C" {
 // sdumc_zpool_bwd with dz := dz + dz_add (dz_add may be NULL): folds the external gradient of cross_fused_feat in
 int sdumc_zpool_bwd_add_(const float* h, const float* beta, const float* dz, const float* dz_add, float* dh, float* dbeta,
@@ -30,7 +35,7 @@ int sdumc_adam_hyper_(float* hyper, float beta1, float beta2, void* stream);
 // ... and the parameter update alone; rng_state != NULL: its call counter advances by rng_inc in the same launch
 int sdumc_adam_apply_(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, const float* hyper,
                       float beta1, float beta2, float eps, float weight_decay, float grad_scale, uint32_t* rng_state,
-                      uint32_t rng_inc, void* stream);
+                      uint32_t rng_inc, const struct sdumc_total_loss* total, void* stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -65,9 +70,11 @@ struct sdumc_chain_args {
 
 extern "C" {
 // loss.hip: the six loss launches of a single-GPU step in two (1 = shape not taken)
+// hyper != nullptr: the second pass also makes the Adam bias-correction update of this step (as total_loss_kernel did)
 int sdumc_losses_fused_(int32_t B, const float* vals, const float* labels, const float* th, const float* ct, const float* z,
                         const float* rnc_feats, int32_t rd, float temperature, const float* weights6, float* d_vals, float* d_th,
-                        float* d_ct, float* d_z, float* d_rnc, float* losses, float* distill_ws, float* rnc_workspace, void* stream);
+                        float* d_ct, float* d_z, float* d_rnc, float* losses, float* distill_ws, float* rnc_workspace,
+                        float* hyper, double beta1, double beta2, void* stream);
 // which: 0 = stage A forward, 1 = stage B forward, 2 = stage B backward, 3 = stage A backward
 int sdumc_chain_launch_(const sdumc_chain_args* a, int which, void* stream);
 // the same four stages with every layer's output columns split over clusters of 4 workgroups (chain_cluster.hip);

@@ -713,6 +713,10 @@ __global__ void expand_lengths_kernel(const int32_t* la, const int32_t* lt, cons
 }
 
 // the attention-pooling descriptor of (site kind k, modality m, run sg) — shared by forward and backward
+bool attn_tickets_on() {
+  static const int fuse = [] { const char* e = getenv("SDUMC_ATTN_TICKETS"); return e ? atoi(e) : 0; }();
+  return fuse != 0;
+}
 sdumc_attnpool attn_desc(const Ctx& c, int k, int m, const Seg& sg) {
   const Plan& pl = c.pl;
   const int nq = k == 0 ? 1 : NQ;
@@ -744,8 +748,7 @@ sdumc_attnpool attn_desc(const Ctx& c, int k, int m, const Seg& sg) {
     // OFF by default: measured at C2 on MI355X the fused second passes LOSE 11 us per step fp32 / 18 us bf16 (1.993 vs 1.982 ms,
     // 1.204 vs 1.186 ms) -- the agent-scope dword stores of the partials and the serial tail of the last chunk cost more than
     // the launch they save.  SDUMC_ATTN_TICKETS=1 turns them on.
-    static const int fuse = [] { const char* e = getenv("SDUMC_ATTN_TICKETS"); return e ? atoi(e) : 0; }();
-    if (fuse) a.tickets = reinterpret_cast<uint32_t*>(c.p(pl.tickets)) + ((int64_t)(k * 3 + m) * 2 * pl.V) + 2 * (int64_t)sg.s0 * pl.B;
+    if (attn_tickets_on()) a.tickets = reinterpret_cast<uint32_t*>(c.p(pl.tickets)) + ((int64_t)(k * 3 + m) * 2 * pl.V) + 2 * (int64_t)sg.s0 * pl.B;
   }
   a.x_drop = in_drop(c, k, m, sg.T, sg.s0, sg.row0);
   if (c.h()) a.x_drop.enabled = 0;
@@ -1036,7 +1039,7 @@ int forward(const Ctx& c) {
                        reinterpret_cast<int32_t*>(c.p(pl.lens)));
     SDUMC_CHECK_LAUNCH();
   }
-  RET(sdumc_fill(c.p(pl.tickets), 0.f, 12LL * V + 16, c.st));   // (self-resetting; this guards a workspace's first use)
+  if (attn_tickets_on()) RET(sdumc_fill(c.p(pl.tickets), 0.f, 12LL * V + 16, c.st));   // (self-resetting; guards a workspace's first use)
   // 1+2. three independent per-modality chains, one per lane:
   //      keep-bits of the two frame-level input dropouts -> frame_dim_reshape_m (model :282-284; audio/video once
   //      for both streams) -> keys of fra2utt_m AND cross_att_fra2utt_m -> FRA2UTT pooling (model :288-290)
@@ -1870,15 +1873,18 @@ extern "C" int sdumc_loss_ssd(const sdumc_net_dims* d, const sdumc_net_io* io, f
 
 namespace {
 int loss_backward_impl(const sdumc_net_dims* d, const sdumc_net_io* io, const sdumc_step_cfg* cfg, const sdumc_net_grads* g,
-                       void* scratch, size_t scratch_bytes, void* stream, float* hyper);
+                       void* scratch, size_t scratch_bytes, void* stream, float* hyper, bool* total_pending = nullptr);
 }
 extern "C" int sdumc_loss_backward(const sdumc_net_dims* d, const sdumc_net_io* io, const sdumc_step_cfg* cfg,
                                    const sdumc_net_grads* g, void* scratch, size_t scratch_bytes, void* stream) {
   return loss_backward_impl(d, io, cfg, g, scratch, scratch_bytes, stream, nullptr);
 }
 namespace {
+// total_pending (the fused step): when the merged loss passes ran, the Adam bias correction has been made by their second pass
+// and losses[0] is left to the Adam launch (sdumc_total_loss) -- no one-thread total_loss launch on the critical path
 int loss_backward_impl(const sdumc_net_dims* d, const sdumc_net_io* io, const sdumc_step_cfg* cfg, const sdumc_net_grads* g,
-                       void* scratch, size_t scratch_bytes, void* stream, float* hyper) {
+                       void* scratch, size_t scratch_bytes, void* stream, float* hyper, bool* total_pending) {
+  if (total_pending) *total_pending = false;
   if (!d || !io || !cfg || !g || !scratch || d->streams != 2) return SDUMC_EINVAL;
   if (!io->vals || !io->fused || !io->rnc || !io->text_hidden || !io->cross_text) return SDUMC_EINVAL;
   if (!g->d_vals || !g->d_fused || !g->d_rnc || !g->d_text_hidden || !g->d_cross_text) return SDUMC_EINVAL;
@@ -1899,9 +1905,14 @@ int loss_backward_impl(const sdumc_net_dims* d, const sdumc_net_io* io, const sd
   bool done = false;
   if (fused && !cfg->rnc_feats_global && !cfg->ssd_global && Bg == B) {
     const int rc = sdumc_losses_fused_(B, io->vals, cfg->labels, io->text_hidden, io->cross_text, io->fused, io->rnc, RD,
-                                       cfg->temperature, w, dv, dth, dct, df, dr, L, ls.ssd_ws, ls.rnc_ws, stream);
+                                       cfg->temperature, w, dv, dth, dct, df, dr, L, ls.ssd_ws, ls.rnc_ws,
+                                       total_pending ? hyper : nullptr, (double)cfg->beta1, (double)cfg->beta2, stream);
     if (rc < 0) return rc;
     done = rc == 0;
+    if (done && total_pending && hyper) {
+      *total_pending = true;
+      return SDUMC_OK;
+    }
   }
   if (!done) {
   // MSELoss x2 (main :137-138) + RMSELoss x3 (main :148; teacher side detached for text_feat / text_query_feat,
@@ -1982,13 +1993,17 @@ extern "C" int sdumc_train_step(const sdumc_net_dims* d, const sdumc_net_io* io,
   g.d_cross_text = g.d_text_hidden + D * V;
   g.grads = reinterpret_cast<float*>(base + sl.grads);
   // the Adam bias-correction update rides in the loss's last launch, the dropout call counter in the Adam launch
-  RET(loss_backward_impl(d, &nio, cfg, &g, base + sl.loss, sl.net - sl.loss, stream, cfg->hyper));
+  bool total_pending = false;
+  RET(loss_backward_impl(d, &nio, cfg, &g, base + sl.loss, sl.net - sl.loss, stream, cfg->hyper, &total_pending));
   mark(static_cast<hipStream_t>(stream), 5);
   RET(sdumc_net_backward(d, &nio, &g, stream));
   mark(static_cast<hipStream_t>(stream), 9);
+  sdumc_total_loss tl;
+  tl.losses = cfg->losses;
+  for (int i = 0; i < 6; ++i) tl.w[i] = cfg->weights[i];
   RET(sdumc_adam_apply_(io->params, g.grads, cfg->adam_m, cfg->adam_v, (int64_t)sl.live, cfg->hyper, cfg->beta1, cfg->beta2,
                         cfg->eps, cfg->weight_decay, 1.0f, d->train ? const_cast<uint32_t*>(io->rng_state) : nullptr, 2u,
-                        stream));
+                        total_pending ? &tl : nullptr, stream));
   mark(static_cast<hipStream_t>(stream), 10);
   return SDUMC_OK;
 }

@@ -538,7 +538,8 @@ __global__ __launch_bounds__(256) void loss_stage1_kernel(const DistillArgs a, c
     distill_partials_body(a, q % mx, q / mx);
   }
 }
-__global__ __launch_bounds__(256) void loss_stage2_kernel(const DistillArgs a, const RncArgs r, const int amx) {
+__global__ __launch_bounds__(256) void loss_stage2_kernel(const DistillArgs a, const RncArgs r, const int amx, float* hyper,
+                                                          const double beta1, const double beta2) {
   extern __shared__ float sm[];
   const int bid = blockIdx.x;
   if (bid < r.n) {
@@ -548,6 +549,12 @@ __global__ __launch_bounds__(256) void loss_stage2_kernel(const DistillArgs a, c
     distill_apply_body(a, q % amx, q / amx);
   } else {
     rnc_loss_body(r.n, r.w, r.loss_out);
+    if (hyper && threadIdx.x == 0) {   // Adam bias correction of this step (adam.hip's adam_hyper_kernel, same double arithmetic)
+      const double t = (double)hyper[1] + 1.0;
+      hyper[1] = (float)t;
+      hyper[2] = (float)((double)hyper[0] / (1.0 - pow(beta1, t)));
+      hyper[3] = (float)sqrt(1.0 - pow(beta2, t));
+    }
   }
 }
 }  // namespace
@@ -768,7 +775,8 @@ extern "C" int sdumc_distill_fwd_bwd(int32_t B, float denom, const float* vals, 
 extern "C" int sdumc_losses_fused_(int32_t B, const float* vals, const float* labels, const float* th, const float* ct,
                                    const float* z, const float* rnc_feats, int32_t rd, float temperature, const float* weights6,
                                    float* d_vals, float* d_th, float* d_ct, float* d_z, float* d_rnc, float* losses,
-                                   float* distill_ws, float* rnc_workspace, void* stream) {
+                                   float* distill_ws, float* rnc_workspace, float* hyper, double beta1, double beta2,
+                                   void* stream) {
   const int n = 2 * B;
   if (B <= 0 || n > 256 || rd <= 0 || temperature <= 0.f) return 1;
   const size_t lds1 = (((size_t)rd + 3) & ~(size_t)3) * sizeof(float) + 5 * (size_t)n * sizeof(float);
@@ -799,7 +807,7 @@ extern "C" int sdumc_losses_fused_(int32_t B, const float* vals, const float* la
   hipStream_t st = as_stream(stream);
   hipLaunchKernelGGL(loss_stage1_kernel, dim3(n + 3 * mx), dim3(256), lds1, st, a, r, mx);
   SDUMC_CHECK_LAUNCH();
-  hipLaunchKernelGGL(loss_stage2_kernel, dim3(n + 4 * amx + 1), dim3(256), lds2, st, a, r, amx);
+  hipLaunchKernelGGL(loss_stage2_kernel, dim3(n + 4 * amx + 1), dim3(256), lds2, st, a, r, amx, hyper, beta1, beta2);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
 }
