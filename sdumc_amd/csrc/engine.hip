@@ -385,7 +385,7 @@ struct LaneSet {
 };
 // Debug timeline (tools/step_marks.py): sdumc_debug_marks(1) makes the step record an event on the caller's stream at a few
 // fixed points; sdumc_debug_marks_read returns their times since mark 0.  Process-wide, single-threaded use only.
-constexpr int kMarks = 32;
+constexpr int kMarks = 48;
 bool g_marks_on = false;
 hipEvent_t g_marks[kMarks] = {};
 bool g_mark_set[kMarks] = {};
@@ -1120,7 +1120,9 @@ int forward(const Ctx& c) {
       }
       RET(lin_fwd(c, pm.frame[m], in, din[m], B * pl.T[m][s], c.p(pl.x[m][s]), D, SDUMC_ACT_NONE, nullptr, c.d.bf16 != 0));
     }
+    mark(c.st, 28 + 4 * m);      // (debug marks 28..39: this modality's lane, frame-level forward: projection done)
     if (bits_done[m] && hipStreamWaitEvent(c.st, bits_done[m], 0) != hipSuccess) return SDUMC_ELAUNCH;
+    mark(c.st, 29 + 4 * m);      // keep-bits awaited
     const bool k3_site0 = k3_ok(c, m);
     if (c.bg) {   // the Cross_Attention keys are not needed before step 8: background lane, beside steps 2-7
       if (k3_site0) RET(umca_site(c, 0, m, true));
@@ -1137,7 +1139,9 @@ int forward(const Ctx& c) {
       RET(keys_gemm_fwd(c, m, 0, 2));
       RET(pool_fwd(c, 0, m));
     }
+    mark(c.st, 30 + 4 * m);      // FRA2UTT site done
   }
+  mark(c.sts[3], 40);            // lane 3: keep-bits + Cross_Attention key projections done
   c.use(0);
   RET(join_all(c));
   if (chain) {   // steps 3-7 in one launch

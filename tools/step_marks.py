@@ -30,13 +30,13 @@ for _ in range(N):
     _lib.lib.sdumc_debug_marks_read(ms, 11)
     for i in range(11):
         acc[i] += ms[i]
-ms2 = [0.0] * 32
+ms2 = [0.0] * 48
 for _ in range(N):
     step.run()
     torch.cuda.synchronize()
-    buf = (C.c_float * 32)()
-    _lib.lib.sdumc_debug_marks_read(buf, 32)
-    for i in range(32):
+    buf = (C.c_float * 48)()
+    _lib.lib.sdumc_debug_marks_read(buf, 48)
+    for i in range(48):
         ms2[i] += buf[i]
 prev = 0.0
 for i, n in enumerate(names):
@@ -44,6 +44,10 @@ for i, n in enumerate(names):
     print(f"{i:2d} {t:8.1f} us  (+{t - prev:7.1f})  {n}")
     prev = t
 
+for m, mod in enumerate(("audio", "text", "video")):
+    print(f"  {mod} lane (frame-level forward): projection done {ms2[28 + 4 * m] / N * 1e3:7.1f}  keep-bits awaited {ms2[29 + 4 * m] / N * 1e3:7.1f}"
+          f"  FRA2UTT site done {ms2[30 + 4 * m] / N * 1e3:7.1f}")
+print(f"  lane 3 (keep-bits, Cross_Attention key projections) done at {ms2[40] / N * 1e3:7.1f} us")
 lane_names = ["pooling bwd + colsum done", "key-projection dX done", "early Cross_Attention dxd awaited", "mask-sum done", "frame dW done"]
 for m, mod in enumerate(("audio", "text", "video")):
     print(f"  {mod} lane (frame-level backward):", "  ".join(f"{lane_names[j]} {ms2[12 + 5 * m + j] / N * 1e3:7.1f}" for j in range(5)))
