@@ -122,3 +122,5 @@ if __name__ == "__main__":
     case("keys dW video 1 site", TN, 256, 256, 28800, TNT, colsum=True, drop=True, row_mod=14400)
     case("ragged K", TN, 256, 1024, 24007, TNT, colsum=True)
     case("square 4096", NT, 4096, 4096, 4096, (1, 12, 13, 16, 17))
+    case("square 4096", TN, 4096, 4096, 4096, (1, 11, 13, 14))
+    case("dW-like, no split needed", TN, 2048, 2048, 24000, (1, 11, 13, 14))
