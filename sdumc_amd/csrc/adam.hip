@@ -48,6 +48,8 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
       float* L = tl.losses;
       L[0] = tl.w[0] * L[1] + tl.w[1] * L[2] + tl.w[2] * L[3] + tl.w[3] * L[4] + tl.w[4] * L[5] + tl.w[5] * L[6];
       L[7] = 0.f;
+      // fail loudly: a clustered utterance-level kernel whose spin ran into its cap finished with wrong data
+      if (tl.chain_err && *tl.chain_err) { L[0] = __int_as_float(0x7fc00000); L[7] = 1.f; }
     }
     for (int64_t t = n4 * 4; t < n; ++t) {
       const float ge = g[t] * gscale + wd * p[t];
@@ -74,6 +76,7 @@ extern "C" int sdumc_adam_apply_(float* param, const float* grad, float* exp_avg
   if (!param || !grad || !exp_avg || !exp_avg_sq || !hyper || n <= 0) return SDUMC_EINVAL;
   sdumc_total_loss tl;
   tl.losses = nullptr;
+  tl.chain_err = nullptr;
   for (int i = 0; i < 6; ++i) tl.w[i] = 0.f;
   if (total) tl = *total;
   if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |

@@ -1049,6 +1049,12 @@ extern "C" int sdumc_chain_cluster_launch_(const sdumc_chain_args* ap, int which
   return SDUMC_OK;
 }
 
+extern "C" const int32_t* sdumc_chain_cluster_err_ptr_() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
+  return g_cl[dev].err;
+}
+
 // 0 = no cluster spin ever exceeded its cap on the current device (synchronises the device; tests)
 extern "C" int sdumc_chain_cluster_error_() {
   ClusterDev* d = cluster_dev();

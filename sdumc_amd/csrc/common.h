@@ -22,6 +22,7 @@ static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 struct sdumc_total_loss {
   float* losses;   // [8] or nullptr
   float w[6];
+  const int32_t* chain_err;   // chain_cluster.hip's error word (a cluster spin ran into its cap) or nullptr: poisons the total with NaN
 };
 extern "C" {
 // sdumc_zpool_bwd with dz := dz + dz_add (dz_add may be NULL): folds the external gradient of cross_fused_feat in
@@ -81,6 +82,7 @@ int sdumc_chain_launch_(const sdumc_chain_args* a, int which, void* stream);
 // returns 1 when the shape does not qualify (the caller then takes sdumc_chain_launch_)
 int sdumc_chain_cluster_launch_(const sdumc_chain_args* a, int which, void* stream);
 int sdumc_chain_cluster_ok_(int V);
+const int32_t* sdumc_chain_cluster_err_ptr_(void);    // device address of the error word (nullptr before the first cluster launch)
 // dst[off ..] = transpose of the n listed [out][in] matrices of src (same offsets in both buffers)
 // fp32 parameters -> bf16 copies as stored (dst) and, where want_t[i], transposed (dst_t); same element offsets as in src
 int sdumc_weights_to_bf16_(const float* src, void* dst, void* dst_t, const int64_t* offs, const int32_t* outs, const int32_t* ins,

@@ -2004,6 +2004,7 @@ extern "C" int sdumc_train_step(const sdumc_net_dims* d, const sdumc_net_io* io,
   mark(static_cast<hipStream_t>(stream), 9);
   sdumc_total_loss tl;
   tl.losses = cfg->losses;
+  tl.chain_err = sdumc_chain_cluster_err_ptr_();
   for (int i = 0; i < 6; ++i) tl.w[i] = cfg->weights[i];
   RET(sdumc_adam_apply_(io->params, g.grads, cfg->adam_m, cfg->adam_v, (int64_t)sl.live, cfg->hyper, cfg->beta1, cfg->beta2,
                         cfg->eps, cfg->weight_decay, 1.0f, d->train ? const_cast<uint32_t*>(io->rng_state) : nullptr, 2u,

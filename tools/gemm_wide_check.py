@@ -107,6 +107,8 @@ if __name__ == "__main__":
     case("frame proj audio", NT, 24000, 256, 1024, NTT, bias=True)
     case("frame proj video", NT, 14400, 256, 1024, NTT, bias=True)
     case("frame proj text", NT, 2048, 256, 4096, NTT, bias=True)
+    case("frame proj text C2 (both streams)", NT, 6400, 256, 4096, NTT, bias=True)
+    case("frame proj text C2 (one stream)", NT, 3200, 256, 4096, NTT, bias=True)
     case("keys audio 1 site", NT, 48000, 256, 256, NTT, bias=True, act=ops.ACT_TANH, drop=True, row_mod=24000)
     case("keys audio 2 sites", NT, 48000, 256, 256, NTT, groups=2, bias=True, act=ops.ACT_TANH, drop=True, row_mod=24000)
     case("keys video 1 site", NT, 28800, 256, 256, NTT, bias=True, act=ops.ACT_TANH, drop=True, row_mod=14400)
