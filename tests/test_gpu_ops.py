@@ -305,6 +305,32 @@ def test_umca_fused_forward_k3(ops, nq, T, shared_q, mask):
     del bits
 
 
+def test_umca_k3_with_key_padding_lengths(ops):
+    """K3 with the key-padding extension (per-sample valid frame counts): identical to the two-kernel path with the same
+    lengths, and frames beyond a sample's length get weight exactly 0."""
+    from sdumc_amd._lib import make_dropout
+    g = torch.Generator().manual_seed(11)
+    B, S, Dm, nq, T = 3, 2, 256, 7, 150
+    V = B * S
+    x = dev(torch.randn(B, T, Dm, generator=g))
+    W, b = dev(torch.randn(Dm, Dm, generator=g) / 16), dev(torch.randn(Dm, generator=g) * 0.1)
+    q = dev(torch.randn(V, nq, Dm, generator=g) / 4)
+    lengths = dev(torch.tensor([T, 1, 64, 65, 128, 17], dtype=torch.int32))
+    xdrop = make_dropout(True, 23, 0.5, T, Dm, B, call0=2, seed=5)
+    bits = ops.dropout_bits(xdrop, S)
+    odrop = make_dropout(True, 24, 0.5, nq, Dm, B, call0=2, seed=5)
+    out, attn, pooled, keys, _ = ops.umca_fwd(x, W, b, q, nq, x_samples=B, x_drop=xdrop, out_drop=odrop, lengths=lengths, V=V)
+    keys2 = ops.gemm(ops.NT, x, W, V * T, Dm, Dm, bias=b, act=ops.ACT_TANH, a_row_mod=B * T, a_drop=xdrop).view(V, T, Dm)
+    out2, attn2, pooled2, _ = ops.attnpool_fwd(x, keys2, q, nq, x_samples=B, x_drop=xdrop, out_drop=odrop, lengths=lengths, tickets=False)
+    close(out, out2, 2e-6)
+    close(attn, attn2, 2e-6)
+    close(pooled, pooled2, 2e-6)
+    for v, n in enumerate(lengths.tolist()):
+        assert float(attn[v, n:].abs().max()) == 0.0 if n < T else True
+        np.testing.assert_allclose(attn[v, :n].sum(0).cpu().numpy(), 1.0, rtol=1e-5)
+    del bits
+
+
 def test_attnpool_multi_equals_single_calls(ops):
     """sdumc_attnpool_fwd_multi / _bwd_multi (the step's three Cross_Attention blocks in one launch pair) against one call per
     site: bit-identical, ragged T, keep-bits masks, key-padding lengths on one site."""
