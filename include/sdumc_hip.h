@@ -454,6 +454,12 @@ typedef struct sdumc_mha {
   int32_t bf16;                  /* 1: every product (projections, q.k^T, P.v and their backward) rounds its operands to bf16,
                                     fp32 accumulate (needs embed and head_dim multiples of 4; otherwise the call stays fp32);
                                     softmax, dropout, bias and the stored tensors are fp32 either way.  0: exact fp32 */
+  /* add_bias_kv / add_zero_attn (multihead_attention.py:28-38, :86-104).  With ts = tk + (bias_k != NULL) + add_zero_attn the
+   * source length becomes ts: k, v are [ts, B, E], probs / probs_drop [B*H, tq, ts], weights [B, tq, ts], attn_drop.width = ts;
+   * attn_mask stays [tq, tk] (the extra columns are unmasked, as the reference's zero-padded mask).  Defaults: NULL, NULL, 0. */
+  const float* bias_k;           /* [E] or NULL; both or neither */
+  const float* bias_v;
+  int32_t add_zero_attn;
 } sdumc_mha;
 
 typedef struct sdumc_mha_grads {
@@ -465,6 +471,8 @@ typedef struct sdumc_mha_grads {
   float* d_in_proj_bias;         /* [3E] or NULL */
   float* d_out_proj_weight;      /* [E, E] */
   float* d_out_proj_bias;        /* [E] or NULL */
+  float* d_bias_k;               /* [E], required when bias_k is given */
+  float* d_bias_v;
 } sdumc_mha_grads;
 
 size_t sdumc_mha_workspace_bytes(const sdumc_mha* m, int32_t backward);

@@ -133,13 +133,15 @@ class Mha(C.Structure):
                 ("out", C.c_void_p), ("weights", C.c_void_p),
                 ("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p),
                 ("probs", C.c_void_p), ("probs_drop", C.c_void_p), ("ctx", C.c_void_p),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("bf16", C.c_int32)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("bf16", C.c_int32),
+                ("bias_k", C.c_void_p), ("bias_v", C.c_void_p), ("add_zero_attn", C.c_int32)]
 
 
 class MhaGrads(C.Structure):
     _fields_ = [("dout", C.c_void_p), ("dquery", C.c_void_p), ("dkey", C.c_void_p), ("dvalue", C.c_void_p),
                 ("d_in_proj_weight", C.c_void_p), ("d_in_proj_bias", C.c_void_p),
-                ("d_out_proj_weight", C.c_void_p), ("d_out_proj_bias", C.c_void_p)]
+                ("d_out_proj_weight", C.c_void_p), ("d_out_proj_bias", C.c_void_p),
+                ("d_bias_k", C.c_void_p), ("d_bias_v", C.c_void_p)]
 
 
 class ProfEntry(C.Structure):

@@ -409,9 +409,26 @@ void gemm_init(sdumc_gemm& g, int layout, int M, int N, int K) {
   g.splitk = 0;
 }
 
+// k[tk] = bias_k, v[tk] = bias_v for every sample (add_bias_kv), then one zero row in both (add_zero_attn)
+__global__ __launch_bounds__(256) void mha_extra_rows_kernel(float* k, float* v, const float* bias_k, const float* bias_v, int tk,
+                                                             int nb, int nz, int B, int E) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x, n = (int64_t)B * E;
+  if (i >= n) return;
+  const int e = (int)(i % E);
+  if (nb) {
+    k[(int64_t)tk * n + i] = bias_k[e];
+    v[(int64_t)tk * n + i] = bias_v[e];
+  }
+  if (nz) {
+    k[(int64_t)(tk + nb) * n + i] = 0.f;
+    v[(int64_t)(tk + nb) * n + i] = 0.f;
+  }
+}
+
 struct MhaPlan {
   int E, H, dh, B, tq, tk, BH;
-  size_t n_q, n_k, n_p;   // floats in a [tq,B,E], a [tk,B,E] and a [BH,tq,tk] tensor
+  int nb, nz, ts;         // add_bias_kv / add_zero_attn rows (multihead_attention.py:86-104); ts = tk + nb + nz = the source length
+  size_t n_q, n_k, n_p;   // floats in a [tq,B,E], a [ts,B,E] and a [BH,tq,ts] tensor
 };
 
 int mha_plan(const sdumc_mha& m, MhaPlan* p) {
@@ -425,9 +442,13 @@ int mha_plan(const sdumc_mha& m, MhaPlan* p) {
   p->tk = m.tk;
   p->BH = m.batch * m.heads;
   if ((long)p->BH > 65535) return SDUMC_EINVAL;
+  if ((m.bias_k != nullptr) != (m.bias_v != nullptr)) return SDUMC_EINVAL;   // :86 asserts both
+  p->nb = m.bias_k ? 1 : 0;
+  p->nz = m.add_zero_attn ? 1 : 0;
+  p->ts = m.tk + p->nb + p->nz;
   p->n_q = (size_t)m.tq * m.batch * m.embed;
-  p->n_k = (size_t)m.tk * m.batch * m.embed;
-  p->n_p = (size_t)p->BH * m.tq * m.tk;
+  p->n_k = (size_t)p->ts * m.batch * m.embed;
+  p->n_p = (size_t)p->BH * m.tq * p->ts;
   return SDUMC_OK;
 }
 
@@ -482,7 +503,7 @@ size_t align_up(size_t n) { return (n + 63) & ~(size_t)63; }
 
 // bf16-operand products need every extent that is a leading dimension, a stride or a channel count to be a multiple of 4
 int mha_bf16(const sdumc_mha& m, const MhaPlan& p) {
-  return m.bf16 && (p.E % 4 == 0) && (p.dh % 4 == 0) && (p.tq % 4 == 0) && (p.tk % 4 == 0) ? 1 : 0;
+  return m.bf16 && (p.E % 4 == 0) && (p.dh % 4 == 0) && (p.tq % 4 == 0) && (p.tk % 4 == 0) && (p.ts % 4 == 0) ? 1 : 0;
 }
 
 struct Runner {   // launches descriptors with the shared split-K scratch
@@ -621,6 +642,9 @@ extern "C" size_t sdumc_mha_workspace_bytes(const sdumc_mha* mp, int32_t backwar
   need(g);
   gemm_init(g, SDUMC_NT, p.tq * p.B, p.E, p.E);
   need(g);
+  // add_bias_kv / add_zero_attn with a mask: the mask grows zero columns (:90, :104); it is rebuilt in the workspace
+  if (p.ts > p.tk && m.attn_mask) gws = std::max(gws, (size_t)p.tq * p.ts * sizeof(float));
+  if (p.nb) gws = std::max(gws, sdumc_colsum_workspace_bytes(p.B, p.E));
   if (!backward) return align_up(gws);
   sdumc_mha_grads gr{};
   float* none[3] = {nullptr, nullptr, nullptr};
@@ -661,17 +685,30 @@ extern "C" int sdumc_mha_forward(const sdumc_mha* mp, void* stream) {
   }
   // S[z] = q_z k_z^T for every (sample, head) z   (:103)
   const int ldx = p.B * p.E;
-  batched_desc(g, p, SDUMC_NT, p.tq, p.tk, p.dh, m.q, ldx, p.dh, m.k, ldx, p.dh, m.probs, p.tk, (long)p.tq * p.tk);
+  // add_bias_kv: k, v grow the row (bias_k | bias_v) for every sample (:86-90); add_zero_attn: a zero row (:100-104)
+  if (p.ts > p.tk) {
+    const int64_t n = (int64_t)p.B * p.E;
+    hipLaunchKernelGGL(mha_extra_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, r.st, m.k, m.v, m.bias_k, m.bias_v,
+                       p.tk, p.nb, p.nz, p.B, p.E);
+    SDUMC_CHECK_LAUNCH();
+  }
+  batched_desc(g, p, SDUMC_NT, p.tq, p.ts, p.dh, m.q, ldx, p.dh, m.k, ldx, p.dh, m.probs, p.ts, (long)p.tq * p.ts);
   r.run(g);
   if (r.rc != SDUMC_OK) return r.rc;
+  const float* mask = m.attn_mask;
+  if (mask && p.ts > p.tk) {   // zero columns for the extra rows: rebuilt in the (now idle) GEMM scratch
+    if (int rc = sdumc_fill(m.workspace, 0.f, (int64_t)p.tq * p.ts, stream)) return rc;
+    if (int rc = sdumc_copy2d(m.attn_mask, p.tk, m.workspace, p.ts, p.tq, p.tk, stream)) return rc;
+    mask = m.workspace;
+  }
   // P = softmax(d_h^-0.5 S + mask), dropout, head mean   (:84, :104-117, :128-130)
   sdumc_softmax s{};
   s.batch = p.B;
   s.heads = p.H;
   s.tq = p.tq;
-  s.tk = p.tk;
+  s.tk = p.ts;
   s.scale = 1.0f / sqrtf((float)p.dh);
-  s.mask = m.attn_mask;
+  s.mask = mask;
   s.scores = m.probs;
   s.probs_drop = m.probs_drop;
   s.weights = m.weights;
@@ -679,7 +716,7 @@ extern "C" int sdumc_mha_forward(const sdumc_mha* mp, void* stream) {
   if (int rc = sdumc_softmax_fwd(&s, stream)) return rc;
   // ctx_z = P_z v_z   (:119), written straight into the [tq, B, E] layout of :122
   const float* pv = m.attn_drop.enabled ? m.probs_drop : m.probs;
-  batched_desc(g, p, SDUMC_NN, p.tq, p.dh, p.tk, pv, p.tk, (long)p.tq * p.tk, m.v, ldx, p.dh, m.ctx, ldx, p.dh);
+  batched_desc(g, p, SDUMC_NN, p.tq, p.dh, p.ts, pv, p.ts, (long)p.tq * p.ts, m.v, ldx, p.dh, m.ctx, ldx, p.dh);
   r.run(g);
   // out = out_proj(ctx)   (:123)
   gemm_init(g, SDUMC_NT, p.tq * p.B, p.E, p.E);
@@ -732,9 +769,9 @@ extern "C" int sdumc_mha_backward(const sdumc_mha* mp, const sdumc_mha_grads* gp
   g.lda = g.ldb = g.ldc = p.E;
   r.run(g);
   // dP_z = dctx_z v_z^T ; dv_z = P_z^T dctx_z
-  batched_desc(g, p, SDUMC_NT, p.tq, p.tk, p.dh, dctx, ldx, p.dh, m.v, ldx, p.dh, dP, p.tk, (long)p.tq * p.tk);
+  batched_desc(g, p, SDUMC_NT, p.tq, p.ts, p.dh, dctx, ldx, p.dh, m.v, ldx, p.dh, dP, p.ts, (long)p.tq * p.ts);
   r.run(g);
-  batched_desc(g, p, SDUMC_TN, p.tk, p.dh, p.tq, pv, p.tk, (long)p.tq * p.tk, dctx, ldx, p.dh, dv, ldx, p.dh);
+  batched_desc(g, p, SDUMC_TN, p.ts, p.dh, p.tq, pv, p.ts, (long)p.tq * p.ts, dctx, ldx, p.dh, dv, ldx, p.dh);
   r.run(g);
   if (r.rc != SDUMC_OK) return r.rc;
   // dS = softmax backward (dropout mask recomputed)
@@ -742,17 +779,24 @@ extern "C" int sdumc_mha_backward(const sdumc_mha* mp, const sdumc_mha_grads* gp
   s.batch = p.B;
   s.heads = p.H;
   s.tq = p.tq;
-  s.tk = p.tk;
+  s.tk = p.ts;
   s.scale = 1.0f / sqrtf((float)p.dh);
   s.scores = m.probs;
   s.probs_drop = m.probs_drop;
   s.drop = m.attn_drop;
   if (int rc = sdumc_softmax_bwd(&s, dP, stream)) return rc;
   // dq_z = dS_z k_z ; dk_z = dS_z^T q_z   (the d_h^-0.5 of :84 is inside dS)
-  batched_desc(g, p, SDUMC_NN, p.tq, p.dh, p.tk, dP, p.tk, (long)p.tq * p.tk, m.k, ldx, p.dh, dq, ldx, p.dh);
+  batched_desc(g, p, SDUMC_NN, p.tq, p.dh, p.ts, dP, p.ts, (long)p.tq * p.ts, m.k, ldx, p.dh, dq, ldx, p.dh);
   r.run(g);
-  batched_desc(g, p, SDUMC_TN, p.tk, p.dh, p.tq, dP, p.tk, (long)p.tq * p.tk, m.q, ldx, p.dh, dk, ldx, p.dh);
+  batched_desc(g, p, SDUMC_TN, p.ts, p.dh, p.tq, dP, p.ts, (long)p.tq * p.ts, m.q, ldx, p.dh, dk, ldx, p.dh);
   r.run(g);
+  if (p.nb) {   // d bias_k / d bias_v = the gradient of row tk summed over the samples (bias.repeat(1, bsz, 1), :88-89)
+    if (!gr.d_bias_k || !gr.d_bias_v) return SDUMC_EINVAL;
+    if (r.rc != SDUMC_OK) return r.rc;
+    if (gws < sdumc_colsum_workspace_bytes(p.B, p.E)) return SDUMC_ENOMEM;
+    if (int rc = sdumc_colsum(dk + (size_t)p.tk * p.B * p.E, p.B, p.E, p.E, gr.d_bias_k, 0, m.workspace, stream)) return rc;
+    if (int rc = sdumc_colsum(dv + (size_t)p.tk * p.B * p.E, p.B, p.E, p.E, gr.d_bias_v, 0, m.workspace, stream)) return rc;
+  }
   // in_proj parameter gradients
   float* dqkv[3] = {dq, dk, dv};
   if (p.tq == p.tk) {

@@ -376,26 +376,29 @@ def drop_add(x, residual=None, drop=None, alpha=1.0, pos_table=None, pos_src=Non
 
 
 def mha_forward(query, key, value, w_in, b_in, w_out, b_out, heads, attn_mask=None, attn_drop=None, need_weights=True,
-                bf16=False):
+                bf16=False, bias_k=None, bias_v=None, add_zero_attn=False):
     """MultiheadAttention.forward on [T, B, E] tensors.  Returns (out, weights, saved) where `saved` is what
-    mha_backward needs."""
+    mha_backward needs.  bias_k / bias_v ([E]) and add_zero_attn lengthen the source by one row each
+    (multihead_attention.py:86-104): the weights are then [B, T_q, T_k + extras]."""
     tq, B, E = query.shape
     tk = key.shape[0]
+    ts = tk + (1 if bias_k is not None else 0) + (1 if add_zero_attn else 0)
     dev = query.device
     m = _lib.Mha()
     m.tq, m.tk, m.batch, m.embed, m.heads = tq, tk, B, E, heads
     m.query, m.key, m.value = ptr(query), ptr(key), ptr(value)
     m.in_proj_weight, m.in_proj_bias, m.out_proj_weight, m.out_proj_bias = ptr(w_in), ptr(b_in), ptr(w_out), ptr(b_out)
     m.attn_mask = ptr(attn_mask)
+    m.bias_k, m.bias_v, m.add_zero_attn = ptr(bias_k), ptr(bias_v), 1 if add_zero_attn else 0
     m.bf16 = 1 if bf16 else 0
     drop_on = attn_drop is not None and attn_drop.enabled
     if drop_on:
         m.attn_drop = attn_drop
     t = {"out": torch.empty(tq, B, E, device=dev),
-         "weights": torch.empty(B, tq, tk, device=dev) if need_weights else None,
-         "q": torch.empty(tq, B, E, device=dev), "k": torch.empty(tk, B, E, device=dev),
-         "v": torch.empty(tk, B, E, device=dev), "probs": torch.empty(B * heads, tq, tk, device=dev),
-         "probs_drop": torch.empty(B * heads, tq, tk, device=dev) if drop_on else None,
+         "weights": torch.empty(B, tq, ts, device=dev) if need_weights else None,
+         "q": torch.empty(tq, B, E, device=dev), "k": torch.empty(ts, B, E, device=dev),
+         "v": torch.empty(ts, B, E, device=dev), "probs": torch.empty(B * heads, tq, ts, device=dev),
+         "probs_drop": torch.empty(B * heads, tq, ts, device=dev) if drop_on else None,
          "ctx": torch.empty(tq, B, E, device=dev)}
     for name, ten in t.items():
         setattr(m, name, ptr(ten))
@@ -404,12 +407,14 @@ def mha_forward(query, key, value, w_in, b_in, w_out, b_out, heads, attn_mask=No
     m.workspace, m.workspace_bytes = ptr(ws), need
     check(lib.sdumc_mha_forward(C.byref(m), _st()), "sdumc_mha_forward")
     t["inputs"] = (query, key, value, w_in, b_in, w_out, b_out, attn_mask)   # keep-alive
+    t["bias_kv"] = (bias_k, bias_v)
     return t["out"], t["weights"], (m, t)
 
 
 def mha_backward(saved, dout):
-    """Returns (dquery, dkey, dvalue, dw_in, db_in, dw_out, db_out).  Inputs that aliased in the forward share ONE
-    summed gradient buffer; it is returned once (for the first of them) and the others come back as None."""
+    """Returns (dquery, dkey, dvalue, dw_in, db_in, dw_out, db_out[, d_bias_k, d_bias_v when add_bias_kv]).  Inputs that
+    aliased in the forward share ONE summed gradient buffer; it is returned once (for the first of them) and the others come
+    back as None."""
     m, t = saved
     query, key, value, w_in, b_in, w_out, b_out, _ = t["inputs"]
     dev = dout.device
@@ -422,8 +427,13 @@ def mha_backward(saved, dout):
     db_out = torch.empty_like(b_out) if b_out is not None else None
     g.dout, g.dquery, g.dkey, g.dvalue = ptr(dout), ptr(dq), ptr(dk), ptr(dv)
     g.d_in_proj_weight, g.d_in_proj_bias, g.d_out_proj_weight, g.d_out_proj_bias = ptr(dw_in), ptr(db_in), ptr(dw_out), ptr(db_out)
+    bias_k, bias_v = t.get("bias_kv", (None, None))
+    dbk = torch.empty_like(bias_k) if bias_k is not None else None
+    dbv = torch.empty_like(bias_v) if bias_v is not None else None
+    g.d_bias_k, g.d_bias_v = ptr(dbk), ptr(dbv)
     need = lib.sdumc_mha_workspace_bytes(C.byref(m), 1)
     ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
     m.workspace, m.workspace_bytes = ptr(ws), need
     check(lib.sdumc_mha_backward(C.byref(m), C.byref(g), _st()), "sdumc_mha_backward")
-    return dq, (None if dk is dq else dk), (None if dv is dq or dv is dk else dv), dw_in, db_in, dw_out, db_out
+    res = (dq, (None if dk is dq else dk), (None if dv is dq or dv is dk else dv), dw_in, db_in, dw_out, db_out)
+    return res + (dbk, dbv) if bias_k is not None else res

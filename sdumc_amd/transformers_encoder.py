@@ -13,8 +13,9 @@ Philox mask keyed by (seed, call, site) from the module-level :class:`DropoutStr
 ``F.dropout`` calls of the reference in call order (calls with p = 0 count too), which is what the golden
 fixtures replay (tests/golden/make_goldens.py: gen_transformer).
 
-Not implemented (fail loudly): ``add_bias_kv`` / ``add_zero_attn`` (multihead_attention.py:28-38; default off
-and never enabled by transformer.py), and gradients flowing into the returned attention weights.
+``add_bias_kv`` / ``add_zero_attn`` (multihead_attention.py:28-38, :86-104; default off and never enabled by
+transformer.py) are built into the HIP path (one extra key/value row each).  Not implemented (fail loudly):
+gradients flowing into the returned attention weights.
 """
 import math
 
@@ -184,7 +185,8 @@ class _DropAddFn(torch.autograd.Function):
 
 class _MhaFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, query, key, value, w_in, b_in, w_out, b_out, attn_mask, heads, drop):
+    def forward(ctx, query, key, value, w_in, b_in, w_out, b_out, attn_mask, heads, drop, bias_k=None, bias_v=None,
+                add_zero_attn=False):
         # aliasing is decided the way the reference decides it (data_ptr() equality, multihead_attention.py:61-62)
         def alias(a, b):
             return a.data_ptr() == b.data_ptr() and a.shape == b.shape and a.stride() == b.stride()
@@ -193,18 +195,24 @@ class _MhaFn(torch.autograd.Function):
         key = query if same_kq else _c(key)
         value = query if same_vq else (key if same_vk else _c(value))
         w_in, b_in, w_out, b_out, attn_mask = _c(w_in), _c(b_in), _c(w_out), _c(b_out), _c(attn_mask)
-        _dev(query, key, value, w_in, b_in, w_out, b_out, attn_mask)
+        bk = _c(bias_k.reshape(-1)) if bias_k is not None else None       # [1, 1, E] parameters -> [E]
+        bv = _c(bias_v.reshape(-1)) if bias_v is not None else None
+        _dev(query, key, value, w_in, b_in, w_out, b_out, attn_mask, bk, bv)
         out, weights, saved = ops.mha_forward(query, key, value, w_in, b_in, w_out, b_out, heads, attn_mask, drop,
-                                              bf16=_BF16)
+                                              bf16=_BF16, bias_k=bk, bias_v=bv, add_zero_attn=add_zero_attn)
         ctx.saved = saved
+        ctx.bias_shape = tuple(bias_k.shape) if bias_k is not None else None
         ctx.mark_non_differentiable(weights)
         return out, weights
 
     @staticmethod
     def backward(ctx, dout, _dweights):
-        dq, dk, dv, dw_in, db_in, dw_out, db_out = ops.mha_backward(ctx.saved, _c(dout))
+        res = ops.mha_backward(ctx.saved, _c(dout))
         ctx.saved = None
-        return dq, dk, dv, dw_in, db_in, dw_out, db_out, None, None, None
+        dq, dk, dv, dw_in, db_in, dw_out, db_out = res[:7]
+        dbk = res[7].view(ctx.bias_shape) if ctx.bias_shape is not None else None
+        dbv = res[8].view(ctx.bias_shape) if ctx.bias_shape is not None else None
+        return dq, dk, dv, dw_in, db_in, dw_out, db_out, None, None, None, dbk, dbv, None
 
 
 def _linear(x, weight, bias, relu=False, drop=None):
@@ -225,15 +233,16 @@ class MultiheadAttention(nn.Module):
         self.head_dim = embed_dim // num_heads
         assert self.head_dim * num_heads == self.embed_dim, "embed_dim must be divisible by num_heads"
         self.scaling = self.head_dim ** -0.5
-        if add_bias_kv or add_zero_attn:
-            raise NotImplementedError("add_bias_kv / add_zero_attn are not built on the HIP path "
-                                      "(multihead_attention.py:28-38; transformer.py never enables them)")
         self.in_proj_weight = nn.Parameter(torch.Tensor(3 * embed_dim, embed_dim))
         self.register_parameter('in_proj_bias', None)
         if bias:
             self.in_proj_bias = nn.Parameter(torch.Tensor(3 * embed_dim))
         self.out_proj = nn.Linear(embed_dim, embed_dim, bias=bias)
-        self.bias_k = self.bias_v = None
+        if add_bias_kv:   # multihead_attention.py:28-32
+            self.bias_k = nn.Parameter(torch.Tensor(1, 1, embed_dim))
+            self.bias_v = nn.Parameter(torch.Tensor(1, 1, embed_dim))
+        else:
+            self.bias_k = self.bias_v = None
         self.add_zero_attn = add_zero_attn
         self.reset_parameters()
 
@@ -243,6 +252,10 @@ class MultiheadAttention(nn.Module):
         if self.in_proj_bias is not None:
             nn.init.constant_(self.in_proj_bias, 0.)
             nn.init.constant_(self.out_proj.bias, 0.)
+        if self.bias_k is not None:
+            nn.init.xavier_normal_(self.bias_k)
+        if self.bias_v is not None:
+            nn.init.xavier_normal_(self.bias_v)
 
     def forward(self, query, key, value, attn_mask=None):
         """Time x Batch x Channel in; returns (attn [T_q, B, E], head-averaged weights [B, T_q, T_k])."""
@@ -253,9 +266,10 @@ class MultiheadAttention(nn.Module):
         src_len = key.size(0)
         if attn_mask is not None and tuple(attn_mask.shape) != (tgt_len, src_len):
             raise RuntimeError(f"attn_mask must be [{tgt_len}, {src_len}], got {tuple(attn_mask.shape)}")
-        drop = dropout_stream.draw(self.attn_dropout, bsz * self.num_heads, tgt_len, src_len, self.training)
+        ext = src_len + (1 if self.bias_k is not None else 0) + (1 if self.add_zero_attn else 0)   # :86-104
+        drop = dropout_stream.draw(self.attn_dropout, bsz * self.num_heads, tgt_len, ext, self.training)
         return _MhaFn.apply(query, key, value, self.in_proj_weight, self.in_proj_bias, self.out_proj.weight,
-                            self.out_proj.bias, attn_mask, self.num_heads, drop)
+                            self.out_proj.bias, attn_mask, self.num_heads, drop, self.bias_k, self.bias_v, self.add_zero_attn)
 
     # the projection helpers of multihead_attention.py:133-154
     def in_proj_qkv(self, query):

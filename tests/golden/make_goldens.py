@@ -491,6 +491,63 @@ def gen_transformer(out):
     np.savez_compressed(os.path.join(out, "transformer.npz"), **d)
 
 
+def gen_transformer_kv(out):
+    """add_bias_kv / add_zero_attn of the generic MultiheadAttention (multihead_attention.py:28-38, :86-104): outputs, weights
+    and every gradient of the REAL module.  A fixture of its own (transformer_kv.npz) so that transformer.npz stays as it is."""
+    ref_tr, ref_mha = load_reference_transformer()
+    d = {}
+    g = torch.Generator().manual_seed(777)
+    rn = lambda *s: torch.randn(*s, generator=g)
+
+    def put(tag, mod, tensors, grads=None):
+        for k, v in mod.state_dict().items():
+            d[f"{tag}/P/{k}"] = np32(v)
+        for k, v in tensors.items():
+            d[f"{tag}/{k}"] = np32(v)
+        if grads is not None:
+            for k, v in mod.named_parameters():
+                d[f"{tag}/G/{k}"] = np32(v.grad)
+            for k, v in grads.items():
+                d[f"{tag}/d{k}"] = np32(v.grad)
+
+    def randomise(mod):
+        with torch.no_grad():
+            for k, v in mod.named_parameters():
+                if k.endswith("bias"):
+                    v.add_(0.2 * torch.randn(v.shape, generator=g))
+
+    # both extras, cross attention with the future mask, attention dropout, gradients
+    torch.manual_seed(11)
+    m = ref_mha.MultiheadAttention(32, 4, attn_dropout=0.25, add_bias_kv=True, add_zero_attn=True); randomise(m); m.train()
+    q, k, v = rn(5, 2, 32).requires_grad_(), rn(9, 2, 32).requires_grad_(), rn(9, 2, 32).requires_grad_()
+    mask = ref_tr.buffered_future_mask(q, k)
+    R = rn(5, 2, 32)
+    with PhiloxDropout(23, 4):
+        o, w = m(q, k, v, attn_mask=mask)
+    (o * R).sum().backward()
+    put("both", m, {"q": q, "k": k, "v": v, "mask": mask, "R": R, "out": o, "weights": w}, {"q": q, "k": k, "v": v})
+    d["both/seed_call"] = np.array([23, 4])
+
+    # add_zero_attn alone, self-attention, eval, gradients (T = 7 -> source length 8)
+    torch.manual_seed(12)
+    m = ref_mha.MultiheadAttention(32, 4, add_zero_attn=True); randomise(m); m.eval()
+    x = rn(7, 3, 32).requires_grad_()
+    R = rn(7, 3, 32)
+    o, w = m(x, x, x)
+    (o * R).sum().backward()
+    put("zero", m, {"x": x, "R": R, "out": o, "weights": w}, {"x": x})
+
+    # add_bias_kv alone, key is value, head_dim 15, no mask, gradients
+    torch.manual_seed(13)
+    m = ref_mha.MultiheadAttention(30, 2, add_bias_kv=True); randomise(m); m.eval()
+    q, kv = rn(6, 2, 30).requires_grad_(), rn(4, 2, 30).requires_grad_()
+    R = rn(6, 2, 30)
+    o, w = m(q, kv, kv)
+    (o * R).sum().backward()
+    put("bias", m, {"q": q, "kv": kv, "R": R, "out": o, "weights": w}, {"q": q, "kv": kv})
+    np.savez_compressed(os.path.join(out, "transformer_kv.npz"), **d)
+
+
 def main():
     torch.set_num_threads(4)
     ref_model, ref_loss = load_reference()
@@ -502,6 +559,7 @@ def main():
     gen_step(ref_model, ref_loss, HERE)
     gen_collate(HERE)
     gen_transformer(HERE)
+    gen_transformer_kv(HERE)
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -157,8 +157,6 @@ def test_modules_refuse_cpu_tensors(te):
     m = te.MultiheadAttention(32, 4)
     with pytest.raises(SdumcError):
         m(torch.randn(3, 2, 32), torch.randn(3, 2, 32), torch.randn(3, 2, 32))
-    with pytest.raises(NotImplementedError):
-        te.MultiheadAttention(32, 4, add_bias_kv=True)
 
 
 def test_state_dict_names_match_reference(te, golden):
@@ -192,6 +190,34 @@ def test_mha_golden_cross_train_grads(te, golden):
     assert torch.equal(w.cpu() == 0, T(g["mha_cross/weights"]) == 0)
     (o * G(g["mha_cross/R"])).sum().backward()
     check_grads(m, g, "mha_cross", q=q, k=k, v=v)
+
+
+def test_mha_golden_add_bias_kv_and_zero_attn(te, golden):
+    """add_bias_kv / add_zero_attn (multihead_attention.py:28-38, :86-104): outputs, weights over the lengthened source and
+    every gradient (incl. bias_k / bias_v) against the real module."""
+    g = golden("transformer_kv")
+    m = load_params(te.MultiheadAttention(32, 4, attn_dropout=0.25, add_bias_kv=True, add_zero_attn=True), g, "both").train()
+    q, k, v = (G(g[f"both/{n}"]).requires_grad_() for n in "qkv")
+    seed, call = (int(i) for i in g["both/seed_call"])
+    te.manual_seed(seed, call)
+    o, w = m(q, k, v, attn_mask=te.buffered_future_mask(q, k))
+    assert tuple(w.shape) == (2, 5, 11)
+    close(o, g["both/out"], what="out"); close(w, g["both/weights"], what="weights")
+    assert torch.equal(w.cpu() == 0, T(g["both/weights"]) == 0)
+    (o * G(g["both/R"])).sum().backward()
+    check_grads(m, g, "both", q=q, k=k, v=v)
+    m = load_params(te.MultiheadAttention(32, 4, add_zero_attn=True), g, "zero").eval()
+    x = G(g["zero/x"]).requires_grad_()
+    o, w = m(x, x, x)
+    close(o, g["zero/out"], what="out"); close(w, g["zero/weights"], what="weights")
+    (o * G(g["zero/R"])).sum().backward()
+    check_grads(m, g, "zero", x=x)
+    m = load_params(te.MultiheadAttention(30, 2, add_bias_kv=True), g, "bias").eval()
+    q, kv = G(g["bias/q"]).requires_grad_(), G(g["bias/kv"]).requires_grad_()
+    o, w = m(q, kv, kv)
+    close(o, g["bias/out"], what="out"); close(w, g["bias/weights"], what="weights")
+    (o * G(g["bias/R"])).sum().backward()
+    check_grads(m, g, "bias", q=q, kv=kv)
 
 
 def test_mha_golden_odd_head_dim_kv_alias(te, golden):
