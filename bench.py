@@ -308,6 +308,8 @@ def main():
     ndev = torch.cuda.device_count()
     if local_rank >= ndev:      # debugging aid only (two ranks on one GPU with SDUMC_DIST_BACKEND=gloo)
         local_rank %= ndev
+    if world > ndev:            # several processes share a GPU: the clustered utterance-level kernels assume they own it
+        os.environ.setdefault("SDUMC_CHAIN_CLUSTER", "0")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
