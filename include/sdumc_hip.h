@@ -152,6 +152,36 @@ size_t sdumc_gemm_bf16_workspace_bytes(const sdumc_gemm_bf16* g);
 int sdumc_gemm_bf16_run(const sdumc_gemm_bf16* g, void* stream);
 
 /* ------------------------------------------------------------------------
+ * Grouped weight-gradient GEMM: every dW = dz^T . x of a backward phase in ONE persistent launch (+ one ordered reduce).
+ * Replaces the autograd products of the Linear layers (aten::mm of grad_output^T with the saved input, plus the bias
+ * gradient's sum over rows) of model :282-284 (frame_dim_reshape), :60 / :82 (input_proj of FRA2UTT_new / Cross_Attention)
+ * and :293-368 (utterance-level MLPs) when main :149 calls loss.backward().
+ *   problem i:  C_i[M,N] (+)= sum over K-segments s of  A_is[K_s, M]^T . mask_is(B_is[K_s, N]),   colsum_i[m] (+)= sum_k A[k, m]
+ * Both operands are row-contiguous in the contraction index (dz [rows, out], x [rows, in]).  The launch is a stream-K
+ * decomposition: the k-tiles of all output tiles of all problems form one line that the resident workgroups (one per CU)
+ * cut into equal contiguous ranges, so every CU multiplies for the same time whatever the shapes; a tile that ends up in
+ * several ranges goes through fp32 partial slabs in `workspace` and the reduce launch sums them in ascending k order
+ * (bit-identical from run to run).  Constraints: M, N, lda, ldb multiples of 4; pointers 16-byte aligned; every operand
+ * below 4 GiB; M <= 256 * 255.
+ * ---------------------------------------------------------------------- */
+#define SDUMC_GG_MAX_PROBLEMS 24   /* per launch pair; longer lists are cut into several */
+typedef struct sdumc_gg_problem {
+  const float* A[2];        /* [K_s, M] with lda: the gradient w.r.t. the layer's pre-activation (segment 1 unused when K[1] == 0) */
+  const float* B[2];        /* [K_s, N] with ldb: the layer's saved input */
+  const uint8_t* b_bits[2]; /* optional keep-bits of a dropout fused on B (byte [row * bits_qw + col/4], bit col%4; rows = k) */
+  int32_t K[2];             /* rows per segment: two segments = the two streams' text frames, which live in separate tensors */
+  int32_t b_row_mod[2];     /* >0: B's source row = k % b_row_mod (the streams share x_audio / x_video) */
+  float* C;                 /* [M, N] with ldc */
+  float* colsum_a;          /* [M] or NULL: the bias gradient */
+  int32_t M, N, lda, ldb, ldc;
+  int32_t bits_qw;          /* bytes per row of b_bits */
+  float b_scale;            /* 1 / (1 - p) of the fused dropout */
+  int32_t accumulate;       /* C += ..., colsum_a += ... */
+} sdumc_gg_problem;
+size_t sdumc_gemm_group_workspace_bytes(const sdumc_gg_problem* probs, int32_t n);
+int sdumc_gemm_group_tn(const sdumc_gg_problem* probs, int32_t n, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------
  * Attention pooling over the time axis = the body shared by
  *   FRA2UTT_new.forward     (model :56-68; nq = 1, query = attention_context_vector, q_stride 0)
  *   Cross_Attention.forward (model :79-95; nq = 7, query = query_proj(multi_query))

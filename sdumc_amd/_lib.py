@@ -54,6 +54,14 @@ class GemmBf16(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
+class GGProblem(C.Structure):
+    _fields_ = [("A", C.c_void_p * 2), ("B", C.c_void_p * 2), ("b_bits", C.c_void_p * 2),
+                ("K", C.c_int32 * 2), ("b_row_mod", C.c_int32 * 2),
+                ("C", C.c_void_p), ("colsum_a", C.c_void_p),
+                ("M", C.c_int32), ("N", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
+                ("bits_qw", C.c_int32), ("b_scale", C.c_float), ("accumulate", C.c_int32)]
+
+
 class AttnPool(C.Structure):
     _fields_ = [("V", C.c_int32), ("T", C.c_int32), ("nq", C.c_int32), ("x_samples", C.c_int32),
                 ("x", C.c_void_p), ("keys", C.c_void_p), ("q", C.c_void_p), ("q_stride", C.c_int64),
@@ -159,6 +167,8 @@ _SIGS = {
     "sdumc_profile_report": (C.c_int, [C.POINTER(ProfEntry), C.c_int]),
     "sdumc_gemm_workspace_bytes": (C.c_size_t, [C.POINTER(Gemm)]),
     "sdumc_gemm_f32": (C.c_int, [C.POINTER(Gemm), C.c_void_p]),
+    "sdumc_gemm_group_workspace_bytes": (C.c_size_t, [C.POINTER(GGProblem), C.c_int32]),
+    "sdumc_gemm_group_tn": (C.c_int, [C.POINTER(GGProblem), C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sdumc_attnpool_fwd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "sdumc_attnpool_fwd": (C.c_int, [C.POINTER(AttnPool), C.c_void_p]),
     "sdumc_attnpool_fwd_workspace_bytes_dim": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

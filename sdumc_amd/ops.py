@@ -68,6 +68,50 @@ def gemm(layout, A, B, M, N, K, bias=None, C_out=None, lda=None, ldb=None, ldc=N
     return Cs if isinstance(A, (list, tuple)) else Cs[0]
 
 
+def gemm_group_tn(problems, workspace=None):
+    """All weight gradients of a phase in one persistent launch + one ordered reduce (sdumc_gemm_group_tn).
+
+    problems: list of dicts {A, B, C, [A1, B1], [bits, bits1], [colsum], [b_row_mod, b_row_mod1], [scale], [accumulate],
+    [M, N, K, K1, lda, ldb, ldc]}: C[M, N] (+)= A[K, M]^T . mask(B[K, N]) (+ the same over the second K segment A1 / B1);
+    A, B are 2-D device tensors (row-contiguous), bits the uint8 keep-bits [K, N / 4] of a dropout fused on B."""
+    n = len(problems)
+    arr = (_lib.GGProblem * n)()
+    keep = []
+    for i, q in enumerate(problems):
+        g = arr[i]
+        A, B = q["A"], q["B"]
+        g.A[0], g.B[0] = ptr(A), ptr(B)
+        g.M = q.get("M", A.shape[1])
+        g.N = q.get("N", B.shape[1])
+        g.K[0] = q.get("K", A.shape[0])
+        g.lda = q.get("lda", A.stride(0))
+        g.ldb = q.get("ldb", B.stride(0))
+        if q.get("A1") is not None:
+            g.A[1], g.B[1] = ptr(q["A1"]), ptr(q["B1"])
+            g.K[1] = q.get("K1", q["A1"].shape[0])
+        g.b_row_mod[0], g.b_row_mod[1] = q.get("b_row_mod", 0), q.get("b_row_mod1", 0)
+        if q.get("bits") is not None:
+            g.b_bits[0] = ptr(q["bits"])
+            g.bits_qw = q["bits"].stride(0)
+            if q.get("bits1") is not None:
+                g.b_bits[1] = ptr(q["bits1"])
+        g.b_scale = q.get("scale", 1.0)
+        Cm = q.get("C")
+        if Cm is None:
+            Cm = torch.empty(g.M, g.N, device=A.device)
+            q["C"] = Cm
+        g.C, g.ldc = ptr(Cm), q.get("ldc", Cm.stride(0))
+        g.colsum_a = ptr(q.get("colsum"))
+        g.accumulate = 1 if q.get("accumulate") else 0
+        keep.append(Cm)
+    need = lib.sdumc_gemm_group_workspace_bytes(arr, n)
+    if workspace is None:
+        workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=problems[0]["A"].device)
+    check(lib.sdumc_gemm_group_tn(arr, n, ptr(workspace), workspace.numel() * workspace.element_size(), _st()),
+          "sdumc_gemm_group_tn")
+    return [q["C"] for q in problems]
+
+
 def gemm_bf16(layout, A, B, M, N, K, bias=None, C_out=None, lda=None, ldb=None, ldc=None, act=ACT_NONE, a_row_mod=0,
               b_row_mod=0, accumulate=False, c_bf16=False, splitk=0, colsum_a=None):
     """GEMM on bf16 storage (sdumc_gemm_bf16_run): A, B torch.bfloat16 device tensors (lists = grouped); C fp32 or bf16."""

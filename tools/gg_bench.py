@@ -1,0 +1,118 @@
+"""Grouped weight-gradient GEMM (sdumc_gemm_group_tn) vs the per-layer split-K GEMMs on the C2 shapes of one backward.
+usage: python3 tools/gg_bench.py [reps]"""
+import sys
+import os
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sdumc_amd import ops  # noqa: E402
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+B, Ta, Tt, Tv, D = 64, 375, 32, 225, 256
+dev = "cuda"
+g = torch.Generator(device=dev).manual_seed(1)
+
+
+def rn(*s):
+    return torch.randn(*s, device=dev, generator=g)
+
+
+def bits(K, N):
+    return torch.randint(0, 16, (K, N // 4), device=dev, generator=g, dtype=torch.uint8)
+
+
+def timeit(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def flops(ps):
+    f = 0
+    for q in ps:
+        f += 2.0 * q["A"].shape[1] * q["B"].shape[1] * (q["A"].shape[0] + (q["A1"].shape[0] if q.get("A1") is not None else 0))
+    return f
+
+
+def frame_problems():
+    ps = []
+    ps.append({"A": rn(B * Ta, D), "B": rn(B * Ta, 1024), "colsum": torch.zeros(D, device=dev)})
+    ps.append({"A": rn(B * Tv, D), "B": rn(B * Tv, 1024), "colsum": torch.zeros(D, device=dev)})
+    ps.append({"A": rn(B * Tt, D), "B": rn(B * Tt, 4096), "A1": rn(B * Tt, D), "B1": rn(B * Tt, 4096),
+               "colsum": torch.zeros(D, device=dev)})
+    return ps
+
+
+def key_problems(sites=(0, 1)):
+    ps = []
+    for T in (Ta, Tv, Tt):
+        x = rn(B * T, D)
+        for _ in sites:
+            ps.append({"A": rn(2 * B * T, D), "B": x, "b_row_mod": B * T, "bits": bits(2 * B * T, D), "scale": 2.0,
+                       "colsum": torch.zeros(D, device=dev)})
+    return ps
+
+
+def utt_problems():
+    V, V7 = 2 * B, 14 * B
+    ps = []
+    for _ in range(6 + 1 + 7):
+        ps.append({"A": rn(V, D), "B": rn(V, D), "colsum": torch.zeros(D, device=dev)})
+    ps.append({"A": rn(V, D), "B": rn(V, 3 * D), "colsum": torch.zeros(D, device=dev)})
+    for _ in range(6):
+        ps.append({"A": rn(V7, D), "B": rn(V7, D), "colsum": torch.zeros(D, device=dev)})
+    for _ in range(3):
+        ps.append({"A": rn(V7, 128), "B": rn(V7, D), "colsum": torch.zeros(128, device=dev)})
+    ps.append({"A": rn(V, D), "B": rn(V, 896), "colsum": torch.zeros(D, device=dev)})
+    ps.append({"A": rn(V, 128), "B": rn(V, D), "colsum": torch.zeros(128, device=dev)})
+    ps.append({"A": rn(V, 64), "B": rn(V, 128), "colsum": torch.zeros(64, device=dev)})
+    ps.append({"A": rn(V, 64), "B": rn(V, 64), "colsum": torch.zeros(64, device=dev)})
+    return ps
+
+
+def old_path(ps):
+    """the round-2 way: one split-K TN GEMM (auto plan) per problem (segments accumulate)"""
+    from sdumc_amd._lib import make_dropout
+    for q in ps:
+        A, Bm = q["A"], q["B"]
+        K, M, N = A.shape[0], A.shape[1], Bm.shape[1]
+        kw = {}
+        if q.get("bits") is not None:
+            d = make_dropout(True, 0, 0.5, 1, N, 1)
+            d.bits = q["bits"].data_ptr()
+            kw = dict(b_drop=d)
+        q.setdefault("C", torch.empty(M, N, device=dev))
+        ops.gemm(ops.TN, A, Bm, M, N, K, C_out=q["C"], splitk=0, colsum_a=q.get("colsum"), b_row_mod=q.get("b_row_mod", 0), **kw)
+        if q.get("A1") is not None:
+            ops.gemm(ops.TN, q["A1"], q["B1"], M, N, q["A1"].shape[0], C_out=q["C"], splitk=0, colsum_a=q.get("colsum"),
+                     accumulate=True)
+
+
+def run(name, ps):
+    for q in ps:
+        q.pop("C", None)
+    f = flops(ps)
+    t_old = timeit(lambda: old_path(ps), reps)
+    c_old = [q["C"].clone() for q in ps]
+    for q in ps:
+        q.pop("C", None)
+    import ctypes as C
+    t_new = timeit(lambda: ops.gemm_group_tn(ps), reps)
+    err = max(float((q["C"] - c).abs().max() / c.abs().max()) for q, c in zip(ps, c_old))
+    print(f"{name:28s} {f / 1e9:7.2f} GF  per-layer {t_old:8.1f} us = {f / t_old / 1e6:6.1f} TF   grouped {t_new:8.1f} us = "
+          f"{f / t_new / 1e6:6.1f} TF   max rel diff {err:.1e}", flush=True)
+
+
+run("frame dW (G2)", frame_problems())
+run("frame dW audio only", frame_problems()[:1])
+run("key dW, 6 sites (masked)", key_problems())
+run("key dW CA sites + utt", key_problems((1,)) + utt_problems()[:12])
+run("utterance-level dW", utt_problems())
+run("everything", frame_problems() + key_problems() + utt_problems())
