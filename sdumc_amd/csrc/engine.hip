@@ -198,6 +198,7 @@ struct Plan {
   int64_t wh = 0, wht = 0;   // [live] bf16 each: weights as stored / transposed (input_proj only), parameter offsets
   int64_t tickets = 0;   // per-sample arrival counters of the attention kernels
   int64_t scratch[4] = {0, 0, 0, 0}, scratch_floats = 0;   // one scratch per lane (stream)
+  int64_t gg_slab[2] = {0, 0}, gg_slab_floats[2] = {0, 0}; // partial-tile slabs of the grouped dW launches: [0] lane 3, [1] the frame dW
   int64_t alloc(int64_t n) {
     const int64_t o = cur;
     cur += (n + 63) & ~(int64_t)63;
@@ -360,6 +361,14 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
   sc = std::max<int64_t>(sc, (int64_t)13 << 20);            // auto split-K: <= ~(320 + tiles) slabs of 64 KiB
   p.scratch_floats = sc;
   for (int l = 0; l < 4; ++l) p.scratch[l] = p.alloc(sc);
+  {   // grouped weight-gradient launches (gemm_group.hip): at most one 256 x 128 tile per 128 output columns of every layer
+    const int utt_tiles = 160;                                            // upper bound over the utterance-level layers
+    const int key_tiles = 6 * 2 * 2;                                      // six input_proj layers, up to two runs each
+    const int frame_tiles = (d.da + 127) / 128 + 2 * ((d.dt + 127) / 128) + (d.dv + 127) / 128;
+    p.gg_slab_floats[0] = (int64_t)(sdumc_gg_slab_bytes_(utt_tiles + key_tiles) / sizeof(float));
+    p.gg_slab_floats[1] = (int64_t)(sdumc_gg_slab_bytes_(frame_tiles) / sizeof(float));
+    for (int i = 0; i < 2; ++i) p.gg_slab[i] = p.alloc(p.gg_slab_floats[i]);
+  }
   return true;
 }
 
@@ -468,6 +477,8 @@ struct Ctx {
   bool multi = false;
   // weight-gradient GEMMs of the utterance-level layers, queued by lin_bwd* and issued in batches on lane 3 (flush_dw)
   mutable std::vector<sdumc_gemm> deferred;
+  // the same products as problems of ONE persistent launch (gemm_group.hip): everything queued here is issued by the next flush_dw
+  mutable std::vector<sdumc_gg_problem> gg;
   float* p(int64_t off) const { return W + off; }
   // bf16 buffers: `off` is the buffer's offset in floats, `elems` an element offset inside it
   unsigned short* ph(int64_t off, int64_t elems = 0) const { return reinterpret_cast<unsigned short*>(W + off) + elems; }
@@ -592,28 +603,83 @@ int colsum(const Ctx& c, const float* a, int64_t rows, int cols, int lda, float*
   return sdumc_colsum(a, rows, cols, lda, out, accumulate, c.scr, c.st);
 }
 
-// Issues the queued utterance-level dW GEMMs on lane 3, ordered after everything lane 0 has issued so far.
+// Weight gradients are off every critical path (only Adam and a data-parallel all-reduce read them): lin_bwd* queue them and
+// flush_dw issues what is queued on lane 3 -- as ONE persistent launch + one reduce (gemm_group.hip) -- ordered after everything
+// lane 0 has issued so far.
 // Why batches: every hipEventRecord on a stream costs its NEXT kernel ~12 us of bubble on this stack (kernel trace of the
 // step: the dX chain ran at one 9 us kernel per 26-30 us while each layer forked its own dW to a side lane, against
 // back-to-back kernels in the link-free forward chain), so the chain records an event at three points instead of at
 // every layer.  Every operand of a queued GEMM (dz, the saved input) is final when it is queued and is not written
 // again before the end of the backward pass, so running it later is safe.
-bool dw_batching() {   // SDUMC_DW_BATCH=0: one fork per layer (the pre-batching schedule, kept for A/B measurements)
+// SDUMC_DW_GROUP=0 restores one split-K GEMM per layer (the round-2 schedule, kept for A/B measurements and as the path of
+// shapes the grouped kernel does not take)
+bool gg_on() {
   static const bool on = [] {
-    const char* e = getenv("SDUMC_DW_BATCH");
+    const char* e = getenv("SDUMC_DW_GROUP");
     return !(e && e[0] == '0');
   }();
   return on;
 }
-int flush_dw(const Ctx& c) {
-  if (c.deferred.empty()) return SDUMC_OK;
-  RET(link(c, 0, 3));
-  c.use(3);
-  for (sdumc_gemm& g : c.deferred) RET(run(c, g));
-  c.use(0);
+// the queued weight-gradient GEMMs go through ONE persistent launch (gemm_group.hip)
+bool gg_utt(const Ctx& c) { return gg_on(); }
+// ... and so do the frame-level ones (input_proj of both attention sites, frame_dim_reshape): fp32 storage only
+bool gg_frame(const Ctx& c) { return gg_utt(c) && !c.h() && c.d.bf16 == 0; }
+
+// one group of a queued TN descriptor as a problem of the grouped launch; false = the grouped kernel does not take it
+bool gg_from_gemm(const sdumc_gemm& g, int grp, sdumc_gg_problem& q) {
+  if (g.layout != SDUMC_TN || g.bf16 || g.batch > 1 || g.a_drop.enabled || g.b_drop.enabled || g.c_drop.enabled || g.a_row_mod ||
+      g.act != SDUMC_ACT_NONE || g.bias[grp] || g.c_mask_y[grp])
+    return false;
+  if ((g.M & 3) || (g.N & 3) || (g.lda & 3) || (g.ldb & 3) || g.M < 4 || g.N < 4) return false;
+  if ((reinterpret_cast<uintptr_t>(g.A[grp]) | reinterpret_cast<uintptr_t>(g.B[grp])) & 15) return false;
+  if (g.b_row_mod > 0 && g.b_row_mod < 16) return false;
+  memset(&q, 0, sizeof(q));
+  q.A[0] = g.A[grp];
+  q.B[0] = g.B[grp];
+  q.K[0] = g.K;
+  q.b_row_mod[0] = g.b_row_mod;
+  q.C = g.C[grp];
+  q.colsum_a = g.colsum_a[grp];
+  q.M = g.M;
+  q.N = g.N;
+  q.lda = g.lda;
+  q.ldb = g.ldb;
+  q.ldc = g.ldc;
+  q.b_scale = 1.f;
+  q.accumulate = g.accumulate;
+  return true;
+}
+
+// issues everything queued (c.deferred, c.gg) on `lane`, ordered after what lane `after` has issued so far
+int flush_dw_on(const Ctx& c, int after, int lane, int slab) {
+  if (c.deferred.empty() && c.gg.empty()) return SDUMC_OK;
+  RET(link(c, after, lane));
+  c.use(lane);
+  const bool grouped = gg_utt(c);
+  for (sdumc_gemm& g : c.deferred) {
+    bool taken = grouped;
+    if (grouped) {
+      const size_t n0 = c.gg.size();
+      for (int grp = 0; grp < g.groups && taken; ++grp) {
+        sdumc_gg_problem q;
+        taken = gg_from_gemm(g, grp, q);
+        if (taken) c.gg.push_back(q);
+      }
+      if (!taken) c.gg.resize(n0);
+    }
+    if (!taken) RET(run(c, g));      // (fc_att, cross_fc_att, fc_out_v: 3 / 7 / 1 output rows)
+  }
   c.deferred.clear();
+  if (!c.gg.empty()) {
+    const int rc = sdumc_gemm_group_tn(c.gg.data(), (int)c.gg.size(), c.p(c.pl.gg_slab[slab]),
+                                       (size_t)c.pl.gg_slab_floats[slab] * sizeof(float), c.st);
+    c.gg.clear();
+    if (rc != SDUMC_OK) return rc;
+  }
+  c.use(after);
   return SDUMC_OK;
 }
+int flush_dw(const Ctx& c) { return flush_dw_on(c, 0, 3, 0); }
 
 // backward of y = act(x W^T + b) given dzv = gradient w.r.t. the pre-activation, [M, L.out] with ld lddz:
 //   dW = dz^T x, db = colsum(dz), dx (=|+=) dz W
@@ -630,7 +696,6 @@ int lin_bwd(const Ctx& c, const Lin& L, const float* dzv, int lddz, const float*
   gw.ldc = L.in;
   gw.colsum_a[0] = c.G + L.b;   // db rides along with the staging of dz
   c.deferred.push_back(gw);     // dW is off the dX critical path: issued later, in a batch, on lane 3 (flush_dw)
-  if (!dw_batching()) RET(flush_dw(c));
   if (dx) {
     sdumc_gemm gx = G_(SDUMC_NN, M, L.in, L.out);
     gx.A[0] = dzv;
@@ -672,7 +737,6 @@ int lin_bwd_grouped(const Ctx& c, const Lin* L, int ng, int M, const GroupPtrs& 
   gw.ldb = q.ldx;
   gw.ldc = L[0].in;
   c.deferred.push_back(gw);
-  if (!dw_batching()) RET(flush_dw(c));
   if (q.dx) {
     gx.c_mask_scale = q.dx_scale;
     gx.lda = q.lddz;
@@ -1348,6 +1412,39 @@ int keys_gemm_bwd_h(const Ctx& c, int m, int k0, int k1, int parts) {
   return run_h(c, g);
 }
 
+// dW (+ db) of the input_proj layers of sites [k0, k1) of modality m, queued for the next grouped launch: one problem per layer,
+// the runs of a modality (streams whose text lengths differ) as its K segments
+bool keys_dw_groupable(const Ctx& c, int m) {
+  if (c.pl.segs[m].size() > 2) return false;
+  for (const Seg& sg : c.pl.segs[m])
+    if (sg.x_samples < sg.V && sg.x_samples * sg.T < 16) return false;
+  return true;
+}
+void keys_dw_queue(const Ctx& c, int m, int k0, int k1) {
+  const Plan& pl = c.pl;
+  for (int k = k0; k < k1; ++k) {
+    const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
+    sdumc_gg_problem q;
+    memset(&q, 0, sizeof(q));
+    int s = 0;
+    for (const Seg& sg : pl.segs[m]) {
+      q.A[s] = c.p(pl.dz[k][m]) + sg.row0 * D;
+      q.B[s] = c.p(sg.x_off);
+      q.K[s] = sg.V * sg.T;
+      q.b_row_mod[s] = sg.x_samples < sg.V ? sg.x_samples * sg.T : 0;
+      const sdumc_dropout dd = in_drop(c, k, m, sg.T, sg.s0, sg.row0);
+      q.b_bits[s] = dd.enabled ? dd.bits : nullptr;
+      q.b_scale = dd.enabled ? dd.scale : 1.f;
+      ++s;
+    }
+    q.C = c.G + L.w;
+    q.colsum_a = c.G + L.b;
+    q.M = q.N = q.lda = q.ldb = q.ldc = D;
+    q.bits_qw = D / 4;
+    c.gg.push_back(q);
+  }
+}
+
 int keys_gemm_bwd(const Ctx& c, int m, int k0, int k1, int parts = 3) {
   if (c.h()) return keys_gemm_bwd_h(c, m, k0, k1, parts);
   const Plan& pl = c.pl;
@@ -1401,11 +1498,26 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   // the caller's stream waits only for the pooling backward before it, so the GEMMs run beside steps 7'-3' and, in phased
   // calls (the data-parallel step), beside whatever the caller does between the phases; a modality on the caller's stream
   // goes through lane 3, which phased calls cannot use for frame-level work (phase 0 ends by waiting for lane 3).
+  // With the grouped weight-gradient launches lane 3 carries persistent kernels that fill the chip for 0.1-0.2 ms each, so
+  // nothing the critical path waits for may queue behind them: the early dX then always takes the modality's own lane.
+  const bool ggf = gg_frame(c);
+  // A/B knob (grouped mode): 0 = early dX on the modality's own lane, its dW grouped; 1 = the early modality keeps the per-layer
+  // dW + dX pair on lane 3 (the round-2 arrangement); 2 = no early key-projection backward at all
+  static const int gg_early = [] { const char* e = getenv("SDUMC_GG_EARLY"); return e ? atoi(e) : 1; }();
+  const int cbgb = (ggf && gg_early == 2) ? 0 : c.bgb;
   int own_lane = 0;
   for (int m = 0; m < 3; ++m)
-    if (phases != 3 && (c.bgb & (1 << m)) && c.multi && LANE_OF[m] != 0) own_lane |= 1 << m;
+    if ((phases != 3 || (ggf && gg_early == 0)) && (cbgb & (1 << m)) && c.multi && LANE_OF[m] != 0) own_lane |= 1 << m;
   // (in a single call the lane-3 route measured 0.15 % faster than the own-lane route; phased calls gain 0.6 % from the latter)
-  const int bgb = phases == 3 ? c.bgb : own_lane;
+  const int bgb = (phases == 3 && !(ggf && gg_early == 0)) ? cbgb : own_lane;
+  // grouped mode: the dW of the Cross_Attention input_proj layers rides in the launch right behind the (grouped) pooling backward
+  // of phase 0 (bit m of ca_dw_mask), the dW of the FRA2UTT ones in the launch behind the FRA2UTT pooling backward of phase 1
+  const bool ca_dw_grouped = ggf && attn_multi_ok(c);
+  int ca_dw_mask = 0, fra_dw_mask = 0;
+  for (int m = 0; m < 3; ++m) {
+    if (ca_dw_grouped && keys_dw_groupable(c, m) && !(gg_early == 1 && (bgb & (1 << m)))) ca_dw_mask |= 1 << m;
+    if (ggf && keys_dw_groupable(c, m)) fra_dw_mask |= 1 << m;
+  }
   // early_done[m]: lane 3 has finished modality m's early key-projection backward (dxd of its Cross_Attention site).  The
   // modality's own lane waits for exactly this event before its mask-sum -- not for whatever else lane 3 has been handed by
   // then (the utterance-level dW batches, the other key-projection dW GEMMs: ~0.25 ms of work that only feeds the bucket).
@@ -1467,9 +1579,11 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     RET(lin_bwd_grouped(c, pm.cmlp0, 3, M, q0));
   }
   }   // !chain
-  RET(flush_dw(c));   // batch 1: heads, cross_attention_mlp, cross_*_mlp
   // 8'. the three Cross_Attention blocks
   const bool grouped = attn_multi_ok(c);
+  // batch 1 of the weight gradients (heads, cross_attention_mlp, cross_*_mlp) -- in the grouped mode together with the
+  // Cross_Attention input_proj dW, right behind the pooling backward that produces their dz
+  if (!ca_dw_grouped) RET(flush_dw(c));
   if (grouped) {   // one grouped launch on the caller's stream, then the early key-projection backwards leave for their lanes
     sdumc_attnpool_bwd_t bb[4];
     int n = 0;
@@ -1498,15 +1612,20 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
       }
     }
     RET(sdumc_attnpool_bwd_multi(bb, n, c.st));
-    for (int m = 0; m < 3; ++m) {
+    for (int m = 0; m < 3; ++m)
+      if (ca_dw_mask & (1 << m)) keys_dw_queue(c, m, 1, 2);
+    for (int m = 0; m < 3; ++m) {     // the early dX (before the flush below: it is on the critical path, the flush is not)
       if (!(bgb & (1 << m))) continue;
       const int lane = (own_lane & (1 << m)) ? LANE_OF[m] : 3;
       RET(link(c, 0, lane));
       c.use(lane);
-      RET(keys_gemm_bwd(c, m, 1, 2));
+      RET(keys_gemm_bwd(c, m, 1, 2, (ca_dw_mask & (1 << m)) ? 2 : 3));
       if (lane == 3) RET(record_early(m));
       c.use(0);
     }
+    // (no flush here: a persistent launch now would hold every CU's registers while the latency-bound utterance-level stage
+    //  7'-3' -- 256 co-resident workgroups -- is trying to start: measured +135 us on that stage.  The queued problems leave
+    //  with the FRA2UTT ones, beside the dX products of the frame-level part.)
   }
   if (!grouped) RET(fork_all(c));
   hipEvent_t pooled[3] = {nullptr, nullptr, nullptr};   // per side lane: its pooling backward is done (partial join)
@@ -1572,8 +1691,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     }
     gw.lda = gw.ldb = gw.ldc = D;
     c.deferred.push_back(gw);
-    if (!dw_batching()) RET(flush_dw(c));
-    for (int m = 0; m < 3; ++m) {
+      for (int m = 0; m < 3; ++m) {
       sdumc_gemm gx = G_(SDUMC_NN, M, D, D);
       gx.A[0] = c.p(pl.d_qp) + (int64_t)m * M * D;
       gx.lda = D;
@@ -1593,7 +1711,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     GroupPtrs qq = {c.p(pl.d_q), D, NQ * D, c.p(pl.qin), (int64_t)V * D, D, c.p(pl.d_qin), (int64_t)V * D, D};
     RET(lin_bwd_grouped(c, pm.query, 7, V, qq));
   }
-  RET(flush_dw(c));   // batch 2: query_proj, the query MLPs
+  if (!gg_utt(c)) RET(flush_dw(c));   // batch 2: query_proj, the query MLPs (grouped mode: they wait for batch 3)
   // 5'. fusion algebra (d_alpha already holds the second-level contribution)
   RET(sdumc_fusion_bwd(c.p(pl.u), c.p(pl.alpha), c.p(pl.d_qin), c.p(pl.d_u), c.p(pl.d_alpha), V, c.st));
   // 4'. fc_att, attention_mlp
@@ -1610,32 +1728,55 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     RET(lin_bwd_grouped(c, pm.umlp0, 3, V, q0));
   }
   }   // !chain
-  RET(flush_dw(c));   // batch 3: fc_att, attention_mlp, audio/text/video_mlp
+  // batch 3: fc_att, attention_mlp, audio/text/video_mlp.  Grouped mode with the frame-level part following in this call:
+  // they stay queued and ride with the FRA2UTT input_proj dW in one launch (below).
+  if (!(ggf && (phases & 2))) RET(flush_dw(c));
   // the dW GEMMs of this part ran on lane 3: after this link [0, pm.early) is final on the caller's stream.  When the
-  // frame-level part follows in the same call the link at its head does the same job.
+  // frame-level part follows in the same call the link at its end does the same job.
   if (!(phases & 2)) RET(link(c, 3, 0));
   }   // phases & 1
   if (!(phases & 2)) return SDUMC_OK;
   // 2'+1'. three independent per-modality chains, one per lane:
   //   fra2utt_m pooling backward (the shared context vector's gradient = sum of the per-sample dq)
   //   -> input_proj backward of both sites (grouped) -> dx = sum of the (up to) four masked paths into the
-  //   projected features -> frame_dim_reshape_m: dW = dx^T feat (split-K) with db fused
+  //   projected features -> frame_dim_reshape_m: dW = dx^T feat with db fused
   RET(fork_all(c));
-  for (int m = 0; m < 3; ++m) {
+  for (int m = 0; m < 3; ++m) {       // pass 1: the pooling backward of every modality (produces dz of the FRA2UTT site)
     c.use(LANE_OF[m]);
     float* dq = c.p(pl.dq_fra) + (int64_t)m * V * D;
     RET(pool_bwd(c, 0, m, c.p(pl.d_hpre) + (int64_t)m * V * D, dq));
     RET(colsum(c, dq, V, D, D, c.G + pm.fra_ctx[m], 0));
     mark(c.st, 12 + 5 * m);      // (debug marks 12..26: this modality's lane, frame-level backward)
+    if (fra_dw_mask & (1 << m)) {
+      keys_dw_queue(c, m, 0, 1);
+      if (!(ca_dw_mask & (1 << m)) && !(bgb & (1 << m))) keys_dw_queue(c, m, 1, 2);   // (the Cross_Attention one, when it did not leave in phase 0)
+      if (!c.capturing) RET(link(c, LANE_OF[m], 3));   // lane 3 (the grouped launch below) needs this lane's dz
+    }
+  }
+  if (ggf) {   // every queued utterance-level dW and the input_proj dW: one launch on lane 3, beside the dX products below
+    c.use(0);
+    // (under hipGraph capture three lanes -> lane 3 -> lane 0 is the dependency pattern hipStreamEndCapture cannot take on this
+    //  stack: the lanes meet on the caller's stream instead and fork again)
+    if (c.capturing) RET(join_all(c));
+    RET(flush_dw(c));
+    if (c.capturing) RET(fork_all(c));
+  }
+  for (int m = 0; m < 3; ++m) {       // pass 2: dX of the key projections, the mask-sum, the frame projection's dW
+    c.use(LANE_OF[m]);
     {
       const int k1 = (bgb & (1 << m)) ? 1 : 2;
-      // bit m: modality m's key-projection dW (off the dz -> dX -> mask-sum -> frame dW chain) runs on lane 3.  Default: audio
-      // only, the longest chain (30.84 vs 30.51 k samples/s, five alternations; audio + video 30.8, all three 30.8).
+      // which of this modality's key-projection dW products are already on their way in a grouped launch
+      const bool fra_q = (fra_dw_mask & (1 << m)) != 0;
+      const bool ca_q = k1 == 2 && (((ca_dw_mask | fra_dw_mask) & (1 << m)) != 0);
+      // bit m: modality m's key-projection dW (off the dz -> dX -> mask-sum -> frame dW chain) runs on lane 3 (ungrouped modes).
       // (re-measured with the clustered utterance-level kernels: fp32 1.923 ms with none on lane 3 vs 1.930 with audio's;
       //  bf16 storage 1.148 vs 1.128 -- so the default follows the mode)
       static const int dw_env = [] { const char* e = getenv("SDUMC_KEYS_DW_LANE3"); return e ? atoi(e) : -1; }();
       const int dw_off = dw_env >= 0 ? dw_env : (c.h() ? 1 : 0);
-      if (c.multi && !c.capturing && (dw_off & (1 << m))) {
+      if (fra_q) {
+        if (k1 == 2 && !ca_q) RET(keys_gemm_bwd(c, m, 1, 2, 1));     // (never in practice: both sites are groupable or neither)
+        RET(keys_gemm_bwd(c, m, 0, k1, 2));
+      } else if (c.multi && !c.capturing && (dw_off & (1 << m))) {
         RET(link(c, LANE_OF[m], 3));
         c.use(3);
         RET(keys_gemm_bwd(c, m, 0, k1, 1));
@@ -1653,6 +1794,8 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
         RET(link(c, 3, LANE_OF[m]));
       }
     }
+    sdumc_gg_problem fq;          // grouped mode: this modality's frame_dim_reshape dW, the streams as K segments
+    memset(&fq, 0, sizeof(fq));
     for (int s = 0; s < (m == 1 ? S : 1); ++s) {
       const int T = pl.T[m][s];
       sdumc_dropsum ds;
@@ -1691,6 +1834,12 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
         RET(run_h(c, gh));
         continue;
       }
+      if (ggf && (din[m] & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+        fq.A[s] = c.p(pl.dx[m][s]);
+        fq.B[s] = in;
+        fq.K[s] = rows;
+        continue;
+      }
       sdumc_gemm g = G_(SDUMC_TN, D, din[m], rows);
       g.A[0] = c.p(pl.dx[m][s]);
       g.lda = D;
@@ -1703,12 +1852,27 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
       g.bf16 = c.d.bf16 && (din[m] % 4 == 0) ? 1 : 0;
       RET(run(c, g));
     }
+    if (fq.K[0] > 0) {
+      fq.C = c.G + pm.frame[m].w;
+      fq.colsum_a = c.G + pm.frame[m].b;
+      fq.M = D;
+      fq.N = din[m];
+      fq.lda = D;
+      fq.ldb = din[m];
+      fq.ldc = din[m];
+      fq.b_scale = 1.f;
+      c.gg.push_back(fq);
+    }
   }
   c.use(0);
   for (int m = 0; m < 3; ++m) mark(c.sts[LANE_OF[m]], 16 + 5 * m);
   mark(c.sts[3], 27);
   RET(join_all(c));
-  RET(link(c, 3, 0));   // the last dW batch of the utterance-level part
+  // grouped mode: the three frame_dim_reshape dW (29 of the step's 127 GFLOP at C2) in one launch on the caller's stream, once
+  // every modality's dx is there
+  if (!c.gg.empty()) RET(flush_dw_on(c, 0, 0, 1));
+  mark(c.st, 41);
+  RET(link(c, 3, 0));   // the dW launches of lane 3
   return SDUMC_OK;
 }
 

@@ -24,6 +24,7 @@
 // 4 independent 32x32x2 fp32 MFMA chains; the keep-bits of the fused input dropout ride the ring as their own 512-byte tile;
 // the bias gradient is accumulated from the A fragments on the VALU in the MFMAs' shadow.
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <type_traits>
@@ -44,8 +45,6 @@ constexpr int A_CH = A_BYTES / 1024, B_CH = B_BYTES / 1024;   // 1-KiB pieces = 
 constexpr int NI = (A_CH + B_CH) / NW;                         // data pieces per wave per stage
 constexpr int BITS_CH = BITS_BYTES / 256;
 constexpr int STAGE_BYTES = A_BYTES + B_BYTES + BITS_BYTES;
-constexpr int NST = 4;
-constexpr int LDS_BYTES = NST * STAGE_BYTES;
 constexpr int SLOT_FLOATS = BM * BN + BM;                      // a partial tile in register order + its column sums of A
 static_assert((A_CH + B_CH) % NW == 0 && A_CH % NW == 0, "pieces divide evenly over the waves");
 static_assert(NI == 3, "issue() below is written for 2 A rows + 1 B piece per wave");
@@ -60,6 +59,7 @@ struct Launch {
                              // (which read the same rows of A) are neighbours on the line.  1 = plain (tile, k) order
   int32_t n;
   int32_t nwg;
+  int32_t stagger;
   float* slab;
 };
 
@@ -110,7 +110,14 @@ __device__ __forceinline__ Where locate(const Launch& L, int x) {
   return w;
 }
 
-__global__ __launch_bounds__(NTHR, 2) void gg_tn_kernel(const Launch L) {
+// what a wave holds of one MFMA group (8 k) of a k-tile: element s of a fragment is k = 8 gq + 4 lh + s
+struct Frag {
+  f32x4 a[TM], b[TN];
+  uint32_t mb[4];         // keep-bits bytes of the B fragment (masked problems)
+};
+
+template <int NST, int OCC, int DBG = 0>
+__global__ __launch_bounds__(NTHR, OCC) void gg_tn_kernel(const Launch L) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -121,158 +128,77 @@ __global__ __launch_bounds__(NTHR, 2) void gg_tn_kernel(const Launch L) {
   const int wg = blockIdx.x;
   int x = range_begin(wg, LL, L.nwg);
   const int x_end = range_begin(wg + 1, LL, L.nwg);
+  constexpr int PER = NI + 1;      // vector-memory operations per wave per stage: 2 A rows, 1 B piece, 1 keep-bits piece (issued
+                                   // for unmasked problems too, against an empty descriptor: the vmcnt bookkeeping stays one)
+  static_assert(NST >= 3 && BK == 16, "the loop below is written for two MFMA groups per k-tile");
 
   f32x16 acc[TM][TN];
   float csum[TM];
+  unsigned long long stamps[12];
+  int nstamp = 0;
+  auto stamp = [&]() {
+    if constexpr (DBG == 5) {
+      if (nstamp < 12) {
+        stamps[nstamp] = (nstamp & 1) ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime();
+        ++nstamp;
+      }
+    }
+  };
+  stamp();
+  stamp();
 
-  // ---- state of the current K-segment (set by seg_begin) ----
-  __amdgpu_buffer_rsrc_t ra, rb, rbits;
-  uint32_t voff[NI], bvoff = 0;
-  int srck[NI];
-  int segK = 0, seg_mod = 0, seg_lda = 0, seg_ldb = 0, seg_qw = 0;
-  float mscale = 1.f;
-
-  // sub-piece = rows [kbeg, kend) of one K-segment of problem pr for the tile at (m0, n0)
-  auto run_ring = [&](const sdumc_gg_problem& pr, int seg, int m0, int n0, int kbeg, int kend, auto mask_c) {
+  // Fragment reads.  The operands lie [k][row] in LDS, so a lane's four k values of one 32-row MFMA tile are four ds_read_b32 a
+  // KiB apart.  Reading 8 bytes instead gives the lane rows 2 li and 2 li + 1: the wave's two MFMA tiles along M (and along N)
+  // take the EVEN and the ODD rows of its 64-row block instead of the lower and the upper half -- half the LDS instructions
+  // and LDS cycles, conflict-free (a lane group covers 256 contiguous bytes).  The permutation is undone where the accumulators
+  // leave the registers: row (i, r) of the block is 2 r + i, column (j, c) is 2 c + j.
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  auto read_frag = [&](const char* base, int gq, Frag& f, auto mask_c) {
     constexpr bool MASK = decltype(mask_c)::value;
-    constexpr int PER = NI + (MASK ? 1 : 0);
-    segK = pr.K[seg];
-    seg_mod = pr.b_row_mod[seg];
-    seg_lda = pr.lda;
-    seg_ldb = pr.ldb;
-    seg_qw = pr.bits_qw;
-    mscale = pr.b_scale;
-    const int b_rows = seg_mod > 0 ? seg_mod : segK;
-    ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.A[seg]), 0, (int)min((size_t)segK * seg_lda * 4, (size_t)0xFFFFFFF0u), 0x00020000);
-    rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.B[seg]), 0, (int)min((size_t)b_rows * seg_ldb * 4, (size_t)0xFFFFFFF0u), 0x00020000);
-    rbits = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(MASK ? pr.b_bits[seg] : (const uint8_t*)pr.A[seg]), 0,
-                                              MASK ? (int)min((size_t)segK * seg_qw, (size_t)0xFFFFFFF0u) : 0, 0x00020000);
-    // pieces of this wave: A k-rows `wave` and `wave + 8` (64 lanes x 4 columns = the 256 columns of the tile), B piece `wave`
-    // = k-rows 2 wave, 2 wave + 1 (32 lanes x 4 columns each)
+    const float* As = reinterpret_cast<const float*>(base) + (8 * gq + 4 * lh) * BM + wm0 + 2 * li;
+    const float* Bs = reinterpret_cast<const float*>(base + A_BYTES) + (8 * gq + 4 * lh) * BN + wn0 + 2 * li;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int col = min(m0 + 4 * lane, pr.M - 4);
-      srck[i] = min(kbeg + wave + 8 * i, segK - 1);
-      voff[i] = ((uint32_t)srck[i] * (uint32_t)seg_lda + (uint32_t)col) * 4u;
+    for (int s = 0; s < 4; ++s) {
+      const f32x2 va = *reinterpret_cast<const f32x2*>(As + s * BM);
+      const f32x2 vb = *reinterpret_cast<const f32x2*>(Bs + s * BN);
+      f.a[0][s] = va[0];
+      f.a[1][s] = va[1];
+      f.b[0][s] = vb[0];
+      f.b[1][s] = vb[1];
     }
-    {
-      const int col = min(n0 + 4 * (lane & 31), pr.N - 4);
-      int kr = min(kbeg + 2 * wave + (lane >> 5), segK - 1);
-      if (seg_mod > 0) kr %= seg_mod;
-      srck[2] = kr;
-      voff[2] = ((uint32_t)kr * (uint32_t)seg_ldb + (uint32_t)col) * 4u;
+    if constexpr (MASK) {   // columns 2 li, 2 li + 1 share one keep-bits byte (bits 2 (li & 1) and 2 (li & 1) + 1)
+      const uint8_t* bt = reinterpret_cast<const uint8_t*>(base + A_BYTES + B_BYTES) + (8 * gq + 4 * lh) * (BN / 4) + ((wn0 + 2 * li) >> 2);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) f.mb[s] = bt[s * (BN / 4)];
     }
+  };
+  // the 16 MFMAs of one group (+ the keep-bits applied to the B fragment, + the column sums of A on the VALU)
+  auto mma = [&](Frag& f, float mscale, auto mask_c) {
+    constexpr bool MASK = decltype(mask_c)::value;
     if constexpr (MASK) {
-      const int idx = ((wave % BITS_CH) << 6) + lane;         // dword index inside the [16][8 dwords] bits tile
-      const int krow = idx >> 3, dw = idx & 7;
-      bvoff = (uint32_t)min(kbeg + krow, segK - 1) * (uint32_t)seg_qw + (uint32_t)(n0 >> 2) + 4u * dw;
+      const uint32_t bit0 = 1u << (2 * (li & 1));
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        f.b[0][s] *= (f.mb[s] & bit0) ? mscale : 0.f;
+        f.b[1][s] *= (f.mb[s] & (bit0 << 1)) ? mscale : 0.f;
+      }
     }
-    auto issue = [&](int buf) {
-      char* base = lds + buf * STAGE_BYTES;
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(base + (wave + 8 * i) * 1024), 16, voff[i], 0, 0, 0);
-        const int nxt = min(srck[i] + BK, segK - 1);     // beyond the last row: stay on it (the tail iteration zeroes it)
-        voff[i] += (uint32_t)(nxt - srck[i]) * (uint32_t)seg_lda * 4u;
-        srck[i] = nxt;
-      }
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(base + A_BYTES + wave * 1024), 16, voff[2], 0, 0, 0);
-      if (seg_mod > 0) {
-        int nxt = srck[2] + BK;
-        voff[2] += (uint32_t)BK * (uint32_t)seg_ldb * 4u;
-        if (nxt >= seg_mod) { nxt -= seg_mod; voff[2] -= (uint32_t)seg_mod * (uint32_t)seg_ldb * 4u; }
-        srck[2] = nxt;
-      } else {
-        const int nxt = min(srck[2] + BK, segK - 1);
-        voff[2] += (uint32_t)(nxt - srck[2]) * (uint32_t)seg_ldb * 4u;
-        srck[2] = nxt;
-      }
-      if constexpr (MASK) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbits, (lds_void_t*)(base + A_BYTES + B_BYTES + (wave % BITS_CH) * 256), 4, bvoff, 0, 0, 0);
-        bvoff += (uint32_t)BK * (uint32_t)seg_qw;      // (rows beyond K read in-range bytes or 0: masked out by the tail anyway)
-      }
-    };
-    // fragments of MFMA group gq (8 k): element s of a fragment is k = 8 gq + 4 lh + s
-    auto read_a = [&](const char* base, int gq, f32x4 (&af)[TM]) {
-      const float* As = reinterpret_cast<const float*>(base);
+    for (int s = 0; s < 4; ++s) {
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        const float* q = As + (8 * gq + 4 * lh) * BM + wm0 + 32 * i + li;
-        af[i][0] = q[0];
-        af[i][1] = q[BM];
-        af[i][2] = q[2 * BM];
-        af[i][3] = q[3 * BM];
-      }
-    };
-    auto read_b = [&](const char* base, int gq, f32x4 (&bf)[TN]) {
-      const float* Bs = reinterpret_cast<const float*>(base + A_BYTES);
+      for (int i = 0; i < TM; ++i) csum[i] += f.a[i][s];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int row = wn0 + 32 * j + li;
-        const float* q = Bs + (8 * gq + 4 * lh) * BN + row;
-        bf[j][0] = q[0];
-        bf[j][1] = q[BN];
-        bf[j][2] = q[2 * BN];
-        bf[j][3] = q[3 * BN];
-        if constexpr (MASK) {
-          const uint8_t* bt = reinterpret_cast<const uint8_t*>(base + A_BYTES + B_BYTES) + (8 * gq + 4 * lh) * (BN / 4) + (row >> 2);
-          const uint32_t bit = 1u << (row & 3);
+      for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int s = 0; s < 4; ++s) bf[j][s] *= (bt[s * (BN / 4)] & bit) ? mscale : 0.f;
-        }
-      }
-    };
-    auto compute = [&](const char* base, int k0, auto tail_c) {
-      constexpr bool TAIL = decltype(tail_c)::value;
-      f32x4 af[2][TM], bf[2][TN];
-      read_a(base, 0, af[0]);
-      read_b(base, 0, bf[0]);
-#pragma unroll
-      for (int gq = 0; gq < BK / 8; ++gq) {
-        const int cur = gq & 1, nxt = cur ^ 1;
-        if (gq + 1 < BK / 8) {
-          read_a(base, gq + 1, af[nxt]);
-          read_b(base, gq + 1, bf[nxt]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          if constexpr (TAIL) {
-            const bool live = k0 + 8 * gq + 4 * lh + s < kend;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[cur][i][s] = live ? af[cur][i][s] : 0.f;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[cur][j][s] = live ? bf[cur][j][s] : 0.f;
-          }
-#pragma unroll
-          for (int i = 0; i < TM; ++i) csum[i] += af[cur][i][s];
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[cur][i][s], bf[cur][j][s], acc[i][j], 0, 0, 0);
-        }
-      }
-    };
-    const int nk = (kend - kbeg + BK - 1) / BK;
-#pragma unroll
-    for (int s = 0; s < NST - 1; ++s)
-      if (s < nk) issue(s);
-    int buf = 0, ibuf = NST - 1;
-    for (int t = 0; t < nk; ++t) {
-      const int ahead = nk - 1 - t;        // stages issued beyond the one multiplied now (capped by the ring)
-      if (ahead >= NST - 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm((NST - 2) * PER));
-      else if (ahead == 1 && NST > 3) __builtin_amdgcn_s_waitcnt(waitcnt_vm(PER));
-      else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
-      __builtin_amdgcn_s_barrier();
-      if (t + NST - 1 < nk) issue(ibuf);
-      const int k0 = kbeg + t * BK;
-      if (k0 + BK > kend) compute(lds + buf * STAGE_BYTES, k0, std::true_type{});
-      else compute(lds + buf * STAGE_BYTES, k0, std::false_type{});
-      buf = buf + 1 == NST ? 0 : buf + 1;
-      ibuf = ibuf + 1 == NST ? 0 : ibuf + 1;
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[i][s], f.b[j][s], acc[i][j], 0, 0, 0);
     }
-    __builtin_amdgcn_s_barrier();          // every wave is done reading the ring before the next sub-piece refills it
+  };
+  // all but the `stages` youngest stages of this wave's LDS-DMA have landed
+  auto wait_stages = [&](int stages) {
+    if (stages >= 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm(2 * PER));
+    else if (stages == 1) __builtin_amdgcn_s_waitcnt(waitcnt_vm(PER));
+    else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
   };
 
   while (x < x_end) {
@@ -291,33 +217,134 @@ __global__ __launch_bounds__(NTHR, 2) void gg_tn_kernel(const Launch L) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     }
-    if (ka < g.nk0) {
-      const int kbeg = ka * BK, kend = min(min(kb, g.nk0) * BK, pr.K[0]);
-      if (pr.b_bits[0]) run_ring(pr, 0, m0, n0, kbeg, kend, std::true_type{});
-      else run_ring(pr, 0, m0, n0, kbeg, kend, std::false_type{});
-    }
-    if (kb > g.nk0) {
-      const int kbeg = (max(ka, g.nk0) - g.nk0) * BK, kend = min((kb - g.nk0) * BK, pr.K[1]);
-      if (pr.b_bits[1]) run_ring(pr, 1, m0, n0, kbeg, kend, std::true_type{});
-      else run_ring(pr, 1, m0, n0, kbeg, kend, std::false_type{});
+#pragma nounroll
+    for (int seg = 0; seg < 2; ++seg) {
+      // k-tiles [t0, t0 + nk) of K-segment `seg`
+      int t0, nk;
+      if (seg == 0) {
+        if (ka >= g.nk0) continue;
+        t0 = ka;
+        nk = min(kb, g.nk0) - ka;
+      } else {
+        if (kb <= g.nk0) continue;
+        t0 = max(ka, g.nk0) - g.nk0;
+        nk = kb - g.nk0 - t0;
+      }
+      const int kbeg = t0 * BK;
+      const int segK = pr.K[seg], seg_mod = pr.b_row_mod[seg];
+      const uint32_t lda4 = (uint32_t)pr.lda * 4u, ldb4 = (uint32_t)pr.ldb * 4u, qw = (uint32_t)pr.bits_qw;
+      const bool masked = pr.b_bits[seg] != nullptr;
+      const float mscale = pr.b_scale;
+      // Rows at and beyond K are outside the descriptors' ranges: the hardware returns zeros for them, so a ragged last k-tile
+      // needs no special case (with a row modulo B stays in range there, against zeros of A).
+      const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.A[seg]), 0, (int)((uint32_t)segK * lda4), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.B[seg]), 0, (int)((uint32_t)(seg_mod > 0 ? seg_mod : segK) * ldb4), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rbits = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(masked ? pr.b_bits[seg] : (const uint8_t*)pr.A[seg]), 0,
+                                                                             masked ? (int)((uint32_t)segK * qw) : 0, 0x00020000);
+      // pieces of this wave: A k-rows `wave` and `wave + 8` (64 lanes x 4 columns = the 256 columns of the tile), B piece `wave`
+      // = k-rows 2 wave, 2 wave + 1 (32 lanes x 4 columns each), keep-bits piece wave % 2
+      uint32_t voff[NI], bvoff;
+      int srck = 0;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) voff[i] = (uint32_t)(kbeg + wave + 8 * i) * lda4 + (uint32_t)min(m0 + 4 * lane, pr.M - 4) * 4u;
+      {
+        int kr = kbeg + 2 * wave + (lane >> 5);
+        if (seg_mod > 0) kr %= seg_mod;
+        srck = kr;
+        voff[2] = (uint32_t)kr * ldb4 + (uint32_t)min(n0 + 4 * (lane & 31), pr.N - 4) * 4u;
+      }
+      {
+        const int idx = ((wave % BITS_CH) << 6) + lane;         // dword index inside the [16][8 dwords] bits tile
+        bvoff = (uint32_t)(kbeg + (idx >> 3)) * qw + (uint32_t)(n0 >> 2) + 4u * (idx & 7);
+      }
+      auto issue = [&](int buf) {
+        char* base = lds + buf * STAGE_BYTES;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(base + wave * 1024), 16, voff[0], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(base + (wave + 8) * 1024), 16, voff[1], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(base + A_BYTES + wave * 1024), 16, voff[2], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbits, (lds_void_t*)(base + A_BYTES + B_BYTES + (wave % BITS_CH) * 256), 4, bvoff, 0, 0, 0);
+        voff[0] += (uint32_t)BK * lda4;
+        voff[1] += (uint32_t)BK * lda4;
+        voff[2] += (uint32_t)BK * ldb4;
+        bvoff += (uint32_t)BK * qw;
+        if (seg_mod > 0) {
+          srck += BK;
+          if (srck >= seg_mod) { srck -= seg_mod; voff[2] -= (uint32_t)seg_mod * ldb4; }
+        }
+      };
+      // Software pipeline over the k-tiles of the sub-piece.  A k-tile is two MFMA groups g0, g1 of 16 MFMAs.  While g0 of tile
+      // t multiplies, the fragments of g1 are read; then -- in the MIDDLE of the tile, with the matrix pipe still draining g0 --
+      // the wave waits for its own pieces of stage t + 1, meets the others at the barrier, issues the LDS-DMA of stage
+      // t + NST - 1 and reads the g0 fragments of tile t + 1, all under the 16 MFMAs of g1.  So the barrier, the DMA issue (60-180
+      // cycles per instruction) and the LDS latency of the next tile's first fragments are covered by matrix work of the same
+      // wave, not exposed at the head of every tile with all eight waves in lock-step.
+      // Stagger: the two waves of a SIMD (waves w and w + 4) run the same program, and with one barrier per k-tile they would
+      // stay in lock-step -- both at the barrier, both issuing DMA, both waiting on LDS at the same moments, the SIMD's matrix
+      // pipe idle meanwhile.  Waves 4-7 therefore take the barrier at the HEAD of the tile instead of in its middle: they wait
+      // there for waves 0-3 (which arrive after their g0) and from then on run half a k-tile behind, so that whenever one wave of
+      // a SIMD sits at a barrier or issues its DMA the other one is in the middle of 16 MFMAs.  Same barriers, same data
+      // hazards: barrier t guarantees stage t + 1 landed and stage t - 1 free for every wave, whichever half arrives first.
+      const bool late = L.stagger && wave >= NW / 2;
+      auto ring = [&](auto mask_c) {
+        Frag f0, f1;
+#pragma unroll
+        for (int s = 0; s < NST - 1; ++s)
+          if (s < nk) issue(s);
+        wait_stages(min(nk, NST - 1) - 1);
+        __builtin_amdgcn_s_barrier();
+        stamp();
+        stamp();
+        read_frag(lds, 0, f0, mask_c);
+        int buf = 0, nbuf = 1, ibuf = NST - 1;
+#pragma nounroll
+        for (int t = 0; t < nk; ++t) {
+          if (late && t + 1 < nk) {
+            wait_stages(min(nk - t - 2, NST - 3));
+            __builtin_amdgcn_s_barrier();
+            if (t + NST - 1 < nk) issue(ibuf);
+          }
+          read_frag(lds + buf * STAGE_BYTES, 1, f1, mask_c);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(f0, mscale, mask_c);
+          __builtin_amdgcn_sched_barrier(0);
+          if (!late && t + 1 < nk) {
+            wait_stages(min(nk - t - 2, NST - 3));
+            __builtin_amdgcn_s_barrier();
+            if (t + NST - 1 < nk) issue(ibuf);
+          }
+          if (t + 1 < nk) read_frag(lds + nbuf * STAGE_BYTES, 0, f0, mask_c);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(f1, mscale, mask_c);
+          __builtin_amdgcn_sched_barrier(0);
+          buf = nbuf;
+          nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
+          ibuf = ibuf + 1 == NST ? 0 : ibuf + 1;
+        }
+      };
+      if (masked) ring(std::true_type{});
+      else ring(std::false_type{});
+      __builtin_amdgcn_s_barrier();          // every wave is done reading the ring before the next sub-piece refills it
     }
     const bool direct = L.nchunk[w.p] == 1 && ka == 0 && kb == g.nk;
     const bool do_cs = pr.colsum_a != nullptr && tile_n == 0 && wn0 == 0;
+    stamp();
+    stamp();
     if (direct) {
       // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+      const bool accum = pr.accumulate != 0;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
-          const int col = n0 + wn0 + 32 * j + li;
+          const int col = n0 + wn0 + 2 * li + j;
           if (col >= pr.N) continue;
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            const int row = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            const int row = m0 + wm0 + 2 * ((e & 3) + 8 * (e >> 2) + 4 * lh) + i;
             if (row >= pr.M) continue;
-            float* dst = pr.C + (size_t)row * pr.ldc + col;
+            float* dst = pr.C + ((uint32_t)row * (uint32_t)pr.ldc + (uint32_t)col);
             float v = acc[i][j][e];
-            if (pr.accumulate) v += *dst;
+            if (accum) v += *dst;
             *dst = v;
           }
         }
@@ -325,16 +352,17 @@ __global__ __launch_bounds__(NTHR, 2) void gg_tn_kernel(const Launch L) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const float v = csum[i] + __shfl_xor(csum[i], 32, 64);
-          const int m = m0 + wm0 + 32 * i + li;
+          const int m = m0 + wm0 + 2 * li + i;
           if (lh == 0 && m < pr.M) {
             float* dst = pr.colsum_a + m;
-            *dst = pr.accumulate ? *dst + v : v;
+            *dst = accum ? *dst + v : v;
           }
         }
       }
     } else {
       // slab slot in register order: [wave][i][j][e / 4][lane][4] -- every store instruction of a wave is 1 KiB contiguous
       float* slot = L.slab + (size_t)(wg + w.unit) * SLOT_FLOATS;
+      float* mine = slot + (uint32_t)(wave * 16 * 64 + lane) * 4u;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -342,17 +370,24 @@ __global__ __launch_bounds__(NTHR, 2) void gg_tn_kernel(const Launch L) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-            *reinterpret_cast<f32x4*>(slot + ((size_t)((wave * 16 + (i * TN + j) * 4 + q) * 64 + lane)) * 4) = v;
+            *reinterpret_cast<f32x4*>(mine + ((i * TN + j) * 4 + q) * 256) = v;
           }
       if (do_cs) {
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const float v = csum[i] + __shfl_xor(csum[i], 32, 64);
-          if (lh == 0) slot[BM * BN + wm0 + 32 * i + li] = v;
+          if (lh == 0) slot[BM * BN + wm0 + 2 * li + i] = v;
         }
       }
     }
     x = px_end;
+  }
+  if constexpr (DBG == 5) {
+    __builtin_amdgcn_s_waitcnt(0);
+    if (tid == 0) {
+      unsigned long long* out = reinterpret_cast<unsigned long long*>(L.slab + (size_t)(L.nwg + L.unit0[L.n]) * SLOT_FLOATS) + wg * 12;
+      for (int i = 0; i < 12; ++i) out[i] = i < nstamp ? stamps[i] : 0ull;
+    }
   }
 #endif
 }
@@ -404,11 +439,11 @@ __global__ __launch_bounds__(NTHR) void gg_reduce_kernel(const Launch L, const i
   }
   const int li = lane & 31, lh = lane >> 5;
   const int ij = part >> 2, q = part & 3, i = ij / TN, j = ij - i * TN;
-  const int col = n0 + (wave % WGN) * WN + 32 * j + li;
+  const int col = n0 + (wave % WGN) * WN + 2 * li + j;
   if (col >= pr.N) return;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const int row = m0 + (wave / WGN) * WM + 32 * i + e + 8 * q + 4 * lh;
+    const int row = m0 + (wave / WGN) * WM + 2 * (e + 8 * q + 4 * lh) + i;
     if (row >= pr.M) continue;
     float* dst = pr.C + (size_t)row * pr.ldc + col;
     *dst = pr.accumulate ? *dst + s[e] : s[e];
@@ -429,6 +464,16 @@ int cu_count() {
   return per_device[dev];
 }
 
+int wg_per_cu() {   // development knob (SDUMC_GG_PER_CU=2): two workgroups per CU on a 3-stage ring
+  static const int v = [] { const char* e = getenv("SDUMC_GG_PER_CU"); return e && atoi(e) == 2 ? 2 : 1; }();
+  return v;
+}
+
+int dbg_mode() {
+  static const int v = [] { const char* e = getenv("SDUMC_GG_DBG"); return e ? atoi(e) : 0; }();
+  return v;
+}
+
 bool set_lds_attr() {   // the dynamic-LDS limit is a per-device function attribute
   static std::mutex mu;
   static bool done[64] = {};
@@ -436,7 +481,10 @@ bool set_lds_attr() {   // the dynamic-LDS limit is a per-device function attrib
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
   std::lock_guard<std::mutex> lock(mu);
   if (!done[dev]) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_tn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_tn_kernel<5, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * STAGE_BYTES) != hipSuccess)
+      return false;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_tn_kernel<5, 2, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * STAGE_BYTES);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_tn_kernel<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE_BYTES) != hipSuccess)
       return false;
     done[dev] = true;
   }
@@ -454,8 +502,10 @@ bool valid(const sdumc_gg_problem& p) {
     if (p.b_bits[s] && ((reinterpret_cast<uintptr_t>(p.b_bits[s]) & 3) || (p.bits_qw & 3) || p.bits_qw * 4 < p.N)) return false;
     if (p.b_row_mod[s] < 0 || (p.b_row_mod[s] > 0 && p.b_row_mod[s] < BK)) return false;
     const size_t brows = p.b_row_mod[s] > 0 ? (size_t)p.b_row_mod[s] : (size_t)p.K[s];
-    if ((size_t)p.K[s] * p.lda * 4 >= 0xFFFFFFF0u || brows * p.ldb * 4 >= 0xFFFFFFF0u) return false;
-    if (p.b_bits[s] && (size_t)p.K[s] * p.bits_qw >= 0xFFFFFFF0u) return false;
+    // (32-bit byte offsets that run up to a ring of k-tiles past the last row; descriptor ranges below 2 GiB)
+    const size_t pad = 8 * BK;
+    if (((size_t)p.K[s] + pad) * p.lda * 4 >= 0x7FFFFFF0u || (brows + pad) * p.ldb * 4 >= 0x7FFFFFF0u) return false;
+    if (p.b_bits[s] && ((size_t)p.K[s] + pad) * p.bits_qw >= 0x7FFFFFF0u) return false;
   }
   return true;
 }
@@ -485,16 +535,23 @@ int plan(const sdumc_gg_problem* probs, int n, int nwg_max, Launch& L, int& unit
 }  // namespace sdumc_gg
 using namespace sdumc_gg;
 
+// engine.hip: slab bytes that cover any problem list with at most `tiles` output tiles (256 x 128) on the current device; also
+// the place where the kernels' per-device attributes are set outside any stream capture
+extern "C" size_t sdumc_gg_slab_bytes_(int tiles) {
+  (void)set_lds_attr();
+  return (size_t)(cu_count() * wg_per_cu() + tiles) * SLOT_FLOATS * sizeof(float);
+}
+
 extern "C" size_t sdumc_gemm_group_workspace_bytes(const sdumc_gg_problem* probs, int32_t n) {
   if (!probs || n <= 0) return 0;
-  const int nwg = cu_count();
+  const int nwg = cu_count() * wg_per_cu();
   size_t need = 0;
   for (int first = 0; first < n; first += MAXP) {
     const int cnt = std::min(MAXP, n - first);
     Launch L;
     int units = 0;
     plan(probs + first, cnt, nwg, L, units);
-    need = std::max(need, (size_t)(L.nwg + units) * SLOT_FLOATS * sizeof(float));
+    need = std::max(need, (size_t)(L.nwg + units) * SLOT_FLOATS * sizeof(float) + (dbg_mode() == 5 ? (size_t)L.nwg * 96 : 0));
   }
   return need;
 }
@@ -505,7 +562,8 @@ extern "C" int sdumc_gemm_group_tn(const sdumc_gg_problem* probs, int32_t n, voi
     if (!valid(probs[i])) return SDUMC_EINVAL;
   if (workspace_bytes < sdumc_gemm_group_workspace_bytes(probs, n)) return SDUMC_ENOMEM;
   if (!set_lds_attr()) return SDUMC_ELAUNCH;
-  const int nwg = cu_count();
+  const int per_cu = wg_per_cu();
+  const int nwg = cu_count() * per_cu;
   hipStream_t st = as_stream(stream);
   for (int first = 0; first < n; first += MAXP) {
     const int cnt = std::min(MAXP, n - first);
@@ -514,7 +572,11 @@ extern "C" int sdumc_gemm_group_tn(const sdumc_gg_problem* probs, int32_t n, voi
     const int tiles = plan(probs + first, cnt, nwg, L, units);
     if ((long long)L.line0[cnt] * (L.nwg + 1) >= (1LL << 31)) return SDUMC_EINVAL;   // 32-bit index arithmetic in the kernels
     L.slab = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(gg_tn_kernel, dim3(L.nwg), dim3(NTHR), LDS_BYTES, st, L);
+    static const int stag = [] { const char* e = getenv("SDUMC_GG_STAGGER"); return e ? atoi(e) : 1; }();
+    L.stagger = stag;
+    if (per_cu == 2) hipLaunchKernelGGL((gg_tn_kernel<3, 4>), dim3(L.nwg), dim3(NTHR), 3 * STAGE_BYTES, st, L);
+    else if (dbg_mode() == 5) hipLaunchKernelGGL((gg_tn_kernel<5, 2, 5>), dim3(L.nwg), dim3(NTHR), 5 * STAGE_BYTES, st, L);
+    else hipLaunchKernelGGL((gg_tn_kernel<5, 2>), dim3(L.nwg), dim3(NTHR), 5 * STAGE_BYTES, st, L);
     SDUMC_CHECK_LAUNCH();
     hipLaunchKernelGGL(gg_reduce_kernel, dim3(tiles, 17), dim3(NTHR), 0, st, L, tiles);
     SDUMC_CHECK_LAUNCH();

@@ -60,7 +60,8 @@ def test_two_simulated_ranks_equal_full_batch():
 
 
 def test_backward_phases_equal_one_call_and_early_slice_is_final():
-    """sdumc_net_backward_phase(0) + (1) == sdumc_net_backward, bit for bit, and after phase 0 alone the slice
+    """sdumc_net_backward_phase(0) + (1) == sdumc_net_backward (to rounding: the grouped weight-gradient launches cut K at
+    points that depend on what else rides in the launch, so the two differ in the last bits), and after phase 0 alone the slice
     [0, layout.early) -- what the data-parallel step all-reduces while phase 1 runs -- already holds its final
     values.  The early/late split is by layer: utterance-level first, frame-level (input_proj, context vectors,
     frame_dim_reshape) last."""
@@ -99,11 +100,11 @@ def test_backward_phases_equal_one_call_and_early_slice_is_final():
             early = be.backward_phase(0)
             torch.cuda.synchronize()
             assert early.numel() == lay.early and torch.isfinite(early.cpu()[used[:lay.early]]).all()
-            # phase 1 has not run: the late slice is untouched, except the audio Cross_Attention input_proj gradients, whose
-            # GEMMs the engine issues early on the audio lane (they run beside whatever follows phase 0)
+            # phase 1 has not run: the late slice is untouched, except the Cross_Attention input_proj gradients, whose
+            # products need nothing from phase 1 and leave with phase 0's weight-gradient launch
             pending = used.clone()
             for n in lay.live_names():
-                if n.startswith("cross_att_fra2utt_0.input_proj."):
+                if n.startswith("cross_att_fra2utt_") and ".input_proj." in n:
                     off, shape, _ = lay.entries[n]
                     pending[off:off + int(np.prod(shape))] = False
             assert not torch.isfinite(be.grads.cpu()[lay.early:][pending[lay.early:]]).any()
@@ -115,7 +116,8 @@ def test_backward_phases_equal_one_call_and_early_slice_is_final():
             be.backward()
         torch.cuda.synchronize()
         res.append(be.grads.clone())
-    assert torch.equal(res[0].cpu()[used], res[1].cpu()[used])
+    a, b = res[0].cpu()[used].double(), res[1].cpu()[used].double()
+    assert torch.isfinite(a).all() and float((a - b).abs().max()) <= 2e-6 * float(a.abs().max())
 
 
 _RCCL_ONE_RANK = r"""

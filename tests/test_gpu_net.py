@@ -208,6 +208,8 @@ def test_graph_replay_equals_eager_and_advances_state(E):
     res = []
     from sdumc_amd import _lib
     _lib.lib.sdumc_set_chain_cluster(0)      # a capture takes chain.hip's kernels: compare like with like
+    _lib.lib.sdumc_set_background_lane(0)    # ... and no early key-projection backward (which decides what rides in which
+                                             # grouped weight-gradient launch, i.e. where their K ranges are cut)
     for use_graph in (False, True):
         flat, lay = flat_from(E, P, dims)
         ts = E.TrainStep(flat, B, Tn, dims, seed=5)
@@ -220,6 +222,7 @@ def test_graph_replay_equals_eager_and_advances_state(E):
         torch.cuda.synchronize()
         res.append((flat.cpu().clone(), ls, ts.rng.call, float(ts.hyper[1])))
     _lib.lib.sdumc_set_chain_cluster(1)
+    _lib.lib.sdumc_set_background_lane(3)
     assert torch.equal(res[0][0], res[1][0]), "graph replay must equal eager launches bit for bit"
     for a, b in zip(res[0][1], res[1][1]):
         assert torch.equal(a, b)

@@ -8,6 +8,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sdumc_amd import ops  # noqa: E402
 
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+legs = sys.argv[2].split(",") if len(sys.argv) > 2 else None
+only_new = len(sys.argv) > 3 and sys.argv[3] == "new"
 B, Ta, Tt, Tv, D = 64, 375, 32, 225, 256
 dev = "cuda"
 g = torch.Generator(device=dev).manual_seed(1)
@@ -22,9 +24,12 @@ def bits(K, N):
 
 
 def timeit(fn, reps):
-    for _ in range(3):
-        fn()
-    torch.cuda.synchronize()
+    import time
+    t0 = time.time()
+    while time.time() - t0 < 0.4:      # clocks ramp up under load: warm up for 0.4 s of back-to-back launches
+        for _ in range(20):
+            fn()
+        torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(reps):
@@ -95,24 +100,34 @@ def old_path(ps):
                      accumulate=True)
 
 
-def run(name, ps):
-    for q in ps:
-        q.pop("C", None)
+def run(name, mk):
+    if legs is not None and name.split()[0] not in legs:
+        return
+    ps = mk()
     f = flops(ps)
+    if only_new:
+        t_new = timeit(lambda: ops.gemm_group_tn(ps), reps)
+        print(f"{name:28s} {f / 1e9:7.2f} GF  grouped {t_new:8.1f} us = {f / t_new / 1e6:6.1f} TF", flush=True)
+        return
     t_old = timeit(lambda: old_path(ps), reps)
     c_old = [q["C"].clone() for q in ps]
     for q in ps:
         q.pop("C", None)
-    import ctypes as C
     t_new = timeit(lambda: ops.gemm_group_tn(ps), reps)
     err = max(float((q["C"] - c).abs().max() / c.abs().max()) for q, c in zip(ps, c_old))
     print(f"{name:28s} {f / 1e9:7.2f} GF  per-layer {t_old:8.1f} us = {f / t_old / 1e6:6.1f} TF   grouped {t_new:8.1f} us = "
           f"{f / t_new / 1e6:6.1f} TF   max rel diff {err:.1e}", flush=True)
 
 
-run("frame dW (G2)", frame_problems())
-run("frame dW audio only", frame_problems()[:1])
-run("key dW, 6 sites (masked)", key_problems())
-run("key dW CA sites + utt", key_problems((1,)) + utt_problems()[:12])
-run("utterance-level dW", utt_problems())
-run("everything", frame_problems() + key_problems() + utt_problems())
+run("p1 K=24000 N=1024", lambda: [{"A": rn(24000, 256), "B": rn(24000, 1024)}])
+run("z1 zeros K=24000 N=1024", lambda: [{"A": torch.zeros(24000, 256, device=dev), "B": torch.zeros(24000, 1024, device=dev)}])
+run("o1 ones K=24000 N=1024", lambda: [{"A": torch.ones(24000, 256, device=dev), "B": torch.ones(24000, 1024, device=dev)}])
+run("p2 K=3000 N=8192", lambda: [{"A": rn(3000, 256), "B": rn(3000, 8192)}])
+run("p3 K=750 N=32768", lambda: [{"A": rn(750, 256), "B": rn(750, 32768)}])
+run("p4 K=24000 N=1024 Bmod=512", lambda: [{"A": rn(24000, 256), "B": rn(512, 1024), "b_row_mod": 512}])
+run("frame dW (G2)", frame_problems)
+run("audio frame dW only", lambda: frame_problems()[:1])
+run("key dW, 6 sites (masked)", key_problems)
+run("keyca dW CA sites + utt", lambda: key_problems((1,)) + utt_problems()[:12])
+run("utt utterance-level dW", utt_problems)
+run("all = frame + key + utt", lambda: frame_problems() + key_problems() + utt_problems())
