@@ -164,7 +164,7 @@ int sdumc_gemm_bf16_run(const sdumc_gemm_bf16* g, void* stream);
  * (bit-identical from run to run).  Constraints: M, N, lda, ldb multiples of 4; pointers 16-byte aligned; every operand
  * below 4 GiB; M <= 256 * 255.
  * ---------------------------------------------------------------------- */
-#define SDUMC_GG_MAX_PROBLEMS 24   /* per launch pair; longer lists are cut into several */
+#define SDUMC_GG_MAX_PROBLEMS 40   /* per launch pair; longer lists are cut into several */
 typedef struct sdumc_gg_problem {
   const float* A[2];        /* [K_s, M] with lda: the gradient w.r.t. the layer's pre-activation (segment 1 unused when K[1] == 0) */
   const float* B[2];        /* [K_s, N] with ldb: the layer's saved input */

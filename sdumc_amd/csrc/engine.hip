@@ -430,7 +430,9 @@ bool create_lanes(LaneSet& S) {
     if (hipStreamCreateWithPriority(&S.s[i], hipStreamNonBlocking, lane_prio[i]) != hipSuccess) return false;
   for (unsigned i = 0; i < LaneSet::NEV; ++i)
     if (hipEventCreateWithFlags(&S.ev[i], hipEventDisableTiming) != hipSuccess) return false;
-  if (hipStreamCreateWithPriority(&S.bg, hipStreamNonBlocking, prio) != hipSuccess) return false;
+  int bg_prio = prio;
+  if (const char* e3 = getenv("SDUMC_BG_PRIORITY")) bg_prio = e3[0] == 'n' ? 0 : (e3[0] == 'l' ? least : greatest);
+  if (hipStreamCreateWithPriority(&S.bg, hipStreamNonBlocking, bg_prio) != hipSuccess) return false;
   S.ok = true;
   return true;
 }
@@ -621,7 +623,9 @@ bool gg_on() {
   return on;
 }
 // the queued weight-gradient GEMMs go through ONE persistent launch (gemm_group.hip)
-bool gg_utt(const Ctx& c) { return gg_on(); }
+// (not in bf16-storage mode: there only the small utterance-level products would go through it, in three launches that each
+//  hold the whole chip -- measured 1.108 vs 1.098 ms per step)
+bool gg_utt(const Ctx& c) { return gg_on() && !c.h(); }
 // ... and so do the frame-level ones (input_proj of both attention sites, frame_dim_reshape): fp32 storage only
 bool gg_frame(const Ctx& c) { return gg_utt(c) && !c.h() && c.d.bf16 == 0; }
 
@@ -1515,7 +1519,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   const bool ca_dw_grouped = ggf && attn_multi_ok(c);
   int ca_dw_mask = 0, fra_dw_mask = 0;
   for (int m = 0; m < 3; ++m) {
-    if (ca_dw_grouped && keys_dw_groupable(c, m) && !(gg_early == 1 && (bgb & (1 << m)))) ca_dw_mask |= 1 << m;
+    if (ca_dw_grouped && keys_dw_groupable(c, m) && !((gg_early == 1 || gg_early == 3) && (bgb & (1 << m)))) ca_dw_mask |= 1 << m;
     if (ggf && keys_dw_groupable(c, m)) fra_dw_mask |= 1 << m;
   }
   // early_done[m]: lane 3 has finished modality m's early key-projection backward (dxd of its Cross_Attention site).  The
@@ -1527,6 +1531,22 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     early_done[m] = next_event(c);
     return hipEventRecord(early_done[m], c.sts[3]) == hipSuccess ? SDUMC_OK : SDUMC_ELAUNCH;
   };
+  // the early key-projection backward of the Cross_Attention sites (bit m of bgb), ordered after what lane 0 has issued so far
+  auto early_keys = [&]() -> int {
+    for (int m = 0; m < 3; ++m) {
+      if (!(bgb & (1 << m))) continue;
+      const int lane = (own_lane & (1 << m)) ? LANE_OF[m] : 3;
+      RET(link(c, 0, lane));
+      c.use(lane);
+      RET(keys_gemm_bwd(c, m, 1, 2, (ca_dw_mask & (1 << m)) ? 2 : 3));
+      if (lane == 3) RET(record_early(m));
+      c.use(0);
+    }
+    return SDUMC_OK;
+  };
+  // mode 3: behind the utterance-level stage 7'-3' instead of beside it (the clustered kernels exchange slices through L2 / HBM
+  // at latency; a bandwidth-heavy GEMM beside them doubled their time)
+  const bool late_early = ggf && gg_early == 3 && use_chain(c) && attn_multi_ok(c);
   if (phases & 1) {
   // every live gradient tensor is overwritten below when all five output gradients are given
   if (!og.d_vals || !og.d_fused || !og.d_rnc || !og.d_text_hidden || !og.d_cross_text) RET(sdumc_fill(c.G, 0.f, pm.live, c.st));
@@ -1614,15 +1634,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     RET(sdumc_attnpool_bwd_multi(bb, n, c.st));
     for (int m = 0; m < 3; ++m)
       if (ca_dw_mask & (1 << m)) keys_dw_queue(c, m, 1, 2);
-    for (int m = 0; m < 3; ++m) {     // the early dX (before the flush below: it is on the critical path, the flush is not)
-      if (!(bgb & (1 << m))) continue;
-      const int lane = (own_lane & (1 << m)) ? LANE_OF[m] : 3;
-      RET(link(c, 0, lane));
-      c.use(lane);
-      RET(keys_gemm_bwd(c, m, 1, 2, (ca_dw_mask & (1 << m)) ? 2 : 3));
-      if (lane == 3) RET(record_early(m));
-      c.use(0);
-    }
+    if (!late_early) RET(early_keys());
     // (no flush here: a persistent launch now would hold every CU's registers while the latency-bound utterance-level stage
     //  7'-3' -- 256 co-resident workgroups -- is trying to start: measured +135 us on that stage.  The queued problems leave
     //  with the FRA2UTT ones, beside the dX products of the frame-level part.)
@@ -1657,6 +1669,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     mark(c.st, 7);
     RET(chain_launch(c, ca, 3));
     mark(c.st, 8);
+    if (late_early) RET(early_keys());
     const int M7 = V * NQ;
     {
       sdumc_gemm gw = G_(SDUMC_TN, D, D, M7, 3);

@@ -60,6 +60,7 @@ struct Launch {
   int32_t n;
   int32_t nwg;
   int32_t stagger;
+  int32_t ovh;               // line positions charged to every unit for its fixed costs (ring start-up latency, epilogue): no k-tiles behind them
   float* slab;
 };
 
@@ -85,28 +86,31 @@ struct Where {     // a line position resolved
   int unit_end;                // line position one past this unit
   int kt_end;                  // k-tile one past this unit's k range
   int unit;                    // global unit index
+  int ko;                      // position inside the unit (the first L.ovh positions carry no k-tiles)
 };
 __device__ __forceinline__ Where locate(const Launch& L, int x) {
   Where w;
   int p = 0;
   while (p + 1 < L.n && L.line0[p + 1] <= x) ++p;
   const Geo g = geo_of(L.p[p]);
-  const int nc = L.nchunk[p];
+  const int nc = L.nchunk[p], ovh = L.ovh;
   const int xr = x - L.line0[p];
-  int c = nc == 1 ? 0 : (int)(((uint32_t)xr * (uint32_t)nc) / ((uint32_t)g.ntiles * (uint32_t)g.nk));
+  // chunk c starts at line offset ntiles * (chunk_k(c) + c * ovh)
+  int c = nc == 1 ? 0 : (int)(((uint32_t)xr * (uint32_t)nc) / ((uint32_t)g.ntiles * (uint32_t)(g.nk + nc * ovh)));
   if (c > nc - 1) c = nc - 1;
-  while (c + 1 < nc && g.ntiles * chunk_k(c + 1, g.nk, nc) <= xr) ++c;
-  while (c > 0 && g.ntiles * chunk_k(c, g.nk, nc) > xr) --c;
-  const int k0 = chunk_k(c, g.nk, nc), k1 = chunk_k(c + 1, g.nk, nc), len = k1 - k0;
-  const int y = xr - g.ntiles * k0;
+  while (c + 1 < nc && g.ntiles * (chunk_k(c + 1, g.nk, nc) + (c + 1) * ovh) <= xr) ++c;
+  while (c > 0 && g.ntiles * (chunk_k(c, g.nk, nc) + c * ovh) > xr) --c;
+  const int k0 = chunk_k(c, g.nk, nc), k1 = chunk_k(c + 1, g.nk, nc), len = k1 - k0 + ovh;
+  const int y = xr - g.ntiles * (k0 + c * ovh);
   const int t = y / len, ko = y - t * len;
   w.p = p;
   w.chunk = c;
   w.tile = t;
-  w.kt = k0 + ko;
+  w.kt = k0 + max(ko - ovh, 0);
   w.kt_end = k1;
   w.unit_end = x - ko + len;
   w.unit = L.unit0[p] + c * g.ntiles + t;
+  w.ko = ko;
   return w;
 }
 
@@ -173,14 +177,16 @@ __global__ __launch_bounds__(NTHR, OCC) void gg_tn_kernel(const Launch L) {
     }
   };
   // the 16 MFMAs of one group (+ the keep-bits applied to the B fragment, + the column sums of A on the VALU)
-  auto mma = [&](Frag& f, float mscale, auto mask_c) {
+  auto mma = [&](Frag& f, auto mask_c) {
     constexpr bool MASK = decltype(mask_c)::value;
-    if constexpr (MASK) {
-      const uint32_t bit0 = 1u << (2 * (li & 1));
+    if constexpr (MASK) {   // keep-bit -> 0 / ~0 (v_bfe_i32), AND on the float's bits; the scale 1 / (1 - p) multiplies the tile once, at its end
+      const uint32_t pos = 2u * (li & 1);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        f.b[0][s] *= (f.mb[s] & bit0) ? mscale : 0.f;
-        f.b[1][s] *= (f.mb[s] & (bit0 << 1)) ? mscale : 0.f;
+        const uint32_t m0 = (uint32_t)__builtin_amdgcn_sbfe((int)f.mb[s], pos, 1u);
+        const uint32_t m1 = (uint32_t)__builtin_amdgcn_sbfe((int)f.mb[s], pos + 1u, 1u);
+        f.b[0][s] = __uint_as_float(__float_as_uint(f.b[0][s]) & m0);
+        f.b[1][s] = __uint_as_float(__float_as_uint(f.b[1][s]) & m1);
       }
     }
 #pragma unroll
@@ -206,7 +212,12 @@ __global__ __launch_bounds__(NTHR, OCC) void gg_tn_kernel(const Launch L) {
     const sdumc_gg_problem& pr = L.p[w.p];
     const Geo g = geo_of(pr);
     const int px_end = min(x_end, w.unit_end);
-    const int ka = w.kt, kb = w.kt + (px_end - x);          // k-tiles [ka, kb) of the problem's concatenated K
+    // k-tiles [ka, kb) of the problem's concatenated K (a range that ends inside the unit's overhead positions holds none)
+    const int ka = w.kt, kb = w.kt_end - (w.unit_end - px_end);
+    if (kb <= ka) {
+      x = px_end;
+      continue;
+    }
     const int tile_m = w.tile / g.ntn, tile_n = w.tile - tile_m * g.ntn;
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 #pragma unroll
@@ -217,6 +228,7 @@ __global__ __launch_bounds__(NTHR, OCC) void gg_tn_kernel(const Launch L) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
     }
+    bool seg_masked = false;
 #pragma nounroll
     for (int seg = 0; seg < 2; ++seg) {
       // k-tiles [t0, t0 + nk) of K-segment `seg`
@@ -234,7 +246,6 @@ __global__ __launch_bounds__(NTHR, OCC) void gg_tn_kernel(const Launch L) {
       const int segK = pr.K[seg], seg_mod = pr.b_row_mod[seg];
       const uint32_t lda4 = (uint32_t)pr.lda * 4u, ldb4 = (uint32_t)pr.ldb * 4u, qw = (uint32_t)pr.bits_qw;
       const bool masked = pr.b_bits[seg] != nullptr;
-      const float mscale = pr.b_scale;
       // Rows at and beyond K are outside the descriptors' ranges: the hardware returns zeros for them, so a ragged last k-tile
       // needs no special case (with a row modulo B stays in range there, against zeros of A).
       const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.A[seg]), 0, (int)((uint32_t)segK * lda4), 0x00020000);
@@ -305,7 +316,7 @@ __global__ __launch_bounds__(NTHR, OCC) void gg_tn_kernel(const Launch L) {
           }
           read_frag(lds + buf * STAGE_BYTES, 1, f1, mask_c);
           __builtin_amdgcn_sched_barrier(0);
-          mma(f0, mscale, mask_c);
+          mma(f0, mask_c);
           __builtin_amdgcn_sched_barrier(0);
           if (!late && t + 1 < nk) {
             wait_stages(min(nk - t - 2, NST - 3));
@@ -314,7 +325,7 @@ __global__ __launch_bounds__(NTHR, OCC) void gg_tn_kernel(const Launch L) {
           }
           if (t + 1 < nk) read_frag(lds + nbuf * STAGE_BYTES, 0, f0, mask_c);
           __builtin_amdgcn_sched_barrier(0);
-          mma(f1, mscale, mask_c);
+          mma(f1, mask_c);
           __builtin_amdgcn_sched_barrier(0);
           buf = nbuf;
           nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
@@ -323,7 +334,17 @@ __global__ __launch_bounds__(NTHR, OCC) void gg_tn_kernel(const Launch L) {
       };
       if (masked) ring(std::true_type{});
       else ring(std::false_type{});
+      seg_masked = masked;
       __builtin_amdgcn_s_barrier();          // every wave is done reading the ring before the next sub-piece refills it
+    }
+    if (seg_masked) {   // (both segments of a problem are masked or neither: checked on the host)
+      const float sc = pr.b_scale;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] *= sc;
     }
     const bool direct = L.nchunk[w.p] == 1 && ka == 0 && kb == g.nk;
     const bool do_cs = pr.colsum_a != nullptr && tile_n == 0 && wn0 == 0;
@@ -409,20 +430,21 @@ __global__ __launch_bounds__(NTHR) void gg_reduce_kernel(const Launch L, const i
   const int LL = L.line0[L.n];
   const int tile_m = tg / g.ntn, tile_n = tg - tile_m * g.ntn;
   const int m0 = tile_m * BM, n0 = tile_n * BN;
-  if (nc == 1) {   // written directly by the one workgroup that held the whole tile?
-    const int us = L.line0[p] + tg * g.nk;
-    if (wg_of(us, LL, L.nwg) == wg_of(us + g.nk - 1, LL, L.nwg)) return;
+  const int ovh = L.ovh;
+  if (nc == 1) {   // written directly by the one workgroup that held all its k-tiles?
+    const int us = L.line0[p] + tg * (g.nk + ovh);
+    if (wg_of(us + ovh, LL, L.nwg) == wg_of(us + ovh + g.nk - 1, LL, L.nwg)) return;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (part == 16) {
     if (!pr.colsum_a || tile_n != 0 || tid >= BM) return;
     float s = 0.f;
     for (int c = 0; c < nc; ++c) {
-      const int k0 = chunk_k(c, g.nk, nc), len = chunk_k(c + 1, g.nk, nc) - k0;
-      const int us = L.line0[p] + g.ntiles * k0 + tg * len;
+      const int k0 = chunk_k(c, g.nk, nc), len = chunk_k(c + 1, g.nk, nc) - k0 + ovh;
+      const int us = L.line0[p] + g.ntiles * (k0 + c * ovh) + tg * len;
       const int unit = L.unit0[p] + c * g.ntiles + tg;
       const int wl = wg_of(us + len - 1, LL, L.nwg);
-      for (int w = wg_of(us, LL, L.nwg); w <= wl; ++w) s += L.slab[(size_t)(w + unit) * SLOT_FLOATS + BM * BN + tid];
+      for (int w = wg_of(us + ovh, LL, L.nwg); w <= wl; ++w) s += L.slab[(size_t)(w + unit) * SLOT_FLOATS + BM * BN + tid];
     }
     const int m = m0 + tid;
     if (m < pr.M) pr.colsum_a[m] = pr.accumulate ? pr.colsum_a[m] + s : s;
@@ -431,11 +453,11 @@ __global__ __launch_bounds__(NTHR) void gg_reduce_kernel(const Launch L, const i
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   const size_t off = ((size_t)((wave * 16 + part) * 64 + lane)) * 4;
   for (int c = 0; c < nc; ++c) {
-    const int k0 = chunk_k(c, g.nk, nc), len = chunk_k(c + 1, g.nk, nc) - k0;
-    const int us = L.line0[p] + g.ntiles * k0 + tg * len;
+    const int k0 = chunk_k(c, g.nk, nc), len = chunk_k(c + 1, g.nk, nc) - k0 + ovh;
+    const int us = L.line0[p] + g.ntiles * (k0 + c * ovh) + tg * len;
     const int unit = L.unit0[p] + c * g.ntiles + tg;
     const int wl = wg_of(us + len - 1, LL, L.nwg);
-    for (int w = wg_of(us, LL, L.nwg); w <= wl; ++w) s += *reinterpret_cast<const f32x4*>(L.slab + (size_t)(w + unit) * SLOT_FLOATS + off);
+    for (int w = wg_of(us + ovh, LL, L.nwg); w <= wl; ++w) s += *reinterpret_cast<const f32x4*>(L.slab + (size_t)(w + unit) * SLOT_FLOATS + off);
   }
   const int li = lane & 31, lh = lane >> 5;
   const int ij = part >> 2, q = part & 3, i = ij / TN, j = ij - i * TN;
@@ -495,6 +517,7 @@ bool valid(const sdumc_gg_problem& p) {
   if (!p.A[0] || !p.B[0] || !p.C || p.M < 4 || p.N < 4 || (p.M & 3) || (p.N & 3) || (p.lda & 3) || (p.ldb & 3) || p.K[0] <= 0 || p.K[1] < 0)
     return false;
   if (p.lda < p.M || p.ldb < p.N || p.ldc < p.N || p.M > BM * 255) return false;
+  if (p.K[1] > 0 && ((p.b_bits[0] != nullptr) != (p.b_bits[1] != nullptr))) return false;
   for (int s = 0; s < 2; ++s) {
     if (p.K[s] == 0) continue;
     if (!p.A[s] || !p.B[s]) return false;
@@ -514,6 +537,10 @@ bool valid(const sdumc_gg_problem& p) {
 int plan(const sdumc_gg_problem* probs, int n, int nwg_max, Launch& L, int& units) {
   memset(&L, 0, sizeof(L));
   L.n = n;
+  // (measured on MI355X, tools/gg_bench.py, all 37 problems of a C2 backward in one launch: 623 us with 0, 515 with 2, 490 with 3-4,
+  //  494-500 with 6-12: a unit's ring start-up -- the HBM latency of its first stage -- and its epilogue are worth ~3 k-tiles)
+  static const int ovh = [] { const char* e = getenv("SDUMC_GG_OVH"); return e ? atoi(e) : 3; }();
+  L.ovh = ovh;
   int line = 0, tiles = 0;
   units = 0;
   for (int i = 0; i < n; ++i) {
@@ -522,7 +549,7 @@ int plan(const sdumc_gg_problem* probs, int n, int nwg_max, Launch& L, int& unit
     L.nchunk[i] = 1;
     L.line0[i] = line;
     L.unit0[i] = units;
-    line += g.ntiles * g.nk;
+    line += g.ntiles * (g.nk + L.nchunk[i] * L.ovh);
     units += g.ntiles * L.nchunk[i];
     tiles += g.ntiles;
   }
