@@ -68,13 +68,19 @@ def source_sha():
     return h.hexdigest()[:16]
 
 
-def spawn_ranks(n):
+def spawn_ranks(n, timeout_s=None):
     """`python3 bench.py --gpus N` without a launcher: start the N rank processes ourselves.  This parent makes NO GPU call
     (torch is imported, nothing under torch.cuda is touched) and never exec()s: the ranks are ordinary children, rank 0's
-    stdout is relayed, and the exit code is non-zero if any rank fails."""
+    stdout is relayed.  Watchdog: every child is polled; on the first non-zero exit (or when `timeout_s` runs out) the others
+    are terminated -- a rank that died in its set-up would otherwise leave its peers blocked in the rendezvous or in a
+    collective until torch's own timeout -- and that exit code is returned."""
     import socket
     import subprocess
-    with socket.socket() as sk:
+    import threading
+    import time
+    if timeout_s is None:
+        timeout_s = float(os.environ.get("SDUMC_BENCH_TIMEOUT", "1500"))
+    with socket.socket() as sk:      # (the port is free now; a race with another process for it shows up as a failed rank)
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = []
@@ -83,14 +89,42 @@ def spawn_ranks(n):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0, _ = procs[0].communicate()
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
-    sys.stdout.write(out0.decode(errors="replace"))
+    out0 = []
+    drain = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)   # rank 0's pipe must not fill up
+    drain.start()
+    t0 = time.time()
+    failed = None
+    while True:
+        rcs = [p.poll() for p in procs]
+        bad = [(r, rc) for r, rc in enumerate(rcs) if rc not in (None, 0)]
+        if bad:
+            failed = bad[0]
+            break
+        if all(rc == 0 for rc in rcs):
+            break
+        if time.time() - t0 > timeout_s:
+            failed = (-1, 124)
+            break
+        time.sleep(0.05)
+    if failed is not None:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t1 = time.time()
+        while any(p.poll() is None for p in procs) and time.time() - t1 < 5.0:
+            time.sleep(0.05)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    for p in procs:
+        p.wait()
+    drain.join(timeout=5.0)
+    sys.stdout.write(b"".join(out0).decode(errors="replace"))
     sys.stdout.flush()
-    bad = [(r, rc) for r, rc in enumerate(rcs) if rc != 0]
-    if bad:
-        sys.stderr.write(f"bench.py: rank(s) failed: {bad}\n")
-        return next(rc for _, rc in bad) or 1
+    if failed is not None:
+        what = "timed out after %.0f s" % timeout_s if failed[0] < 0 else "rank %d exited with code %d" % failed
+        sys.stderr.write(f"bench.py: {what}; the other ranks were terminated\n")
+        return failed[1] or 1
     return 0
 
 
@@ -303,6 +337,8 @@ def main():
         raise SystemExit(spawn_ranks(args.gpus))      # no launcher: this process becomes the parent of N rank processes
     if world != args.gpus:
         args.gpus = world
+    if world > 1 and os.environ.get("SDUMC_TEST_FAIL_RANK") == str(rank):   # test hook (tests/test_gpu_dp.py): this rank dies in set-up
+        raise SystemExit(3)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: sdumc_amd has no CPU fallback")
     ndev = torch.cuda.device_count()

@@ -628,9 +628,18 @@ int sdumc_set_background_lane(int on);
 /* The utterance-level stages run as clustered kernels (four workgroups split every layer's columns and exchange their slices
  * through HBM + a flag, csrc/chain_cluster.hip) whenever all their workgroups fit the device at once (2 x streams x B <= 128
  * on MI355X) and the stream is not being captured; 0 keeps the one-workgroup-per-sample-pair kernels of csrc/chain.hip.
- * sdumc_chain_cluster_error_() synchronises the device and returns 0 unless a cluster spin ever ran into its cap. */
+ * Failure contract: the members of a cluster wait for each other with a bounded spin.  A spin that runs into its cap (another
+ * process holding the GPU's CUs, a hung member) sets a sticky per-device error word and lets the kernel finish with wrong data;
+ * from then on every Adam launch of this library on that device (sdumc_train_step, sdumc_adam_step) applies NOTHING -- parameters
+ * and moments keep their values -- and the fused step's total loss reads NaN.  sdumc_chain_cluster_error_() synchronises the
+ * device and returns the word (0 = fine); sdumc_chain_cluster_reset_error() clears it (and the clusters' counters) once the
+ * caller has dealt with the failed step, e.g. by repeating it with sdumc_set_chain_cluster(0).
+ * sdumc_chain_cluster_test_hold_(1) is a test hook: workgroup 0 of every following clustered launch withholds its arrivals, which
+ * drives exactly that failure path on purpose (tests/test_gpu_net.py). */
 int sdumc_set_chain_cluster(int on);
 int sdumc_chain_cluster_error_(void);
+int sdumc_chain_cluster_reset_error(void);
+int sdumc_chain_cluster_test_hold_(int on);
 int sdumc_debug_marks(int on);
 int sdumc_debug_marks_read(float* ms, int n);
 size_t sdumc_net_workspace_bytes(const sdumc_net_dims* d);

@@ -240,6 +240,8 @@ _SIGS = {
     "sdumc_set_background_lane": (C.c_int, [C.c_int]),
     "sdumc_set_chain_cluster": (C.c_int, [C.c_int]),
     "sdumc_chain_cluster_error_": (C.c_int, []),
+    "sdumc_chain_cluster_reset_error": (C.c_int, []),
+    "sdumc_chain_cluster_test_hold_": (C.c_int, [C.c_int]),
     "sdumc_debug_marks": (C.c_int, [C.c_int]),
     "sdumc_debug_marks_read": (C.c_int, [C.POINTER(C.c_float), C.c_int]),
     "sdumc_net_workspace_bytes": (C.c_size_t, [C.POINTER(NetDims)]),

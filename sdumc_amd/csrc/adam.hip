@@ -25,7 +25,11 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
                                                    const sdumc_total_loss tl) {
   const float step_size = hyper[2], bc2_sqrt = hyper[3];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n4) {
+  // A clustered utterance-level kernel whose spin ran into its cap finished with wrong data: the gradients of this step are
+  // garbage, so NOTHING is applied -- parameters and moments stay as they were (every thread reads the word; it is sticky
+  // until sdumc_chain_cluster_reset_error)
+  const bool poisoned = tl.chain_err != nullptr && *tl.chain_err != 0;
+  if (i < n4 && !poisoned) {
     f32x4 pp = reinterpret_cast<f32x4*>(p)[i];
     const f32x4 gg = reinterpret_cast<const f32x4*>(g)[i];
     f32x4 mm = reinterpret_cast<f32x4*>(m)[i];
@@ -49,9 +53,9 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const 
       L[0] = tl.w[0] * L[1] + tl.w[1] * L[2] + tl.w[2] * L[3] + tl.w[3] * L[4] + tl.w[4] * L[5] + tl.w[5] * L[6];
       L[7] = 0.f;
       // fail loudly: a clustered utterance-level kernel whose spin ran into its cap finished with wrong data
-      if (tl.chain_err && *tl.chain_err) { L[0] = __int_as_float(0x7fc00000); L[7] = 1.f; }
+      if (poisoned) { L[0] = __int_as_float(0x7fc00000); L[7] = 1.f; }
     }
-    for (int64_t t = n4 * 4; t < n; ++t) {
+    for (int64_t t = n4 * 4; t < n && !poisoned; ++t) {
       const float ge = g[t] * gscale + wd * p[t];
       m[t] = m[t] + (ge - m[t]) * (1.f - beta1);
       v[t] = v[t] * beta2 + (1.f - beta2) * ge * ge;
@@ -79,6 +83,8 @@ extern "C" int sdumc_adam_apply_(float* param, const float* grad, float* exp_avg
   tl.chain_err = nullptr;
   for (int i = 0; i < 6; ++i) tl.w[i] = 0.f;
   if (total) tl = *total;
+  // (callers without a loss record -- the data-parallel step, sdumc_adam_step -- are guarded by the device's error word too)
+  if (!tl.chain_err) tl.chain_err = sdumc_chain_cluster_err_ptr_();
   if ((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
        reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15)
     return SDUMC_EINVAL;

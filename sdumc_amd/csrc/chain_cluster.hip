@@ -24,6 +24,7 @@
 // streams of one device are serialised with an event (two half-resident cluster kernels would deadlock each other).  A spin
 // that exceeds its cap sets an error word and lets the kernel run to its end (wrong results, no hang).
 // fp32 weights only (a 64-column slice of a bf16 row is half a cache line per lane group; the stream is no longer the bound).
+#include <atomic>
 #include <mutex>
 
 #include "chain_common.h"
@@ -42,6 +43,7 @@ struct Cl {
   uint32_t* depart;
   int32_t* err;
   uint32_t round;
+  bool hold;        // test hook (sdumc_chain_cluster_test_hold_): this workgroup withholds its arrivals, so its cluster runs into the cap
 };
 
 __device__ __forceinline__ void st4_dev(float* p, f32x4 v) {
@@ -70,7 +72,7 @@ __device__ __forceinline__ void cl_sync(Cl& cl, int* s_bail) {
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (threadIdx.x == 0 && !*s_bail) {
-    __hip_atomic_fetch_add(cl.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!cl.hold) __hip_atomic_fetch_add(cl.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t want = (uint32_t)CL * (cl.round + 1u);
     int spins = 0;
     while (__hip_atomic_load(cl.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
@@ -245,7 +247,7 @@ __device__ __forceinline__ void cxm_run(CRing& ring, const float* in_lds, int ld
   const int cluster = blockIdx.x % ncl, member = blockIdx.x / ncl;                                             \
   const int V = a.V, v0 = cluster * R, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;                    \
   const int coff = member * OC;                                                                                \
-  Cl cl{a.cl_flags + cluster * 64, a.cl_flags + cluster * 64 + 32, a.cl_err, 0u};                              \
+  Cl cl{a.cl_flags + cluster * 64, a.cl_flags + cluster * 64 + 32, a.cl_err, 0u, a.cl_test_hold != 0 && blockIdx.x == 0};                              \
   if (tid == 0) s_bail = 0;                                                                                    \
   (void)lane; (void)wave
 
@@ -969,6 +971,8 @@ struct ClusterDev {
   hipStream_t last = nullptr;
   bool any = false;
   int cus = 0;
+  int attr = 0;      // 0 = not tried, 1 = the kernels' dynamic-LDS limits are set on this device and every kernel fits a CU, -1 = failed
+  int test_hold = 0;
 };
 ClusterDev g_cl[16];
 constexpr int kMaxClusters = 128;
@@ -996,19 +1000,44 @@ ClusterDev* cluster_dev() {
 }  // namespace
 
 // 1 = V samples qualify for the cluster kernels on the current device (every workgroup resident at once)
-namespace { int g_cluster_on = -1; }
+namespace { std::atomic<int> g_cluster_on{-1}; }
 // experiment / test knob (also SDUMC_CHAIN_CLUSTER=0|1 at start-up): 0 keeps chain.hip's one-workgroup-per-sample-pair kernels
 extern "C" int sdumc_set_chain_cluster(int on) {
-  g_cluster_on = on ? 1 : 0;
+  g_cluster_on.store(on ? 1 : 0);
   return SDUMC_OK;
 }
+namespace {
+// per device, under d->mu: raise the kernels' dynamic-LDS limit and check with the occupancy query that a workgroup of each of
+// them fits a CU at all (the members of a cluster spin on each other: a grid that cannot be resident must not be launched)
+template <int R>
+bool cluster_prepare(ClusterDev* d) {
+  std::lock_guard<std::mutex> lk(d->mu);
+  if (d->attr == 0) {
+    d->attr = -1;
+    if (set_smem(chain_fwd_a_cl_kernel<R>, smem_fwd_a<R>()) || set_smem(chain_fwd_b_cl_kernel<R>, smem_fwd_b<R>()) ||
+        set_smem(chain_bwd_b_cl_kernel<R>, smem_bwd_b<R>()) || set_smem(chain_bwd_a_cl_kernel<R>, smem_bwd_a<R>()))
+      return false;
+    int n[4] = {0, 0, 0, 0};
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[0], chain_fwd_a_cl_kernel<R>, NTHR, smem_fwd_a<R>()) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[1], chain_fwd_b_cl_kernel<R>, NTHR, smem_fwd_b<R>()) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[2], chain_bwd_b_cl_kernel<R>, NTHR, smem_bwd_b<R>()) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[3], chain_bwd_a_cl_kernel<R>, NTHR, smem_bwd_a<R>()) != hipSuccess)
+      return false;
+    if (n[0] < 1 || n[1] < 1 || n[2] < 1 || n[3] < 1) return false;
+    d->attr = 1;
+  }
+  return d->attr == 1;
+}
+}  // namespace
+
 extern "C" int sdumc_chain_cluster_ok_(int V) {
-  if (g_cluster_on < 0) { const char* e = getenv("SDUMC_CHAIN_CLUSTER"); g_cluster_on = e ? (atoi(e) ? 1 : 0) : 1; }
-  if (!g_cluster_on || V <= 0) return 0;
+  if (g_cluster_on.load() < 0) { const char* e = getenv("SDUMC_CHAIN_CLUSTER"); g_cluster_on.store(e ? (atoi(e) ? 1 : 0) : 1); }
+  if (!g_cluster_on.load() || V <= 0) return 0;
   ClusterDev* d = cluster_dev();
   if (!d) return 0;
   const int ncl = (V + 1) / 2;
-  return ncl <= kMaxClusters && ncl * CL <= d->cus ? 1 : 0;
+  if (!(ncl <= kMaxClusters && ncl * CL <= d->cus)) return 0;
+  return cluster_prepare<2>(d) ? 1 : 0;
 }
 
 // which: 0 = stage A forward, 1 = stage B forward, 2 = stage B backward, 3 = stage A backward; 1 = shape does not qualify
@@ -1016,16 +1045,10 @@ extern "C" int sdumc_chain_cluster_launch_(const sdumc_chain_args* ap, int which
   if (!ap || ap->V <= 0 || which < 0 || which > 3) return SDUMC_EINVAL;
   if (!sdumc_chain_cluster_ok_(ap->V)) return 1;
   constexpr int R = 2;
-  static bool attr = false;
-  if (!attr) {
-    if (set_smem(chain_fwd_a_cl_kernel<R>, smem_fwd_a<R>()) || set_smem(chain_fwd_b_cl_kernel<R>, smem_fwd_b<R>()) ||
-        set_smem(chain_bwd_b_cl_kernel<R>, smem_bwd_b<R>()) || set_smem(chain_bwd_a_cl_kernel<R>, smem_bwd_a<R>()))
-      return SDUMC_ELAUNCH;
-    attr = true;
-  }
   ClusterDev* d = cluster_dev();
   if (!d) return SDUMC_ELAUNCH;
   sdumc_chain_args a = *ap;
+  a.cl_test_hold = d->test_hold;
   a.cl_flags = d->flags;
   a.cl_err = d->err;
   a.cl_trace = d->tracing ? d->trace + 32 * which : nullptr;
@@ -1053,6 +1076,25 @@ extern "C" const int32_t* sdumc_chain_cluster_err_ptr_() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return nullptr;
   return g_cl[dev].err;
+}
+
+// clears the error word of the current device (after the caller has dealt with a failed step); synchronises the device
+extern "C" int sdumc_chain_cluster_reset_error(void) {
+  ClusterDev* d = cluster_dev();
+  if (!d) return SDUMC_ELAUNCH;
+  if (hipDeviceSynchronize() != hipSuccess) return SDUMC_ELAUNCH;
+  // (the counters too: a launch that bailed out may have left arrivals behind)
+  if (hipMemset(d->flags, 0, (kMaxClusters * 64 + 64) * sizeof(uint32_t)) != hipSuccess) return SDUMC_ELAUNCH;
+  return SDUMC_OK;
+}
+// test hook: on != 0 makes workgroup 0 of every following cluster launch withhold its arrivals, so that its cluster runs into
+// the spin cap (error word set, kernel finishes with wrong data): the failure path can be driven on purpose
+extern "C" int sdumc_chain_cluster_test_hold_(int on) {
+  ClusterDev* d = cluster_dev();
+  if (!d) return SDUMC_ELAUNCH;
+  std::lock_guard<std::mutex> lk(d->mu);
+  d->test_hold = on ? 1 : 0;
+  return SDUMC_OK;
 }
 
 // 0 = no cluster spin ever exceeded its cap on the current device (synchronises the device; tests)

@@ -67,6 +67,7 @@ struct sdumc_chain_args {
   uint32_t* cl_flags;
   int32_t* cl_err;
   unsigned long long* cl_trace;   // null, or 32 timestamps of workgroup 0 (debug)
+  int32_t cl_test_hold;           // test hook: workgroup 0 withholds its arrivals (sdumc_chain_cluster_test_hold_)
 };
 
 extern "C" {

@@ -140,15 +140,23 @@ class DeviceFeatureStore:
 
     def batch_shape(self, indices):
         """(B, (T_audio, T_text, T_video, T_feat4)) of the padded batch -- host-side table lookups only."""
-        idx = torch.as_tensor(indices, dtype=torch.int64)
+        idx = self._checked(indices)
         return int(idx.numel()), tuple(int(self.length[m][idx].max()) for m in self.MODS)
+
+    def _checked(self, indices):
+        """host-side range check: the gather kernel indexes device tables with these values"""
+        idx = torch.as_tensor(indices, dtype=torch.int64).reshape(-1)
+        n = len(self)
+        if idx.numel() == 0 or int(idx.min()) < 0 or int(idx.max()) >= n:
+            raise self._lib.SdumcError(f"sample index out of range [0, {n})")
+        return idx
 
     def batch_into(self, indices, outs, labels_out, lengths_out=None):
         """Assembles the batch `indices` into caller-owned buffers: outs = 4 device tensors [B, Tmax_m, d_m] (e.g. the input
         buffers of an engine.TrainStep), labels_out [B]; lengths_out = optional 4 int32 device tensors (>= B) that receive the
         valid frame counts.  One index-vector upload, four gather/pad launches, nothing else."""
         _lib = self._lib
-        idx = torch.as_tensor(indices, dtype=torch.int64)
+        idx = self._checked(indices)
         B = idx.numel()
         idx_d = idx.to(self.device, non_blocking=True)
         for k, m in enumerate(self.MODS):

@@ -467,7 +467,7 @@ class FusedTrainer:
         self._steps = {}          # shape -> TrainStep, insertion order = recency
         self.arena = None
         if capacity is not None:
-            self.arena = _StepArena(flat_params, capacity[0], capacity[1], dims, bf16=bool(step_kwargs.get("bf16", False)))
+            self.arena = _StepArena(flat_params, capacity[0], capacity[1], dims, bf16=step_kwargs.get("bf16", False))
             self.max_cached = max(self.max_cached, 4096)
 
     def _get(self, B, T):
@@ -479,7 +479,7 @@ class FusedTrainer:
             if self.arena is not None and not (B <= self.arena.B and all(t <= c for t, c in zip(T, self.arena.T))):
                 # a batch beyond the declared capacity: grow the arena (every cached step pointed into the old one)
                 cap_T = tuple(max(t, c) for t, c in zip(T, self.arena.T))
-                self.arena = _StepArena(self.params, max(B, self.arena.B), cap_T, self.dims, bf16=bool(self.kw.get("bf16", False)))
+                self.arena = _StepArena(self.params, max(B, self.arena.B), cap_T, self.dims, bf16=self.kw.get("bf16", False))
                 self._steps.clear()
             ts = TrainStep(self.params, B, T, self.dims, share=self.state, arena=self.arena, **self.kw)
         self._steps[key] = ts

@@ -128,6 +128,78 @@ def test_c4_global_batch_512_on_one_gpu_and_two_simulated_ranks(E):
                                ((p_full - flat) * 1e4).cpu().numpy()[ok.numpy()], rtol=5e-2, atol=5e-2)
 
 
+C5_BF16_GRAD_MAX = 0.2     # worst tensor measured on MI355X: 0.11 (cross_audio_mlp.3.bias)
+
+
+def grad_errors(lay, got, ref):
+    """norm-wise relative error of every live gradient tensor; tensors whose reference gradient is numerically zero -- per-element
+    rms below 1e-6 of the largest tensor's: orgin_linear_change.{0,2}.bias, zero by the translation invariance of RnC -- carry
+    no signal for a relative error and must be just as small on the device"""
+    rms = {k: float(ref[k].double().norm() / np.sqrt(ref[k].numel())) for k in lay.live_names()}
+    G = max(rms.values())
+    errs = {}
+    for k in lay.live_names():
+        d = float((got[k].double() - ref[k].double()).norm())
+        if rms[k] < 1e-6 * G:
+            assert d / np.sqrt(ref[k].numel()) < 1e-5 * G, (k, d, G)
+            continue
+        errs[k] = d / float(ref[k].double().norm())
+    return errs
+
+
+def _bf16_full_batch_properties(E, dims, B, Tn, seed):
+    """bf16-storage step at a BASELINE batch size (no CPU oracle at this size): size-independent properties -- the eval-mode
+    forward of the batch equals that of its two halves, two runs are bit-identical, every live gradient tensor is finite and
+    non-zero, and the loss terms agree with the fp32 step on the same inputs and masks at the bf16 bar (2e-2)."""
+    from oracle import sdumc_oracle as O
+    P = O.init_params(dims, seed=0)
+    flat, lay = flat_from(E, P, dims)
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    audio, text, video, feat4 = [torch.randn(B, Tn[i], dims[i], device="cuda", generator=g) for i in range(4)]
+    vals = torch.rand(B, device="cuda", generator=g) * 6 - 3
+    full = [t.clone() for t in E.NetCall(flat, audio, [text, feat4], video, False, None, bf16=True).forward()]
+    h = B // 2
+    for lo in (0, h):
+        part = E.NetCall(flat, audio[lo:lo + h].contiguous(), [text[lo:lo + h].contiguous(), feat4[lo:lo + h].contiguous()],
+                         video[lo:lo + h].contiguous(), False, None, bf16=True).forward()
+        for n, f, p in zip(NAMES, full, part):
+            for s in range(2):
+                close(p[s * h:(s + 1) * h], f[s * B + lo:s * B + lo + h], 1e-5, "bf16 halves " + n)
+    del full, part
+    runs = []
+    for mode in (True, True, False):
+        p = flat.clone()
+        ts = E.TrainStep(p, B, Tn, dims, seed=seed, bf16=mode)
+        ts.set_batch(audio, text, video, feat4, vals)
+        losses = ts.run().cpu().clone()
+        runs.append((losses, ts.grads.cpu().clone(), p.cpu().clone()))
+        del ts
+    # two runs of the same step.  Not asserted bit for bit in this mode: with the clustered utterance-level kernels AND a bf16
+    # key-projection GEMM of the background lane resident beside them, a few samples' stage-A outputs come out an ulp apart
+    # from run to run (DESIGN.md section 7, open issue; fp32 storage is bit-reproducible -- test_gpu_net.py)
+    np.testing.assert_allclose(runs[0][0].numpy()[:7], runs[1][0].numpy()[:7], rtol=1e-5, atol=1e-7)
+    gs = float(runs[0][1].abs().max())
+    assert float((runs[0][1] - runs[1][1]).abs().max()) < 1e-4 * gs
+    assert torch.isfinite(runs[0][0]).all() and torch.isfinite(runs[0][1]).all()
+    np.testing.assert_allclose(runs[0][0].numpy()[:7], runs[2][0].numpy()[:7], rtol=2e-2, atol=1e-4)
+    assert not torch.equal(runs[0][1], runs[2][1]), "bf16 mode is not active"
+    gb, gf = lay.views(torch.cat([runs[0][1], torch.zeros(lay.total - lay.live)])), lay.views(torch.cat([runs[2][1], torch.zeros(lay.total - lay.live)]))
+    errs = grad_errors(lay, gb, gf)
+    for k, err in errs.items():
+        assert float(gb[k].abs().max()) > 0.0, k
+        assert err < C5_BF16_GRAD_MAX, (k, err)
+
+
+def test_c3_bf16_step_at_batch_64_properties(E):
+    """BASELINE configs[2] (C3) at its stated batch: MOSEI shapes, B = 64, bf16 storage"""
+    _bf16_full_batch_properties(E, (1024, 4096, 1024, 4096), 64, (375, 32, 225, 32), 31)
+
+
+def test_c5_bf16_step_at_batch_32_properties(E):
+    """BASELINE configs[4] (C5) at its per-GPU batch: T = 512 for every modality, d = 1024, B = 32, bf16 storage"""
+    _bf16_full_batch_properties(E, (1024, 1024, 1024, 1024), 32, (512, 512, 512, 512), 37)
+
+
 def test_c5_long_sequence_shapes_in_bf16_vs_fp32_oracle(E):
     """BASELINE configs[4] (C5) in its stated arithmetic: T = 512 for every modality, d = 1024, bf16 mode, one full
     train step against the fp32 oracle at the bf16 bar of SURVEY §8(d) (2e-2), gradients norm-wise."""
@@ -152,16 +224,15 @@ def test_c5_long_sequence_shapes_in_bf16_vs_fp32_oracle(E):
     gv = lay.views(torch.cat([ts.grads.cpu(), torch.zeros(lay.total - lay.live)]))
     # norm-wise per tensor; tensors whose gradient is (analytically or numerically) negligible next to the largest one --
     # orgin_linear_change.2.bias is exactly zero by the translation invariance of RnC -- carry no signal to compare
-    errs = {}
-    for k in lay.live_names():
-        if k == "orgin_linear_change.2.bias":
-            continue
-        ref = grads[k].double()
-        errs[k] = float((gv[k].double() - ref).norm() / (ref.norm() + 1e-12))
+    errs = grad_errors(lay, gv, grads)
     vals = sorted(errs.values())
     worst = max(errs, key=errs.get)
-    # median 2 %; a few small tensors (a handful of biases whose gradient is a difference of large terms) sit higher
+    print("C5 bf16 gradient errors: median %.3g, 90th percentile %.3g, worst %s = %.3g" %
+          (float(np.median(vals)), vals[int(0.9 * len(vals))], worst, errs[worst]))
+    # median 2 %; a few small tensors (a handful of biases whose gradient is a difference of large terms) sit higher; EVERY
+    # tensor is bounded (C5_BF16_GRAD_MAX): a tensor of garbage would read >= 1
     assert float(np.median(vals)) < 4e-2 and vals[int(0.9 * len(vals))] < 0.2, (float(np.median(vals)), worst, errs[worst])
+    assert errs[worst] < C5_BF16_GRAD_MAX, (worst, errs[worst])
 
 
 def test_data_parallel_step_over_changing_shapes_and_resume(E):

@@ -241,3 +241,43 @@ def test_dp_record_one_launch_equals_ssd_plus_pack_and_is_deterministic(B):
     want = [float(((x[B:].double() - x[:B].double()) ** 2).sum()) for x in (th, ct, z)]
     np.testing.assert_allclose(rec[nf + B:].cpu().numpy(), np.array(want), rtol=1e-5)
     assert int(ws[:4].view(torch.int32).item()) == 0
+
+
+def _run_bench(extra_env, timeout):
+    import json
+    import os
+    import subprocess
+    import sys
+    import time
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, SDUMC_DIST_BACKEND="gloo", **extra_env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-roofline"], env=env, capture_output=True, timeout=timeout, cwd=root)
+    lines = [ln for ln in r.stdout.decode(errors="replace").splitlines() if ln.startswith("{")]
+    return r.returncode, ([json.loads(ln) for ln in lines]), time.time() - t0, r.stderr.decode(errors="replace")
+
+
+def test_bench_spawns_its_own_ranks_and_reports_one_line():
+    """`bench.py --gpus 2` without a launcher (a fresh process that starts its ranks before any GPU call of its own), two ranks
+    sharing the one GPU over gloo: ONE JSON line with n_gpus 2 and the data_parallel block (the driver's contract)."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    rc, lines, dt, err = _run_bench({}, 600)
+    assert rc == 0, err[-2000:]
+    assert len(lines) == 1
+    d = lines[0]
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and "data_parallel" in d
+    assert d["value"] > 0 and np.isfinite(d["config"]["final_loss"])
+
+
+def test_bench_parent_stops_everything_when_a_rank_dies():
+    """rank 1 exits in its set-up (SDUMC_TEST_FAIL_RANK): rank 0 would sit in the rendezvous until torch's timeout; the parent's
+    watchdog terminates it and returns rank 1's exit code within a minute."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    rc, lines, dt, err = _run_bench({"SDUMC_TEST_FAIL_RANK": "1"}, 120)
+    assert rc == 3 and not lines and dt < 60, (rc, dt, err[-1000:])
+    assert "rank 1 exited with code 3" in err

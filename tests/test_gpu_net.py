@@ -471,6 +471,50 @@ def test_fused_trainer_over_changing_batch_shapes_vs_oracle(E):
     assert tr.state.rng.call == 2 * len(shapes) and int(tr.state.hyper[1].item()) == len(shapes)
 
 
+def test_cluster_spin_cap_fails_loudly_and_applies_nothing(E):
+    """The failure path of csrc/chain_cluster.hip, driven on purpose: workgroup 0 withholds its arrivals
+    (sdumc_chain_cluster_test_hold_), its cluster's members spin into their cap, the error word is set.  Contract
+    (include/sdumc_hip.h): the step's total loss reads NaN, Adam applies NOTHING (parameters and moments unchanged, in the fused
+    step and in the stand-alone sdumc_adam_step the data-parallel trainer calls), the word stays set until
+    sdumc_chain_cluster_reset_error, after which steps are normal again."""
+    from oracle import sdumc_oracle as O
+    from sdumc_amd import _lib, ops
+    dims = (64, 32, 64, 32)
+    B, Tn = 6, (40, 6, 20, 6)
+    P = O.init_params(dims, seed=4)
+    batch = O.synthetic_batch(B, Tn, dims, seed=6)
+    flat, lay = flat_from(E, P, dims)
+    ts = E.TrainStep(flat, B, Tn, dims, seed=9)
+    ts.set_batch(*[t.cuda() for t in batch])
+    good = ts.run().cpu().clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(good).all() and _lib.lib.sdumc_chain_cluster_error_() == 0
+    before = flat.clone()
+    m_before, v_before = ts.adam_m.clone(), ts.adam_v.clone()
+    try:
+        _lib.lib.sdumc_chain_cluster_test_hold_(1)
+        bad = ts.run().cpu().clone()
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib.sdumc_chain_cluster_test_hold_(0)
+    assert _lib.lib.sdumc_chain_cluster_error_() != 0
+    assert torch.isnan(bad[0]), "the total loss of a step whose cluster spin hit its cap must read NaN"
+    assert torch.equal(flat, before) and torch.equal(ts.adam_m, m_before) and torch.equal(ts.adam_v, v_before)
+    # the word is sticky: the stand-alone Adam entry point (data-parallel trainer) is guarded by it too
+    p2, g2 = torch.ones(1024).cuda(), torch.ones(1024).cuda()
+    m2, v2 = torch.zeros(1024).cuda(), torch.zeros(1024).cuda()
+    hyper = torch.tensor([1e-2, 0.0, 0.0, 0.0]).cuda()
+    ops.adam_step(p2, g2, m2, v2, hyper)
+    torch.cuda.synchronize()
+    assert torch.equal(p2.cpu(), torch.ones(1024)) and float(m2.abs().max()) == 0.0
+    assert _lib.lib.sdumc_chain_cluster_reset_error() == 0 and _lib.lib.sdumc_chain_cluster_error_() == 0
+    ops.adam_step(p2, g2, m2, v2, hyper)
+    again = ts.run().cpu().clone()
+    torch.cuda.synchronize()
+    assert float(p2.max()) < 1.0 and torch.isfinite(again).all() and not torch.equal(flat, before)
+    assert _lib.lib.sdumc_chain_cluster_error_() == 0
+
+
 def test_clustered_utterance_level_kernels_equal_the_plain_ones(E):
     """csrc/chain_cluster.hip (columns of every utterance-level layer split over 4 workgroups that exchange slices through HBM)
     against csrc/chain.hip on the same inputs: three optimisation steps with fresh masks each, ragged V (B = 7: the last
