@@ -247,7 +247,7 @@ __device__ __forceinline__ void cxm_run(CRing& ring, const float* in_lds, int ld
   const int cluster = blockIdx.x % ncl, member = blockIdx.x / ncl;                                             \
   const int V = a.V, v0 = cluster * R, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;                    \
   const int coff = member * OC;                                                                                \
-  Cl cl{a.cl_flags + cluster * 64, a.cl_flags + cluster * 64 + 32, a.cl_err, 0u, a.cl_test_hold != 0 && blockIdx.x == 0};                              \
+  Cl cl{a.cl_flags + cluster * 64, a.cl_flags + cluster * 64 + 32, a.cl_err, 0u, a.cl_test_hold == 1 && blockIdx.x == 0};                              \
   if (tid == 0) s_bail = 0;                                                                                    \
   (void)lane; (void)wave
 

@@ -23,6 +23,8 @@ if os.environ.get("SERIAL") == "1":
     _lib.lib.sdumc_set_concurrency(0)
 if "BG" in os.environ:
     _lib.lib.sdumc_set_background_lane(int(os.environ["BG"]))
+if "HOLD" in os.environ:
+    _lib.lib.sdumc_chain_cluster_test_hold_(int(os.environ["HOLD"]))
 ref = None
 bad = {n: 0 for n in NAMES}
 reps = int(os.environ.get("REPS", "30"))
