@@ -180,6 +180,11 @@ typedef struct sdumc_gg_problem {
 } sdumc_gg_problem;
 size_t sdumc_gemm_group_workspace_bytes(const sdumc_gg_problem* probs, int32_t n);
 int sdumc_gemm_group_tn(const sdumc_gg_problem* probs, int32_t n, void* workspace, size_t workspace_bytes, void* stream);
+/* The same on bf16 STORAGE (sdumc_net_dims.bf16 = 2; BASELINE configs[2] / [4]): A and B point to bf16 tensors (lda / ldb in
+ * elements; M, N, lda, ldb multiples of 8; b_row_mod 0 or >= 64; no fused dropout -- b_bits must be NULL, the engine materialises
+ * the masked frames), products accumulate in fp32 on v_mfma_f32_32x32x16_bf16, C / colsum_a / the slabs are fp32. */
+size_t sdumc_gemm_group_bf16_workspace_bytes(const sdumc_gg_problem* probs, int32_t n);
+int sdumc_gemm_group_tn_bf16(const sdumc_gg_problem* probs, int32_t n, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
  * Attention pooling over the time axis = the body shared by

@@ -481,6 +481,7 @@ struct Ctx {
   mutable std::vector<sdumc_gemm> deferred;
   // the same products as problems of ONE persistent launch (gemm_group.hip): everything queued here is issued by the next flush_dw
   mutable std::vector<sdumc_gg_problem> gg;
+  mutable std::vector<sdumc_gg_problem> ggh;     // ... on bf16 operands (bf16-storage mode: sdumc_gemm_group_tn_bf16)
   float* p(int64_t off) const { return W + off; }
   // bf16 buffers: `off` is the buffer's offset in floats, `elems` an element offset inside it
   unsigned short* ph(int64_t off, int64_t elems = 0) const { return reinterpret_cast<unsigned short*>(W + off) + elems; }
@@ -625,9 +626,10 @@ bool gg_on() {
 // the queued weight-gradient GEMMs go through ONE persistent launch (gemm_group.hip)
 // (not in bf16-storage mode: there only the small utterance-level products would go through it, in three launches that each
 //  hold the whole chip -- measured 1.108 vs 1.098 ms per step)
-bool gg_utt(const Ctx& c) { return gg_on() && !c.h(); }
-// ... and so do the frame-level ones (input_proj of both attention sites, frame_dim_reshape): fp32 storage only
-bool gg_frame(const Ctx& c) { return gg_utt(c) && !c.h() && c.d.bf16 == 0; }
+bool gg_utt(const Ctx& c) { static const int hfu = [] { const char* e = getenv("SDUMC_GG_UTT_HF"); return e ? atoi(e) : 1; }(); return gg_on() && (!c.h() || hfu); }
+// ... and so do the frame-level ones (input_proj of both attention sites, frame_dim_reshape), on fp32 or on bf16 storage
+// (not in the operand-rounding mode bf16 = 1, whose products round fp32 operands while staging them)
+bool gg_frame(const Ctx& c) { return gg_on() && (c.h() || c.d.bf16 == 0); }
 
 // one group of a queued TN descriptor as a problem of the grouped launch; false = the grouped kernel does not take it
 bool gg_from_gemm(const sdumc_gemm& g, int grp, sdumc_gg_problem& q) {
@@ -655,8 +657,11 @@ bool gg_from_gemm(const sdumc_gemm& g, int grp, sdumc_gg_problem& q) {
 }
 
 // issues everything queued (c.deferred, c.gg) on `lane`, ordered after what lane `after` has issued so far
-int flush_dw_on(const Ctx& c, int after, int lane, int slab) {
-  if (c.deferred.empty() && c.gg.empty()) return SDUMC_OK;
+// small_only: only the per-layer launches of c.deferred (modes in which the utterance-level products do not ride in a grouped
+// launch keep their early flush points; the grouped frame-level problems queued so far wait for theirs)
+int flush_dw_on(const Ctx& c, int after, int lane, int slab, bool small_only = false) {
+  if (small_only && gg_utt(c)) return SDUMC_OK;
+  if (c.deferred.empty() && (small_only || (c.gg.empty() && c.ggh.empty()))) return SDUMC_OK;
   RET(link(c, after, lane));
   c.use(lane);
   const bool grouped = gg_utt(c);
@@ -674,10 +679,20 @@ int flush_dw_on(const Ctx& c, int after, int lane, int slab) {
     if (!taken) RET(run(c, g));      // (fc_att, cross_fc_att, fc_out_v: 3 / 7 / 1 output rows)
   }
   c.deferred.clear();
+  if (small_only) {
+    c.use(after);
+    return SDUMC_OK;
+  }
   if (!c.gg.empty()) {
     const int rc = sdumc_gemm_group_tn(c.gg.data(), (int)c.gg.size(), c.p(c.pl.gg_slab[slab]),
                                        (size_t)c.pl.gg_slab_floats[slab] * sizeof(float), c.st);
     c.gg.clear();
+    if (rc != SDUMC_OK) return rc;
+  }
+  if (!c.ggh.empty()) {      // (same slab: this launch is ordered behind the previous one's reduce)
+    const int rc = sdumc_gemm_group_tn_bf16(c.ggh.data(), (int)c.ggh.size(), c.p(c.pl.gg_slab[slab]),
+                                            (size_t)c.pl.gg_slab_floats[slab] * sizeof(float), c.st);
+    c.ggh.clear();
     if (rc != SDUMC_OK) return rc;
   }
   c.use(after);
@@ -1420,8 +1435,11 @@ int keys_gemm_bwd_h(const Ctx& c, int m, int k0, int k1, int parts) {
 // the runs of a modality (streams whose text lengths differ) as its K segments
 bool keys_dw_groupable(const Ctx& c, int m) {
   if (c.pl.segs[m].size() > 2) return false;
-  for (const Seg& sg : c.pl.segs[m])
-    if (sg.x_samples < sg.V && sg.x_samples * sg.T < 16) return false;
+  const int min_mod = c.h() ? 64 : 16;
+  for (const Seg& sg : c.pl.segs[m]) {
+    const bool shared = c.h() ? (!c.d.train && sg.x_samples < sg.V) : sg.x_samples < sg.V;
+    if (shared && sg.x_samples * sg.T < min_mod) return false;
+  }
   return true;
 }
 void keys_dw_queue(const Ctx& c, int m, int k0, int k1) {
@@ -1432,20 +1450,27 @@ void keys_dw_queue(const Ctx& c, int m, int k0, int k1) {
     memset(&q, 0, sizeof(q));
     int s = 0;
     for (const Seg& sg : pl.segs[m]) {
-      q.A[s] = c.p(pl.dz[k][m]) + sg.row0 * D;
-      q.B[s] = c.p(sg.x_off);
       q.K[s] = sg.V * sg.T;
-      q.b_row_mod[s] = sg.x_samples < sg.V ? sg.x_samples * sg.T : 0;
-      const sdumc_dropout dd = in_drop(c, k, m, sg.T, sg.s0, sg.row0);
-      q.b_bits[s] = dd.enabled ? dd.bits : nullptr;
-      q.b_scale = dd.enabled ? dd.scale : 1.f;
+      if (c.h()) {     // bf16 storage: dz and the materialised masked frames xd (train) / the shared x (eval)
+        q.A[s] = reinterpret_cast<const float*>(c.ph(pl.dz[k][m], sg.row0 * D));
+        q.B[s] = reinterpret_cast<const float*>(c.d.train ? c.ph(pl.xd[k][m], sg.row0 * D) : c.ph(sg.x_off));
+        q.b_row_mod[s] = (!c.d.train && sg.x_samples < sg.V) ? sg.x_samples * sg.T : 0;
+      } else {
+        q.A[s] = c.p(pl.dz[k][m]) + sg.row0 * D;
+        q.B[s] = c.p(sg.x_off);
+        q.b_row_mod[s] = sg.x_samples < sg.V ? sg.x_samples * sg.T : 0;
+        const sdumc_dropout dd = in_drop(c, k, m, sg.T, sg.s0, sg.row0);
+        q.b_bits[s] = dd.enabled ? dd.bits : nullptr;
+        if (dd.enabled) q.b_scale = dd.scale;
+      }
       ++s;
     }
+    if (q.b_scale == 0.f) q.b_scale = 1.f;
     q.C = c.G + L.w;
     q.colsum_a = c.G + L.b;
     q.M = q.N = q.lda = q.ldb = q.ldc = D;
     q.bits_qw = D / 4;
-    c.gg.push_back(q);
+    (c.h() ? c.ggh : c.gg).push_back(q);
   }
 }
 
@@ -1604,6 +1629,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   // batch 1 of the weight gradients (heads, cross_attention_mlp, cross_*_mlp) -- in the grouped mode together with the
   // Cross_Attention input_proj dW, right behind the pooling backward that produces their dz
   if (!ca_dw_grouped) RET(flush_dw(c));
+  else RET(flush_dw_on(c, 0, 3, 0, true));
   if (grouped) {   // one grouped launch on the caller's stream, then the early key-projection backwards leave for their lanes
     sdumc_attnpool_bwd_t bb[4];
     int n = 0;
@@ -1724,7 +1750,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     GroupPtrs qq = {c.p(pl.d_q), D, NQ * D, c.p(pl.qin), (int64_t)V * D, D, c.p(pl.d_qin), (int64_t)V * D, D};
     RET(lin_bwd_grouped(c, pm.query, 7, V, qq));
   }
-  if (!gg_utt(c)) RET(flush_dw(c));   // batch 2: query_proj, the query MLPs (grouped mode: they wait for batch 3)
+  if (!gg_utt(c)) RET(flush_dw_on(c, 0, 3, 0, ggf));   // batch 2: query_proj, the query MLPs (grouped mode: they wait for batch 3)
   // 5'. fusion algebra (d_alpha already holds the second-level contribution)
   RET(sdumc_fusion_bwd(c.p(pl.u), c.p(pl.alpha), c.p(pl.d_qin), c.p(pl.d_u), c.p(pl.d_alpha), V, c.st));
   // 4'. fc_att, attention_mlp
@@ -1744,6 +1770,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   // batch 3: fc_att, attention_mlp, audio/text/video_mlp.  Grouped mode with the frame-level part following in this call:
   // they stay queued and ride with the FRA2UTT input_proj dW in one launch (below).
   if (!(ggf && (phases & 2))) RET(flush_dw(c));
+  else RET(flush_dw_on(c, 0, 3, 0, true));
   // the dW GEMMs of this part ran on lane 3: after this link [0, pm.early) is final on the caller's stream.  When the
   // frame-level part follows in the same call the link at its end does the same job.
   if (!(phases & 2)) RET(link(c, 3, 0));
@@ -1834,6 +1861,12 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
       if (s == 0) mark(c.st, 15 + 5 * m);
       const float* in = m == 0 ? c.io.audio : (m == 2 ? c.io.video : c.io.text[s]);
       const int rows = B * T;
+      if (c.h() && ggf && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+        fq.A[s] = reinterpret_cast<const float*>(c.ph(pl.dx[m][s]));
+        fq.B[s] = in;
+        fq.K[s] = rows;
+        continue;
+      }
       if (c.h()) {     // dW_frame = dx^T features on bf16 storage
         sdumc_gemm_bf16 gh = GH_(SDUMC_TN, D, din[m], rows);
         gh.A[0] = c.ph(pl.dx[m][s]);
@@ -1874,7 +1907,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
       fq.ldb = din[m];
       fq.ldc = din[m];
       fq.b_scale = 1.f;
-      c.gg.push_back(fq);
+      (c.h() ? c.ggh : c.gg).push_back(fq);
     }
   }
   c.use(0);
@@ -1883,7 +1916,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   RET(join_all(c));
   // grouped mode: the three frame_dim_reshape dW (29 of the step's 127 GFLOP at C2) in one launch on the caller's stream, once
   // every modality's dx is there
-  if (!c.gg.empty()) RET(flush_dw_on(c, 0, 0, 1));
+  if (!c.gg.empty() || !c.ggh.empty()) RET(flush_dw_on(c, 0, 0, 1));
   mark(c.st, 41);
   RET(link(c, 3, 0));   // the dW launches of lane 3
   return SDUMC_OK;

@@ -60,6 +60,8 @@ struct Launch {
   int32_t n;
   int32_t nwg;
   int32_t stagger;
+  int32_t bk;                // rows of K per k-tile: 16 (fp32 operands) or 64 (bf16 operands)
+  int32_t hf;                // 1: A and B are bf16 tensors (gg_tn_bf16_kernel); the accumulator tiles then keep their natural row order
   int32_t ovh;               // line positions charged to every unit for its fixed costs (ring start-up latency, epilogue): no k-tiles behind them
   float* slab;
 };
@@ -67,12 +69,12 @@ struct Launch {
 struct Geo {       // derived shape of one problem
   int ntn, ntiles, nk0, nk;
 };
-__host__ __device__ inline Geo geo_of(const sdumc_gg_problem& p) {
+__host__ __device__ inline Geo geo_of(const sdumc_gg_problem& p, int bk) {
   Geo g;
   g.ntn = (p.N + BN - 1) / BN;
   g.ntiles = g.ntn * ((p.M + BM - 1) / BM);
-  g.nk0 = (p.K[0] + BK - 1) / BK;
-  g.nk = g.nk0 + (p.K[1] > 0 ? (p.K[1] + BK - 1) / BK : 0);
+  g.nk0 = (p.K[0] + bk - 1) / bk;
+  g.nk = g.nk0 + (p.K[1] > 0 ? (p.K[1] + bk - 1) / bk : 0);
   return g;
 }
 // (32-bit products: the host refuses lines with L * nwg >= 2^31)
@@ -92,7 +94,7 @@ __device__ __forceinline__ Where locate(const Launch& L, int x) {
   Where w;
   int p = 0;
   while (p + 1 < L.n && L.line0[p + 1] <= x) ++p;
-  const Geo g = geo_of(L.p[p]);
+  const Geo g = geo_of(L.p[p], L.bk);
   const int nc = L.nchunk[p], ovh = L.ovh;
   const int xr = x - L.line0[p];
   // chunk c starts at line offset ntiles * (chunk_k(c) + c * ovh)
@@ -210,7 +212,7 @@ __global__ __launch_bounds__(NTHR, OCC) void gg_tn_kernel(const Launch L) {
   while (x < x_end) {
     const Where w = locate(L, x);
     const sdumc_gg_problem& pr = L.p[w.p];
-    const Geo g = geo_of(pr);
+    const Geo g = geo_of(pr, L.bk);
     const int px_end = min(x_end, w.unit_end);
     // k-tiles [ka, kb) of the problem's concatenated K (a range that ends inside the unit's overhead positions holds none)
     const int ka = w.kt, kb = w.kt_end - (w.unit_end - px_end);
@@ -413,17 +415,236 @@ __global__ __launch_bounds__(NTHR, OCC) void gg_tn_kernel(const Launch L) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The same launch on bf16 STORAGE (the engine's bf16 mode, BASELINE configs[2] / [4]): dz / dx and the (masked) frames / features
+// are bf16 tensors, products accumulate in fp32 on v_mfma_f32_32x32x16_bf16, C and the slabs are fp32.  Tile 256 x 128 x 64 k
+// (48 KiB per stage, 3 stages).  Operands are row-contiguous ([k][row] tiles); an MFMA operand -- 8 consecutive k of one row --
+// comes out of two transposing reads (ds_read_b64_tr_b16: a 16-lane group reads a 4 k x 16 row block).  The 16-byte chunks of
+// a k-row are XOR-swizzled by 4 (k & 3) (applied to the DMA's source address and again at the read): the four k-rows of a
+// transposing read are a multiple of 256 bytes apart and would otherwise share their banks.
+// At bf16 MFMA rates this kernel is bound by the operand stream (48 KiB per 1024 matrix-pipe cycles and CU), not by the
+// matrix cores; what the grouping buys is the same as in fp32 -- every CU streams for the same time, one launch, one reduce.
+// ------------------------------------------------------------------------------------------------------------------------
+namespace hf {
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+constexpr int HBK = 64, HNST = 3;
+constexpr int HA_BYTES = HBK * BM * 2, HB_BYTES = HBK * BN * 2, HSTAGE = HA_BYTES + HB_BYTES;
+constexpr int HA_CH = HA_BYTES / 1024, HB_CH = HB_BYTES / 1024, HNI = (HA_CH + HB_CH) / NW;     // 32 + 16 pieces, 6 per wave
+static_assert(HNI == 6 && HA_CH % NW == 0, "pieces per wave");
+}  // namespace hf
+
+__global__ __launch_bounds__(NTHR, 2) void gg_tn_bf16_kernel(const Launch L) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using namespace hf;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
+  const int LL = L.line0[L.n];
+  const int wg = blockIdx.x;
+  int x = range_begin(wg, LL, L.nwg);
+  const int x_end = range_begin(wg + 1, LL, L.nwg);
+  constexpr int PER = HNI;
+
+  f32x16 acc[TM][TN];
+  float csum[TM];
+
+  // one MFMA operand: rows rowbase + li, k = 16 s + 8 lh .. + 7 of a [k][BR] tile
+  auto frag = [&](const char* tile, int rowbase, int s, int BR) -> bf16x8 {
+    const int g16 = (lane >> 4) & 1, i16 = lane & 15, q = i16 >> 2, p = i16 & 3;
+    const int k0 = 16 * s + 8 * lh + q;                    // this lane's k row of the first read (the second: k0 + 4, same k & 3)
+    const int col = rowbase + 16 * g16 + 4 * p;            // first of the 4 columns this lane addresses
+    const int chunk = (col >> 3) ^ ((k0 & 3) << 2);
+    const char* a0 = tile + (k0 * BR + chunk * 8 + (col & 7)) * 2;
+    const s16x4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+    const s16x4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 4 * BR * 2));
+    s16x8 v = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+    return *reinterpret_cast<bf16x8*>(&v);
+  };
+
+  while (x < x_end) {
+    const Where w = locate(L, x);
+    const sdumc_gg_problem& pr = L.p[w.p];
+    const Geo g = geo_of(pr, L.bk);
+    const int px_end = min(x_end, w.unit_end);
+    const int ka = w.kt, kb = w.kt_end - (w.unit_end - px_end);
+    if (kb <= ka) {
+      x = px_end;
+      continue;
+    }
+    const int tile_m = w.tile / g.ntn, tile_n = w.tile - tile_m * g.ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const bool do_cs = pr.colsum_a != nullptr && tile_n == 0 && wn0 == 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      csum[i] = 0.f;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    }
+#pragma nounroll
+    for (int seg = 0; seg < 2; ++seg) {
+      int t0, nk;
+      if (seg == 0) {
+        if (ka >= g.nk0) continue;
+        t0 = ka;
+        nk = min(kb, g.nk0) - ka;
+      } else {
+        if (kb <= g.nk0) continue;
+        t0 = max(ka, g.nk0) - g.nk0;
+        nk = kb - g.nk0 - t0;
+      }
+      const int kbeg = t0 * HBK;
+      const int segK = pr.K[seg], seg_mod = pr.b_row_mod[seg];
+      const uint32_t lda2 = (uint32_t)pr.lda * 2u, ldb2 = (uint32_t)pr.ldb * 2u;
+      // (rows at and beyond K lie outside the descriptors' ranges: zeros)
+      const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.A[seg]), 0, (int)((uint32_t)segK * lda2), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.B[seg]), 0, (int)((uint32_t)(seg_mod > 0 ? seg_mod : segK) * ldb2), 0x00020000);
+      // pieces of this wave: A pieces wave + 8 i (i < 4): k-rows 2 piece, 2 piece + 1 of the 64 (a k-row of 256 bf16 = 32 chunks);
+      // B pieces wave + 8 i (i < 2): k-rows 4 piece .. 4 piece + 3 (a k-row of 128 bf16 = 16 chunks).  Lane l of a piece writes LDS
+      // chunk position (piece * 64 + l); the column chunk it FETCHES is that position's chunk index ^ 4 (k & 3).
+      uint32_t voff[HNI];
+      int srck = 0;      // B rows with a modulo: source row of B piece 0 of this wave's lane (pieces advance by a fixed 32 rows)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int q = ((wave + 8 * i) << 6) + lane, krow = q >> 5, cpos = q & 31;
+        const int c = cpos ^ ((krow & 3) << 2);
+        voff[i] = (uint32_t)(kbeg + krow) * lda2 + (uint32_t)min(m0 + 8 * c, pr.M - 8) * 2u;
+      }
+      int bk_row[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int q = ((wave + 8 * i) << 6) + lane, krow = q >> 4, cpos = q & 15;
+        const int c = cpos ^ ((krow & 3) << 2);
+        int kr = kbeg + krow;
+        if (seg_mod > 0) kr %= seg_mod;
+        bk_row[i] = kr;
+        voff[4 + i] = (uint32_t)kr * ldb2 + (uint32_t)min(n0 + 8 * c, pr.N - 8) * 2u;
+      }
+      (void)srck;
+      auto issue = [&](int buf) {
+        char* base = lds + buf * HSTAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(base + (wave + 8 * i) * 1024), 16, voff[i], 0, 0, 0);
+          voff[i] += (uint32_t)HBK * lda2;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(base + HA_BYTES + (wave + 8 * i) * 1024), 16, voff[4 + i], 0, 0, 0);
+          voff[4 + i] += (uint32_t)HBK * ldb2;
+          if (seg_mod > 0) {
+            bk_row[i] += HBK;
+            while (bk_row[i] >= seg_mod) { bk_row[i] -= seg_mod; voff[4 + i] -= (uint32_t)seg_mod * ldb2; }
+          }
+        }
+      };
+      auto compute = [&](const char* base) {
+#pragma unroll
+        for (int s = 0; s < HBK / 16; ++s) {
+          bf16x8 af[TM], bfr[TN];
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[i] = frag(base, wm0 + 32 * i, s, BM);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) bfr[j] = frag(base + HA_BYTES, wn0 + 32 * j, s, BN);
+          if (do_cs) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int e = 0; e < 8; ++e) csum[i] += (float)af[i][e];
+          }
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+      };
+#pragma unroll
+      for (int s = 0; s < HNST - 1; ++s)
+        if (s < nk) issue(s);
+      int buf = 0, ibuf = HNST - 1;
+#pragma nounroll
+      for (int t = 0; t < nk; ++t) {
+        if (t + HNST - 2 < nk) __builtin_amdgcn_s_waitcnt(waitcnt_vm((HNST - 2) * PER));
+        else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+        __builtin_amdgcn_s_barrier();
+        if (t + HNST - 1 < nk) issue(ibuf);
+        compute(lds + buf * HSTAGE);
+        buf = buf + 1 == HNST ? 0 : buf + 1;
+        ibuf = ibuf + 1 == HNST ? 0 : ibuf + 1;
+      }
+      __builtin_amdgcn_s_barrier();
+    }
+    const bool direct = L.nchunk[w.p] == 1 && ka == 0 && kb == g.nk;
+    if (direct) {
+      const bool accum = pr.accumulate != 0;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int col = n0 + wn0 + 32 * j + li;
+          if (col >= pr.N) continue;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (row >= pr.M) continue;
+            float* dst = pr.C + ((uint32_t)row * (uint32_t)pr.ldc + (uint32_t)col);
+            float v = acc[i][j][e];
+            if (accum) v += *dst;
+            *dst = v;
+          }
+        }
+      if (do_cs) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float v = csum[i] + __shfl_xor(csum[i], 32, 64);
+          const int m = m0 + wm0 + 32 * i + li;
+          if (lh == 0 && m < pr.M) {
+            float* dst = pr.colsum_a + m;
+            *dst = accum ? *dst + v : v;
+          }
+        }
+      }
+    } else {
+      float* slot = L.slab + (size_t)(wg + w.unit) * SLOT_FLOATS;
+      float* mine = slot + (uint32_t)(wave * 16 * 64 + lane) * 4u;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            *reinterpret_cast<f32x4*>(mine + ((i * TN + j) * 4 + q) * 256) = v;
+          }
+      if (do_cs) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float v = csum[i] + __shfl_xor(csum[i], 32, 64);
+          if (lh == 0) slot[BM * BN + wm0 + 32 * i + li] = v;
+        }
+      }
+    }
+    x = px_end;
+  }
+#endif
+}
+
 // One workgroup per (tile, part): parts 0..15 = the sixteen float4 chunks a lane holds of its wave's 64 x 64 block, part 16 =
 // the column sums of A.  Sums the tile's slab slots in ascending k order and writes C (the GEMM kernel's epilogue arithmetic).
 __global__ __launch_bounds__(NTHR) void gg_reduce_kernel(const Launch L, const int tiles_total) {
   const int part = blockIdx.y;
   int tg = blockIdx.x;
   int p = 0;
-  Geo g = geo_of(L.p[0]);
+  Geo g = geo_of(L.p[0], L.bk);
   while (p + 1 < L.n && tg >= g.ntiles) {
     tg -= g.ntiles;
     ++p;
-    g = geo_of(L.p[p]);
+    g = geo_of(L.p[p], L.bk);
   }
   const sdumc_gg_problem& pr = L.p[p];
   const int nc = L.nchunk[p];
@@ -461,11 +682,12 @@ __global__ __launch_bounds__(NTHR) void gg_reduce_kernel(const Launch L, const i
   }
   const int li = lane & 31, lh = lane >> 5;
   const int ij = part >> 2, q = part & 3, i = ij / TN, j = ij - i * TN;
-  const int col = n0 + (wave % WGN) * WN + 2 * li + j;
+  const int col = n0 + (wave % WGN) * WN + (L.hf ? 32 * j + li : 2 * li + j);
   if (col >= pr.N) return;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
-    const int row = m0 + (wave / WGN) * WM + 2 * (e + 8 * q + 4 * lh) + i;
+    const int rr = e + 8 * q + 4 * lh;
+    const int row = m0 + (wave / WGN) * WM + (L.hf ? 32 * i + rr : 2 * rr + i);
     if (row >= pr.M) continue;
     float* dst = pr.C + (size_t)row * pr.ldc + col;
     *dst = pr.accumulate ? *dst + s[e] : s[e];
@@ -506,6 +728,8 @@ bool set_lds_attr() {   // the dynamic-LDS limit is a per-device function attrib
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_tn_kernel<5, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * STAGE_BYTES) != hipSuccess)
       return false;
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_tn_kernel<5, 2, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * STAGE_BYTES);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_tn_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, hf::HNST * hf::HSTAGE) != hipSuccess)
+      return false;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_tn_kernel<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE_BYTES) != hipSuccess)
       return false;
     done[dev] = true;
@@ -534,18 +758,21 @@ bool valid(const sdumc_gg_problem& p) {
 }
 
 // fills L for problems [first, first + n); returns the number of tiles
-int plan(const sdumc_gg_problem* probs, int n, int nwg_max, Launch& L, int& units) {
+int plan(const sdumc_gg_problem* probs, int n, int nwg_max, bool hf, Launch& L, int& units) {
   memset(&L, 0, sizeof(L));
   L.n = n;
+  L.hf = hf ? 1 : 0;
+  L.bk = hf ? 64 : BK;
   // (measured on MI355X, tools/gg_bench.py, all 37 problems of a C2 backward in one launch: 623 us with 0, 515 with 2, 490 with 3-4,
   //  494-500 with 6-12: a unit's ring start-up -- the HBM latency of its first stage -- and its epilogue are worth ~3 k-tiles)
   static const int ovh = [] { const char* e = getenv("SDUMC_GG_OVH"); return e ? atoi(e) : 3; }();
-  L.ovh = ovh;
+  static const int ovh_hf = [] { const char* e = getenv("SDUMC_GG_OVH_BF16"); return e ? atoi(e) : 5; }();   // (a 64-row bf16 k-tile is ~3x shorter)
+  L.ovh = hf ? ovh_hf : ovh;
   int line = 0, tiles = 0;
   units = 0;
   for (int i = 0; i < n; ++i) {
     L.p[i] = probs[i];
-    const Geo g = geo_of(probs[i]);
+    const Geo g = geo_of(probs[i], L.bk);
     L.nchunk[i] = 1;
     L.line0[i] = line;
     L.unit0[i] = units;
@@ -564,44 +791,62 @@ using namespace sdumc_gg;
 
 // engine.hip: slab bytes that cover any problem list with at most `tiles` output tiles (256 x 128) on the current device; also
 // the place where the kernels' per-device attributes are set outside any stream capture
+bool valid_bf16(const sdumc_gg_problem& p) {
+  if (!p.A[0] || !p.B[0] || !p.C || p.M < 8 || p.N < 8 || (p.M & 7) || (p.N & 7) || (p.lda & 7) || (p.ldb & 7) || p.K[0] <= 0 || p.K[1] < 0)
+    return false;
+  if (p.lda < p.M || p.ldb < p.N || p.ldc < p.N || p.M > BM * 255) return false;
+  for (int s = 0; s < 2; ++s) {
+    if (p.K[s] == 0) continue;
+    if (!p.A[s] || !p.B[s] || p.b_bits[s]) return false;      // no fused dropout on bf16 storage: the engine materialises the masked frames
+    if ((reinterpret_cast<uintptr_t>(p.A[s]) | reinterpret_cast<uintptr_t>(p.B[s])) & 15) return false;
+    if (p.b_row_mod[s] < 0 || (p.b_row_mod[s] > 0 && p.b_row_mod[s] < 64)) return false;
+    const size_t brows = p.b_row_mod[s] > 0 ? (size_t)p.b_row_mod[s] : (size_t)p.K[s];
+    const size_t pad = 4 * 64;
+    if (((size_t)p.K[s] + pad) * p.lda * 2 >= 0x7FFFFFF0u || (brows + pad) * p.ldb * 2 >= 0x7FFFFFF0u) return false;
+  }
+  return true;
+}
+
 extern "C" size_t sdumc_gg_slab_bytes_(int tiles) {
   (void)set_lds_attr();
   return (size_t)(cu_count() * wg_per_cu() + tiles) * SLOT_FLOATS * sizeof(float);
 }
 
-extern "C" size_t sdumc_gemm_group_workspace_bytes(const sdumc_gg_problem* probs, int32_t n) {
+namespace {
+size_t gg_workspace_bytes(const sdumc_gg_problem* probs, int32_t n, bool hf) {
   if (!probs || n <= 0) return 0;
-  const int nwg = cu_count() * wg_per_cu();
+  const int nwg = cu_count() * (hf ? 1 : wg_per_cu());
   size_t need = 0;
   for (int first = 0; first < n; first += MAXP) {
     const int cnt = std::min(MAXP, n - first);
     Launch L;
     int units = 0;
-    plan(probs + first, cnt, nwg, L, units);
+    plan(probs + first, cnt, nwg, hf, L, units);
     need = std::max(need, (size_t)(L.nwg + units) * SLOT_FLOATS * sizeof(float) + (dbg_mode() == 5 ? (size_t)L.nwg * 96 : 0));
   }
   return need;
 }
 
-extern "C" int sdumc_gemm_group_tn(const sdumc_gg_problem* probs, int32_t n, void* workspace, size_t workspace_bytes, void* stream) {
+int gg_run(const sdumc_gg_problem* probs, int32_t n, void* workspace, size_t workspace_bytes, bool hf, void* stream) {
   if (!probs || n <= 0 || !workspace || (reinterpret_cast<uintptr_t>(workspace) & 15)) return SDUMC_EINVAL;
   for (int i = 0; i < n; ++i)
-    if (!valid(probs[i])) return SDUMC_EINVAL;
-  if (workspace_bytes < sdumc_gemm_group_workspace_bytes(probs, n)) return SDUMC_ENOMEM;
+    if (!(hf ? valid_bf16(probs[i]) : valid(probs[i]))) return SDUMC_EINVAL;
+  if (workspace_bytes < gg_workspace_bytes(probs, n, hf)) return SDUMC_ENOMEM;
   if (!set_lds_attr()) return SDUMC_ELAUNCH;
-  const int per_cu = wg_per_cu();
+  const int per_cu = hf ? 1 : wg_per_cu();
   const int nwg = cu_count() * per_cu;
   hipStream_t st = as_stream(stream);
   for (int first = 0; first < n; first += MAXP) {
     const int cnt = std::min(MAXP, n - first);
     Launch L;
     int units = 0;
-    const int tiles = plan(probs + first, cnt, nwg, L, units);
+    const int tiles = plan(probs + first, cnt, nwg, hf, L, units);
     if ((long long)L.line0[cnt] * (L.nwg + 1) >= (1LL << 31)) return SDUMC_EINVAL;   // 32-bit index arithmetic in the kernels
     L.slab = static_cast<float*>(workspace);
     static const int stag = [] { const char* e = getenv("SDUMC_GG_STAGGER"); return e ? atoi(e) : 1; }();
     L.stagger = stag;
-    if (per_cu == 2) hipLaunchKernelGGL((gg_tn_kernel<3, 4>), dim3(L.nwg), dim3(NTHR), 3 * STAGE_BYTES, st, L);
+    if (hf) hipLaunchKernelGGL(gg_tn_bf16_kernel, dim3(L.nwg), dim3(NTHR), hf::HNST * hf::HSTAGE, st, L);
+    else if (per_cu == 2) hipLaunchKernelGGL((gg_tn_kernel<3, 4>), dim3(L.nwg), dim3(NTHR), 3 * STAGE_BYTES, st, L);
     else if (dbg_mode() == 5) hipLaunchKernelGGL((gg_tn_kernel<5, 2, 5>), dim3(L.nwg), dim3(NTHR), 5 * STAGE_BYTES, st, L);
     else hipLaunchKernelGGL((gg_tn_kernel<5, 2>), dim3(L.nwg), dim3(NTHR), 5 * STAGE_BYTES, st, L);
     SDUMC_CHECK_LAUNCH();
@@ -609,4 +854,15 @@ extern "C" int sdumc_gemm_group_tn(const sdumc_gg_problem* probs, int32_t n, voi
     SDUMC_CHECK_LAUNCH();
   }
   return SDUMC_OK;
+}
+}  // namespace
+
+extern "C" size_t sdumc_gemm_group_workspace_bytes(const sdumc_gg_problem* probs, int32_t n) { return gg_workspace_bytes(probs, n, false); }
+extern "C" int sdumc_gemm_group_tn(const sdumc_gg_problem* probs, int32_t n, void* workspace, size_t workspace_bytes, void* stream) {
+  return gg_run(probs, n, workspace, workspace_bytes, false, stream);
+}
+// A, B: bf16 tensors (lda / ldb in elements; M, N, lda, ldb multiples of 8; no fused dropout), C and colsum_a fp32
+extern "C" size_t sdumc_gemm_group_bf16_workspace_bytes(const sdumc_gg_problem* probs, int32_t n) { return gg_workspace_bytes(probs, n, true); }
+extern "C" int sdumc_gemm_group_tn_bf16(const sdumc_gg_problem* probs, int32_t n, void* workspace, size_t workspace_bytes, void* stream) {
+  return gg_run(probs, n, workspace, workspace_bytes, true, stream);
 }

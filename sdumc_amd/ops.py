@@ -104,11 +104,12 @@ def gemm_group_tn(problems, workspace=None):
         g.colsum_a = ptr(q.get("colsum"))
         g.accumulate = 1 if q.get("accumulate") else 0
         keep.append(Cm)
-    need = lib.sdumc_gemm_group_workspace_bytes(arr, n)
+    hf = problems[0]["A"].dtype == torch.bfloat16      # bf16 storage: sdumc_gemm_group_tn_bf16 (C stays fp32)
+    need = (lib.sdumc_gemm_group_bf16_workspace_bytes if hf else lib.sdumc_gemm_group_workspace_bytes)(arr, n)
     if workspace is None:
         workspace = torch.empty(max(need, 16), dtype=torch.uint8, device=problems[0]["A"].device)
-    check(lib.sdumc_gemm_group_tn(arr, n, ptr(workspace), workspace.numel() * workspace.element_size(), _st()),
-          "sdumc_gemm_group_tn")
+    fn = lib.sdumc_gemm_group_tn_bf16 if hf else lib.sdumc_gemm_group_tn
+    check(fn(arr, n, ptr(workspace), workspace.numel() * workspace.element_size(), _st()), "sdumc_gemm_group_tn")
     return [q["C"] for q in problems]
 
 

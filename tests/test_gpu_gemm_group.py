@@ -157,3 +157,45 @@ def test_full_size_frame_problems_property(ops):
     close(whole, (h0.double() + h1.double()), 1e-5)
     old = ops.gemm(ops.TN, A, B, M, N, K, splitk=0)
     close(whole, old.double(), 1e-5)
+
+
+def make_bf16(specs, seed):
+    g = torch.Generator().manual_seed(seed)
+    probs = []
+    for sp in specs:
+        M, N, K, mod = sp["M"], sp["N"], sp["K"], sp.get("mod", 0)
+        q = {"A": torch.randn(K, M, generator=g).bfloat16().cuda(), "B": torch.randn(mod or K, N, generator=g).bfloat16().cuda(),
+             "b_row_mod": mod}
+        if sp.get("K1"):
+            q["A1"] = torch.randn(sp["K1"], M, generator=g).bfloat16().cuda()
+            q["B1"] = torch.randn(sp["K1"], N, generator=g).bfloat16().cuda()
+        if sp.get("cs", True):
+            q["colsum"] = torch.zeros(M).cuda()
+        probs.append(q)
+    return probs
+
+
+def test_bf16_storage_problems(ops):
+    """sdumc_gemm_group_tn_bf16: bf16 operands, fp32 accumulation and output, against fp64 products of the same bf16 values
+    (2e-5: only the summation differs), bit-identical repeats; shapes of the frame-level problems at reduced K, ragged K,
+    the row modulo, two K segments, narrow M / N, and a mix in one launch"""
+    specs = [dict(M=256, N=1024, K=3000), dict(M=256, N=256, K=4096, mod=2048), dict(M=256, N=512, K=1000, K1=1030),
+             dict(M=128, N=256, K=77), dict(M=64, N=64, K=640), dict(M=256, N=128, K=64), dict(M=8, N=16, K=200),
+             dict(M=256, N=2048, K=512, K1=512, cs=False)]
+    for sp in specs:
+        probs = make_bf16([sp], 3 + sp["K"])
+        outs = ops.gemm_group_tn(probs)
+        first = outs[0].clone()
+        w, cs = ref_of(probs[0], {})
+        close(outs[0], w, 2e-5, str(sp))
+        if probs[0].get("colsum") is not None:
+            close(probs[0]["colsum"], cs, 2e-5, "colsum " + str(sp))
+        probs[0]["C"].fill_(float("nan"))
+        assert torch.equal(ops.gemm_group_tn(probs)[0], first)
+    probs = make_bf16(specs, 77)
+    outs = ops.gemm_group_tn(probs)
+    for i, q in enumerate(probs):
+        w, cs = ref_of(q, {})
+        close(outs[i], w, 2e-5, f"mixed launch, problem {i}")
+        if q.get("colsum") is not None:
+            close(q["colsum"], cs, 2e-5)
