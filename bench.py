@@ -32,6 +32,7 @@ DIMS = (1024, 4096, 1024, 4096)         # WavLM-L / Vicuna-7B / MANet / Vicuna-7
 TRAIN_FLOPS_PER_SAMPLE = 1980.7e6       # algorithmic, audio/video projection counted once
 PEAK_F32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0          # same guide: dense bf16 matrix peak (the bf16-operand kernels are priced against it)
+PEAK_HBM_GBS = 8000.0                  # same guide: HBM3E peak (6.3 TB/s achievable with a streaming copy)
 # The default is the configuration the metric is quoted on (configs[1]); the others are the parity-test shapes of
 # SURVEY §8, selectable for side measurements (`--workload c1|c5`), never what the driver's default run reports.
 WORKLOADS = {   # name: (batch per GPU, T, dims, algorithmic train FLOPs per sample, description)
@@ -186,7 +187,7 @@ def roofline_leg(_lib, launch, steps, traffic_ok=True):
     top = rows[0]
     # the committed PMC summary was collected on the default workload in fp32: it describes no other configuration
     traffic, traffic_src = recorded_traffic(top["kernel"]) if traffic_ok else (None, None)
-    bf16_kernel = top["kernel"].startswith("gemm_bf16")      # bf16-operand (gemm_bf16_*) and bf16-storage (gemm_bf16s_*) kernels
+    bf16_kernel = top["kernel"].startswith("gemm_bf16") or top["kernel"].endswith("_bf16")   # bf16-operand / bf16-storage kernels
     peak = PEAK_BF16_MFMA_TFLOPS if bf16_kernel else PEAK_F32_MFMA_TFLOPS
     return {"bound": "mfma", "achieved": round(top["tflops"], 2), "peak": peak, "unit": "TFLOP/s",
             "frac": round(top["tflops"] / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -195,6 +196,29 @@ def roofline_leg(_lib, launch, steps, traffic_ok=True):
             "launches_per_step": top["launches_per_step"],
             "gemm_ms_per_step": round(sum(r["ms_per_step"] for r in rows), 4),
             "all_gemm_variants": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]}
+
+
+def hbm_roofline_bf16(ms_per_step, mfma):
+    """bf16 storage: at bf16 MFMA rates (16x fp32) the step is bound by HBM traffic and by the latency of its launch chain, not by
+    the matrix cores.  achieved = HBM-side bytes per step (profiles/pmc_traffic_bf16.json: separate rocprofv3 FETCH_SIZE /
+    WRITE_SIZE passes over this command, fetch x2 gfx950 correction) / the measured step time; the MFMA figure of the dominant
+    GEMM stays as a side key.  Bytes are reported only when the summary was collected on these kernel sources."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "pmc_traffic_bf16.json")
+    traffic, src = None, None
+    try:
+        with open(path) as f:
+            doc = json.load(f)
+        if doc.get("source_sha") == source_sha():
+            traffic = int(doc["per_step"]["fetch_bytes"] + doc["per_step"]["write_bytes"])
+            src = "profiles/pmc_traffic_bf16.json (whole step, rocprofv3 PMC passes on these sources)"
+        else:
+            src = f"profiles/pmc_traffic_bf16.json is stale (collected on sources {doc.get('source_sha')}, this build is {source_sha()})"
+    except (OSError, ValueError, KeyError):
+        pass
+    ach = traffic / (ms_per_step * 1e-3) / 1e9 if traffic else None
+    return {"bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": round(ach / PEAK_HBM_GBS, 4) if ach else None, "traffic": traffic, "traffic_source": src,
+            "kernel": "whole step (HBM-side bytes of every launch)", "mfma": mfma}
 
 
 def recorded_traffic(kernel):
@@ -315,9 +339,6 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help=argparse.SUPPRESS)   # old spelling of the default
     ap.add_argument("--serial-lanes", action="store_true",
                     help="keep every kernel on one stream (for rocprofv3 --kernel-trace: per-kernel durations)")
-    ap.add_argument("--background-lane", action="store_true",
-                    help="issue the Cross_Attention-site key-projection GEMMs on a fourth stream beside the utterance-level "
-                         "chain instead of grouped with the FRA2UTT ones (A/B switch; measured +0.8 %% per step)")
     ap.add_argument("--bf16", action="store_true",
                     help="BASELINE configs[2] arithmetic: bf16 operands (fp32 accumulate) in the frame-level projections, "
                          "forward and backward; NOT the default workload (configs[1] is fp32)")
@@ -369,8 +390,6 @@ def main():
 
     if args.serial_lanes:
         _lib.lib.sdumc_set_concurrency(0)
-    if args.background_lane or "SDUMC_BG_MODE" in os.environ:   # experiment knob; the library default is mode 2 (forward only)
-        _lib.lib.sdumc_set_background_lane(int(os.environ.get("SDUMC_BG_MODE", "2")))
     flat, lay = init_flat_params(engine, dev)
     if epoch:
         if world != 1:
@@ -443,7 +462,7 @@ def main():
                    "batch_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU,
                    "T_audio_text_video_feat4": list(T_MOSEI), "feature_dims": list(DIMS),
                    "parallelism": f"dp{world}" if world > 1 else ("dp1 (one-rank RCCL communicator, all collectives issued)" if force_dp else "single"),
-                   "launch": "hipGraph replay" if (args.graph and world == 1) else "eager, 4 lanes (caller stream + 2 high-priority modality side streams + 1 side stream for dW batches, keep-bits and the forward Cross_Attention key GEMMs)",
+                   "launch": "hipGraph replay" if (args.graph and world == 1) else "eager, 4 lanes (caller stream + 2 high-priority modality side streams + 1 side stream for the grouped weight-gradient launches, keep-bits and the forward Cross_Attention key GEMMs)",
                    "params": lay.total, "final_loss": round(float(losses[0]), 5)},
         "whole_step_tflops": round(value * TRAIN_FLOPS_PER_SAMPLE / 1e12, 2),
         "whole_step_frac_of_f32_mfma_peak": round(value * TRAIN_FLOPS_PER_SAMPLE / 1e12 / (world * PEAK_F32_MFMA_TFLOPS), 4),
@@ -454,7 +473,7 @@ def main():
         roof = roofline_leg(_lib, step.launch if (world == 1 and not force_dp) else step.step, max(3, min(10, args.steps)),
                             traffic_ok=(args.workload == "c2" and not args.bf16))
         if rank == 0:
-            out["roofline"] = roof
+            out["roofline"] = hbm_roofline_bf16(out["ms_per_step"], roof) if (args.bf16 and args.workload == "c2" and world == 1) else roof
     if rank == 0 and world == 1:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_leg()

@@ -405,8 +405,8 @@ inline void mark(hipStream_t st, int id) {
 }
 bool g_concurrency = true;   // sdumc_set_concurrency(0): everything on the caller's stream (profiling)
 int g_background = 3;      // 0 off; 2 forward only (+1.0 % per step over 0); 3 (default) = 2 + the AUDIO Cross_Attention key-projection
-                           // backward early on lane 3 (+0.6 % over 2: it shortens the longest frame-level chain); 4 = audio + video (+0.4 %);
-                           // 1 = all three (-1.6 %)
+                           // backward early on lane 3 (it shortens the longest frame-level chain; more modalities early measured
+                           // slower in rounds 1 and 2: profiles/README.md)
 
 // The side lanes are HIGH-priority streams.  The HIP runtime multiplexes the streams of one priority class onto
 // GPU_MAX_HW_QUEUES (default 4) hardware queues, handing a new stream the least-used queue: once other components
@@ -414,25 +414,21 @@ int g_background = 3;      // 0 off; 2 forward only (+1.0 % per step over 0); 3 
 // land on ONE hardware queue and the three modality chains serialise -- measured on MI355X: 2.59-2.63 ms per step
 // instead of 2.18 whenever the process group had been initialised first (tools/rccl_queue_probe.py), and 2.18 again
 // with GPU_MAX_HW_QUEUES=8 or with the lanes in their own priority class (2.17-2.20 ms in both orders).
-// SDUMC_LANE_PRIORITY=normal|low restores / varies the class for experiments.
 // (Measured and rejected for lane 3: a stream confined to 7/8 or 1/2 of the CUs with hipExtStreamCreateWithCUMask, 128x128
 // tiles on it, the lowest priority, a fourth side stream of the same class: profiles/README.md.)
 bool create_lanes(LaneSet& S) {
   if (hipGetDevice(&S.device) != hipSuccess) return false;
   int least = 0, greatest = 0;
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return false;
-  const char* e = getenv("SDUMC_LANE_PRIORITY");
-  const int prio = (e && e[0] == 'n') ? 0 : ((e && e[0] == 'l') ? least : greatest);
-  int lane_prio[2] = {prio, prio};
-  if (const char* e2 = getenv("SDUMC_LANE_PRIORITIES"))    // experiment knob: one letter (h/n/l) per side lane
-    for (int i = 0; i < 2 && e2[i]; ++i) lane_prio[i] = e2[i] == 'n' ? 0 : (e2[i] == 'l' ? least : greatest);
+  (void)least;
+  const int prio = greatest;
   for (int i = 0; i < 2; ++i)
-    if (hipStreamCreateWithPriority(&S.s[i], hipStreamNonBlocking, lane_prio[i]) != hipSuccess) return false;
+    if (hipStreamCreateWithPriority(&S.s[i], hipStreamNonBlocking, prio) != hipSuccess) return false;
   for (unsigned i = 0; i < LaneSet::NEV; ++i)
     if (hipEventCreateWithFlags(&S.ev[i], hipEventDisableTiming) != hipSuccess) return false;
-  int bg_prio = prio;
-  if (const char* e3 = getenv("SDUMC_BG_PRIORITY")) bg_prio = e3[0] == 'n' ? 0 : (e3[0] == 'l' ? least : greatest);
-  if (hipStreamCreateWithPriority(&S.bg, hipStreamNonBlocking, bg_prio) != hipSuccess) return false;
+  // (lane 3 at the lowest priority, so that the grouped weight-gradient launches would only fill what the critical lanes
+  //  leave: measured 1.877 vs 1.784 ms per step -- the launches then start late and end up as the step's tail)
+  if (hipStreamCreateWithPriority(&S.bg, hipStreamNonBlocking, prio) != hipSuccess) return false;
   S.ok = true;
   return true;
 }
@@ -493,7 +489,7 @@ struct Ctx {
     sts[0] = st;
     multi = S.ok && g_concurrency;
     bg = g_background != 0;               // the launch decomposition is the same with and without real streams
-    bgb = g_background == 1 ? 7 : (g_background == 3 ? 1 : (g_background == 4 ? 5 : 0));   // 3: audio only, 4: audio + video
+    bgb = g_background == 3 ? 1 : 0;      // 3: the audio modality's
     {   // under hipGraph capture the extra lane-3 dependencies (three lanes -> lane 3 -> lane 0) make hipStreamEndCapture
         // segfault on this stack (ROCm 7.0 runtime inside torch 2.10): captured steps keep the grouped launches
       hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -535,11 +531,6 @@ struct LaneMap {
   // high-priority streams, so this gives the longest chain dispatch preference: 29.87 k samples/s against 29.72 k with audio on
   // the caller's stream ({0, 2, 1}), the better of the two in each of four alternations (six permutations tried)
   int v[3] = {2, 1, 0};
-  LaneMap() {
-    if (const char* e = getenv("SDUMC_LANE_MAP"))      // experiment knob: three digits, lane of audio / text / video
-      if (strlen(e) == 3)
-        for (int i = 0; i < 3; ++i) v[i] = (e[i] - '0') % 3;
-  }
   int operator[](int m) const { return v[m]; }
 };
 const LaneMap LANE_OF;
@@ -624,9 +615,9 @@ bool gg_on() {
   return on;
 }
 // the queued weight-gradient GEMMs go through ONE persistent launch (gemm_group.hip)
-// (not in bf16-storage mode: there only the small utterance-level products would go through it, in three launches that each
-//  hold the whole chip -- measured 1.108 vs 1.098 ms per step)
-bool gg_utt(const Ctx& c) { static const int hfu = [] { const char* e = getenv("SDUMC_GG_UTT_HF"); return e ? atoi(e) : 1; }(); return gg_on() && (!c.h() || hfu); }
+// (bf16-storage mode too: its utterance-level operands are fp32; ONE launch behind the frame-level pooling backward -- 1.087 vs
+//  1.107 ms per step against the fifteen per-layer launches, which end up as lane 3's tail)
+bool gg_utt(const Ctx& c) { (void)c; return gg_on(); }
 // ... and so do the frame-level ones (input_proj of both attention sites, frame_dim_reshape), on fp32 or on bf16 storage
 // (not in the operand-rounding mode bf16 = 1, whose products round fp32 operands while staging them)
 bool gg_frame(const Ctx& c) { return gg_on() && (c.h() || c.d.bf16 == 0); }
@@ -657,11 +648,8 @@ bool gg_from_gemm(const sdumc_gemm& g, int grp, sdumc_gg_problem& q) {
 }
 
 // issues everything queued (c.deferred, c.gg) on `lane`, ordered after what lane `after` has issued so far
-// small_only: only the per-layer launches of c.deferred (modes in which the utterance-level products do not ride in a grouped
-// launch keep their early flush points; the grouped frame-level problems queued so far wait for theirs)
-int flush_dw_on(const Ctx& c, int after, int lane, int slab, bool small_only = false) {
-  if (small_only && gg_utt(c)) return SDUMC_OK;
-  if (c.deferred.empty() && (small_only || (c.gg.empty() && c.ggh.empty()))) return SDUMC_OK;
+int flush_dw_on(const Ctx& c, int after, int lane, int slab) {
+  if (c.deferred.empty() && c.gg.empty() && c.ggh.empty()) return SDUMC_OK;
   RET(link(c, after, lane));
   c.use(lane);
   const bool grouped = gg_utt(c);
@@ -679,10 +667,6 @@ int flush_dw_on(const Ctx& c, int after, int lane, int slab, bool small_only = f
     if (!taken) RET(run(c, g));      // (fc_att, cross_fc_att, fc_out_v: 3 / 7 / 1 output rows)
   }
   c.deferred.clear();
-  if (small_only) {
-    c.use(after);
-    return SDUMC_OK;
-  }
   if (!c.gg.empty()) {
     const int rc = sdumc_gemm_group_tn(c.gg.data(), (int)c.gg.size(), c.p(c.pl.gg_slab[slab]),
                                        (size_t)c.pl.gg_slab_floats[slab] * sizeof(float), c.st);
@@ -796,10 +780,6 @@ __global__ void expand_lengths_kernel(const int32_t* la, const int32_t* lt, cons
 }
 
 // the attention-pooling descriptor of (site kind k, modality m, run sg) — shared by forward and backward
-bool attn_tickets_on() {
-  static const int fuse = [] { const char* e = getenv("SDUMC_ATTN_TICKETS"); return e ? atoi(e) : 0; }();
-  return fuse != 0;
-}
 sdumc_attnpool attn_desc(const Ctx& c, int k, int m, const Seg& sg) {
   const Plan& pl = c.pl;
   const int nq = k == 0 ? 1 : NQ;
@@ -827,12 +807,6 @@ sdumc_attnpool attn_desc(const Ctx& c, int k, int m, const Seg& sg) {
     a.q_stride = (int64_t)NQ * D;
   }
   a.scale = 0.3f;
-  {   // counters of this (site, run): 2 x sg.V words
-    // OFF by default: measured at C2 on MI355X the fused second passes LOSE 11 us per step fp32 / 18 us bf16 (1.993 vs 1.982 ms,
-    // 1.204 vs 1.186 ms) -- the agent-scope dword stores of the partials and the serial tail of the last chunk cost more than
-    // the launch they save.  SDUMC_ATTN_TICKETS=1 turns them on.
-    if (attn_tickets_on()) a.tickets = reinterpret_cast<uint32_t*>(c.p(pl.tickets)) + ((int64_t)(k * 3 + m) * 2 * pl.V) + 2 * (int64_t)sg.s0 * pl.B;
-  }
   a.x_drop = in_drop(c, k, m, sg.T, sg.s0, sg.row0);
   if (c.h()) a.x_drop.enabled = 0;
   a.out_drop = mkdrop(c, SITE_OUT[k][m], c.d.p_frame, nq, D, sg.s0);
@@ -1025,16 +999,10 @@ std::vector<const Lin*> chain_lins(const ParamMap& pm) {
   return v;
 }
 
-// SDUMC_KEYS_DX_NT=1: the key-projection dX product dxd += dz W as NT on a transposed weight mirror through the wide LDS-DMA
-// kernel instead of as NN through the 64x64 kernel.  Alone the wide kernel is faster (96-98 vs 70 TF); inside the step it
-// LOSES -- 1.952 vs 1.925 ms in two alternations, bit-identical results: its 60 KB LDS rings co-reside badly with the other
-// lanes' kernels -- so the default stays NN.
-int keys_dx_nt() {
-  static const int v = [] { const char* e = getenv("SDUMC_KEYS_DX_NT"); return e ? atoi(e) : 0; }();
-  return v;
-}
-// transposed fp32 mirror, refreshed once per forward: the utterance-level weights (the chain kernels stream W^T forward) and,
-// for SDUMC_KEYS_DX_NT, the six input_proj weights
+// transposed fp32 mirror of the utterance-level weights, refreshed once per forward (the chain kernels stream W^T forward).
+// (The key-projection dX as NT on such a mirror of the input_proj weights through the wide LDS-DMA kernel: faster alone, 96-98 vs
+//  70 TF, slower inside the step in rounds 2 and 3 -- 1.884 vs 1.784 ms -- its 60 KB LDS rings co-reside badly with the other
+//  lanes' kernels; the small-footprint NN kernel stays.)
 int chain_transpose(const Ctx& c) {
   int64_t offs[40];
   int32_t outs[40], ins[40];
@@ -1043,11 +1011,6 @@ int chain_transpose(const Ctx& c) {
     const std::vector<const Lin*> ls = chain_lins(c.pm);
     for (const Lin* L : ls) { offs[n] = L->w; outs[n] = L->out; ins[n] = L->in; ++n; }
   }
-  if (!c.h() && keys_dx_nt())
-    for (int m = 0; m < 3; ++m) {
-      offs[n] = c.pm.fra_proj[m].w; outs[n] = D; ins[n] = D; ++n;
-      offs[n] = c.pm.ca_in[m].w; outs[n] = D; ins[n] = D; ++n;
-    }
   if (n == 0) return SDUMC_OK;
   return sdumc_chain_transpose_(c.P, c.p(c.pl.wt), offs, outs, ins, n, c.st);
 }
@@ -1122,7 +1085,6 @@ int forward(const Ctx& c) {
                        reinterpret_cast<int32_t*>(c.p(pl.lens)));
     SDUMC_CHECK_LAUNCH();
   }
-  if (attn_tickets_on()) RET(sdumc_fill(c.p(pl.tickets), 0.f, 12LL * V + 16, c.st));   // (self-resetting; guards a workspace's first use)
   // 1+2. three independent per-modality chains, one per lane:
   //      keep-bits of the two frame-level input dropouts -> frame_dim_reshape_m (model :282-284; audio/video once
   //      for both streams) -> keys of fra2utt_m AND cross_att_fra2utt_m -> FRA2UTT pooling (model :288-290)
@@ -1152,7 +1114,7 @@ int forward(const Ctx& c) {
     }
     RET(fork_all(c));      // (the lanes forked above did not see these launches)
   }
-  if (chain || (!c.h() && keys_dx_nt())) {   // transposed mirrors (first needed after the frame-level part / in the backward): lane 3
+  if (chain) {   // transposed mirror (first needed after the frame-level part): lane 3
     RET(link(c, 0, 3));
     c.use(3);
     RET(chain_transpose(c));
@@ -1501,13 +1463,12 @@ int keys_gemm_bwd(const Ctx& c, int m, int k0, int k1, int parts = 3) {
     first = false;
   }
   if (!(parts & 2)) return SDUMC_OK;
-  // dxd += dz W (the key-projection path joins the pooling path): NT on the transposed mirror (chain_transpose)
-  const int as_nt = keys_dx_nt();
-  sdumc_gemm g = G_(as_nt ? SDUMC_NT : SDUMC_NN, (int)pl.rows[m], D, D, k1 - k0);
+  // dxd += dz W (the key-projection path joins the pooling path)
+  sdumc_gemm g = G_(SDUMC_NN, (int)pl.rows[m], D, D, k1 - k0);
   for (int k = k0; k < k1; ++k) {
     const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
     g.A[k - k0] = c.p(pl.dz[k][m]);
-    g.B[k - k0] = as_nt ? c.p(pl.wt) + L.w : c.P + L.w;
+    g.B[k - k0] = c.P + L.w;
     g.C[k - k0] = c.p(pl.dxd[k][m]);
   }
   g.lda = g.ldb = g.ldc = D;
@@ -1530,21 +1491,20 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   // With the grouped weight-gradient launches lane 3 carries persistent kernels that fill the chip for 0.1-0.2 ms each, so
   // nothing the critical path waits for may queue behind them: the early dX then always takes the modality's own lane.
   const bool ggf = gg_frame(c);
-  // A/B knob (grouped mode): 0 = early dX on the modality's own lane, its dW grouped; 1 = the early modality keeps the per-layer
-  // dW + dX pair on lane 3 (the round-2 arrangement); 2 = no early key-projection backward at all
-  static const int gg_early = [] { const char* e = getenv("SDUMC_GG_EARLY"); return e ? atoi(e) : 1; }();
-  const int cbgb = (ggf && gg_early == 2) ? 0 : c.bgb;
+  // The early modality keeps its per-layer dW + dX pair (small-footprint kernels that run beside the utterance-level stage
+  // 7'-3'); measured in the grouped mode, fp32 C2: 1.787 ms, against 1.816 with only its dX early and the dW grouped, 1.833 with
+  // no early work at all, 1.831 with the pair issued behind that stage instead of beside it.
   int own_lane = 0;
   for (int m = 0; m < 3; ++m)
-    if ((phases != 3 || (ggf && gg_early == 0)) && (cbgb & (1 << m)) && c.multi && LANE_OF[m] != 0) own_lane |= 1 << m;
+    if (phases != 3 && (c.bgb & (1 << m)) && c.multi && LANE_OF[m] != 0) own_lane |= 1 << m;
   // (in a single call the lane-3 route measured 0.15 % faster than the own-lane route; phased calls gain 0.6 % from the latter)
-  const int bgb = (phases == 3 && !(ggf && gg_early == 0)) ? cbgb : own_lane;
+  const int bgb = phases == 3 ? c.bgb : own_lane;
   // grouped mode: the dW of the Cross_Attention input_proj layers rides in the launch right behind the (grouped) pooling backward
   // of phase 0 (bit m of ca_dw_mask), the dW of the FRA2UTT ones in the launch behind the FRA2UTT pooling backward of phase 1
   const bool ca_dw_grouped = ggf && attn_multi_ok(c);
   int ca_dw_mask = 0, fra_dw_mask = 0;
   for (int m = 0; m < 3; ++m) {
-    if (ca_dw_grouped && keys_dw_groupable(c, m) && !((gg_early == 1 || gg_early == 3) && (bgb & (1 << m)))) ca_dw_mask |= 1 << m;
+    if (ca_dw_grouped && keys_dw_groupable(c, m) && !(bgb & (1 << m))) ca_dw_mask |= 1 << m;
     if (ggf && keys_dw_groupable(c, m)) fra_dw_mask |= 1 << m;
   }
   // early_done[m]: lane 3 has finished modality m's early key-projection backward (dxd of its Cross_Attention site).  The
@@ -1569,9 +1529,6 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     }
     return SDUMC_OK;
   };
-  // mode 3: behind the utterance-level stage 7'-3' instead of beside it (the clustered kernels exchange slices through L2 / HBM
-  // at latency; a bandwidth-heavy GEMM beside them doubled their time)
-  const bool late_early = ggf && gg_early == 3 && use_chain(c) && attn_multi_ok(c);
   if (phases & 1) {
   // every live gradient tensor is overwritten below when all five output gradients are given
   if (!og.d_vals || !og.d_fused || !og.d_rnc || !og.d_text_hidden || !og.d_cross_text) RET(sdumc_fill(c.G, 0.f, pm.live, c.st));
@@ -1629,7 +1586,6 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   // batch 1 of the weight gradients (heads, cross_attention_mlp, cross_*_mlp) -- in the grouped mode together with the
   // Cross_Attention input_proj dW, right behind the pooling backward that produces their dz
   if (!ca_dw_grouped) RET(flush_dw(c));
-  else RET(flush_dw_on(c, 0, 3, 0, true));
   if (grouped) {   // one grouped launch on the caller's stream, then the early key-projection backwards leave for their lanes
     sdumc_attnpool_bwd_t bb[4];
     int n = 0;
@@ -1660,7 +1616,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     RET(sdumc_attnpool_bwd_multi(bb, n, c.st));
     for (int m = 0; m < 3; ++m)
       if (ca_dw_mask & (1 << m)) keys_dw_queue(c, m, 1, 2);
-    if (!late_early) RET(early_keys());
+    RET(early_keys());
     // (no flush here: a persistent launch now would hold every CU's registers while the latency-bound utterance-level stage
     //  7'-3' -- 256 co-resident workgroups -- is trying to start: measured +135 us on that stage.  The queued problems leave
     //  with the FRA2UTT ones, beside the dX products of the frame-level part.)
@@ -1695,7 +1651,6 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     mark(c.st, 7);
     RET(chain_launch(c, ca, 3));
     mark(c.st, 8);
-    if (late_early) RET(early_keys());
     const int M7 = V * NQ;
     {
       sdumc_gemm gw = G_(SDUMC_TN, D, D, M7, 3);
@@ -1750,7 +1705,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     GroupPtrs qq = {c.p(pl.d_q), D, NQ * D, c.p(pl.qin), (int64_t)V * D, D, c.p(pl.d_qin), (int64_t)V * D, D};
     RET(lin_bwd_grouped(c, pm.query, 7, V, qq));
   }
-  if (!gg_utt(c)) RET(flush_dw_on(c, 0, 3, 0, ggf));   // batch 2: query_proj, the query MLPs (grouped mode: they wait for batch 3)
+  if (!gg_utt(c)) RET(flush_dw(c));   // batch 2: query_proj, the query MLPs (grouped mode: they wait for batch 3)
   // 5'. fusion algebra (d_alpha already holds the second-level contribution)
   RET(sdumc_fusion_bwd(c.p(pl.u), c.p(pl.alpha), c.p(pl.d_qin), c.p(pl.d_u), c.p(pl.d_alpha), V, c.st));
   // 4'. fc_att, attention_mlp
@@ -1770,7 +1725,6 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   // batch 3: fc_att, attention_mlp, audio/text/video_mlp.  Grouped mode with the frame-level part following in this call:
   // they stay queued and ride with the FRA2UTT input_proj dW in one launch (below).
   if (!(ggf && (phases & 2))) RET(flush_dw(c));
-  else RET(flush_dw_on(c, 0, 3, 0, true));
   // the dW GEMMs of this part ran on lane 3: after this link [0, pm.early) is final on the caller's stream.  When the
   // frame-level part follows in the same call the link at its end does the same job.
   if (!(phases & 2)) RET(link(c, 3, 0));
@@ -1811,8 +1765,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
       // bit m: modality m's key-projection dW (off the dz -> dX -> mask-sum -> frame dW chain) runs on lane 3 (ungrouped modes).
       // (re-measured with the clustered utterance-level kernels: fp32 1.923 ms with none on lane 3 vs 1.930 with audio's;
       //  bf16 storage 1.148 vs 1.128 -- so the default follows the mode)
-      static const int dw_env = [] { const char* e = getenv("SDUMC_KEYS_DW_LANE3"); return e ? atoi(e) : -1; }();
-      const int dw_off = dw_env >= 0 ? dw_env : (c.h() ? 1 : 0);
+      const int dw_off = c.h() ? 1 : 0;
       if (fra_q) {
         if (k1 == 2 && !ca_q) RET(keys_gemm_bwd(c, m, 1, 2, 1));     // (never in practice: both sites are groupable or neither)
         RET(keys_gemm_bwd(c, m, 0, k1, 2));

@@ -353,8 +353,6 @@ __global__ __launch_bounds__(256) void bf16_splitk_reduce_kernel(const sdumc_gem
 
 using NT128 = HCfg<128, 128, 2, 2, 64, 2, true, 2>;     // 64 KiB LDS: two workgroups per CU
 using NT64 = HCfg<64, 128, 1, 4, 64, 3, true, 2>;       // 72 KiB: for M below ~16k rows (more tiles)
-using TN128 = HCfg<128, 128, 2, 2, 32, 3, false, 2>;    // 48 KiB
-using TN128b = HCfg<128, 128, 2, 2, 64, 2, false, 2>;   // longer k-tiles: one barrier per 16 MFMAs
 using TN128w = HCfg<128, 128, 2, 4, 64, 2, false, 4>;   // 8 waves (wave tile 64x32): two waves per SIMD from one workgroup
 
 struct Plan {
@@ -457,9 +455,8 @@ extern "C" int sdumc_gemm_bf16_run(const sdumc_gemm_bf16* gp, void* stream) {
   else {
     // measured on MI355X (tools/gemm_bf16_check.py; frame dW 256 x 1024 x 24000 / keys dW 256 x 256 x 48000 / 4096^3):
     //   4 waves, BK 32, 3 stages: 70 / 58 us / 482 TF;  4 waves, BK 64, 2 stages: 62 / 53 us / 610 TF;
-    //   8 waves (wave tile 64x32), BK 64, 2 stages: 55 / 47 us / 646 TF  <- default (SDUMC_BF16_TN_CFG=0 / 1 select the others)
-    static const int tn_cfg = [] { const char* e = getenv("SDUMC_BF16_TN_CFG"); return e ? atoi(e) : 2; }();
-    rc = tn_cfg == 1 ? launch<TN128b>(g, p, cs, st) : tn_cfg == 2 ? launch<TN128w>(g, p, cs, st) : launch<TN128>(g, p, cs, st);
+    //   8 waves (wave tile 64x32), BK 64, 2 stages: 55 / 47 us / 646 TF  <- the one kept
+    rc = launch<TN128w>(g, p, cs, st);
   }
   if (rc != SDUMC_OK) return rc;
   SDUMC_CHECK_LAUNCH();

@@ -59,7 +59,6 @@ struct Launch {
                              // (which read the same rows of A) are neighbours on the line.  1 = plain (tile, k) order
   int32_t n;
   int32_t nwg;
-  int32_t stagger;
   int32_t bk;                // rows of K per k-tile: 16 (fp32 operands) or 64 (bf16 operands)
   int32_t hf;                // 1: A and B are bf16 tensors (gg_tn_bf16_kernel); the accumulator tiles then keep their natural row order
   int32_t ovh;               // line positions charged to every unit for its fixed costs (ring start-up latency, epilogue): no k-tiles behind them
@@ -122,7 +121,7 @@ struct Frag {
   uint32_t mb[4];         // keep-bits bytes of the B fragment (masked problems)
 };
 
-template <int NST, int OCC, int DBG = 0>
+template <int NST, int OCC>
 __global__ __launch_bounds__(NTHR, OCC) void gg_tn_kernel(const Launch L) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -140,19 +139,6 @@ __global__ __launch_bounds__(NTHR, OCC) void gg_tn_kernel(const Launch L) {
 
   f32x16 acc[TM][TN];
   float csum[TM];
-  unsigned long long stamps[12];
-  int nstamp = 0;
-  auto stamp = [&]() {
-    if constexpr (DBG == 5) {
-      if (nstamp < 12) {
-        stamps[nstamp] = (nstamp & 1) ? __builtin_amdgcn_s_memtime() : __builtin_amdgcn_s_memrealtime();
-        ++nstamp;
-      }
-    }
-  };
-  stamp();
-  stamp();
-
   // Fragment reads.  The operands lie [k][row] in LDS, so a lane's four k values of one 32-row MFMA tile are four ds_read_b32 a
   // KiB apart.  Reading 8 bytes instead gives the lane rows 2 li and 2 li + 1: the wave's two MFMA tiles along M (and along N)
   // take the EVEN and the ODD rows of its 64-row block instead of the lower and the upper half -- half the LDS instructions
@@ -291,13 +277,8 @@ __global__ __launch_bounds__(NTHR, OCC) void gg_tn_kernel(const Launch L) {
       // t + NST - 1 and reads the g0 fragments of tile t + 1, all under the 16 MFMAs of g1.  So the barrier, the DMA issue (60-180
       // cycles per instruction) and the LDS latency of the next tile's first fragments are covered by matrix work of the same
       // wave, not exposed at the head of every tile with all eight waves in lock-step.
-      // Stagger: the two waves of a SIMD (waves w and w + 4) run the same program, and with one barrier per k-tile they would
-      // stay in lock-step -- both at the barrier, both issuing DMA, both waiting on LDS at the same moments, the SIMD's matrix
-      // pipe idle meanwhile.  Waves 4-7 therefore take the barrier at the HEAD of the tile instead of in its middle: they wait
-      // there for waves 0-3 (which arrive after their g0) and from then on run half a k-tile behind, so that whenever one wave of
-      // a SIMD sits at a barrier or issues its DMA the other one is in the middle of 16 MFMAs.  Same barriers, same data
-      // hazards: barrier t guarantees stage t + 1 landed and stage t - 1 free for every wave, whichever half arrives first.
-      const bool late = L.stagger && wave >= NW / 2;
+      // (Tried on top of this: waves 4-7 taking the barrier at the head of the tile, half a tile behind waves 0-3, so that the two
+      //  waves of a SIMD never sit at the barrier together -- 114.0 vs 114.8 TF on the frame problems, no gain: dropped.)
       auto ring = [&](auto mask_c) {
         Frag f0, f1;
 #pragma unroll
@@ -305,27 +286,20 @@ __global__ __launch_bounds__(NTHR, OCC) void gg_tn_kernel(const Launch L) {
           if (s < nk) issue(s);
         wait_stages(min(nk, NST - 1) - 1);
         __builtin_amdgcn_s_barrier();
-        stamp();
-        stamp();
         read_frag(lds, 0, f0, mask_c);
         int buf = 0, nbuf = 1, ibuf = NST - 1;
 #pragma nounroll
         for (int t = 0; t < nk; ++t) {
-          if (late && t + 1 < nk) {
-            wait_stages(min(nk - t - 2, NST - 3));
-            __builtin_amdgcn_s_barrier();
-            if (t + NST - 1 < nk) issue(ibuf);
-          }
           read_frag(lds + buf * STAGE_BYTES, 1, f1, mask_c);
           __builtin_amdgcn_sched_barrier(0);
           mma(f0, mask_c);
           __builtin_amdgcn_sched_barrier(0);
-          if (!late && t + 1 < nk) {
+          if (t + 1 < nk) {
             wait_stages(min(nk - t - 2, NST - 3));
             __builtin_amdgcn_s_barrier();
             if (t + NST - 1 < nk) issue(ibuf);
+            read_frag(lds + nbuf * STAGE_BYTES, 0, f0, mask_c);
           }
-          if (t + 1 < nk) read_frag(lds + nbuf * STAGE_BYTES, 0, f0, mask_c);
           __builtin_amdgcn_sched_barrier(0);
           mma(f1, mask_c);
           __builtin_amdgcn_sched_barrier(0);
@@ -350,8 +324,6 @@ __global__ __launch_bounds__(NTHR, OCC) void gg_tn_kernel(const Launch L) {
     }
     const bool direct = L.nchunk[w.p] == 1 && ka == 0 && kb == g.nk;
     const bool do_cs = pr.colsum_a != nullptr && tile_n == 0 && wn0 == 0;
-    stamp();
-    stamp();
     if (direct) {
       // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
       const bool accum = pr.accumulate != 0;
@@ -404,13 +376,6 @@ __global__ __launch_bounds__(NTHR, OCC) void gg_tn_kernel(const Launch L) {
       }
     }
     x = px_end;
-  }
-  if constexpr (DBG == 5) {
-    __builtin_amdgcn_s_waitcnt(0);
-    if (tid == 0) {
-      unsigned long long* out = reinterpret_cast<unsigned long long*>(L.slab + (size_t)(L.nwg + L.unit0[L.n]) * SLOT_FLOATS) + wg * 12;
-      for (int i = 0; i < 12; ++i) out[i] = i < nstamp ? stamps[i] : 0ull;
-    }
   }
 #endif
 }
@@ -708,16 +673,6 @@ int cu_count() {
   return per_device[dev];
 }
 
-int wg_per_cu() {   // development knob (SDUMC_GG_PER_CU=2): two workgroups per CU on a 3-stage ring
-  static const int v = [] { const char* e = getenv("SDUMC_GG_PER_CU"); return e && atoi(e) == 2 ? 2 : 1; }();
-  return v;
-}
-
-int dbg_mode() {
-  static const int v = [] { const char* e = getenv("SDUMC_GG_DBG"); return e ? atoi(e) : 0; }();
-  return v;
-}
-
 bool set_lds_attr() {   // the dynamic-LDS limit is a per-device function attribute
   static std::mutex mu;
   static bool done[64] = {};
@@ -727,10 +682,7 @@ bool set_lds_attr() {   // the dynamic-LDS limit is a per-device function attrib
   if (!done[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_tn_kernel<5, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * STAGE_BYTES) != hipSuccess)
       return false;
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_tn_kernel<5, 2, 5>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * STAGE_BYTES);
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_tn_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, hf::HNST * hf::HSTAGE) != hipSuccess)
-      return false;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_tn_kernel<3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * STAGE_BYTES) != hipSuccess)
       return false;
     done[dev] = true;
   }
@@ -765,9 +717,7 @@ int plan(const sdumc_gg_problem* probs, int n, int nwg_max, bool hf, Launch& L, 
   L.bk = hf ? 64 : BK;
   // (measured on MI355X, tools/gg_bench.py, all 37 problems of a C2 backward in one launch: 623 us with 0, 515 with 2, 490 with 3-4,
   //  494-500 with 6-12: a unit's ring start-up -- the HBM latency of its first stage -- and its epilogue are worth ~3 k-tiles)
-  static const int ovh = [] { const char* e = getenv("SDUMC_GG_OVH"); return e ? atoi(e) : 3; }();
-  static const int ovh_hf = [] { const char* e = getenv("SDUMC_GG_OVH_BF16"); return e ? atoi(e) : 5; }();   // (a 64-row bf16 k-tile is ~3x shorter)
-  L.ovh = hf ? ovh_hf : ovh;
+  L.ovh = hf ? 5 : 3;      // (bf16: 2, 5, 8, 12 measured 110 / 111 / 115 / 118 us on the frame-level problems of a C2 backward)
   int line = 0, tiles = 0;
   units = 0;
   for (int i = 0; i < n; ++i) {
@@ -809,20 +759,23 @@ bool valid_bf16(const sdumc_gg_problem& p) {
 
 extern "C" size_t sdumc_gg_slab_bytes_(int tiles) {
   (void)set_lds_attr();
-  return (size_t)(cu_count() * wg_per_cu() + tiles) * SLOT_FLOATS * sizeof(float);
+  return (size_t)(cu_count() + tiles) * SLOT_FLOATS * sizeof(float);
 }
+
+extern "C" int sdumc_prof_begin_(int variant, double flops, void* stream);     // gemm_f32.hip: bench.py's per-launch HIP events
+extern "C" void sdumc_prof_end_(int token, void* stream);
 
 namespace {
 size_t gg_workspace_bytes(const sdumc_gg_problem* probs, int32_t n, bool hf) {
   if (!probs || n <= 0) return 0;
-  const int nwg = cu_count() * (hf ? 1 : wg_per_cu());
+  const int nwg = cu_count();
   size_t need = 0;
   for (int first = 0; first < n; first += MAXP) {
     const int cnt = std::min(MAXP, n - first);
     Launch L;
     int units = 0;
     plan(probs + first, cnt, nwg, hf, L, units);
-    need = std::max(need, (size_t)(L.nwg + units) * SLOT_FLOATS * sizeof(float) + (dbg_mode() == 5 ? (size_t)L.nwg * 96 : 0));
+    need = std::max(need, (size_t)(L.nwg + units) * SLOT_FLOATS * sizeof(float));
   }
   return need;
 }
@@ -833,8 +786,7 @@ int gg_run(const sdumc_gg_problem* probs, int32_t n, void* workspace, size_t wor
     if (!(hf ? valid_bf16(probs[i]) : valid(probs[i]))) return SDUMC_EINVAL;
   if (workspace_bytes < gg_workspace_bytes(probs, n, hf)) return SDUMC_ENOMEM;
   if (!set_lds_attr()) return SDUMC_ELAUNCH;
-  const int per_cu = hf ? 1 : wg_per_cu();
-  const int nwg = cu_count() * per_cu;
+  const int nwg = cu_count();      // one workgroup per CU (two on a 3-stage ring spilled registers and ran at 2/3 of the rate)
   hipStream_t st = as_stream(stream);
   for (int first = 0; first < n; first += MAXP) {
     const int cnt = std::min(MAXP, n - first);
@@ -843,12 +795,12 @@ int gg_run(const sdumc_gg_problem* probs, int32_t n, void* workspace, size_t wor
     const int tiles = plan(probs + first, cnt, nwg, hf, L, units);
     if ((long long)L.line0[cnt] * (L.nwg + 1) >= (1LL << 31)) return SDUMC_EINVAL;   // 32-bit index arithmetic in the kernels
     L.slab = static_cast<float*>(workspace);
-    static const int stag = [] { const char* e = getenv("SDUMC_GG_STAGGER"); return e ? atoi(e) : 1; }();
-    L.stagger = stag;
+    double flops = 0.0;
+    for (int i = 0; i < cnt; ++i) flops += 2.0 * probs[first + i].M * (double)probs[first + i].N * ((double)probs[first + i].K[0] + probs[first + i].K[1]);
+    const int tok = sdumc_prof_begin_(hf ? 20 : 19, flops, stream);
     if (hf) hipLaunchKernelGGL(gg_tn_bf16_kernel, dim3(L.nwg), dim3(NTHR), hf::HNST * hf::HSTAGE, st, L);
-    else if (per_cu == 2) hipLaunchKernelGGL((gg_tn_kernel<3, 4>), dim3(L.nwg), dim3(NTHR), 3 * STAGE_BYTES, st, L);
-    else if (dbg_mode() == 5) hipLaunchKernelGGL((gg_tn_kernel<5, 2, 5>), dim3(L.nwg), dim3(NTHR), 5 * STAGE_BYTES, st, L);
     else hipLaunchKernelGGL((gg_tn_kernel<5, 2>), dim3(L.nwg), dim3(NTHR), 5 * STAGE_BYTES, st, L);
+    sdumc_prof_end_(tok, stream);
     SDUMC_CHECK_LAUNCH();
     hipLaunchKernelGGL(gg_reduce_kernel, dim3(tiles, 17), dim3(NTHR), 0, st, L, tiles);
     SDUMC_CHECK_LAUNCH();

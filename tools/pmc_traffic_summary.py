@@ -24,6 +24,10 @@ def short(name):
     if m:
         lay = {("true", "true"): "nt", ("false", "false"): "tn", ("true", "false"): "nn", ("false", "true"): "tt"}[m.groups()]
         return f"gemm_small_{lay}"
+    if "gg_tn_bf16_kernel" in name:
+        return "gemm_group_tn_bf16"
+    if "gg_tn_kernel" in name:
+        return "gemm_group_tn"
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void ", "", name)
     return name.split("(")[0]
