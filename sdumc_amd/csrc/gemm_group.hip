@@ -326,6 +326,7 @@ __global__ __launch_bounds__(NTHR, OCC) void gg_tn_kernel(const Launch L) {
     const bool do_cs = pr.colsum_a != nullptr && tile_n == 0 && wn0 == 0;
     if (direct) {
       // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+      // (with the column permutation a lane's j = 0 / 1 values are NEIGHBOURS in C, columns 2 li and 2 li + 1)
       const bool accum = pr.accumulate != 0;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -723,6 +724,10 @@ int plan(const sdumc_gg_problem* probs, int n, int nwg_max, bool hf, Launch& L, 
   for (int i = 0; i < n; ++i) {
     L.p[i] = probs[i];
     const Geo g = geo_of(probs[i], L.bk);
+    // (a second problem form in this kernel -- the input gradients dxd += dz . W of the input_proj layers, A k-contiguous, M the
+    //  long dimension, K = 256 -- was built and measured in round 3: 237 us for the five sites of a C2 backward against 210 us
+    //  for the per-layer 64x64 NN kernel: units of 16 k-tiles pay a ring start-up and a 256 KB read-modify-write epilogue each;
+    //  removed again)
     L.nchunk[i] = 1;
     L.line0[i] = line;
     L.unit0[i] = units;
