@@ -2,7 +2,7 @@
 # Collects the round's measurement artefacts on the GPU box into gpurun_out/<tag>/ (copied to profiles/ afterwards):
 #   bench lines (fp32 default, bf16, epoch, c1, c5), serial-lane rocprofv3 kernel stats (fp32 + bf16), PMC traffic passes.
 # usage: bash tools/collect_profiles.sh <tag>
-TAG=${1:-r2}
+TAG=${1:-r3}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
