@@ -388,7 +388,9 @@ class TrainStep(_OptStateMixin):
         check(lib.sdumc_train_step(C.byref(self.dims), C.byref(self.io), C.byref(self.cfg), st), "sdumc_train_step")
 
     def capture(self):
-        """Capture one step into a hipGraph; run() then replays it (launch overhead ~ one graph launch)."""
+        """Capture one step into a hipGraph; run() then replays it.  For embedding the step in a captured region, not for speed:
+        the capture records a plain three-lane fork/join (no background lane, chain.hip instead of the clustered kernels) and
+        measured slower than the eager four-lane launches, which are the production path."""
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         s = torch.cuda.Stream()
