@@ -331,7 +331,7 @@ class DataParallelStep:
         point of a data-parallel run, so it is also where a failed clustered-kernel step surfaces: the device's error word
         (include/sdumc_hip.h, sdumc_set_chain_cluster) makes every Adam launch a no-op until it is reset, and is raised here."""
         from . import _lib
-        if _lib.lib.sdumc_chain_cluster_error_() != 0:
+        if losses.is_cuda and _lib.lib.sdumc_chain_cluster_error_() > 0:
             raise _lib.SdumcError("a clustered utterance-level kernel ran into its spin cap: the steps since then applied nothing; "
                                   "call sdumc_chain_cluster_reset_error() and repeat them, e.g. with sdumc_set_chain_cluster(0)")
         l = losses.clone()
