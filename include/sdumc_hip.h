@@ -187,6 +187,32 @@ size_t sdumc_gemm_group_bf16_workspace_bytes(const sdumc_gg_problem* probs, int3
 int sdumc_gemm_group_tn_bf16(const sdumc_gg_problem* probs, int32_t n, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------
+ * The tall 256 x 256 products of the frame-level part in one persistent launch (gemm_rows.hip):
+ *   C[M x 256] = act((A . keep) B * a_scale + bias) (+ C),   K = N = 256
+ * - the key projections  keys = tanh(drop(x) W^T + b)  of FRA2UTT_new / Cross_Attention (model :60, :82; main :144 in train
+ *   mode): A = the projected frames, a_bits = the keep-bits of the fused input dropout, B = W^T (a [in][out] copy);
+ * - their input gradients dxd += dz W (autograd, main :149): A = dz, B = the weight as stored ([out][in]), accumulate = 1.
+ * A is [M][256] row-major with row stride lda (floats, 16-byte aligned rows); row r reads source row r % a_row_mod when
+ * a_row_mod > 0 (the two streams share the audio / video frames).  B is [256 k][256 n] with row stride ldb.  a_bits (NULL = no
+ * dropout) holds one byte per 4 columns and row of A's VIRTUAL rows ([M][64], low nibble, as sdumc_dropout_bits writes it).
+ * Every problem of one call takes the same kernel variant: all masked, all accumulating, or neither (else SDUMC_EINVAL).
+ * ------------------------------------------------------------------------ */
+#define SDUMC_ROWS_MAX_PROBLEMS 8
+typedef struct sdumc_rows_problem {
+  const float* A;
+  const float* B;
+  const uint8_t* a_bits;
+  const float* bias;        /* [256] or NULL */
+  float* C;                 /* [M][256], row stride ldc */
+  int32_t M, lda, ldb, ldc;
+  int32_t a_row_mod;
+  float a_scale;            /* 1 / (1 - p); read only with a_bits */
+  int32_t accumulate;
+  int32_t act;              /* SDUMC_ACT_NONE or SDUMC_ACT_TANH */
+} sdumc_rows_problem;
+int sdumc_gemm_rows256(const sdumc_rows_problem* probs, int32_t n, void* stream);
+
+/* ------------------------------------------------------------------------
  * Attention pooling over the time axis = the body shared by
  *   FRA2UTT_new.forward     (model :56-68; nq = 1, query = attention_context_vector, q_stride 0)
  *   Cross_Attention.forward (model :79-95; nq = 7, query = query_proj(multi_query))

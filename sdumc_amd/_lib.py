@@ -62,6 +62,12 @@ class GGProblem(C.Structure):
                 ("bits_qw", C.c_int32), ("b_scale", C.c_float), ("accumulate", C.c_int32)]
 
 
+class RowsProblem(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("a_bits", C.c_void_p), ("bias", C.c_void_p), ("C", C.c_void_p),
+                ("M", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32), ("a_row_mod", C.c_int32),
+                ("a_scale", C.c_float), ("accumulate", C.c_int32), ("act", C.c_int32)]
+
+
 class AttnPool(C.Structure):
     _fields_ = [("V", C.c_int32), ("T", C.c_int32), ("nq", C.c_int32), ("x_samples", C.c_int32),
                 ("x", C.c_void_p), ("keys", C.c_void_p), ("q", C.c_void_p), ("q_stride", C.c_int64),
@@ -171,6 +177,7 @@ _SIGS = {
     "sdumc_gemm_group_tn": (C.c_int, [C.POINTER(GGProblem), C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sdumc_gemm_group_bf16_workspace_bytes": (C.c_size_t, [C.POINTER(GGProblem), C.c_int32]),
     "sdumc_gemm_group_tn_bf16": (C.c_int, [C.POINTER(GGProblem), C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sdumc_gemm_rows256": (C.c_int, [C.POINTER(RowsProblem), C.c_int32, C.c_void_p]),
     "sdumc_attnpool_fwd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "sdumc_attnpool_fwd": (C.c_int, [C.POINTER(AttnPool), C.c_void_p]),
     "sdumc_attnpool_fwd_workspace_bytes_dim": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

@@ -622,6 +622,20 @@ bool gg_utt(const Ctx& c) { (void)c; return gg_on(); }
 // (not in the operand-rounding mode bf16 = 1, whose products round fp32 operands while staging them)
 bool gg_frame(const Ctx& c) { return gg_on() && (c.h() || c.d.bf16 == 0); }
 
+// The input gradients dxd += dz W of the frame-level part go through the persistent B-stationary launch (gemm_rows.hip), one
+// launch per modality on the modality's lane (SDUMC_ROWS=0: the 64x64 NN kernel).  Measured at C2, fp32 (tools/rows_bench.py and
+// bench.py, alternated on one box): the five sites 138 us at 113 TF against 219 us at 71 TF alone; inside the step 1.737-1.749
+// against 1.748-1.753 ms -- the phase is a sequence of chip-filling launches either way.  Also measured and dropped: all
+// modalities in ONE launch on the caller's stream behind the three pooling backwards (1.768-1.774: the grouped dW launch then
+// queues behind it with its small leading GEMMs starved); the Cross_Attention key projections of the forward pass through the
+// masked variant of the same kernel (72 vs 71 us for the audio site alone, 37 vs 51 video; step 1.780-1.791: an exclusive
+// persistent launch on the background lane holds the CUs the three modality lanes' critical kernels are waiting for).
+bool rows_on() {
+  static const bool on = [] { const char* e = getenv("SDUMC_ROWS"); return !(e && e[0] == '0'); }();
+  return on;
+}
+bool rows_ok(const Ctx& c) { return D == 256 && !c.h() && c.d.bf16 == 0; }
+
 // one group of a queued TN descriptor as a problem of the grouped launch; false = the grouped kernel does not take it
 bool gg_from_gemm(const sdumc_gemm& g, int grp, sdumc_gg_problem& q) {
   if (g.layout != SDUMC_TN || g.bf16 || g.batch > 1 || g.a_drop.enabled || g.b_drop.enabled || g.c_drop.enabled || g.a_row_mod ||
@@ -1436,6 +1450,23 @@ void keys_dw_queue(const Ctx& c, int m, int k0, int k1) {
   }
 }
 
+// dxd += dz W of sites [k0, k1) of modality m as problems of a rows launch
+int keys_dx_rows(const Ctx& c, int m, int k0, int k1, sdumc_rows_problem* q) {
+  int n = 0;
+  for (int k = k0; k < k1; ++k) {
+    const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
+    sdumc_rows_problem& r = q[n++];
+    memset(&r, 0, sizeof(r));
+    r.A = c.p(c.pl.dz[k][m]);
+    r.B = c.P + L.w;
+    r.C = c.p(c.pl.dxd[k][m]);
+    r.M = (int)c.pl.rows[m];
+    r.lda = r.ldb = r.ldc = D;
+    r.accumulate = 1;
+  }
+  return n;
+}
+
 int keys_gemm_bwd(const Ctx& c, int m, int k0, int k1, int parts = 3) {
   if (c.h()) return keys_gemm_bwd_h(c, m, k0, k1, parts);
   const Plan& pl = c.pl;
@@ -1464,6 +1495,12 @@ int keys_gemm_bwd(const Ctx& c, int m, int k0, int k1, int parts = 3) {
   }
   if (!(parts & 2)) return SDUMC_OK;
   // dxd += dz W (the key-projection path joins the pooling path)
+  if (parts == 2 && rows_on() && rows_ok(c)) {   // (the early dW + dX pair keeps the small-footprint kernels: it runs beside
+                                                         //  the co-resident utterance-level stage, which a persistent launch would stall)
+    sdumc_rows_problem q[2];
+    const int n = keys_dx_rows(c, m, k0, k1, q);
+    return sdumc_gemm_rows256(q, n, c.st);
+  }
   sdumc_gemm g = G_(SDUMC_NN, (int)pl.rows[m], D, D, k1 - k0);
   for (int k = k0; k < k1; ++k) {
     const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];

@@ -1,0 +1,353 @@
+// gemm_rows.hip — C[M x 256] = act((A . keep) B * scale + bias) (+ C): the tall 256 x 256 products of the frame-level part in
+// one persistent, B-stationary launch (gfx950).
+//
+// What runs here (C2 shapes): the input gradients dxd += dz W of the input_proj layers of FRA2UTT_new / Cross_Attention
+// (autograd of model :60, :82; M = 2*B*T up to 48000 rows, B = the weight as stored, K = N = 256).  The same kernel computes the
+// key projections keys = tanh(drop(x) W^T + b) (B = a transposed weight copy, input dropout fused on x): a tested entry point
+// (tests/test_gpu_gemm_rows.py) the engine does not call -- see engine.hip rows_on() for the measurement.
+//
+// Why a kernel of its own: these products are tall and thin -- a 64-row tile has only 256 rows of K behind it, so a tiled
+// GEMM launch (gemm_wide.hip, gemm_f32.hip) is one short k-loop per workgroup: ring start-up, 8-16 k-tiles, epilogue, exit;
+// both operands cross LDS, B (the same 256 KB for every tile) is fetched again by every workgroup, and A is read twice because
+// the tile is 128 columns wide.  They ran at 66-85 TF of the 157 TF fp32 matrix peak; this one at 101-113 (tools/rows_bench.py).
+//
+// Structure:
+//   * one 512-thread workgroup per CU works through a contiguous range of 64-row tiles; a tile is 64 x 256 -- ALL columns, so
+//     A is read from HBM exactly once;
+//   * B never touches LDS: wave w keeps columns [32 w, 32 w + 32) of all 256 rows of K in 128 VGPRs (one MFMA B operand per
+//     register) for as long as the workgroup stays on one problem;
+//   * A streams through an 8-slot LDS ring (one slot = 64 rows x 32 k = 8 KB, a tile = 8 slots) by LDS-DMA, six stages ahead,
+//     and the ring never drains between tiles: the loads of the next tile are in flight while this tile's epilogue runs.
+//     The rows are k-contiguous; the 16-byte chunks of a row are XOR-swizzled by the row (applied to the DMA's source address
+//     and again at the ds_read_b128 fragment read: conflict-free);
+//   * every wave multiplies the same A fragments (64 rows) with its own 32 columns: 2 independent 32x32x2 fp32 MFMA chains, 32
+//     MFMAs per stage and wave against 8 ds_read_b128 and one DMA instruction;
+//   * the input-dropout keep-bits of a tile (64 rows x 64 bytes) ride ahead of it as two 256-byte pieces per wave
+//     (double-buffered) and are applied to the A fragments; the scale 1 / (1 - p) multiplies the tile once, in the epilogue;
+//   * `accumulate`: the C tile is prefetched into registers two stages before the epilogue needs it.
+// The vector-memory queue of a wave holds, in issue order, LDS-DMA loads, the C prefetch and the epilogue's stores; the waits
+// are counted (s_waitcnt vmcnt(n) with n = the loads issued after the one waited for -- loads return in order; stores only make
+// a wait conservative), so nothing ever drains the queue inside a problem.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <type_traits>
+
+#include "common.h"
+
+namespace sdumc_gr {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+constexpr int waitcnt_vm(int n) { return (n & 0xF) | ((n >> 4) << 14) | (0x7 << 4) | (0xF << 8); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }   // = gemm_wide.hip
+
+constexpr int BM = 64, DK = 256, DN = 256, BK = 32;
+constexpr int NS = DK / BK;                      // stages per tile = ring slots
+constexpr int NW = 8, NTHR = 64 * NW;
+constexpr int PF = 6;                            // stages in flight ahead of the one being multiplied
+constexpr int A_STAGE = BM * BK * 4;             // 8 KB: one 1-KB piece per wave
+constexpr int RING = NS * A_STAGE;
+constexpr int QW = DK / 4;                       // keep-bits: one byte per 4 columns (low nibble), 64 bytes per row
+constexpr int BITS_TILE = BM * QW;               // 4 KB: two 256-byte pieces per wave
+constexpr int LDS_BYTES = RING + 2 * BITS_TILE;
+constexpr int MAXP = SDUMC_ROWS_MAX_PROBLEMS;
+#define SDUMC_GR_NULL_OFF 0x80000000u            /* a byte offset outside every descriptor: the load returns zeros */
+static_assert(A_STAGE == NW * 1024 && BITS_TILE == NW * 512 && NS == 8, "pieces per wave; the stage list below is written out for 8");
+
+struct Launch {
+  sdumc_rows_problem p[MAXP];
+  int32_t unit0[MAXP + 1];   // first 64-row tile of problem i in the launch's tile list; unit0[n] = all tiles
+  int32_t n, nwg;
+};
+
+// ---- the vector-memory bookkeeping of one wave --------------------------------------------------------------------------
+// Issue point of stage t (steady state): [the two keep-bits pieces of the next tile, t == 2] the A piece of stage t + PF [32
+// loads of the C tile, t == 5].  The wait in stage s is for the A piece of stage s + 1, issued at stage s + 1 - PF.
+constexpr int T_BITS = 2, T_C = 5;
+template <bool MASK, bool ACC>
+constexpr int ops_at(int t) { return 1 + ((MASK && t == T_BITS) ? 2 : 0) + ((ACC && t == T_C) ? 32 : 0); }
+template <bool MASK, bool ACC>
+constexpr int younger(int s) {
+  const int t0 = ((s + 1 - PF) % NS + NS) % NS;
+  int n = (ACC && t0 == T_C) ? 32 : 0;                 // what followed the A piece at its own issue point
+  for (int t = 1; t < PF - 1; ++t) n += ops_at<MASK, ACC>((t0 + t) % NS);
+  return n;
+}
+
+template <bool MASK, bool ACC>
+__global__ __launch_bounds__(NTHR, 2) void gr_kernel(const Launch L) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0 = wave * 32;
+  const int U = L.unit0[L.n];
+  int u = (int)(((uint32_t)blockIdx.x * (uint32_t)U) / (uint32_t)L.nwg);
+  const int u_end = (int)((((uint32_t)blockIdx.x + 1u) * (uint32_t)U) / (uint32_t)L.nwg);
+
+  // fragment reads: rows 32 i + li of the slot, 16-byte chunk 2 c + lh (k = 8 c + 4 lh .. + 3 of the stage)
+  uint32_t foff[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) foff[c] = (uint32_t)(li * (BK * 4) + (((2 * c + lh) ^ (li & 7)) << 4));
+  const uint32_t moff = (uint32_t)(li * QW), msh = 8u * (uint32_t)lh;
+  // LDS-DMA: this wave's piece of a stage = rows 8 wave .. + 7; lane -> row 8 wave + lane / 8, LDS chunk lane % 8
+  const int dr = 8 * wave + (lane >> 3);
+  const uint32_t dq16 = (uint32_t)(((lane & 7) ^ (lane >> 3)) << 4);    // source chunk of that LDS chunk (bytes)
+  char* const bits_lds = lds + RING;
+
+  typedef float f32x4_ __attribute__((ext_vector_type(4)));
+  f32x16 acc[2];
+
+  while (u < u_end) {
+    int p = 0;
+    while (p + 1 < L.n && L.unit0[p + 1] <= u) ++p;
+    const sdumc_rows_problem& pr = L.p[p];
+    const int ub = min(u_end, L.unit0[p + 1]);
+    const int tile0 = L.unit0[p];
+    const uint32_t lda4 = (uint32_t)pr.lda * 4u, ldc4 = (uint32_t)pr.ldc * 4u;
+    const int a_rows = pr.a_row_mod > 0 ? pr.a_row_mod : pr.M;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.A), 0, (int)((uint32_t)a_rows * lda4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbits = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(MASK ? pr.a_bits : (const uint8_t*)pr.A), 0,
+                                                                           MASK ? (int)((uint32_t)pr.M * QW) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(pr.C, 0, (int)((uint32_t)pr.M * ldc4), 0x00020000);
+
+    // B: one register per MFMA step j = 16 s + 4 c + e  <->  k = 32 s + 8 c + 4 lh + e (the order the A fragments arrive in)
+    float breg[DK / 2];
+    {
+      const uint32_t ldb4 = (uint32_t)pr.ldb * 4u;
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.B), 0, (int)((uint32_t)DK * ldb4), 0x00020000);
+      const uint32_t bo = (uint32_t)(4 * lh) * ldb4 + (uint32_t)(n0 + li) * 4u;
+#pragma unroll
+      for (int j = 0; j < DK / 2; ++j)
+        breg[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, bo, (32 * (j >> 4) + 8 * ((j >> 2) & 3) + (j & 3)) * ldb4, 0));
+    }
+    const float bias = pr.bias ? pr.bias[n0 + li] : 0.f;
+    const float scale = MASK ? pr.a_scale : 1.f;
+    const bool do_tanh = pr.act == SDUMC_ACT_TANH;
+
+    // byte offset of this lane's 16 bytes of stage 0 of tile t (rows past M: outside the descriptor, or wrapped by the modulo)
+    auto a_off = [&](int t) -> uint32_t {
+      int r = (t - tile0) * BM + dr;
+      if (pr.a_row_mod > 0) r %= pr.a_row_mod;
+      return (uint32_t)r * lda4 + dq16;
+    };
+    // (the wave's 8 rows of keep-bits are 512 contiguous bytes: two 256-byte pieces)
+    auto bits_off = [&](int t) -> uint32_t { return (uint32_t)((t - tile0) * BM + 8 * wave) * QW + 4u * lane; };
+    auto issue_a = [&](uint32_t off, int chunk) {    // stage `chunk` of a tile into slot `chunk` (the k offset rides in the scalar
+                                                     // offset: an instruction offset would move the LDS address too)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(lds + chunk * A_STAGE + wave * 1024), 16, off, chunk * (BK * 4), 0, 0);
+    };
+    auto issue_bits = [&](uint32_t off, int par) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rbits, (lds_void_t*)(bits_lds + par * BITS_TILE + wave * 512), 4, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rbits, (lds_void_t*)(bits_lds + par * BITS_TILE + wave * 512 + 256), 4, off, 256, 0, 0);
+    };
+    // half h of a stage = k 16 h .. 16 h + 15 of its 32: chunks c = 2 h, 2 h + 1 of both 32-row blocks -- the two accumulator
+    // chains alternate inside every half
+    struct Frag {
+      f32x4_ a[2][2];
+      uint32_t mw[2];
+    };
+    auto read_frag = [&](int slot, int h, int par, Frag& f) {
+      const char* base = lds + slot * A_STAGE;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) f.a[i][cc] = *reinterpret_cast<const f32x4_*>(base + i * (32 * BK * 4) + foff[2 * h + cc]);
+      if constexpr (MASK) {   // keep-bits bytes 8 slot + 4 h .. + 3 of the row; byte 2 cc + lh is chunk (2 h + cc, lh): its bit e -> bit 16 cc + e
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          f.mw[i] = *reinterpret_cast<const uint32_t*>(bits_lds + par * BITS_TILE + i * (32 * QW) + moff + 8 * slot + 4 * h) >> msh;
+      }
+    };
+    auto mma = [&](Frag& f, int h, int s) {
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            float a = f.a[i][cc][e];
+            if constexpr (MASK) a = __uint_as_float(__float_as_uint(a) & (uint32_t)__builtin_amdgcn_sbfe((int)f.mw[i], 16 * cc + e, 1u));
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, breg[16 * s + 4 * (2 * h + cc) + e], acc[i], 0, 0, 0);
+          }
+      if constexpr (MASK) {   // keep every mask next to its MFMA (all 16 computed up front cost 16 more live registers: spills)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        }
+      }
+    };
+
+    // ---- prologue: the ring belongs to this problem from here (the previous one drained it) ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    int par = 0;
+    {
+      const uint32_t o = a_off(u);
+      if constexpr (MASK) issue_bits(bits_off(u), 0);
+#pragma unroll
+      for (int s = 0; s < PF; ++s) issue_a(o, s);
+    }
+    __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+    __builtin_amdgcn_s_barrier();
+    Frag fa, fb;
+    read_frag(0, 0, par, fa);
+
+    // ---- steady state: 8 stages per tile, one barrier per stage ----
+#pragma nounroll
+    for (; u < ub; ++u) {
+      const uint32_t o_cur = a_off(u);
+      const uint32_t o_nxt = u + 1 < ub ? a_off(u + 1) : SDUMC_GR_NULL_OFF;
+      const uint32_t b_nxt = u + 1 < ub ? bits_off(u + 1) : SDUMC_GR_NULL_OFF;
+      // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+      const uint32_t c_off = (uint32_t)((u - tile0) * BM + 4 * lh) * ldc4 + (uint32_t)(n0 + li) * 4u;
+      float cpre[ACC ? 32 : 1];
+      auto stage = [&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        read_frag(s, 1, par, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa, 0, s);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(waitcnt_vm(younger<MASK, ACC>(s)));
+        __builtin_amdgcn_s_barrier();
+        if constexpr (MASK) {
+          if constexpr (s == T_BITS) issue_bits(b_nxt, par ^ 1);
+        }
+        issue_a(s + PF < NS ? o_cur : o_nxt, (s + PF) % NS);
+        if constexpr (ACC) {
+          if constexpr (s == T_C) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int e = 0; e < 16; ++e)
+                cpre[i * 16 + e] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rc, c_off, (32 * i + (e & 3) + 8 * (e >> 2)) * ldc4, 0));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        read_frag((s + 1) % NS, 0, s + 1 == NS ? par ^ 1 : par, fa);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fb, 1, s);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      stage(std::integral_constant<int, 0>{});
+      stage(std::integral_constant<int, 1>{});
+      stage(std::integral_constant<int, 2>{});
+      stage(std::integral_constant<int, 3>{});
+      stage(std::integral_constant<int, 4>{});
+      stage(std::integral_constant<int, 5>{});
+      stage(std::integral_constant<int, 6>{});
+      stage(std::integral_constant<int, 7>{});
+      // ---- epilogue of tile u (the next tile's stages are in flight behind it) ----
+      auto epilogue = [&](auto tanh_c) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            float v = acc[i][e];
+            if constexpr (MASK) v *= scale;
+            v += bias;
+            if constexpr (ACC) v += cpre[i * 16 + e];
+            if constexpr (decltype(tanh_c)::value) v = fast_tanh(v);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, c_off, (32 * i + (e & 3) + 8 * (e >> 2)) * ldc4, 0);
+            acc[i][e] = 0.f;
+          }
+      };
+      if (do_tanh) epilogue(std::true_type{});
+      else epilogue(std::false_type{});
+      __builtin_amdgcn_sched_barrier(0);
+      par ^= 1;
+    }
+    // the last tile's issue points loaded "the next tile" from nowhere (zeros into free slots): let them land before the next
+    // problem's prologue reuses the ring
+    __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+    __builtin_amdgcn_s_barrier();
+  }
+#endif
+}
+
+int cu_count() {
+  static std::mutex mu;
+  static int per_device[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!per_device[dev]) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    per_device[dev] = n;
+  }
+  return per_device[dev];
+}
+
+bool set_lds_attr() {   // the dynamic-LDS limit is a per-device function attribute
+  static std::mutex mu;
+  static bool done[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!done[dev]) {
+    const void* ks[3] = {reinterpret_cast<const void*>(&gr_kernel<false, false>), reinterpret_cast<const void*>(&gr_kernel<true, false>),
+                         reinterpret_cast<const void*>(&gr_kernel<false, true>)};
+    for (const void* k : ks)
+      if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return false;
+    done[dev] = true;
+  }
+  return true;
+}
+
+bool valid(const sdumc_rows_problem& p) {
+  if (!p.A || !p.B || !p.C || p.M <= 0 || p.lda < DK || p.ldb < DN || p.ldc < DN || (p.lda & 3) || p.a_row_mod < 0) return false;
+  if (reinterpret_cast<uintptr_t>(p.A) & 15) return false;
+  if ((reinterpret_cast<uintptr_t>(p.B) | reinterpret_cast<uintptr_t>(p.C)) & 3) return false;
+  if (p.a_bits && (reinterpret_cast<uintptr_t>(p.a_bits) & 3)) return false;
+  if (p.act != SDUMC_ACT_NONE && p.act != SDUMC_ACT_TANH) return false;
+  // 32-bit byte offsets, descriptor ranges below 2 GiB (a tile past the last row is still addressed)
+  const size_t rows = (size_t)p.M + 2 * BM;
+  if (rows * p.lda * 4 >= 0x7FFFFFF0u || rows * p.ldc * 4 >= 0x7FFFFFF0u) return false;
+  return true;
+}
+
+}  // namespace sdumc_gr
+using namespace sdumc_gr;
+
+extern "C" int sdumc_prof_begin_(int variant, double flops, void* stream);     // gemm_f32.hip: bench.py's per-launch HIP events
+extern "C" void sdumc_prof_end_(int token, void* stream);
+
+extern "C" int sdumc_gemm_rows_prepare_(void) { return set_lds_attr() ? SDUMC_OK : SDUMC_ELAUNCH; }
+
+extern "C" int sdumc_gemm_rows256(const sdumc_rows_problem* probs, int32_t n, void* stream) {
+  if (!probs || n <= 0 || n > MAXP) return SDUMC_EINVAL;
+  const bool mask = probs[0].a_bits != nullptr, accum = probs[0].accumulate != 0;
+  if (mask && accum) return SDUMC_EINVAL;
+  Launch L;
+  memset(&L, 0, sizeof(L));
+  int units = 0;
+  double flops = 0.0;
+  for (int i = 0; i < n; ++i) {
+    if (!valid(probs[i])) return SDUMC_EINVAL;
+    if ((probs[i].a_bits != nullptr) != mask || (probs[i].accumulate != 0) != accum) return SDUMC_EINVAL;   // one kernel variant per launch
+    L.p[i] = probs[i];
+    L.unit0[i] = units;
+    units += (probs[i].M + BM - 1) / BM;
+    flops += 2.0 * probs[i].M * (double)DK * DN;
+  }
+  L.unit0[n] = units;
+  L.n = n;
+  L.nwg = std::min(cu_count(), units);
+  if ((long long)units * (L.nwg + 1) >= (1LL << 31)) return SDUMC_EINVAL;
+  if (!set_lds_attr()) return SDUMC_ELAUNCH;
+  hipStream_t st = as_stream(stream);
+  const int tok = sdumc_prof_begin_(21, flops, stream);
+  if (mask) hipLaunchKernelGGL((gr_kernel<true, false>), dim3(L.nwg), dim3(NTHR), LDS_BYTES, st, L);
+  else if (accum) hipLaunchKernelGGL((gr_kernel<false, true>), dim3(L.nwg), dim3(NTHR), LDS_BYTES, st, L);
+  else hipLaunchKernelGGL((gr_kernel<false, false>), dim3(L.nwg), dim3(NTHR), LDS_BYTES, st, L);
+  sdumc_prof_end_(tok, stream);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}

@@ -113,6 +113,35 @@ def gemm_group_tn(problems, workspace=None):
     return [q["C"] for q in problems]
 
 
+def gemm_rows256(problems):
+    """The tall 256 x 256 products of the frame-level part in one persistent launch (sdumc_gemm_rows256).
+
+    problems: list of dicts {A, B, [C], [bits], [bias], [scale], [a_row_mod], [accumulate], [act], [M]}:
+    C[M, 256] = act((A . keep) B * scale + bias) (+ C); A [rows, 256] and B [256 k, 256 n] 2-D fp32 device tensors, bits the
+    uint8 keep-bits [M, 64] of a dropout fused on A's virtual rows.  All masked, all accumulating, or neither."""
+    n = len(problems)
+    arr = (_lib.RowsProblem * n)()
+    for i, q in enumerate(problems):
+        g = arr[i]
+        A, B = q["A"], q["B"]
+        g.A, g.B = ptr(A), ptr(B)
+        g.M = q.get("M", A.shape[0])
+        g.lda, g.ldb = A.stride(0), B.stride(0)
+        g.a_row_mod = q.get("a_row_mod", 0)
+        g.a_bits = ptr(q.get("bits"))
+        g.bias = ptr(q.get("bias"))
+        g.a_scale = q.get("scale", 1.0)
+        Cm = q.get("C")
+        if Cm is None:
+            Cm = torch.empty(g.M, 256, device=A.device)
+            q["C"] = Cm
+        g.C, g.ldc = ptr(Cm), Cm.stride(0)
+        g.accumulate = 1 if q.get("accumulate") else 0
+        g.act = q.get("act", ACT_NONE)
+    check(lib.sdumc_gemm_rows256(arr, n, _st()), "sdumc_gemm_rows256")
+    return [q["C"] for q in problems]
+
+
 def gemm_bf16(layout, A, B, M, N, K, bias=None, C_out=None, lda=None, ldb=None, ldc=None, act=ACT_NONE, a_row_mod=0,
               b_row_mod=0, accumulate=False, c_bf16=False, splitk=0, colsum_a=None):
     """GEMM on bf16 storage (sdumc_gemm_bf16_run): A, B torch.bfloat16 device tensors (lists = grouped); C fp32 or bf16."""

@@ -1,0 +1,131 @@
+"""GPU parity tests of the persistent B-stationary rows GEMM (sdumc_gemm_rows256, csrc/gemm_rows.hip): the key projections
+keys = tanh(drop(x) W^T + b) of FRA2UTT_new / Cross_Attention (model :60, :82) and their input gradients dxd += dz W under
+loss.backward() (main :149).  Checked against fp64 matmuls at 2e-5 and for bit-identical repeats."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from sdumc_amd import ops as o
+    return o
+
+
+def close(got, want, tol=2e-5, msg=""):
+    got = got.detach().cpu().double().numpy()
+    want = want.detach().cpu().double().numpy()
+    scale = max(1.0, np.abs(want).max())
+    np.testing.assert_allclose(got, want, rtol=tol, atol=tol * scale, err_msg=msg)
+
+
+def keep_bits(M, g, p=0.5):
+    """uint8 [M, 64], bit e of byte q = keep column 4q + e (as sdumc_dropout_bits writes them); and the 0/1 mask."""
+    m = torch.rand(M, 256, generator=g) >= p
+    b = (m.reshape(M, 64, 4).to(torch.int32) * torch.tensor([1, 2, 4, 8], dtype=torch.int32)).sum(-1).to(torch.uint8)
+    return b, m.double()
+
+
+def ref_of(q, mask, C0):
+    A, B = q["A"].cpu().double(), q["B"].cpu().double()
+    M = q.get("M", A.shape[0])
+    mod = q.get("a_row_mod", 0)
+    rows = torch.arange(M) % mod if mod else torch.arange(M)
+    Av = A[rows]
+    if mask is not None:
+        Av = Av * mask * q.get("scale", 1.0)
+    out = Av @ B
+    if q.get("bias") is not None:
+        out = out + q["bias"].cpu().double()
+    if q.get("accumulate"):
+        out = out + C0.cpu().double()
+    if q.get("act", 0) == 2:
+        out = torch.tanh(out)
+    return out
+
+
+def run_case(ops, specs, seed, repeat=False):
+    g = torch.Generator().manual_seed(seed)
+    probs, masks, c0s = [], [], []
+    for sp in specs:
+        M, mod = sp["M"], sp.get("mod", 0)
+        q = {"A": (torch.randn(mod or M, 256, generator=g) * 0.5).cuda(), "B": (torch.randn(256, 256, generator=g) / 16).cuda(),
+             "M": M, "a_row_mod": mod, "act": sp.get("act", 0)}
+        if sp.get("bias"):
+            q["bias"] = torch.randn(256, generator=g).cuda()
+        mask = None
+        if sp.get("mask"):
+            bits, mask = keep_bits(M, g)
+            q["bits"] = bits.cuda()
+            q["scale"] = 2.0
+        C0 = torch.randn(M, 256, generator=g).cuda()
+        if sp.get("accumulate"):
+            q["accumulate"] = True
+        q["C"] = C0.clone()
+        probs.append(q)
+        masks.append(mask)
+        c0s.append(C0)
+    out = [c.clone() for c in ops.gemm_rows256(probs)]
+    torch.cuda.synchronize()
+    for q, mask, C0, got, sp in zip(probs, masks, c0s, out, specs):
+        close(got, ref_of(q, mask, C0), msg=str(sp))
+    if repeat:
+        for q, C0 in zip(probs, c0s):
+            q["C"].copy_(C0)
+        again = ops.gemm_rows256(probs)
+        torch.cuda.synchronize()
+        for a, b in zip(out, again):
+            assert torch.equal(a, b)
+    return out
+
+
+def test_plain_products_whole_and_ragged_tiles(ops):
+    # one tile, a ragged last tile, fewer tiles than CUs, more tiles than CUs (several tiles per workgroup)
+    for M in (64, 50, 1000, 64 * 300 + 17):
+        run_case(ops, [{"M": M}], seed=M)
+
+
+def test_bias_and_tanh_epilogue(ops):
+    run_case(ops, [{"M": 3200, "bias": True, "act": 2}], seed=1)
+    run_case(ops, [{"M": 777, "bias": True}], seed=2)
+
+
+def test_key_projection_with_fused_input_dropout(ops):
+    """keys = tanh(drop(x) W^T + b): keep-bits on A's virtual rows, the two streams reading the same frames (row modulo)."""
+    run_case(ops, [{"M": 2 * 1500, "mod": 1500, "mask": True, "bias": True, "act": 2}], seed=3, repeat=True)
+    run_case(ops, [{"M": 2 * 64 * 40 + 2 * 13, "mod": 64 * 40 + 13, "mask": True, "bias": True, "act": 2}], seed=4)
+
+
+def test_input_gradient_accumulates_into_c(ops):
+    """dxd += dz W."""
+    run_case(ops, [{"M": 6400, "accumulate": True}], seed=5, repeat=True)
+    run_case(ops, [{"M": 1234, "accumulate": True}], seed=6)
+
+
+def test_several_problems_in_one_launch(ops):
+    """A launch's tile list is cut into one contiguous range per workgroup: ranges that cross problem boundaries reload B."""
+    run_case(ops, [{"M": 64 * 90 + 5, "accumulate": True}, {"M": 64 * 37, "accumulate": True}, {"M": 100, "accumulate": True},
+                   {"M": 64 * 200 + 63, "accumulate": True}], seed=7, repeat=True)
+    run_case(ops, [{"M": 3000, "mod": 1500, "mask": True, "bias": True, "act": 2}, {"M": 64, "mask": True, "act": 2},
+                   {"M": 64 * 129, "mask": True, "bias": True, "act": 2}], seed=8)
+
+
+def test_c2_shapes(ops):
+    """The audio sites of a C2 step: 48000 virtual rows of 24000 frames."""
+    run_case(ops, [{"M": 48000, "mod": 24000, "mask": True, "bias": True, "act": 2}], seed=9)
+    run_case(ops, [{"M": 48000, "accumulate": True}, {"M": 28800, "accumulate": True}], seed=10)
+
+
+def test_mixed_variants_are_refused(ops):
+    g = torch.Generator().manual_seed(0)
+    A = torch.randn(128, 256, generator=g).cuda()
+    B = torch.randn(256, 256, generator=g).cuda()
+    bits, _ = keep_bits(128, g)
+    with pytest.raises(RuntimeError):
+        ops.gemm_rows256([{"A": A, "B": B, "bits": bits.cuda()}, {"A": A, "B": B}])
+    with pytest.raises(RuntimeError):
+        ops.gemm_rows256([{"A": A, "B": B, "bits": bits.cuda(), "accumulate": True}])

@@ -1,0 +1,51 @@
+"""Standalone rate of sdumc_gemm_rows256 on the C2 shapes against the kernels it replaces (run on the GPU box).
+usage: python tools/rows_bench.py"""
+import sys, time
+sys.path.insert(0, ".")
+import torch
+from sdumc_amd import ops
+
+torch.manual_seed(0)
+dev = "cuda"
+
+
+def timeit(fn, reps=30):
+    t0 = time.time()
+    while time.time() - t0 < 0.5:       # clocks up
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def bits_of(M):
+    return torch.randint(0, 16, (M, 64), dtype=torch.uint8, device=dev)
+
+
+W = [torch.randn(256, 256, device=dev) / 16 for _ in range(4)]
+bias = torch.randn(256, device=dev)
+for name, Ms in (("audio site", [48000]), ("video both sites", [28800, 28800]), ("text both", [6400, 6400]),
+                 ("audio+video+text dX (5 sites)", [48000, 28800, 28800, 6400, 6400])):
+    fl = sum(2.0 * M * 65536 for M in Ms)
+    A = [torch.randn(M, 256, device=dev) for M in Ms]
+    C = [torch.randn(M, 256, device=dev) for M in Ms]
+    # dX: accumulate
+    probs = [{"A": a, "B": W[i % 4], "C": c, "accumulate": True} for i, (a, c) in enumerate(zip(A, C))]
+    t = timeit(lambda: ops.gemm_rows256(probs))
+    # the 64x64 NN kernel (one launch per site here; the engine groups sites of equal M)
+    def old():
+        for i, (a, c) in enumerate(zip(A, C)):
+            ops.gemm(ops.NN, a, W[i % 4], a.shape[0], 256, 256, C_out=c, accumulate=True)
+    t_old = timeit(old)
+    # forward: masked + bias + tanh
+    bts = [bits_of(M) for M in Ms]
+    probs_f = [{"A": a, "B": W[i % 4], "C": c, "bits": b, "scale": 2.0, "bias": bias, "act": ops.ACT_TANH}
+               for i, (a, c, b) in enumerate(zip(A, C, bts))]
+    t_f = timeit(lambda: ops.gemm_rows256(probs_f))
+    print(f"{name:32s} {fl / 1e9:6.2f} GF  dX rows {t:7.1f} us {fl / t / 1e6:6.1f} TF | dX 64x64 NN {t_old:7.1f} us {fl / t_old / 1e6:6.1f} TF"
+          f" | fwd masked+tanh {t_f:7.1f} us {fl / t_f / 1e6:6.1f} TF")
