@@ -211,6 +211,11 @@ typedef struct sdumc_rows_problem {
   int32_t act;              /* SDUMC_ACT_NONE or SDUMC_ACT_TANH */
 } sdumc_rows_problem;
 int sdumc_gemm_rows256(const sdumc_rows_problem* probs, int32_t n, void* stream);
+/* The same on bf16 STORAGE (sdumc_net_dims.bf16 = 2): A ([M][256]), B and C are bf16 tensors (lda / ldb / ldc in elements, lda
+ * and ldb multiples of 8, A and B 16-byte aligned); B is [256 n][256 k] -- the rows of B are the OUTPUT columns, C = A B^T: the
+ * bf16 weight copy as stored for the key projections, its transposed copy for dxd += dz W; bias fp32; a_bits must be NULL (the
+ * engine materialises the masked frames); products accumulate in fp32 on v_mfma_f32_32x32x16_bf16. */
+int sdumc_gemm_rows256_bf16(const sdumc_rows_problem* probs, int32_t n, void* stream);
 
 /* ------------------------------------------------------------------------
  * Attention pooling over the time axis = the body shared by

@@ -37,7 +37,7 @@ struct ProfRec {
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::mutex g_prof_mu;
-constexpr int kNumVariants = 22;
+constexpr int kNumVariants = 23;
 const char* const kVariantName[kNumVariants] = {"gemm_nt_128x128", "gemm_nt_64x64",  "gemm_nn_128x128",
                                                 "gemm_nn_64x64",   "gemm_tn_128x128", "gemm_tn_64x64",
                                                 "gemm_small_nt",   "gemm_small_nn",   "gemm_small_tn",
@@ -47,7 +47,7 @@ const char* const kVariantName[kNumVariants] = {"gemm_nt_128x128", "gemm_nt_64x6
                                                 "gemm_wide_nt", "gemm_wide_tn",
                                                 "gemm_bf16s_nt", "gemm_bf16s_tn",    // gemm_bf16.hip (bf16 storage)
                                                 "gemm_group_tn", "gemm_group_tn_bf16",    // gemm_group.hip (the persistent kernel alone, without its reduce)
-                                                "gemm_rows256"};                          // gemm_rows.hip
+                                                "gemm_rows256", "gemm_rows256_bf16"};     // gemm_rows.hip
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;

@@ -40,7 +40,8 @@ namespace sdumc_gr {
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-constexpr int waitcnt_vm(int n) { return (n & 0xF) | ((n >> 4) << 14) | (0x7 << 4) | (0xF << 8); }
+// (vmcnt is a 6-bit counter: a count beyond 63 is waited for as 63 -- stricter, so still correct)
+constexpr int waitcnt_vm(int n) { return ((n > 63 ? 63 : n) & 0xF) | (((n > 63 ? 63 : n) >> 4) << 14) | (0x7 << 4) | (0xF << 8); }
 __device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }   // = gemm_wide.hip
 
 constexpr int BM = 64, DK = 256, DN = 256, BK = 32;
@@ -75,6 +76,11 @@ constexpr int younger(int s) {
   for (int t = 1; t < PF - 1; ++t) n += ops_at<MASK, ACC>((t0 + t) % NS);
   return n;
 }
+
+// (the tables these formulas produce, stage 0..7: plain 4 x 8; masked 4 4 4 6 6 6 6 4; accumulating 36 36 36 4 4 4 36 36)
+static_assert(younger<false, false>(0) == 4 && younger<false, false>(5) == 4, "plain");
+static_assert(younger<true, false>(2) == 4 && younger<true, false>(3) == 6 && younger<true, false>(6) == 6 && younger<true, false>(7) == 4, "masked");
+static_assert(younger<false, true>(2) == 36 && younger<false, true>(3) == 4 && younger<false, true>(5) == 4 && younger<false, true>(6) == 36, "accumulating");
 
 template <bool MASK, bool ACC>
 __global__ __launch_bounds__(NTHR, 2) void gr_kernel(const Launch L) {
@@ -271,6 +277,193 @@ __global__ __launch_bounds__(NTHR, 2) void gr_kernel(const Launch L) {
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// The same launch on bf16 STORAGE (the engine's bf16 mode, BASELINE configs[2] / [4]): A ([M][256], the masked frames xd or dz),
+// B ([256 n][256 k]: the weight copy whose rows are the output columns) and C are bf16 tensors, products accumulate in fp32 on
+// v_mfma_f32_32x32x16_bf16, bias / tanh in fp32.  A row of a stage is 64 k = 128 bytes, so the ring slots, the swizzle, the
+// DMA pieces and the fragment reads are those of the fp32 kernel; a tile is 4 stages, the 8-slot ring holds two, and the
+// unrolled body works through a PAIR of tiles.  B is 64 VGPRs per wave.  At bf16 matrix rates a 64-row tile multiplies in
+// under a microsecond: the kernel is bound by its streams (A in, C out, C in for the accumulate) -- what the persistent ring
+// buys here is 48 KB per CU in flight all the time instead of one short k-loop per workgroup.
+// ------------------------------------------------------------------------------------------------------------------------
+namespace hf {
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+#define SDUMC_GR_HNS 4                            /* stages per tile (64 k each) */
+constexpr int T_C0 = 1, T_C1 = 5;               // issue points (of the pair's 8) that carry the C prefetch of tile 0 / tile 1
+template <bool ACC>
+constexpr int ops_at(int t) { return 1 + ((ACC && (t == T_C0 || t == T_C1)) ? 32 : 0); }
+template <bool ACC>
+constexpr int younger(int s) {
+  const int t0 = ((s + 1 - PF) % NS + NS) % NS;
+  int n = (ACC && (t0 == T_C0 || t0 == T_C1)) ? 32 : 0;
+  for (int t = 1; t < PF - 1; ++t) n += ops_at<ACC>((t0 + t) % NS);
+  return n;
+}
+__device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {
+  __bf16 h = (__bf16)f;      // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
+  return *reinterpret_cast<unsigned short*>(&h);
+}
+}  // namespace hf
+
+// (stage 0..7 of a pair: plain 4 x 8; accumulating 36 36 68 36 36 36 68 36 -- 68 = both C prefetches were issued behind the A piece)
+static_assert(hf::younger<false>(0) == 4 && hf::younger<true>(0) == 36 && hf::younger<true>(1) == 36 && hf::younger<true>(2) == 68 &&
+              hf::younger<true>(3) == 36 && hf::younger<true>(6) == 68 && hf::younger<true>(7) == 36, "bf16 pair: C prefetch at stages 1 and 5");
+
+template <bool ACC>
+__global__ __launch_bounds__(NTHR, 2) void gr_bf16_kernel(const Launch L) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using namespace hf;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0 = wave * 32;
+  const int U = L.unit0[L.n];
+  int u = (int)(((uint32_t)blockIdx.x * (uint32_t)U) / (uint32_t)L.nwg);
+  const int u_end = (int)((((uint32_t)blockIdx.x + 1u) * (uint32_t)U) / (uint32_t)L.nwg);
+  uint32_t foff[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) foff[c] = (uint32_t)(li * 128 + (((2 * c + lh) ^ (li & 7)) << 4));
+  const int dr = 8 * wave + (lane >> 3);
+  const uint32_t dq16 = (uint32_t)(((lane & 7) ^ (lane >> 3)) << 4);
+  typedef float f32x4_ __attribute__((ext_vector_type(4)));
+  f32x16 acc[2];
+
+  while (u < u_end) {
+    int p = 0;
+    while (p + 1 < L.n && L.unit0[p + 1] <= u) ++p;
+    const sdumc_rows_problem& pr = L.p[p];
+    const int ub = min(u_end, L.unit0[p + 1]);
+    const int tile0 = L.unit0[p];
+    const uint32_t lda2 = (uint32_t)pr.lda * 2u, ldc2 = (uint32_t)pr.ldc * 2u;
+    const int a_rows = pr.a_row_mod > 0 ? pr.a_row_mod : pr.M;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.A), 0, (int)((uint32_t)a_rows * lda2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(pr.C, 0, (int)((uint32_t)pr.M * ldc2), 0x00020000);
+    // B: the MFMA operand of step j = 4 s + c is k = 64 s + 16 c + 8 lh .. + 7 of row n0 + li: one 16-byte load
+    bf16x8 breg[16];
+    {
+      const uint32_t ldb2 = (uint32_t)pr.ldb * 2u;
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.B), 0, (int)((uint32_t)DN * ldb2), 0x00020000);
+      const uint32_t bo = (uint32_t)(n0 + li) * ldb2 + 16u * (uint32_t)lh;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rb, bo, 32 * j, 0);
+        breg[j] = *reinterpret_cast<const bf16x8*>(&v);
+      }
+    }
+    const float bias = pr.bias ? pr.bias[n0 + li] : 0.f;
+    const bool do_tanh = pr.act == SDUMC_ACT_TANH;
+
+    auto a_off = [&](int t) -> uint32_t {      // tiles at and past the end of this workgroup's run of the problem: nothing
+      if (t >= ub) return SDUMC_GR_NULL_OFF;
+      int r = (t - tile0) * BM + dr;
+      if (pr.a_row_mod > 0) r %= pr.a_row_mod;
+      return (uint32_t)r * lda2 + dq16;
+    };
+    auto c_off_of = [&](int t) -> uint32_t {
+      if (t >= ub) return SDUMC_GR_NULL_OFF;
+      return (uint32_t)((t - tile0) * BM + 4 * lh) * ldc2 + (uint32_t)(n0 + li) * 2u;
+    };
+    auto issue_a = [&](uint32_t off, int chunk, int slot) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(lds + slot * A_STAGE + wave * 1024), 16, off, chunk * 128, 0, 0);
+    };
+    struct Frag {
+      f32x4_ a[2][2];
+    };
+    auto read_frag = [&](int slot, int h, Frag& f) {
+      const char* base = lds + slot * A_STAGE;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int cc = 0; cc < 2; ++cc) f.a[i][cc] = *reinterpret_cast<const f32x4_*>(base + i * (32 * 128) + foff[2 * h + cc]);
+    };
+    auto mma = [&](Frag& f, int h, int s4) {
+#pragma unroll
+      for (int cc = 0; cc < 2; ++cc)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&f.a[i][cc]), breg[4 * s4 + 2 * h + cc], acc[i], 0, 0, 0);
+    };
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    {
+      const uint32_t o0 = a_off(u), o1 = a_off(u + 1);
+#pragma unroll
+      for (int s = 0; s < PF; ++s) issue_a(s < SDUMC_GR_HNS ? o0 : o1, s % SDUMC_GR_HNS, s);
+    }
+    __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+    __builtin_amdgcn_s_barrier();
+    Frag fa, fb;
+    read_frag(0, 0, fa);
+
+#pragma nounroll
+    for (; u < ub; u += 2) {
+      const uint32_t o[4] = {a_off(u), a_off(u + 1), a_off(u + 2), a_off(u + 3)};
+      const uint32_t co[2] = {c_off_of(u), c_off_of(u + 1)};
+      float cpre[ACC ? 32 : 1];
+      auto epilogue = [&](uint32_t c_off, auto tanh_c) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            float v = acc[i][e] + bias;
+            if constexpr (ACC) v += cpre[i * 16 + e];
+            if constexpr (decltype(tanh_c)::value) v = fast_tanh(v);
+            __builtin_amdgcn_raw_buffer_store_b16(f2bf(v), rc, c_off, (32 * i + (e & 3) + 8 * (e >> 2)) * ldc2, 0);
+            acc[i][e] = 0.f;
+          }
+      };
+      auto stage = [&](auto sc) {
+        constexpr int s = decltype(sc)::value;        // stage of the pair: tile s / 4, its stage s % 4; ring slot s
+        read_frag(s, 1, fb);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa, 0, s % SDUMC_GR_HNS);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(waitcnt_vm(hf::younger<ACC>(s)));
+        __builtin_amdgcn_s_barrier();
+        issue_a(o[(s + PF) / SDUMC_GR_HNS], (s + PF) % SDUMC_GR_HNS, (s + PF) % NS);
+        if constexpr (ACC) {
+          if constexpr (s == T_C0 || s == T_C1) {
+            const uint32_t c_off = co[s == T_C0 ? 0 : 1];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+              for (int e = 0; e < 16; ++e)
+                cpre[i * 16 + e] = bf2f(__builtin_amdgcn_raw_buffer_load_b16(rc, c_off, (32 * i + (e & 3) + 8 * (e >> 2)) * ldc2, 0));
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        read_frag((s + 1) % NS, 0, fa);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fb, 1, s % SDUMC_GR_HNS);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (s % SDUMC_GR_HNS == SDUMC_GR_HNS - 1) {       // a tile is complete (the next one's stages are in flight behind its epilogue)
+          if (do_tanh) epilogue(co[s / SDUMC_GR_HNS], std::true_type{});
+          else epilogue(co[s / SDUMC_GR_HNS], std::false_type{});
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      stage(std::integral_constant<int, 0>{});
+      stage(std::integral_constant<int, 1>{});
+      stage(std::integral_constant<int, 2>{});
+      stage(std::integral_constant<int, 3>{});
+      stage(std::integral_constant<int, 4>{});
+      stage(std::integral_constant<int, 5>{});
+      stage(std::integral_constant<int, 6>{});
+      stage(std::integral_constant<int, 7>{});
+    }
+    u = ub;
+    __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+    __builtin_amdgcn_s_barrier();
+  }
+#endif
+}
+
 int cu_count() {
   static std::mutex mu;
   static int per_device[64] = {};
@@ -296,6 +489,8 @@ bool set_lds_attr() {   // the dynamic-LDS limit is a per-device function attrib
                          reinterpret_cast<const void*>(&gr_kernel<false, true>)};
     for (const void* k : ks)
       if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return false;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gr_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, RING) != hipSuccess) return false;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gr_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, RING) != hipSuccess) return false;
     done[dev] = true;
   }
   return true;
@@ -347,6 +542,44 @@ extern "C" int sdumc_gemm_rows256(const sdumc_rows_problem* probs, int32_t n, vo
   if (mask) hipLaunchKernelGGL((gr_kernel<true, false>), dim3(L.nwg), dim3(NTHR), LDS_BYTES, st, L);
   else if (accum) hipLaunchKernelGGL((gr_kernel<false, true>), dim3(L.nwg), dim3(NTHR), LDS_BYTES, st, L);
   else hipLaunchKernelGGL((gr_kernel<false, false>), dim3(L.nwg), dim3(NTHR), LDS_BYTES, st, L);
+  sdumc_prof_end_(tok, stream);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+// A ([M][256]), B ([256 n][256 k], row stride ldb: C = A B^T) and C are bf16 tensors (lda / ldb / ldc in elements, lda a multiple
+// of 8, A 16-byte aligned); bias fp32; no fused dropout (a_bits must be NULL: the engine materialises the masked frames)
+extern "C" int sdumc_gemm_rows256_bf16(const sdumc_rows_problem* probs, int32_t n, void* stream) {
+  if (!probs || n <= 0 || n > MAXP) return SDUMC_EINVAL;
+  const bool accum = probs[0].accumulate != 0;
+  Launch L;
+  memset(&L, 0, sizeof(L));
+  int units = 0;
+  double flops = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const sdumc_rows_problem& p = probs[i];
+    if (!p.A || !p.B || !p.C || p.a_bits || p.M <= 0 || p.lda < DK || p.ldb < DK || p.ldc < DN || (p.lda & 7) || (p.ldb & 7) || p.a_row_mod < 0)
+      return SDUMC_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(p.A) | reinterpret_cast<uintptr_t>(p.B)) & 15) return SDUMC_EINVAL;
+    if (reinterpret_cast<uintptr_t>(p.C) & 1) return SDUMC_EINVAL;
+    if (p.act != SDUMC_ACT_NONE && p.act != SDUMC_ACT_TANH) return SDUMC_EINVAL;
+    const size_t rows = (size_t)p.M + 4 * BM;
+    if (rows * p.lda * 2 >= 0x7FFFFFF0u || rows * p.ldc * 2 >= 0x7FFFFFF0u) return SDUMC_EINVAL;
+    if ((p.accumulate != 0) != accum) return SDUMC_EINVAL;
+    L.p[i] = p;
+    L.unit0[i] = units;
+    units += (p.M + BM - 1) / BM;
+    flops += 2.0 * p.M * (double)DK * DN;
+  }
+  L.unit0[n] = units;
+  L.n = n;
+  L.nwg = std::min(cu_count(), units);      // (a workgroup works through pairs of tiles; with fewer tiles than CUs a pair is one tile and nothing)
+  if ((long long)units * (L.nwg + 1) >= (1LL << 31)) return SDUMC_EINVAL;
+  if (!set_lds_attr()) return SDUMC_ELAUNCH;
+  hipStream_t st = as_stream(stream);
+  const int tok = sdumc_prof_begin_(22, flops, stream);
+  if (accum) hipLaunchKernelGGL((gr_bf16_kernel<true>), dim3(L.nwg), dim3(NTHR), RING, st, L);
+  else hipLaunchKernelGGL((gr_bf16_kernel<false>), dim3(L.nwg), dim3(NTHR), RING, st, L);
   sdumc_prof_end_(tok, stream);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;

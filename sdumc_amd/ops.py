@@ -118,7 +118,8 @@ def gemm_rows256(problems):
 
     problems: list of dicts {A, B, [C], [bits], [bias], [scale], [a_row_mod], [accumulate], [act], [M]}:
     C[M, 256] = act((A . keep) B * scale + bias) (+ C); A [rows, 256] and B [256 k, 256 n] 2-D fp32 device tensors, bits the
-    uint8 keep-bits [M, 64] of a dropout fused on A's virtual rows.  All masked, all accumulating, or neither."""
+    uint8 keep-bits [M, 64] of a dropout fused on A's virtual rows.  All masked, all accumulating, or neither.
+    torch.bfloat16 tensors go to sdumc_gemm_rows256_bf16: B is then [256 n, 256 k] (C = A B^T), C bf16, no bits."""
     n = len(problems)
     arr = (_lib.RowsProblem * n)()
     for i, q in enumerate(problems):
@@ -133,12 +134,13 @@ def gemm_rows256(problems):
         g.a_scale = q.get("scale", 1.0)
         Cm = q.get("C")
         if Cm is None:
-            Cm = torch.empty(g.M, 256, device=A.device)
+            Cm = torch.empty(g.M, 256, device=A.device, dtype=A.dtype)
             q["C"] = Cm
         g.C, g.ldc = ptr(Cm), Cm.stride(0)
         g.accumulate = 1 if q.get("accumulate") else 0
         g.act = q.get("act", ACT_NONE)
-    check(lib.sdumc_gemm_rows256(arr, n, _st()), "sdumc_gemm_rows256")
+    hf = problems[0]["A"].dtype == torch.bfloat16
+    check((lib.sdumc_gemm_rows256_bf16 if hf else lib.sdumc_gemm_rows256)(arr, n, _st()), "sdumc_gemm_rows256")
     return [q["C"] for q in problems]
 
 

@@ -129,3 +129,51 @@ def test_mixed_variants_are_refused(ops):
         ops.gemm_rows256([{"A": A, "B": B, "bits": bits.cuda()}, {"A": A, "B": B}])
     with pytest.raises(RuntimeError):
         ops.gemm_rows256([{"A": A, "B": B, "bits": bits.cuda(), "accumulate": True}])
+
+
+# ---- bf16 storage (sdumc_gemm_rows256_bf16) ----
+def run_case_bf16(ops, specs, seed, repeat=False):
+    g = torch.Generator().manual_seed(seed)
+    probs, c0s = [], []
+    for sp in specs:
+        M, mod = sp["M"], sp.get("mod", 0)
+        q = {"A": (torch.randn(mod or M, 256, generator=g) * 0.5).to(torch.bfloat16).cuda(),
+             "B": (torch.randn(256, 256, generator=g) / 16).to(torch.bfloat16).cuda(),      # [n][k]
+             "M": M, "a_row_mod": mod, "act": sp.get("act", 0)}
+        if sp.get("bias"):
+            q["bias"] = torch.randn(256, generator=g).cuda()
+        C0 = torch.randn(M, 256, generator=g).to(torch.bfloat16).cuda()
+        if sp.get("accumulate"):
+            q["accumulate"] = True
+        q["C"] = C0.clone()
+        probs.append(q)
+        c0s.append(C0)
+    out = [c.clone() for c in ops.gemm_rows256(probs)]
+    torch.cuda.synchronize()
+    for q, C0, got, sp in zip(probs, c0s, out, specs):
+        qq = dict(q)
+        qq["B"] = q["B"].float().t().contiguous()      # the fp32 reference takes B as [k][n]
+        qq["A"] = q["A"].float()
+        want = ref_of(qq, None, C0.float())
+        close(got.float(), want, tol=6e-3, msg=str(sp))      # one bf16 rounding of the result (2^-9 relative)
+    if repeat:
+        for q, C0 in zip(probs, c0s):
+            q["C"].copy_(C0)
+        again = ops.gemm_rows256(probs)
+        torch.cuda.synchronize()
+        for a, b in zip(out, again):
+            assert torch.equal(a, b)
+
+
+def test_bf16_plain_ragged_and_paired_tiles(ops):
+    # one tile (its pair partner is nothing), odd and even tile counts per workgroup, a ragged last tile
+    for M in (64, 50, 128, 1000, 64 * 300 + 17, 64 * 513):
+        run_case_bf16(ops, [{"M": M}], seed=M)
+
+
+def test_bf16_key_projection_and_input_gradient(ops):
+    run_case_bf16(ops, [{"M": 48000, "bias": True, "act": 2}], seed=21, repeat=True)
+    run_case_bf16(ops, [{"M": 3000, "mod": 1500, "bias": True, "act": 2}], seed=22)
+    run_case_bf16(ops, [{"M": 48000, "accumulate": True}, {"M": 28800, "accumulate": True}, {"M": 100, "accumulate": True}],
+                  seed=23, repeat=True)
+    run_case_bf16(ops, [{"M": 64 * 37 + 5, "accumulate": True}, {"M": 64 * 90, "accumulate": True}], seed=24)

@@ -49,3 +49,28 @@ for name, Ms in (("audio site", [48000]), ("video both sites", [28800, 28800]), 
     t_f = timeit(lambda: ops.gemm_rows256(probs_f))
     print(f"{name:32s} {fl / 1e9:6.2f} GF  dX rows {t:7.1f} us {fl / t / 1e6:6.1f} TF | dX 64x64 NN {t_old:7.1f} us {fl / t_old / 1e6:6.1f} TF"
           f" | fwd masked+tanh {t_f:7.1f} us {fl / t_f / 1e6:6.1f} TF")
+
+# ---- bf16 storage ----
+print("bf16 storage:")
+Wh = [w.to(torch.bfloat16) for w in W]
+for name, Ms in (("audio site", [48000]), ("video both sites", [28800, 28800]), ("text both", [6400, 6400]),
+                 ("audio+video+text (5 sites)", [48000, 28800, 28800, 6400, 6400])):
+    fl = sum(2.0 * M * 65536 for M in Ms)
+    A = [torch.randn(M, 256, device=dev).to(torch.bfloat16) for M in Ms]
+    C = [torch.randn(M, 256, device=dev).to(torch.bfloat16) for M in Ms]
+    probs = [{"A": a, "B": Wh[i % 4], "C": c, "accumulate": True} for i, (a, c) in enumerate(zip(A, C))]
+    t = timeit(lambda: ops.gemm_rows256(probs))
+    by = sum(M * 512 * 3 for M in Ms)
+    def old():
+        for i, (a, c) in enumerate(zip(A, C)):
+            ops.gemm_bf16(ops.NT, a, Wh[i % 4], a.shape[0], 256, 256, C_out=c, accumulate=True, c_bf16=True)
+    t_old = timeit(old)
+    probs_f = [{"A": a, "B": Wh[i % 4], "C": c, "bias": bias, "act": ops.ACT_TANH} for i, (a, c) in enumerate(zip(A, C))]
+    t_f = timeit(lambda: ops.gemm_rows256(probs_f))
+    byf = sum(M * 512 * 2 for M in Ms)
+    def oldf():
+        for i, (a, c) in enumerate(zip(A, C)):
+            ops.gemm_bf16(ops.NT, a, Wh[i % 4], a.shape[0], 256, 256, bias=bias, C_out=c, act=ops.ACT_TANH, c_bf16=True)
+    t_oldf = timeit(oldf)
+    print(f"{name:32s} dX rows {t:7.1f} us {by / t / 1e6:5.2f} TB/s | dX gemm_bf16 {t_old:7.1f} us | fwd rows {t_f:7.1f} us {byf / t_f / 1e6:5.2f} TB/s"
+          f" | fwd gemm_bf16 {t_oldf:7.1f} us")
