@@ -219,6 +219,28 @@ __device__ __forceinline__ void attn_fwd_partial_body(const sdumc_attnpool p, fl
     st4(q_s + i * LDQ + 4 * cq, i < nq ? ld4(p.q + (size_t)v * p.q_stride + (size_t)i * DD + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f});
   }
   __syncthreads();
+  // The pooling below streams this wave's 16 frame rows (one 16-byte access per lane and row).  Rows 0-7 are requested HERE,
+  // before the scores: their HBM round trip then runs under the key-row loads, the MFMAs and the two chunk reductions instead
+  // of being exposed behind them; rows 8-15 are requested while rows 0-7 are consumed.  (Round 3: the forward pooling of the
+  // three Cross_Attention sites 40.6 -> see profiles/README.md.)
+  constexpr int RB = 4;
+  const DropRT xd = drop_resolve(p.x_drop);
+  const int vx = v % p.x_samples;
+  const bool masked = !PHILOX && xd.enabled != 0;
+  f32x4 xa[RB], xb[RB];
+  uint32_t ma[RB], mb2[RB];
+  auto load_rows = [&](int rb, f32x4* xr, uint32_t* mb) {       // channel block 0
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int t = min(t0 + 16 * wave + rb + j, T - 1);   // rows beyond T re-read the last row; their P_s is 0
+      xr[j] = ldx<HF>(p.x, ((size_t)vx * T + t) * DD + 4 * lane);
+      mb[j] = masked ? xd.bits[(size_t)(v * T + t) * xd.qwidth + lane] : 0xfu;
+    }
+  };
+  if constexpr (!PHILOX) {
+    load_rows(0, xa, ma);
+    load_rows(RB, xb, mb2);
+  }
   const int myrow = t0 + 16 * wave + r16;
   const DropRT nodrop = {};
   const f32x4 s4 = KLDS ? rows_times_cols<false, C, false>(k_lds, q_s, nodrop, 0u, r16, kk, (size_t)(16 * wave + r16) * UMCA_LDK)
@@ -263,8 +285,6 @@ __device__ __forceinline__ void attn_fwd_partial_body(const sdumc_attnpool p, fl
   }
   // unnormalised pooling of this chunk, one 256-channel block at a time: lane owns channels 4*lane..4*lane+3 of the
   // block, wave owns 16 rows
-  const DropRT xd = drop_resolve(p.x_drop);
-  const int vx = v % p.x_samples;
   // (a generic lambda called once per block, not a loop over blocks: ANY enclosing loop -- even one of trip count 1 --
   // makes hipcc (ROCm 7.2) unroll the row loops inside it despite their `unroll 1` and spill ~4600 VGPRs)
   auto pool_block = [&](auto cbc) {
@@ -285,11 +305,32 @@ __device__ __forceinline__ void attn_fwd_partial_body(const sdumc_attnpool p, fl
         for (int i = 0; i < MAXQ; ++i)
           if (i < nq) acc[i] += x * P_s[rl * MAXQ + i];
       }
+    } else if constexpr (cb == 0) {
+      // rows in batches of RB, two batches in flight (requested before the scores, see above)
+      const float mscale = masked ? xd.scale : 1.f;
+      auto consume = [&](int rb, const f32x4* xr, const uint32_t* mb) {
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          const int rl = 16 * wave + rb + j;
+          f32x4 x = xr[j];
+          const uint32_t b = mb[j];
+          x[0] = (b & 1u) ? x[0] * mscale : 0.f;
+          x[1] = (b & 2u) ? x[1] * mscale : 0.f;
+          x[2] = (b & 4u) ? x[2] * mscale : 0.f;
+          x[3] = (b & 8u) ? x[3] * mscale : 0.f;
+#pragma unroll
+          for (int i = 0; i < MAXQ; ++i)
+            if (i < nq) acc[i] += x * P_s[rl * MAXQ + i];   // rows beyond T: P_s = 0
+        }
+      };
+      consume(0, xa, ma);
+      load_rows(2 * RB, xa, ma);
+      consume(RB, xb, mb2);
+      load_rows(3 * RB, xb, mb2);
+      consume(2 * RB, xa, ma);
+      consume(3 * RB, xb, mb2);
     } else {
-      // rows in batches of RB: all of a batch's 16-byte loads (and keep-bits bytes) are in flight before the first
-      // FMA consumes one -- the row-at-a-time loop this replaces paid one memory round trip per row (16 per wave)
-      constexpr int RB = 4;
-      const bool masked = xd.enabled != 0;
+      // (channel blocks 1..3 of the blocks' stand-alone 1024-channel use: batches of RB, one at a time)
       const float mscale = masked ? xd.scale : 1.f;
 #pragma unroll 1
       for (int rb = 0; rb < 16; rb += RB) {
@@ -415,6 +456,18 @@ __device__ __forceinline__ void attnpool_bwd_body(const sdumc_attnpool_bwd_t b, 
   const int t0 = chunk * CH;
   const bool fuse = p.tickets != nullptr;
   const DropRT od = drop_resolve(p.out_drop);
+  // this wave's first four key rows are requested before anything else: the round trip runs under the dO staging, the
+  // delta dot products and the dA MFMAs
+  constexpr int RB = 4;
+  f32x4 kr[2][RB];
+  auto load_batch = [&](int rb, f32x4* dst, int ch) {
+#pragma unroll
+    for (int j = 0; j < RB; ++j) {
+      const int t = t0 + 16 * wave + rb + j;
+      dst[j] = t < T ? ldx<HF>(p.keys, ((size_t)v * T + t) * DD + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  load_batch(0, kr[0], 4 * lane);
   for (int e = tid; e < MAXQ * (DD / 4); e += 256) {
     const int i = e / (DD / 4), cq = e - i * (DD / 4);
     f32x4 g = {0.f, 0.f, 0.f, 0.f};
@@ -477,20 +530,17 @@ __device__ __forceinline__ void attnpool_bwd_body(const sdumc_attnpool_bwd_t b, 
     }
     // rows in batches of RB: the batch's key-row loads are all in flight before the first row is processed
     // (bf16 rows: 8 per batch measured SLOWER -- 1.156 vs 1.128 ms per bf16 step -- although they are half as long)
-    constexpr int RB = 4;
+    // (round 3: the NEXT batch's loads are issued before this batch's stores -- the compiler does not move a load above a
+    //  store that may alias it, so every batch used to start with an exposed HBM round trip)
+    if (cb > 0) load_batch(0, kr[0], ch);
 #pragma unroll
     for (int rb = 0; rb < 16; rb += RB) {
-      f32x4 kr[RB];
-#pragma unroll
-      for (int j = 0; j < RB; ++j) {
-        const int t = t0 + 16 * wave + rb + j;
-        kr[j] = t < T ? ldx<HF>(p.keys, ((size_t)v * T + t) * DD + ch) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
+      if (rb + RB < 16) load_batch(rb + RB, kr[((rb / RB) + 1) & 1], ch);
 #pragma unroll
       for (int j = 0; j < RB; ++j) {
         const int rl = 16 * wave + rb + j, t = t0 + rl;
         const size_t row = (size_t)v * T + t;
-        const f32x4 k = kr[j];
+        const f32x4 k = kr[(rb / RB) & 1][j];
         f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dx = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int i = 0; i < MAXQ; ++i)

@@ -89,6 +89,7 @@ const int32_t* sdumc_chain_cluster_err_ptr_(void);    // device address of the e
 int sdumc_weights_to_bf16_(const float* src, void* dst, void* dst_t, const int64_t* offs, const int32_t* outs, const int32_t* ins,
                            const int32_t* want_t, int n, void* stream);
 size_t sdumc_gg_slab_bytes_(int tiles);   // gemm_group.hip: workspace bound for sdumc_gemm_group_tn by output-tile count
+int sdumc_gemm_rows_prepare_(void);       // gemm_rows.hip: the kernels' per-device attributes, set outside any stream capture
 int sdumc_chain_transpose_(const float* src, float* dst, const int64_t* offs, const int32_t* outs, const int32_t* ins, int n,
                            void* stream);
 }

@@ -2031,6 +2031,7 @@ extern "C" int32_t sdumc_param_table(int32_t da, int32_t dt, int32_t dv, char* b
 
 extern "C" size_t sdumc_net_workspace_bytes(const sdumc_net_dims* d) {
   ensure_side_streams();   // never called under stream capture: the place to create the internal lanes
+  (void)sdumc_gemm_rows_prepare_();
   Plan p;
   if (!d || !make_plan(*d, p)) return 0;
   return (size_t)p.cur * sizeof(float);
