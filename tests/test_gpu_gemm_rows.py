@@ -177,3 +177,20 @@ def test_bf16_key_projection_and_input_gradient(ops):
     run_case_bf16(ops, [{"M": 48000, "accumulate": True}, {"M": 28800, "accumulate": True}, {"M": 100, "accumulate": True}],
                   seed=23, repeat=True)
     run_case_bf16(ops, [{"M": 64 * 37 + 5, "accumulate": True}, {"M": 64 * 90, "accumulate": True}], seed=24)
+
+
+def test_row_strides_wider_than_256(ops):
+    """A, B and C as column slices of wider tensors (lda / ldb / ldc > 256)."""
+    g = torch.Generator().manual_seed(31)
+    M = 64 * 5 + 9
+    Aw = (torch.randn(M, 320, generator=g) * 0.5).cuda()
+    Bw = (torch.randn(256, 384, generator=g) / 16).cuda()
+    Cw = torch.randn(M, 512, generator=g).cuda()
+    C0 = Cw.clone()
+    A, B, C = Aw[:, 32:288], Bw[:, 64:320], Cw[:, 128:384]
+    assert A.stride(0) == 320 and B.stride(0) == 384 and C.stride(0) == 512
+    ops.gemm_rows256([{"A": A, "B": B, "C": C, "accumulate": True}])
+    torch.cuda.synchronize()
+    want = C0[:, 128:384].cpu().double() + A.cpu().double() @ B.cpu().double()
+    close(C, want)
+    assert torch.equal(Cw[:, :128], C0[:, :128]) and torch.equal(Cw[:, 384:], C0[:, 384:])     # nothing outside the slice is touched
