@@ -565,6 +565,12 @@ int sdumc_dropout_bits(const sdumc_dropout* d, int32_t streams, uint8_t* bits, v
  * (width must be a multiple of 16: four quads are packed per 32-bit store; bits[s] 4-byte aligned) */
 int sdumc_dropout_bits_multi(const sdumc_dropout* d, int32_t streams, int32_t nsite, int32_t site_stride,
                              uint8_t* const* bits, void* stream);
+/* bf16-storage mode: the keep-bits of the TWO sites d->site and d->site + site_stride (they read the same frames: fra2utt_m and
+ * cross_att_fra2utt_m, model :59, :81) and the masked frames xd[s][row, :] = bf16(x[row % x_rows, :] * keep_s * d->scale) of
+ * both, in one pass over x -- what sdumc_dropout_bits_multi followed by two sdumc_mask_apply_bf16 produce, bit for bit.
+ * x, xd[s]: bf16 [.., width], 16-byte aligned; width % 16 == 0; d->enabled must be set. */
+int sdumc_dropout_bits_apply_bf16(const sdumc_dropout* d, int32_t streams, int32_t site_stride, uint8_t* const* bits,
+                                  const void* x, int64_t x_rows, void* const* xd, void* stream);
 /* writes the dropout mask values (0 or scale) of a [streams*samples, rows, width] tensor: test hook */
 int sdumc_dropout_mask(const sdumc_dropout* d, int32_t streams, float* mask, void* stream);
 const char* sdumc_version(void);

@@ -230,6 +230,8 @@ _SIGS = {
     "sdumc_rng_advance": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "sdumc_dropout_bits": (C.c_int, [C.POINTER(Dropout), C.c_int32, C.c_void_p, C.c_void_p]),
     "sdumc_dropout_bits_multi": (C.c_int, [C.POINTER(Dropout), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.c_void_p]),
+    "sdumc_dropout_bits_apply_bf16": (C.c_int, [C.POINTER(Dropout), C.c_int32, C.c_int32, C.POINTER(C.c_void_p), C.c_void_p, C.c_int64,
+                                               C.POINTER(C.c_void_p), C.c_void_p]),
     "sdumc_dropout_mask": (C.c_int, [C.POINTER(Dropout), C.c_int32, C.c_void_p, C.c_void_p]),
     "sdumc_version": (C.c_char_p, []),
     # generic MHA / Transformer-encoder pieces (transformer.hip)

@@ -238,6 +238,55 @@ __global__ void dropout_bits_kernel(const sdumc_dropout d, int64_t nwords, int n
   }
 }
 
+// bf16-storage mode: the keep-bits of TWO sites that share a row space (fra2utt_m and cross_att_fra2utt_m read the same frames)
+// AND the masked frames xd_s = bf16(x * keep_s * scale) of both, in one pass over x: a thread owns 16 channels of one virtual
+// row = one 32-bit word of keep-bits per site (dropout_bits_kernel's arithmetic) and 32 bytes of x (mask_apply_bf16_kernel's).
+struct XdOut {
+  unsigned short* p[2];
+};
+__global__ void dropout_bits_apply_bf16_kernel(const sdumc_dropout d, int64_t nwords, int site_stride, BitsOut out,
+                                               const unsigned short* __restrict__ x, int64_t x_rows, XdOut xd) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nwords) return;
+  DropRT r = drop_resolve(d);
+  r.bits = nullptr;   // always from Philox
+  const uint32_t wpr = r.qwidth >> 2;                      // 32-bit words (16 channels) per row
+  const uint32_t vrow = (uint32_t)(i / wpr), w = (uint32_t)(i - (int64_t)vrow * wpr);
+  const uint4* xp = reinterpret_cast<const uint4*>(x + (((int64_t)vrow % x_rows) * wpr + w) * 16);
+  const uint4 xin[2] = {xp[0], xp[1]};
+  const float scale = r.scale;
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    uint32_t word = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 m = drop_mask4(r, vrow, 4 * w + q);
+      word |= (uint32_t)((m[0] != 0.f) | ((m[1] != 0.f) << 1) | ((m[2] != 0.f) << 2) | ((m[3] != 0.f) << 3)) << (8 * q);
+    }
+    reinterpret_cast<uint32_t*>(out.p[s])[i] = word;
+    uint4 o[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {      // 8 channels = bytes 2h, 2h + 1 of the word
+      const unsigned m = (word >> (16 * h)) & 0xffffu;
+      const unsigned wv[4] = {xin[h].x, xin[h].y, xin[h].z, xin[h].w};
+      unsigned ov[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const unsigned b0 = (m >> (8 * (k >> 1) + 2 * (k & 1))) & 1u, b1 = (m >> (8 * (k >> 1) + 2 * (k & 1) + 1)) & 1u;
+        const float lo = b0 ? __uint_as_float(wv[k] << 16) * scale : 0.f, hi = b1 ? __uint_as_float(wv[k] & 0xffff0000u) * scale : 0.f;
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        const bf16x2 hh = {(__bf16)lo, (__bf16)hi};
+        ov[k] = *reinterpret_cast<const unsigned*>(&hh);
+      }
+      o[h] = uint4{ov[0], ov[1], ov[2], ov[3]};
+    }
+    uint4* op = reinterpret_cast<uint4*>(xd.p[s] + i * 16);
+    op[0] = o[0];
+    op[1] = o[1];
+    r.site += (uint32_t)site_stride;
+  }
+}
+
 // dx[b,t,:] = sum_k g_k[b,t,:] * mask_k  : one thread per 4 channels
 __global__ void dropsum_bwd_kernel(const sdumc_dropsum p, int64_t nquads) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -504,6 +553,25 @@ extern "C" int sdumc_dropout_bits_multi(const sdumc_dropout* d, int32_t streams,
   const int64_t nwords = (int64_t)streams * d->samples * (d->rows ? d->rows : 1) * (d->width / 16);
   hipLaunchKernelGGL(dropout_bits_kernel, dim3(nblk(nwords)), dim3(256), 0, as_stream(stream), *d, nwords, nsite,
                      site_stride, out);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_dropout_bits_apply_bf16(const sdumc_dropout* d, int32_t streams, int32_t site_stride, uint8_t* const* bits,
+                                             const void* x, int64_t x_rows, void* const* xd, void* stream) {
+  if (!d || !bits || !xd || !x || streams < 1 || x_rows <= 0 || (d->width & 15) || d->width == 0 || !d->enabled) return SDUMC_EINVAL;
+  BitsOut out;
+  XdOut xo;
+  for (int s = 0; s < 4; ++s) out.p[s] = nullptr;
+  for (int s = 0; s < 2; ++s) {
+    if (!bits[s] || !xd[s] || (reinterpret_cast<uintptr_t>(bits[s]) & 3) || (reinterpret_cast<uintptr_t>(xd[s]) & 15)) return SDUMC_EINVAL;
+    out.p[s] = bits[s];
+    xo.p[s] = static_cast<unsigned short*>(xd[s]);
+  }
+  if (reinterpret_cast<uintptr_t>(x) & 15) return SDUMC_EINVAL;
+  const int64_t nwords = (int64_t)streams * d->samples * (d->rows ? d->rows : 1) * (d->width / 16);
+  hipLaunchKernelGGL(dropout_bits_apply_bf16_kernel, dim3(nblk(nwords)), dim3(256), 0, as_stream(stream), *d, nwords, site_stride, out,
+                     static_cast<const unsigned short*>(x), x_rows, xo);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
 }

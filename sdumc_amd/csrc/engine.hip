@@ -852,7 +852,7 @@ sdumc_gemm_bf16 GH_(int layout, int M, int N, int K, int groups = 1) {
   return g;
 }
 
-// bf16-storage mode: xd = drop(x) of the sites [k0, k1) materialised from the keep-bits, then keys = tanh(xd W^T + b)
+// bf16-storage mode: keys = tanh(xd W^T + b) of the sites [k0, k1), xd = drop(x) materialised by forward() (train) or x (eval)
 int keys_gemm_fwd_h(const Ctx& c, int m, int k0, int k1) {
   const Plan& pl = c.pl;
   for (const Seg& sg : pl.segs[m]) {
@@ -860,10 +860,7 @@ int keys_gemm_fwd_h(const Ctx& c, int m, int k0, int k1) {
     sdumc_gemm_bf16 g = GH_(SDUMC_NT, (int)rows, D, D, k1 - k0);
     for (int k = k0; k < k1; ++k) {
       const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
-      if (c.d.train) {
-        const sdumc_dropout dd = in_drop(c, k, m, sg.T, sg.s0, sg.row0);
-        RET(sdumc_mask_apply_bf16(c.ph(sg.x_off), dd.bits, c.ph(pl.xd[k][m], sg.row0 * D), rows, (int64_t)sg.x_samples * sg.T, D,
-                                  dd.scale, c.st));
+      if (c.d.train) {     // the masked frames xd were written together with the keep-bits (forward())
         g.A[k - k0] = c.ph(pl.xd[k][m], sg.row0 * D);
       } else {
         g.A[k - k0] = c.ph(sg.x_off);
@@ -1142,7 +1139,10 @@ int forward(const Ctx& c) {
   // on lane 3 in the shadow of the MFMA-bound frame projections, which read no mask; each modality's lane waits for its
   // own bits before the key projections.  Heaviest modality first.
   hipEvent_t bits_done[3] = {nullptr, nullptr, nullptr};
-  if (c.d.train) {
+  // bf16 storage: the keep-bits are produced together with the masked frames xd of both sites, behind the modality's frame
+  // projection on the modality's own lane (one pass over x instead of a bits launch on lane 3 plus one mask_apply per site)
+  const bool bits_with_xd = c.h() && c.d.train;
+  if (c.d.train && !bits_with_xd) {
     RET(link(c, 0, 3));
     c.use(3);
     const int order[3] = {0, 2, 1};
@@ -1181,6 +1181,16 @@ int forward(const Ctx& c) {
     }
     mark(c.st, 28 + 4 * m);      // (debug marks 28..39: this modality's lane, frame-level forward: projection done)
     if (bits_done[m] && hipStreamWaitEvent(c.st, bits_done[m], 0) != hipSuccess) return SDUMC_ELAUNCH;
+    if (bits_with_xd) {
+      for (const Seg& sg : pl.segs[m]) {
+        const sdumc_dropout d = mkdrop(c, SITE_IN[0][m], c.d.p_frame, sg.T, D, sg.s0);
+        uint8_t* bo[2] = {reinterpret_cast<uint8_t*>(c.p(pl.bits[0][m])) + sg.row0 * (D / 4),
+                          reinterpret_cast<uint8_t*>(c.p(pl.bits[1][m])) + sg.row0 * (D / 4)};
+        void* xo[2] = {c.ph(pl.xd[0][m], sg.row0 * D), c.ph(pl.xd[1][m], sg.row0 * D)};
+        RET(sdumc_dropout_bits_apply_bf16(&d, sg.V / B, SITE_IN[1][m] - SITE_IN[0][m], bo, c.ph(sg.x_off), (int64_t)sg.x_samples * sg.T,
+                                          xo, c.st));
+      }
+    }
     mark(c.st, 29 + 4 * m);      // keep-bits awaited
     const bool k3_site0 = k3_ok(c, m);
     if (c.bg) {   // the Cross_Attention keys are not needed before step 8: background lane, beside steps 2-7

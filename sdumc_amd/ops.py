@@ -319,6 +319,21 @@ def dropout_bits(d, streams):
     return bits
 
 
+def dropout_bits_apply_bf16(d, streams, site_stride, x):
+    """bf16 storage: keep-bits of sites d.site and d.site + site_stride and the masked frames of both, in one pass over x
+    (sdumc_dropout_bits_apply_bf16).  x: bf16 [x_rows, width]; returns (bits0, bits1, xd0, xd1)."""
+    rows = streams * d.samples * max(d.rows, 1)
+    bits = [torch.empty(rows * (d.width // 4), dtype=torch.uint8, device=x.device) for _ in range(2)]
+    xd = [torch.empty(rows, d.width, dtype=torch.bfloat16, device=x.device) for _ in range(2)]
+    barr = (C.c_void_p * 2)(ptr(bits[0]), ptr(bits[1]))
+    xarr = (C.c_void_p * 2)(ptr(xd[0]), ptr(xd[1]))
+    saved, d.bits = d.bits, None
+    check(lib.sdumc_dropout_bits_apply_bf16(C.byref(d), streams, site_stride, barr, ptr(x), x.shape[0], xarr, _st()),
+          "sdumc_dropout_bits_apply_bf16")
+    d.bits = saved
+    return bits[0], bits[1], xd[0], xd[1]
+
+
 def colsum(a, accumulate_into=None):
     rows, cols = a.shape
     out = accumulate_into if accumulate_into is not None else torch.empty(cols, device=a.device)

@@ -51,6 +51,29 @@ def test_dropout_mask_bit_exact(ops):
     np.testing.assert_array_equal(ops.dropout_mask(d, 1).cpu().numpy(), philox.dropout_mask(2, 2, 8, 0.5, 5, 9, 3))
 
 
+def test_dropout_bits_and_masked_frames_in_one_pass_bf16(ops):
+    """sdumc_dropout_bits_apply_bf16 == sdumc_dropout_bits (per site) followed by sdumc_mask_apply_bf16, bit for bit; the two
+    streams read the same frames (row modulo)."""
+    import ctypes as C
+    from sdumc_amd._lib import lib, make_dropout, ptr
+    for samples, T, streams, stride in [(3, 37, 2, 24), (2, 64, 1, 5)]:
+        g = torch.Generator().manual_seed(samples * T)
+        x = torch.randn(samples * T, 256, generator=g).to(torch.bfloat16).cuda()
+        d = make_dropout(True, 4, 0.5, T, 256, samples, call0=3, seed=777)
+        b0, b1, xd0, xd1 = ops.dropout_bits_apply_bf16(d, streams, stride, x)
+        rows = streams * samples * T
+        for site, bits, xd in ((4, b0, xd0), (4 + stride, b1, xd1)):
+            ds = make_dropout(True, site, 0.5, T, 256, samples, call0=3, seed=777)
+            want_bits = ops.dropout_bits(ds, streams)
+            assert torch.equal(bits, want_bits)
+            want = torch.empty(rows, 256, dtype=torch.bfloat16, device="cuda")
+            assert lib.sdumc_mask_apply_bf16(ptr(x), ptr(want_bits), ptr(want), rows, samples * T, 256, C.c_float(ds.scale),
+                                             None) == 0
+            torch.cuda.synchronize()
+            assert torch.equal(xd.view(torch.int16), want.view(torch.int16))
+            ds.bits = None
+
+
 @pytest.mark.parametrize("M,N,K,tile", [(128, 256, 256, 0), (300, 256, 1024, 1), (77, 3, 256, 2), (64, 7, 128, 0),
                                         (513, 130, 96, 1), (2048, 256, 4096, 0), (5, 1, 128, 0), (300, 256, 1024, 4),
                                         (129, 65, 40, 4), (16384, 256, 1024, 0)])
