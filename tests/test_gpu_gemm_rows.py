@@ -194,3 +194,43 @@ def test_row_strides_wider_than_256(ops):
     want = C0[:, 128:384].cpu().double() + A.cpu().double() @ B.cpu().double()
     close(C, want)
     assert torch.equal(Cw[:, :128], C0[:, :128]) and torch.equal(Cw[:, 384:], C0[:, 384:])     # nothing outside the slice is touched
+
+
+def test_results_do_not_depend_on_memory_latency(ops):
+    """The kernels never drain their vector-memory queue: every wait is a counted s_waitcnt vmcnt(n).  A copy loop on a second
+    stream keeps HBM busy (loads land late and out of their usual rhythm); the results must stay bit-identical to a quiet run."""
+    g = torch.Generator().manual_seed(41)
+    M = 64 * 700 + 11
+    A = (torch.randn(M, 256, generator=g) * 0.5).cuda()
+    B = (torch.randn(256, 256, generator=g) / 16).cuda()
+    C0 = torch.randn(M, 256, generator=g).cuda()
+    bits, _ = keep_bits(M, g)
+    bits = bits.cuda()
+    bias = torch.randn(256, generator=g).cuda()
+    Ah, Bh, C0h = A.to(torch.bfloat16), B.to(torch.bfloat16), C0.to(torch.bfloat16)
+
+    def run_all():
+        outs = []
+        c = C0.clone()
+        ops.gemm_rows256([{"A": A, "B": B, "C": c, "accumulate": True}])
+        outs.append(c)
+        outs.append(ops.gemm_rows256([{"A": A, "B": B, "bits": bits, "scale": 2.0, "bias": bias, "act": 2}])[0])
+        c = C0h.clone()
+        ops.gemm_rows256([{"A": Ah, "B": Bh, "C": c, "accumulate": True}])
+        outs.append(c)
+        outs.append(ops.gemm_rows256([{"A": Ah, "B": Bh, "bias": bias, "act": 2}])[0])
+        torch.cuda.synchronize()
+        return outs
+
+    quiet = run_all()
+    src = torch.empty(512 << 20, dtype=torch.uint8, device="cuda")
+    dst = torch.empty_like(src)
+    side = torch.cuda.Stream()
+    for rep in range(6):
+        with torch.cuda.stream(side):
+            for _ in range(12):
+                dst.copy_(src, non_blocking=True)
+        busy = run_all()
+        side.synchronize()
+        for a, b in zip(quiet, busy):
+            assert torch.equal(a.view(torch.int16) if a.dtype == torch.bfloat16 else a, b.view(torch.int16) if b.dtype == torch.bfloat16 else b)
