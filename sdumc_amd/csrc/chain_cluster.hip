@@ -1057,8 +1057,16 @@ extern "C" int sdumc_chain_cluster_launch_(const sdumc_chain_args* ap, int which
   const dim3 grid(ncl * CL), blk(NTHR);
   hipStream_t st = as_stream(stream);
   std::lock_guard<std::mutex> lk(d->mu);
-  // one cluster kernel at a time per device: a second one on another stream waits for the first
-  if (d->any && d->last != st && hipStreamWaitEvent(st, d->done, 0) != hipSuccess) return SDUMC_ELAUNCH;
+  // One cluster kernel at a time per device: a launch on ANOTHER stream than the previous one is ordered behind everything
+  // submitted to that stream so far.  The event is recorded here, when it is needed, not after every launch: an event record
+  // behind a kernel costs the recording stream ~8 us before its next kernel starts (four of them sat on the step's critical
+  // path, between the utterance-level stages and the pooling / loss launches that follow them).
+  if (d->any && d->last != st) {
+    if (hipEventRecord(d->done, d->last) != hipSuccess || hipStreamWaitEvent(st, d->done, 0) != hipSuccess) {
+      (void)hipGetLastError();                                   // (the other stream is gone: nothing of it can still be running
+      if (hipDeviceSynchronize() != hipSuccess) return SDUMC_ELAUNCH;   //  after this)
+    }
+  }
   switch (which) {
     case 0: hipLaunchKernelGGL(chain_fwd_a_cl_kernel<R>, grid, blk, smem_fwd_a<R>(), st, a, ncl); break;
     case 1: hipLaunchKernelGGL(chain_fwd_b_cl_kernel<R>, grid, blk, smem_fwd_b<R>(), st, a, ncl); break;
@@ -1066,7 +1074,6 @@ extern "C" int sdumc_chain_cluster_launch_(const sdumc_chain_args* ap, int which
     default: hipLaunchKernelGGL(chain_bwd_a_cl_kernel<R>, grid, blk, smem_bwd_a<R>(), st, a, ncl); break;
   }
   SDUMC_CHECK_LAUNCH();
-  if (hipEventRecord(d->done, st) != hipSuccess) return SDUMC_ELAUNCH;
   d->last = st;
   d->any = true;
   return SDUMC_OK;
