@@ -1160,6 +1160,7 @@ int forward(const Ctx& c) {
       }
     }
   }
+  hipEvent_t fra_done[3] = {nullptr, nullptr, nullptr}, ca_done[3] = {nullptr, nullptr, nullptr};
   for (int m = 0; m < 3; ++m) {
     c.use(LANE_OF[m]);
     for (int s = 0; s < (m == 1 ? S : 1); ++s) {
@@ -1193,7 +1194,20 @@ int forward(const Ctx& c) {
     }
     mark(c.st, 29 + 4 * m);      // keep-bits awaited
     const bool k3_site0 = k3_ok(c, m);
-    if (c.bg) {   // the Cross_Attention keys are not needed before step 8: background lane, beside steps 2-7
+    // Audio's Cross_Attention keys (the largest of the three key projections) stay on audio's own lane, BEHIND a partial
+    // join: the caller's stream (stage A) waits only for the FRA2UTT site, the keys are awaited before step 8.  Lane 3 then
+    // carries two key projections instead of three and the pooling of step 8 waits ~10 us less for it (fp32 C2 1.726-1.731
+    // against 1.733-1.738 ms, bf16 1.046-1.047 against 1.053-1.057; video's instead: 1.756-1.772, both: 1.732-1.738).
+    constexpr int ca_own = 1;
+    if (c.bg && (ca_own & (1 << m)) && LANE_OF[m] != 0 && c.multi && !c.capturing) {
+      if (k3_site0) RET(umca_site(c, 0, m, true));
+      else { RET(keys_gemm_fwd(c, m, 0, 1)); RET(pool_fwd(c, 0, m)); }
+      fra_done[m] = next_event(c);
+      if (hipEventRecord(fra_done[m], c.st) != hipSuccess) return SDUMC_ELAUNCH;
+      RET(keys_gemm_fwd(c, m, 1, 2));
+      ca_done[m] = next_event(c);
+      if (hipEventRecord(ca_done[m], c.st) != hipSuccess) return SDUMC_ELAUNCH;
+    } else if (c.bg) {   // the Cross_Attention keys are not needed before step 8: background lane, beside steps 2-7
       if (k3_site0) RET(umca_site(c, 0, m, true));
       else RET(keys_gemm_fwd(c, m, 0, 1));
       RET(link(c, LANE_OF[m], 3));
@@ -1212,7 +1226,15 @@ int forward(const Ctx& c) {
   }
   mark(c.sts[3], 40);            // lane 3: keep-bits + Cross_Attention key projections done
   c.use(0);
-  RET(join_all(c));
+  for (int lane = 1; lane <= 2; ++lane) {
+    int m_of = -1;
+    for (int m = 0; m < 3; ++m) if (LANE_OF[m] == lane && fra_done[m]) m_of = m;
+    if (m_of >= 0) {
+      if (hipStreamWaitEvent(c.sts[0], fra_done[m_of], 0) != hipSuccess) return SDUMC_ELAUNCH;
+    } else {
+      RET(link(c, lane, 0));
+    }
+  }
   if (chain) {   // steps 3-7 in one launch
     if (wt_done && hipStreamWaitEvent(c.st, wt_done, 0) != hipSuccess) return SDUMC_ELAUNCH;
     const sdumc_chain_args ca = chain_args(c, true, nullptr, true);
@@ -1285,6 +1307,8 @@ int forward(const Ctx& c) {
   // 8. cross_att_fra2utt_{0,1,2} (model :334-336): one grouped launch on the caller's stream (a fork/join around three 17-30 us
   //    kernels cost 86-91 us between the two utterance-level launches, of which ~35 us were cross-queue event latency)
   RET(link(c, 3, 0));   // their keys
+  for (int m = 0; m < 3; ++m)
+    if (ca_done[m] && hipStreamWaitEvent(c.sts[0], ca_done[m], 0) != hipSuccess) return SDUMC_ELAUNCH;
   if (attn_multi_ok(c)) {
     RET(pool_fwd_multi(c, 1));
   } else {
