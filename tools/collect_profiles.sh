@@ -15,8 +15,8 @@ python3 bench.py --workload epoch --bf16 --steps 200 --warmup 10 > $O/bench_epoc
 python3 bench.py --workload c1 --steps 50 --warmup 10 --no-cpu-baseline > $O/bench_c1.json 2>> $O/bench.err
 python3 bench.py --workload c5 --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_c5.json 2>> $O/bench.err
 python3 bench.py --workload c5 --bf16 --steps 30 --warmup 5 --no-cpu-baseline > $O/bench_c5_bf16.json 2>> $O/bench.err
-SDUMC_FORCE_DP=1 python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline > $O/bench_one_rank_rccl_dp.json 2>> $O/bench.err
-SDUMC_DIST_BACKEND=gloo python3 bench.py --gpus 2 --steps 5 --warmup 2 --no-roofline > $O/bench_gloo_2ranks_1gpu.json 2>> $O/bench.err
+SDUMC_FORCE_DP=1 timeout 200 python3 bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-roofline > $O/bench_one_rank_rccl_dp.json 2>> $O/bench.err
+SDUMC_BENCH_TIMEOUT=90 SDUMC_DIST_BACKEND=gloo timeout 150 python3 bench.py --gpus 2 --steps 5 --warmup 2 --no-roofline > $O/bench_gloo_2ranks_1gpu.json 2>> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 10 --warmup 3 --serial-lanes --no-cpu-baseline --no-roofline > $O/kt.log 2>&1
 cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/kernel_stats_bench_serial_lanes.csv
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktb -- python3 bench.py --bf16 --steps 10 --warmup 3 --serial-lanes --no-cpu-baseline --no-roofline > $O/ktb.log 2>&1
