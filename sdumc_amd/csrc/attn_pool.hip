@@ -808,7 +808,8 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 constexpr int waitcnt_vm(int n) { return (n & 0xF) | ((n >> 4) << 14) | (0x7 << 4) | (0xF << 8); }
 constexpr int BM = 64, BN = 256, BK = 16, NST = 3, NW = 4;
 constexpr int A_BYTES = BM * BK * 4, B_BYTES = BN * BK * 4, BITS_LDS = 256;
-constexpr int A_CH = A_BYTES / 1024, B_CH = B_BYTES / 1024, NI = (A_CH + B_CH) / NW;
+constexpr int A_CH = A_BYTES / 1024, B_CH = B_BYTES / 1024;
+[[maybe_unused]] constexpr int NI = (A_CH + B_CH) / NW;
 constexpr int STAGE_BYTES = A_BYTES + B_BYTES + BITS_LDS, RING_BYTES = NST * STAGE_BYTES;
 constexpr int K_BYTES = BM * UMCA_LDK * 4;
 constexpr int TOP_BYTES = K_BYTES > RING_BYTES ? K_BYTES : RING_BYTES;

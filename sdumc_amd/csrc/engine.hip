@@ -1450,7 +1450,8 @@ int keys_gemm_bwd_h(const Ctx& c, int m, int k0, int k1, int parts) {
       r.lda = r.ldb = r.ldc = D;
       r.accumulate = 1;
     }
-    return sdumc_gemm_rows256_bf16(q, k1 - k0, c.st);
+    const int rc = sdumc_gemm_rows256_bf16(q, k1 - k0, c.st);
+    if (rc != SDUMC_EINVAL) return rc;
   }
   return run_h(c, g);
 }
@@ -1547,7 +1548,8 @@ int keys_gemm_bwd(const Ctx& c, int m, int k0, int k1, int parts = 3) {
                                                          //  the co-resident utterance-level stage, which a persistent launch would stall)
     sdumc_rows_problem q[2];
     const int n = keys_dx_rows(c, m, k0, k1, q);
-    return sdumc_gemm_rows256(q, n, c.st);
+    const int rc = sdumc_gemm_rows256(q, n, c.st);
+    if (rc != SDUMC_EINVAL) return rc;      // (a shape the rows launch refuses -- 2 GiB of rows -- takes the tiled kernel below)
   }
   sdumc_gemm g = G_(SDUMC_NN, (int)pl.rows[m], D, D, k1 - k0);
   for (int k = k0; k < k1; ++k) {

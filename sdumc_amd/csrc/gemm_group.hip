@@ -43,7 +43,7 @@ constexpr int WM = 64, WN = 64, TM = 2, TN = 2;
 constexpr int A_BYTES = BK * BM * 4, B_BYTES = BK * BN * 4, BITS_BYTES = BK * (BN / 4);
 constexpr int A_CH = A_BYTES / 1024, B_CH = B_BYTES / 1024;   // 1-KiB pieces = one wave-instruction each
 constexpr int NI = (A_CH + B_CH) / NW;                         // data pieces per wave per stage
-constexpr int BITS_CH = BITS_BYTES / 256;
+[[maybe_unused]] constexpr int BITS_CH = BITS_BYTES / 256;
 constexpr int STAGE_BYTES = A_BYTES + B_BYTES + BITS_BYTES;
 constexpr int SLOT_FLOATS = BM * BN + BM;                      // a partial tile in register order + its column sums of A
 static_assert((A_CH + B_CH) % NW == 0 && A_CH % NW == 0, "pieces divide evenly over the waves");
