@@ -165,15 +165,17 @@ def roofline_leg(_lib, launch, steps, traffic_ok=True):
     on the launch stream.  Returns the dominant GEMM variant's achieved TFLOP/s."""
     lib = _lib.lib
     torch.cuda.synchronize()
-    lib.sdumc_set_concurrency(0)      # one lane: a kernel's event-bracketed duration is then its own
-    lib.sdumc_profile_enable(1)
-    for _ in range(steps):
-        launch()
-    torch.cuda.synchronize()
-    arr = (_lib.ProfEntry * 32)()
-    n = lib.sdumc_profile_report(arr, 32)
-    lib.sdumc_profile_enable(0)
-    lib.sdumc_set_concurrency(1)
+    try:
+        lib.sdumc_set_concurrency(0)      # one lane: a kernel's event-bracketed duration is then its own
+        lib.sdumc_profile_enable(1)
+        for _ in range(steps):
+            launch()
+        torch.cuda.synchronize()
+        arr = (_lib.ProfEntry * 32)()
+        n = lib.sdumc_profile_report(arr, 32)
+    finally:                              # (process-wide switches: never leave them flipped behind an exception)
+        lib.sdumc_profile_enable(0)
+        lib.sdumc_set_concurrency(1)
     rows = []
     for i in range(max(n, 0)):
         e = arr[i]
@@ -219,6 +221,32 @@ def hbm_roofline_bf16(ms_per_step, mfma):
     return {"bound": "hbm", "achieved": round(ach, 1) if ach else None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
             "frac": round(ach / PEAK_HBM_GBS, 4) if ach else None, "traffic": traffic, "traffic_source": src,
             "kernel": "whole step (HBM-side bytes of every launch)", "mfma": mfma}
+
+
+def c3_bf16_side_leg(engine, flat, batch, args):
+    """BASELINE configs[2] (MOSEI shapes, B = 64, text-missing stream + self-distillation, bf16) under the same clock as the
+    headline: the bf16-storage step on the same batch, same --steps / --warmup, timed the same way, right after the headline's
+    timed region.  A side block of the one JSON line; the headline keys stay those of configs[1]."""
+    step = engine.TrainStep(flat.clone(), B_PER_GPU, T_MOSEI, DIMS, seed=2024, bf16=True)
+    step.set_batch(*batch)
+    for _ in range(args.warmup):
+        step.run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step.run()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    losses = step.losses.cpu()
+    if not torch.isfinite(losses).all():
+        raise SystemExit(f"non-finite loss in the bf16-storage side leg: {losses.tolist()}")
+    ms = 1e3 * dt / args.steps
+    roof = hbm_roofline_bf16(ms, None)
+    roof.pop("mfma", None)
+    return {"workload": "BASELINE configs[2]: the headline's batch in bf16 storage of features / frames / keys / frame-level gradients, "
+                        "f32 accumulation, softmax, utterance-level layers, losses and Adam",
+            "value": round(B_PER_GPU * args.steps / dt, 2), "unit": "samples/s", "ms_per_step": round(ms, 4),
+            "steps": args.steps, "warmup": args.warmup, "final_loss": round(float(losses[0]), 5), "roofline": roof}
 
 
 def recorded_traffic(kernel):
@@ -463,12 +491,15 @@ def main():
                    "T_audio_text_video_feat4": list(T_MOSEI), "feature_dims": list(DIMS),
                    "parallelism": f"dp{world}" if world > 1 else ("dp1 (one-rank RCCL communicator, all collectives issued)" if force_dp else "single"),
                    "launch": "hipGraph replay" if (args.graph and world == 1) else "eager, 4 lanes (caller stream + 2 high-priority modality side streams + 1 side stream for the grouped weight-gradient launches, keep-bits and the forward Cross_Attention key GEMMs)",
-                   "params": lay.total, "final_loss": round(float(losses[0]), 5)},
+                   "params": sum(int(torch.Size(shape).numel()) for _, shape, _ in lay.entries.values()),
+                   "param_buffer_floats": lay.total, "final_loss": round(float(losses[0]), 5)},
         "whole_step_tflops": round(value * TRAIN_FLOPS_PER_SAMPLE / 1e12, 2),
         "whole_step_frac_of_f32_mfma_peak": round(value * TRAIN_FLOPS_PER_SAMPLE / 1e12 / (world * PEAK_F32_MFMA_TFLOPS), 4),
     }
     if dp_extra is not None:
         out["data_parallel"] = dp_extra
+    if world == 1 and not force_dp and args.workload == "c2" and not args.bf16 and not args.graph and not args.serial_lanes:
+        out["side"] = {"c3_bf16": c3_bf16_side_leg(engine, flat, batch, args)}
     if not args.no_roofline:     # every rank runs it (the DP step has collectives); rank 0 reports
         roof = roofline_leg(_lib, step.launch if (world == 1 and not force_dp) else step.step, max(3, min(10, args.steps)),
                             traffic_ok=(args.workload == "c2" and not args.bf16))

@@ -282,6 +282,10 @@ typedef struct sdumc_attnpool_bwd {
   float* dq;
   float* workspace;      /* >= sdumc_attnpool_bwd_workspace_bytes(V, T, nq): per-chunk dq slabs */
   size_t workspace_bytes;
+  float* dq_sum;         /* optional [nq, dim]: SHARED query (f.q_stride == 0, FRA2UTT_new's context vector, model :50-52): the
+                            sum over v of the per-sample gradients, written by ONE launch that reduces the per-chunk slabs of
+                            every sample in a fixed order; dq is then NOT written.  NULL = per-sample dq as above.  Single-site
+                            sdumc_attnpool_bwd only (the _multi form requires NULL). */
 } sdumc_attnpool_bwd_t;
 
 size_t sdumc_attnpool_bwd_workspace_bytes(int32_t V, int32_t T, int32_t nq);
@@ -305,6 +309,10 @@ int sdumc_umca_fwd(const sdumc_umca* p, void* stream);
  * calls.  Replaces the three Cross_Attention.forward calls of models/wengnet_mosei_multviews_text_missing.py:334-336. */
 int sdumc_attnpool_fwd_multi(const sdumc_attnpool* sites, int32_t n, void* stream);
 int sdumc_attnpool_bwd_multi(const sdumc_attnpool_bwd_t* sites, int32_t n, void* stream);
+/* Measurement / test hook: 0 routes the 256-channel, keep-bits, two-pass-combine cases back to the round-3 pooling kernels
+ * (the round-4 "v2" kernels -- every global load issued up front, XCD-aware stream pairing -- are the default; results are
+ * bit-identical: tests/test_gpu_ops.py).  Process-wide. */
+int sdumc_attnpool_set_v2_(int on);
 
 /* ------------------------------------------------------------------------
  * Small fused element-wise / reduction kernels of the utterance-level network.
@@ -682,8 +690,22 @@ int sdumc_set_chain_cluster(int on);
 int sdumc_chain_cluster_error_(void);
 int sdumc_chain_cluster_reset_error(void);
 int sdumc_chain_cluster_test_hold_(int on);
+/* Data-parallel runs (one process per GPU): the error word is per device, so the ranks exchange it with the gradients.
+ * _flag writes 1.0f (word set) or 0.0f into `flag` -- a float the caller appends to its gradient bucket -- stream-ordered and
+ * without a host synchronisation; after the SUM all-reduce of the bucket, _merge sets the local word when the reduced flag is
+ * non-zero, so that every rank's Adam applies nothing and every rank raises (sdumc_amd/trainer.py). */
+/* Diagnosis (SDUMC_CL_MODE bit 4): records of cached weight loads that differed from agent-scope loads of the same address in the
+ * stage-A forward kernel: out[0] = count, out[8 + 12 i ..] = {workgroup, thread, ring slot, address low word, 4 cached words, 4
+ * coherent words}; synchronises the device and clears the records.  Not part of the data path. */
+int sdumc_chain_cluster_debug_read_(uint32_t* out, int n);
+int sdumc_chain_cluster_error_flag(float* flag, void* stream);
+int sdumc_chain_cluster_error_merge(const float* flag, void* stream);
 int sdumc_debug_marks(int on);
 int sdumc_debug_marks_read(float* ms, int n);
+/* Debug: the workspace plan of sdumc_net_forward as text lines "name offset length" (floats, relative to
+ * sdumc_net_io.workspace); returns the text length, or minus the buffer size needed.  For probes that compare intermediate
+ * tensors of two runs (tools/fwd_determinism_probe.py); not part of the data path. */
+int32_t sdumc_debug_plan_table(const sdumc_net_dims* d, char* buf, size_t buflen);
 size_t sdumc_net_workspace_bytes(const sdumc_net_dims* d);
 int sdumc_net_forward(const sdumc_net_dims* d, const sdumc_net_io* io, void* stream);
 

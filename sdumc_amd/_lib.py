@@ -83,7 +83,7 @@ class Umca(C.Structure):
 
 class AttnPoolBwd(C.Structure):
     _fields_ = [("f", AttnPool), ("dout", C.c_void_p), ("dz", C.c_void_p), ("dxd", C.c_void_p),
-                ("dq", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("dq", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("dq_sum", C.c_void_p)]
 
 
 class DropSum(C.Structure):
@@ -254,8 +254,13 @@ _SIGS = {
     "sdumc_chain_cluster_error_": (C.c_int, []),
     "sdumc_chain_cluster_reset_error": (C.c_int, []),
     "sdumc_chain_cluster_test_hold_": (C.c_int, [C.c_int]),
+    "sdumc_chain_cluster_debug_read_": (C.c_int, [C.c_void_p, C.c_int]),
+    "sdumc_chain_cluster_error_flag": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "sdumc_chain_cluster_error_merge": (C.c_int, [C.c_void_p, C.c_void_p]),
     "sdumc_debug_marks": (C.c_int, [C.c_int]),
     "sdumc_debug_marks_read": (C.c_int, [C.POINTER(C.c_float), C.c_int]),
+    "sdumc_attnpool_set_v2_": (C.c_int, [C.c_int]),
+    "sdumc_debug_plan_table": (C.c_int32, [C.POINTER(NetDims), C.c_char_p, C.c_size_t]),
     "sdumc_net_workspace_bytes": (C.c_size_t, [C.POINTER(NetDims)]),
     "sdumc_net_forward": (C.c_int, [C.POINTER(NetDims), C.POINTER(NetIO), C.c_void_p]),
     "sdumc_net_backward": (C.c_int, [C.POINTER(NetDims), C.POINTER(NetIO), C.POINTER(NetGrads), C.c_void_p]),

@@ -605,6 +605,372 @@ __global__ __launch_bounds__(256, 2) void attnpool_bwd_multi_kernel(const MultiB
   attnpool_bwd_body<1, HF>(b, static_cast<float*>(b.workspace), nchunk, local % nchunk, local / nchunk);
 }
 
+// ====================================================================================================================
+// Round 4: the network path's pooling kernels re-cut for memory-level parallelism ("v2": 256-channel rows, keep-bits or
+// pre-masked bf16 frames, two-pass combine -- everything the engine launches; the kernels above stay for 512..1024-channel rows,
+// recomputed Philox masks and the ticket option).
+// What bounded the kernels above (profiles/r3x: 4.2 TB/s = 0.52 of the HBM peak backward, 4.3 forward): a wave never had more
+// than 8-12 KiB of frame rows in flight (4-row register batches behind a prologue of three dependent round trips), and the
+// grids' last dispatch round was 40-80 % full.  Here
+//   * EVERY global load of a workgroup is issued in its first instructions, smallest first (loads return in order: the prologue's
+//     few dwords must not queue behind the rows): per wave the 16 rows of the MFMA operand tile and the 16 rows of the stream
+//     tile, 32 KiB in flight, held in registers until used (2 waves per SIMD);
+//   * the per-row softmax factors reach the row x channel FMAs through v_readlane from the MFMA result layout (SGPR operands:
+//     no LDS round trip, no barrier between the two phases);
+//   * workgroup -> (stream, sample, chunk) is XCD-aware: the two streams' workgroups that read the SAME frame rows x[b, t0..]
+//     (audio / video: one x for both streams) are dispatched 8 apart, i.e. to the same XCD at about the same time, so the second
+//     read is an L2 hit instead of a second HBM fetch.
+// Same arithmetic and summation order as the kernels above (bit-identical results: tests/test_gpu_ops.py).
+// ====================================================================================================================
+template <bool HF> struct RawRow { typedef f32x4 type; };
+template <> struct RawRow<true> { typedef uint2 type; };
+template <bool HF>
+__device__ __forceinline__ typename RawRow<HF>::type ldraw(const float* base, size_t off) {
+  if constexpr (HF) return *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + off);
+  else return ld4(base + off);
+}
+template <bool HF>
+__device__ __forceinline__ f32x4 cvtraw(const typename RawRow<HF>::type& u) {
+  if constexpr (HF) return f32x4{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                                 __uint_as_float(u.y & 0xffff0000u)};
+  else return u;
+}
+__device__ __forceinline__ float lane_bcast(float v, int srclane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), srclane));
+}
+// keep-bits nibble -> the 4 channels of a quad: kept ones pass, dropped ones become +0 (the 1/(1-p) scale is applied by the caller)
+__device__ __forceinline__ f32x4 keep4(f32x4 x, uint32_t b) {
+  f32x4 r;
+  r[0] = __uint_as_float(__float_as_uint(x[0]) & (uint32_t)__builtin_amdgcn_sbfe(b, 0, 1));
+  r[1] = __uint_as_float(__float_as_uint(x[1]) & (uint32_t)__builtin_amdgcn_sbfe(b, 1, 1));
+  r[2] = __uint_as_float(__float_as_uint(x[2]) & (uint32_t)__builtin_amdgcn_sbfe(b, 2, 1));
+  r[3] = __uint_as_float(__float_as_uint(x[3]) & (uint32_t)__builtin_amdgcn_sbfe(b, 3, 1));
+  return r;
+}
+// workgroup id inside a site -> (v, chunk): see the header comment (pairs of streams 8 workgroups apart when they share x)
+__device__ __forceinline__ void v2_unit(const sdumc_attnpool& p, int local, int nchunk, int& v, int& chunk) {
+  if (p.x_samples * 2 == p.V) {
+    const int U = p.x_samples * nchunk;
+    const int blk = local >> 4, base = blk << 3;
+    const int rem = min(8, U - base), w = local - (blk << 4);
+    const int s = w / rem, unit = base + (w - s * rem);
+    v = s * p.x_samples + unit / nchunk;
+    chunk = unit % nchunk;
+  } else {
+    v = local / nchunk;
+    chunk = local - v * nchunk;
+  }
+}
+
+// ---- backward v2 --------------------------------------------------------------------------------------------------
+template <bool HF, int NQT>
+__device__ __forceinline__ void attnpool_bwd_v2(const sdumc_attnpool_bwd_t b, float* dq_part, const int nchunk, const int chunk, const int v) {
+  constexpr int LDQ = D + 16;
+  typedef typename RawRow<HF>::type raw_t;
+  __shared__ __attribute__((aligned(16))) float dO_s[MAXQ * LDQ];
+  __shared__ __attribute__((aligned(16))) float red[4 * NQT * D];
+  __shared__ float delta_s[16];
+  const sdumc_attnpool& p = b.f;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kk = lane >> 4;
+  const int T = p.T;
+  const int t0 = chunk * CH, tw = t0 + 16 * wave;       // this wave's first row
+  const DropRT od = drop_resolve(p.out_drop);
+  const DropRT xd = drop_resolve(p.x_drop);
+  const bool masked = xd.enabled != 0;                  // (keep-bits attached: checked by the launcher)
+  const int vx = v % p.x_samples;
+  // ---- 1. every global load, smallest first -----------------------------------------------------------------------
+  // dout quads of this thread (<= 2), pooled rows for delta (<= 2 per wave), the weights of the wave's rows, the queries
+  f32x4 gq[2], po[2], qv[NQT];
+  float av[4];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + 256 * u, i = e >> 6, cq = e & 63;
+    gq[u] = (NQT * 64 > 256 * u && i < NQT) ? ld4(b.dout + ((size_t)v * NQT + i) * D + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = wave + 4 * u;
+    po[u] = i < NQT ? ld4(p.pooled + ((size_t)v * NQT + i) * D + 4 * lane) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int t = tw + 4 * kk + e;
+    av[e] = (r16 < NQT && t < T) ? p.attn[((size_t)v * T + t) * NQT + r16] : 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < NQT; ++i) qv[i] = ld4(p.q + (size_t)v * p.q_stride + (size_t)i * D + 4 * lane);
+  // the wave's 16 frame rows as the MFMA A operand: lane (r16, kk) takes x[row r16][16 j + 4 kk ..], j = 0..15; their keep-bits
+  // (64 bytes per row) as four 16-byte loads; then the 16 key rows, lane = 4 channels
+  raw_t xa[16], kr[16];
+  uint4 xb[4] = {};
+  {
+    const int t = min(tw + r16, T - 1);                 // rows beyond T re-read the last row; their weights are 0
+    const size_t ro = ((size_t)vx * T + t) * D + 4 * kk;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xa[j] = ldraw<HF>(p.x, ro + 16 * j);
+    if (!HF && masked) {
+      const uint4* bp = reinterpret_cast<const uint4*>(xd.bits + ((size_t)v * T + t) * (D / 4));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xb[j] = bp[j];
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) kr[r] = ldraw<HF>(p.keys, ((size_t)v * T + min(tw + r, T - 1)) * D + 4 * lane);
+  // ---- 2. dO = dout * out_mask -> LDS; delta_i = dO_i . O_i ----------------------------------------------------------
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + 256 * u, i = e >> 6, cq = e & 63;
+    if (i < MAXQ) {
+      f32x4 g = gq[u];
+      if (i < NQT && od.enabled) g *= drop_mask4(od, (uint32_t)(v * NQT + i), (uint32_t)cq);
+      st4(dO_s + i * LDQ + 4 * cq, g);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int i = wave + 4 * u;
+    if (i < NQT) {
+      const float d = wave_sum(dot4(ld4(dO_s + i * LDQ + 4 * lane), po[u]));
+      if (lane == 0) delta_s[i] = d;
+    }
+  }
+  __syncthreads();
+  // ---- 3. dA = xd . dO^T on the matrix cores; dS = 0.3 A (dA - delta) -------------------------------------------------
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  {
+    const uint32_t sh = 8u * (uint32_t)kk;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      f32x4 a = cvtraw<HF>(xa[j]);
+      if (!HF && masked) {
+        const uint4 w4 = xb[j >> 2];
+        const uint32_t w = (j & 3) == 0 ? w4.x : (j & 3) == 1 ? w4.y : (j & 3) == 2 ? w4.z : w4.w;
+        a = keep4(a, w >> sh);
+      }
+      f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+      if (r16 < MAXQ) bq = ld4(dO_s + r16 * LDQ + 16 * j + 4 * kk);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bq[e], acc, 0, 0, 0);
+    }
+  }
+  const float xscale = (!HF && masked) ? xd.scale : 1.f;
+  float dSv[4];
+  {
+    const float dl = r16 < NQT ? delta_s[r16] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dSv[e] = p.scale * av[e] * (acc[e] * xscale - dl);      // rows beyond T, columns beyond nq: av = 0
+  }
+  // ---- 4. the row x channel parts: lane = 4 channels, the row's factors by v_readlane ----------------------------------
+  f32x4 g[NQT], dqa[NQT];
+#pragma unroll
+  for (int i = 0; i < NQT; ++i) {
+    g[i] = ld4(dO_s + i * LDQ + 4 * lane);
+    dqa[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const f32x4 one = {1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const f32x4 k = cvtraw<HF>(kr[r]);
+    f32x4 dk = {0.f, 0.f, 0.f, 0.f}, dx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < NQT; ++i) {
+      const float dS = lane_bcast(dSv[r & 3], 16 * (r >> 2) + i), a = lane_bcast(av[r & 3], 16 * (r >> 2) + i);
+      dk += qv[i] * dS;
+      dx += g[i] * a;
+      dqa[i] += k * dS;
+    }
+    if (tw + r < T) {
+      const size_t row = (size_t)v * T + tw + r;
+      stx<HF>(b.dz, row * D + 4 * lane, dk * (one - k * k));
+      stx<HF>(b.dxd, row * D + 4 * lane, dx);
+    }
+  }
+  // ---- 5. dQ partial of the chunk: four waves summed in a fixed order ----------------------------------------------------
+#pragma unroll
+  for (int i = 0; i < NQT; ++i) st4(red + (wave * NQT + i) * D + 4 * lane, dqa[i]);
+  __syncthreads();
+  for (int e = tid; e < NQT * (D / 4); e += 256) {
+    const int i = e / (D / 4), cq = e - i * (D / 4);
+    f32x4 s = ld4(red + i * D + 4 * cq);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) s += ld4(red + (w * NQT + i) * D + 4 * cq);
+    st4(dq_part + (((size_t)v * nchunk + chunk) * NQT + i) * D + 4 * cq, s);
+  }
+}
+
+template <bool HF, int NQT>
+__global__ __launch_bounds__(256, 2) void attnpool_bwd_v2_kernel(const sdumc_attnpool_bwd_t b, float* dq_part, const int nchunk) {
+  int v, chunk;
+  v2_unit(b.f, blockIdx.x, nchunk, v, chunk);
+  attnpool_bwd_v2<HF, NQT>(b, dq_part, nchunk, chunk, v);
+}
+template <bool HF, int NQT>
+__global__ __launch_bounds__(256, 2) void attnpool_bwd_v2_multi_kernel(const MultiBwd m) {
+  const int s = site_of(m.wg_end, blockIdx.x);
+  const int local = blockIdx.x - (s ? m.wg_end[s - 1] : 0);
+  const int nchunk = m.nchunk[s];
+  sdumc_attnpool_bwd_t b = m.b[0];     // uniform select, by value (see attnpool_bwd_multi_kernel)
+  if (s == 1) b = m.b[1];
+  if (s == 2) b = m.b[2];
+  if (s == 3) b = m.b[3];
+  int v, chunk;
+  v2_unit(b.f, local, nchunk, v, chunk);
+  attnpool_bwd_v2<HF, NQT>(b, static_cast<float*>(b.workspace), nchunk, chunk, v);
+}
+
+// ---- forward partial v2 ---------------------------------------------------------------------------------------------
+template <bool HF, int NQT>
+__device__ __forceinline__ void attn_fwd_partial_v2(const sdumc_attnpool p, float* ws, const int nchunk, const int chunk, const int v) {
+  constexpr int LDQ = D + 16;
+  typedef typename RawRow<HF>::type raw_t;
+  __shared__ __attribute__((aligned(16))) float q_s[MAXQ * LDQ];
+  __shared__ __attribute__((aligned(16))) float red[4 * NQT * D];
+  __shared__ float wstat[4][16];
+  __shared__ float cstat[16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r16 = lane & 15, kk = lane >> 4;
+  const int T = p.T;
+  const int t0 = chunk * CH, tw = t0 + 16 * wave;
+  const FwdWs w = fwd_ws(ws, p.V, nchunk, NQT, D);
+  const int Tv = p.lengths ? min(T, max(1, p.lengths[v])) : T;
+  const DropRT xd = drop_resolve(p.x_drop);
+  const bool masked = xd.enabled != 0;
+  const int vx = v % p.x_samples;
+  // ---- 1. every global load: the queries (<= 2 quads per thread), the 16 key rows as the MFMA A operand, the 16 frame rows
+  f32x4 qq[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + 256 * u, i = e >> 6, cq = e & 63;
+    qq[u] = (NQT * 64 > 256 * u && i < NQT) ? ld4(p.q + (size_t)v * p.q_stride + (size_t)i * D + 4 * cq) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  raw_t ka[16], xr[16];
+  uint32_t xm[16];
+  {
+    const size_t ro = ((size_t)v * T + min(tw + r16, T - 1)) * D + 4 * kk;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) ka[j] = ldraw<HF>(p.keys, ro + 16 * j);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int t = min(tw + r, T - 1);                  // rows beyond T re-read the last row; their weight is 0
+    xr[r] = ldraw<HF>(p.x, ((size_t)vx * T + t) * D + 4 * lane);
+    xm[r] = (!HF && masked) ? xd.bits[((size_t)v * T + t) * (D / 4) + lane] : 0xfu;
+  }
+  // ---- 2. scores of the wave's 16 rows against the queries -----------------------------------------------------------------
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int e = tid + 256 * u, i = e >> 6, cq = e & 63;
+    if (i < MAXQ) st4(q_s + i * LDQ + 4 * cq, qq[u]);
+  }
+  __syncthreads();
+  f32x4 s4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const f32x4 a = cvtraw<HF>(ka[j]);
+    f32x4 bq = {0.f, 0.f, 0.f, 0.f};
+    if (r16 < MAXQ) bq = ld4(q_s + r16 * LDQ + 16 * j + 4 * kk);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bq[e], s4, 0, 0, 0);
+  }
+  // C layout: column (query) = lane & 15, rows = 16 wave + 4 (lane >> 4) + e
+  float s[4], mx = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int t = tw + 4 * kk + e;
+    s[e] = t < Tv ? p.scale * s4[e] : -INFINITY;
+    mx = fmaxf(mx, s[e]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  if (lane < 16) wstat[wave][lane] = mx;
+  __syncthreads();
+  if (tid < 16) cstat[tid] = fmaxf(fmaxf(wstat[0][tid], wstat[1][tid]), fmaxf(wstat[2][tid], wstat[3][tid]));
+  __syncthreads();
+  const float mc = cstat[r16];          // chunk max of my query column (-inf only for a chunk wholly beyond Tv)
+  float pe[4], lsum = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int t = tw + 4 * kk + e;
+    pe[e] = t < Tv ? expf(s[e] - mc) : 0.f;
+    lsum += pe[e];
+    if (r16 < NQT && t < T) p.attn[((size_t)v * T + t) * NQT + r16] = pe[e];      // normalised by the combine step
+  }
+  lsum += __shfl_xor(lsum, 16, 64);
+  lsum += __shfl_xor(lsum, 32, 64);
+  __syncthreads();                      // cstat reads done
+  if (lane < 16) wstat[wave][lane] = lsum;
+  __syncthreads();
+  if (tid < NQT) {
+    float* st = w.stats + ((size_t)v * nchunk + chunk) * 2 * MAXQ;
+    st[tid] = cstat[tid];
+    st[MAXQ + tid] = wstat[0][tid] + wstat[1][tid] + wstat[2][tid] + wstat[3][tid];
+  }
+  // ---- 3. unnormalised pooling of the chunk: lane = 4 channels, the row's weights by v_readlane ---------------------------
+  f32x4 acc[NQT];
+#pragma unroll
+  for (int i = 0; i < NQT; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float mscale = (!HF && masked) ? xd.scale : 1.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    f32x4 x = cvtraw<HF>(xr[r]);
+    if (!HF && masked) {
+      const uint32_t bb = xm[r];
+      x[0] = (bb & 1u) ? x[0] * mscale : 0.f;
+      x[1] = (bb & 2u) ? x[1] * mscale : 0.f;
+      x[2] = (bb & 4u) ? x[2] * mscale : 0.f;
+      x[3] = (bb & 8u) ? x[3] * mscale : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < NQT; ++i) acc[i] += x * lane_bcast(pe[r & 3], 16 * (r >> 2) + i);     // rows beyond T: weight 0
+  }
+#pragma unroll
+  for (int i = 0; i < NQT; ++i) st4(red + (wave * NQT + i) * D + 4 * lane, acc[i]);
+  __syncthreads();
+  for (int e = tid; e < NQT * (D / 4); e += 256) {
+    const int i = e / (D / 4), cq = e - i * (D / 4);
+    f32x4 sum = ld4(red + i * D + 4 * cq);
+#pragma unroll
+    for (int ww = 1; ww < 4; ++ww) sum += ld4(red + (ww * NQT + i) * D + 4 * cq);
+    st4(w.part + (((size_t)v * nchunk + chunk) * NQT + i) * D + 4 * cq, sum);
+  }
+}
+
+template <bool HF, int NQT>
+__global__ __launch_bounds__(256, 2) void attn_fwd_partial_v2_kernel(const sdumc_attnpool p, float* ws, const int nchunk) {
+  int v, chunk;
+  v2_unit(p, blockIdx.x, nchunk, v, chunk);
+  attn_fwd_partial_v2<HF, NQT>(p, ws, nchunk, chunk, v);
+}
+template <bool HF, int NQT>
+__global__ __launch_bounds__(256, 2) void attn_fwd_partial_v2_multi_kernel(const MultiFwd m) {
+  const int s = site_of(m.wg_end, blockIdx.x);
+  const int local = blockIdx.x - (s ? m.wg_end[s - 1] : 0);
+  const int nchunk = m.nchunk[s];
+  sdumc_attnpool p = m.p[0];
+  if (s == 1) p = m.p[1];
+  if (s == 2) p = m.p[2];
+  if (s == 3) p = m.p[3];
+  int v, chunk;
+  v2_unit(p, local, nchunk, v, chunk);
+  attn_fwd_partial_v2<HF, NQT>(p, static_cast<float*>(p.workspace), nchunk, chunk, v);
+}
+
+// the v2 kernels take: 256-channel rows, nq = 1 or 7, keep-bits (or no input mask), the two-pass combine.  SDUMC_ATTN_V2=0 keeps
+// the round-3 kernels (A/B measurements)
+int g_v2 = -1;     // -1: not read yet (SDUMC_ATTN_V2, default on); sdumc_attnpool_set_v2_ (tests, A/B tools)
+bool v2_on() {
+  if (g_v2 < 0) { const char* e = getenv("SDUMC_ATTN_V2"); g_v2 = (e && e[0] == '0') ? 0 : 1; }
+  return g_v2 != 0;
+}
+bool v2_takes(const sdumc_attnpool& p) {
+  return v2_on() && row_dim(p) == D && (p.nq == 1 || p.nq == 7) && !p.tickets && !(p.x_drop.enabled && !p.x_drop.bits) &&
+         (!p.bf16 || !p.x_drop.enabled);
+}
+
 __global__ __launch_bounds__(256) void dq_reduce_kernel(const float* part, float* dq, const int nchunk,
                                                         const int per_v /* nq*256 */, const size_t total) {
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -614,6 +980,35 @@ __global__ __launch_bounds__(256) void dq_reduce_kernel(const float* part, float
   float a = 0.f;
   for (int c = 0; c < nchunk; ++c) a += s[(size_t)c * per_v];
   dq[idx] = a;
+}
+
+// shared query (FRA2UTT_new's context vector): sum of the per-chunk slabs of EVERY sample, one workgroup per 64 quads of the
+// [nq, dim] gradient: 16 row groups x 64 quads, a group walks rows g, g + 16, .. eight loads at a time, the groups meet in LDS
+// in ascending order -- one launch where dq_reduce + two column-sum launches (a 4-workgroup first stage of 25-38 us inside the
+// step, profiles/r3x_timeline_fp32.txt) used to sit on every modality's lane in front of its input-gradient launch
+__global__ __launch_bounds__(1024) void dq_sum_kernel(const float* part, float* dq_sum, const int rows /* V * nchunk */,
+                                                      const int per_v /* nq * dim */) {
+  __shared__ __attribute__((aligned(16))) float red[16][256];
+  const int cq = threadIdx.x & 63, g = threadIdx.x >> 6;
+  const size_t col = (size_t)blockIdx.x * 256 + 4 * cq;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  int r = g;
+  for (; r + 7 * 16 < rows; r += 8 * 16) {
+    f32x4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = ld4(part + (size_t)(r + 16 * u) * per_v + col);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += t[u];
+  }
+  for (; r < rows; r += 16) acc += ld4(part + (size_t)r * per_v + col);
+  st4(&red[g][4 * cq], acc);
+  __syncthreads();
+  if (g == 0) {
+    f32x4 s = ld4(&red[0][4 * cq]);
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += ld4(&red[k][4 * cq]);
+    st4(dq_sum + col, s);
+  }
 }
 
 __global__ __launch_bounds__(256) void dq_reduce_multi_kernel(const MultiBwd m) {
@@ -642,6 +1037,11 @@ int check(const sdumc_attnpool& p) {
 
 }  // namespace
 
+extern "C" int sdumc_attnpool_set_v2_(int on) {
+  g_v2 = on ? 1 : 0;
+  return SDUMC_OK;
+}
+
 extern "C" size_t sdumc_attnpool_fwd_workspace_bytes_dim(int32_t V, int32_t T, int32_t nq, int32_t dim) {
   const size_t nchunk = (size_t)(T + CH - 1) / CH;
   return ((size_t)V * nchunk * nq * (dim > 0 ? dim : D) + (size_t)V * nchunk * 2 * MAXQ) * sizeof(float);
@@ -660,6 +1060,21 @@ extern "C" int sdumc_attnpool_fwd(const sdumc_attnpool* pp, void* stream) {
   const int nchunk = (p.T + CH - 1) / CH;
   const bool philox = p.x_drop.enabled && !p.x_drop.bits;
   const dim3 grid(nchunk, p.V), blk(256);
+  if (v2_takes(p)) {
+    const dim3 g1(nchunk * p.V);
+    if (p.bf16) {
+      if (p.nq == 1) hipLaunchKernelGGL((attn_fwd_partial_v2_kernel<true, 1>), g1, blk, 0, st, p, static_cast<float*>(p.workspace), nchunk);
+      else hipLaunchKernelGGL((attn_fwd_partial_v2_kernel<true, 7>), g1, blk, 0, st, p, static_cast<float*>(p.workspace), nchunk);
+    } else {
+      if (p.nq == 1) hipLaunchKernelGGL((attn_fwd_partial_v2_kernel<false, 1>), g1, blk, 0, st, p, static_cast<float*>(p.workspace), nchunk);
+      else hipLaunchKernelGGL((attn_fwd_partial_v2_kernel<false, 7>), g1, blk, 0, st, p, static_cast<float*>(p.workspace), nchunk);
+    }
+    SDUMC_CHECK_LAUNCH();
+    hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(p.V), dim3(256), (size_t)nchunk * MAXQ * sizeof(float), st, p,
+                       p.workspace, nchunk);
+    SDUMC_CHECK_LAUNCH();
+    return SDUMC_OK;
+  }
 #define FWD_PARTIAL(PH, CC) hipLaunchKernelGGL((attn_fwd_partial_kernel<PH, CC>), grid, blk, 0, st, p, p.workspace, nchunk)
   if (p.bf16) {      // bf16 frames: the engine's bf16-storage mode (256 channels, masks pre-applied or keep-bits attached)
     if (row_dim(p) != D || philox) return SDUMC_EINVAL;
@@ -693,14 +1108,25 @@ extern "C" int sdumc_attnpool_bwd(const sdumc_attnpool_bwd_t* bp, void* stream) 
   const sdumc_attnpool_bwd_t& b = *bp;
   int rc = check(b.f);
   if (rc) return rc;
-  if (!b.dout || !b.dz || !b.dxd || !b.dq || !b.workspace) return SDUMC_EINVAL;
+  if (!b.dout || !b.dz || !b.dxd || (!b.dq && !b.dq_sum) || !b.workspace) return SDUMC_EINVAL;
   const sdumc_attnpool& p = b.f;
+  if (b.dq_sum && (p.q_stride != 0 || p.tickets)) return SDUMC_EINVAL;      // the sum over samples is the gradient of a SHARED query
   const int nchunk = (p.T + CH - 1) / CH;
   const int DD = row_dim(p);
   if (b.workspace_bytes < sdumc_attnpool_bwd_workspace_bytes_dim(p.V, p.T, p.nq, DD)) return SDUMC_ENOMEM;
   hipStream_t st = as_stream(stream);
   const dim3 grid(nchunk, p.V), blk(256);
-  if (p.bf16) {
+  if (v2_takes(p)) {
+    const dim3 g1(nchunk * p.V);
+    float* wsf = static_cast<float*>(b.workspace);
+    if (p.bf16) {
+      if (p.nq == 1) hipLaunchKernelGGL((attnpool_bwd_v2_kernel<true, 1>), g1, blk, 0, st, b, wsf, nchunk);
+      else hipLaunchKernelGGL((attnpool_bwd_v2_kernel<true, 7>), g1, blk, 0, st, b, wsf, nchunk);
+    } else {
+      if (p.nq == 1) hipLaunchKernelGGL((attnpool_bwd_v2_kernel<false, 1>), g1, blk, 0, st, b, wsf, nchunk);
+      else hipLaunchKernelGGL((attnpool_bwd_v2_kernel<false, 7>), g1, blk, 0, st, b, wsf, nchunk);
+    }
+  } else if (p.bf16) {
     if (DD != D || (p.x_drop.enabled && !p.x_drop.bits)) return SDUMC_EINVAL;
     hipLaunchKernelGGL((attnpool_bwd_kernel<1, true>), grid, blk, 0, st, b, b.workspace, nchunk);
   } else
@@ -711,6 +1137,11 @@ extern "C" int sdumc_attnpool_bwd(const sdumc_attnpool_bwd_t* bp, void* stream) 
     default: hipLaunchKernelGGL(attnpool_bwd_kernel<4>, grid, blk, 0, st, b, b.workspace, nchunk); break;
   }
   SDUMC_CHECK_LAUNCH();
+  if (b.dq_sum) {                          // shared query: every sample's slabs summed in one launch
+    hipLaunchKernelGGL(dq_sum_kernel, dim3((unsigned)(p.nq * DD / 256)), dim3(1024), 0, st, b.workspace, b.dq_sum, p.V * nchunk, p.nq * DD);
+    SDUMC_CHECK_LAUNCH();
+    return SDUMC_OK;
+  }
   if (p.tickets) return SDUMC_OK;          // the slabs were summed inside the kernel
   const size_t total = (size_t)p.V * p.nq * DD;
   hipLaunchKernelGGL(dq_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, b.workspace, b.dq,
@@ -746,7 +1177,17 @@ extern "C" int sdumc_attnpool_fwd_multi(const sdumc_attnpool* ps, int32_t n, voi
     m.v_end[i] = vs;
   }
   hipStream_t st = as_stream(stream);
-  if (ps[0].bf16) hipLaunchKernelGGL(attn_fwd_partial_multi_kernel<true>, dim3(wg), dim3(256), 0, st, m);
+  bool v2 = true;
+  for (int i = 0; i < n; ++i) v2 = v2 && v2_takes(ps[i]) && ps[i].nq == ps[0].nq;
+  if (v2) {
+    if (ps[0].bf16) {
+      if (ps[0].nq == 1) hipLaunchKernelGGL((attn_fwd_partial_v2_multi_kernel<true, 1>), dim3(wg), dim3(256), 0, st, m);
+      else hipLaunchKernelGGL((attn_fwd_partial_v2_multi_kernel<true, 7>), dim3(wg), dim3(256), 0, st, m);
+    } else {
+      if (ps[0].nq == 1) hipLaunchKernelGGL((attn_fwd_partial_v2_multi_kernel<false, 1>), dim3(wg), dim3(256), 0, st, m);
+      else hipLaunchKernelGGL((attn_fwd_partial_v2_multi_kernel<false, 7>), dim3(wg), dim3(256), 0, st, m);
+    }
+  } else if (ps[0].bf16) hipLaunchKernelGGL(attn_fwd_partial_multi_kernel<true>, dim3(wg), dim3(256), 0, st, m);
   else hipLaunchKernelGGL(attn_fwd_partial_multi_kernel<false>, dim3(wg), dim3(256), 0, st, m);
   SDUMC_CHECK_LAUNCH();
   if (ps[0].tickets) return SDUMC_OK;
@@ -767,7 +1208,7 @@ extern "C" int sdumc_attnpool_bwd_multi(const sdumc_attnpool_bwd_t* bs, int32_t 
       const sdumc_attnpool& p = b.f;
       int rc = check(p);
       if (rc) return rc;
-      if (!b.dout || !b.dz || !b.dxd || !b.dq || !b.workspace) return SDUMC_EINVAL;
+      if (!b.dout || !b.dz || !b.dxd || !b.dq || !b.workspace || b.dq_sum) return SDUMC_EINVAL;
       if (row_dim(p) != D || (p.x_drop.enabled && !p.x_drop.bits) || p.bf16 != bs[0].f.bf16) return SDUMC_EINVAL;
       if ((p.tickets != nullptr) != (bs[0].f.tickets != nullptr)) return SDUMC_EINVAL;
       if (b.workspace_bytes < sdumc_attnpool_bwd_workspace_bytes_dim(p.V, p.T, p.nq, D)) return SDUMC_ENOMEM;
@@ -780,7 +1221,17 @@ extern "C" int sdumc_attnpool_bwd_multi(const sdumc_attnpool_bwd_t* bs, int32_t 
     m.dq_end[i] = dq;
   }
   hipStream_t st = as_stream(stream);
-  if (bs[0].f.bf16) hipLaunchKernelGGL(attnpool_bwd_multi_kernel<true>, dim3(wg), dim3(256), 0, st, m);
+  bool v2 = true;
+  for (int i = 0; i < n; ++i) v2 = v2 && v2_takes(bs[i].f) && bs[i].f.nq == bs[0].f.nq;
+  if (v2) {
+    if (bs[0].f.bf16) {
+      if (bs[0].f.nq == 1) hipLaunchKernelGGL((attnpool_bwd_v2_multi_kernel<true, 1>), dim3(wg), dim3(256), 0, st, m);
+      else hipLaunchKernelGGL((attnpool_bwd_v2_multi_kernel<true, 7>), dim3(wg), dim3(256), 0, st, m);
+    } else {
+      if (bs[0].f.nq == 1) hipLaunchKernelGGL((attnpool_bwd_v2_multi_kernel<false, 1>), dim3(wg), dim3(256), 0, st, m);
+      else hipLaunchKernelGGL((attnpool_bwd_v2_multi_kernel<false, 7>), dim3(wg), dim3(256), 0, st, m);
+    }
+  } else if (bs[0].f.bf16) hipLaunchKernelGGL(attnpool_bwd_multi_kernel<true>, dim3(wg), dim3(256), 0, st, m);
   else hipLaunchKernelGGL(attnpool_bwd_multi_kernel<false>, dim3(wg), dim3(256), 0, st, m);
   SDUMC_CHECK_LAUNCH();
   if (bs[0].f.tickets) return SDUMC_OK;

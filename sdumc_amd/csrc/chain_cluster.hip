@@ -44,6 +44,7 @@ struct Cl {
   int32_t* err;
   uint32_t round;
   bool hold;        // test hook (sdumc_chain_cluster_test_hold_): this workgroup withholds its arrivals, so its cluster runs into the cap
+  uint32_t mode;    // sdumc_chain_args.cl_mode
 };
 
 __device__ __forceinline__ void st4_dev(float* p, f32x4 v) {
@@ -69,10 +70,14 @@ __device__ __forceinline__ void reload_rows(float* dst_lds, int ld_dst, const fl
 
 // every member's stores of the phase are complete and every member has arrived; ends with a workgroup barrier
 __device__ __forceinline__ void cl_sync(Cl& cl, int* s_bail) {
+  if (cl.mode & 1u) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   __builtin_amdgcn_s_waitcnt(0);
   __syncthreads();
   if (threadIdx.x == 0 && !*s_bail) {
-    if (!cl.hold) __hip_atomic_fetch_add(cl.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!cl.hold) {
+      if (cl.mode & 1u) __hip_atomic_fetch_add(cl.arrive, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      else __hip_atomic_fetch_add(cl.arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     const uint32_t want = (uint32_t)CL * (cl.round + 1u);
     int spins = 0;
     while (__hip_atomic_load(cl.arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
@@ -86,6 +91,7 @@ __device__ __forceinline__ void cl_sync(Cl& cl, int* s_bail) {
   }
   ++cl.round;
   __syncthreads();
+  if (cl.mode & 1u) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 // after a member's last cl_sync: the last one to leave zeroes the counters for the next launch
 __device__ __forceinline__ void cl_exit(Cl& cl) {
@@ -178,6 +184,38 @@ __device__ __forceinline__ void cxm_prefetch(CRing& ring, const float* __restric
   }
 }
 
+// diagnosis (cl_mode bit 4): the weights the prefetch has just loaded through the caches against agent-scope (cache-bypassing)
+// loads of the same addresses; a difference is recorded in dbg = {count, -, .. | records of 12 words}
+template <int I, int O, int RSv>
+__device__ __forceinline__ void cxm_selfcheck(const CRing& ring, const float* M, int ldm, uint32_t* dbg) {
+  using G = CGeom<I, O, RSv>;
+  const int lane = threadIdx.x & 63, wg = (threadIdx.x >> 6) % G::MW;
+  if (wg < G::WAVES && dbg) {
+    const int sq = lane / G::OG, cg = lane % G::OG;
+    const float* mp = M + (size_t)(wg * G::IW + 4 * sq) * ldm + 4 * cg;
+    static_for<G::PRE>([&](auto dc) {
+      constexpr int sl = decltype(dc)::value;
+      static_for<4>([&](auto ec) {
+        constexpr int e = decltype(ec)::value;
+        const uint32_t* ad = reinterpret_cast<const uint32_t*>(mp + (size_t)(sl * 4 * G::S + e) * ldm);
+        const uint4 c = ring.w[sl * 4 + e];
+        uint32_t b[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) b[k] = __hip_atomic_load(ad + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (c.x != b[0] || c.y != b[1] || c.z != b[2] || c.w != b[3]) {
+          const uint32_t idx = atomicAdd(dbg, 1u);
+          if (idx < 20) {
+            uint32_t* r = dbg + 8 + 12 * idx;
+            r[0] = blockIdx.x; r[1] = threadIdx.x; r[2] = sl * 4 + e;
+            r[3] = (uint32_t)(reinterpret_cast<uintptr_t>(ad) & 0xffffffffu);
+            r[4] = c.x; r[5] = c.y; r[6] = c.z; r[7] = c.w; r[8] = b[0]; r[9] = b[1]; r[10] = b[2]; r[11] = b[3];
+          }
+        }
+      });
+    });
+  }
+}
+
 // in_lds: [ROWS][ld_in]; M: this member's column slice of a row-major [I][ldm] matrix; epi(r, col, v) with col in [0, O).
 // The matching prefetch is cxm_prefetch<I, O, ROWS >= 14 ? 2 : 1> (macros PF / PF14 below).
 template <int ROWS, int I, int O, class Epi, class Hook>
@@ -247,7 +285,7 @@ __device__ __forceinline__ void cxm_run(CRing& ring, const float* in_lds, int ld
   const int cluster = blockIdx.x % ncl, member = blockIdx.x / ncl;                                             \
   const int V = a.V, v0 = cluster * R, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;                    \
   const int coff = member * OC;                                                                                \
-  Cl cl{a.cl_flags + cluster * 64, a.cl_flags + cluster * 64 + 32, a.cl_err, 0u, a.cl_test_hold == 1 && blockIdx.x == 0};                              \
+  Cl cl{a.cl_flags + cluster * 64, a.cl_flags + cluster * 64 + 32, a.cl_err, 0u, a.cl_test_hold == 1 && blockIdx.x == 0, (uint32_t)a.cl_mode};                              \
   if (tid == 0) s_bail = 0;                                                                                    \
   (void)lane; (void)wave
 
@@ -282,7 +320,11 @@ __global__ __launch_bounds__(NTHR) void chain_fwd_a_cl_kernel(const sdumc_chain_
   }
   const DropRT dbase = drop_resolve(a.drop);
   CRing ring;
+  if (a.cl_mode & 2) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  if (a.cl_mode & 8)
+    for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(127);
   PF(D, OC, a.umlp0_w[0] + coff, D);
+  if (a.cl_mode & 16) cxm_selfcheck<D, OC, 1>(ring, a.umlp0_w[0] + coff, D, a.cl_dbg);
   for (int m = 0; m < 3; ++m) load_rows<R>(s_hpre + m * R * D, a.hpre + m * VD, D, D, v0, V);
   __syncthreads();
   // audio / text / video_mlp (model :293-295)
@@ -966,6 +1008,7 @@ struct ClusterDev {
   uint32_t* flags = nullptr;     // [128 clusters][64 words]: arrival counter at +0, departure counter at +32 (own 128-byte lines)
   int32_t* err = nullptr;
   unsigned long long* trace = nullptr;   // 4 x 32 time stamps, written only while tracing is on
+  uint32_t* dbg = nullptr;               // 256 words of diagnosis records (cl_mode bit 4)
   bool tracing = false;
   hipEvent_t done = nullptr;
   hipStream_t last = nullptr;
@@ -986,9 +1029,10 @@ ClusterDev* cluster_dev() {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return nullptr;
     uint32_t* f = nullptr;
-    if (hipMalloc(&f, (kMaxClusters * 64 + 64 + 256) * sizeof(uint32_t)) != hipSuccess) return nullptr;
-    if (hipMemset(f, 0, (kMaxClusters * 64 + 64 + 256) * sizeof(uint32_t)) != hipSuccess) return nullptr;
+    if (hipMalloc(&f, (kMaxClusters * 64 + 64 + 256 + 256) * sizeof(uint32_t)) != hipSuccess) return nullptr;
+    if (hipMemset(f, 0, (kMaxClusters * 64 + 64 + 256 + 256) * sizeof(uint32_t)) != hipSuccess) return nullptr;
     d.trace = reinterpret_cast<unsigned long long*>(f + kMaxClusters * 64 + 64);
+    d.dbg = f + kMaxClusters * 64 + 64 + 256;
     if (hipEventCreateWithFlags(&d.done, hipEventDisableTiming) != hipSuccess) return nullptr;
     d.err = reinterpret_cast<int32_t*>(f + kMaxClusters * 64);
     d.cus = cus;
@@ -1014,7 +1058,7 @@ bool cluster_prepare(ClusterDev* d) {
   std::lock_guard<std::mutex> lk(d->mu);
   if (d->attr == 0) {
     d->attr = -1;
-    if (set_smem(chain_fwd_a_cl_kernel<R>, smem_fwd_a<R>()) || set_smem(chain_fwd_b_cl_kernel<R>, smem_fwd_b<R>()) ||
+    if (set_smem(chain_fwd_a_cl_kernel<R>, 158 * 1024) || set_smem(chain_fwd_b_cl_kernel<R>, smem_fwd_b<R>()) ||
         set_smem(chain_bwd_b_cl_kernel<R>, smem_bwd_b<R>()) || set_smem(chain_bwd_a_cl_kernel<R>, smem_bwd_a<R>()))
       return false;
     int n[4] = {0, 0, 0, 0};
@@ -1053,6 +1097,11 @@ extern "C" int sdumc_chain_cluster_launch_(const sdumc_chain_args* ap, int which
   a.cl_err = d->err;
   a.cl_trace = d->tracing ? d->trace + 32 * which : nullptr;
   a.w_bf16 = 0;
+  {
+    static const int mode = [] { const char* e = getenv("SDUMC_CL_MODE"); return e ? atoi(e) : 0; }();
+    a.cl_mode = mode;
+  }
+  a.cl_dbg = d->dbg;
   const int ncl = (a.V + R - 1) / R;
   const dim3 grid(ncl * CL), blk(NTHR);
   hipStream_t st = as_stream(stream);
@@ -1068,7 +1117,7 @@ extern "C" int sdumc_chain_cluster_launch_(const sdumc_chain_args* ap, int which
     }
   }
   switch (which) {
-    case 0: hipLaunchKernelGGL(chain_fwd_a_cl_kernel<R>, grid, blk, smem_fwd_a<R>(), st, a, ncl); break;
+    case 0: hipLaunchKernelGGL(chain_fwd_a_cl_kernel<R>, grid, blk, (a.cl_mode & 32) ? (size_t)158 * 1024 : smem_fwd_a<R>(), st, a, ncl); break;   // (bit 5, diagnosis: the whole CU's LDS -> no LDS-using neighbour on the CU)
     case 1: hipLaunchKernelGGL(chain_fwd_b_cl_kernel<R>, grid, blk, smem_fwd_b<R>(), st, a, ncl); break;
     case 2: hipLaunchKernelGGL(chain_bwd_b_cl_kernel<R>, grid, blk, smem_bwd_b<R>(), st, a, ncl); break;
     default: hipLaunchKernelGGL(chain_bwd_a_cl_kernel<R>, grid, blk, smem_bwd_a<R>(), st, a, ncl); break;
@@ -1094,6 +1143,33 @@ extern "C" int sdumc_chain_cluster_reset_error(void) {
   if (hipMemset(d->flags, 0, (kMaxClusters * 64 + 64) * sizeof(uint32_t)) != hipSuccess) return SDUMC_ELAUNCH;
   return SDUMC_OK;
 }
+// Data-parallel runs: the error word is per device, so a rank whose spin hit its cap would all-reduce garbage gradients into
+// every rank while only ITS Adam applies nothing.  The ranks therefore exchange the word with the gradient bucket: _flag writes
+// 1.0 / 0.0 into a float the caller appends to the bucket (stream-ordered, no host sync), the sum all-reduce carries it, and
+// _merge sets the local word when the reduced value is non-zero -- every rank then skips the update and raises together.
+namespace {
+__global__ void cl_err_flag_kernel(const int32_t* err, float* flag) { flag[0] = (err && *err != 0) ? 1.f : 0.f; }
+__global__ void cl_err_merge_kernel(int32_t* err, const float* flag) {
+  if (flag[0] != 0.f) *err = 1;      // (NaN included: a poisoned reduction is a failure too)
+}
+}  // namespace
+extern "C" int sdumc_chain_cluster_error_flag(float* flag, void* stream) {
+  if (!flag) return SDUMC_EINVAL;
+  ClusterDev* d = cluster_dev();
+  if (!d) return SDUMC_ELAUNCH;
+  hipLaunchKernelGGL(cl_err_flag_kernel, dim3(1), dim3(1), 0, as_stream(stream), d->err, flag);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+extern "C" int sdumc_chain_cluster_error_merge(const float* flag, void* stream) {
+  if (!flag) return SDUMC_EINVAL;
+  ClusterDev* d = cluster_dev();
+  if (!d) return SDUMC_ELAUNCH;
+  hipLaunchKernelGGL(cl_err_merge_kernel, dim3(1), dim3(1), 0, as_stream(stream), d->err, flag);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
 // test hook: on != 0 makes workgroup 0 of every following cluster launch withhold its arrivals, so that its cluster runs into
 // the spin cap (error word set, kernel finishes with wrong data): the failure path can be driven on purpose
 extern "C" int sdumc_chain_cluster_test_hold_(int on) {
@@ -1112,6 +1188,15 @@ extern "C" int sdumc_chain_cluster_error_() {
   if (hipDeviceSynchronize() != hipSuccess) return -1;
   if (hipMemcpy(&e, d->err, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return -1;
   return e;
+}
+
+// diagnosis records of cl_mode bit 4 (synchronises the device); clears them
+extern "C" int sdumc_chain_cluster_debug_read_(uint32_t* out, int n) {
+  ClusterDev* d = cluster_dev();
+  if (!d || !out || n < 1 || n > 256) return SDUMC_EINVAL;
+  if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(out, d->dbg, n * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess) return SDUMC_ELAUNCH;
+  if (hipMemset(d->dbg, 0, 256 * sizeof(uint32_t)) != hipSuccess) return SDUMC_ELAUNCH;
+  return SDUMC_OK;
 }
 
 // debug: on = 1 makes workgroup 0 of every cluster kernel stamp its phase boundaries; out (4 x 32 doubles, may be null) receives

@@ -68,6 +68,9 @@ struct sdumc_chain_args {
   int32_t* cl_err;
   unsigned long long* cl_trace;   // null, or 32 timestamps of workgroup 0 (debug)
   int32_t cl_test_hold;           // test hook: workgroup 0 withholds its arrivals (sdumc_chain_cluster_test_hold_)
+  int32_t cl_mode;                // exchange hand-shake: bit 0 = release / acquire fences at agent scope around the arrival counter
+                                  // (SDUMC_CL_MODE; bits 1.. = diagnosis switches of the stage-A forward kernel, chain_cluster.hip)
+  uint32_t* cl_dbg;               // diagnosis records (sdumc_chain_cluster_debug_read_)
 };
 
 extern "C" {

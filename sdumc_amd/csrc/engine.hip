@@ -1381,7 +1381,8 @@ int forward(const Ctx& c) {
 }
 
 // backward of the pooling of site (k, m): dz (pre-tanh key gradient), dxd (pooling path), dq
-int pool_bwd(const Ctx& c, int k, int m, const float* dout_base /* [V, nq, D] */, float* dq_base /* [V, nq, D] */) {
+int pool_bwd(const Ctx& c, int k, int m, const float* dout_base /* [V, nq, D] */, float* dq_base /* [V, nq, D] */,
+             float* dq_sum = nullptr /* shared query: [nq, D] sum over the samples instead of dq */) {
   const Plan& pl = c.pl;
   const int nq = k == 0 ? 1 : NQ;
   for (const Seg& sg : pl.segs[m]) {
@@ -1397,6 +1398,7 @@ int pool_bwd(const Ctx& c, int k, int m, const float* dout_base /* [V, nq, D] */
       b.dxd = reinterpret_cast<float*>(c.ph(pl.dxd[k][m], sg.row0 * D));
     }
     b.dq = dq_base + voff;
+    b.dq_sum = dq_sum;
     b.workspace = c.scr;
     b.workspace_bytes = (size_t)pl.scratch_floats * sizeof(float);
     RET(sdumc_attnpool_bwd(&b, c.st));
@@ -1825,8 +1827,11 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   for (int m = 0; m < 3; ++m) {       // pass 1: the pooling backward of every modality (produces dz of the FRA2UTT site)
     c.use(LANE_OF[m]);
     float* dq = c.p(pl.dq_fra) + (int64_t)m * V * D;
-    RET(pool_bwd(c, 0, m, c.p(pl.d_hpre) + (int64_t)m * V * D, dq));
-    RET(colsum(c, dq, V, D, D, c.G + pm.fra_ctx[m], 0));
+    // (the context vector is one query shared by every sample: its gradient, the sum over the samples' dq, leaves the pooling
+    //  backward's own reduce launch -- one run per modality; two runs (unequal text lengths) keep dq + a column sum)
+    float* ctx_grad = pl.segs[m].size() == 1 ? c.G + pm.fra_ctx[m] : nullptr;
+    RET(pool_bwd(c, 0, m, c.p(pl.d_hpre) + (int64_t)m * V * D, dq, ctx_grad));
+    if (!ctx_grad) RET(colsum(c, dq, V, D, D, c.G + pm.fra_ctx[m], 0));
     mark(c.st, 12 + 5 * m);      // (debug marks 12..26: this modality's lane, frame-level backward)
     if (fra_dw_mask & (1 << m)) {
       keys_dw_queue(c, m, 0, 1);
@@ -1876,6 +1881,13 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     }
     sdumc_gg_problem fq;          // grouped mode: this modality's frame_dim_reshape dW, the streams as K segments
     memset(&fq, 0, sizeof(fq));
+    // grouped or per-layer is decided ONCE per modality: the grouped problem overwrites its output (accumulate = 0) after the
+    // lanes have joined, so a modality whose streams took different paths would lose the per-layer stream's contribution
+    bool frame_grouped = ggf && (c.h() || (din[m] & 3) == 0);
+    for (int s = 0; s < (m == 1 ? S : 1); ++s) {
+      const float* in_s = m == 0 ? c.io.audio : (m == 2 ? c.io.video : c.io.text[s]);
+      if (reinterpret_cast<uintptr_t>(in_s) & 15) frame_grouped = false;
+    }
     for (int s = 0; s < (m == 1 ? S : 1); ++s) {
       const int T = pl.T[m][s];
       sdumc_dropsum ds;
@@ -1901,7 +1913,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
       if (s == 0) mark(c.st, 15 + 5 * m);
       const float* in = m == 0 ? c.io.audio : (m == 2 ? c.io.video : c.io.text[s]);
       const int rows = B * T;
-      if (c.h() && ggf && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+      if (c.h() && frame_grouped) {
         fq.A[s] = reinterpret_cast<const float*>(c.ph(pl.dx[m][s]));
         fq.B[s] = in;
         fq.K[s] = rows;
@@ -1920,7 +1932,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
         RET(run_h(c, gh));
         continue;
       }
-      if (ggf && (din[m] & 3) == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0) {
+      if (frame_grouped) {
         fq.A[s] = c.p(pl.dx[m][s]);
         fq.B[s] = in;
         fq.K[s] = rows;
@@ -2278,6 +2290,40 @@ extern "C" int sdumc_debug_marks_read(float* ms, int n) {
     }
   }
   return SDUMC_OK;
+}
+
+// debug / probes (tools/fwd_determinism_probe.py): the workspace plan of sdumc_net_forward as text lines
+// "name offset_in_floats length_in_floats" (offsets relative to sdumc_net_io.workspace; bf16-storage tensors: their length in floats)
+extern "C" int32_t sdumc_debug_plan_table(const sdumc_net_dims* d, char* buf, size_t buflen) {
+  Plan p;
+  if (!d || !make_plan(*d, p)) return 0;
+  const int HS = p.hf ? 2 : 1;
+  const int64_t V = p.V;
+  std::string s;
+  auto put = [&](const std::string& name, int64_t off, int64_t n) {
+    char line[160];
+    snprintf(line, sizeof(line), "%s %lld %lld\n", name.c_str(), (long long)off, (long long)n);
+    s += line;
+  };
+  const char* mod[3] = {"a", "t", "v"};
+  for (int m = 0; m < 3; ++m) {
+    put(std::string("x_") + mod[m], p.x[m][0], p.rows[m] / (m == 1 ? 1 : p.S) * D / HS);
+    for (int k = 0; k < 2; ++k) {
+      const std::string sfx = std::to_string(k) + mod[m];
+      put("keys" + sfx, p.keys[k][m], p.rows[m] * D / HS);
+      put("attn" + sfx, p.attn[k][m], p.rows[m] * (k == 0 ? 1 : NQ));
+      put("pooled" + sfx, p.pooled[k][m], V * (k == 0 ? 1 : NQ) * D);
+    }
+  }
+  put("hpre", p.hpre, 3 * V * D); put("u1", p.u1, 3 * V * D); put("u", p.u, 3 * V * D); put("att1", p.att1, V * D);
+  put("att2", p.att2, V * D); put("alpha", p.alpha, V * 3); put("qin", p.qin, 7 * V * D); put("q", p.q, 7 * V * D);
+  put("qp", p.qp, 3 * V * NQ * D); put("ca_out", p.ca_out, 3 * V * NQ * D); put("c1", p.c1, 3 * V * NQ * D);
+  put("c", p.c, 3 * V * NQ * H); put("h", p.h, V * NQ * H); put("e1", p.e1, V * D); put("e2", p.e2, V * H);
+  put("beta", p.beta, V * NQ); put("z", p.z, V * H); put("vals", p.vals, V); put("r1", p.r1, V * RD); put("r", p.r, V * RD);
+  put("wt", p.wt, build_params(d->da, d->dt, d->dv).early);
+  if (!buf || s.size() + 1 > buflen) return -(int32_t)(s.size() + 1);
+  memcpy(buf, s.c_str(), s.size() + 1);
+  return (int32_t)s.size();
 }
 
 // gradient bucket of the most recent sdumc_train_step inside its workspace (for tests / DP all-reduce)

@@ -212,19 +212,25 @@ def attnpool_fwd(x, keys, q, nq, x_samples=None, q_shared=False, x_drop=None, ou
     return out, attn, pooled, a
 
 
-def attnpool_bwd(desc, dout, keep):
-    """desc: the AttnPool returned by attnpool_fwd; keep: tensors that must stay alive."""
+def attnpool_bwd(desc, dout, keep, shared_q_sum=False):
+    """desc: the AttnPool returned by attnpool_fwd; keep: tensors that must stay alive.  shared_q_sum (descriptors with a shared
+    query, q_stride 0): dq comes back as the [1, nq, dim] SUM over the samples, from the backward's own single reduce launch."""
     V, T, nq = desc.V, desc.T, desc.nq
     dev = dout.device
     Dm = desc.dim or _lib.D
-    dz = torch.empty(V, T, Dm, device=dev)
-    dxd = torch.empty(V, T, Dm, device=dev)
-    dq = torch.empty(V, nq, Dm, device=dev)
+    fdt = torch.bfloat16 if desc.bf16 else torch.float32
+    dz = torch.empty(V, T, Dm, device=dev, dtype=fdt)
+    dxd = torch.empty(V, T, Dm, device=dev, dtype=fdt)
+    dq = torch.empty(1 if shared_q_sum else V, nq, Dm, device=dev)
     need = lib.sdumc_attnpool_bwd_workspace_bytes_dim(V, T, nq, Dm)
     ws = torch.empty(need, dtype=torch.uint8, device=dev)
     b = _lib.AttnPoolBwd()
     b.f = desc
-    b.dout, b.dz, b.dxd, b.dq = ptr(dout), ptr(dz), ptr(dxd), ptr(dq)
+    b.dout, b.dz, b.dxd = ptr(dout), ptr(dz), ptr(dxd)
+    if shared_q_sum:
+        b.dq_sum = ptr(dq)
+    else:
+        b.dq = ptr(dq)
     b.workspace, b.workspace_bytes = ptr(ws), need
     check(lib.sdumc_attnpool_bwd(C.byref(b), _st()), "sdumc_attnpool_bwd")
     return dz, dxd, dq

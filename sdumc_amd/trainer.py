@@ -67,8 +67,11 @@ class HipBackend:
         self.d_text_hidden = torch.empty(V, engine.D, device=dev)
         self.d_cross_text = torch.empty(V, engine.NQ, engine.H, device=dev)
         if getattr(st, "grads", None) is None:
-            st.grads = torch.zeros(self.layout.live, device=dev)     # the all-reduce bucket: one per run, not per shape
-        self.grads = st.grads
+            # the all-reduce bucket: one per run, not per shape; 4 trailing floats carry this rank's clustered-kernel error
+            # word through the same collective (err_flag / err_merge)
+            st.bucket = torch.zeros(self.layout.live + 4, device=dev)
+            st.grads = st.bucket[:self.layout.live]
+        self.grads, self.bucket = st.grads, st.bucket
         self.adam_m, self.adam_v, self.hyper, self.losses = st.adam_m, st.adam_v, st.hyper, st.losses
         self.ssd = torch.zeros(4, device=dev)
         nb = lib.sdumc_loss_workspace_bytes(C.byref(self.call.dims), B_global)
@@ -166,6 +169,19 @@ class HipBackend:
         _lib.check(lib.sdumc_net_backward_phase(C.byref(self.call.dims), C.byref(self.call.io), C.byref(self.g), phase,
                                                 _lib.current_stream()), "sdumc_net_backward_phase")
         return self.grads[:self.layout.early] if phase == 0 else self.grads[self.layout.early:]
+
+    def err_flag(self):
+        """bucket[live] = 1.0 if a clustered utterance-level kernel of this rank ran into its spin cap (its gradients are
+        garbage), else 0.0 -- written on the stream, no host sync; the gradient all-reduce then carries it to every rank."""
+        lib, _lib = self._lib.lib, self._lib
+        _lib.check(lib.sdumc_chain_cluster_error_flag(_lib.ptr(self.bucket[self.layout.live:]), _lib.current_stream()),
+                   "sdumc_chain_cluster_error_flag")
+
+    def err_merge(self):
+        """after the all-reduce: any rank failed -> this rank's error word is set too: its Adam applies nothing, it raises too"""
+        lib, _lib = self._lib.lib, self._lib
+        _lib.check(lib.sdumc_chain_cluster_error_merge(_lib.ptr(self.bucket[self.layout.live:]), _lib.current_stream()),
+                   "sdumc_chain_cluster_error_merge")
 
     def adam(self, grad_scale=1.0):
         lib, _lib = self._lib.lib, self._lib
@@ -313,16 +329,28 @@ class DataParallelStep:
             losses = be.loss_backward(ssd, feats, labels2, (self.rank * B, W * B + self.rank * B))
         else:
             losses = be.loss_backward()
+        # The clustered kernels' error word is per device: a rank whose spin hit its cap must not all-reduce garbage into ranks
+        # that then apply it.  Its flag rides in 4 floats behind the gradients (HipBackend.bucket), so the SAME collective
+        # tells every rank; err_merge sets the local word wherever the sum is non-zero: no rank applies, every rank raises.
+        flagged = self.collect and hasattr(be, "err_flag")
         if self.overlap and hasattr(be, "backward_phase"):
             early = be.backward_phase(0)
             pending = dist.all_reduce(early, async_op=True)   # rides the comm stream beside the frame-level backward
             late = be.backward_phase(1)
+            if flagged:
+                be.err_flag()
+                late = be.bucket[be.layout.early:]
             dist.all_reduce(late)
             pending.wait()
         else:
             grads = be.backward()
             if self.collect:
-                dist.all_reduce(grads)                      # one flat bucket
+                if flagged:
+                    be.err_flag()
+                    grads = be.bucket
+                dist.all_reduce(grads)                      # one flat bucket (+ the error flag)
+        if flagged:
+            be.err_merge()
         be.adam(1.0 if (self.exact or W == 1) else 1.0 / W)
         return losses
 

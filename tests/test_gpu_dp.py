@@ -281,3 +281,75 @@ def test_bench_parent_stops_everything_when_a_rank_dies():
     rc, lines, dt, err = _run_bench({"SDUMC_TEST_FAIL_RANK": "1"}, 120)
     assert rc == 3 and not lines and dt < 60, (rc, dt, err[-1000:])
     assert "rank 1 exited with code 3" in err
+
+
+_TWO_RANKS_ONE_FAILS = r"""
+import json, os, sys
+sys.path.insert(0, os.environ["SDUMC_REPO"])
+import torch
+import torch.distributed as dist
+rank = int(os.environ["RANK"])
+dist.init_process_group("gloo", rank=rank, world_size=2, init_method="tcp://127.0.0.1:" + os.environ["SDUMC_PORT"])
+torch.cuda.set_device(0)
+from oracle import sdumc_oracle as O       # (parameter initialisation and the synthetic batch only)
+from sdumc_amd import _lib, engine as E
+from sdumc_amd.trainer import DataParallelStep
+dims, B, Tn = (64, 32, 64, 32), 4, (40, 6, 20, 6)
+P = O.init_params(dims, seed=4)
+lay = E.ParamLayout.get(*dims[:3])
+flat = torch.zeros(lay.total)
+for k, v in lay.views(flat).items():
+    v.copy_(P[k])
+flat = flat.cuda()
+batch = [t.cuda() for t in O.synthetic_batch(2 * B, Tn, dims, seed=6)]
+dp = DataParallelStep(flat, B, Tn, dims, seed=9)
+dp.set_batch(*[t[rank * B:(rank + 1) * B].contiguous() for t in batch])
+good = dp.global_losses(dp.step())
+torch.cuda.synchronize()
+after_good = flat.clone()
+if rank == 1:
+    _lib.lib.sdumc_chain_cluster_test_hold_(1)      # THIS rank's clustered kernels run into their spin cap
+losses = dp.step()
+torch.cuda.synchronize()
+_lib.lib.sdumc_chain_cluster_test_hold_(0)
+raised = False
+try:
+    dp.global_losses(losses)
+except _lib.SdumcError:
+    raised = True
+out = {"rank": rank, "good_finite": bool(torch.isfinite(good).all()), "unchanged_in_failed_step": bool(torch.equal(flat, after_good)), "raised": raised,
+       "error_word": int(_lib.lib.sdumc_chain_cluster_error_())}
+print(json.dumps(out), flush=True)
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+def test_two_ranks_one_cluster_failure_stops_every_rank(tmp_path):
+    """Data-parallel failure contract: the clustered kernels' error word is per device, so a rank whose spin hit its cap
+    (driven on purpose on rank 1 with sdumc_chain_cluster_test_hold_) must not leave the OTHER rank applying the all-reduced
+    garbage.  The word rides behind the gradient bucket through the same all-reduce (trainer.HipBackend.err_flag / err_merge):
+    after the failed step BOTH ranks' parameters are unchanged, BOTH error words are set and BOTH raise in global_losses.
+    Two processes sharing the one GPU over gloo."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import json, os, subprocess, sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "two_ranks_one_fails.py"
+    script.write_text(_TWO_RANKS_ONE_FAILS)
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, SDUMC_REPO=repo, SDUMC_PORT="29561", RANK=str(rank), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        try:
+            so, se = p.communicate(timeout=300)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        assert p.returncode == 0, se[-3000:]
+        outs.append(json.loads([l for l in so.splitlines() if l.startswith("{")][-1]))
+    for o in outs:
+        assert o["good_finite"] and o["unchanged_in_failed_step"] and o["raised"] and o["error_word"] != 0, o

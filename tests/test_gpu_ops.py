@@ -387,6 +387,83 @@ def test_attnpool_multi_equals_single_calls(ops):
         assert int(m[3]._keep_tickets.abs().sum()) == 0
 
 
+@pytest.mark.parametrize("nq,T,shared_x,bf16", [(7, 130, True, False), (1, 375, True, False), (7, 32, False, False), (1, 64, True, False),
+                                                (7, 225, True, True), (1, 37, False, True)])
+def test_attnpool_v2_kernels_equal_the_round3_kernels_and_fp64(ops, nq, T, shared_x, bf16):
+    """The round-4 pooling kernels (every global load issued up front, softmax factors through v_readlane, XCD-aware pairing of
+    the two streams' workgroups: what the engine launches -- keep-bits masks, two-pass combine) against the round-3 kernels on
+    the same descriptors: bit-identical forward (out, weights, pooled rows) and backward (dz, dxd, dq), fp32 and bf16 frames,
+    nq = 1 (FRA2UTT_new, model :56-68) and 7 (Cross_Attention, model :79-95), ragged last chunks, x shared by the two streams
+    or not, key-padding lengths; the fp32 forward also against the fp64 restatement; the shared-query gradient from the
+    backward's single reduce launch (dq_sum) against the per-sample dq summed."""
+    from sdumc_amd import _lib
+    from sdumc_amd._lib import make_dropout
+    g = torch.Generator().manual_seed(nq * 1000 + T)
+    B, S, Dm = 5, 2, 256
+    V = B * S
+    xs = B if shared_x else V
+    x = torch.randn(xs, T, Dm, generator=g)
+    keys = torch.tanh(torch.randn(V, T, Dm, generator=g))
+    q = torch.randn(V, nq, Dm, generator=g) / 4
+    lengths = dev(torch.randint(1, T + 1, (V,), generator=g).to(torch.int32))
+    xdrop = make_dropout(True, 23, 0.5, T, Dm, B, call0=4, seed=9)
+    odrop = make_dropout(True, 24, 0.5, nq, Dm, B, call0=4, seed=9)
+    xg, kg, qg = dev(x), dev(keys), dev(q)
+    if bf16:      # bf16 storage: the masked frames exist per virtual sample, the pooling kernels read no mask
+        m = ops.dropout_mask(xdrop, S).view(V, T, Dm)
+        xg = ((xg if not shared_x else xg.repeat(S, 1, 1)) * m).to(torch.bfloat16).contiguous()
+        kg = kg.to(torch.bfloat16)
+        xs, xdrop = V, None
+    else:
+        bits = ops.dropout_bits(xdrop, S)
+    dout = dev(torch.randn(V, nq, Dm, generator=g))
+    res = []
+    try:
+        for v2 in (0, 1):
+            _lib.lib.sdumc_attnpool_set_v2_(v2)
+            for lens in (None, lengths):
+                attn, pooled, out = [torch.empty(s_, device="cuda") for s_ in ((V, T, nq), (V, nq, Dm), (V, nq, Dm))]
+                a = ops.attnpool_desc(xg, kg, qg, V, T, nq, xs, nq * Dm, xdrop, odrop, attn, pooled, out, lengths=lens, tickets=False)
+                a.bf16 = 1 if bf16 else 0
+                need = _lib.lib.sdumc_attnpool_fwd_workspace_bytes(V, T, nq)
+                ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+                a.workspace, a.workspace_bytes = _lib.ptr(ws), need
+                import ctypes as C
+                _lib.check(_lib.lib.sdumc_attnpool_fwd(C.byref(a), _lib.current_stream()), "sdumc_attnpool_fwd")
+                dz, dxd, dq = ops.attnpool_bwd(a, dout, ())
+                torch.cuda.synchronize()
+                res.append((out.clone(), attn.clone(), pooled.clone(), dz, dxd, dq))
+    finally:
+        _lib.lib.sdumc_attnpool_set_v2_(1)
+    for old, new in zip(res[:2], res[2:]):
+        for t_old, t_new in zip(old, new):
+            assert torch.equal(t_old, t_new)
+    assert not torch.equal(res[2][0], res[3][0])          # (the key-padding lengths do change the result)
+    if not bf16:
+        from oracle import philox
+        xm = torch.from_numpy(np.concatenate([philox.dropout_mask(B, T, Dm, 0.5, 9, 4 + s_, 23) for s_ in range(S)])).double()
+        xd = (x if not shared_x else x.repeat(S, 1, 1)).double() * xm
+        sc = torch.einsum("vtd,vqd->vtq", keys.double(), q.double()) * 0.3
+        att = torch.softmax(sc, dim=1)
+        close(res[2][1], att, 2e-5)
+        close(res[2][2], torch.einsum("vtq,vtd->vqd", att, xd), 2e-5)
+    if nq == 1:       # a shared query's gradient from the one-launch reduce == the per-sample gradients summed
+        attn, pooled, out = [torch.empty(s_, device="cuda") for s_ in ((V, T, nq), (V, nq, Dm), (V, nq, Dm))]
+        q1 = qg[:1].contiguous()
+        a = ops.attnpool_desc(xg, kg, q1, V, T, nq, xs, 0, xdrop, odrop, attn, pooled, out, tickets=False)
+        a.bf16 = 1 if bf16 else 0
+        need = _lib.lib.sdumc_attnpool_fwd_workspace_bytes(V, T, nq)
+        ws = torch.empty(need, dtype=torch.uint8, device="cuda")
+        a.workspace, a.workspace_bytes = _lib.ptr(ws), need
+        import ctypes as C
+        _lib.check(_lib.lib.sdumc_attnpool_fwd(C.byref(a), _lib.current_stream()), "sdumc_attnpool_fwd")
+        _, _, dq_each = ops.attnpool_bwd(a, dout, ())
+        dz2, dxd2, dq_sum = ops.attnpool_bwd(a, dout, (), shared_q_sum=True)
+        close(dq_sum, dq_each.double().sum(0, keepdim=True), 1e-5)
+        again = ops.attnpool_bwd(a, dout, (), shared_q_sum=True)[2]
+        assert torch.equal(dq_sum, again)
+
+
 def test_losses_against_reference_goldens(ops, golden):
     g = golden("losses")
     T = lambda k: dev(torch.from_numpy(g[k]))
