@@ -663,7 +663,7 @@ __device__ __forceinline__ void v2_unit(const sdumc_attnpool& p, int local, int 
 }
 
 // ---- backward v2 --------------------------------------------------------------------------------------------------
-template <bool HF, int NQT>
+template <bool HF, int NQT, int VAR = 0>
 __device__ __forceinline__ void attnpool_bwd_v2(const sdumc_attnpool_bwd_t b, float* dq_part, const int nchunk, const int chunk, const int v) {
   constexpr int LDQ = D + 16;
   typedef typename RawRow<HF>::type raw_t;
@@ -699,8 +699,10 @@ __device__ __forceinline__ void attnpool_bwd_v2(const sdumc_attnpool_bwd_t b, fl
     const int t = tw + 4 * kk + e;
     av[e] = (r16 < NQT && t < T) ? p.attn[((size_t)v * T + t) * NQT + r16] : 0.f;
   }
+  if constexpr (VAR != 3) {
 #pragma unroll
-  for (int i = 0; i < NQT; ++i) qv[i] = ld4(p.q + (size_t)v * p.q_stride + (size_t)i * D + 4 * lane);
+    for (int i = 0; i < NQT; ++i) qv[i] = ld4(p.q + (size_t)v * p.q_stride + (size_t)i * D + 4 * lane);
+  }
   // the wave's 16 frame rows as the MFMA A operand: lane (r16, kk) takes x[row r16][16 j + 4 kk ..], j = 0..15; their keep-bits
   // (64 bytes per row) as four 16-byte loads; then the 16 key rows, lane = 4 channels
   raw_t xa[16], kr[16];
@@ -716,8 +718,14 @@ __device__ __forceinline__ void attnpool_bwd_v2(const sdumc_attnpool_bwd_t b, fl
       for (int j = 0; j < 4; ++j) xb[j] = bp[j];
     }
   }
+  if constexpr (VAR != 1) {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) kr[r] = ldraw<HF>(p.keys, ((size_t)v * T + min(tw + r, T - 1)) * D + 4 * lane);
+    for (int r = 0; r < 16; ++r) kr[r] = ldraw<HF>(p.keys, ((size_t)v * T + min(tw + r, T - 1)) * D + 4 * lane);
+  }
+  if constexpr (VAR == 2) {      // experiment: every other dispatch round starts late, so that co-resident workgroups are in different phases
+    if ((blockIdx.x >> 8) & 1)
+      for (int i = 0; i < 2; ++i) __builtin_amdgcn_s_sleep(127);
+  }
   // ---- 2. dO = dout * out_mask -> LDS; delta_i = dO_i . O_i ----------------------------------------------------------
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
@@ -755,6 +763,14 @@ __device__ __forceinline__ void attnpool_bwd_v2(const sdumc_attnpool_bwd_t b, fl
 #pragma unroll
       for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bq[e], acc, 0, 0, 0);
     }
+  }
+  if constexpr (VAR == 1) {      // experiment: the key rows are requested once the frame tile's registers are free (3 waves per SIMD)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) kr[r] = ldraw<HF>(p.keys, ((size_t)v * T + min(tw + r, T - 1)) * D + 4 * lane);
+  }
+  if constexpr (VAR == 3) {      // experiment: the (L2-resident) query rows are requested once the frame tile's registers are free
+#pragma unroll
+    for (int i = 0; i < NQT; ++i) qv[i] = ld4(p.q + (size_t)v * p.q_stride + (size_t)i * D + 4 * lane);
   }
   const float xscale = (!HF && masked) ? xd.scale : 1.f;
   float dSv[4];
@@ -807,8 +823,8 @@ __global__ __launch_bounds__(256, 2) void attnpool_bwd_v2_kernel(const sdumc_att
   v2_unit(b.f, blockIdx.x, nchunk, v, chunk);
   attnpool_bwd_v2<HF, NQT>(b, dq_part, nchunk, chunk, v);
 }
-template <bool HF, int NQT>
-__global__ __launch_bounds__(256, 2) void attnpool_bwd_v2_multi_kernel(const MultiBwd m) {
+template <bool HF, int NQT, int VAR = 0>
+__global__ __launch_bounds__(256, (VAR == 1 || VAR == 3) ? 3 : 2) void attnpool_bwd_v2_multi_kernel(const MultiBwd m) {
   const int s = site_of(m.wg_end, blockIdx.x);
   const int local = blockIdx.x - (s ? m.wg_end[s - 1] : 0);
   const int nchunk = m.nchunk[s];
@@ -818,11 +834,11 @@ __global__ __launch_bounds__(256, 2) void attnpool_bwd_v2_multi_kernel(const Mul
   if (s == 3) b = m.b[3];
   int v, chunk;
   v2_unit(b.f, local, nchunk, v, chunk);
-  attnpool_bwd_v2<HF, NQT>(b, static_cast<float*>(b.workspace), nchunk, chunk, v);
+  attnpool_bwd_v2<HF, NQT, VAR>(b, static_cast<float*>(b.workspace), nchunk, chunk, v);
 }
 
 // ---- forward partial v2 ---------------------------------------------------------------------------------------------
-template <bool HF, int NQT>
+template <bool HF, int NQT, int VAR = 0>
 __device__ __forceinline__ void attn_fwd_partial_v2(const sdumc_attnpool p, float* ws, const int nchunk, const int chunk, const int v) {
   constexpr int LDQ = D + 16;
   typedef typename RawRow<HF>::type raw_t;
@@ -854,12 +870,15 @@ __device__ __forceinline__ void attn_fwd_partial_v2(const sdumc_attnpool p, floa
 #pragma unroll
     for (int j = 0; j < 16; ++j) ka[j] = ldraw<HF>(p.keys, ro + 16 * j);
   }
+  auto load_x = [&]() {
 #pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const int t = min(tw + r, T - 1);                  // rows beyond T re-read the last row; their weight is 0
-    xr[r] = ldraw<HF>(p.x, ((size_t)vx * T + t) * D + 4 * lane);
-    xm[r] = (!HF && masked) ? xd.bits[((size_t)v * T + t) * (D / 4) + lane] : 0xfu;
-  }
+    for (int r = 0; r < 16; ++r) {
+      const int t = min(tw + r, T - 1);                  // rows beyond T re-read the last row; their weight is 0
+      xr[r] = ldraw<HF>(p.x, ((size_t)vx * T + t) * D + 4 * lane);
+      xm[r] = (!HF && masked) ? xd.bits[((size_t)v * T + t) * (D / 4) + lane] : 0xfu;
+    }
+  };
+  if constexpr (VAR != 1) load_x();
   // ---- 2. scores of the wave's 16 rows against the queries -----------------------------------------------------------------
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
@@ -876,6 +895,7 @@ __device__ __forceinline__ void attn_fwd_partial_v2(const sdumc_attnpool p, floa
 #pragma unroll
     for (int e = 0; e < 4; ++e) s4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bq[e], s4, 0, 0, 0);
   }
+  if constexpr (VAR == 1) load_x();      // experiment: the frame rows are requested once the key tile's registers are free (4 waves per SIMD)
   // C layout: column (query) = lane & 15, rows = 16 wave + 4 (lane >> 4) + e
   float s[4], mx = -INFINITY;
 #pragma unroll
@@ -945,8 +965,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_partial_v2_kernel(const sdumc
   v2_unit(p, blockIdx.x, nchunk, v, chunk);
   attn_fwd_partial_v2<HF, NQT>(p, ws, nchunk, chunk, v);
 }
-template <bool HF, int NQT>
-__global__ __launch_bounds__(256, 2) void attn_fwd_partial_v2_multi_kernel(const MultiFwd m) {
+template <bool HF, int NQT, int VAR = 0>
+__global__ __launch_bounds__(256, VAR == 1 ? 4 : 2) void attn_fwd_partial_v2_multi_kernel(const MultiFwd m) {
   const int s = site_of(m.wg_end, blockIdx.x);
   const int local = blockIdx.x - (s ? m.wg_end[s - 1] : 0);
   const int nchunk = m.nchunk[s];
@@ -956,7 +976,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_partial_v2_multi_kernel(const
   if (s == 3) p = m.p[3];
   int v, chunk;
   v2_unit(p, local, nchunk, v, chunk);
-  attn_fwd_partial_v2<HF, NQT>(p, static_cast<float*>(p.workspace), nchunk, chunk, v);
+  attn_fwd_partial_v2<HF, NQT, VAR>(p, static_cast<float*>(p.workspace), nchunk, chunk, v);
 }
 
 // the v2 kernels take: 256-channel rows, nq = 1 or 7, keep-bits (or no input mask), the two-pass combine.  SDUMC_ATTN_V2=0 keeps
@@ -1184,7 +1204,9 @@ extern "C" int sdumc_attnpool_fwd_multi(const sdumc_attnpool* ps, int32_t n, voi
       if (ps[0].nq == 1) hipLaunchKernelGGL((attn_fwd_partial_v2_multi_kernel<true, 1>), dim3(wg), dim3(256), 0, st, m);
       else hipLaunchKernelGGL((attn_fwd_partial_v2_multi_kernel<true, 7>), dim3(wg), dim3(256), 0, st, m);
     } else {
+      static const int fvar = [] { const char* e = getenv("SDUMC_ATTN_FVAR"); return e ? atoi(e) : 0; }();     // (experiments)
       if (ps[0].nq == 1) hipLaunchKernelGGL((attn_fwd_partial_v2_multi_kernel<false, 1>), dim3(wg), dim3(256), 0, st, m);
+      else if (fvar == 1) hipLaunchKernelGGL((attn_fwd_partial_v2_multi_kernel<false, 7, 1>), dim3(wg), dim3(256), 0, st, m);
       else hipLaunchKernelGGL((attn_fwd_partial_v2_multi_kernel<false, 7>), dim3(wg), dim3(256), 0, st, m);
     }
   } else if (ps[0].bf16) hipLaunchKernelGGL(attn_fwd_partial_multi_kernel<true>, dim3(wg), dim3(256), 0, st, m);
@@ -1228,7 +1250,11 @@ extern "C" int sdumc_attnpool_bwd_multi(const sdumc_attnpool_bwd_t* bs, int32_t 
       if (bs[0].f.nq == 1) hipLaunchKernelGGL((attnpool_bwd_v2_multi_kernel<true, 1>), dim3(wg), dim3(256), 0, st, m);
       else hipLaunchKernelGGL((attnpool_bwd_v2_multi_kernel<true, 7>), dim3(wg), dim3(256), 0, st, m);
     } else {
+      static const int var = [] { const char* e = getenv("SDUMC_ATTN_VAR"); return e ? atoi(e) : 0; }();     // (experiments)
       if (bs[0].f.nq == 1) hipLaunchKernelGGL((attnpool_bwd_v2_multi_kernel<false, 1>), dim3(wg), dim3(256), 0, st, m);
+      else if (var == 1) hipLaunchKernelGGL((attnpool_bwd_v2_multi_kernel<false, 7, 1>), dim3(wg), dim3(256), 0, st, m);
+      else if (var == 2) hipLaunchKernelGGL((attnpool_bwd_v2_multi_kernel<false, 7, 2>), dim3(wg), dim3(256), 0, st, m);
+      else if (var == 3) hipLaunchKernelGGL((attnpool_bwd_v2_multi_kernel<false, 7, 3>), dim3(wg), dim3(256), 0, st, m);
       else hipLaunchKernelGGL((attnpool_bwd_v2_multi_kernel<false, 7>), dim3(wg), dim3(256), 0, st, m);
     }
   } else if (bs[0].f.bf16) hipLaunchKernelGGL(attnpool_bwd_multi_kernel<true>, dim3(wg), dim3(256), 0, st, m);

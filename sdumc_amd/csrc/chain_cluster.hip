@@ -216,6 +216,29 @@ __device__ __forceinline__ void cxm_selfcheck(const CRing& ring, const float* M,
   }
 }
 
+// diagnosis (cl_mode bit 6): the LDS copy of the stage's input rows against global memory (the inputs are final before the launch)
+template <int ROWS>
+__device__ __forceinline__ void lds_selfcheck(const float* lds_rows, const float* src, int width, int row0, int nrows, uint32_t* dbg, int tag) {
+  if (!dbg) return;
+  const int q = width >> 2;
+  for (int u = threadIdx.x; u < ROWS * q; u += NTHR) {
+    const int r = u / q, c = u - r * q;
+    if (row0 + r >= nrows) continue;
+    const f32x4 l = ld4(lds_rows + r * width + 4 * c);
+    const f32x4 g = ld4(src + (int64_t)(row0 + r) * width + 4 * c);
+    if (__float_as_uint(l[0]) != __float_as_uint(g[0]) || __float_as_uint(l[1]) != __float_as_uint(g[1]) ||
+        __float_as_uint(l[2]) != __float_as_uint(g[2]) || __float_as_uint(l[3]) != __float_as_uint(g[3])) {
+      const uint32_t idx = atomicAdd(dbg, 1u);
+      if (idx < 20) {
+        uint32_t* rec = dbg + 8 + 12 * idx;
+        rec[0] = blockIdx.x; rec[1] = threadIdx.x; rec[2] = (uint32_t)tag; rec[3] = (uint32_t)(r * width + 4 * c);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { rec[4 + k] = __float_as_uint(l[k]); rec[8 + k] = __float_as_uint(g[k]); }
+      }
+    }
+  }
+}
+
 // in_lds: [ROWS][ld_in]; M: this member's column slice of a row-major [I][ldm] matrix; epi(r, col, v) with col in [0, O).
 // The matching prefetch is cxm_prefetch<I, O, ROWS >= 14 ? 2 : 1> (macros PF / PF14 below).
 template <int ROWS, int I, int O, class Epi, class Hook>
@@ -297,7 +320,7 @@ typedef float WT;   // weights stream as fp32
 // stage A forward (model :293-332 + :85); 5 exchanges: u1, u, att1, att2, q
 // ------------------------------------------------------------------------------------------------------------------
 template <int R>
-__global__ __launch_bounds__(NTHR) void chain_fwd_a_cl_kernel(const sdumc_chain_args a, const int ncl) {
+__device__ __forceinline__ void chain_fwd_a_cl_body(const sdumc_chain_args a, const int ncl) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* part = sm;                              // PARTC
   float* s_hpre = part + PARTC;                  // [3][R][256]
@@ -327,6 +350,8 @@ __global__ __launch_bounds__(NTHR) void chain_fwd_a_cl_kernel(const sdumc_chain_
   if (a.cl_mode & 16) cxm_selfcheck<D, OC, 1>(ring, a.umlp0_w[0] + coff, D, a.cl_dbg);
   for (int m = 0; m < 3; ++m) load_rows<R>(s_hpre + m * R * D, a.hpre + m * VD, D, D, v0, V);
   __syncthreads();
+  if (a.cl_mode & 64)
+    for (int m = 0; m < 3; ++m) lds_selfcheck<R>(s_hpre + m * R * D, a.hpre + m * VD, D, v0, V, a.cl_dbg, 10 + m);
   // audio / text / video_mlp (model :293-295)
 #pragma unroll 1
   for (int m = 0; m < 3; ++m) {
@@ -340,6 +365,8 @@ __global__ __launch_bounds__(NTHR) void chain_fwd_a_cl_kernel(const sdumc_chain_
                                 [&] { PF(D, OC, (m < 2 ? a.umlp0_w[m + 1] : a.umlp3_w[0]) + coff, D); });
   }
   TR(1);
+  if (a.cl_mode & 64)       // ... and again after the three layers that read it
+    for (int m = 0; m < 3; ++m) lds_selfcheck<R>(s_hpre + m * R * D, a.hpre + m * VD, D, v0, V, a.cl_dbg, 20 + m);
   cl_sync(cl, &s_bail);
   TR(2);
   for (int m = 0; m < 3; ++m) reload_rows<R>(s_u1 + m * R * D, D, a.u1 + m * VD, D, D, v0, V);
@@ -449,13 +476,19 @@ __global__ __launch_bounds__(NTHR) void chain_fwd_a_cl_kernel(const sdumc_chain_
   }
   TR(31);
 }
+// two entry points per stage: with packed FP32 VALU instructions (fp32 storage), and without (SDUMC_NO_PACKED_FP32, chain_common.h:
+// whenever bf16 MFMA kernels run beside this one, i.e. sdumc_net_dims.bf16 != 0)
+template <int R>
+__global__ __launch_bounds__(NTHR) void chain_fwd_a_cl_kernel(const sdumc_chain_args a, const int ncl) { chain_fwd_a_cl_body<R>(a, ncl); }
+template <int R>
+__global__ SDUMC_NO_PACKED_FP32 __launch_bounds__(NTHR) void chain_fwd_a_cl_np_kernel(const sdumc_chain_args a, const int ncl) { chain_fwd_a_cl_body<R>(a, ncl); }
 
 // ------------------------------------------------------------------------------------------------------------------
 // stage B forward (model :338-368); 4 exchanges: c1, c, e1, e2.  The tail (beta, cross_fused_feat, fc_out_v,
 // orgin_linear_change: 2 x <= 128 columns) is member 0's alone.
 // ------------------------------------------------------------------------------------------------------------------
 template <int R>
-__global__ __launch_bounds__(NTHR) void chain_fwd_b_cl_kernel(const sdumc_chain_args a, const int ncl) {
+__device__ __forceinline__ void chain_fwd_b_cl_body(const sdumc_chain_args a, const int ncl) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* part = sm;
   float* s_x = part + PARTC;                     // [3][7R][256]  ca_out, then c1
@@ -626,13 +659,19 @@ __global__ __launch_bounds__(NTHR) void chain_fwd_b_cl_kernel(const sdumc_chain_
   }
   TR(31);
 }
+// two entry points per stage: with packed FP32 VALU instructions (fp32 storage), and without (SDUMC_NO_PACKED_FP32, chain_common.h:
+// whenever bf16 MFMA kernels run beside this one, i.e. sdumc_net_dims.bf16 != 0)
+template <int R>
+__global__ __launch_bounds__(NTHR) void chain_fwd_b_cl_kernel(const sdumc_chain_args a, const int ncl) { chain_fwd_b_cl_body<R>(a, ncl); }
+template <int R>
+__global__ SDUMC_NO_PACKED_FP32 __launch_bounds__(NTHR) void chain_fwd_b_cl_np_kernel(const sdumc_chain_args a, const int ncl) { chain_fwd_b_cl_body<R>(a, ncl); }
 
 // ------------------------------------------------------------------------------------------------------------------
 // stage B backward; 3 exchanges: d_e1, d_h, d_c1.  The head (orgin_linear_change, zpool, cross_fc_att backward: <= 128
 // columns) is computed by every member, written by member 0.
 // ------------------------------------------------------------------------------------------------------------------
 template <int R>
-__global__ __launch_bounds__(NTHR) void chain_bwd_b_cl_kernel(const sdumc_chain_args a, const int ncl) {
+__device__ __forceinline__ void chain_bwd_b_cl_body(const sdumc_chain_args a, const int ncl) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* part = sm;
   float* s_g = part + PARTC;                     // [R][64]   d_rnc
@@ -807,12 +846,18 @@ __global__ __launch_bounds__(NTHR) void chain_bwd_b_cl_kernel(const sdumc_chain_
   }
   TR(31);
 }
+// two entry points per stage: with packed FP32 VALU instructions (fp32 storage), and without (SDUMC_NO_PACKED_FP32, chain_common.h:
+// whenever bf16 MFMA kernels run beside this one, i.e. sdumc_net_dims.bf16 != 0)
+template <int R>
+__global__ __launch_bounds__(NTHR) void chain_bwd_b_cl_kernel(const sdumc_chain_args a, const int ncl) { chain_bwd_b_cl_body<R>(a, ncl); }
+template <int R>
+__global__ SDUMC_NO_PACKED_FP32 __launch_bounds__(NTHR) void chain_bwd_b_cl_np_kernel(const sdumc_chain_args a, const int ncl) { chain_bwd_b_cl_body<R>(a, ncl); }
 
 // ------------------------------------------------------------------------------------------------------------------
 // stage A backward; 6 exchanges: d_q, d_qin, d_att1, d_u, d_u1 (+ none for d_hpre, the stage's output)
 // ------------------------------------------------------------------------------------------------------------------
 template <int R>
-__global__ __launch_bounds__(NTHR) void chain_bwd_a_cl_kernel(const sdumc_chain_args a, const int ncl) {
+__device__ __forceinline__ void chain_bwd_a_cl_body(const sdumc_chain_args a, const int ncl) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* part = sm;
   float* s_x = part + PARTC;                     // [3][7R][256]  d_qp
@@ -985,6 +1030,12 @@ __global__ __launch_bounds__(NTHR) void chain_bwd_a_cl_kernel(const sdumc_chain_
   }
   TR(31);
 }
+// two entry points per stage: with packed FP32 VALU instructions (fp32 storage), and without (SDUMC_NO_PACKED_FP32, chain_common.h:
+// whenever bf16 MFMA kernels run beside this one, i.e. sdumc_net_dims.bf16 != 0)
+template <int R>
+__global__ __launch_bounds__(NTHR) void chain_bwd_a_cl_kernel(const sdumc_chain_args a, const int ncl) { chain_bwd_a_cl_body<R>(a, ncl); }
+template <int R>
+__global__ SDUMC_NO_PACKED_FP32 __launch_bounds__(NTHR) void chain_bwd_a_cl_np_kernel(const sdumc_chain_args a, const int ncl) { chain_bwd_a_cl_body<R>(a, ncl); }
 
 #undef PF
 #undef PF14
@@ -1059,13 +1110,21 @@ bool cluster_prepare(ClusterDev* d) {
   if (d->attr == 0) {
     d->attr = -1;
     if (set_smem(chain_fwd_a_cl_kernel<R>, 158 * 1024) || set_smem(chain_fwd_b_cl_kernel<R>, smem_fwd_b<R>()) ||
-        set_smem(chain_bwd_b_cl_kernel<R>, smem_bwd_b<R>()) || set_smem(chain_bwd_a_cl_kernel<R>, smem_bwd_a<R>()))
+        set_smem(chain_bwd_b_cl_kernel<R>, smem_bwd_b<R>()) || set_smem(chain_bwd_a_cl_kernel<R>, smem_bwd_a<R>()) ||
+        set_smem(chain_fwd_a_cl_np_kernel<R>, 158 * 1024) || set_smem(chain_fwd_b_cl_np_kernel<R>, smem_fwd_b<R>()) ||
+        set_smem(chain_bwd_b_cl_np_kernel<R>, smem_bwd_b<R>()) || set_smem(chain_bwd_a_cl_np_kernel<R>, smem_bwd_a<R>()))
       return false;
     int n[4] = {0, 0, 0, 0};
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[0], chain_fwd_a_cl_kernel<R>, NTHR, smem_fwd_a<R>()) != hipSuccess ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[1], chain_fwd_b_cl_kernel<R>, NTHR, smem_fwd_b<R>()) != hipSuccess ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[2], chain_bwd_b_cl_kernel<R>, NTHR, smem_bwd_b<R>()) != hipSuccess ||
         hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[3], chain_bwd_a_cl_kernel<R>, NTHR, smem_bwd_a<R>()) != hipSuccess)
+      return false;
+    if (n[0] < 1 || n[1] < 1 || n[2] < 1 || n[3] < 1) return false;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[0], chain_fwd_a_cl_np_kernel<R>, NTHR, smem_fwd_a<R>()) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[1], chain_fwd_b_cl_np_kernel<R>, NTHR, smem_fwd_b<R>()) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[2], chain_bwd_b_cl_np_kernel<R>, NTHR, smem_bwd_b<R>()) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&n[3], chain_bwd_a_cl_np_kernel<R>, NTHR, smem_bwd_a<R>()) != hipSuccess)
       return false;
     if (n[0] < 1 || n[1] < 1 || n[2] < 1 || n[3] < 1) return false;
     d->attr = 1;
@@ -1116,11 +1175,21 @@ extern "C" int sdumc_chain_cluster_launch_(const sdumc_chain_args* ap, int which
       if (hipDeviceSynchronize() != hipSuccess) return SDUMC_ELAUNCH;   //  after this)
     }
   }
-  switch (which) {
-    case 0: hipLaunchKernelGGL(chain_fwd_a_cl_kernel<R>, grid, blk, (a.cl_mode & 32) ? (size_t)158 * 1024 : smem_fwd_a<R>(), st, a, ncl); break;   // (bit 5, diagnosis: the whole CU's LDS -> no LDS-using neighbour on the CU)
-    case 1: hipLaunchKernelGGL(chain_fwd_b_cl_kernel<R>, grid, blk, smem_fwd_b<R>(), st, a, ncl); break;
-    case 2: hipLaunchKernelGGL(chain_bwd_b_cl_kernel<R>, grid, blk, smem_bwd_b<R>(), st, a, ncl); break;
-    default: hipLaunchKernelGGL(chain_bwd_a_cl_kernel<R>, grid, blk, smem_bwd_a<R>(), st, a, ncl); break;
+  const size_t smem_a = (a.cl_mode & 32) ? (size_t)158 * 1024 : smem_fwd_a<R>();   // (bit 5, diagnosis: the whole CU's LDS -> no LDS-using neighbour on the CU)
+  if (a.no_packed_fp32) {
+    switch (which) {
+      case 0: hipLaunchKernelGGL(chain_fwd_a_cl_np_kernel<R>, grid, blk, smem_a, st, a, ncl); break;
+      case 1: hipLaunchKernelGGL(chain_fwd_b_cl_np_kernel<R>, grid, blk, smem_fwd_b<R>(), st, a, ncl); break;
+      case 2: hipLaunchKernelGGL(chain_bwd_b_cl_np_kernel<R>, grid, blk, smem_bwd_b<R>(), st, a, ncl); break;
+      default: hipLaunchKernelGGL(chain_bwd_a_cl_np_kernel<R>, grid, blk, smem_bwd_a<R>(), st, a, ncl); break;
+    }
+  } else {
+    switch (which) {
+      case 0: hipLaunchKernelGGL(chain_fwd_a_cl_kernel<R>, grid, blk, smem_a, st, a, ncl); break;
+      case 1: hipLaunchKernelGGL(chain_fwd_b_cl_kernel<R>, grid, blk, smem_fwd_b<R>(), st, a, ncl); break;
+      case 2: hipLaunchKernelGGL(chain_bwd_b_cl_kernel<R>, grid, blk, smem_bwd_b<R>(), st, a, ncl); break;
+      default: hipLaunchKernelGGL(chain_bwd_a_cl_kernel<R>, grid, blk, smem_bwd_a<R>(), st, a, ncl); break;
+    }
   }
   SDUMC_CHECK_LAUNCH();
   d->last = st;

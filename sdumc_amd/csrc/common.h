@@ -48,6 +48,7 @@ struct sdumc_chain_args {
   sdumc_dropout drop;           // template: enabled, threshold / scale of p_mlp, samples, sample0, dev_state (site, rows, width per layer)
   float relu_scale;             // 1 / (1 - p_mlp) in train mode, 1 in eval mode (backward masks)
   int32_t w_bf16;               // 1: the streamed weight matrices (everything below except fc_att / cfa / fcv / rnc*) are bf16 copies
+  int32_t no_packed_fp32;       // 1: take the entry points compiled without packed FP32 VALU ops (bf16 MFMA kernels run beside: chain_common.h)
   // transposed weights (forward) / weights as stored (backward), biases
   const float *umlp0_w[3], *umlp0_b[3], *umlp3_w[3], *umlp3_b[3];
   const float *att0_w, *att0_b, *att3_w, *att3_b, *fc_att_w, *fc_att_b;       // fc_att_w always as stored [3][256]

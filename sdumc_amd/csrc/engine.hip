@@ -1044,6 +1044,7 @@ sdumc_chain_args chain_args(const Ctx& c, bool fwd, const sdumc_net_grads* og, b
   // backward: sdumc_weights_to_bf16_ in forward()); orgin_linear_change stays fp32 (64 columns: too narrow for 8-column lanes)
   const bool wb = c.h() && stage_a && !use_cluster(c);
   a.w_bf16 = wb ? 1 : 0;
+  a.no_packed_fp32 = c.d.bf16 != 0 ? 1 : 0;     // bf16 MFMA kernels run beside the utterance-level stages (chain_common.h)
   auto W = [&](const Lin& L) -> const float* {
     if (wb) return reinterpret_cast<const float*>(c.ph(fwd ? pl.wht : pl.wh, L.w));
     return WB + L.w;

@@ -128,7 +128,10 @@ def test_c4_global_batch_512_on_one_gpu_and_two_simulated_ranks(E):
                                ((p_full - flat) * 1e4).cpu().numpy()[ok.numpy()], rtol=5e-2, atol=5e-2)
 
 
-C5_BF16_GRAD_MAX = 0.2     # worst tensor measured on MI355X: 0.11 (cross_audio_mlp.3.bias)
+# bf16 storage against the fp32 step / fp32 oracle: this only bounds the size of the ROUNDING (bf16 carries 8 mantissa bits and the
+# step rounds x, keys, dz, dxd, dx: a few per cent on most tensors, up to 0.11 on small biases).  It is not the error check: that
+# is tests/test_gpu_fullsize.py, every gradient tensor against an fp64 evaluation that rounds where the engine rounds (4e-3).
+C5_BF16_GRAD_MAX = 0.2
 
 
 def grad_errors(lay, got, ref):
@@ -148,9 +151,10 @@ def grad_errors(lay, got, ref):
 
 
 def _bf16_full_batch_properties(E, dims, B, Tn, seed):
-    """bf16-storage step at a BASELINE batch size (no CPU oracle at this size): size-independent properties -- the eval-mode
-    forward of the batch equals that of its two halves, two runs are bit-identical, every live gradient tensor is finite and
-    non-zero, and the loss terms agree with the fp32 step on the same inputs and masks at the bf16 bar (2e-2)."""
+    """bf16-storage step at a BASELINE batch size: size-independent properties -- the eval-mode forward of the batch equals that
+    of its two halves, two runs are bit-identical, every live gradient tensor is finite and non-zero, and the loss terms agree
+    with the fp32 step on the same inputs and masks at the bf16 bar (2e-2).  (The comparison with the CPU oracle at these sizes,
+    every gradient tensor against an fp64 evaluation with the engine's bf16 rounding points: tests/test_gpu_fullsize.py.)"""
     from oracle import sdumc_oracle as O
     P = O.init_params(dims, seed=0)
     flat, lay = flat_from(E, P, dims)
@@ -174,12 +178,11 @@ def _bf16_full_batch_properties(E, dims, B, Tn, seed):
         losses = ts.run().cpu().clone()
         runs.append((losses, ts.grads.cpu().clone(), p.cpu().clone()))
         del ts
-    # two runs of the same step.  Not asserted bit for bit in this mode: with the clustered utterance-level kernels AND a bf16
-    # key-projection GEMM of the background lane resident beside them, a few samples' stage-A outputs come out an ulp apart
-    # from run to run (open issue; fp32 storage is bit-reproducible -- test_gpu_net.py)
-    np.testing.assert_allclose(runs[0][0].numpy()[:7], runs[1][0].numpy()[:7], rtol=1e-5, atol=1e-7)
-    gs = float(runs[0][1].abs().max())
-    assert float((runs[0][1] - runs[1][1]).abs().max()) < 1e-4 * gs
+    # two runs of the same step: bit for bit (round 4: the run-to-run differences of this mode were wrong low halves of packed FP32
+    # results in the utterance-level kernels when a bf16 MFMA workgroup shared their CU -- those kernels now run without packed
+    # FP32 instructions in the bf16 modes: csrc/chain_common.h)
+    for a, b in zip(runs[0], runs[1]):
+        assert torch.equal(a, b)
     assert torch.isfinite(runs[0][0]).all() and torch.isfinite(runs[0][1]).all()
     np.testing.assert_allclose(runs[0][0].numpy()[:7], runs[2][0].numpy()[:7], rtol=2e-2, atol=1e-4)
     assert not torch.equal(runs[0][1], runs[2][1]), "bf16 mode is not active"
@@ -395,3 +398,35 @@ def test_two_host_threads_with_their_own_contexts_match_the_sequential_run(E):
                 assert torch.equal(a, b)
         for c in ctxs:
             c.close()
+
+
+def test_bf16_forward_is_bit_reproducible_over_200_runs_with_a_busy_neighbour(E):
+    """The run-to-run differences of round 3 (2-20 % of bf16-storage forwards differed from the first in a
+    few rows of the utterance-level stages' outputs, by up to 1e-2 -- wrong low halves of packed FP32 results next to bf16 MFMA
+    workgroups): 200 eval-mode forwards of C3 (B = 64), every one on a freshly allocated workspace, the last 60 with a
+    bandwidth-heavy copy loop on another stream beside them; all five outputs bit-identical to the first run's, and the first
+    run equal to the fp64 evaluation of the first utterance-level layer from the kernel's own inputs is covered by the oracle
+    tests (tests/test_gpu_fullsize.py)."""
+    from oracle import sdumc_oracle as O
+    dims, B, Tn = (1024, 4096, 1024, 4096), 64, (375, 32, 225, 32)
+    P = O.init_params(dims, seed=0)
+    flat, lay = flat_from(E, P, dims)
+    g = torch.Generator(device="cuda").manual_seed(37)
+    audio, text, video, feat4 = [torch.randn(B, Tn[i], dims[i], device="cuda", generator=g) for i in range(4)]
+    side = torch.cuda.Stream()
+    src, dst = torch.empty(32 << 20, device="cuda"), torch.empty(32 << 20, device="cuda")
+    ref, bad = None, 0
+    for rep in range(200):
+        nc = E.NetCall(flat, audio, [text, feat4], video, False, None, bf16=True)
+        torch.cuda.synchronize()
+        if rep >= 140:
+            with torch.cuda.stream(side):
+                for _ in range(4):
+                    dst.copy_(src)
+        out = [t.clone() for t in nc.forward()]
+        torch.cuda.synchronize()
+        if ref is None:
+            ref = out
+        elif not all(torch.equal(a, b) for a, b in zip(ref, out)):
+            bad += 1
+    assert bad == 0, f"{bad} of 199 bf16-storage forwards differed from the first"

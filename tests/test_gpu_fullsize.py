@@ -18,8 +18,13 @@ pytestmark = pytest.mark.gpu
 C2 = ((1024, 4096, 1024, 4096), 64, (375, 32, 225, 32))
 C5 = ((1024, 1024, 1024, 1024), 32, (512, 512, 512, 512))
 # bf16 storage against the fp64 evaluation that rounds where the engine rounds: what is left is fp32 accumulation order, the
-# hardware tanh / exp, and bf16 roundings that flip where the two sides differ in the last fp32 bits
-BF16_EMU_GRAD_TOL = 4e-3      # worst tensor measured on MI355X: 2.02e-3 (cross_fused_query_mlp.0.bias at C3, B = 64); a kernel off by 5 % reads 5e-2
+# hardware tanh / exp, and bf16 roundings that flip where the two sides differ in the last fp32 bits (a few thousand of the 24 M
+# stored frame elements; they show in bias gradients that are sums with heavy cancellation).  Measured on MI355X: median over the
+# gradient tensors 1.6e-5 (C5) / ~1e-5 (C3), worst tensor 2.0e-3 (C3: cross_fused_query_mlp.0.bias) and 4.8e-3 (C5:
+# video_mlp.0.bias).  A kernel off by 5 % moves every tensor downstream of it to 5e-2.
+BF16_EMU_GRAD_TOL = 1e-2          # every tensor
+BF16_EMU_GRAD_P90 = 2e-3          # 90th percentile over the tensors
+BF16_EMU_GRAD_MEDIAN = 5e-4
 BF16_EMU_OUT_TOL = 2e-3
 
 
@@ -104,6 +109,8 @@ def _step_bf16_vs_oracles(E, cfg, pseed, bseed, seed):
           (float(np.median(vals)), worst, errs[worst], max(grad_errors(lay, gv, grads32).values())))
     for k, e in errs.items():
         assert e < BF16_EMU_GRAD_TOL, (k, e)
+    assert vals[int(0.9 * len(vals))] < BF16_EMU_GRAD_P90 and float(np.median(vals)) < BF16_EMU_GRAD_MEDIAN, \
+        (float(np.median(vals)), vals[int(0.9 * len(vals))])
 
 
 def test_c3_bf16_step_at_batch_64_vs_oracles(E):

@@ -207,22 +207,24 @@ def test_graph_replay_equals_eager_and_advances_state(E):
     batch = O.synthetic_batch(B, Tn, dims, seed=3)
     res = []
     from sdumc_amd import _lib
-    _lib.lib.sdumc_set_chain_cluster(0)      # a capture takes chain.hip's kernels: compare like with like
-    _lib.lib.sdumc_set_background_lane(0)    # ... and no early key-projection backward (which decides what rides in which
-                                             # grouped weight-gradient launch, i.e. where their K ranges are cut)
-    for use_graph in (False, True):
-        flat, lay = flat_from(E, P, dims)
-        ts = E.TrainStep(flat, B, Tn, dims, seed=5)
-        ts.set_batch(*[t.cuda() for t in batch])
-        if use_graph:
-            ts.capture()
-        ls = []
-        for _ in range(3):
-            ls.append(ts.run().cpu().clone())
-        torch.cuda.synchronize()
-        res.append((flat.cpu().clone(), ls, ts.rng.call, float(ts.hyper[1])))
-    _lib.lib.sdumc_set_chain_cluster(1)
-    _lib.lib.sdumc_set_background_lane(3)
+    try:
+        _lib.lib.sdumc_set_chain_cluster(0)      # a capture takes chain.hip's kernels: compare like with like
+        _lib.lib.sdumc_set_background_lane(0)    # ... and no early key-projection backward (which decides what rides in which
+                                                 # grouped weight-gradient launch, i.e. where their K ranges are cut)
+        for use_graph in (False, True):
+            flat, lay = flat_from(E, P, dims)
+            ts = E.TrainStep(flat, B, Tn, dims, seed=5)
+            ts.set_batch(*[t.cuda() for t in batch])
+            if use_graph:
+                ts.capture()
+            ls = []
+            for _ in range(3):
+                ls.append(ts.run().cpu().clone())
+            torch.cuda.synchronize()
+            res.append((flat.cpu().clone(), ls, ts.rng.call, float(ts.hyper[1])))
+    finally:                                     # process-wide switches (tests/conftest.py restores them too)
+        _lib.lib.sdumc_set_chain_cluster(1)
+        _lib.lib.sdumc_set_background_lane(3)
     assert torch.equal(res[0][0], res[1][0]), "graph replay must equal eager launches bit for bit"
     for a, b in zip(res[0][1], res[1][1]):
         assert torch.equal(a, b)
@@ -231,8 +233,9 @@ def test_graph_replay_equals_eager_and_advances_state(E):
 
 
 def test_mosei_shape_forward_and_step_vs_oracle(E):
-    """BASELINE config C2 shapes (B reduced to 8 so the CPU oracle finishes in seconds): full T and
-    feature widths, train mode with Philox masks, one complete optimisation step."""
+    """BASELINE config C2 shapes at B = 8 (the plain, un-clustered schedule of a small batch; the stated batch of 64 runs against
+    the oracle in tests/test_gpu_fullsize.py): full T and feature widths, train mode with Philox masks, one complete
+    optimisation step."""
     from oracle import sdumc_oracle as O
     dims = (1024, 4096, 1024, 4096)
     B, Tn = 8, (375, 32, 225, 32)
@@ -369,7 +372,7 @@ def test_c5_global_batch_on_one_gpu_properties(E):
 
 def test_long_sequence_c5_shapes_vs_oracle(E):
     """BASELINE configs[4] shape family: T_t = T_a = T_v = 512 (8 row chunks per sample in the pooling kernels),
-    d = 1024 for every modality; one train step against the oracle (B reduced so the CPU side takes seconds)."""
+    d = 1024 for every modality; one train step against the oracle at B = 4 (the per-GPU slice B = 32: tests/test_gpu_fullsize.py)."""
     from oracle import sdumc_oracle as O
     dims = (1024, 1024, 1024, 1024)
     B, Tn = 4, (512, 512, 512, 512)
@@ -409,7 +412,7 @@ def test_large_batch_rnc_1024_rows(E):
 def test_bf16_operand_mode_c3(E):
     """BASELINE configs[2] (C3: MOSEI shapes, text-missing stream + self-distillation, bf16): the frame-level forward
     projections round their operands to bf16 (fp32 accumulate); SURVEY §8d bar for that mode: activations <= 2e-2 of
-    the fp32 oracle, loss in fp32.  B reduced to 8 so that the CPU oracle finishes in seconds."""
+    the fp32 oracle, loss in fp32.  B = 8 here; the stated batch of 64 against both oracles: tests/test_gpu_fullsize.py."""
     from oracle import sdumc_oracle as O
     dims = (1024, 4096, 1024, 4096)
     B, Tn = 8, (375, 32, 225, 32)
@@ -526,15 +529,17 @@ def test_clustered_utterance_level_kernels_equal_the_plain_ones(E):
     P = O.init_params(dims, seed=4)
     batch = O.synthetic_batch(B, Tn, dims, seed=6)
     res = []
-    for cluster in (0, 1):
-        _lib.lib.sdumc_set_chain_cluster(cluster)
-        flat, lay = flat_from(E, P, dims)
-        ts = E.TrainStep(flat, B, Tn, dims, seed=9)
-        ts.set_batch(*[t.cuda() for t in batch])
-        ls = [ts.run().cpu().clone() for _ in range(3)]
-        torch.cuda.synchronize()
-        res.append((flat.cpu().clone(), ls, ts.grads.cpu().clone()))
-    _lib.lib.sdumc_set_chain_cluster(1)
+    try:
+        for cluster in (0, 1):
+            _lib.lib.sdumc_set_chain_cluster(cluster)
+            flat, lay = flat_from(E, P, dims)
+            ts = E.TrainStep(flat, B, Tn, dims, seed=9)
+            ts.set_batch(*[t.cuda() for t in batch])
+            ls = [ts.run().cpu().clone() for _ in range(3)]
+            torch.cuda.synchronize()
+            res.append((flat.cpu().clone(), ls, ts.grads.cpu().clone()))
+    finally:
+        _lib.lib.sdumc_set_chain_cluster(1)
     assert _lib.lib.sdumc_chain_cluster_error_() == 0
     for a, b in zip(res[0][1], res[1][1]):
         np.testing.assert_allclose(a.numpy(), b.numpy(), rtol=2e-5, atol=1e-6)

@@ -130,6 +130,8 @@ def case(nq, bf16):
 
 
 if __name__ == "__main__":
+    only = os.environ.get("CASES")           # e.g. CASES=7f,1f,7h,1h (nq + f|h)
     for bf16 in (False, True):
         for nq in (7, 1):
-            case(nq, bf16)
+            if only is None or f"{nq}{'h' if bf16 else 'f'}" in only.split(","):
+                case(nq, bf16)

@@ -93,6 +93,9 @@ for rep in range(reps):
         continue
     bad = [k for k in ORDER if k in snap and not torch.equal(snap[k].view(torch.int32), ref[k].view(torch.int32))]
     if bad:
+        upstream = [k for k in bad if k.startswith(("x_", "keys", "attn0", "pooled0", "hpre", "wt"))]
+        if upstream:
+            print(f"rep {rep}: tensors that do NOT depend on stage A differ too: {upstream}")
         nbad += 1
         k = bad[0]
         first_bad[k] = first_bad.get(k, 0) + 1
@@ -123,12 +126,12 @@ print(cfg, "bf16" if bf else "fp32", "train" if train else "eval", f"CL_MODE={os
       f"CLUSTER={os.environ.get('SDUMC_CHAIN_CLUSTER', '1')}", f"NEIGHBOUR={os.environ.get('NEIGHBOUR', '0')}", "fresh workspaces" if fresh else "one workspace",
       f"runs that differ from the first: {nbad} of {reps - 1}; first differing tensor counts: {first_bad}")
 print("cluster error word", _lib.lib.sdumc_chain_cluster_error_())
-if int(os.environ.get("SDUMC_CL_MODE", "0")) & 16:
+if int(os.environ.get("SDUMC_CL_MODE", "0")) & (16 | 64):
     dbg = (C.c_uint32 * 256)()
     _lib.lib.sdumc_chain_cluster_debug_read_(dbg, 256)
-    print("self-check: cached weight loads that differed from agent-scope loads of the same address:", dbg[0])
+    print("self-check records (mode 16: cached weight loads != agent-scope loads; mode 64: LDS copy of hpre != global hpre):", dbg[0])
     import struct
     for i in range(min(dbg[0], 20)):
         r = dbg[8 + 12 * i: 8 + 12 * i + 12]
         f = lambda w: struct.unpack("f", struct.pack("I", w))[0]
-        print(f"   wg {r[0]} tid {r[1]} ring {r[2]} addr..{r[3]:08x}: cached {[round(f(w), 6) for w in r[4:8]]} coherent {[round(f(w), 6) for w in r[8:12]]}")
+        print(f"   wg {r[0]} tid {r[1]} tag {r[2]} addr/idx {r[3]:08x}: first {[round(f(w), 6) for w in r[4:8]]} ({[hex(w) for w in r[4:8]]}) second {[round(f(w), 6) for w in r[8:12]]}")
