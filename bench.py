@@ -374,6 +374,7 @@ def main():
                     help="c2 = BASELINE configs[1], the configuration the metric is quoted on (default); c1 / c5 / c5g = side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-side", action="store_true", help="skip the configs[2] (bf16 storage) side leg of the default line (profiling runs)")
     args = ap.parse_args()
     global B_PER_GPU, T_MOSEI, DIMS, TRAIN_FLOPS_PER_SAMPLE, WORKLOAD_TEXT
     epoch = args.workload == "epoch"
@@ -498,7 +499,7 @@ def main():
     }
     if dp_extra is not None:
         out["data_parallel"] = dp_extra
-    if world == 1 and not force_dp and args.workload == "c2" and not args.bf16 and not args.graph and not args.serial_lanes:
+    if world == 1 and not force_dp and args.workload == "c2" and not args.bf16 and not args.graph and not args.serial_lanes and not args.no_side:
         out["side"] = {"c3_bf16": c3_bf16_side_leg(engine, flat, batch, args)}
     if not args.no_roofline:     # every rank runs it (the DP step has collectives); rank 0 reports
         roof = roofline_leg(_lib, step.launch if (world == 1 and not force_dp) else step.step, max(3, min(10, args.steps)),

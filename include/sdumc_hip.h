@@ -260,6 +260,10 @@ typedef struct sdumc_attnpool {
                           finish combines that sample's softmax partials (forward, counters [0, V)) / sums its dq slabs
                           (backward, counters [V, 2V)) -- instead of in a second launch.  Same arithmetic in the same order.
                           (The engine leaves this NULL: at the MOSEI shapes the second launch measured cheaper, see engine.hip.) */
+  int32_t partial_only; /* forward: 1 = stop after the per-chunk pass: `workspace` then holds the flash-style partials -- unnormalised
+                          pooled rows [V][nchunk][nq][dim], then {chunk max, chunk sum} [V][nchunk][2][8] -- and `attn` the unnormalised
+                          weights; out / pooled are NOT written.  The caller finishes the softmax itself (the engine's clustered
+                          utterance-level stage does, for the FRA2UTT sites: csrc/chain_cluster.hip).  Requires tickets == NULL. */
 } sdumc_attnpool;
 
 size_t sdumc_attnpool_fwd_workspace_bytes(int32_t V, int32_t T, int32_t nq);
@@ -658,6 +662,14 @@ typedef struct sdumc_net_io {
  * through the context is pending. */
 int sdumc_ctx_create(void** ctx);
 int sdumc_ctx_destroy(void* ctx);
+/* Schedule options of ONE execution context (ctx NULL = the current device's default context): nothing process-wide changes, so
+ * two callers -- or two tests -- with their own contexts cannot disturb each other.  value < 0 returns the option to the
+ * process-wide default (the sdumc_set_* calls below, kept for callers without a context).
+ *   SDUMC_OPT_CONCURRENCY      0 = every launch on the caller's stream (per-kernel profiling), 1 = the internal lanes
+ *   SDUMC_OPT_BACKGROUND_LANE  0 / 2 / 3 as sdumc_set_background_lane
+ *   SDUMC_OPT_CHAIN_CLUSTER    0 = csrc/chain.hip's kernels, 1 = the clustered ones wherever the shape fits */
+enum { SDUMC_OPT_CONCURRENCY = 0, SDUMC_OPT_BACKGROUND_LANE = 1, SDUMC_OPT_CHAIN_CLUSTER = 2 };
+int sdumc_ctx_set_option(void* ctx, int32_t option, int32_t value);
 
 /* The network-level calls issue independent branches (the three per-modality chains; the dW GEMMs) on up to
  * two internal side streams forked from / joined to `stream` with events: the call stays stream-ordered

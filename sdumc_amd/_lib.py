@@ -74,7 +74,7 @@ class AttnPool(C.Structure):
                 ("scale", C.c_float), ("x_drop", Dropout), ("out_drop", Dropout),
                 ("attn", C.c_void_p), ("pooled", C.c_void_p), ("out", C.c_void_p),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("dim", C.c_int32),
-                ("lengths", C.c_void_p), ("bf16", C.c_int32), ("tickets", C.c_void_p)]
+                ("lengths", C.c_void_p), ("bf16", C.c_int32), ("tickets", C.c_void_p), ("partial_only", C.c_int32)]
 
 
 class Umca(C.Structure):
@@ -224,6 +224,7 @@ _SIGS = {
     "sdumc_gemm_bf16_run": (C.c_int, [C.POINTER(GemmBf16), C.c_void_p]),
     "sdumc_ctx_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "sdumc_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "sdumc_ctx_set_option": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "sdumc_gather_pad_idx": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
     "sdumc_fill": (C.c_int, [C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),

@@ -612,9 +612,10 @@ __global__ __launch_bounds__(256, 2) void attnpool_bwd_multi_kernel(const MultiB
 // What bounded the kernels above (profiles/r3x: 4.2 TB/s = 0.52 of the HBM peak backward, 4.3 forward): a wave never had more
 // than 8-12 KiB of frame rows in flight (4-row register batches behind a prologue of three dependent round trips), and the
 // grids' last dispatch round was 40-80 % full.  Here
-//   * EVERY global load of a workgroup is issued in its first instructions, smallest first (loads return in order: the prologue's
-//     few dwords must not queue behind the rows): per wave the 16 rows of the MFMA operand tile and the 16 rows of the stream
-//     tile, 32 KiB in flight, held in registers until used (2 waves per SIMD);
+//   * the global loads of a workgroup are issued in its first instructions, smallest first (loads return in order: the prologue's
+//     few dwords must not queue behind the rows): per wave the 16 rows of the MFMA operand tile at once, and the 16 rows of the
+//     stream tile right behind them (bf16 rows) or as soon as the MFMA phase has released the operand tile's registers (fp32
+//     rows: occupancy -- three / four waves per SIMD -- measured worth more than the second 16 KiB in flight);
 //   * the per-row softmax factors reach the row x channel FMAs through v_readlane from the MFMA result layout (SGPR operands:
 //     no LDS round trip, no barrier between the two phases);
 //   * workgroup -> (stream, sample, chunk) is XCD-aware: the two streams' workgroups that read the SAME frame rows x[b, t0..]
@@ -663,8 +664,12 @@ __device__ __forceinline__ void v2_unit(const sdumc_attnpool& p, int local, int 
 }
 
 // ---- backward v2 --------------------------------------------------------------------------------------------------
-template <bool HF, int NQT, int VAR = 0>
+template <bool HF, int NQT>
 __device__ __forceinline__ void attnpool_bwd_v2(const sdumc_attnpool_bwd_t b, float* dq_part, const int nchunk, const int chunk, const int v) {
+  // fp32 rows: the 16 key rows are requested when the MFMA phase has released the frame tile's 64 registers -- 157 instead of 216
+  // VGPRs, three waves per SIMD instead of two (measured, tools/attn_bench.py: 78.6 vs 83.4 us for the three Cross_Attention
+  // sites; early keys at three waves spill: 99 us).  bf16 rows are half as wide: everything up front, three waves either way.
+  constexpr bool LATE_KEYS = !HF;
   constexpr int LDQ = D + 16;
   typedef typename RawRow<HF>::type raw_t;
   __shared__ __attribute__((aligned(16))) float dO_s[MAXQ * LDQ];
@@ -699,10 +704,8 @@ __device__ __forceinline__ void attnpool_bwd_v2(const sdumc_attnpool_bwd_t b, fl
     const int t = tw + 4 * kk + e;
     av[e] = (r16 < NQT && t < T) ? p.attn[((size_t)v * T + t) * NQT + r16] : 0.f;
   }
-  if constexpr (VAR != 3) {
 #pragma unroll
-    for (int i = 0; i < NQT; ++i) qv[i] = ld4(p.q + (size_t)v * p.q_stride + (size_t)i * D + 4 * lane);
-  }
+  for (int i = 0; i < NQT; ++i) qv[i] = ld4(p.q + (size_t)v * p.q_stride + (size_t)i * D + 4 * lane);
   // the wave's 16 frame rows as the MFMA A operand: lane (r16, kk) takes x[row r16][16 j + 4 kk ..], j = 0..15; their keep-bits
   // (64 bytes per row) as four 16-byte loads; then the 16 key rows, lane = 4 channels
   raw_t xa[16], kr[16];
@@ -718,13 +721,9 @@ __device__ __forceinline__ void attnpool_bwd_v2(const sdumc_attnpool_bwd_t b, fl
       for (int j = 0; j < 4; ++j) xb[j] = bp[j];
     }
   }
-  if constexpr (VAR != 1) {
+  if constexpr (!LATE_KEYS) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) kr[r] = ldraw<HF>(p.keys, ((size_t)v * T + min(tw + r, T - 1)) * D + 4 * lane);
-  }
-  if constexpr (VAR == 2) {      // experiment: every other dispatch round starts late, so that co-resident workgroups are in different phases
-    if ((blockIdx.x >> 8) & 1)
-      for (int i = 0; i < 2; ++i) __builtin_amdgcn_s_sleep(127);
   }
   // ---- 2. dO = dout * out_mask -> LDS; delta_i = dO_i . O_i ----------------------------------------------------------
 #pragma unroll
@@ -764,13 +763,9 @@ __device__ __forceinline__ void attnpool_bwd_v2(const sdumc_attnpool_bwd_t b, fl
       for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bq[e], acc, 0, 0, 0);
     }
   }
-  if constexpr (VAR == 1) {      // experiment: the key rows are requested once the frame tile's registers are free (3 waves per SIMD)
+  if constexpr (LATE_KEYS) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) kr[r] = ldraw<HF>(p.keys, ((size_t)v * T + min(tw + r, T - 1)) * D + 4 * lane);
-  }
-  if constexpr (VAR == 3) {      // experiment: the (L2-resident) query rows are requested once the frame tile's registers are free
-#pragma unroll
-    for (int i = 0; i < NQT; ++i) qv[i] = ld4(p.q + (size_t)v * p.q_stride + (size_t)i * D + 4 * lane);
   }
   const float xscale = (!HF && masked) ? xd.scale : 1.f;
   float dSv[4];
@@ -817,14 +812,15 @@ __device__ __forceinline__ void attnpool_bwd_v2(const sdumc_attnpool_bwd_t b, fl
   }
 }
 
+constexpr int bwd_v2_occ(bool, int nq) { return nq == 1 ? 4 : 3; }
 template <bool HF, int NQT>
-__global__ __launch_bounds__(256, 2) void attnpool_bwd_v2_kernel(const sdumc_attnpool_bwd_t b, float* dq_part, const int nchunk) {
+__global__ __launch_bounds__(256, bwd_v2_occ(HF, NQT)) void attnpool_bwd_v2_kernel(const sdumc_attnpool_bwd_t b, float* dq_part, const int nchunk) {
   int v, chunk;
   v2_unit(b.f, blockIdx.x, nchunk, v, chunk);
   attnpool_bwd_v2<HF, NQT>(b, dq_part, nchunk, chunk, v);
 }
-template <bool HF, int NQT, int VAR = 0>
-__global__ __launch_bounds__(256, (VAR == 1 || VAR == 3) ? 3 : 2) void attnpool_bwd_v2_multi_kernel(const MultiBwd m) {
+template <bool HF, int NQT>
+__global__ __launch_bounds__(256, bwd_v2_occ(HF, NQT)) void attnpool_bwd_v2_multi_kernel(const MultiBwd m) {
   const int s = site_of(m.wg_end, blockIdx.x);
   const int local = blockIdx.x - (s ? m.wg_end[s - 1] : 0);
   const int nchunk = m.nchunk[s];
@@ -834,12 +830,15 @@ __global__ __launch_bounds__(256, (VAR == 1 || VAR == 3) ? 3 : 2) void attnpool_
   if (s == 3) b = m.b[3];
   int v, chunk;
   v2_unit(b.f, local, nchunk, v, chunk);
-  attnpool_bwd_v2<HF, NQT, VAR>(b, static_cast<float*>(b.workspace), nchunk, chunk, v);
+  attnpool_bwd_v2<HF, NQT>(b, static_cast<float*>(b.workspace), nchunk, chunk, v);
 }
 
 // ---- forward partial v2 ---------------------------------------------------------------------------------------------
-template <bool HF, int NQT, int VAR = 0>
+template <bool HF, int NQT>
 __device__ __forceinline__ void attn_fwd_partial_v2(const sdumc_attnpool p, float* ws, const int nchunk, const int chunk, const int v) {
+  // fp32 rows: the 16 frame rows are requested when the score MFMAs have released the key tile's registers -- 104 instead of 168
+  // VGPRs, four waves per SIMD instead of three (measured: 41.9 vs 45.0 us for the three Cross_Attention sites)
+  constexpr bool LATE_X = !HF;
   constexpr int LDQ = D + 16;
   typedef typename RawRow<HF>::type raw_t;
   __shared__ __attribute__((aligned(16))) float q_s[MAXQ * LDQ];
@@ -878,7 +877,7 @@ __device__ __forceinline__ void attn_fwd_partial_v2(const sdumc_attnpool p, floa
       xm[r] = (!HF && masked) ? xd.bits[((size_t)v * T + t) * (D / 4) + lane] : 0xfu;
     }
   };
-  if constexpr (VAR != 1) load_x();
+  if constexpr (!LATE_X) load_x();
   // ---- 2. scores of the wave's 16 rows against the queries -----------------------------------------------------------------
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
@@ -895,7 +894,7 @@ __device__ __forceinline__ void attn_fwd_partial_v2(const sdumc_attnpool p, floa
 #pragma unroll
     for (int e = 0; e < 4; ++e) s4 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[e], bq[e], s4, 0, 0, 0);
   }
-  if constexpr (VAR == 1) load_x();      // experiment: the frame rows are requested once the key tile's registers are free (4 waves per SIMD)
+  if constexpr (LATE_X) load_x();
   // C layout: column (query) = lane & 15, rows = 16 wave + 4 (lane >> 4) + e
   float s[4], mx = -INFINITY;
 #pragma unroll
@@ -960,13 +959,13 @@ __device__ __forceinline__ void attn_fwd_partial_v2(const sdumc_attnpool p, floa
 }
 
 template <bool HF, int NQT>
-__global__ __launch_bounds__(256, 2) void attn_fwd_partial_v2_kernel(const sdumc_attnpool p, float* ws, const int nchunk) {
+__global__ __launch_bounds__(256, 4) void attn_fwd_partial_v2_kernel(const sdumc_attnpool p, float* ws, const int nchunk) {
   int v, chunk;
   v2_unit(p, blockIdx.x, nchunk, v, chunk);
   attn_fwd_partial_v2<HF, NQT>(p, ws, nchunk, chunk, v);
 }
-template <bool HF, int NQT, int VAR = 0>
-__global__ __launch_bounds__(256, VAR == 1 ? 4 : 2) void attn_fwd_partial_v2_multi_kernel(const MultiFwd m) {
+template <bool HF, int NQT>
+__global__ __launch_bounds__(256, 4) void attn_fwd_partial_v2_multi_kernel(const MultiFwd m) {
   const int s = site_of(m.wg_end, blockIdx.x);
   const int local = blockIdx.x - (s ? m.wg_end[s - 1] : 0);
   const int nchunk = m.nchunk[s];
@@ -976,7 +975,7 @@ __global__ __launch_bounds__(256, VAR == 1 ? 4 : 2) void attn_fwd_partial_v2_mul
   if (s == 3) p = m.p[3];
   int v, chunk;
   v2_unit(p, local, nchunk, v, chunk);
-  attn_fwd_partial_v2<HF, NQT, VAR>(p, static_cast<float*>(p.workspace), nchunk, chunk, v);
+  attn_fwd_partial_v2<HF, NQT>(p, static_cast<float*>(p.workspace), nchunk, chunk, v);
 }
 
 // the v2 kernels take: 256-channel rows, nq = 1 or 7, keep-bits (or no input mask), the two-pass combine.  SDUMC_ATTN_V2=0 keeps
@@ -1052,6 +1051,7 @@ int check(const sdumc_attnpool& p) {
   if (p.dim != 0 && p.dim != 256 && p.dim != 512 && p.dim != 768 && p.dim != 1024) return SDUMC_EINVAL;
   if (!p.x || !p.keys || !p.q || !p.attn || !p.pooled || !p.out) return SDUMC_EINVAL;
   if ((p.T + CH - 1) / CH > 4096) return SDUMC_EINVAL;
+  if (p.partial_only && p.tickets) return SDUMC_EINVAL;
   return SDUMC_OK;
 }
 
@@ -1090,6 +1090,7 @@ extern "C" int sdumc_attnpool_fwd(const sdumc_attnpool* pp, void* stream) {
       else hipLaunchKernelGGL((attn_fwd_partial_v2_kernel<false, 7>), g1, blk, 0, st, p, static_cast<float*>(p.workspace), nchunk);
     }
     SDUMC_CHECK_LAUNCH();
+    if (p.partial_only) return SDUMC_OK;      // the caller combines the chunks
     hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(p.V), dim3(256), (size_t)nchunk * MAXQ * sizeof(float), st, p,
                        p.workspace, nchunk);
     SDUMC_CHECK_LAUNCH();
@@ -1108,7 +1109,7 @@ extern "C" int sdumc_attnpool_fwd(const sdumc_attnpool* pp, void* stream) {
   }
 #undef FWD_PARTIAL
   SDUMC_CHECK_LAUNCH();
-  if (p.tickets) return SDUMC_OK;          // the combine ran inside the partial kernel
+  if (p.tickets || p.partial_only) return SDUMC_OK;          // the combine ran inside the partial kernel / is the caller's
   hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(p.V), dim3(256), (size_t)nchunk * MAXQ * sizeof(float), st, p,
                      p.workspace, nchunk);
   SDUMC_CHECK_LAUNCH();
@@ -1184,7 +1185,7 @@ extern "C" int sdumc_attnpool_fwd_multi(const sdumc_attnpool* ps, int32_t n, voi
       const sdumc_attnpool& p = ps[i];
       int rc = check(p);
       if (rc) return rc;
-      if (row_dim(p) != D || (p.x_drop.enabled && !p.x_drop.bits) || p.bf16 != ps[0].bf16) return SDUMC_EINVAL;
+      if (row_dim(p) != D || (p.x_drop.enabled && !p.x_drop.bits) || p.bf16 != ps[0].bf16 || p.partial_only) return SDUMC_EINVAL;
       if ((p.tickets != nullptr) != (ps[0].tickets != nullptr)) return SDUMC_EINVAL;
       if (!p.workspace || p.workspace_bytes < sdumc_attnpool_fwd_workspace_bytes_dim(p.V, p.T, p.nq, D)) return SDUMC_ENOMEM;
       m.p[i] = p;
@@ -1204,9 +1205,7 @@ extern "C" int sdumc_attnpool_fwd_multi(const sdumc_attnpool* ps, int32_t n, voi
       if (ps[0].nq == 1) hipLaunchKernelGGL((attn_fwd_partial_v2_multi_kernel<true, 1>), dim3(wg), dim3(256), 0, st, m);
       else hipLaunchKernelGGL((attn_fwd_partial_v2_multi_kernel<true, 7>), dim3(wg), dim3(256), 0, st, m);
     } else {
-      static const int fvar = [] { const char* e = getenv("SDUMC_ATTN_FVAR"); return e ? atoi(e) : 0; }();     // (experiments)
       if (ps[0].nq == 1) hipLaunchKernelGGL((attn_fwd_partial_v2_multi_kernel<false, 1>), dim3(wg), dim3(256), 0, st, m);
-      else if (fvar == 1) hipLaunchKernelGGL((attn_fwd_partial_v2_multi_kernel<false, 7, 1>), dim3(wg), dim3(256), 0, st, m);
       else hipLaunchKernelGGL((attn_fwd_partial_v2_multi_kernel<false, 7>), dim3(wg), dim3(256), 0, st, m);
     }
   } else if (ps[0].bf16) hipLaunchKernelGGL(attn_fwd_partial_multi_kernel<true>, dim3(wg), dim3(256), 0, st, m);
@@ -1250,11 +1249,7 @@ extern "C" int sdumc_attnpool_bwd_multi(const sdumc_attnpool_bwd_t* bs, int32_t 
       if (bs[0].f.nq == 1) hipLaunchKernelGGL((attnpool_bwd_v2_multi_kernel<true, 1>), dim3(wg), dim3(256), 0, st, m);
       else hipLaunchKernelGGL((attnpool_bwd_v2_multi_kernel<true, 7>), dim3(wg), dim3(256), 0, st, m);
     } else {
-      static const int var = [] { const char* e = getenv("SDUMC_ATTN_VAR"); return e ? atoi(e) : 0; }();     // (experiments)
       if (bs[0].f.nq == 1) hipLaunchKernelGGL((attnpool_bwd_v2_multi_kernel<false, 1>), dim3(wg), dim3(256), 0, st, m);
-      else if (var == 1) hipLaunchKernelGGL((attnpool_bwd_v2_multi_kernel<false, 7, 1>), dim3(wg), dim3(256), 0, st, m);
-      else if (var == 2) hipLaunchKernelGGL((attnpool_bwd_v2_multi_kernel<false, 7, 2>), dim3(wg), dim3(256), 0, st, m);
-      else if (var == 3) hipLaunchKernelGGL((attnpool_bwd_v2_multi_kernel<false, 7, 3>), dim3(wg), dim3(256), 0, st, m);
       else hipLaunchKernelGGL((attnpool_bwd_v2_multi_kernel<false, 7>), dim3(wg), dim3(256), 0, st, m);
     }
   } else if (bs[0].f.bf16) hipLaunchKernelGGL(attnpool_bwd_multi_kernel<true>, dim3(wg), dim3(256), 0, st, m);
@@ -1465,6 +1460,7 @@ extern "C" int sdumc_umca_fwd(const sdumc_umca* up, void* stream) {
   if (p.x_drop.enabled) hipLaunchKernelGGL(sdumc_k3::umca_fwd_kernel<true>, grid, blk, sdumc_k3::LDS_BYTES, st, u, nchunk);
   else hipLaunchKernelGGL(sdumc_k3::umca_fwd_kernel<false>, grid, blk, sdumc_k3::LDS_BYTES, st, u, nchunk);
   SDUMC_CHECK_LAUNCH();
+  if (p.partial_only) return SDUMC_OK;
   hipLaunchKernelGGL(attn_fwd_combine_kernel, dim3(p.V), dim3(256), (size_t)nchunk * MAXQ * sizeof(float), st, p,
                      static_cast<const float*>(p.workspace), nchunk);
   SDUMC_CHECK_LAUNCH();

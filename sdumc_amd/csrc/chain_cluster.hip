@@ -216,6 +216,62 @@ __device__ __forceinline__ void cxm_selfcheck(const CRing& ring, const float* M,
   }
 }
 
+// Stage A's input rows from the FRA2UTT sites' softmax partials (sdumc_chain_args.fra_*): what attn_fwd_combine_body (attn_pool.hip)
+// does per sample -- fac_c = exp(max_c - max) / sum_c' l_c' exp(max_c' - max); pooled = sum_c fac_c part_c (ascending c); out =
+// dropout(pooled); weights *= fac -- for this cluster's R samples of the three modalities.  Every member computes the rows (it needs
+// them in LDS; 22 KB of L2-resident partials at C2); the (modality, sample) pairs are dealt round-robin to the members for the
+// writes to HBM (hpre, pooled) and for the in-place normalisation of the stored weights.  Saves the three combine launches that
+// sat between the modality lanes and this stage (31-39 us each inside the step, + the cross-lane event behind them).
+constexpr int FRA_MAXCHUNK = 32;
+template <int R>
+__device__ __forceinline__ void fra_combine(const sdumc_chain_args& a, float* s_hpre, float* s_fac /* [3 R][FRA_MAXCHUNK] */, const int v0,
+                                            const int V, const int member, const DropRT& dbase) {
+  const int tid = threadIdx.x;
+  if (tid < 3 * R) {
+    const int m = tid / R, r = tid - m * R, v = v0 + r;
+    if (v < V) {
+      const int nc = a.fra_nchunk[m];
+      const float* st = a.fra_stats[m] + (size_t)v * nc * 16;
+      float mx = -INFINITY;
+      for (int c = 0; c < nc; ++c) mx = fmaxf(mx, st[c * 16]);
+      float l = 0.f;
+      for (int c = 0; c < nc; ++c) l += st[c * 16 + 8] * expf(st[c * 16] - mx);
+      const float inv = 1.f / l;
+      for (int c = 0; c < nc; ++c) s_fac[tid * FRA_MAXCHUNK + c] = expf(st[c * 16] - mx) * inv;
+    }
+  }
+  __syncthreads();
+  for (int u = tid; u < 3 * R * (D / 4); u += NTHR) {
+    const int mr = u / (D / 4), cq = u - mr * (D / 4);
+    const int m = mr / R, r = mr - m * R, v = v0 + r;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (v < V) {
+      const int nc = a.fra_nchunk[m];
+      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+      for (int c = 0; c < nc; ++c) sum += ld4(a.fra_part[m] + ((size_t)v * nc + c) * D + 4 * cq) * s_fac[mr * FRA_MAXCHUNK + c];
+      o = sum;
+      if (dbase.enabled) {
+        DropRT od = mkdrop_rt(dbase, (uint32_t)a.fra_site[m], 1, D);
+        od.threshold = a.fra_threshold;
+        od.scale = a.fra_scale;
+        o *= drop_mask4(od, (uint32_t)v, (uint32_t)cq);
+      }
+      if ((mr & (CL - 1)) == member) {
+        st4(a.fra_pooled[m] + (size_t)v * D + 4 * cq, sum);
+        st4(a.hpre + ((size_t)m * V + v) * D + 4 * cq, o);
+      }
+    }
+    st4(s_hpre + mr * D + 4 * cq, o);
+  }
+  for (int mr = member; mr < 3 * R; mr += CL) {
+    const int m = mr / R, r = mr - m * R, v = v0 + r;
+    if (v >= V) continue;
+    const int T = a.fra_T[m];
+    float* w = a.fra_attn[m] + (size_t)v * T;
+    for (int t = tid; t < T; t += NTHR) w[t] *= s_fac[mr * FRA_MAXCHUNK + (t >> 6)];
+  }
+}
+
 // diagnosis (cl_mode bit 6): the LDS copy of the stage's input rows against global memory (the inputs are final before the launch)
 template <int ROWS>
 __device__ __forceinline__ void lds_selfcheck(const float* lds_rows, const float* src, int width, int row0, int nrows, uint32_t* dbg, int tag) {
@@ -348,9 +404,10 @@ __device__ __forceinline__ void chain_fwd_a_cl_body(const sdumc_chain_args a, co
     for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(127);
   PF(D, OC, a.umlp0_w[0] + coff, D);
   if (a.cl_mode & 16) cxm_selfcheck<D, OC, 1>(ring, a.umlp0_w[0] + coff, D, a.cl_dbg);
-  for (int m = 0; m < 3; ++m) load_rows<R>(s_hpre + m * R * D, a.hpre + m * VD, D, D, v0, V);
+  if (a.fra_part[0]) fra_combine<R>(a, s_hpre, s_qin, v0, V, member, dbase);      // (s_qin is first written after the layers that read s_hpre's successors)
+  else for (int m = 0; m < 3; ++m) load_rows<R>(s_hpre + m * R * D, a.hpre + m * VD, D, D, v0, V);
   __syncthreads();
-  if (a.cl_mode & 64)
+  if ((a.cl_mode & 64) && !a.fra_part[0])
     for (int m = 0; m < 3; ++m) lds_selfcheck<R>(s_hpre + m * R * D, a.hpre + m * VD, D, v0, V, a.cl_dbg, 10 + m);
   // audio / text / video_mlp (model :293-295)
 #pragma unroll 1
@@ -365,7 +422,7 @@ __device__ __forceinline__ void chain_fwd_a_cl_body(const sdumc_chain_args a, co
                                 [&] { PF(D, OC, (m < 2 ? a.umlp0_w[m + 1] : a.umlp3_w[0]) + coff, D); });
   }
   TR(1);
-  if (a.cl_mode & 64)       // ... and again after the three layers that read it
+  if ((a.cl_mode & 64) && !a.fra_part[0])       // ... and again after the three layers that read it
     for (int m = 0; m < 3; ++m) lds_selfcheck<R>(s_hpre + m * R * D, a.hpre + m * VD, D, v0, V, a.cl_dbg, 20 + m);
   cl_sync(cl, &s_bail);
   TR(2);
@@ -1135,7 +1192,11 @@ bool cluster_prepare(ClusterDev* d) {
 
 extern "C" int sdumc_chain_cluster_ok_(int V) {
   if (g_cluster_on.load() < 0) { const char* e = getenv("SDUMC_CHAIN_CLUSTER"); g_cluster_on.store(e ? (atoi(e) ? 1 : 0) : 1); }
-  if (!g_cluster_on.load() || V <= 0) return 0;
+  if (!g_cluster_on.load()) return 0;
+  return sdumc_chain_cluster_fits_(V);
+}
+extern "C" int sdumc_chain_cluster_fits_(int V) {
+  if (V <= 0) return 0;
   ClusterDev* d = cluster_dev();
   if (!d) return 0;
   const int ncl = (V + 1) / 2;
@@ -1146,7 +1207,7 @@ extern "C" int sdumc_chain_cluster_ok_(int V) {
 // which: 0 = stage A forward, 1 = stage B forward, 2 = stage B backward, 3 = stage A backward; 1 = shape does not qualify
 extern "C" int sdumc_chain_cluster_launch_(const sdumc_chain_args* ap, int which, void* stream) {
   if (!ap || ap->V <= 0 || which < 0 || which > 3) return SDUMC_EINVAL;
-  if (!sdumc_chain_cluster_ok_(ap->V)) return 1;
+  if (!sdumc_chain_cluster_fits_(ap->V)) return 1;      // (whether to take the clustered kernels at all is the caller's decision)
   constexpr int R = 2;
   ClusterDev* d = cluster_dev();
   if (!d) return SDUMC_ELAUNCH;

@@ -64,6 +64,17 @@ struct sdumc_chain_args {
   const float *g_vals, *g_fused, *g_rnc, *g_text_hidden, *g_cross_text;
   float *d_r1, *d_z, *d_beta, *d_e2, *d_e1, *d_h, *d_c, *d_c1, *d_ca_out, *d_alpha;
   float *d_qp, *d_q, *d_qin, *d_u, *d_att2, *d_att1, *d_u1, *d_hpre;
+  // stage A forward of chain_cluster.hip: the FRA2UTT sites' flash-style softmax partials (sdumc_attnpool.partial_only), combined
+  // by the stage's own prologue instead of by one combine launch per modality lane in front of it (fra_part[0] == nullptr: the
+  // stage reads hpre as before).  Layouts: attn_pool.hip fwd_ws with nq = 1, 256 channels.
+  const float* fra_part[3];       // [V][nchunk][256] unnormalised pooled rows
+  const float* fra_stats[3];      // [V][nchunk][2][8]: chunk max, chunk sum (query 0)
+  float* fra_attn[3];             // [V][T] softmax weights, normalised in place
+  float* fra_pooled[3];           // [V][256] pooled rows before the output dropout (the pooling backward reads them)
+  int32_t fra_nchunk[3], fra_T[3];
+  int32_t fra_site[3];            // Philox site of the sites' output dropout (p_frame)
+  uint32_t fra_threshold;
+  float fra_scale;
   // chain_cluster.hip only (filled by sdumc_chain_cluster_launch_): per-cluster arrival / departure counters, error word
   uint32_t* cl_flags;
   int32_t* cl_err;
@@ -86,7 +97,8 @@ int sdumc_chain_launch_(const sdumc_chain_args* a, int which, void* stream);
 // the same four stages with every layer's output columns split over clusters of 4 workgroups (chain_cluster.hip);
 // returns 1 when the shape does not qualify (the caller then takes sdumc_chain_launch_)
 int sdumc_chain_cluster_launch_(const sdumc_chain_args* a, int which, void* stream);
-int sdumc_chain_cluster_ok_(int V);
+int sdumc_chain_cluster_ok_(int V);       // the process-wide switch is on AND the shape fits
+int sdumc_chain_cluster_fits_(int V);     // capability only: every workgroup of the clustered kernels resident at once on this device
 const int32_t* sdumc_chain_cluster_err_ptr_(void);    // device address of the error word (nullptr before the first cluster launch)
 // dst[off ..] = transpose of the n listed [out][in] matrices of src (same offsets in both buffers)
 // fp32 parameters -> bf16 copies as stored (dst) and, where want_t[i], transposed (dst_t); same element offsets as in src

@@ -197,6 +197,7 @@ struct Plan {
   int64_t xd[2][3] = {{0, 0, 0}, {0, 0, 0}};
   int64_t wh = 0, wht = 0;   // [live] bf16 each: weights as stored / transposed (input_proj only), parameter offsets
   int64_t tickets = 0;   // per-sample arrival counters of the attention kernels
+  int64_t fra_ws[3] = {0, 0, 0};   // FRA2UTT softmax partials of modality m, kept until the clustered stage A has combined them (fra_fold)
   int64_t scratch[4] = {0, 0, 0, 0}, scratch_floats = 0;   // one scratch per lane (stream)
   int64_t gg_slab[2] = {0, 0}, gg_slab_floats[2] = {0, 0}; // partial-tile slabs of the grouped dW launches: [0] lane 3, [1] the frame dW
   int64_t alloc(int64_t n) {
@@ -332,6 +333,8 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
   p.dq_fra = p.alloc(3LL * V * D);
   p.lens = p.alloc(3LL * V);
   p.tickets = p.alloc(12LL * V + 16);    // attention sites [2][3] x 2V counters (sdumc_attnpool.tickets), zeroed by forward()
+  for (int m = 0; m < 3; ++m)
+    p.fra_ws[m] = p.alloc((int64_t)(sdumc_attnpool_fwd_workspace_bytes(V, p.segs[m][0].T, 1) / sizeof(float)));
   p.wt = p.alloc(build_params(d.da, d.dt, d.dv).live);   // transposed mirror: utterance-level layers (chain) + the six input_proj
   if (p.hf) {
     const int64_t live = build_params(d.da, d.dt, d.dv).live;
@@ -391,6 +394,9 @@ struct LaneSet {
   std::atomic<unsigned> next{0};
   int device = -1;
   bool ok = false;
+  // per-context schedule options (sdumc_ctx_set_option); -1 = the process-wide default (sdumc_set_concurrency / _background_lane /
+  // _chain_cluster, kept as the defaults of contexts that set nothing)
+  int opt_concurrency = -1, opt_background = -1, opt_chain_cluster = -1;
 };
 // Debug timeline (tools/step_marks.py): sdumc_debug_marks(1) makes the step record an event on the caller's stream at a few
 // fixed points; sdumc_debug_marks_read returns their times since mark 0.  Process-wide, single-threaded use only.
@@ -470,6 +476,7 @@ struct Ctx {
   LaneSet* lanes = nullptr;   // io.ctx (caller-owned) or the device's default set
   bool bg = false;   // the Cross_Attention-site key projections are issued on lane 3 (background)
   bool capturing = false;   // the caller's stream is under hipGraph capture: only the plain three-lane fork/join pattern is used
+  int chain_cluster_opt = -1;   // the context's SDUMC_OPT_CHAIN_CLUSTER (-1: the process-wide switch decides)
   int bgb = 0;       // bit m: the Cross_Attention key-projection BACKWARD of modality m runs early, on lane 3, beside steps 7'-3'
   mutable float* scr = nullptr;   // scratch of the current lane
   bool multi = false;
@@ -487,9 +494,11 @@ struct Ctx {
     static LaneSet none;
     const LaneSet& S = lanes ? *lanes : none;
     sts[0] = st;
-    multi = S.ok && g_concurrency;
-    bg = g_background != 0;               // the launch decomposition is the same with and without real streams
-    bgb = g_background == 3 ? 1 : 0;      // 3: the audio modality's
+    const int background = S.opt_background >= 0 ? S.opt_background : g_background;
+    multi = S.ok && (S.opt_concurrency >= 0 ? S.opt_concurrency != 0 : g_concurrency);
+    bg = background != 0;                 // the launch decomposition is the same with and without real streams
+    bgb = background == 3 ? 1 : 0;        // 3: the audio modality's
+    chain_cluster_opt = S.opt_chain_cluster;
     {   // under hipGraph capture the extra lane-3 dependencies (three lanes -> lane 3 -> lane 0) make hipStreamEndCapture
         // segfault on this stack (ROCm 7.0 runtime inside torch 2.10): captured steps keep the grouped launches
       hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -945,6 +954,8 @@ bool k3_ok(const Ctx& c, int m) {
     if (sg.T < 96) return false;
   return true;
 }
+bool fra_fold(const Ctx& c);                                        // (defined with the chain launch helpers below)
+void fra_partial_only(const Ctx& c, int m, sdumc_attnpool& a);
 int umca_site(const Ctx& c, int k, int m, bool keep) {
   for (const Seg& sg : c.pl.segs[m]) {
     sdumc_umca u;
@@ -954,6 +965,7 @@ int umca_site(const Ctx& c, int k, int m, bool keep) {
     if (!keep) u.a.keys = nullptr;
     u.a.workspace = c.scr;
     u.a.workspace_bytes = (size_t)c.pl.scratch_floats * sizeof(float);
+    if (k == 0 && fra_fold(c)) fra_partial_only(c, m, u.a);
     const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
     u.w_in = c.P + L.w;
     u.b_in = c.P + L.b;
@@ -967,6 +979,7 @@ int pool_fwd(const Ctx& c, int k, int m) {
     sdumc_attnpool a = attn_desc(c, k, m, sg);
     a.workspace = c.scr;
     a.workspace_bytes = (size_t)c.pl.scratch_floats * sizeof(float);
+    if (k == 0 && fra_fold(c)) fra_partial_only(c, m, a);
     RET(sdumc_attnpool_fwd(&a, c.st));
   }
   return SDUMC_OK;
@@ -987,13 +1000,36 @@ bool use_chain(const Ctx& c) {
 
 // chain_cluster.hip instead of chain.hip: every workgroup of the clustered kernels must be resident at once (V <= 128 on
 // MI355X) and their launches wait on a per-device event, which a stream capture cannot contain
-bool use_cluster(const Ctx& c) { return use_chain(c) && !c.capturing && sdumc_chain_cluster_ok_(c.pl.V) == 1; }
+bool use_cluster(const Ctx& c) {
+  if (!use_chain(c) || c.capturing || c.chain_cluster_opt == 0) return false;
+  return c.chain_cluster_opt == 1 ? sdumc_chain_cluster_fits_(c.pl.V) == 1 : sdumc_chain_cluster_ok_(c.pl.V) == 1;
+}
+
+// The clustered stage A combines the FRA2UTT sites' softmax partials in its own prologue (chain_cluster.hip::fra_combine): the
+// pooling launches of the three modality lanes then stop after their per-chunk pass (sdumc_attnpool.partial_only) and the three
+// combine launches -- 31-39 us each inside the step, on every lane's way to this stage -- are gone.  One run per modality (equal
+// text / feat4 lengths), at most 32 chunks per sample; SDUMC_FRA_FOLD=0 keeps the separate combine launches (A/B).
+bool fra_fold(const Ctx& c) {
+  static const int on = [] { const char* e = getenv("SDUMC_FRA_FOLD"); return e ? atoi(e) : 1; }();
+  if (!on || !use_cluster(c)) return false;
+  for (int m = 0; m < 3; ++m)
+    if (c.pl.segs[m].size() != 1 || (c.pl.segs[m][0].T + 63) / 64 > 32) return false;
+  return true;
+}
+// site (0, m)'s descriptor for the partial-only pass
+void fra_partial_only(const Ctx& c, int m, sdumc_attnpool& a) {
+  a.partial_only = 1;
+  a.tickets = nullptr;
+  a.workspace = c.p(c.pl.fra_ws[m]);
+  a.workspace_bytes = sdumc_attnpool_fwd_workspace_bytes(a.V, a.T, 1);
+}
 
 int chain_launch(const Ctx& c, const sdumc_chain_args& ca, int which) {
   if (use_cluster(c)) {
     const int rc = sdumc_chain_cluster_launch_(&ca, which, c.st);
     if (rc != 1) return rc;
   }
+  if (ca.fra_part[0]) return SDUMC_ELAUNCH;      // (the partials are only combined by the clustered stage A)
   return sdumc_chain_launch_(&ca, which, c.st);
 }
 
@@ -1074,6 +1110,21 @@ sdumc_chain_args chain_args(const Ctx& c, bool fwd, const sdumc_net_grads* og, b
   if (fwd) {
     a.o_vals = c.io.vals; a.o_fused = c.io.fused; a.o_rnc = c.io.rnc; a.o_text_hidden = c.io.text_hidden;
     a.o_cross_text = c.io.cross_text;
+  }
+  if (fwd && stage_a && fra_fold(c)) {
+    for (int m = 0; m < 3; ++m) {
+      const Seg& sg = pl.segs[m][0];
+      const int nchunk = (sg.T + 63) / 64;
+      a.fra_part[m] = c.p(pl.fra_ws[m]);
+      a.fra_stats[m] = c.p(pl.fra_ws[m]) + (int64_t)pl.V * nchunk * D;
+      a.fra_attn[m] = c.p(pl.attn[0][m]);
+      a.fra_pooled[m] = c.p(pl.pooled[0][m]);
+      a.fra_nchunk[m] = nchunk;
+      a.fra_T[m] = sg.T;
+      a.fra_site[m] = SITE_OUT[0][m];
+    }
+    a.fra_threshold = (uint32_t)(uint64_t)(c.d.p_frame * 4294967296.0);
+    a.fra_scale = 1.0f / (1.0f - (float)c.d.p_frame);
   }
   if (og) {
     a.g_vals = og->d_vals; a.g_fused = og->d_fused; a.g_rnc = og->d_rnc; a.g_text_hidden = og->d_text_hidden;
@@ -1594,7 +1645,12 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   const bool ca_dw_grouped = ggf && attn_multi_ok(c);
   int ca_dw_mask = 0, fra_dw_mask = 0;
   for (int m = 0; m < 3; ++m) {
-    if (ca_dw_grouped && keys_dw_groupable(c, m) && !(bgb & (1 << m))) ca_dw_mask |= 1 << m;
+    // Only the dX of the early modality's Cross_Attention site runs early (it feeds that modality's mask-sum); its dW rides in the
+    // grouped launch like every other weight gradient.  Round 3 measured the per-layer dW + dX PAIR ahead (1.787 vs 1.816 ms);
+    // with the round-4 pooling kernels and reduce launches the order flipped: fp32 C2 1.690-1.698 vs 1.701-1.706 ms with the pair,
+    // bf16 storage 0.956-0.959 vs 1.019-1.021 (three alternations on one box).  SDUMC_EARLY_DW=1 restores the pair.
+    static const int early_dw = [] { const char* e = getenv("SDUMC_EARLY_DW"); return e ? atoi(e) : 0; }();
+    if (ca_dw_grouped && keys_dw_groupable(c, m) && (!(bgb & (1 << m)) || !early_dw)) ca_dw_mask |= 1 << m;
     if (ggf && keys_dw_groupable(c, m)) fra_dw_mask |= 1 << m;
   }
   // early_done[m]: lane 3 has finished modality m's early key-projection backward (dxd of its Cross_Attention site).  The
@@ -2051,6 +2107,21 @@ extern "C" int sdumc_ctx_destroy(void* ctx) {
   LaneSet* S = static_cast<LaneSet*>(ctx);
   destroy_lanes(*S);
   delete S;
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_ctx_set_option(void* ctx, int32_t option, int32_t value) {
+  LaneSet* S = ctx ? static_cast<LaneSet*>(ctx) : default_lanes();
+  if (!S) return SDUMC_ELAUNCH;
+  switch (option) {
+    case SDUMC_OPT_CONCURRENCY: S->opt_concurrency = value < 0 ? -1 : (value != 0); break;
+    case SDUMC_OPT_BACKGROUND_LANE:
+      if (value > 3) return SDUMC_EINVAL;
+      S->opt_background = value < 0 ? -1 : value;
+      break;
+    case SDUMC_OPT_CHAIN_CLUSTER: S->opt_chain_cluster = value < 0 ? -1 : (value != 0); break;
+    default: return SDUMC_EINVAL;
+  }
   return SDUMC_OK;
 }
 

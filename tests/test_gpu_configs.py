@@ -430,3 +430,48 @@ def test_bf16_forward_is_bit_reproducible_over_200_runs_with_a_busy_neighbour(E)
         elif not all(torch.equal(a, b) for a, b in zip(ref, out)):
             bad += 1
     assert bad == 0, f"{bad} of 199 bf16-storage forwards differed from the first"
+
+
+def test_context_options_select_the_schedule_without_touching_process_wide_state(E):
+    """sdumc_ctx_set_option (no global state in the C ABI): a context with chain_cluster = 0 / concurrency = 0 runs
+    csrc/chain.hip's kernels / one lane -- bit-identical to the same step under the deprecated process-wide setters -- while a step
+    on the default context, before and after, still takes the clustered kernels (its gradients differ in the last bits from the
+    plain kernels': another summation order)."""
+    from oracle import sdumc_oracle as O
+    from sdumc_amd import _lib
+    dims, B, Tn = (64, 32, 64, 32), 7, (40, 6, 20, 6)
+    P = O.init_params(dims, seed=4)
+    batch = [t.cuda() for t in O.synthetic_batch(B, Tn, dims, seed=6)]
+
+    def run(ctx=None):
+        flat, lay = flat_from(E, P, dims)
+        ts = E.TrainStep(flat, B, Tn, dims, seed=9, ctx=ctx)
+        ts.set_batch(*batch)
+        losses = ts.run().clone()
+        torch.cuda.synchronize()
+        return losses, ts.grads.clone(), flat.clone()
+
+    default_before = run()
+    ctx = E.ExecContext()
+    ctx.set_option("chain_cluster", 0)
+    ctx.set_option("concurrency", 0)
+    with_ctx = run(ctx)
+    default_after = run()
+    try:
+        _lib.lib.sdumc_set_chain_cluster(0)
+        _lib.lib.sdumc_set_concurrency(0)
+        with_globals = run()
+    finally:
+        _lib.lib.sdumc_set_chain_cluster(1)
+        _lib.lib.sdumc_set_concurrency(1)
+    for a, b in zip(with_ctx, with_globals):
+        assert torch.equal(a, b)
+    for a, b in zip(default_before, default_after):
+        assert torch.equal(a, b)
+    assert not torch.equal(default_before[1], with_ctx[1])          # (the clustered kernels really ran on the default context)
+    ctx.set_option("chain_cluster", None)
+    ctx.set_option("concurrency", None)
+    back = run(ctx)
+    for a, b in zip(back, default_before):
+        assert torch.equal(a, b)
+    ctx.close()
