@@ -1185,7 +1185,7 @@ extern "C" int sdumc_attnpool_fwd_multi(const sdumc_attnpool* ps, int32_t n, voi
       const sdumc_attnpool& p = ps[i];
       int rc = check(p);
       if (rc) return rc;
-      if (row_dim(p) != D || (p.x_drop.enabled && !p.x_drop.bits) || p.bf16 != ps[0].bf16 || p.partial_only) return SDUMC_EINVAL;
+      if (row_dim(p) != D || (p.x_drop.enabled && !p.x_drop.bits) || p.bf16 != ps[0].bf16 || p.partial_only != ps[0].partial_only) return SDUMC_EINVAL;
       if ((p.tickets != nullptr) != (ps[0].tickets != nullptr)) return SDUMC_EINVAL;
       if (!p.workspace || p.workspace_bytes < sdumc_attnpool_fwd_workspace_bytes_dim(p.V, p.T, p.nq, D)) return SDUMC_ENOMEM;
       m.p[i] = p;
@@ -1211,7 +1211,7 @@ extern "C" int sdumc_attnpool_fwd_multi(const sdumc_attnpool* ps, int32_t n, voi
   } else if (ps[0].bf16) hipLaunchKernelGGL(attn_fwd_partial_multi_kernel<true>, dim3(wg), dim3(256), 0, st, m);
   else hipLaunchKernelGGL(attn_fwd_partial_multi_kernel<false>, dim3(wg), dim3(256), 0, st, m);
   SDUMC_CHECK_LAUNCH();
-  if (ps[0].tickets) return SDUMC_OK;
+  if (ps[0].tickets || ps[0].partial_only) return SDUMC_OK;
   hipLaunchKernelGGL(attn_fwd_combine_multi_kernel, dim3(vs), dim3(256), (size_t)max_chunk * MAXQ * sizeof(float), st, m);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;

@@ -216,59 +216,66 @@ __device__ __forceinline__ void cxm_selfcheck(const CRing& ring, const float* M,
   }
 }
 
-// Stage A's input rows from the FRA2UTT sites' softmax partials (sdumc_chain_args.fra_*): what attn_fwd_combine_body (attn_pool.hip)
-// does per sample -- fac_c = exp(max_c - max) / sum_c' l_c' exp(max_c' - max); pooled = sum_c fac_c part_c (ascending c); out =
-// dropout(pooled); weights *= fac -- for this cluster's R samples of the three modalities.  Every member computes the rows (it needs
-// them in LDS; 22 KB of L2-resident partials at C2); the (modality, sample) pairs are dealt round-robin to the members for the
-// writes to HBM (hpre, pooled) and for the in-place normalisation of the stored weights.  Saves the three combine launches that
-// sat between the modality lanes and this stage (31-39 us each inside the step, + the cross-lane event behind them).
-constexpr int FRA_MAXCHUNK = 32;
-template <int R>
-__device__ __forceinline__ void fra_combine(const sdumc_chain_args& a, float* s_hpre, float* s_fac /* [3 R][FRA_MAXCHUNK] */, const int v0,
-                                            const int V, const int member, const DropRT& dbase) {
+// A forward stage's input rows from the softmax partials of the pooling sites in front of it (sdumc_chain_fold): what
+// attn_fwd_combine_body (attn_pool.hip) does per sample and query -- fac_c = exp(max_c - max) / sum_c' l_c' exp(max_c' - max); pooled =
+// sum_c fac_c part_c (ascending c); out = dropout(pooled); stored weights *= fac -- for this cluster's R samples of the three
+// modalities.  Every member computes the rows (it needs them in LDS; the partials are L2-resident: 22 KB per cluster at the
+// FRA2UTT sites of C2, 154 KB at the Cross_Attention sites); the (modality, sample) pairs are dealt round-robin to the members
+// for the writes to HBM (the stage's input tensor, pooled) and for the in-place normalisation of the stored weights.
+// s_rows: [3][R * NQT][256]; s_fac: scratch [3 R][FOLD_MAXCHUNK][8]; out: [3][V][NQT][256].
+constexpr int FOLD_MAXCHUNK = 32;
+template <int R, int NQT>
+__device__ __forceinline__ void fold_combine(const sdumc_chain_fold& f, float* out, float* s_rows, float* s_fac, const int v0, const int V,
+                                             const int member, const DropRT& dbase) {
   const int tid = threadIdx.x;
-  if (tid < 3 * R) {
-    const int m = tid / R, r = tid - m * R, v = v0 + r;
+  for (int u = tid; u < 3 * R * NQT; u += NTHR) {
+    const int mr = u / NQT, i = u - mr * NQT;
+    const int m = mr / R, v = v0 + (mr - m * R);
     if (v < V) {
-      const int nc = a.fra_nchunk[m];
-      const float* st = a.fra_stats[m] + (size_t)v * nc * 16;
+      const int nc = f.nchunk[m];
+      const float* st = f.stats[m] + (size_t)v * nc * 16 + i;
       float mx = -INFINITY;
       for (int c = 0; c < nc; ++c) mx = fmaxf(mx, st[c * 16]);
       float l = 0.f;
       for (int c = 0; c < nc; ++c) l += st[c * 16 + 8] * expf(st[c * 16] - mx);
       const float inv = 1.f / l;
-      for (int c = 0; c < nc; ++c) s_fac[tid * FRA_MAXCHUNK + c] = expf(st[c * 16] - mx) * inv;
+      for (int c = 0; c < nc; ++c) s_fac[(mr * FOLD_MAXCHUNK + c) * 8 + i] = expf(st[c * 16] - mx) * inv;
     }
   }
   __syncthreads();
-  for (int u = tid; u < 3 * R * (D / 4); u += NTHR) {
-    const int mr = u / (D / 4), cq = u - mr * (D / 4);
-    const int m = mr / R, r = mr - m * R, v = v0 + r;
+  for (int u = tid; u < 3 * R * NQT * (D / 4); u += NTHR) {
+    const int row = u / (D / 4), cq = u - row * (D / 4);         // row = (m R + r) NQT + i
+    const int mr = row / NQT, i = row - mr * NQT;
+    const int m = mr / R, v = v0 + (mr - m * R);
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     if (v < V) {
-      const int nc = a.fra_nchunk[m];
+      const int nc = f.nchunk[m];
       f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-      for (int c = 0; c < nc; ++c) sum += ld4(a.fra_part[m] + ((size_t)v * nc + c) * D + 4 * cq) * s_fac[mr * FRA_MAXCHUNK + c];
+      for (int c = 0; c < nc; ++c)
+        sum += ld4(f.part[m] + (((size_t)v * nc + c) * NQT + i) * D + 4 * cq) * s_fac[(mr * FOLD_MAXCHUNK + c) * 8 + i];
       o = sum;
       if (dbase.enabled) {
-        DropRT od = mkdrop_rt(dbase, (uint32_t)a.fra_site[m], 1, D);
-        od.threshold = a.fra_threshold;
-        od.scale = a.fra_scale;
-        o *= drop_mask4(od, (uint32_t)v, (uint32_t)cq);
+        DropRT od = mkdrop_rt(dbase, (uint32_t)f.site[m], NQT, D);
+        od.threshold = f.threshold;
+        od.scale = f.scale;
+        o *= drop_mask4(od, (uint32_t)(v * NQT + i), (uint32_t)cq);
       }
       if ((mr & (CL - 1)) == member) {
-        st4(a.fra_pooled[m] + (size_t)v * D + 4 * cq, sum);
-        st4(a.hpre + ((size_t)m * V + v) * D + 4 * cq, o);
+        st4(f.pooled[m] + ((size_t)v * NQT + i) * D + 4 * cq, sum);
+        st4(out + (((size_t)m * V + v) * NQT + i) * D + 4 * cq, o);
       }
     }
-    st4(s_hpre + mr * D + 4 * cq, o);
+    st4(s_rows + (size_t)row * D + 4 * cq, o);
   }
   for (int mr = member; mr < 3 * R; mr += CL) {
-    const int m = mr / R, r = mr - m * R, v = v0 + r;
+    const int m = mr / R, v = v0 + (mr - m * R);
     if (v >= V) continue;
-    const int T = a.fra_T[m];
-    float* w = a.fra_attn[m] + (size_t)v * T;
-    for (int t = tid; t < T; t += NTHR) w[t] *= s_fac[mr * FRA_MAXCHUNK + (t >> 6)];
+    const int T = f.T[m];
+    float* w = f.attn[m] + (size_t)v * T * NQT;
+    for (int e = tid; e < T * NQT; e += NTHR) {
+      const int t = e / NQT, i = e - t * NQT;
+      w[e] *= s_fac[(mr * FOLD_MAXCHUNK + (t >> 6)) * 8 + i];
+    }
   }
 }
 
@@ -404,10 +411,11 @@ __device__ __forceinline__ void chain_fwd_a_cl_body(const sdumc_chain_args a, co
     for (int i = 0; i < 8; ++i) __builtin_amdgcn_s_sleep(127);
   PF(D, OC, a.umlp0_w[0] + coff, D);
   if (a.cl_mode & 16) cxm_selfcheck<D, OC, 1>(ring, a.umlp0_w[0] + coff, D, a.cl_dbg);
-  if (a.fra_part[0]) fra_combine<R>(a, s_hpre, s_qin, v0, V, member, dbase);      // (s_qin is first written after the layers that read s_hpre's successors)
+  // the FRA2UTT sites' combine (three launches, 31-39 us each inside the step, on every modality lane's way to this stage) rides here
+  if (a.fra.part[0]) fold_combine<R, 1>(a.fra, a.hpre, s_hpre, s_qin, v0, V, member, dbase);      // (s_qin: free until the fusion algebra)
   else for (int m = 0; m < 3; ++m) load_rows<R>(s_hpre + m * R * D, a.hpre + m * VD, D, D, v0, V);
   __syncthreads();
-  if ((a.cl_mode & 64) && !a.fra_part[0])
+  if ((a.cl_mode & 64) && !a.fra.part[0])
     for (int m = 0; m < 3; ++m) lds_selfcheck<R>(s_hpre + m * R * D, a.hpre + m * VD, D, v0, V, a.cl_dbg, 10 + m);
   // audio / text / video_mlp (model :293-295)
 #pragma unroll 1
@@ -422,7 +430,7 @@ __device__ __forceinline__ void chain_fwd_a_cl_body(const sdumc_chain_args a, co
                                 [&] { PF(D, OC, (m < 2 ? a.umlp0_w[m + 1] : a.umlp3_w[0]) + coff, D); });
   }
   TR(1);
-  if ((a.cl_mode & 64) && !a.fra_part[0])       // ... and again after the three layers that read it
+  if ((a.cl_mode & 64) && !a.fra.part[0])       // ... and again after the three layers that read it
     for (int m = 0; m < 3; ++m) lds_selfcheck<R>(s_hpre + m * R * D, a.hpre + m * VD, D, v0, V, a.cl_dbg, 20 + m);
   cl_sync(cl, &s_bail);
   TR(2);
@@ -578,7 +586,9 @@ __device__ __forceinline__ void chain_fwd_b_cl_body(const sdumc_chain_args a, co
     const int r = u / 3, j = u - 3 * r;
     s_small[r * 4 + j] = v0 + r < V ? a.alpha[(int64_t)(v0 + r) * 3 + j] : 0.f;
   }
-  for (int m = 0; m < 3; ++m) load_rows<NQ * R>(s_x + m * NQ * R * D, a.ca_out + (int64_t)m * VQ * D, D, D, v0 * NQ, V * NQ);
+  // the Cross_Attention sites' combine (one grouped launch between the pooling and this stage) rides here
+  if (a.ca.part[0]) fold_combine<R, NQ>(a.ca, a.ca_out, s_x, s_c, v0, V, member, dbase);      // (s_c: first written by cross_*_mlp.3)
+  else for (int m = 0; m < 3; ++m) load_rows<NQ * R>(s_x + m * NQ * R * D, a.ca_out + (int64_t)m * VQ * D, D, D, v0 * NQ, V * NQ);
   __syncthreads();
   // cross_{audio,text,video}_mlp (model :338-340), rows = (sample, query)
 #pragma unroll 1

@@ -43,6 +43,16 @@ int sdumc_adam_apply_(float* param, const float* grad, float* exp_avg, float* ex
 // chain.hip: the utterance-level network in four launches.  Arguments = device pointers into the flat parameter buffer
 // (backward), its transposed mirror (forward) and the engine's workspace.
 // ---------------------------------------------------------------------------
+struct sdumc_chain_fold {
+  const float* part[3];       // [V][nchunk][nq][256] unnormalised pooled rows
+  const float* stats[3];      // [V][nchunk][2][8]: chunk max, chunk sum per query
+  float* attn[3];             // [V][T][nq] softmax weights, normalised in place
+  float* pooled[3];           // [V][nq][256] pooled rows before the output dropout (the pooling backward reads them)
+  int32_t nchunk[3], T[3];
+  int32_t site[3];            // Philox site of the sites' output dropout
+  uint32_t threshold;         // ... and its keep threshold / scale (p_frame)
+  float scale;
+};
 struct sdumc_chain_args {
   int32_t V, B;                 // virtual samples (streams * B), samples per stream
   sdumc_dropout drop;           // template: enabled, threshold / scale of p_mlp, samples, sample0, dev_state (site, rows, width per layer)
@@ -64,17 +74,11 @@ struct sdumc_chain_args {
   const float *g_vals, *g_fused, *g_rnc, *g_text_hidden, *g_cross_text;
   float *d_r1, *d_z, *d_beta, *d_e2, *d_e1, *d_h, *d_c, *d_c1, *d_ca_out, *d_alpha;
   float *d_qp, *d_q, *d_qin, *d_u, *d_att2, *d_att1, *d_u1, *d_hpre;
-  // stage A forward of chain_cluster.hip: the FRA2UTT sites' flash-style softmax partials (sdumc_attnpool.partial_only), combined
-  // by the stage's own prologue instead of by one combine launch per modality lane in front of it (fra_part[0] == nullptr: the
-  // stage reads hpre as before).  Layouts: attn_pool.hip fwd_ws with nq = 1, 256 channels.
-  const float* fra_part[3];       // [V][nchunk][256] unnormalised pooled rows
-  const float* fra_stats[3];      // [V][nchunk][2][8]: chunk max, chunk sum (query 0)
-  float* fra_attn[3];             // [V][T] softmax weights, normalised in place
-  float* fra_pooled[3];           // [V][256] pooled rows before the output dropout (the pooling backward reads them)
-  int32_t fra_nchunk[3], fra_T[3];
-  int32_t fra_site[3];            // Philox site of the sites' output dropout (p_frame)
-  uint32_t fra_threshold;
-  float fra_scale;
+  // chain_cluster.hip, forward stages: the flash-style softmax partials of the three pooling sites in front of the stage
+  // (sdumc_attnpool.partial_only; layouts: attn_pool.hip fwd_ws, 256 channels), combined by the stage's own prologue instead of by
+  // a combine launch in front of it.  fra: the FRA2UTT sites (nq = 1) -> stage A's input rows hpre; ca: the Cross_Attention sites
+  // (nq = 7) -> stage B's input rows ca_out.  part[0] == nullptr: the stage reads its input rows from HBM as before.
+  sdumc_chain_fold fra, ca;
   // chain_cluster.hip only (filled by sdumc_chain_cluster_launch_): per-cluster arrival / departure counters, error word
   uint32_t* cl_flags;
   int32_t* cl_err;
