@@ -263,7 +263,9 @@ typedef struct sdumc_attnpool {
   int32_t partial_only; /* forward: 1 = stop after the per-chunk pass: `workspace` then holds the flash-style partials -- unnormalised
                           pooled rows [V][nchunk][nq][dim], then {chunk max, chunk sum} [V][nchunk][2][8] -- and `attn` the unnormalised
                           weights; out / pooled are NOT written.  The caller finishes the softmax itself (the engine's clustered
-                          utterance-level stage does, for the FRA2UTT sites: csrc/chain_cluster.hip).  Requires tickets == NULL. */
+                          utterance-level stages do: csrc/chain_cluster.hip).  Requires tickets == NULL.
+                          sdumc_attnpool_bwd_multi with f.partial_only = 1: the per-chunk dq slabs [V][nchunk][nq][256] stay in
+                          `workspace` and dq is NOT written (the caller sums the chunks). */
 } sdumc_attnpool;
 
 size_t sdumc_attnpool_fwd_workspace_bytes(int32_t V, int32_t T, int32_t nq);
@@ -659,7 +661,10 @@ typedef struct sdumc_net_io {
 } sdumc_net_io;
 
 /* Execution contexts (see sdumc_net_io.ctx).  Create / destroy outside stream capture; destroy only when no work issued
- * through the context is pending. */
+ * through the context is pending.  Stream lifetime: the clustered utterance-level launches of a device order themselves behind
+ * the previous such launch with an event recorded on THAT launch's stream -- a caller that destroys the stream it ran its last
+ * step on must have synchronised it first (torch's pooled streams are never destroyed; the library's own lanes are handled by
+ * sdumc_ctx_destroy). */
 int sdumc_ctx_create(void** ctx);
 int sdumc_ctx_destroy(void* ctx);
 /* Schedule options of ONE execution context (ctx NULL = the current device's default context): nothing process-wide changes, so

@@ -1229,7 +1229,7 @@ extern "C" int sdumc_attnpool_bwd_multi(const sdumc_attnpool_bwd_t* bs, int32_t 
       const sdumc_attnpool& p = b.f;
       int rc = check(p);
       if (rc) return rc;
-      if (!b.dout || !b.dz || !b.dxd || !b.dq || !b.workspace || b.dq_sum) return SDUMC_EINVAL;
+      if (!b.dout || !b.dz || !b.dxd || !b.dq || !b.workspace || b.dq_sum || p.partial_only != bs[0].f.partial_only) return SDUMC_EINVAL;
       if (row_dim(p) != D || (p.x_drop.enabled && !p.x_drop.bits) || p.bf16 != bs[0].f.bf16) return SDUMC_EINVAL;
       if ((p.tickets != nullptr) != (bs[0].f.tickets != nullptr)) return SDUMC_EINVAL;
       if (b.workspace_bytes < sdumc_attnpool_bwd_workspace_bytes_dim(p.V, p.T, p.nq, D)) return SDUMC_ENOMEM;
@@ -1255,7 +1255,7 @@ extern "C" int sdumc_attnpool_bwd_multi(const sdumc_attnpool_bwd_t* bs, int32_t 
   } else if (bs[0].f.bf16) hipLaunchKernelGGL(attnpool_bwd_multi_kernel<true>, dim3(wg), dim3(256), 0, st, m);
   else hipLaunchKernelGGL(attnpool_bwd_multi_kernel<false>, dim3(wg), dim3(256), 0, st, m);
   SDUMC_CHECK_LAUNCH();
-  if (bs[0].f.tickets) return SDUMC_OK;
+  if (bs[0].f.tickets || bs[0].f.partial_only) return SDUMC_OK;      // (partial_only: the caller sums the per-chunk dq slabs of `workspace`)
   hipLaunchKernelGGL(dq_reduce_multi_kernel, dim3((unsigned)((dq + 255) / 256)), dim3(256), 0, st, m);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;

@@ -950,7 +950,23 @@ __device__ __forceinline__ void chain_bwd_a_cl_body(const sdumc_chain_args a, co
   load_rows<R>(s_a2, a.att2, D, D, v0, V);
   load_rows<R>(s_a1, a.att1, D, D, v0, V);
   for (int m = 0; m < 3; ++m) load_rows<R>(s_u1 + m * R * D, a.u1 + m * VD, D, D, v0, V);
-  for (int m = 0; m < 3; ++m) load_rows<NQ * R>(s_x + m * NQ * R * D, a.d_qp + (int64_t)m * VQ * D, D, D, v0 * NQ, V * NQ);
+  if (a.dq_part[0]) {      // the pooling backward's dq reduce (a launch between it and this stage) rides here
+    for (int u = tid; u < 3 * R * NQ * (D / 4); u += NTHR) {
+      const int row = u / (D / 4), cq = u - row * (D / 4);           // row = (m R + r) NQ + i
+      const int mr = row / NQ, i = row - mr * NQ;
+      const int m = mr / R, v = v0 + (mr - m * R);
+      f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+      if (v < V) {
+        const int nc = a.dq_nchunk[m];
+        const float* src = a.dq_part[m] + ((size_t)v * nc * NQ + i) * D + 4 * cq;
+        for (int c = 0; c < nc; ++c) sum += ld4(src + (size_t)c * NQ * D);
+        if ((mr & (CL - 1)) == member) st4(a.d_qp + (((size_t)m * V + v) * NQ + i) * D + 4 * cq, sum);
+      }
+      st4(s_x + (size_t)row * D + 4 * cq, sum);
+    }
+  } else {
+    for (int m = 0; m < 3; ++m) load_rows<NQ * R>(s_x + m * NQ * R * D, a.d_qp + (int64_t)m * VQ * D, D, D, v0 * NQ, V * NQ);
+  }
   for (int u = tid; u < R * 3; u += NTHR) {
     const int r = u / 3, j = u - 3 * r;
     s_alpha[r * 4 + j] = v0 + r < V ? a.alpha[(int64_t)(v0 + r) * 3 + j] : 0.f;
@@ -1131,6 +1147,7 @@ struct ClusterDev {
   hipEvent_t done = nullptr;
   hipStream_t last = nullptr;
   bool any = false;
+  bool multi = false;            // more than one stream has launched clustered kernels on this device: record the event eagerly
   int cus = 0;
   int attr = 0;      // 0 = not tried, 1 = the kernels' dynamic-LDS limits are set on this device and every kernel fits a CU, -1 = failed
   int test_hold = 0;
@@ -1240,11 +1257,19 @@ extern "C" int sdumc_chain_cluster_launch_(const sdumc_chain_args* ap, int which
   // submitted to that stream so far.  The event is recorded here, when it is needed, not after every launch: an event record
   // behind a kernel costs the recording stream ~8 us before its next kernel starts (four of them sat on the step's critical
   // path, between the utterance-level stages and the pooling / loss launches that follow them).
+  // Once a SECOND stream has launched clustered kernels on this device (several host threads with their own contexts), every
+  // launch records the event on its own -- live -- stream right away, and a launch of another stream only waits on it: the handle
+  // of a stream that may have been destroyed in the meantime is touched at that first hand-over only (single-stream callers, the
+  // normal case, never record).
   if (d->any && d->last != st) {
-    if (hipEventRecord(d->done, d->last) != hipSuccess || hipStreamWaitEvent(st, d->done, 0) != hipSuccess) {
-      (void)hipGetLastError();                                   // (the other stream is gone: nothing of it can still be running
-      if (hipDeviceSynchronize() != hipSuccess) return SDUMC_ELAUNCH;   //  after this)
+    if (!d->multi) {
+      d->multi = true;
+      if (hipEventRecord(d->done, d->last) != hipSuccess) {
+        (void)hipGetLastError();                                 // (the other stream is gone: nothing of it can still be running
+        if (hipDeviceSynchronize() != hipSuccess) return SDUMC_ELAUNCH;   //  after this)
+      }
     }
+    if (hipStreamWaitEvent(st, d->done, 0) != hipSuccess) return SDUMC_ELAUNCH;
   }
   const size_t smem_a = (a.cl_mode & 32) ? (size_t)158 * 1024 : smem_fwd_a<R>();   // (bit 5, diagnosis: the whole CU's LDS -> no LDS-using neighbour on the CU)
   if (a.no_packed_fp32) {
@@ -1263,8 +1288,25 @@ extern "C" int sdumc_chain_cluster_launch_(const sdumc_chain_args* ap, int which
     }
   }
   SDUMC_CHECK_LAUNCH();
+  if (d->multi && hipEventRecord(d->done, st) != hipSuccess) return SDUMC_ELAUNCH;
   d->last = st;
   d->any = true;
+  return SDUMC_OK;
+}
+
+// A stream that is about to be destroyed (sdumc_ctx_destroy: the context's lanes) must not stay behind as "the stream of the last
+// clustered launch": the next launch would record its ordering event on a dead handle.  Waits for the stream's work and forgets it.
+// (Caller-owned streams: a caller that destroys the stream of its last step must have synchronised it -- include/sdumc_hip.h.)
+extern "C" int sdumc_chain_cluster_forget_stream_(void* stream) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SDUMC_ELAUNCH;
+  ClusterDev& d = g_cl[dev];
+  std::lock_guard<std::mutex> lk(d.mu);
+  if (d.any && d.last == as_stream(stream)) {
+    if (hipStreamSynchronize(d.last) != hipSuccess) return SDUMC_ELAUNCH;
+    d.any = false;
+    d.last = nullptr;
+  }
   return SDUMC_OK;
 }
 

@@ -79,6 +79,11 @@ struct sdumc_chain_args {
   // a combine launch in front of it.  fra: the FRA2UTT sites (nq = 1) -> stage A's input rows hpre; ca: the Cross_Attention sites
   // (nq = 7) -> stage B's input rows ca_out.  part[0] == nullptr: the stage reads its input rows from HBM as before.
   sdumc_chain_fold fra, ca;
+  // stage A backward of chain_cluster.hip: the per-chunk dq slabs of the three Cross_Attention sites' pooling backward
+  // (sdumc_attnpool_bwd_multi with partial_only), summed over the chunks by the stage's prologue (ascending chunk order, as
+  // dq_reduce_multi did) and written to d_qp.  dq_part[0] == nullptr: the stage reads d_qp as before.
+  const float* dq_part[3];      // [V][nchunk][7][256]
+  int32_t dq_nchunk[3];
   // chain_cluster.hip only (filled by sdumc_chain_cluster_launch_): per-cluster arrival / departure counters, error word
   uint32_t* cl_flags;
   int32_t* cl_err;
@@ -103,6 +108,7 @@ int sdumc_chain_launch_(const sdumc_chain_args* a, int which, void* stream);
 int sdumc_chain_cluster_launch_(const sdumc_chain_args* a, int which, void* stream);
 int sdumc_chain_cluster_ok_(int V);       // the process-wide switch is on AND the shape fits
 int sdumc_chain_cluster_fits_(int V);     // capability only: every workgroup of the clustered kernels resident at once on this device
+int sdumc_chain_cluster_forget_stream_(void* stream);    // before a stream is destroyed: it may be the one the next clustered launch orders itself behind
 const int32_t* sdumc_chain_cluster_err_ptr_(void);    // device address of the error word (nullptr before the first cluster launch)
 // dst[off ..] = transpose of the n listed [out][in] matrices of src (same offsets in both buffers)
 // fp32 parameters -> bf16 copies as stored (dst) and, where want_t[i], transposed (dst_t); same element offsets as in src
@@ -110,6 +116,8 @@ int sdumc_weights_to_bf16_(const float* src, void* dst, void* dst_t, const int64
                            const int32_t* want_t, int n, void* stream);
 size_t sdumc_gg_slab_bytes_(int tiles);   // gemm_group.hip: workspace bound for sdumc_gemm_group_tn by output-tile count
 int sdumc_gemm_rows_prepare_(void);       // gemm_rows.hip: the kernels' per-device attributes, set outside any stream capture
+int sdumc_gemm_rows256_capped_(const sdumc_rows_problem* probs, int32_t n, int32_t max_wg, void* stream);   // sdumc_gemm_rows256 on <= max_wg workgroups
+int sdumc_gemm_rows256_bf16_capped_(const sdumc_rows_problem* probs, int32_t n, int32_t max_wg, void* stream);
 int sdumc_chain_transpose_(const float* src, float* dst, const int64_t* offs, const int32_t* outs, const int32_t* ins, int n,
                            void* stream);
 }

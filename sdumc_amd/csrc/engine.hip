@@ -441,8 +441,8 @@ bool create_lanes(LaneSet& S) {
 }
 void destroy_lanes(LaneSet& S) {
   for (int i = 0; i < 2; ++i)
-    if (S.s[i]) (void)hipStreamDestroy(S.s[i]);
-  if (S.bg) (void)hipStreamDestroy(S.bg);
+    if (S.s[i]) { (void)sdumc_chain_cluster_forget_stream_(S.s[i]); (void)hipStreamDestroy(S.s[i]); }
+  if (S.bg) { (void)sdumc_chain_cluster_forget_stream_(S.bg); (void)hipStreamDestroy(S.bg); }
   if (S.ok)
     for (unsigned i = 0; i < LaneSet::NEV; ++i) (void)hipEventDestroy(S.ev[i]);
   S.ok = false;
@@ -478,6 +478,8 @@ struct Ctx {
   bool bg = false;   // the Cross_Attention-site key projections are issued on lane 3 (background)
   bool capturing = false;   // the caller's stream is under hipGraph capture: only the plain three-lane fork/join pattern is used
   int chain_cluster_opt = -1;   // the context's SDUMC_OPT_CHAIN_CLUSTER (-1: the process-wide switch decides)
+  mutable const float* dq_part[3] = {nullptr, nullptr, nullptr};   // backward: the Cross_Attention sites' dq slabs left for stage A (fra_fold)
+  mutable int dq_nchunk[3] = {0, 0, 0};
   int bgb = 0;       // bit m: the Cross_Attention key-projection BACKWARD of modality m runs early, on lane 3, beside steps 7'-3'
   mutable float* scr = nullptr;   // scratch of the current lane
   bool multi = false;
@@ -588,8 +590,10 @@ int run(const Ctx& c, sdumc_gemm& g) {
 
 // y = act(x W^T + b) (+ dropout), single group
 int lin_fwd(const Ctx& c, const Lin& L, const float* x, int lda, int M, float* y, int ldc, int act,
-            const sdumc_dropout* drop, bool bf16 = false) {
+            const sdumc_dropout* drop, bool bf16 = false, int tile = 0, int splitk = 0) {
   sdumc_gemm g = G_(SDUMC_NT, M, L.out, L.in);
+  g.tile = tile;
+  g.splitk = splitk;
   g.bf16 = bf16 && (lda % 4 == 0) && (L.in % 4 == 0) ? 1 : 0;
   g.A[0] = x;
   g.lda = lda;
@@ -671,6 +675,17 @@ bool gg_from_gemm(const sdumc_gemm& g, int grp, sdumc_gg_problem& q) {
   return true;
 }
 
+// one grouped launch; a problem list whose partial-tile slots do not fit the planned slab (the plan sizes it from upper bounds on the
+// layers' output tiles) is issued in halves instead of failing the step
+int gg_launch(const Ctx& c, const sdumc_gg_problem* p, int n, bool hf, int slab) {
+  void* ws = c.p(c.pl.gg_slab[slab]);
+  const size_t bytes = (size_t)c.pl.gg_slab_floats[slab] * sizeof(float);
+  const int rc = hf ? sdumc_gemm_group_tn_bf16(p, n, ws, bytes, c.st) : sdumc_gemm_group_tn(p, n, ws, bytes, c.st);
+  if (rc != SDUMC_ENOMEM || n < 2) return rc;
+  RET(gg_launch(c, p, n / 2, hf, slab));
+  return gg_launch(c, p + n / 2, n - n / 2, hf, slab);
+}
+
 // issues everything queued (c.deferred, c.gg) on `lane`, ordered after what lane `after` has issued so far
 int flush_dw_on(const Ctx& c, int after, int lane, int slab) {
   if (c.deferred.empty() && c.gg.empty() && c.ggh.empty()) return SDUMC_OK;
@@ -694,14 +709,12 @@ int flush_dw_on(const Ctx& c, int after, int lane, int slab) {
   }
   c.deferred.clear();
   if (!c.gg.empty()) {
-    const int rc = sdumc_gemm_group_tn(c.gg.data(), (int)c.gg.size(), c.p(c.pl.gg_slab[slab]),
-                                       (size_t)c.pl.gg_slab_floats[slab] * sizeof(float), c.st);
+    const int rc = gg_launch(c, c.gg.data(), (int)c.gg.size(), false, slab);
     c.gg.clear();
     if (rc != SDUMC_OK) return rc;
   }
   if (!c.ggh.empty()) {      // (same slab: this launch is ordered behind the previous one's reduce)
-    const int rc = sdumc_gemm_group_tn_bf16(c.ggh.data(), (int)c.ggh.size(), c.p(c.pl.gg_slab[slab]),
-                                            (size_t)c.pl.gg_slab_floats[slab] * sizeof(float), c.st);
+    const int rc = gg_launch(c, c.ggh.data(), (int)c.ggh.size(), true, slab);
     c.ggh.clear();
     if (rc != SDUMC_OK) return rc;
   }
@@ -1033,7 +1046,7 @@ int chain_launch(const Ctx& c, const sdumc_chain_args& ca, int which) {
     const int rc = sdumc_chain_cluster_launch_(&ca, which, c.st);
     if (rc != 1) return rc;
   }
-  if (ca.fra.part[0] || ca.ca.part[0]) return SDUMC_ELAUNCH;      // (the partials are only combined by the clustered stages)
+  if (ca.fra.part[0] || ca.ca.part[0] || ca.dq_part[0]) return SDUMC_ELAUNCH;      // (the partials are only combined by the clustered stages)
   return sdumc_chain_launch_(&ca, which, c.st);
 }
 
@@ -1114,6 +1127,9 @@ sdumc_chain_args chain_args(const Ctx& c, bool fwd, const sdumc_net_grads* og, b
   if (fwd) {
     a.o_vals = c.io.vals; a.o_fused = c.io.fused; a.o_rnc = c.io.rnc; a.o_text_hidden = c.io.text_hidden;
     a.o_cross_text = c.io.cross_text;
+  }
+  if (!fwd && stage_a && c.dq_part[0]) {
+    for (int m = 0; m < 3; ++m) { a.dq_part[m] = c.dq_part[m]; a.dq_nchunk[m] = c.dq_nchunk[m]; }
   }
   if (fwd && fra_fold(c)) {      // stage A combines the FRA2UTT sites' partials, stage B the Cross_Attention sites'
     const int k = stage_a ? 0 : 1, nq = stage_a ? 1 : NQ;
@@ -1236,7 +1252,14 @@ int forward(const Ctx& c) {
         RET(run_h(c, g));
         continue;
       }
-      RET(lin_fwd(c, pm.frame[m], in, din[m], B * pl.T[m][s], c.p(pl.x[m][s]), D, SDUMC_ACT_NONE, nullptr, c.d.bf16 != 0));
+      // few-row / long-K projections (the text slot: 2048 x 256 x 4096 per stream at C2) through the wide LDS-DMA kernel with K split
+      // 8 ways over workgroups (512 of them, 32 k-tiles each) instead of the 64x64 register-staged kernel's automatic split:
+      // fp32 C2 step 1.665-1.669 vs 1.671-1.676 ms (split 4: 1.674-1.678, split 2: 1.705-1.710).  SDUMC_TEXT_WIDE=S: A/B, 0 = off
+      static const int text_wide = [] { const char* e = getenv("SDUMC_TEXT_WIDE"); return e ? atoi(e) : 8; }();
+      const int rows_ms = B * pl.T[m][s];
+      const bool wide_split = text_wide > 0 && !c.d.bf16 && rows_ms < 8192 && din[m] >= 2048 && (din[m] % (16 * text_wide)) == 0 && (rows_ms % 64) == 0;
+      RET(lin_fwd(c, pm.frame[m], in, din[m], rows_ms, c.p(pl.x[m][s]), D, SDUMC_ACT_NONE, nullptr, c.d.bf16 != 0,
+                  wide_split ? 14 : 0, wide_split ? text_wide : 0));
     }
     mark(c.st, 28 + 4 * m);      // (debug marks 28..39: this modality's lane, frame-level forward: projection done)
     if (bits_done[m] && hipStreamWaitEvent(c.st, bits_done[m], 0) != hipSuccess) return SDUMC_ELAUNCH;
@@ -1364,9 +1387,11 @@ int forward(const Ctx& c) {
   }   // !chain
   // 8. cross_att_fra2utt_{0,1,2} (model :334-336): one grouped launch on the caller's stream (a fork/join around three 17-30 us
   //    kernels cost 86-91 us between the two utterance-level launches, of which ~35 us were cross-queue event latency)
-  RET(link(c, 3, 0));   // their keys
+  // their keys: lane 3 collects the own-lane projections' events, so that the caller's stream -- the critical chain -- takes ONE
+  // cross-stream wait between stage A and the pooling instead of one per lane
   for (int m = 0; m < 3; ++m)
-    if (ca_done[m] && hipStreamWaitEvent(c.sts[0], ca_done[m], 0) != hipSuccess) return SDUMC_ELAUNCH;
+    if (ca_done[m] && hipStreamWaitEvent(c.sts[3], ca_done[m], 0) != hipSuccess) return SDUMC_ELAUNCH;
+  RET(link(c, 3, 0));
   if (attn_multi_ok(c)) {
     RET(pool_fwd_multi(c, 1));
   } else {
@@ -1466,7 +1491,7 @@ int pool_bwd(const Ctx& c, int k, int m, const float* dout_base /* [V, nq, D] */
 
 // input_proj backward of the sites [k0, k1) of modality m (grouped when both): dW = dz^T drop(x) (+ db), dxd += dz W
 // parts: bit 0 = dW (off every critical path: feeds only the gradient bucket), bit 1 = dX
-int keys_gemm_bwd_h(const Ctx& c, int m, int k0, int k1, int parts) {
+int keys_gemm_bwd_h(const Ctx& c, int m, int k0, int k1, int parts, int rows_cap = 0) {
   const Plan& pl = c.pl;
   if (parts & 1) {
     bool first = true;
@@ -1510,7 +1535,7 @@ int keys_gemm_bwd_h(const Ctx& c, int m, int k0, int k1, int parts) {
       r.lda = r.ldb = r.ldc = D;
       r.accumulate = 1;
     }
-    const int rc = sdumc_gemm_rows256_bf16(q, k1 - k0, c.st);
+    const int rc = sdumc_gemm_rows256_bf16_capped_(q, k1 - k0, rows_cap > 0 ? rows_cap : 0, c.st);
     if (rc != SDUMC_EINVAL) return rc;
   }
   return run_h(c, g);
@@ -1576,8 +1601,9 @@ int keys_dx_rows(const Ctx& c, int m, int k0, int k1, sdumc_rows_problem* q) {
   return n;
 }
 
-int keys_gemm_bwd(const Ctx& c, int m, int k0, int k1, int parts = 3) {
-  if (c.h()) return keys_gemm_bwd_h(c, m, k0, k1, parts);
+// rows_cap (fp32 dX through the persistent rows launch): > 0 = at most that many workgroups, < 0 = the tiled 64x64 kernel instead
+int keys_gemm_bwd(const Ctx& c, int m, int k0, int k1, int parts = 3, int rows_cap = 0) {
+  if (c.h()) return keys_gemm_bwd_h(c, m, k0, k1, parts, 0);      // (bf16 storage: the cap measured 0.957-0.966 vs 0.951-0.959 ms: every CU)
   const Plan& pl = c.pl;
   // dW: one grouped GEMM per run (runs differ in their x buffer), later runs accumulate
   bool first = true;
@@ -1604,11 +1630,11 @@ int keys_gemm_bwd(const Ctx& c, int m, int k0, int k1, int parts = 3) {
   }
   if (!(parts & 2)) return SDUMC_OK;
   // dxd += dz W (the key-projection path joins the pooling path)
-  if (parts == 2 && rows_on() && rows_ok(c)) {   // (the early dW + dX pair keeps the small-footprint kernels: it runs beside
+  if (parts == 2 && rows_cap >= 0 && rows_on() && rows_ok(c)) {   // (the early dW + dX pair keeps the small-footprint kernels: it runs beside
                                                          //  the co-resident utterance-level stage, which a persistent launch would stall)
     sdumc_rows_problem q[2];
     const int n = keys_dx_rows(c, m, k0, k1, q);
-    const int rc = sdumc_gemm_rows256(q, n, c.st);
+    const int rc = sdumc_gemm_rows256_capped_(q, n, rows_cap, c.st);
     if (rc != SDUMC_EINVAL) return rc;      // (a shape the rows launch refuses -- 2 GiB of rows -- takes the tiled kernel below)
   }
   sdumc_gemm g = G_(SDUMC_NN, (int)pl.rows[m], D, D, k1 - k0);
@@ -1675,7 +1701,13 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
       const int lane = (own_lane & (1 << m)) ? LANE_OF[m] : 3;
       RET(link(c, 0, lane));
       c.use(lane);
-      RET(keys_gemm_bwd(c, m, 1, 2, (ca_dw_mask & (1 << m)) ? 2 : 3));
+      // The early dX runs as the persistent rows launch on HALF of the CUs: a full-chip launch holds every CU's register file, so
+      // the FRA2UTT pooling backward of the three modality lanes -- the next link of the critical chain, HBM-bound, issued while
+      // this launch is still running -- crawled beside it (86-104 us instead of ~60); the early dX itself has slack until its
+      // modality's mask-sum.  Measured, fp32 C2, three alternations on one box: 128 workgroups 1.670-1.680 ms, 64: 1.675-1.679,
+      // 256 (every CU): 1.686-1.689, the tiled 64x64 kernel: 1.689-1.695.  (SDUMC_EARLY_DX: N workgroups, 0 = every CU, -1 = tiled)
+      static const int early_dx = [] { const char* e = getenv("SDUMC_EARLY_DX"); return e ? atoi(e) : 128; }();
+      RET(keys_gemm_bwd(c, m, 1, 2, (ca_dw_mask & (1 << m)) ? 2 : 3, early_dx));
       if (lane == 3) RET(record_early(m));
       c.use(0);
     }
@@ -1762,6 +1794,11 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
         const size_t bytes = sdumc_attnpool_bwd_workspace_bytes(sg.V, sg.T, NQ);
         b.workspace = ws;
         b.workspace_bytes = bytes;
+        if (fra_fold(c)) {      // the clustered stage 7'-3' right behind this launch sums the chunks (this lane's scratch is untouched in between)
+          b.f.partial_only = 1;
+          c.dq_part[m] = ws;
+          c.dq_nchunk[m] = (sg.T + 63) / 64;
+        }
         ws += (bytes / sizeof(float) + 63) / 64 * 64;
       }
     }

@@ -69,10 +69,8 @@ namespace sdumc_bf16 {
 __device__ __forceinline__ int swz(int row) { return (row >> 1) & 7; }
 
 template <class CF, bool CS>
-__global__ __launch_bounds__(CF::NTHR, CF::OCC) void gemm_bf16_kernel(const sdumc_gemm_bf16 g, const int nsplit_flags, const int kchunk) {
+__global__ __launch_bounds__(CF::NTHR, CF::OCC) void gemm_bf16_kernel(const sdumc_gemm_bf16 g, const int nsplit, const int kchunk) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  const int nsplit = nsplit_flags & 0xffff;
-  const bool direct_epilogue = (nsplit_flags & 0x10000) != 0;      // diagnosis (SDUMC_BF16_EPI=0): bf16 output without the LDS turn
   constexpr int BM = CF::BM, BN = CF::BN, BK = CF::BK, NST = CF::NST, NW = CF::NW, TM = CF::TM, TN = CF::TN, NKS = CF::NKS;
   constexpr bool KC = CF::KC;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -249,7 +247,7 @@ __global__ __launch_bounds__(CF::NTHR, CF::OCC) void gemm_bf16_kernel(const sdum
   float* Cf = to_slab ? g.workspace + ((size_t)grp * nsplit + ks_) * (size_t)g.M * g.N : static_cast<float*>(g.C[grp]);
   unsigned short* Ch = static_cast<unsigned short*>(g.C[grp]);
   const int ldc = to_slab ? g.N : g.ldc;
-  if (cbf && !direct_epilogue && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(Ch) & 15) == 0) {
+  if (cbf && (ldc & 7) == 0 && (reinterpret_cast<uintptr_t>(Ch) & 15) == 0) {
     // bf16 output: a lane owns one COLUMN of the accumulator tile, i.e. 2-byte stores 64 bytes apart per instruction.  Turn the
     // tile through LDS (32 rows at a time, the k-loop's ring is free by now) so that a lane stores 8 consecutive columns = 16 bytes.
     constexpr int LDT = CF::WN + 4;                         // floats per transposed row (keeps the b128 reads 16-byte aligned)
@@ -395,14 +393,7 @@ inline Plan plan(const sdumc_gemm_bf16& g, size_t have) {
 template <class CF>
 int launch(const sdumc_gemm_bf16& g, const Plan& p, bool cs, hipStream_t st) {
   const dim3 grid((g.N + CF::BN - 1) / CF::BN, (g.M + CF::BM - 1) / CF::BM, g.groups * p.nsplit);
-  // (SDUMC_BF16_LDS_PAD, diagnosis: request extra LDS so that the kernel cannot share a CU with another LDS-heavy workgroup)
-  static const size_t pad_all = [] { const char* e = getenv("SDUMC_BF16_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
-  static const int pad_cfg = [] { const char* e = getenv("SDUMC_BF16_LDS_PAD_CFG"); return e ? atoi(e) : 7; }();     // 1 NT128, 2 NT64, 4 TN
-  static const int epi = [] { const char* e = getenv("SDUMC_BF16_EPI"); return e ? atoi(e) : 1; }();
-  const int my_cfg = !CF::KC ? 4 : (CF::BM == 128 ? 1 : 2);
-  const size_t pad = (pad_cfg & my_cfg) ? pad_all : 0;
-  const size_t shm = CF::LDS_BYTES + pad;
-  const int nsplit_flags = p.nsplit | (epi ? 0 : 0x10000);
+  const size_t shm = CF::LDS_BYTES;
 #define SDUMC_H_LAUNCH(CSV)                                                                                                  \
   do {                                                                                                                       \
     static bool attr_set = false;                                                                                            \
@@ -412,7 +403,7 @@ int launch(const sdumc_gemm_bf16& g, const Plan& p, bool cs, hipStream_t st) {
         return SDUMC_ELAUNCH;                                                                                                \
       attr_set = true;                                                                                                       \
     }                                                                                                                        \
-    hipLaunchKernelGGL((gemm_bf16_kernel<CF, CSV>), grid, dim3(CF::NTHR), shm, st, g, nsplit_flags, p.kchunk);                \
+    hipLaunchKernelGGL((gemm_bf16_kernel<CF, CSV>), grid, dim3(CF::NTHR), shm, st, g, p.nsplit, p.kchunk);                   \
   } while (0)
   if (cs) SDUMC_H_LAUNCH(true);
   else SDUMC_H_LAUNCH(false);

@@ -517,6 +517,10 @@ extern "C" void sdumc_prof_end_(int token, void* stream);
 extern "C" int sdumc_gemm_rows_prepare_(void) { return set_lds_attr() ? SDUMC_OK : SDUMC_ELAUNCH; }
 
 extern "C" int sdumc_gemm_rows256(const sdumc_rows_problem* probs, int32_t n, void* stream) {
+  return sdumc_gemm_rows256_capped_(probs, n, 0, stream);
+}
+// max_wg > 0: at most that many (persistent) workgroups -- a launch that should leave part of the chip to a neighbour
+extern "C" int sdumc_gemm_rows256_capped_(const sdumc_rows_problem* probs, int32_t n, int32_t max_wg, void* stream) {
   if (!probs || n <= 0 || n > MAXP) return SDUMC_EINVAL;
   const bool mask = probs[0].a_bits != nullptr, accum = probs[0].accumulate != 0;
   if (mask && accum) return SDUMC_EINVAL;
@@ -535,6 +539,7 @@ extern "C" int sdumc_gemm_rows256(const sdumc_rows_problem* probs, int32_t n, vo
   L.unit0[n] = units;
   L.n = n;
   L.nwg = std::min(cu_count(), units);
+  if (max_wg > 0) L.nwg = std::min(L.nwg, (int)max_wg);
   if ((long long)units * (L.nwg + 1) >= (1LL << 31)) return SDUMC_EINVAL;
   if (!set_lds_attr()) return SDUMC_ELAUNCH;
   hipStream_t st = as_stream(stream);
@@ -550,6 +555,9 @@ extern "C" int sdumc_gemm_rows256(const sdumc_rows_problem* probs, int32_t n, vo
 // A ([M][256]), B ([256 n][256 k], row stride ldb: C = A B^T) and C are bf16 tensors (lda / ldb / ldc in elements, lda a multiple
 // of 8, A 16-byte aligned); bias fp32; no fused dropout (a_bits must be NULL: the engine materialises the masked frames)
 extern "C" int sdumc_gemm_rows256_bf16(const sdumc_rows_problem* probs, int32_t n, void* stream) {
+  return sdumc_gemm_rows256_bf16_capped_(probs, n, 0, stream);
+}
+extern "C" int sdumc_gemm_rows256_bf16_capped_(const sdumc_rows_problem* probs, int32_t n, int32_t max_wg, void* stream) {
   if (!probs || n <= 0 || n > MAXP) return SDUMC_EINVAL;
   const bool accum = probs[0].accumulate != 0;
   Launch L;
@@ -574,6 +582,7 @@ extern "C" int sdumc_gemm_rows256_bf16(const sdumc_rows_problem* probs, int32_t 
   L.unit0[n] = units;
   L.n = n;
   L.nwg = std::min(cu_count(), units);      // (a workgroup works through pairs of tiles; with fewer tiles than CUs a pair is one tile and nothing)
+  if (max_wg > 0) L.nwg = std::min(L.nwg, (int)max_wg);
   if ((long long)units * (L.nwg + 1) >= (1LL << 31)) return SDUMC_EINVAL;
   if (!set_lds_attr()) return SDUMC_ELAUNCH;
   hipStream_t st = as_stream(stream);
