@@ -185,6 +185,11 @@ int sdumc_gemm_group_tn(const sdumc_gg_problem* probs, int32_t n, void* workspac
  * the masked frames), products accumulate in fp32 on v_mfma_f32_32x32x16_bf16, C / colsum_a / the slabs are fp32. */
 size_t sdumc_gemm_group_bf16_workspace_bytes(const sdumc_gg_problem* probs, int32_t n);
 int sdumc_gemm_group_tn_bf16(const sdumc_gg_problem* probs, int32_t n, void* workspace, size_t workspace_bytes, void* stream);
+/* Measurement / test hook for the fp32 launch (sdumc_gemm_group_tn): 1 (default; environment SDUMC_GG_SPLIT) computes every
+ * fp32 product on the bf16 matrix pipe from operands split exactly into three bf16 parts each (six v_mfma_f32_32x32x16_bf16 per
+ * 32 x 32 x 16 block, fp32 accumulation: products exact, error per product < 2^-23 |a b|, the size of one fp32 rounding); 0 uses
+ * v_mfma_f32_32x32x2_f32.  Process-wide.  gemm_group.hip, "fp32 products on the bf16 pipe". */
+void sdumc_gg_set_split_(int on);
 
 /* ------------------------------------------------------------------------
  * The tall 256 x 256 products of the frame-level part in one persistent launch (gemm_rows.hip):
