@@ -190,6 +190,9 @@ int sdumc_gemm_group_tn_bf16(const sdumc_gg_problem* probs, int32_t n, void* wor
  * 32 x 32 x 16 block, fp32 accumulation: products exact, error per product < 2^-23 |a b|, the size of one fp32 rounding); 0 uses
  * v_mfma_f32_32x32x2_f32.  Process-wide.  gemm_group.hip, "fp32 products on the bf16 pipe". */
 void sdumc_gg_set_split_(int on);
+/* The same switch for the NT launches of the wide-tile kernel (gemm_wide.hip: frame projections, key projections;
+ * environment SDUMC_WIDE_SPLIT, default 1). */
+void sdumc_gemm_wide_set_split_(int on);
 
 /* ------------------------------------------------------------------------
  * The tall 256 x 256 products of the frame-level part in one persistent launch (gemm_rows.hip):

@@ -19,6 +19,7 @@
 // Every fusion gemm_f32.hip offers on these shapes is kept; anything else (ragged K, unaligned operands, epilogue dropout,
 // strided batches, bf16) stays on gemm_f32.hip -- sdumc_gemm_wide_ returns 1 ("not mine") and the caller falls through.
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <type_traits>
 
@@ -66,13 +67,15 @@ __device__ __forceinline__ int swz(int row) {
   return (row >> SH) & (CPR - 1);
 }
 
-template <class CF, bool MASK, bool CS>
-__global__ __launch_bounds__(CF::NTHR, CF::OCC) void gemm_wide_kernel(const sdumc_gemm g, const int nsplit,
-                                                                                  const int kchunk) {
+// SPLIT (NT configurations): every fp32 product on the bf16 matrix pipe from operands split exactly into three bf16 parts -- six
+// v_mfma_f32_32x32x16_bf16 per 32 x 32 x 16 block instead of eight v_mfma_f32_32x32x2_f32, at the fp32 kernel's accuracy
+// (gemm_group.hip, "fp32 products on the bf16 pipe", has the arithmetic).
+template <class CF, bool MASK, bool CS, bool SPLIT>
+__device__ __forceinline__ void gemm_wide_body(const sdumc_gemm& g, const int nsplit, const int kchunk, char* lds) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the host pass only needs the launch stub: the body uses gfx950-only types (__amdgpu_buffer_rsrc_t)
   constexpr int BM = CF::BM, BN = CF::BN, BK = CF::BK, NST = CF::NST, NW = CF::NW, TM = CF::TM, TN = CF::TN;
   constexpr bool A_KC = CF::A_KC, B_KC = CF::B_KC;
-  extern __shared__ __attribute__((aligned(16))) char lds[];
+  static_assert(!SPLIT || (A_KC && B_KC && BK == 16 && !CS), "the split form is written for the NT configurations");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
@@ -305,6 +308,54 @@ __global__ __launch_bounds__(CF::NTHR, CF::OCC) void gemm_wide_kernel(const sdum
     }
   };
 
+  // the k-tile (16 k) as ONE bf16 MFMA depth: a lane's eight k of an operand are its two fp32 fragments side by side
+  // (k = 4 lh + s and 8 + 4 lh + s), the same assignment for A and B
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2s __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  auto pk = [](float x, float y) -> uint32_t {       // v_cvt_pk_bf16_f32 (round to nearest even), low half = x
+    const f32x2s v = {x, y};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+  };
+  auto split8 = [&](const f32x4 lo, const f32x4 hi, u32x4* pl) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const float x = d < 2 ? lo[2 * d] : hi[2 * d - 4], y = d < 2 ? lo[2 * d + 1] : hi[2 * d - 3];
+      const uint32_t p0 = pk(x, y);
+      const float x1 = x - __uint_as_float(p0 << 16), y1 = y - __uint_as_float(p0 & 0xFFFF0000u);       // exact
+      const uint32_t p1 = pk(x1, y1);
+      const float x2 = x1 - __uint_as_float(p1 << 16), y2 = y1 - __uint_as_float(p1 & 0xFFFF0000u);     // exact
+      pl[0][d] = p0;
+      pl[1][d] = p1;
+      pl[2][d] = pk(x2, y2);
+    }
+  };
+  auto compute_split = [&](const char* base) {
+    f32x4 af[2][TM], bf[2][TN];
+    read_a(base, 0, af[0]);
+    read_a(base, 1, af[1]);
+    read_b(base, 0, bf[0]);
+    read_b(base, 1, bf[1]);
+    u32x4 pa[TM][3], pb[TN][3];
+    auto op = [](const u32x4& v) { return __builtin_bit_cast(bf16x8, v); };
+#pragma unroll
+    for (int j = 0; j < TN; ++j) split8(bf[0][j], bf[1][j], pb[j]);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      split8(af[0][i], af[1][i], pa[i]);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {   // smallest terms first
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(pa[i][2]), op(pb[j][0]), acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(pa[i][0]), op(pb[j][2]), acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(pa[i][1]), op(pb[j][1]), acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(pa[i][1]), op(pb[j][0]), acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(pa[i][0]), op(pb[j][1]), acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(pa[i][0]), op(pb[j][0]), acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
   // ---- the ring: stage t lives in buffer t % NST; NST - 1 stages are in flight ahead of the one being multiplied ----
 #pragma unroll
   for (int s = 0; s < NST - 1; ++s)
@@ -316,7 +367,8 @@ __global__ __launch_bounds__(CF::NTHR, CF::OCC) void gemm_wide_kernel(const sdum
     __builtin_amdgcn_s_barrier();
     if (t + NST - 1 < nk) issue(ibuf);
     const int k0 = kbeg + t * BK;
-    if ((!A_KC || !B_KC) && k0 + BK > kend) compute(lds + buf * CF::STAGE_BYTES, k0, std::true_type{});
+    if constexpr (SPLIT) compute_split(lds + buf * CF::STAGE_BYTES);
+    else if ((!A_KC || !B_KC) && k0 + BK > kend) compute(lds + buf * CF::STAGE_BYTES, k0, std::true_type{});
     else compute(lds + buf * CF::STAGE_BYTES, k0, std::false_type{});
     buf = buf + 1 == NST ? 0 : buf + 1;
     ibuf = ibuf + 1 == NST ? 0 : ibuf + 1;
@@ -369,6 +421,34 @@ __global__ __launch_bounds__(CF::NTHR, CF::OCC) void gemm_wide_kernel(const sdum
     }
 #endif
 }
+template <class CF, bool MASK, bool CS>
+__global__ __launch_bounds__(CF::NTHR, CF::OCC) void gemm_wide_kernel(const sdumc_gemm g, const int nsplit, const int kchunk) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  gemm_wide_body<CF, MASK, CS, false>(g, nsplit, kchunk, lds);
+}
+// (no packed fp32 VALU operations beside bf16 MFMAs: gemm_group.hip has the reasons)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define WIDE_NO_PACKED_FP32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define WIDE_NO_PACKED_FP32
+#endif
+template <class CF, bool MASK>
+__global__ __launch_bounds__(CF::NTHR, CF::OCC) WIDE_NO_PACKED_FP32 void gemm_wide_split_kernel(const sdumc_gemm g, const int nsplit, const int kchunk) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  gemm_wide_body<CF, MASK, false, true>(g, nsplit, kchunk, lds);
+}
+
+std::atomic<int> g_split{-1};
+// NT launches: products as six bf16 MFMAs on split operands (SDUMC_WIDE_SPLIT, sdumc_gemm_wide_set_split_)
+bool split_products() {
+  int v = g_split.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("SDUMC_WIDE_SPLIT");
+    v = e ? (atoi(e) != 0) : 1;
+    g_split.store(v, std::memory_order_relaxed);
+  }
+  return v != 0;
+}
 
 // (A persistent NT variant -- a workgroup walking a range of output tiles with the LDS ring running on across tile boundaries,
 //  DMA issue interleaved between the MFMAs, staggered starts -- was built and measured in round 2: within +-2 % of this
@@ -389,14 +469,31 @@ int launch_cfg(const sdumc_gemm& g, int nsplit, int kchunk, bool mask, bool cs, 
     }                                                                                                                        \
     hipLaunchKernelGGL((gemm_wide_kernel<CF, MK, CSV>), grid, blk, shm, st, g, nsplit, kchunk);                              \
   } while (0)
+#define SDUMC_WIDE_LAUNCH_SPLIT(MK)                                                                                           \
+  do {                                                                                                                       \
+    static bool attr_set = false;                                                                                            \
+    if (!attr_set) {                                                                                                         \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wide_split_kernel<CF, MK>),                               \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)                         \
+        return SDUMC_ELAUNCH;                                                                                                \
+      attr_set = true;                                                                                                       \
+    }                                                                                                                        \
+    hipLaunchKernelGGL((gemm_wide_split_kernel<CF, MK>), grid, blk, shm, st, g, nsplit, kchunk);                             \
+  } while (0)
   if constexpr (CF::A_KC) {       // NT: optional mask on A
-    if (mask) SDUMC_WIDE_LAUNCH(true, false);
-    else SDUMC_WIDE_LAUNCH(false, false);
+    if (split_products()) {
+      if (mask) SDUMC_WIDE_LAUNCH_SPLIT(true);
+      else SDUMC_WIDE_LAUNCH_SPLIT(false);
+    } else {
+      if (mask) SDUMC_WIDE_LAUNCH(true, false);
+      else SDUMC_WIDE_LAUNCH(false, false);
+    }
   } else {                        // TN: optional mask on B, optional column sums of A
     if (mask) { if (cs) SDUMC_WIDE_LAUNCH(true, true); else SDUMC_WIDE_LAUNCH(true, false); }
     else { if (cs) SDUMC_WIDE_LAUNCH(false, true); else SDUMC_WIDE_LAUNCH(false, false); }
   }
 #undef SDUMC_WIDE_LAUNCH
+#undef SDUMC_WIDE_LAUNCH_SPLIT
   return SDUMC_OK;
 }
 
@@ -473,3 +570,4 @@ extern "C" int sdumc_gemm_wide_(const sdumc_gemm* gp, int cfg, int nsplit, int k
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
 }
+extern "C" void sdumc_gemm_wide_set_split_(int on) { g_split.store(on ? 1 : 0, std::memory_order_relaxed); }
