@@ -185,14 +185,17 @@ int sdumc_gemm_group_tn(const sdumc_gg_problem* probs, int32_t n, void* workspac
  * the masked frames), products accumulate in fp32 on v_mfma_f32_32x32x16_bf16, C / colsum_a / the slabs are fp32. */
 size_t sdumc_gemm_group_bf16_workspace_bytes(const sdumc_gg_problem* probs, int32_t n);
 int sdumc_gemm_group_tn_bf16(const sdumc_gg_problem* probs, int32_t n, void* workspace, size_t workspace_bytes, void* stream);
-/* Measurement / test hook for the fp32 launch (sdumc_gemm_group_tn): 1 (default; environment SDUMC_GG_SPLIT) computes every
- * fp32 product on the bf16 matrix pipe from operands split exactly into three bf16 parts each (six v_mfma_f32_32x32x16_bf16 per
- * 32 x 32 x 16 block, fp32 accumulation: products exact, error per product < 2^-23 |a b|, the size of one fp32 rounding); 0 uses
- * v_mfma_f32_32x32x2_f32.  Process-wide.  gemm_group.hip, "fp32 products on the bf16 pipe". */
-void sdumc_gg_set_split_(int on);
-/* The same switch for the NT launches of the wide-tile kernel (gemm_wide.hip: frame projections, key projections;
- * environment SDUMC_WIDE_SPLIT, default 1). */
-void sdumc_gemm_wide_set_split_(int on);
+/* fp32 products on the bf16 matrix pipe.  v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 MFMA rate; an fp32 value is the exact
+ * sum of three bf16 values, so the fp32 GEMM kernels below split both operands in registers (round to nearest, exact residuals)
+ * and accumulate the six largest of the nine bf16 x bf16 products -- each exact in fp32 -- with six v_mfma_f32_32x32x16_bf16 per
+ * 32 x 32 x 16 block instead of eight fp32 MFMAs.  The three dropped products are below 2^-23 |a b| together, the size of ONE fp32
+ * rounding: measured against fp64 the results are as close as the fp32-MFMA kernels' (tools/gg_split_check.py,
+ * tools/wide_split_check.py; tests/test_gpu_split.py).  Inputs, outputs and accumulators stay fp32.
+ * Measurement / test hook, process-wide: bit 0 the grouped weight-gradient launch (sdumc_gemm_group_tn), bit 1 the wide-tile NT
+ * launches of the GEMM entry point (frame / key projections), bit 2 the key projection inside sdumc_umca_fwd, bit 3
+ * sdumc_gemm_rows256.
+ * Default all (environment SDUMC_SPLIT); 0 = every product on the fp32 MFMAs. */
+void sdumc_set_split_(int mask);
 
 /* ------------------------------------------------------------------------
  * The tall 256 x 256 products of the frame-level part in one persistent launch (gemm_rows.hip):

@@ -1292,10 +1292,11 @@ static_assert(4 * MAXQ * D * 4 <= TOP_BYTES, "the pooling reduce overlays the ke
 __device__ __forceinline__ int swz16(int row) { return (row >> 2) & 3; }   // gemm_wide.hip swz<16>
 __device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }   // = gemm_wide.hip
 
-template <bool MASK>
-__global__ __launch_bounds__(256, 2) void umca_fwd_kernel(const sdumc_umca u, const int nchunk) {
+// SPLIT: the key projection's fp32 products on the bf16 matrix pipe from exactly split operands (gemm_group.hip, "fp32 products
+// on the bf16 pipe", has the arithmetic; sdumc_hip.h: sdumc_set_split_).
+template <bool MASK, bool SPLIT>
+__device__ __forceinline__ void umca_fwd_body(const sdumc_umca& u, const int nchunk, char* lds) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  extern __shared__ __attribute__((aligned(16))) char lds[];
   const sdumc_attnpool& p = u.a;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1394,6 +1395,53 @@ __global__ __launch_bounds__(256, 2) void umca_fwd_kernel(const sdumc_umca u, co
     }
   };
 
+  // the k-tile (16 k) as ONE bf16 MFMA depth: a lane's eight k of an operand are its two fp32 fragments side by side
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2s __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  auto pk = [](float x, float y) -> uint32_t {       // v_cvt_pk_bf16_f32 (round to nearest even), low half = x
+    const f32x2s v = {x, y};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+  };
+  auto split8 = [&](const f32x4 lo, const f32x4 hi, u32x4* pl) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const float x = d < 2 ? lo[2 * d] : hi[2 * d - 4], y = d < 2 ? lo[2 * d + 1] : hi[2 * d - 3];
+      const uint32_t p0 = pk(x, y);
+      const float x1 = x - __uint_as_float(p0 << 16), y1 = y - __uint_as_float(p0 & 0xFFFF0000u);       // exact
+      const uint32_t p1 = pk(x1, y1);
+      const float x2 = x1 - __uint_as_float(p1 << 16), y2 = y1 - __uint_as_float(p1 & 0xFFFF0000u);     // exact
+      pl[0][d] = p0;
+      pl[1][d] = p1;
+      pl[2][d] = pk(x2, y2);
+    }
+  };
+  auto compute_split = [&](const char* base) {
+    f32x4 af[2][2], bf[2][2];
+    read_a(base, 0, af[0]);
+    read_a(base, 1, af[1]);
+    read_b(base, 0, bf[0]);
+    read_b(base, 1, bf[1]);
+    u32x4 pa[2][3], pb[2][3];
+    auto op = [](const u32x4& v) { return __builtin_bit_cast(bf16x8, v); };
+#pragma unroll
+    for (int j = 0; j < 2; ++j) split8(bf[0][j], bf[1][j], pb[j]);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      split8(af[0][i], af[1][i], pa[i]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {   // smallest terms first
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(pa[i][2]), op(pb[j][0]), acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(pa[i][0]), op(pb[j][2]), acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(pa[i][1]), op(pb[j][1]), acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(pa[i][1]), op(pb[j][0]), acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(pa[i][0]), op(pb[j][1]), acc[i][j], 0, 0, 0);
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(pa[i][0]), op(pb[j][0]), acc[i][j], 0, 0, 0);
+      }
+    }
+  };
+
   // ---- key projection: 16 k-tiles through the ring ----
   constexpr int nk = D / BK;
 #pragma unroll
@@ -1404,7 +1452,8 @@ __global__ __launch_bounds__(256, 2) void umca_fwd_kernel(const sdumc_umca u, co
     else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
     __builtin_amdgcn_s_barrier();
     if (t + NST - 1 < nk) issue(ibuf);
-    compute(lds + buf * STAGE_BYTES);
+    if constexpr (SPLIT) compute_split(lds + buf * STAGE_BYTES);
+    else compute(lds + buf * STAGE_BYTES);
     buf = buf + 1 == NST ? 0 : buf + 1;
     ibuf = ibuf + 1 == NST ? 0 : ibuf + 1;
   }
@@ -1432,6 +1481,22 @@ __global__ __launch_bounds__(256, 2) void umca_fwd_kernel(const sdumc_umca u, co
   attn_fwd_partial_body<false, 1, false, true>(p, static_cast<float*>(p.workspace), nchunk, chunk, v, K_s, q_s, K_s);
 #endif
 }
+template <bool MASK>
+__global__ __launch_bounds__(256, 2) void umca_fwd_kernel(const sdumc_umca u, const int nchunk) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  umca_fwd_body<MASK, false>(u, nchunk, lds);
+}
+// (no packed fp32 VALU operations beside bf16 MFMAs: gemm_group.hip has the reasons)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define K3_NO_PACKED_FP32 __attribute__((target("no-packed-fp32-ops")))
+#else
+#define K3_NO_PACKED_FP32
+#endif
+template <bool MASK>
+__global__ __launch_bounds__(256, 2) K3_NO_PACKED_FP32 void umca_fwd_split_kernel(const sdumc_umca u, const int nchunk) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  umca_fwd_body<MASK, true>(u, nchunk, lds);
+}
 
 }  // namespace sdumc_k3
 
@@ -1450,6 +1515,10 @@ extern "C" int sdumc_umca_fwd(const sdumc_umca* up, void* stream) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sdumc_k3::umca_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             sdumc_k3::LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&sdumc_k3::umca_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            sdumc_k3::LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&sdumc_k3::umca_fwd_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            sdumc_k3::LDS_BYTES) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void*>(&sdumc_k3::umca_fwd_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             sdumc_k3::LDS_BYTES) != hipSuccess)
       return SDUMC_ELAUNCH;
     attr = true;
@@ -1457,7 +1526,10 @@ extern "C" int sdumc_umca_fwd(const sdumc_umca* up, void* stream) {
   hipStream_t st = as_stream(stream);
   const int nchunk = (p.T + CH - 1) / CH;
   const dim3 grid(nchunk, p.V), blk(256);
-  if (p.x_drop.enabled) hipLaunchKernelGGL(sdumc_k3::umca_fwd_kernel<true>, grid, blk, sdumc_k3::LDS_BYTES, st, u, nchunk);
+  if (sdumc_split_on_(SDUMC_SPLIT_UMCA)) {
+    if (p.x_drop.enabled) hipLaunchKernelGGL(sdumc_k3::umca_fwd_split_kernel<true>, grid, blk, sdumc_k3::LDS_BYTES, st, u, nchunk);
+    else hipLaunchKernelGGL(sdumc_k3::umca_fwd_split_kernel<false>, grid, blk, sdumc_k3::LDS_BYTES, st, u, nchunk);
+  } else if (p.x_drop.enabled) hipLaunchKernelGGL(sdumc_k3::umca_fwd_kernel<true>, grid, blk, sdumc_k3::LDS_BYTES, st, u, nchunk);
   else hipLaunchKernelGGL(sdumc_k3::umca_fwd_kernel<false>, grid, blk, sdumc_k3::LDS_BYTES, st, u, nchunk);
   SDUMC_CHECK_LAUNCH();
   if (p.partial_only) return SDUMC_OK;

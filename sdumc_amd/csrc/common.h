@@ -116,6 +116,14 @@ int sdumc_weights_to_bf16_(const float* src, void* dst, void* dst_t, const int64
                            const int32_t* want_t, int n, void* stream);
 size_t sdumc_gg_slab_bytes_(int tiles);   // gemm_group.hip: workspace bound for sdumc_gemm_group_tn by output-tile count
 int sdumc_gemm_rows_prepare_(void);       // gemm_rows.hip: the kernels' per-device attributes, set outside any stream capture
+// fp32 GEMM kernels whose products run on the bf16 matrix pipe from exactly split operands (gemm_group.hip has the arithmetic):
+// sdumc_split_on_(bit) is the process-wide switch the launchers ask (sdumc_hip.h: sdumc_set_split_)
+#define SDUMC_SPLIT_GROUP 1   /* gemm_group.hip: the grouped weight-gradient launch */
+#define SDUMC_SPLIT_WIDE 2    /* gemm_wide.hip: NT launches (frame projections, key projections) */
+#define SDUMC_SPLIT_UMCA 4    /* attn_pool.hip: the fused key projection of sdumc_umca_fwd */
+#define SDUMC_SPLIT_ROWS 8    /* gemm_rows.hip */
+#define SDUMC_SPLIT_ALL 15
+int sdumc_split_on_(int bit);
 int sdumc_gemm_rows256_capped_(const sdumc_rows_problem* probs, int32_t n, int32_t max_wg, void* stream);   // sdumc_gemm_rows256 on <= max_wg workgroups
 int sdumc_gemm_rows256_bf16_capped_(const sdumc_rows_problem* probs, int32_t n, int32_t max_wg, void* stream);
 int sdumc_chain_transpose_(const float* src, float* dst, const int64_t* offs, const int32_t* outs, const int32_t* ins, int n,

@@ -1097,7 +1097,10 @@ sdumc_chain_args chain_args(const Ctx& c, bool fwd, const sdumc_net_grads* og, b
   // backward: sdumc_weights_to_bf16_ in forward()); orgin_linear_change stays fp32 (64 columns: too narrow for 8-column lanes)
   const bool wb = c.h() && stage_a && !use_cluster(c);
   a.w_bf16 = wb ? 1 : 0;
-  a.no_packed_fp32 = c.d.bf16 != 0 ? 1 : 0;     // bf16 MFMA kernels run beside the utterance-level stages (chain_common.h)
+  // bf16 MFMA kernels run beside the utterance-level stages (chain_common.h): in the bf16 modes always, in fp32 when the GEMM
+  // kernels compute their products on the bf16 matrix pipe (sdumc_set_split_).  SDUMC_NO_PACKED=0/1 overrides (diagnosis).
+  static const int np_env = [] { const char* e = getenv("SDUMC_NO_PACKED"); return e ? atoi(e) : -1; }();
+  a.no_packed_fp32 = np_env >= 0 ? np_env : ((c.d.bf16 != 0 || sdumc_split_on_(SDUMC_SPLIT_ALL)) ? 1 : 0);
   auto W = [&](const Lin& L) -> const float* {
     if (wb) return reinterpret_cast<const float*>(c.ph(fwd ? pl.wht : pl.wh, L.w));
     return WB + L.w;

@@ -914,17 +914,7 @@ extern "C" int sdumc_prof_begin_(int variant, double flops, void* stream);     /
 extern "C" void sdumc_prof_end_(int token, void* stream);
 
 namespace {
-std::atomic<int> g_split{-1};
-// fp32 launches: products as six bf16 MFMAs on split operands (SDUMC_GG_SPLIT, sdumc_gg_set_split_)
-bool split_products() {
-  int v = g_split.load(std::memory_order_relaxed);
-  if (v < 0) {
-    const char* e = getenv("SDUMC_GG_SPLIT");
-    v = e ? (atoi(e) != 0) : 1;
-    g_split.store(v, std::memory_order_relaxed);
-  }
-  return v != 0;
-}
+bool split_products() { return sdumc_split_on_(SDUMC_SPLIT_GROUP) != 0; }
 size_t gg_workspace_bytes(const sdumc_gg_problem* probs, int32_t n, bool hf) {
   if (!probs || n <= 0) return 0;
   const int nwg = cu_count();
@@ -978,4 +968,17 @@ extern "C" size_t sdumc_gemm_group_bf16_workspace_bytes(const sdumc_gg_problem* 
 extern "C" int sdumc_gemm_group_tn_bf16(const sdumc_gg_problem* probs, int32_t n, void* workspace, size_t workspace_bytes, void* stream) {
   return gg_run(probs, n, workspace, workspace_bytes, true, stream);
 }
-extern "C" void sdumc_gg_set_split_(int on) { g_split.store(on ? 1 : 0, std::memory_order_relaxed); }
+// ---- which fp32 GEMM kernels compute their products on the bf16 matrix pipe (SDUMC_SPLIT_* bits; environment SDUMC_SPLIT) ----
+namespace {
+std::atomic<int> g_split_mask{-1};
+}
+extern "C" int sdumc_split_on_(int bit) {
+  int v = g_split_mask.load(std::memory_order_relaxed);
+  if (v < 0) {
+    const char* e = getenv("SDUMC_SPLIT");
+    v = e ? (atoi(e) & SDUMC_SPLIT_ALL) : SDUMC_SPLIT_ALL;
+    g_split_mask.store(v, std::memory_order_relaxed);
+  }
+  return (v & bit) != 0;
+}
+extern "C" void sdumc_set_split_(int mask) { g_split_mask.store(mask & SDUMC_SPLIT_ALL, std::memory_order_relaxed); }

@@ -438,17 +438,7 @@ __global__ __launch_bounds__(CF::NTHR, CF::OCC) WIDE_NO_PACKED_FP32 void gemm_wi
   gemm_wide_body<CF, MASK, false, true>(g, nsplit, kchunk, lds);
 }
 
-std::atomic<int> g_split{-1};
-// NT launches: products as six bf16 MFMAs on split operands (SDUMC_WIDE_SPLIT, sdumc_gemm_wide_set_split_)
-bool split_products() {
-  int v = g_split.load(std::memory_order_relaxed);
-  if (v < 0) {
-    const char* e = getenv("SDUMC_WIDE_SPLIT");
-    v = e ? (atoi(e) != 0) : 1;
-    g_split.store(v, std::memory_order_relaxed);
-  }
-  return v != 0;
-}
+bool split_products() { return sdumc_split_on_(SDUMC_SPLIT_WIDE) != 0; }
 
 // (A persistent NT variant -- a workgroup walking a range of output tiles with the LDS ring running on across tile boundaries,
 //  DMA issue interleaved between the MFMAs, staggered starts -- was built and measured in round 2: within +-2 % of this
@@ -570,4 +560,3 @@ extern "C" int sdumc_gemm_wide_(const sdumc_gemm* gp, int cfg, int nsplit, int k
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
 }
-extern "C" void sdumc_gemm_wide_set_split_(int on) { g_split.store(on ? 1 : 0, std::memory_order_relaxed); }

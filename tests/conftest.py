@@ -25,7 +25,7 @@ def golden():
 
 @pytest.fixture(autouse=True)
 def _restore_library_switches():
-    """The C ABI's process-wide schedule switches (sdumc_set_concurrency / _background_lane / _chain_cluster) are restored to
+    """The C ABI's process-wide schedule switches (sdumc_set_concurrency / _background_lane / _chain_cluster / sdumc_set_split_) are restored to
     their defaults after EVERY test, so that a test that flips one and then fails cannot change the schedule the rest of the
     session runs (tests still restore them themselves in try/finally; this is the backstop)."""
     yield
@@ -37,3 +37,5 @@ def _restore_library_switches():
     lib.sdumc_set_background_lane(3)
     e = os.environ.get("SDUMC_CHAIN_CLUSTER")
     lib.sdumc_set_chain_cluster(int(e) if e else 1)
+    e = os.environ.get("SDUMC_SPLIT")
+    lib.sdumc_set_split_(int(e) if e else 15)

@@ -34,7 +34,7 @@ def case(name, M, N, K, tile, tanh=False, drop=False, row_mod=0, splitk=0):
     C = torch.empty(M, N, device=dev)
     res = {}
     for split in (0, 1, 0, 1):
-        _lib.lib.sdumc_gemm_wide_set_split_(split)
+        _lib.lib.sdumc_set_split_(15 if split else 0)
         run = lambda: ops.gemm(ops.NT, A, B, M, N, K, bias=bias, C_out=C, tile=tile, splitk=splitk, **kw)
         run()
         torch.cuda.synchronize()
@@ -45,9 +45,15 @@ def case(name, M, N, K, tile, tanh=False, drop=False, row_mod=0, splitk=0):
         t = min(r[0] for r in res[split])
         print(f"{name:28s} M={M:6d} K={K:5d} tile {tile} {'split bf16 x6' if split else 'fp32 MFMA    '} {t:7.1f} us = {fl / t / 1e6:6.1f} TF   "
               f"max |C - fp64| / max |C| {res[split][0][1]:.2e}", flush=True)
-    _lib.lib.sdumc_gemm_wide_set_split_(1)
+    _lib.lib.sdumc_set_split_(15)
 
 
+for t in (11, 12, 13):
+    case("frame proj audio", 24000, 256, 1024, t)
+    case("frame proj video", 14400, 256, 1024, t)
+case("keys video (CA site)", 28800, 256, 256, 14, tanh=True, drop=True, row_mod=14400)
+case("keys audio (CA site)", 48000, 256, 256, 14, tanh=True, drop=True, row_mod=24000)
+case("keys audio (CA site)", 48000, 256, 256, 12, tanh=True, drop=True, row_mod=24000)
 case("frame proj audio", 24000, 256, 1024, 14)
 case("frame proj video", 14400, 256, 1024, 14)
 case("frame proj text (split-K 8)", 4096, 256, 4096, 14, splitk=8)
