@@ -278,6 +278,286 @@ __global__ __launch_bounds__(NTHR, 2) void gr_kernel(const Launch L) {
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// The fp32 launch with its products on the bf16 matrix pipe (sdumc_hip.h: sdumc_set_split_; the arithmetic -- every fp32 operand
+// the exact sum of three bf16 parts, the six largest of the nine part products accumulated in fp32 -- is described in
+// gemm_group.hip).  What changes against gr_kernel:
+//   * A is split ONCE per workgroup, not once per wave: after the barrier that publishes raw stage s + 1 every lane converts one
+//     16-byte chunk of it (4 k of one row; the keep-bits are applied here) into three bf16 planes in LDS ([64 rows][32 k] bf16
+//     per plane and stage, double-buffered, 16-byte chunks XOR-swizzled by row / 4); the MFMA operands of stage s + 1 are then
+//     one ds_read_b128 per plane -- the VALU work per wave and stage is 22 operations for A instead of 176;
+//   * B stays fp32 in 128 VGPRs (three planes would be 192) and the 16 values of a stage are split beside the MFMAs (88 VALU
+//     operations per stage and wave, under the 24 MFMAs = 768 matrix-pipe cycles);
+//   * a lane's eight k of one MFMA operand are contiguous (k = 16 h + 8 lh .. + 7 of the stage), so B is loaded in that order;
+//   * the raw ring is consumed one stage earlier (the conversion of stage s + 1 runs in stage s), so the LDS-DMA runs PF2 = 7
+//     stages ahead instead of 6 and the keep-bits of the next tile are issued at stage 0.
+// One barrier per stage, as before: it publishes raw stage s + 2 AND the planes of stage s + 1, and it retires the planes of
+// stage s - 1 (overwritten by the conversion in stage s + 1... of the same parity).
+// ------------------------------------------------------------------------------------------------------------------------
+namespace sp {
+constexpr int PF2 = 7;
+constexpr int T_BITS2 = 0, T_C2 = 1;
+constexpr int PL_STAGE = 3 * BM * BK * 2;            // three planes of one stage: 12 KB
+constexpr int C_TILE = BM * DN * 4;                  // `accumulate`: the C tile waits in LDS (64 KB; MASK and ACC exclude each other,
+                                                     // so it starts where the keep-bits would lie) -- 32 registers a wave does not have
+constexpr int LDS_BYTES2 = RING + 2 * PL_STAGE + (C_TILE > 2 * BITS_TILE ? C_TILE : 2 * BITS_TILE);
+constexpr int C_OPS = BM / NW;                       // LDS-DMA instructions per wave for the C tile: one row each
+template <bool MASK, bool ACC>
+constexpr int ops_at(int t) { return 1 + ((MASK && t == T_BITS2) ? 2 : 0) + ((ACC && t == T_C2) ? C_OPS : 0); }
+// the wait in stage s is for the A piece of stage s + 2, issued at issue point s + 2 - PF2: what was issued after it
+template <bool MASK, bool ACC>
+constexpr int younger(int s) {
+  const int t0 = ((s + 2 - PF2) % NS + NS) % NS;
+  int n = (ACC && t0 == T_C2) ? C_OPS : 0;            // what followed the A piece at its own issue point (the bits precede it)
+  for (int t = 1; t < PF2 - 2; ++t) n += ops_at<MASK, ACC>((t0 + t) % NS);
+  return n;
+}
+static_assert(younger<false, false>(0) == 4 && younger<false, false>(7) == 4, "plain: four issue points of one piece");
+}  // namespace sp
+
+template <bool MASK, bool ACC>
+__global__ __launch_bounds__(NTHR, 2) void gr_split_kernel(const Launch L) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using namespace sp;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int n0 = wave * 32;
+  const int U = L.unit0[L.n];
+  int u = (int)(((uint32_t)blockIdx.x * (uint32_t)U) / (uint32_t)L.nwg);
+  const int u_end = (int)((((uint32_t)blockIdx.x + 1u) * (uint32_t)U) / (uint32_t)L.nwg);
+
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2s __attribute__((ext_vector_type(2)));
+  typedef float f32x4_ __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+  auto pk = [](float x, float y) -> uint32_t {       // v_cvt_pk_bf16_f32 (round to nearest even), low half = x
+    const f32x2s v = {x, y};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+  };
+  // two values -> their three parts, one dword per plane
+  auto split2 = [&](float x, float y, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+    p0 = pk(x, y);
+    const float x1 = x - __uint_as_float(p0 << 16), y1 = y - __uint_as_float(p0 & 0xFFFF0000u);       // exact
+    p1 = pk(x1, y1);
+    const float x2 = x1 - __uint_as_float(p1 << 16), y2 = y1 - __uint_as_float(p1 & 0xFFFF0000u);     // exact
+    p2 = pk(x2, y2);
+  };
+
+  // conversion: this lane's chunk of a raw stage = row cr, k 4 cg .. 4 cg + 3
+  const int cq = (wave << 6) + lane, cr = cq >> 3, cg = cq & 7;
+  const uint32_t raw_off = (uint32_t)(cr * (BK * 4) + ((cg ^ (cr & 7)) << 4));
+  const uint32_t pl_woff = (uint32_t)(cr * (BK * 2) + ((((cg >> 1) ^ ((cr >> 2) & 3)) << 4) | ((cg & 1) << 3)));
+  const uint32_t cbit_off = (uint32_t)(cr * QW + cg);
+  // operand reads: rows 32 i + li, plane chunk 2 h + lh
+  uint32_t pl_roff[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int row = 32 * i + li;
+      pl_roff[i][h] = (uint32_t)(row * (BK * 2) + (((2 * h + lh) ^ ((row >> 2) & 3)) << 4));
+    }
+  // LDS-DMA: this wave's piece of a stage = rows 8 wave .. + 7; lane -> row 8 wave + lane / 8, LDS chunk lane % 8
+  const int dr = 8 * wave + (lane >> 3);
+  const uint32_t dq16 = (uint32_t)(((lane & 7) ^ (lane >> 3)) << 4);
+  char* const planes = lds + RING;
+  char* const bits_lds = planes + 2 * PL_STAGE;       // MASK: the keep-bits of two tiles; ACC: the C tile
+  char* const c_lds = bits_lds;
+
+  f32x16 acc[2];
+
+  while (u < u_end) {
+    int p = 0;
+    while (p + 1 < L.n && L.unit0[p + 1] <= u) ++p;
+    const sdumc_rows_problem& pr = L.p[p];
+    const int ub = min(u_end, L.unit0[p + 1]);
+    const int tile0 = L.unit0[p];
+    const uint32_t lda4 = (uint32_t)pr.lda * 4u, ldc4 = (uint32_t)pr.ldc * 4u;
+    const int a_rows = pr.a_row_mod > 0 ? pr.a_row_mod : pr.M;
+    const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.A), 0, (int)((uint32_t)a_rows * lda4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbits = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(MASK ? pr.a_bits : (const uint8_t*)pr.A), 0,
+                                                                           MASK ? (int)((uint32_t)pr.M * QW) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(pr.C, 0, (int)((uint32_t)pr.M * ldc4), 0x00020000);
+
+    // B: register j = 16 s + 8 h + e  <->  k = 32 s + 16 h + 8 lh + e
+    float breg[DK / 2];
+    {
+      const uint32_t ldb4 = (uint32_t)pr.ldb * 4u;
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.B), 0, (int)((uint32_t)DK * ldb4), 0x00020000);
+      const uint32_t bo = (uint32_t)(8 * lh) * ldb4 + (uint32_t)(n0 + li) * 4u;
+#pragma unroll
+      for (int j = 0; j < DK / 2; ++j)
+        breg[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rb, bo, (32 * (j >> 4) + 16 * ((j >> 3) & 1) + (j & 7)) * ldb4, 0));
+    }
+    const float bias = pr.bias ? pr.bias[n0 + li] : 0.f;
+    const float scale = MASK ? pr.a_scale : 1.f;
+    const bool do_tanh = pr.act == SDUMC_ACT_TANH;
+
+    auto a_off = [&](int t) -> uint32_t {
+      int r = (t - tile0) * BM + dr;
+      if (pr.a_row_mod > 0) r %= pr.a_row_mod;
+      return (uint32_t)r * lda4 + dq16;
+    };
+    auto bits_off = [&](int t) -> uint32_t { return (uint32_t)((t - tile0) * BM + 8 * wave) * QW + 4u * lane; };
+    auto issue_a = [&](uint32_t off, int chunk) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(lds + chunk * A_STAGE + wave * 1024), 16, off, chunk * (BK * 4), 0, 0);
+    };
+    auto issue_bits = [&](uint32_t off, int par) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rbits, (lds_void_t*)(bits_lds + par * BITS_TILE + wave * 512), 4, off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rbits, (lds_void_t*)(bits_lds + par * BITS_TILE + wave * 512 + 256), 4, off, 256, 0, 0);
+    };
+    // raw stage `slot` (keep-bits parity `par`) -> planes buffer `pb`
+    auto convert = [&](int slot, int par, int pb) {
+      f32x4_ v = *reinterpret_cast<const f32x4_*>(lds + slot * A_STAGE + raw_off);
+      if constexpr (MASK) {
+        const uint32_t b = *reinterpret_cast<const uint8_t*>(bits_lds + par * BITS_TILE + cbit_off + 8 * slot);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = __uint_as_float(__float_as_uint(v[e]) & (uint32_t)__builtin_amdgcn_sbfe((int)b, e, 1u));
+      }
+      uint32_t q[3][2];
+      split2(v[0], v[1], q[0][0], q[1][0], q[2][0]);
+      split2(v[2], v[3], q[0][1], q[1][1], q[2][1]);
+      char* dst = planes + pb * PL_STAGE + pl_woff;
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) {
+        const u32x2 w = {q[pl][0], q[pl][1]};
+        *reinterpret_cast<u32x2*>(dst + pl * (BM * BK * 2)) = w;
+      }
+    };
+    auto op = [](const u32x4& v) { return __builtin_bit_cast(bf16x8, v); };
+    // the three parts of the 8 B values of half h of stage s (registers 16 s + 8 h .. + 7)
+    struct Parts {
+      u32x4 p[3];
+    };
+    auto bsplit = [&](int s, int h, Parts& o) {
+      uint32_t bq[3][4];
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        // (the parts of B do not change from tile to tile, and the compiler would hoist all 192 registers of them out of the
+        //  tile loop and spill: an empty asm makes the two values opaque here)
+        float x = breg[16 * s + 8 * h + 2 * d], y = breg[16 * s + 8 * h + 2 * d + 1];
+        asm volatile("" : "+v"(x), "+v"(y));
+        split2(x, y, bq[0][d], bq[1][d], bq[2][d]);
+      }
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) o.p[pl] = u32x4{bq[pl][0], bq[pl][1], bq[pl][2], bq[pl][3]};
+    };
+    auto read_a = [&](int pb, int i, int h, Parts& o) {
+      const char* base = planes + pb * PL_STAGE + pl_roff[i][h];
+#pragma unroll
+      for (int pl = 0; pl < 3; ++pl) o.p[pl] = *reinterpret_cast<const u32x4*>(base + pl * (BM * BK * 2));
+    };
+    auto mma6 = [&](int i, const Parts& a, const Parts& bb) {     // smallest terms first
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(a.p[2]), op(bb.p[0]), acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(a.p[0]), op(bb.p[2]), acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(a.p[1]), op(bb.p[1]), acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(a.p[1]), op(bb.p[0]), acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(a.p[0]), op(bb.p[1]), acc[i], 0, 0, 0);
+      acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(a.p[0]), op(bb.p[0]), acc[i], 0, 0, 0);
+    };
+
+    // ---- prologue: the ring belongs to this problem from here (the previous one drained it) ----
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    int par = 0;
+    {
+      const uint32_t o = a_off(u);
+      if constexpr (MASK) issue_bits(bits_off(u), 0);
+#pragma unroll
+      for (int s = 0; s < PF2; ++s) issue_a(o, s);
+    }
+    __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+    __builtin_amdgcn_s_barrier();
+    convert(0, 0, 0);
+    __builtin_amdgcn_s_barrier();
+    Parts bh0;
+    bsplit(0, 0, bh0);
+
+    // ---- steady state: 8 stages per tile, one barrier per stage ----
+#pragma nounroll
+    for (; u < ub; ++u) {
+      const uint32_t o_cur = a_off(u);
+      const uint32_t o_nxt = u + 1 < ub ? a_off(u + 1) : SDUMC_GR_NULL_OFF;
+      const uint32_t b_nxt = u + 1 < ub ? bits_off(u + 1) : SDUMC_GR_NULL_OFF;
+      const uint32_t c_off = (uint32_t)((u - tile0) * BM + 4 * lh) * ldc4 + (uint32_t)(n0 + li) * 4u;
+      const uint32_t c_row0 = (uint32_t)((u - tile0) * BM + 8 * wave) * ldc4 + 16u * (uint32_t)lane;
+      auto stage = [&](auto sc) {
+        constexpr int s = decltype(sc)::value;
+        // raw stage s + 1 (published by the previous barrier) -> the other planes buffer; stage 8 = the next tile's first
+        convert((s + 1) % NS, s + 1 == NS ? par ^ 1 : par, (s + 1) & 1);
+        // four blocks of six MFMAs: (h, i) = (0, 0), (0, 1), (1, 0), (1, 1).  The A parts of the next block are read and the B
+        // parts of the next half are split while a block multiplies; bh0 (the B parts of this stage's first half) was made in
+        // the previous stage's last block.
+        Parts a0, a1, bh1;
+        read_a(s & 1, 0, 0, a0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(s & 1, 1, 0, a1);
+        bsplit(s, 1, bh1);
+        mma6(0, a0, bh0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(s & 1, 0, 1, a0);
+        mma6(1, a1, bh0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(s & 1, 1, 1, a1);
+        bsplit((s + 1) % NS, 0, bh0);
+        mma6(0, a0, bh1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma6(1, a1, bh1);
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(waitcnt_vm(sp::younger<MASK, ACC>(s)));
+        __builtin_amdgcn_s_barrier();
+        if constexpr (MASK) {
+          if constexpr (s == T_BITS2) issue_bits(b_nxt, par ^ 1);
+        }
+        issue_a(s + PF2 < NS ? o_cur : o_nxt, (s + PF2) % NS);
+        if constexpr (ACC) {
+          if constexpr (s == T_C2) {   // this wave's rows 8 wave .. + 7 of the C tile (rows past M: outside the descriptor, zeros)
+#pragma unroll
+            for (int j = 0; j < C_OPS; ++j)
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, (lds_void_t*)(c_lds + (8 * wave + j) * (DN * 4)), 16, c_row0 + (uint32_t)j * ldc4, 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      stage(std::integral_constant<int, 0>{});
+      stage(std::integral_constant<int, 1>{});
+      stage(std::integral_constant<int, 2>{});
+      stage(std::integral_constant<int, 3>{});
+      stage(std::integral_constant<int, 4>{});
+      stage(std::integral_constant<int, 5>{});
+      stage(std::integral_constant<int, 6>{});
+      stage(std::integral_constant<int, 7>{});
+      auto epilogue = [&](auto tanh_c) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            float v = acc[i][e];
+            if constexpr (MASK) v *= scale;
+            v += bias;
+            if constexpr (ACC) v += *reinterpret_cast<const float*>(c_lds + (32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh) * (DN * 4) + (n0 + li) * 4);
+            if constexpr (decltype(tanh_c)::value) v = fast_tanh(v);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, c_off, (32 * i + (e & 3) + 8 * (e >> 2)) * ldc4, 0);
+            acc[i][e] = 0.f;
+          }
+      };
+      if (do_tanh) epilogue(std::true_type{});
+      else epilogue(std::false_type{});
+      __builtin_amdgcn_sched_barrier(0);
+      par ^= 1;
+    }
+    __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+    __builtin_amdgcn_s_barrier();
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // The same launch on bf16 STORAGE (the engine's bf16 mode, BASELINE configs[2] / [4]): A ([M][256], the masked frames xd or dz),
 // B ([256 n][256 k]: the weight copy whose rows are the output columns) and C are bf16 tensors, products accumulate in fp32 on
 // v_mfma_f32_32x32x16_bf16, bias / tanh in fp32.  A row of a stage is 64 k = 128 bytes, so the ring slots, the swizzle, the
@@ -489,6 +769,10 @@ bool set_lds_attr() {   // the dynamic-LDS limit is a per-device function attrib
                          reinterpret_cast<const void*>(&gr_kernel<false, true>)};
     for (const void* k : ks)
       if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return false;
+    const void* ks2[3] = {reinterpret_cast<const void*>(&gr_split_kernel<false, false>), reinterpret_cast<const void*>(&gr_split_kernel<true, false>),
+                          reinterpret_cast<const void*>(&gr_split_kernel<false, true>)};
+    for (const void* k : ks2)
+      if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, sp::LDS_BYTES2) != hipSuccess) return false;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gr_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, RING) != hipSuccess) return false;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gr_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, RING) != hipSuccess) return false;
     done[dev] = true;
@@ -544,7 +828,11 @@ extern "C" int sdumc_gemm_rows256_capped_(const sdumc_rows_problem* probs, int32
   if (!set_lds_attr()) return SDUMC_ELAUNCH;
   hipStream_t st = as_stream(stream);
   const int tok = sdumc_prof_begin_(21, flops, stream);
-  if (mask) hipLaunchKernelGGL((gr_kernel<true, false>), dim3(L.nwg), dim3(NTHR), LDS_BYTES, st, L);
+  if (sdumc_split_on_(SDUMC_SPLIT_ROWS)) {
+    if (mask) hipLaunchKernelGGL((gr_split_kernel<true, false>), dim3(L.nwg), dim3(NTHR), sp::LDS_BYTES2, st, L);
+    else if (accum) hipLaunchKernelGGL((gr_split_kernel<false, true>), dim3(L.nwg), dim3(NTHR), sp::LDS_BYTES2, st, L);
+    else hipLaunchKernelGGL((gr_split_kernel<false, false>), dim3(L.nwg), dim3(NTHR), sp::LDS_BYTES2, st, L);
+  } else if (mask) hipLaunchKernelGGL((gr_kernel<true, false>), dim3(L.nwg), dim3(NTHR), LDS_BYTES, st, L);
   else if (accum) hipLaunchKernelGGL((gr_kernel<false, true>), dim3(L.nwg), dim3(NTHR), LDS_BYTES, st, L);
   else hipLaunchKernelGGL((gr_kernel<false, false>), dim3(L.nwg), dim3(NTHR), LDS_BYTES, st, L);
   sdumc_prof_end_(tok, stream);
