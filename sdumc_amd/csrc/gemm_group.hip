@@ -62,6 +62,8 @@ struct Launch {
   int32_t nwg;
   int32_t bk;                // rows of K per k-tile: 16 (fp32 operands) or 64 (bf16 operands)
   int32_t hf;                // 1: A and B are bf16 tensors (gg_tn_bf16_kernel); the accumulator tiles then keep their natural row order
+  int32_t bn;                // width of an output tile: 128, or 256 (gg_tn_split2_kernel)
+  int32_t nat;               // 1: the accumulator tiles of the slabs are in natural row / column order (gg_tn_split2_kernel, bf16)
   int32_t ovh;               // line positions charged to every unit for its fixed costs (ring start-up latency, epilogue): no k-tiles behind them
   float* slab;
 };
@@ -69,9 +71,9 @@ struct Launch {
 struct Geo {       // derived shape of one problem
   int ntn, ntiles, nk0, nk;
 };
-__host__ __device__ inline Geo geo_of(const sdumc_gg_problem& p, int bk) {
+__host__ __device__ inline Geo geo_of(const sdumc_gg_problem& p, int bk, int bn) {
   Geo g;
-  g.ntn = (p.N + BN - 1) / BN;
+  g.ntn = (p.N + bn - 1) / bn;
   g.ntiles = g.ntn * ((p.M + BM - 1) / BM);
   g.nk0 = (p.K[0] + bk - 1) / bk;
   g.nk = g.nk0 + (p.K[1] > 0 ? (p.K[1] + bk - 1) / bk : 0);
@@ -94,7 +96,7 @@ __device__ __forceinline__ Where locate(const Launch& L, int x) {
   Where w;
   int p = 0;
   while (p + 1 < L.n && L.line0[p + 1] <= x) ++p;
-  const Geo g = geo_of(L.p[p], L.bk);
+  const Geo g = geo_of(L.p[p], L.bk, L.bn);
   const int nc = L.nchunk[p], ovh = L.ovh;
   const int xr = x - L.line0[p];
   // chunk c starts at line offset ntiles * (chunk_k(c) + c * ovh)
@@ -216,7 +218,7 @@ __device__ __forceinline__ void gg_tn_body(const Launch& L, char* lds) {
   while (x < x_end) {
     const Where w = locate(L, x);
     const sdumc_gg_problem& pr = L.p[w.p];
-    const Geo g = geo_of(pr, L.bk);
+    const Geo g = geo_of(pr, L.bk, L.bn);
     const int px_end = min(x_end, w.unit_end);
     // k-tiles [ka, kb) of the problem's concatenated K (a range that ends inside the unit's overhead positions holds none)
     const int ka = w.kt, kb = w.kt_end - (w.unit_end - px_end);
@@ -523,6 +525,307 @@ __global__ __launch_bounds__(NTHR, OCC) GG_NO_PACKED_FP32 void gg_tn_split_kerne
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
+// The split form with the operands split ONCE per workgroup (gg_tn_split2_kernel; SDUMC_GG_SPLIT2=0 selects the in-fragment form
+// above).  In the in-fragment form every wave splits the fragments it multiplies -- a 64-row block of A is split by two waves,
+// a 64-column block of B by four -- and the ~230 VALU operations per wave and k-tile, not the 24 MFMAs, bound the loop
+// (9.7 VALU instructions per MFMA in the counters; 136-147 TF).  Here, per k-tile:
+//   1. the raw fp32 stage (the same LDS-DMA ring) is converted by all 512 threads: a thread takes 8 k of one A row and 4 k of one
+//      B column (column reads of the [k][row] tiles: conflict-free ds_read_b32), applies the keep-bits, adds its A values to its
+//      column-sum register, splits, and writes the parts k-contiguous into three bf16 planes ([row][16 k] per plane; the two 16-byte
+//      halves of a row swapped by bit 3 of the row: conflict-free ds_read_b128 / ds_write_b128);   66 VALU operations per thread
+//   2. barrier; every wave reads its operands -- one ds_read_b128 per plane and 32-row block -- and issues the 24 MFMAs;
+//   3. barrier (the planes are single-buffered: 36 KB beside the 5-stage raw ring = 158.5 KB of LDS), LDS-DMA issue of the stage
+//      that goes into the buffer just converted.
+// The accumulator tiles keep their natural row / column order (Launch.nat: the reduce kernel's index arithmetic).
+// ------------------------------------------------------------------------------------------------------------------------
+namespace s2 {
+constexpr int BN2 = 256, WGN2 = 4, WM2 = 128, WN2 = 64, TM2 = 4, TN2 = 2;      // 2 x 4 waves, each 128 x 64
+constexpr int B2_BYTES = BK * BN2 * 4, BITS2_BYTES = BK * (BN2 / 4), STAGE2 = A_BYTES + B2_BYTES + BITS2_BYTES;   // 33 KB
+constexpr int PA_BYTES = BM * BK * 2, PB_BYTES = BN2 * BK * 2;        // one plane of A / B of a k-tile: 8 KB each
+constexpr int PLANES_BYTES = 3 * (PA_BYTES + PB_BYTES);               // 48 KB
+constexpr int NST2 = 3;
+constexpr int LDS2 = NST2 * STAGE2 + PLANES_BYTES;        // 147 KB (the column-sum exchange at a unit's end uses the planes' memory)
+constexpr int SLOT2_FLOATS = BM * BN2 + BM;
+static_assert(LDS2 <= 160 * 1024, "LDS");
+}  // namespace s2
+
+__global__ __launch_bounds__(NTHR, 2) void gg_tn_split2_kernel(const Launch L) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using namespace s2;
+  constexpr int NST = NST2;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  // (the planes first: their addresses then fit the 16-bit offset field of the LDS instructions, plane by plane, from one
+  //  register per operand -- behind the ring every (operand, plane) pair would need a register of its own)
+  char* const planes = lds;
+  char* const ring0 = lds + PLANES_BYTES;
+  float* const cs_x = reinterpret_cast<float*>(planes);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int wm0 = (wave / WGN2) * WM2, wn0 = (wave % WGN2) * WN2;
+  const int LL = L.line0[L.n];
+  const int wg = blockIdx.x;
+  int x = range_begin(wg, LL, L.nwg);
+  const int x_end = range_begin(wg + 1, LL, L.nwg);
+  constexpr int PER = 5;      // 2 A rows, 2 B rows, 1 keep-bits piece per wave and stage
+
+  typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+  typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+  typedef float f32x2s __attribute__((ext_vector_type(2)));
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  auto pk = [](float a, float b) -> uint32_t {       // v_cvt_pk_bf16_f32 (round to nearest even), low half = a
+    const f32x2s v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+  };
+  auto split2 = [&](float a, float b, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+    p0 = pk(a, b);
+    const float a1 = a - __uint_as_float(p0 << 16), b1 = b - __uint_as_float(p0 & 0xFFFF0000u);       // exact
+    p1 = pk(a1, b1);
+    const float a2 = a1 - __uint_as_float(p1 << 16), b2 = b1 - __uint_as_float(p1 & 0xFFFF0000u);     // exact
+    p2 = pk(a2, b2);
+  };
+  auto op = [](const u32x4& v) { return __builtin_bit_cast(bf16x8, v); };
+
+  // conversion roles: row ar of A and column ar of B, k 8 ag .. + 7 of both
+  const int ar = tid & (BM - 1), ag = tid >> 8;
+  const uint32_t a_rd = (uint32_t)((8 * ag) * BM + ar) * 4u;                                  // + s * BM * 4
+  const uint32_t a_wr = (uint32_t)(ar * (BK * 2) + ((ag ^ ((ar >> 3) & 1)) << 4));
+  const uint32_t b_rd = (uint32_t)(A_BYTES + ((8 * ag) * BN2 + ar) * 4);                      // + s * BN2 * 4
+  const uint32_t b_wr = (uint32_t)(3 * PA_BYTES) + a_wr;
+  const uint32_t bit_rd = (uint32_t)(A_BYTES + B2_BYTES + (8 * ag) * (BN2 / 4) + (ar >> 2));  // + s * (BN2 / 4)
+  const uint32_t bit_pos = (uint32_t)(ar & 3);
+  // operand reads: rows (columns) 32 i + li of the wave's block, k group lh
+  uint32_t a_op[TM2], b_op[TN2];
+#pragma unroll
+  for (int i = 0; i < TM2; ++i) {
+    const int r = wm0 + 32 * i + li;
+    a_op[i] = (uint32_t)(r * (BK * 2) + ((lh ^ ((r >> 3) & 1)) << 4));
+  }
+#pragma unroll
+  for (int j = 0; j < TN2; ++j) {
+    const int c = wn0 + 32 * j + li;
+    b_op[j] = (uint32_t)(3 * PA_BYTES + c * (BK * 2) + ((lh ^ ((c >> 3) & 1)) << 4));
+  }
+
+  f32x16 acc[TM2][TN2];
+  auto wait_n = [&](int n) {
+    if (n >= 4) __builtin_amdgcn_s_waitcnt(waitcnt_vm(4 * PER));
+    else if (n == 3) __builtin_amdgcn_s_waitcnt(waitcnt_vm(3 * PER));
+    else if (n == 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm(2 * PER));
+    else if (n == 1) __builtin_amdgcn_s_waitcnt(waitcnt_vm(PER));
+    else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+  };
+
+  while (x < x_end) {
+    const Where w = locate(L, x);
+    const sdumc_gg_problem& pr = L.p[w.p];
+    const Geo g = geo_of(pr, L.bk, L.bn);
+    const int px_end = min(x_end, w.unit_end);
+    const int ka = w.kt, kb = w.kt_end - (w.unit_end - px_end);
+    if (kb <= ka) {
+      x = px_end;
+      continue;
+    }
+    const int tile_m = w.tile / g.ntn, tile_n = w.tile - tile_m * g.ntn;
+    const int m0 = tile_m * BM, n0 = tile_n * BN2;
+    float csum = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM2; ++i)
+#pragma unroll
+      for (int j = 0; j < TN2; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    bool seg_masked = false;
+#pragma nounroll
+    for (int seg = 0; seg < 2; ++seg) {
+      int t0, nk;
+      if (seg == 0) {
+        if (ka >= g.nk0) continue;
+        t0 = ka;
+        nk = min(kb, g.nk0) - ka;
+      } else {
+        if (kb <= g.nk0) continue;
+        t0 = max(ka, g.nk0) - g.nk0;
+        nk = kb - g.nk0 - t0;
+      }
+      const int kbeg = t0 * BK;
+      const int segK = pr.K[seg], seg_mod = pr.b_row_mod[seg];
+      const uint32_t lda4 = (uint32_t)pr.lda * 4u, ldb4 = (uint32_t)pr.ldb * 4u, qw = (uint32_t)pr.bits_qw;
+      const bool masked = pr.b_bits[seg] != nullptr;
+      const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.A[seg]), 0, (int)((uint32_t)segK * lda4), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.B[seg]), 0, (int)((uint32_t)(seg_mod > 0 ? seg_mod : segK) * ldb4), 0x00020000);
+      const __amdgpu_buffer_rsrc_t rbits = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(masked ? pr.b_bits[seg] : (const uint8_t*)pr.A[seg]), 0,
+                                                                             masked ? (int)((uint32_t)segK * qw) : 0, 0x00020000);
+      uint32_t voff[4], bvoff;
+      int srck[2] = {0, 0};
+#pragma unroll
+      for (int i = 0; i < 2; ++i) voff[i] = (uint32_t)(kbeg + wave + 8 * i) * lda4 + (uint32_t)min(m0 + 4 * lane, pr.M - 4) * 4u;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        int kr = kbeg + wave + 8 * i;
+        if (seg_mod > 0) kr %= seg_mod;
+        srck[i] = kr;
+        voff[2 + i] = (uint32_t)kr * ldb4 + (uint32_t)min(n0 + 4 * lane, pr.N - 4) * 4u;
+      }
+      {
+        const int idx = ((wave & 3) << 6) + lane;               // dword index inside the [16][16 dwords] bits tile
+        bvoff = (uint32_t)(kbeg + (idx >> 4)) * qw + (uint32_t)(n0 >> 2) + 4u * (idx & 15);
+      }
+      auto issue = [&](int buf) {
+        char* base = ring0 + buf * STAGE2;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(base + wave * 1024), 16, voff[0], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(base + (wave + 8) * 1024), 16, voff[1], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(base + A_BYTES + wave * 1024), 16, voff[2], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(base + A_BYTES + (wave + 8) * 1024), 16, voff[3], 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbits, (lds_void_t*)(base + A_BYTES + B2_BYTES + (wave & 3) * 256), 4, bvoff, 0, 0, 0);
+        voff[0] += (uint32_t)BK * lda4;
+        voff[1] += (uint32_t)BK * lda4;
+        voff[2] += (uint32_t)BK * ldb4;
+        voff[3] += (uint32_t)BK * ldb4;
+        bvoff += (uint32_t)BK * qw;
+        if (seg_mod > 0) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            srck[i] += BK;
+            if (srck[i] >= seg_mod) { srck[i] -= seg_mod; voff[2 + i] -= (uint32_t)seg_mod * ldb4; }
+          }
+        }
+      };
+      // (`masked` is a runtime branch around eight byte reads here, not a second instantiation of the loop: with two copies
+      //  of the k loop the register allocator kept five of the eight accumulator tiles in scratch)
+      auto convert = [&](const char* base) {
+        float av[8], bv[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) av[s] = *reinterpret_cast<const float*>(base + a_rd + s * (BM * 4));
+#pragma unroll
+        for (int s = 0; s < 8; ++s) bv[s] = *reinterpret_cast<const float*>(base + b_rd + s * (BN2 * 4));
+        if (masked) {
+#pragma unroll
+          for (int s = 0; s < 8; ++s) {
+            const uint32_t byte = *reinterpret_cast<const uint8_t*>(base + bit_rd + s * (BN2 / 4));
+            bv[s] = __uint_as_float(__float_as_uint(bv[s]) & (uint32_t)__builtin_amdgcn_sbfe((int)byte, bit_pos, 1u));
+          }
+        }
+        csum += ((av[0] + av[1]) + (av[2] + av[3])) + ((av[4] + av[5]) + (av[6] + av[7]));
+        uint32_t q[3][4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) split2(av[2 * d], av[2 * d + 1], q[0][d], q[1][d], q[2][d]);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(planes + pl * PA_BYTES + a_wr) = u32x4{q[pl][0], q[pl][1], q[pl][2], q[pl][3]};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) split2(bv[2 * d], bv[2 * d + 1], q[0][d], q[1][d], q[2][d]);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) *reinterpret_cast<u32x4*>(planes + pl * PB_BYTES + b_wr) = u32x4{q[pl][0], q[pl][1], q[pl][2], q[pl][3]};
+      };
+      auto multiply = [&]() {
+        u32x4 pb[TN2][3], pa[2][3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) pa[0][pl] = *reinterpret_cast<const u32x4*>(planes + pl * PA_BYTES + a_op[0]);
+#pragma unroll
+        for (int j = 0; j < TN2; ++j)
+#pragma unroll
+          for (int pl = 0; pl < 3; ++pl) pb[j][pl] = *reinterpret_cast<const u32x4*>(planes + pl * PB_BYTES + b_op[j]);
+#pragma unroll
+        for (int i = 0; i < TM2; ++i) {
+          // (one block of rows ahead, not all four: 128 accumulator registers leave room for little else)
+          if (i + 1 < TM2) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) pa[(i + 1) & 1][pl] = *reinterpret_cast<const u32x4*>(planes + pl * PA_BYTES + a_op[i + 1]);
+          }
+          const u32x4* A_ = pa[i & 1];
+#pragma unroll
+          for (int j = 0; j < TN2; ++j) {   // smallest terms first
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(A_[2]), op(pb[j][0]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(A_[0]), op(pb[j][2]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(A_[1]), op(pb[j][1]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(A_[1]), op(pb[j][0]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(A_[0]), op(pb[j][1]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(A_[0]), op(pb[j][0]), acc[i][j], 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      {
+#pragma unroll
+        for (int s = 0; s < NST - 1; ++s)
+          if (s < nk) issue(s);
+        int buf = 0, ibuf = NST - 1;
+#pragma nounroll
+        for (int t = 0; t < nk; ++t) {
+          // stage t has landed (this wave's pieces) / everyone is done with the planes of k-tile t - 1 and has converted stage t - 1
+          wait_n(min(nk - t - 1, NST - 2));
+          __builtin_amdgcn_s_barrier();
+          if (t + NST - 1 < nk) issue(ibuf);
+          convert(ring0 + buf * STAGE2);
+          __builtin_amdgcn_s_barrier();
+          multiply();
+          buf = buf + 1 == NST ? 0 : buf + 1;
+          ibuf = ibuf + 1 == NST ? 0 : ibuf + 1;
+        }
+      }
+      seg_masked = masked;
+      __builtin_amdgcn_s_barrier();          // every wave is done with the planes before the next sub-piece converts into them
+    }
+    if (seg_masked) {
+      const float sc = pr.b_scale;
+#pragma unroll
+      for (int i = 0; i < TM2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN2; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) acc[i][j][e] *= sc;
+    }
+    const bool direct = L.nchunk[w.p] == 1 && ka == 0 && kb == g.nk;
+    const bool do_cs = pr.colsum_a != nullptr && tile_n == 0;
+    if (do_cs) {      // the two k-group halves of a row meet in LDS (all 512 threads hold a partial)
+      cs_x[tid] = csum;
+      __builtin_amdgcn_s_barrier();
+      if (tid < BM) csum = cs_x[tid] + cs_x[tid + BM];
+    }
+    if (direct) {
+      // C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+      const bool accum = pr.accumulate != 0;
+#pragma unroll
+      for (int i = 0; i < TM2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN2; ++j) {
+          const int col = n0 + wn0 + 32 * j + li;
+          if (col >= pr.N) continue;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int row = m0 + wm0 + 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+            if (row >= pr.M) continue;
+            float* dst = pr.C + ((uint32_t)row * (uint32_t)pr.ldc + (uint32_t)col);
+            float v = acc[i][j][e];
+            if (accum) v += *dst;
+            *dst = v;
+          }
+        }
+      if (do_cs && tid < BM && m0 + tid < pr.M) {
+        float* dst = pr.colsum_a + m0 + tid;
+        *dst = accum ? *dst + csum : csum;
+      }
+    } else {
+      // slab slot in register order: [wave][i][j][e / 4][lane][4]
+      float* slot = L.slab + (size_t)(wg + w.unit) * SLOT2_FLOATS;
+      float* mine = slot + (uint32_t)(wave * 32 * 64 + lane) * 4u;
+#pragma unroll
+      for (int i = 0; i < TM2; ++i)
+#pragma unroll
+        for (int j = 0; j < TN2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            *reinterpret_cast<f32x4*>(mine + ((i * TN2 + j) * 4 + q) * 256) = v;
+          }
+      if (do_cs && tid < BM) slot[BM * BN2 + tid] = csum;
+    }
+    x = px_end;
+  }
+#endif
+}
+
+// ------------------------------------------------------------------------------------------------------------------------
 // The same launch on bf16 STORAGE (the engine's bf16 mode, BASELINE configs[2] / [4]): dz / dx and the (masked) frames / features
 // are bf16 tensors, products accumulate in fp32 on v_mfma_f32_32x32x16_bf16, C and the slabs are fp32.  Tile 256 x 128 x 64 k
 // (48 KiB per stage, 3 stages).  Operands are row-contiguous ([k][row] tiles); an MFMA operand -- 8 consecutive k of one row --
@@ -575,7 +878,7 @@ __global__ __launch_bounds__(NTHR, 2) void gg_tn_bf16_kernel(const Launch L) {
   while (x < x_end) {
     const Where w = locate(L, x);
     const sdumc_gg_problem& pr = L.p[w.p];
-    const Geo g = geo_of(pr, L.bk);
+    const Geo g = geo_of(pr, L.bk, L.bn);
     const int px_end = min(x_end, w.unit_end);
     const int ka = w.kt, kb = w.kt_end - (w.unit_end - px_end);
     if (kb <= ka) {
@@ -741,30 +1044,34 @@ __global__ __launch_bounds__(NTHR, 2) void gg_tn_bf16_kernel(const Launch L) {
 #endif
 }
 
-// One workgroup per (tile, part): parts 0..15 = the sixteen float4 chunks a lane holds of its wave's 64 x 64 block, part 16 =
-// the column sums of A.  Sums the tile's slab slots in ascending k order and writes C (the GEMM kernel's epilogue arithmetic).
+// One workgroup per (tile, part): the float4 chunks a lane holds of its wave's block (16 for the 64 x 64 blocks of the 256 x 128
+// tiles, 32 for the 128 x 64 blocks of gg_tn_split2_kernel's 256 x 256 tiles), last part = the column sums of A.  Sums the tile's
+// slab slots in ascending k order and writes C (the GEMM kernel's epilogue arithmetic).
 __global__ __launch_bounds__(NTHR) void gg_reduce_kernel(const Launch L, const int tiles_total) {
+  const bool wide = L.bn == s2::BN2;
+  const int nparts = wide ? 32 : 16, slot_floats = BM * L.bn + BM;
+  const int wgn = wide ? s2::WGN2 : WGN, wmx = wide ? s2::WM2 : WM, wnx = wide ? s2::WN2 : WN, tnx = wide ? s2::TN2 : TN;
   const int part = blockIdx.y;
   int tg = blockIdx.x;
   int p = 0;
-  Geo g = geo_of(L.p[0], L.bk);
+  Geo g = geo_of(L.p[0], L.bk, L.bn);
   while (p + 1 < L.n && tg >= g.ntiles) {
     tg -= g.ntiles;
     ++p;
-    g = geo_of(L.p[p], L.bk);
+    g = geo_of(L.p[p], L.bk, L.bn);
   }
   const sdumc_gg_problem& pr = L.p[p];
   const int nc = L.nchunk[p];
   const int LL = L.line0[L.n];
   const int tile_m = tg / g.ntn, tile_n = tg - tile_m * g.ntn;
-  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int m0 = tile_m * BM, n0 = tile_n * L.bn;
   const int ovh = L.ovh;
   if (nc == 1) {   // written directly by the one workgroup that held all its k-tiles?
     const int us = L.line0[p] + tg * (g.nk + ovh);
     if (wg_of(us + ovh, LL, L.nwg) == wg_of(us + ovh + g.nk - 1, LL, L.nwg)) return;
   }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (part == 16) {
+  if (part == nparts) {
     if (!pr.colsum_a || tile_n != 0 || tid >= BM) return;
     float s = 0.f;
     for (int c = 0; c < nc; ++c) {
@@ -772,29 +1079,30 @@ __global__ __launch_bounds__(NTHR) void gg_reduce_kernel(const Launch L, const i
       const int us = L.line0[p] + g.ntiles * (k0 + c * ovh) + tg * len;
       const int unit = L.unit0[p] + c * g.ntiles + tg;
       const int wl = wg_of(us + len - 1, LL, L.nwg);
-      for (int w = wg_of(us + ovh, LL, L.nwg); w <= wl; ++w) s += L.slab[(size_t)(w + unit) * SLOT_FLOATS + BM * BN + tid];
+      for (int w = wg_of(us + ovh, LL, L.nwg); w <= wl; ++w) s += L.slab[(size_t)(w + unit) * slot_floats + BM * L.bn + tid];
     }
     const int m = m0 + tid;
     if (m < pr.M) pr.colsum_a[m] = pr.accumulate ? pr.colsum_a[m] + s : s;
     return;
   }
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  const size_t off = ((size_t)((wave * 16 + part) * 64 + lane)) * 4;
+  const size_t off = ((size_t)((wave * nparts + part) * 64 + lane)) * 4;
   for (int c = 0; c < nc; ++c) {
     const int k0 = chunk_k(c, g.nk, nc), len = chunk_k(c + 1, g.nk, nc) - k0 + ovh;
     const int us = L.line0[p] + g.ntiles * (k0 + c * ovh) + tg * len;
     const int unit = L.unit0[p] + c * g.ntiles + tg;
     const int wl = wg_of(us + len - 1, LL, L.nwg);
-    for (int w = wg_of(us + ovh, LL, L.nwg); w <= wl; ++w) s += *reinterpret_cast<const f32x4*>(L.slab + (size_t)(w + unit) * SLOT_FLOATS + off);
+    for (int w = wg_of(us + ovh, LL, L.nwg); w <= wl; ++w) s += *reinterpret_cast<const f32x4*>(L.slab + (size_t)(w + unit) * slot_floats + off);
   }
   const int li = lane & 31, lh = lane >> 5;
-  const int ij = part >> 2, q = part & 3, i = ij / TN, j = ij - i * TN;
-  const int col = n0 + (wave % WGN) * WN + (L.hf ? 32 * j + li : 2 * li + j);
+  const int ij = part >> 2, q = part & 3, i = ij / tnx, j = ij - i * tnx;
+  const bool nat = L.hf || L.nat;
+  const int col = n0 + (wave % wgn) * wnx + (nat ? 32 * j + li : 2 * li + j);
   if (col >= pr.N) return;
 #pragma unroll
   for (int e = 0; e < 4; ++e) {
     const int rr = e + 8 * q + 4 * lh;
-    const int row = m0 + (wave / WGN) * WM + (L.hf ? 32 * i + rr : 2 * rr + i);
+    const int row = m0 + (wave / wgn) * wmx + (nat ? 32 * i + rr : 2 * rr + i);
     if (row >= pr.M) continue;
     float* dst = pr.C + (size_t)row * pr.ldc + col;
     *dst = pr.accumulate ? *dst + s[e] : s[e];
@@ -828,6 +1136,8 @@ bool set_lds_attr() {   // the dynamic-LDS limit is a per-device function attrib
       return false;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_tn_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, hf::HNST * hf::HSTAGE) != hipSuccess)
       return false;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_tn_split2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, s2::LDS2) != hipSuccess)
+      return false;
     done[dev] = true;
   }
   return true;
@@ -854,19 +1164,24 @@ bool valid(const sdumc_gg_problem& p) {
 }
 
 // fills L for problems [first, first + n); returns the number of tiles
-int plan(const sdumc_gg_problem* probs, int n, int nwg_max, bool hf, Launch& L, int& units) {
+int plan(const sdumc_gg_problem* probs, int n, int nwg_max, bool hf, bool wide, Launch& L, int& units) {
   memset(&L, 0, sizeof(L));
   L.n = n;
   L.hf = hf ? 1 : 0;
   L.bk = hf ? 64 : BK;
+  L.bn = wide ? s2::BN2 : BN;
+  L.nat = wide ? 1 : 0;
   // (measured on MI355X, tools/gg_bench.py, all 37 problems of a C2 backward in one launch: 623 us with 0, 515 with 2, 490 with 3-4,
   //  494-500 with 6-12: a unit's ring start-up -- the HBM latency of its first stage -- and its epilogue are worth ~3 k-tiles)
   L.ovh = hf ? 5 : 3;      // (bf16: 2, 5, 8, 12 measured 110 / 111 / 115 / 118 us on the frame-level problems of a C2 backward)
+  // (the 256 x 256 form: 1, 2, 3, 5, 8 measured 400 / 364 / 339 / 323 / 325 us on all problems of a C2 backward in one launch; no
+  //  difference on the step, which issues them as two launches: 1.456-1.469 ms at 2, 3 and 5)
+  if (wide) L.ovh = 4;
   int line = 0, tiles = 0;
   units = 0;
   for (int i = 0; i < n; ++i) {
     L.p[i] = probs[i];
-    const Geo g = geo_of(probs[i], L.bk);
+    const Geo g = geo_of(probs[i], L.bk, L.bn);
     // (a second problem form in this kernel -- the input gradients dxd += dz . W of the input_proj layers, A k-contiguous, M the
     //  long dimension, K = 256 -- was built and measured in round 3: 237 us for the five sites of a C2 backward against 210 us
     //  for the per-layer 64x64 NN kernel: units of 16 k-tiles pay a ring start-up and a 256 KB read-modify-write epilogue each;
@@ -907,7 +1222,8 @@ bool valid_bf16(const sdumc_gg_problem& p) {
 
 extern "C" size_t sdumc_gg_slab_bytes_(int tiles) {
   (void)set_lds_attr();
-  return (size_t)(cu_count() + tiles) * SLOT_FLOATS * sizeof(float);
+  // (`tiles` counts 256 x 128 tiles; the 256 x 256 form has at most as many, of twice the size)
+  return (size_t)(cu_count() + tiles) * s2::SLOT2_FLOATS * sizeof(float);
 }
 
 extern "C" int sdumc_prof_begin_(int variant, double flops, void* stream);     // gemm_f32.hip: bench.py's per-launch HIP events
@@ -915,6 +1231,10 @@ extern "C" void sdumc_prof_end_(int token, void* stream);
 
 namespace {
 bool split_products() { return sdumc_split_on_(SDUMC_SPLIT_GROUP) != 0; }
+bool split2_form() {
+  static const int on = [] { const char* e = getenv("SDUMC_GG_SPLIT2"); return e ? atoi(e) : 1; }();
+  return on != 0;
+}
 size_t gg_workspace_bytes(const sdumc_gg_problem* probs, int32_t n, bool hf) {
   if (!probs || n <= 0) return 0;
   const int nwg = cu_count();
@@ -923,8 +1243,12 @@ size_t gg_workspace_bytes(const sdumc_gg_problem* probs, int32_t n, bool hf) {
     const int cnt = std::min(MAXP, n - first);
     Launch L;
     int units = 0;
-    plan(probs + first, cnt, nwg, hf, L, units);
+    plan(probs + first, cnt, nwg, hf, false, L, units);
     need = std::max(need, (size_t)(L.nwg + units) * SLOT_FLOATS * sizeof(float));
+    if (!hf) {      // whichever form the process-wide switch selects at launch time fits
+      plan(probs + first, cnt, nwg, hf, true, L, units);
+      need = std::max(need, (size_t)(L.nwg + units) * s2::SLOT2_FLOATS * sizeof(float));
+    }
   }
   return need;
 }
@@ -941,18 +1265,21 @@ int gg_run(const sdumc_gg_problem* probs, int32_t n, void* workspace, size_t wor
     const int cnt = std::min(MAXP, n - first);
     Launch L;
     int units = 0;
-    const int tiles = plan(probs + first, cnt, nwg, hf, L, units);
+    const bool wide = !hf && split_products() && split2_form();
+    const int tiles = plan(probs + first, cnt, nwg, hf, wide, L, units);
     if ((long long)L.line0[cnt] * (L.nwg + 1) >= (1LL << 31)) return SDUMC_EINVAL;   // 32-bit index arithmetic in the kernels
     L.slab = static_cast<float*>(workspace);
     double flops = 0.0;
     for (int i = 0; i < cnt; ++i) flops += 2.0 * probs[first + i].M * (double)probs[first + i].N * ((double)probs[first + i].K[0] + probs[first + i].K[1]);
     const int tok = sdumc_prof_begin_(hf ? 20 : 19, flops, stream);
     if (hf) hipLaunchKernelGGL(gg_tn_bf16_kernel, dim3(L.nwg), dim3(NTHR), hf::HNST * hf::HSTAGE, st, L);
-    else if (split_products()) hipLaunchKernelGGL((gg_tn_split_kernel<5, 2>), dim3(L.nwg), dim3(NTHR), 5 * STAGE_BYTES, st, L);
+    else if (wide) {
+      hipLaunchKernelGGL(gg_tn_split2_kernel, dim3(L.nwg), dim3(NTHR), s2::LDS2, st, L);
+    } else if (split_products()) hipLaunchKernelGGL((gg_tn_split_kernel<5, 2>), dim3(L.nwg), dim3(NTHR), 5 * STAGE_BYTES, st, L);
     else hipLaunchKernelGGL((gg_tn_kernel<5, 2>), dim3(L.nwg), dim3(NTHR), 5 * STAGE_BYTES, st, L);
     sdumc_prof_end_(tok, stream);
     SDUMC_CHECK_LAUNCH();
-    hipLaunchKernelGGL(gg_reduce_kernel, dim3(tiles, 17), dim3(NTHR), 0, st, L, tiles);
+    hipLaunchKernelGGL(gg_reduce_kernel, dim3(tiles, wide ? 33 : 17), dim3(NTHR), 0, st, L, tiles);
     SDUMC_CHECK_LAUNCH();
   }
   return SDUMC_OK;
