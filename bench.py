@@ -32,6 +32,13 @@ DIMS = (1024, 4096, 1024, 4096)         # WavLM-L / Vicuna-7B / MANet / Vicuna-7
 TRAIN_FLOPS_PER_SAMPLE = 1980.7e6       # algorithmic, audio/video projection counted once
 PEAK_F32_MFMA_TFLOPS = 157.3            # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_BF16_MFMA_TFLOPS = 2500.0          # same guide: dense bf16 matrix peak (the bf16-operand kernels are priced against it)
+# fp32 GEMM kernels whose products run on the bf16 matrix pipe (variant names "..._bf16x3"): every fp32 product costs six
+# v_mfma_f32_32x32x16_bf16 terms, so the matrix-pipe ceiling for fp32-equivalent FLOPs is a sixth of the dense bf16 peak
+PEAK_F32_ON_BF16_PIPE_TFLOPS = PEAK_BF16_MFMA_TFLOPS / 6.0
+F32_ARITHMETIC = ("f32 in, out and accumulation; GEMM products on the bf16 matrix pipe from operands split exactly into three bf16 "
+                  "parts each (six of the nine part products, each exact in f32; error per product < 2^-23, as close to f64 as the "
+                  "v_mfma_f32_32x32x2_f32 path: tools/gg_split_check.py, tests/test_gpu_split.py); side.c2_f32_mfma is the same step "
+                  "with every product on the f32 MFMAs")
 PEAK_HBM_GBS = 8000.0                  # same guide: HBM3E peak (6.3 TB/s achievable with a streaming copy)
 # The default is the configuration the metric is quoted on (configs[1]); the others are the parity-test shapes of
 # SURVEY §8, selectable for side measurements (`--workload c1|c5`), never what the driver's default run reports.
@@ -190,8 +197,12 @@ def roofline_leg(_lib, launch, steps, traffic_ok=True):
     # the committed PMC summary was collected on the default workload in fp32: it describes no other configuration
     traffic, traffic_src = recorded_traffic(top["kernel"]) if traffic_ok else (None, None)
     bf16_kernel = top["kernel"].startswith("gemm_bf16") or top["kernel"].endswith("_bf16")   # bf16-operand / bf16-storage kernels
-    peak = PEAK_BF16_MFMA_TFLOPS if bf16_kernel else PEAK_F32_MFMA_TFLOPS
+    split_kernel = top["kernel"].endswith("_bf16x3")                                          # f32 operands, six bf16 MFMA terms per product
+    peak = PEAK_BF16_MFMA_TFLOPS if bf16_kernel else round(PEAK_F32_ON_BF16_PIPE_TFLOPS, 1) if split_kernel else PEAK_F32_MFMA_TFLOPS
     return {"bound": "mfma", "achieved": round(top["tflops"], 2), "peak": peak, "unit": "TFLOP/s",
+            "peak_note": ("dense bf16 MFMA peak / 6: this kernel computes every f32 product as six bf16 MFMA terms (f32-equivalent FLOPs counted)"
+                          if split_kernel else "dense bf16 MFMA peak" if bf16_kernel else "dense f32 MFMA peak"),
+            "frac_of_f32_mfma_peak": round(top["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
             "frac": round(top["tflops"] / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
             "kernel": top["kernel"], "avg_launch_us": round(top["avg_us"], 2),
             "gflop_per_launch": round(top["gflop_per_launch"], 3),
@@ -247,6 +258,32 @@ def c3_bf16_side_leg(engine, flat, batch, args):
                         "f32 accumulation, softmax, utterance-level layers, losses and Adam",
             "value": round(B_PER_GPU * args.steps / dt, 2), "unit": "samples/s", "ms_per_step": round(ms, 4),
             "steps": args.steps, "warmup": args.warmup, "final_loss": round(float(losses[0]), 5), "roofline": roof}
+
+
+def c2_f32_mfma_side_leg(engine, _lib, flat, batch, args):
+    """The headline step with every GEMM product on v_mfma_f32_32x32x2_f32 (sdumc_set_split_(0)): what the default's products on
+    the bf16 matrix pipe buy, under the same clock."""
+    lib = _lib.lib
+    try:
+        lib.sdumc_set_split_(0)
+        step = engine.TrainStep(flat.clone(), B_PER_GPU, T_MOSEI, DIMS, seed=2024)
+        step.set_batch(*batch)
+        for _ in range(args.warmup):
+            step.run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step.run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        losses = step.losses.cpu()
+    finally:
+        lib.sdumc_set_split_(15)
+    if not torch.isfinite(losses).all():
+        raise SystemExit(f"non-finite loss in the f32-MFMA side leg: {losses.tolist()}")
+    return {"workload": "the headline step with sdumc_set_split_(0): every GEMM product on v_mfma_f32_32x32x2_f32",
+            "value": round(B_PER_GPU * args.steps / dt, 2), "unit": "samples/s", "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "steps": args.steps, "warmup": args.warmup, "final_loss": round(float(losses[0]), 5)}
 
 
 def recorded_traffic(kernel):
@@ -487,6 +524,7 @@ def main():
         "ms_per_step": round(1e3 * dt / args.steps, 4), "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 4),
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16 storage of features / frames / keys / frame-level gradients with f32 accumulation; f32 softmax, utterance-level layers, losses and Adam (f32 master weights)" if args.bf16 else "f32", "data": "synthetic",
+        **({} if args.bf16 else {"arithmetic": F32_ARITHMETIC}),
         "config": {"workload": ("bf16 storage (--bf16, the dtype of BASELINE configs[2]/[4]) on: " if args.bf16 else "") + WORKLOAD_TEXT,
                    "batch_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU,
                    "T_audio_text_video_feat4": list(T_MOSEI), "feature_dims": list(DIMS),
@@ -500,7 +538,8 @@ def main():
     if dp_extra is not None:
         out["data_parallel"] = dp_extra
     if world == 1 and not force_dp and args.workload == "c2" and not args.bf16 and not args.graph and not args.serial_lanes and not args.no_side:
-        out["side"] = {"c3_bf16": c3_bf16_side_leg(engine, flat, batch, args)}
+        out["side"] = {"c3_bf16": c3_bf16_side_leg(engine, flat, batch, args),
+                       "c2_f32_mfma": c2_f32_mfma_side_leg(engine, _lib, flat, batch, args)}
     if not args.no_roofline:     # every rank runs it (the DP step has collectives); rank 0 reports
         roof = roofline_leg(_lib, step.launch if (world == 1 and not force_dp) else step.step, max(3, min(10, args.steps)),
                             traffic_ok=(args.workload == "c2" and not args.bf16))

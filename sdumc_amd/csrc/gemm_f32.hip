@@ -37,7 +37,7 @@ struct ProfRec {
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::mutex g_prof_mu;
-constexpr int kNumVariants = 23;
+constexpr int kNumVariants = 26;
 const char* const kVariantName[kNumVariants] = {"gemm_nt_128x128", "gemm_nt_64x64",  "gemm_nn_128x128",
                                                 "gemm_nn_64x64",   "gemm_tn_128x128", "gemm_tn_64x64",
                                                 "gemm_small_nt",   "gemm_small_nn",   "gemm_small_tn",
@@ -47,7 +47,9 @@ const char* const kVariantName[kNumVariants] = {"gemm_nt_128x128", "gemm_nt_64x6
                                                 "gemm_wide_nt", "gemm_wide_tn",
                                                 "gemm_bf16s_nt", "gemm_bf16s_tn",    // gemm_bf16.hip (bf16 storage)
                                                 "gemm_group_tn", "gemm_group_tn_bf16",    // gemm_group.hip (the persistent kernel alone, without its reduce)
-                                                "gemm_rows256", "gemm_rows256_bf16"};     // gemm_rows.hip
+                                                "gemm_rows256", "gemm_rows256_bf16",      // gemm_rows.hip
+                                                // fp32 operands, products on the bf16 matrix pipe from exactly split operands (sdumc_set_split_)
+                                                "gemm_wide_nt_bf16x3", "gemm_group_tn_bf16x3", "gemm_rows256_bf16x3"};
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;
@@ -889,7 +891,7 @@ extern "C" int sdumc_gemm_f32(const sdumc_gemm* gp, void* stream) {
     const bool wprof = g_prof_on;
     if (wprof) {
       if (hipEventCreate(&wrec.a) != hipSuccess || hipEventCreate(&wrec.b) != hipSuccess) return SDUMC_ELAUNCH;
-      wrec.variant = g.layout == SDUMC_TN ? 16 : 15;
+      wrec.variant = g.layout == SDUMC_TN ? 16 : (sdumc_split_on_(SDUMC_SPLIT_WIDE) ? 23 : 15);
       wrec.flops = 2.0 * g.M * (double)g.N * g.K * g.groups;
       (void)hipEventRecord(wrec.a, st);
     }

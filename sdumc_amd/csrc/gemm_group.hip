@@ -1271,7 +1271,7 @@ int gg_run(const sdumc_gg_problem* probs, int32_t n, void* workspace, size_t wor
     L.slab = static_cast<float*>(workspace);
     double flops = 0.0;
     for (int i = 0; i < cnt; ++i) flops += 2.0 * probs[first + i].M * (double)probs[first + i].N * ((double)probs[first + i].K[0] + probs[first + i].K[1]);
-    const int tok = sdumc_prof_begin_(hf ? 20 : 19, flops, stream);
+    const int tok = sdumc_prof_begin_(hf ? 20 : (split_products() ? 24 : 19), flops, stream);
     if (hf) hipLaunchKernelGGL(gg_tn_bf16_kernel, dim3(L.nwg), dim3(NTHR), hf::HNST * hf::HSTAGE, st, L);
     else if (wide) {
       hipLaunchKernelGGL(gg_tn_split2_kernel, dim3(L.nwg), dim3(NTHR), s2::LDS2, st, L);

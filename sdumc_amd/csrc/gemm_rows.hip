@@ -827,7 +827,7 @@ extern "C" int sdumc_gemm_rows256_capped_(const sdumc_rows_problem* probs, int32
   if ((long long)units * (L.nwg + 1) >= (1LL << 31)) return SDUMC_EINVAL;
   if (!set_lds_attr()) return SDUMC_ELAUNCH;
   hipStream_t st = as_stream(stream);
-  const int tok = sdumc_prof_begin_(21, flops, stream);
+  const int tok = sdumc_prof_begin_(sdumc_split_on_(SDUMC_SPLIT_ROWS) ? 25 : 21, flops, stream);
   if (sdumc_split_on_(SDUMC_SPLIT_ROWS)) {
     if (mask) hipLaunchKernelGGL((gr_split_kernel<true, false>), dim3(L.nwg), dim3(NTHR), sp::LDS_BYTES2, st, L);
     else if (accum) hipLaunchKernelGGL((gr_split_kernel<false, true>), dim3(L.nwg), dim3(NTHR), sp::LDS_BYTES2, st, L);

@@ -26,6 +26,17 @@ def short(name):
         return f"gemm_small_{lay}"
     if "gg_tn_bf16_kernel" in name:
         return "gemm_group_tn_bf16"
+    if "gg_tn_split" in name:                 # fp32 operands, products on the bf16 matrix pipe (both forms)
+        return "gemm_group_tn_bf16x3"
+    if "gr_split_kernel" in name:
+        return "gemm_rows256_bf16x3"
+    if "gr_bf16_kernel" in name:
+        return "gemm_rows256_bf16"
+    if "gr_kernel" in name:
+        return "gemm_rows256"
+    m = re.search(r"gemm_wide(_split)?_kernel<sdumc_wide::WideCfg<\d+, \d+, \d+, \d+, \d+, \d+, (true|false), (true|false)", name)
+    if m:
+        return "gemm_wide_" + ("nt" if m.group(2) == "true" else "tn") + ("_bf16x3" if m.group(1) else "")
     if "gg_tn_kernel" in name:
         return "gemm_group_tn"
     name = re.sub(r"\(anonymous namespace\)::", "", name)
