@@ -1257,8 +1257,10 @@ int forward(const Ctx& c) {
       }
       // few-row / long-K projections (the text slot: 2048 x 256 x 4096 per stream at C2) through the wide LDS-DMA kernel with K split
       // 8 ways over workgroups (512 of them, 32 k-tiles each) instead of the 64x64 register-staged kernel's automatic split:
-      // fp32 C2 step 1.665-1.669 vs 1.671-1.676 ms (split 4: 1.674-1.678, split 2: 1.705-1.710).  SDUMC_TEXT_WIDE=S: A/B, 0 = off
-      static const int text_wide = [] { const char* e = getenv("SDUMC_TEXT_WIDE"); return e ? atoi(e) : 8; }();
+      // fp32 C2 step 1.665-1.669 vs 1.671-1.676 ms (split 4: 1.674-1.678, split 2: 1.705-1.710).  With the products on the bf16
+      // matrix pipe the k-loop is shorter and half as many slabs win: split 4 1.424-1.438 against split 8 1.444-1.450 and split
+      // 2 1.440-1.450 (three alternations).  SDUMC_TEXT_WIDE=S: A/B, 0 = off
+      static const int text_wide = [] { const char* e = getenv("SDUMC_TEXT_WIDE"); return e ? atoi(e) : 4; }();
       const int rows_ms = B * pl.T[m][s];
       const bool wide_split = text_wide > 0 && !c.d.bf16 && rows_ms < 8192 && din[m] >= 2048 && (din[m] % (16 * text_wide)) == 0 && (rows_ms % 64) == 0;
       RET(lin_fwd(c, pm.frame[m], in, din[m], rows_ms, c.p(pl.x[m][s]), D, SDUMC_ACT_NONE, nullptr, c.d.bf16 != 0,
@@ -1709,7 +1711,8 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
       // this launch is still running -- crawled beside it (86-104 us instead of ~60); the early dX itself has slack until its
       // modality's mask-sum.  Measured, fp32 C2, three alternations on one box: 128 workgroups 1.670-1.680 ms, 64: 1.675-1.679,
       // 256 (every CU): 1.686-1.689, the tiled 64x64 kernel: 1.689-1.695.  (SDUMC_EARLY_DX: N workgroups, 0 = every CU, -1 = tiled)
-      static const int early_dx = [] { const char* e = getenv("SDUMC_EARLY_DX"); return e ? atoi(e) : 128; }();
+      // (round 4, rows launch on the bf16 matrix pipe: 160 workgroups 1.414-1.427 against 128 1.424-1.438 and 192 1.425-1.438)
+      static const int early_dx = [] { const char* e = getenv("SDUMC_EARLY_DX"); return e ? atoi(e) : 160; }();
       RET(keys_gemm_bwd(c, m, 1, 2, (ca_dw_mask & (1 << m)) ? 2 : 3, early_dx));
       if (lane == 3) RET(record_early(m));
       c.use(0);
