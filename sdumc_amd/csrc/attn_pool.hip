@@ -1486,14 +1486,8 @@ __global__ __launch_bounds__(256, 2) void umca_fwd_kernel(const sdumc_umca u, co
   extern __shared__ __attribute__((aligned(16))) char lds[];
   umca_fwd_body<MASK, false>(u, nchunk, lds);
 }
-// (no packed fp32 VALU operations beside bf16 MFMAs: gemm_group.hip has the reasons)
-#if defined(__HIP_DEVICE_COMPILE__)
-#define K3_NO_PACKED_FP32 __attribute__((target("no-packed-fp32-ops")))
-#else
-#define K3_NO_PACKED_FP32
-#endif
 template <bool MASK>
-__global__ __launch_bounds__(256, 2) K3_NO_PACKED_FP32 void umca_fwd_split_kernel(const sdumc_umca u, const int nchunk) {
+__global__ __launch_bounds__(256, 2) void umca_fwd_split_kernel(const sdumc_umca u, const int nchunk) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   umca_fwd_body<MASK, true>(u, nchunk, lds);
 }

@@ -2,15 +2,17 @@
 // stages with every layer's output columns split over a cluster of workgroups).  See chain.hip for the design notes.
 #pragma once
 
-// The utterance-level kernels are compiled WITHOUT packed FP32 VALU instructions (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32).
+// Packed FP32 VALU instructions (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32) and bf16 MFMAs on one CU.
 // Measured on MI355X (round 4: tools/fwd_determinism_probe.py, profiles/README.md): when a workgroup of these kernels shares a CU
-// with a workgroup of the bf16 MFMA GEMM (v_mfma_f32_32x32x16_bf16 -- the Cross_Attention key projections that run beside stage A
-// in bf16-storage mode), the LOW half of some v_pk_fma_f32 results comes out wrong: 26-56 of 299 forwards differed from the fp64
-// truth in a few even-numbered output columns of a layer; 0 of 3 x 299 without packed ops, 0 of 2 x 299 when the two kernels
-// cannot share a CU (LDS padding), 0 of 199 in fp32 storage (fp32 MFMA neighbours).  Inputs were verified intact inside the kernel
-// (weights in registers against agent-scope reloads, the LDS copy of the input rows against global memory).  The kernels are
-// latency-bound, not VALU-bound: the flag costs nothing measurable.  (A function attribute on the device pass, not a compiler flag: the flag also
-// reaches the host pass, which warns about it.)
+// with a workgroup of a bf16 MFMA GEMM (v_mfma_f32_32x32x16_bf16 -- the Cross_Attention key projections that run beside stage A),
+// the LOW half of some v_pk_fma_f32 results comes out wrong: 26-56 of 299 forwards differed from the fp64 truth in a few
+// even-numbered output columns of a layer; 0 of 3 x 299 without packed ops, 0 of 2 x 299 when the two kernels cannot share a CU
+// (LDS padding), 0 of 199 with fp32-MFMA neighbours.  Inputs were verified intact inside the kernel (weights in registers against
+// agent-scope reloads, the LDS copy of the input rows against global memory).
+// The whole library is now built without packed fp32 operations (Makefile, NOPACK: since the fp32 GEMMs compute their products on
+// the bf16 matrix pipe every kernel has such neighbours, and the pooling kernels showed the same symptom).  The attribute below
+// and the "_np_" entry points it marks (selected by sdumc_chain_args.no_packed_fp32) predate that flag; under it both entry points
+// of a stage compile to the same code.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define SDUMC_NO_PACKED_FP32 __attribute__((target("no-packed-fp32-ops")))
 #else

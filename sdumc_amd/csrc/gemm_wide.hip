@@ -426,14 +426,8 @@ __global__ __launch_bounds__(CF::NTHR, CF::OCC) void gemm_wide_kernel(const sdum
   extern __shared__ __attribute__((aligned(16))) char lds[];
   gemm_wide_body<CF, MASK, CS, false>(g, nsplit, kchunk, lds);
 }
-// (no packed fp32 VALU operations beside bf16 MFMAs: gemm_group.hip has the reasons)
-#if defined(__HIP_DEVICE_COMPILE__)
-#define WIDE_NO_PACKED_FP32 __attribute__((target("no-packed-fp32-ops")))
-#else
-#define WIDE_NO_PACKED_FP32
-#endif
 template <class CF, bool MASK>
-__global__ __launch_bounds__(CF::NTHR, CF::OCC) WIDE_NO_PACKED_FP32 void gemm_wide_split_kernel(const sdumc_gemm g, const int nsplit, const int kchunk) {
+__global__ __launch_bounds__(CF::NTHR, CF::OCC) void gemm_wide_split_kernel(const sdumc_gemm g, const int nsplit, const int kchunk) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
   gemm_wide_body<CF, MASK, false, true>(g, nsplit, kchunk, lds);
 }
