@@ -2,6 +2,8 @@
 (torch fp32/fp64 on the host).  Tolerances: fp32 1e-3 is the north-star bar;
 these tests hold the kernels to 1e-4 or tighter.  Dropout masks, RnC masks and
 index math are bit-exact."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -323,7 +325,7 @@ def test_umca_fused_forward_k3(ops, nq, T, shared_q, mask):
         out_f, attn_f, pooled_f, keys_f, _ = ops.umca_fwd(xg, Wg, bg, qg, nq, x_samples=B, q_shared=shared_q,
                                                           x_drop=xdrop if mask else None, out_drop=odrop, V=V)
     finally:
-        _lib.lib.sdumc_set_split_(15)
+        _lib.lib.sdumc_set_split_(int(os.environ.get("SDUMC_SPLIT", "15")))      # (the session's default, as tests/conftest.py restores it)
     close(keys_f, keys2, 1e-6)
     close(out_f, out2, 2e-6)
     close(attn_f, attn2, 2e-6)
