@@ -234,11 +234,11 @@ def hbm_roofline_bf16(ms_per_step, mfma):
             "kernel": "whole step (HBM-side bytes of every launch)", "mfma": mfma}
 
 
-def c3_bf16_side_leg(engine, flat, batch, args):
+def c3_bf16_side_leg(engine, flat0, batch, args):
     """BASELINE configs[2] (MOSEI shapes, B = 64, text-missing stream + self-distillation, bf16) under the same clock as the
     headline: the bf16-storage step on the same batch, same --steps / --warmup, timed the same way, right after the headline's
     timed region.  A side block of the one JSON line; the headline keys stay those of configs[1]."""
-    step = engine.TrainStep(flat.clone(), B_PER_GPU, T_MOSEI, DIMS, seed=2024, bf16=True)
+    step = engine.TrainStep(flat0.clone(), B_PER_GPU, T_MOSEI, DIMS, seed=2024, bf16=True)
     step.set_batch(*batch)
     for _ in range(args.warmup):
         step.run()
@@ -260,13 +260,15 @@ def c3_bf16_side_leg(engine, flat, batch, args):
             "steps": args.steps, "warmup": args.warmup, "final_loss": round(float(losses[0]), 5), "roofline": roof}
 
 
-def c2_f32_mfma_side_leg(engine, _lib, flat, batch, args):
+def c2_f32_mfma_side_leg(engine, _lib, flat0, batch, args, headline_losses):
     """The headline step with every GEMM product on v_mfma_f32_32x32x2_f32 (sdumc_set_split_(0)): what the default's products on
-    the bf16 matrix pipe buy, under the same clock."""
+    the bf16 matrix pipe buy, under the same clock.  It starts from a clone of the INITIAL parameters and runs the same number of
+    steps as the headline, so `loss_abs_diff_vs_headline` is a driver-run cross-check of the split arithmetic against the f32 MFMAs."""
     lib = _lib.lib
+    prev = split_mask_default()
     try:
         lib.sdumc_set_split_(0)
-        step = engine.TrainStep(flat.clone(), B_PER_GPU, T_MOSEI, DIMS, seed=2024)
+        step = engine.TrainStep(flat0.clone(), B_PER_GPU, T_MOSEI, DIMS, seed=2024)
         step.set_batch(*batch)
         for _ in range(args.warmup):
             step.run()
@@ -278,12 +280,42 @@ def c2_f32_mfma_side_leg(engine, _lib, flat, batch, args):
         dt = time.perf_counter() - t0
         losses = step.losses.cpu()
     finally:
-        lib.sdumc_set_split_(15)
+        lib.sdumc_set_split_(prev)
     if not torch.isfinite(losses).all():
         raise SystemExit(f"non-finite loss in the f32-MFMA side leg: {losses.tolist()}")
     return {"workload": "the headline step with sdumc_set_split_(0): every GEMM product on v_mfma_f32_32x32x2_f32",
             "value": round(B_PER_GPU * args.steps / dt, 2), "unit": "samples/s", "ms_per_step": round(1e3 * dt / args.steps, 4),
-            "steps": args.steps, "warmup": args.warmup, "final_loss": round(float(losses[0]), 5)}
+            "steps": args.steps, "warmup": args.warmup, "final_loss": round(float(losses[0]), 5),
+            "loss_abs_diff_vs_headline": round(abs(float(losses[0]) - float(headline_losses[0])), 7),
+            "loss_terms_max_abs_diff_vs_headline": round(float((losses[:7] - headline_losses[:7]).abs().max()), 7)}
+
+
+def split_mask_default():
+    """The process default of the split switch (environment SDUMC_SPLIT, else every kernel family)."""
+    try:
+        return int(os.environ.get("SDUMC_SPLIT", "15"))
+    except ValueError:
+        return 15
+
+
+def prewarm_leg(engine, flat0, batch, bf16, min_s):
+    """Wall-clock pre-warm: a THROWAWAY step object runs the same step until `min_s` seconds have passed, so that the timed
+    steps are not read while the chip is still ramping its clock (~0.1 s from idle: profiles/README.md, round 3).  The headline
+    step object starts from the initial parameters and step counter afterwards."""
+    if min_s <= 0:
+        return 0.0, 0
+    st = engine.TrainStep(flat0.clone(), B_PER_GPU, T_MOSEI, DIMS, seed=2024, bf16=bf16)
+    st.set_batch(*batch)
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < min_s:
+        for _ in range(8):
+            st.run()
+        n += 8
+        torch.cuda.synchronize()
+    del st
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0, n
 
 
 def recorded_traffic(kernel):
@@ -411,6 +443,8 @@ def main():
                     help="c2 = BASELINE configs[1], the configuration the metric is quoted on (default); c1 / c5 / c5g = side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--prewarm-s", type=float, default=0.3,
+                    help="seconds of untimed steps on a throwaway step object before --warmup (clock ramp; 0 = off)")
     ap.add_argument("--no-side", action="store_true", help="skip the configs[2] (bf16 storage) side leg of the default line (profiling runs)")
     args = ap.parse_args()
     global B_PER_GPU, T_MOSEI, DIMS, TRAIN_FLOPS_PER_SAMPLE, WORKLOAD_TEXT
@@ -463,6 +497,8 @@ def main():
         print(json.dumps(epoch_leg(args, engine, flat, lay, dev)), flush=True)
         return
     batch = [t.to(dev) for t in synthetic_shard(B_PER_GPU, rank)]
+    flat0 = flat.clone()          # the initial parameters: what the side legs start from (the step updates `flat` in place)
+    prewarm_s, prewarm_steps = prewarm_leg(engine, flat0, batch, args.bf16, args.prewarm_s)
 
     if world == 1 and not force_dp:
         step = engine.TrainStep(flat, B_PER_GPU, T_MOSEI, DIMS, seed=2024, bf16=args.bf16)
@@ -521,6 +557,7 @@ def main():
     out = {
         "metric": "train samples/sec at MOSEI feature shapes (two-stream forward + 6-term loss + backward + Adam)",
         "value": round(value, 2), "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "prewarm_s": round(prewarm_s, 3), "prewarm_steps": prewarm_steps,
         "ms_per_step": round(1e3 * dt / args.steps, 4), "host_enqueue_ms_per_step": round(1e3 * t_enq / args.steps, 4),
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16 storage of features / frames / keys / frame-level gradients with f32 accumulation; f32 softmax, utterance-level layers, losses and Adam (f32 master weights)" if args.bf16 else "f32", "data": "synthetic",
@@ -538,8 +575,8 @@ def main():
     if dp_extra is not None:
         out["data_parallel"] = dp_extra
     if world == 1 and not force_dp and args.workload == "c2" and not args.bf16 and not args.graph and not args.serial_lanes and not args.no_side:
-        out["side"] = {"c3_bf16": c3_bf16_side_leg(engine, flat, batch, args),
-                       "c2_f32_mfma": c2_f32_mfma_side_leg(engine, _lib, flat, batch, args)}
+        out["side"] = {"c3_bf16": c3_bf16_side_leg(engine, flat0, batch, args),
+                       "c2_f32_mfma": c2_f32_mfma_side_leg(engine, _lib, flat0, batch, args, losses)}
     if not args.no_roofline:     # every rank runs it (the DP step has collectives); rank 0 reports
         roof = roofline_leg(_lib, step.launch if (world == 1 and not force_dp) else step.step, max(3, min(10, args.steps)),
                             traffic_ok=(args.workload == "c2" and not args.bf16))

@@ -194,8 +194,29 @@ int sdumc_gemm_group_tn_bf16(const sdumc_gg_problem* probs, int32_t n, void* wor
  * Measurement / test hook, process-wide: bit 0 the grouped weight-gradient launch (sdumc_gemm_group_tn), bit 1 the wide-tile NT
  * launches of the GEMM entry point (frame / key projections), bit 2 the key projection inside sdumc_umca_fwd, bit 3
  * sdumc_gemm_rows256.
- * Default all (environment SDUMC_SPLIT); 0 = every product on the fp32 MFMAs. */
+ * Default all (environment SDUMC_SPLIT); 0 = every product on the fp32 MFMAs.
+ *
+ * CONTRACT AT THE EDGES of the split kernels (tests/test_split_arithmetic.py restates it on the CPU, tests/test_gpu_split.py holds
+ * each kernel family to it; x = any operand element, fp32 MFMA = what sdumc_set_split_(0) returns):
+ *   - finite x with |x| < 0x1.FEp127 (3.3895e38): as documented above.  -0 behaves as +0 in a product sum (as in fp32).
+ *   - NaN operand -> NaN in every output element its row / column feeds (same as the fp32 MFMAs).
+ *   - +-Inf operand -> NaN there (the fp32 MFMAs keep +-Inf unless 0 * Inf or Inf - Inf occurs): the first part is Inf, the residual
+ *     Inf - Inf is NaN.  A step that meets an infinity is lost either way (NaN loss; Adam then spreads it).
+ *   - finite |x| >= 0x1.FEp127 (within half a bf16 ulp of FLT_MAX: 3.3895e38 .. 3.4028e38) rounds to Inf in its first part and is
+ *     treated like Inf: NaN.  The fp32 MFMAs overflow for such values as soon as |x * b| >= 2^128.
+ *   - tiny values: bf16 has fp32's exponent range but its subnormals stop at 2^-133, and the matrix pipe may flush subnormal
+ *     inputs.  |x| >= 2^-102: every non-zero part is a normal bf16 -- exact as above.  Below: a part under 2^-126 may be lost, the
+ *     absolute error of such an x is < 2^-125 (of a product: < 2^-125 |b|) -- nothing on this path (features ~N(0,1), weights
+ *     ~1e-2, gradients >= 1e-20) comes near it.
+ * No clamping is done: the kernels do not spend VALU work on values a training step cannot survive anyway.
+ *
+ * The switch is an option of the execution context -- sdumc_ctx_set_option(ctx, SDUMC_OPT_SPLIT, mask): the network-level calls made
+ * with that context then take it (two contexts can hold different arithmetic, nothing process-wide changes).
+ * sdumc_set_split_ sets the PROCESS DEFAULT used by contexts without the option and by the stand-alone kernel entry points (deprecated
+ * as a control for network-level calls; kept for kernel-level tests and benches); sdumc_get_split_ returns the mask in force for the
+ * calling thread (the default, or the context's inside a network-level call). */
 void sdumc_set_split_(int mask);
+int sdumc_get_split_(void);
 
 /* ------------------------------------------------------------------------
  * The tall 256 x 256 products of the frame-level part in one persistent launch (gemm_rows.hip):
@@ -683,8 +704,9 @@ int sdumc_ctx_destroy(void* ctx);
  * process-wide default (the sdumc_set_* calls below, kept for callers without a context).
  *   SDUMC_OPT_CONCURRENCY      0 = every launch on the caller's stream (per-kernel profiling), 1 = the internal lanes
  *   SDUMC_OPT_BACKGROUND_LANE  0 / 2 / 3 as sdumc_set_background_lane
- *   SDUMC_OPT_CHAIN_CLUSTER    0 = csrc/chain.hip's kernels, 1 = the clustered ones wherever the shape fits */
-enum { SDUMC_OPT_CONCURRENCY = 0, SDUMC_OPT_BACKGROUND_LANE = 1, SDUMC_OPT_CHAIN_CLUSTER = 2 };
+ *   SDUMC_OPT_CHAIN_CLUSTER    0 = csrc/chain.hip's kernels, 1 = the clustered ones wherever the shape fits
+ *   SDUMC_OPT_SPLIT            0..15: which fp32 GEMM kernel families multiply on the bf16 matrix pipe (bits as sdumc_set_split_) */
+enum { SDUMC_OPT_CONCURRENCY = 0, SDUMC_OPT_BACKGROUND_LANE = 1, SDUMC_OPT_CHAIN_CLUSTER = 2, SDUMC_OPT_SPLIT = 3 };
 int sdumc_ctx_set_option(void* ctx, int32_t option, int32_t value);
 
 /* The network-level calls issue independent branches (the three per-modality chains; the dW GEMMs) on up to

@@ -178,6 +178,7 @@ _SIGS = {
     "sdumc_gemm_group_bf16_workspace_bytes": (C.c_size_t, [C.POINTER(GGProblem), C.c_int32]),
     "sdumc_gemm_group_tn_bf16": (C.c_int, [C.POINTER(GGProblem), C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sdumc_set_split_": (None, [C.c_int]),
+    "sdumc_get_split_": (C.c_int, []),
     "sdumc_gemm_rows256": (C.c_int, [C.POINTER(RowsProblem), C.c_int32, C.c_void_p]),
     "sdumc_gemm_rows256_bf16": (C.c_int, [C.POINTER(RowsProblem), C.c_int32, C.c_void_p]),
     "sdumc_attnpool_fwd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),

@@ -124,6 +124,7 @@ int sdumc_gemm_rows_prepare_(void);       // gemm_rows.hip: the kernels' per-dev
 #define SDUMC_SPLIT_ROWS 8    /* gemm_rows.hip */
 #define SDUMC_SPLIT_ALL 15
 int sdumc_split_on_(int bit);
+int sdumc_split_scope_(int mask);   // this host thread's override for the duration of a network-level call (-1 = none); returns the previous value
 int sdumc_gemm_rows256_capped_(const sdumc_rows_problem* probs, int32_t n, int32_t max_wg, void* stream);   // sdumc_gemm_rows256 on <= max_wg workgroups
 int sdumc_gemm_rows256_bf16_capped_(const sdumc_rows_problem* probs, int32_t n, int32_t max_wg, void* stream);
 int sdumc_chain_transpose_(const float* src, float* dst, const int64_t* offs, const int32_t* outs, const int32_t* ins, int n,

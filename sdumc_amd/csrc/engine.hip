@@ -198,6 +198,8 @@ struct Plan {
   int64_t wh = 0, wht = 0;   // [live] bf16 each: weights as stored / transposed (input_proj only), parameter offsets
   int64_t tickets = 0;   // per-sample arrival counters of the attention kernels
   int64_t fold_ws[2][3] = {{0, 0, 0}, {0, 0, 0}};   // softmax partials of site (k, m), kept until the clustered stage behind them has combined them (fra_fold)
+  int64_t dq_ws = 0;        // per-chunk dq slabs of the grouped Cross_Attention pooling backward, kept until the clustered stage 7'-3' has summed them
+                            // (their own allocation: with one lane every "lane" shares scratch[0], and early_keys() may use it in between)
   int64_t scratch[4] = {0, 0, 0, 0}, scratch_floats = 0;   // one scratch per lane (stream)
   int64_t gg_slab[2] = {0, 0}, gg_slab_floats[2] = {0, 0}; // partial-tile slabs of the grouped dW launches: [0] lane 3, [1] the frame dW
   int64_t alloc(int64_t n) {
@@ -336,6 +338,13 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
   for (int k = 0; k < 2; ++k)
     for (int m = 0; m < 3; ++m)
       p.fold_ws[k][m] = p.alloc((int64_t)(sdumc_attnpool_fwd_workspace_bytes(V, p.segs[m][0].T, nq[k]) / sizeof(float)));
+  {
+    int64_t sum = 0;
+    for (int m = 0; m < 3; ++m)
+      for (const Seg& sg : p.segs[m])
+        sum += ((int64_t)(sdumc_attnpool_bwd_workspace_bytes(sg.V, sg.T, NQ) / sizeof(float)) + 63) / 64 * 64;
+    p.dq_ws = p.alloc(sum);
+  }
   p.wt = p.alloc(build_params(d.da, d.dt, d.dv).live);   // transposed mirror: utterance-level layers (chain) + the six input_proj
   if (p.hf) {
     const int64_t live = build_params(d.da, d.dt, d.dv).live;
@@ -398,6 +407,7 @@ struct LaneSet {
   // per-context schedule options (sdumc_ctx_set_option); -1 = the process-wide default (sdumc_set_concurrency / _background_lane /
   // _chain_cluster, kept as the defaults of contexts that set nothing)
   int opt_concurrency = -1, opt_background = -1, opt_chain_cluster = -1;
+  int opt_split = -1;   // SDUMC_OPT_SPLIT: which fp32 GEMM families multiply on the bf16 matrix pipe inside this context's calls
 };
 // Debug timeline (tools/step_marks.py): sdumc_debug_marks(1) makes the step record an event on the caller's stream at a few
 // fixed points; sdumc_debug_marks_read returns their times since mark 0.  Process-wide, single-threaded use only.
@@ -463,6 +473,19 @@ LaneSet* default_lanes() {
   return S;
 }
 void ensure_side_streams() { (void)default_lanes(); }
+
+// the context's split option for the duration of one network-level call (thread-local: the launchers ask sdumc_split_on_)
+struct SplitScope {
+  int prev = -1;
+  bool on = false;
+  explicit SplitScope(const sdumc_net_io* io) {
+    const LaneSet* S = !io ? nullptr : (io->ctx ? static_cast<const LaneSet*>(io->ctx) : default_lanes());
+    if (S && S->opt_split >= 0) { prev = sdumc_split_scope_(S->opt_split); on = true; }
+  }
+  ~SplitScope() { if (on) sdumc_split_scope_(prev); }
+  SplitScope(const SplitScope&) = delete;
+  SplitScope& operator=(const SplitScope&) = delete;
+};
 
 struct Ctx {
   const sdumc_net_dims& d;
@@ -1779,7 +1802,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   if (grouped) {   // one grouped launch on the caller's stream, then the early key-projection backwards leave for their lanes
     sdumc_attnpool_bwd_t bb[4];
     int n = 0;
-    float* ws = c.scr;
+    float* ws = fra_fold(c) ? c.p(pl.dq_ws) : c.scr;   // folded: the slabs outlive this launch (stage 7'-3' sums them)
     const int order[3] = {0, 2, 1};
     for (int oi = 0; oi < 3; ++oi) {
       const int m = order[oi];
@@ -1800,7 +1823,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
         const size_t bytes = sdumc_attnpool_bwd_workspace_bytes(sg.V, sg.T, NQ);
         b.workspace = ws;
         b.workspace_bytes = bytes;
-        if (fra_fold(c)) {      // the clustered stage 7'-3' right behind this launch sums the chunks (this lane's scratch is untouched in between)
+        if (fra_fold(c)) {      // the clustered stage 7'-3' behind this launch sums the chunks
           b.f.partial_only = 1;
           c.dq_part[m] = ws;
           c.dq_nchunk[m] = (sg.T + 63) / 64;
@@ -2169,6 +2192,10 @@ extern "C" int sdumc_ctx_set_option(void* ctx, int32_t option, int32_t value) {
       S->opt_background = value < 0 ? -1 : value;
       break;
     case SDUMC_OPT_CHAIN_CLUSTER: S->opt_chain_cluster = value < 0 ? -1 : (value != 0); break;
+    case SDUMC_OPT_SPLIT:
+      if (value > SDUMC_SPLIT_ALL) return SDUMC_EINVAL;
+      S->opt_split = value < 0 ? -1 : value;
+      break;
     default: return SDUMC_EINVAL;
   }
   return SDUMC_OK;
@@ -2208,6 +2235,7 @@ extern "C" size_t sdumc_net_workspace_bytes(const sdumc_net_dims* d) {
 
 extern "C" int sdumc_net_forward(const sdumc_net_dims* d, const sdumc_net_io* io, void* stream) {
   RET(check_io(d, io));
+  const SplitScope split_scope(io);
   Ctx c{*d, *io, as_stream(stream), build_params(d->da, d->dt, d->dv), Plan(), nullptr, nullptr, nullptr};
   if (!make_plan(*d, c.pl)) return SDUMC_EINVAL;
   if (io->workspace_bytes < (size_t)c.pl.cur * sizeof(float)) return SDUMC_ENOMEM;
@@ -2220,6 +2248,7 @@ extern "C" int sdumc_net_forward(const sdumc_net_dims* d, const sdumc_net_io* io
 extern "C" int sdumc_net_backward(const sdumc_net_dims* d, const sdumc_net_io* io, const sdumc_net_grads* g,
                                   void* stream) {
   RET(check_io(d, io));
+  const SplitScope split_scope(io);
   if (!g || !g->grads || (reinterpret_cast<uintptr_t>(g->grads) & 15)) return SDUMC_EINVAL;
   Ctx c{*d, *io, as_stream(stream), build_params(d->da, d->dt, d->dv), Plan(), nullptr, nullptr, nullptr};
   if (!make_plan(*d, c.pl)) return SDUMC_EINVAL;
@@ -2234,6 +2263,7 @@ extern "C" int sdumc_net_backward(const sdumc_net_dims* d, const sdumc_net_io* i
 extern "C" int sdumc_net_backward_phase(const sdumc_net_dims* d, const sdumc_net_io* io, const sdumc_net_grads* g,
                                         int32_t phase, void* stream) {
   RET(check_io(d, io));
+  const SplitScope split_scope(io);
   if (!g || !g->grads || (reinterpret_cast<uintptr_t>(g->grads) & 15) || phase < 0 || phase > 1) return SDUMC_EINVAL;
   Ctx c{*d, *io, as_stream(stream), build_params(d->da, d->dt, d->dv), Plan(), nullptr, nullptr, nullptr};
   if (!make_plan(*d, c.pl)) return SDUMC_EINVAL;

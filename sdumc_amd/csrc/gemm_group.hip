@@ -1292,14 +1292,25 @@ extern "C" int sdumc_gemm_group_tn_bf16(const sdumc_gg_problem* probs, int32_t n
 // ---- which fp32 GEMM kernels compute their products on the bf16 matrix pipe (SDUMC_SPLIT_* bits; environment SDUMC_SPLIT) ----
 namespace {
 std::atomic<int> g_split_mask{-1};
+// the mask of the network-level call this host thread is inside (sdumc_ctx_set_option(SDUMC_OPT_SPLIT): engine.hip opens a scope
+// around forward / backward / step), -1 outside: every launcher of such a call then sees the CONTEXT's arithmetic, two contexts
+// can hold different ones, and nothing process-wide changes
+thread_local int tl_split_scope = -1;
 }
-extern "C" int sdumc_split_on_(int bit) {
+extern "C" int sdumc_get_split_(void) {
+  if (tl_split_scope >= 0) return tl_split_scope;
   int v = g_split_mask.load(std::memory_order_relaxed);
   if (v < 0) {
     const char* e = getenv("SDUMC_SPLIT");
     v = e ? (atoi(e) & SDUMC_SPLIT_ALL) : SDUMC_SPLIT_ALL;
     g_split_mask.store(v, std::memory_order_relaxed);
   }
-  return (v & bit) != 0;
+  return v;
 }
+extern "C" int sdumc_split_on_(int bit) { return (sdumc_get_split_() & bit) != 0; }
 extern "C" void sdumc_set_split_(int mask) { g_split_mask.store(mask & SDUMC_SPLIT_ALL, std::memory_order_relaxed); }
+extern "C" int sdumc_split_scope_(int mask) {      // returns the previous scope value (restore with it)
+  const int prev = tl_split_scope;
+  tl_split_scope = mask < 0 ? -1 : (mask & SDUMC_SPLIT_ALL);
+  return prev;
+}

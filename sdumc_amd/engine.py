@@ -106,11 +106,12 @@ class ExecContext:
         check(lib.sdumc_ctx_create(C.byref(h)), "sdumc_ctx_create")
         self.handle = h
 
-    OPTIONS = {"concurrency": 0, "background_lane": 1, "chain_cluster": 2}
+    OPTIONS = {"concurrency": 0, "background_lane": 1, "chain_cluster": 2, "split": 3}
 
     def set_option(self, name, value):
         """Schedule options of THIS context only (sdumc_ctx_set_option): 'concurrency' 0 | 1, 'background_lane' 0 | 2 | 3,
-        'chain_cluster' 0 | 1; None (or a negative value) returns the option to the process-wide default."""
+        'chain_cluster' 0 | 1, 'split' 0..15 (which fp32 GEMM kernel families multiply on the bf16 matrix pipe: sdumc_hip.h,
+        sdumc_set_split_); None (or a negative value) returns the option to the process-wide default."""
         check(lib.sdumc_ctx_set_option(self.handle, self.OPTIONS[name], -1 if value is None else int(value)), "sdumc_ctx_set_option")
 
     def close(self):

@@ -79,3 +79,58 @@ def test_a_dot_product_on_six_terms_is_as_accurate_as_the_fp32_fma_chain():
     # (this emulation rounds after EVERY one of the 6 K additions -- an upper bound on what an MFMA's block sum of 16 products per
     #  instruction commits; on the GPU the six-term kernels measure as close to fp64 as the fp32-MFMA kernels, tests/test_gpu_split.py)
     assert e_six < 1e-6 and e_six <= 4.0 * e_chain + 1e-8, (e_chain, e_six)
+
+
+def six_term_product(a, b):
+    """the six kept part products of a * b summed in fp32, smallest first (what one k step of the kernels adds)"""
+    pa, pb = split3(a)[:3], split3(b)[:3]
+    acc = torch.zeros_like(a)
+    for x, y in ((2, 0), (0, 2), (1, 1), (1, 0), (0, 1), (0, 0)):
+        acc = acc + pa[x] * pb[y]
+    return acc
+
+
+def test_contract_at_the_edges_of_the_split():
+    """include/sdumc_hip.h, "CONTRACT AT THE EDGES": what the split arithmetic returns for NaN, +-Inf, values that round to Inf in
+    bf16, -0 and tiny values -- restated on the CPU (the GPU cases are in tests/test_gpu_split.py)."""
+    FLT_MAX = float(np.finfo(np.float32).max)
+    one = torch.tensor([1.5])
+    # NaN stays NaN
+    assert torch.isnan(six_term_product(torch.tensor([float("nan")]), one)).all()
+    # +-Inf -> NaN (the first part is Inf, the residual Inf - Inf is NaN); the fp32 product would be +-Inf
+    for v in (float("inf"), -float("inf")):
+        a0, a1, a2, r1, r2 = split3(torch.tensor([v]))
+        assert torch.isinf(a0).all() and torch.isnan(r1).all()
+        assert torch.isnan(six_term_product(torch.tensor([v]), one)).all()
+        assert torch.isinf(torch.tensor([v]) * one).all()
+    # the largest fp32 whose first part is still finite: 0x7F7F7FFF (just below 0x1.FEp127 + half a bf16 ulp); above it -> Inf -> NaN
+    edge_ok = torch.tensor([0x7F7F7FFF], dtype=torch.int32).view(torch.float32)
+    edge_bad = torch.tensor([0x7F7F8000], dtype=torch.int32).view(torch.float32)
+    assert float(edge_bad) > 3.3895e38 and float(edge_bad) < FLT_MAX
+    a0, a1, a2, r1, r2 = split3(edge_ok)
+    assert torch.isfinite(a0).all() and torch.equal((a0.double() + a1.double() + a2.double()), edge_ok.double())
+    assert torch.isinf(split3(edge_bad)[0]).all()
+    assert torch.isnan(six_term_product(edge_bad, torch.tensor([1e-3]))).all()      # fp32: a finite 3.39e35
+    assert torch.isnan(six_term_product(torch.tensor([FLT_MAX]), torch.tensor([1e-3]))).all()
+    # -0 and +0: every part is a zero, the product sum is a zero
+    for z in (0.0, -0.0):
+        parts = split3(torch.tensor([z]))[:3]
+        assert all(float(p) == 0.0 for p in parts)
+        assert float(six_term_product(torch.tensor([z]), one)) == 0.0
+    # tiny values.  bf16 has fp32's exponent range but its subnormals stop at 2^-133 (fp32: 2^-149), and the matrix pipe may flush
+    # subnormal bf16 inputs.  (i) |x| >= 2^-102: every non-zero part is a multiple of ulp(x) >= 2^-125, i.e. a NORMAL bf16: exact,
+    # flush or not.  (ii) below: a part under 2^-126 may be lost: absolute error per value < 2^-125.
+    g = torch.Generator().manual_seed(11)
+    x = torch.cat([torch.randn(20000, generator=g) * 2.0 ** -101, torch.tensor([2.0 ** -102, -(2.0 ** -102) * (1 + 2.0 ** -23)])])
+    x = x[x.abs() >= 2.0 ** -102]
+    a0, a1, a2, _, _ = split3(x)
+    assert torch.equal(a0.double() + a1.double() + a2.double(), x.double())
+    for part in (a0, a1, a2):
+        nz = part != 0
+        assert (part[nz].abs() >= 2.0 ** -126).all(), "a part of a value >= 2^-102 must be a normal bf16"
+    tiny = torch.cat([torch.randn(20000, generator=g) * 2.0 ** -120, torch.tensor([1.1e-36, -3.3e-38, 1e-40, 2.0 ** -126, 2.0 ** -149])])
+    parts = split3(tiny)[:3]
+    flushed = [torch.where(p.abs() < 2.0 ** -126, torch.zeros_like(p), p) for p in parts]
+    for ps in (parts, flushed):
+        err = (ps[0].double() + ps[1].double() + ps[2].double() - tiny.double()).abs()
+        assert float(err.max()) < 2.0 ** -125
