@@ -219,6 +219,50 @@ void sdumc_set_split_(int mask);
 int sdumc_get_split_(void);
 
 /* ------------------------------------------------------------------------
+ * fp32 GEMM on operands split ONCE PER TENSOR into three bf16 planes (csrc/gemm_p3.hip).  Replaces F.linear of
+ * frame_dim_reshape_{0,1,2} (model :193-195, :282-284) and of input_proj in FRA2UTT_new / Cross_Attention (model :60, :82) in
+ * the fp32 step: same arithmetic as the split kernels above (six bf16 x bf16 part products per fp32 product, fp32 accumulation,
+ * same edge contract), but the split is paid where a tensor is PRODUCED -- sdumc_p3_split for the features (once per batch; they
+ * do not change across epochs) and the weights (once per step), the epilogue of this GEMM for the projected frames -- instead of
+ * per workgroup per k-tile.
+ * P3 layout of a row-major X[rows][K], K % 8 == 0: row r = 6 K bytes at r * ld_bytes; chunk c (48 bytes) holds k = 8 c .. 8 c + 7
+ * as [plane 0: 8 bf16][plane 1][plane 2]; p0 = bf16(x) (round to nearest even), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1);
+ * x == (p0 + p1) + p2 exactly for finite |x| < 0x1.FEp127 (edges: see sdumc_set_split_).  1.5x the bytes of the fp32 tensor.
+ * The weight operand of the NT product is stored FRAGMENT-MAJOR (sdumc_p3_split_frag): [N / 32][K / 16][3 planes][64 lanes][16 bytes],
+ * lane (li = lane & 31, lh = lane >> 5) of block (rb, kt) holds W[32 rb + li][16 kt + 8 lh .. + 7] -- a wavefront's MFMA operand of a
+ * k-tile is three contiguous KiB, loaded straight into registers (the weight never passes through LDS: only the wave that owns the
+ * 32 output columns multiplies them).
+ *   NT:  C[M, N] = act((A . keep)[M, K] . B[N, K]^T * a_scale + bias),  N % 256 == 0, K % 64 == 0
+ * ---------------------------------------------------------------------- */
+typedef struct sdumc_gemm_p3 {
+  int32_t M, N, K;
+  const void* A;            /* P3 [M or a_row_mod rows][K], row stride lda BYTES (>= 6 K, multiple of 16; operand below 4 GiB) */
+  const void* B;            /* fragment-major P3 of the weight [N][K] (sdumc_p3_split_frag) */
+  int64_t lda, ldb;         /* ldb: bytes between two 32-row blocks of B (>= K / 16 * 3072) */
+  int32_t a_row_mod;        /* >0: A's source row = m % a_row_mod (the two streams share x_audio / x_video) */
+  const uint8_t* a_bits;    /* optional keep-bits of a dropout fused on A: byte [m * bits_qw + k/4], bit k%4 (rows = VIRTUAL rows m) */
+  int32_t bits_qw;          /* bytes per row of a_bits (>= K/4, multiple of 4) */
+  float a_scale;            /* 1 / (1 - p); read only with a_bits */
+  const float* bias;        /* [N] or NULL */
+  int32_t act;              /* SDUMC_ACT_* */
+  float* C;                 /* fp32 [M][N], row stride ldc floats; may be NULL when C_p3 is given */
+  int32_t ldc;
+  void* C_p3;               /* optional: the same values as a P3 tensor, row stride ldc_p3 bytes (>= 6 N) */
+  int64_t ldc_p3;
+  int32_t splitk;           /* 0 auto, 1 none, > 1: K split over workgroups (fp32 slabs in workspace + an ordered reduce) */
+  int32_t tile_m;           /* 0 auto (64 / 96 / 128 rows per workgroup, whichever fills 256 CUs in whole rounds) */
+  float* workspace;         /* >= sdumc_gemm_p3_workspace_bytes */
+  size_t workspace_bytes;
+} sdumc_gemm_p3;
+size_t sdumc_gemm_p3_workspace_bytes(const sdumc_gemm_p3* g);
+int sdumc_gemm_p3_nt(const sdumc_gemm_p3* g, void* stream);
+/* fp32 [rows][cols] (row stride ld floats, cols % 8 == 0, 16-byte aligned) <-> P3 (row stride ld_bytes); join is bit-exact */
+int sdumc_p3_split(const float* src, int64_t ld, void* dst, int64_t ld_bytes, int64_t rows, int32_t cols, void* stream);
+/* fp32 weight [rows][cols] (rows % 32 == 0, cols % 16 == 0) -> fragment-major P3, 6 rows cols bytes, blocks of 32 rows contiguous */
+int sdumc_p3_split_frag(const float* src, int64_t ld, void* dst, int32_t rows, int32_t cols, void* stream);
+int sdumc_p3_join(const void* src, int64_t ld_bytes, float* dst, int64_t ld, int64_t rows, int32_t cols, void* stream);
+
+/* ------------------------------------------------------------------------
  * The tall 256 x 256 products of the frame-level part in one persistent launch (gemm_rows.hip):
  *   C[M x 256] = act((A . keep) B * a_scale + bias) (+ C),   K = N = 256
  * - the key projections  keys = tanh(drop(x) W^T + b)  of FRA2UTT_new / Cross_Attention (model :60, :82; main :144 in train

@@ -62,6 +62,16 @@ class GGProblem(C.Structure):
                 ("bits_qw", C.c_int32), ("b_scale", C.c_float), ("accumulate", C.c_int32)]
 
 
+class GemmP3(C.Structure):
+    _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("A", C.c_void_p), ("B", C.c_void_p), ("lda", C.c_int64), ("ldb", C.c_int64),
+                ("a_row_mod", C.c_int32), ("a_bits", C.c_void_p), ("bits_qw", C.c_int32), ("a_scale", C.c_float),
+                ("bias", C.c_void_p), ("act", C.c_int32),
+                ("C", C.c_void_p), ("ldc", C.c_int32), ("C_p3", C.c_void_p), ("ldc_p3", C.c_int64),
+                ("splitk", C.c_int32), ("tile_m", C.c_int32),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
 class RowsProblem(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("a_bits", C.c_void_p), ("bias", C.c_void_p), ("C", C.c_void_p),
                 ("M", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32), ("a_row_mod", C.c_int32),
@@ -179,6 +189,11 @@ _SIGS = {
     "sdumc_gemm_group_tn_bf16": (C.c_int, [C.POINTER(GGProblem), C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p]),
     "sdumc_set_split_": (None, [C.c_int]),
     "sdumc_get_split_": (C.c_int, []),
+    "sdumc_gemm_p3_workspace_bytes": (C.c_size_t, [C.POINTER(GemmP3)]),
+    "sdumc_gemm_p3_nt": (C.c_int, [C.POINTER(GemmP3), C.c_void_p]),
+    "sdumc_p3_split": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
+    "sdumc_p3_split_frag": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
+    "sdumc_p3_join": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     "sdumc_gemm_rows256": (C.c_int, [C.POINTER(RowsProblem), C.c_int32, C.c_void_p]),
     "sdumc_gemm_rows256_bf16": (C.c_int, [C.POINTER(RowsProblem), C.c_int32, C.c_void_p]),
     "sdumc_attnpool_fwd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),

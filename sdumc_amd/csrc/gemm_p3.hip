@@ -1,0 +1,564 @@
+// gemm_p3.hip — fp32 GEMMs on operands that were split ONCE PER TENSOR into three bf16 planes ("P3" layout), gfx950.
+//
+// Round 4 moved the fp32 products onto the bf16 matrix pipe: an fp32 value is the exact sum of three bf16 values, the six largest
+// of the nine part products are accumulated in fp32 (gemm_group.hip has the arithmetic and its error bound).  Those kernels split
+// their operands per workgroup per k-tile: a 256 x 1024 weight was re-split by every m-tile of every launch, the features by
+// every consumer -- ~10 VALU instructions per MFMA, and the VALU, not the matrix pipe, set the rate (0.25 of the six-term
+// ceiling).  Here the split happens once, where a tensor is produced (sdumc_p3_split for the features when a batch is installed
+// and for the weights at the head of a forward; the GEMM epilogue below for the projected frames), and the inner loop is a plain
+// LDS-DMA bf16 loop with six v_mfma_f32_32x32x16_bf16 per loaded (A, B) fragment pair.
+//
+// P3 layout of a row-major matrix X[rows][K] (K a multiple of 8): row r is 6 K bytes at r * ld (bytes), made of K / 8 chunks of
+// 48 bytes; chunk c holds k = 8 c .. 8 c + 7 as [plane 0: 8 bf16][plane 1: 8 bf16][plane 2: 8 bf16], plane 0 = bf16(x) (round to
+// nearest even), plane 1 = bf16(x - p0), plane 2 = bf16(x - p0 - p1): x == p0 + p1 + p2 exactly (sdumc_hip.h states the edges).
+// The three planes of a k-tile of a row are ONE contiguous run (96 bytes per 16 k), so the operand streams of the NT product
+// below -- and of a TN product that contracts over the rows -- are sequential in HBM.
+//
+// What runs here (C2 shapes): NT  C[M, 256] = act(mask(A)[M, K] . B[256, K]^T * scale + bias)
+//   * the frame projections frame_dim_reshape_{0,1,2} (model :193-195, :282-284): A = feature planes, B = weight planes,
+//     K = 1024 / 4096, M = B T up to 24 000 (the text slot: K split over workgroups, fp32 slabs, ordered reduce);
+//   * the key projections input_proj of FRA2UTT_new / Cross_Attention (model :60, :82): A = the projected frames' planes with the
+//     keep-bits of the fused input dropout applied to all three planes, bias + tanh in the epilogue.
+// Tile: BM x 256 (all of N: A crosses HBM once) per 512-thread workgroup, wave w owns columns [32 w, 32 w + 32) of every row --
+// TM = BM / 32 accumulator tiles, 3 (TM + 1) ds_read_b128 per 6 TM MFMAs, far below what the LDS array delivers.  Operands go
+// global -> LDS by LDS-DMA through a ring of NST k-tiles of 16 k (rows of 96 bytes; the two 48-byte k-halves of a row swapped by
+// bit 3 of the row: conflict-free b128 reads for every lane group), ONE raw barrier per k-tile, counted vmcnt.  BM is chosen per
+// shape so that the tiles fill 256 CUs in whole rounds (24 000 rows: 250 tiles of 96).
+#include <algorithm>
+#include <cstdlib>
+#include <type_traits>
+
+#include "common.h"
+
+namespace sdumc_p3 {
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2s __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int waitcnt_vm(int n) { return (n & 0xF) | ((n >> 4) << 14) | (0x7 << 4) | (0xF << 8); }
+
+__device__ __forceinline__ float fast_tanh(float x) { return 1.f - 2.f * __frcp_rn(1.f + __expf(2.f * x)); }
+
+__device__ __forceinline__ uint32_t pk(float x, float y) {       // v_cvt_pk_bf16_f32 (round to nearest even), low half = x
+  const f32x2s v = {x, y};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+}
+// eight fp32 values -> their three bf16 planes (4 dwords each)
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&pl)[3]) {
+#pragma unroll
+  for (int d = 0; d < 4; ++d) {
+    const float x = v[2 * d], y = v[2 * d + 1];
+    const uint32_t p0 = pk(x, y);
+    const float x1 = x - __uint_as_float(p0 << 16), y1 = y - __uint_as_float(p0 & 0xFFFF0000u);       // exact
+    const uint32_t p1 = pk(x1, y1);
+    const float x2 = x1 - __uint_as_float(p1 << 16), y2 = y1 - __uint_as_float(p1 & 0xFFFF0000u);     // exact
+    pl[0][d] = p0;
+    pl[1][d] = p1;
+    pl[2][d] = pk(x2, y2);
+  }
+}
+
+constexpr int BN = 256, NW = 8, NTHR = 512, BK = 16, ROWB = 96;      // ROWB: bytes of one row of a k-tile (16 k x 3 planes x 2)
+constexpr int NBS = 4, DB = 3;      // register sets of B fragments / how many k-tiles ahead B is requested
+constexpr int FRAG_KT = 3 * 1024;   // bytes of one (32-row block, k-tile) of a fragment-major tensor: 3 planes x 64 lanes x 16 bytes
+
+template <int BM_, int NST_, bool MASK_>
+struct PCfg {
+  static constexpr int BM = BM_, NST = NST_, TM = BM_ / 32;
+  static constexpr bool MASK = MASK_;
+  static constexpr int A_BYTES = BM * ROWB;
+  static constexpr int A_P = A_BYTES / 1024;                                 // 1-KiB DMA pieces of A per stage: wave w takes w and w + 8
+  static constexpr int NA = (A_P + NW - 1) / NW;
+  static constexpr int BITS_BYTES = BM * 4;                                  // keep-bits of a k-tile: [BM][4 bytes] (low nibbles)
+  static constexpr int BITS_P = (BITS_BYTES + 255) / 256;                    // 256-byte pieces (4 bytes per lane): wave w < BITS_P takes piece w
+  static constexpr int BITS_LDS = MASK ? BITS_P * 256 : 0;
+  static constexpr int STAGE = A_BYTES + BITS_LDS;
+  static constexpr int EPI_BYTES = NW * 32 * 36 * 4;                         // epilogue staging (overlays the ring)
+  static constexpr int LDS_BYTES = NST * STAGE > EPI_BYTES ? NST * STAGE : EPI_BYTES;
+  static_assert(BM % 32 == 0 && A_BYTES % 1024 == 0 && NA <= 2, "tile shape");
+  static_assert(NST >= DB + 1, "the A stage a step needs must be older in the queue than the B fragments it needs");
+  static_assert(3 * (3 + NA + 1) < 64, "vmcnt is a 6-bit counter");
+};
+
+struct Args {
+  sdumc_gemm_p3 g;
+  int nsplit, kchunk;
+};
+
+// The loop (one 512-thread workgroup per BM x 256 tile; wave w owns columns [32 w, 32 w + 32) of every row):
+//   * A (features / projected frames, P3 rows) is what the eight waves SHARE: it goes global -> LDS by LDS-DMA through a ring of NST
+//     k-tiles (rows of 96 bytes, the two 48-byte k-halves swapped by bit 3 of the row: conflict-free ds_read_b128 for every lane
+//     group), one raw barrier per k-tile, counted vmcnt;
+//   * B (the weight, fragment-major) is PRIVATE to a wave -- nobody else multiplies its 32 columns -- so it never touches LDS: three
+//     coalesced 1-KiB global loads per k-tile bring a wave's MFMA operands straight into registers, DB k-tiles ahead, through four
+//     register sets.  With B in the LDS ring too (first form of this kernel) a k-tile moved 34 KB through LDS-DMA per CU and the
+//     fill path -- ~70 GB/s per CU whatever the source -- set the time: 0.70 us per k-tile against 0.48 of MFMA work;
+//   * A fragments are double-buffered in registers: while the six MFMA terms of k-tile t run, the fragments of k-tile t + 1 are read
+//     from LDS into the other set -- the LDS latency sits in the gaps between MFMAs instead of in front of them.
+// A wave's vector-memory queue is in issue order: step s issues [A pieces of stage s + NST, B fragments of k-tile s + DB].  Step t
+// needs stage t + 1 in LDS and B(t) in registers; both belong to step t - DB's group or older (NST >= DB + 1), so the wait is
+// "at most DB - 1 groups outstanding".
+template <class CF>
+__global__ __launch_bounds__(NTHR, 1) void gemm_p3_nt_kernel(const Args a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int BM = CF::BM, NST = CF::NST, TM = CF::TM;
+  constexpr bool MASK = CF::MASK;
+  const sdumc_gemm_p3& g = a.g;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int tiles_n = g.N / BN;
+  const int tlin = blockIdx.x;
+  const int tile_m = tlin / tiles_n, tile_n = tlin - tile_m * tiles_n;
+  const int ks = blockIdx.y;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int kbeg = ks * a.kchunk, kend = min(g.K, kbeg + a.kchunk);
+  const int nk = (kend - kbeg) / BK;                      // a multiple of 4 (the launcher checks K and the split)
+
+  const int a_rows = g.a_row_mod > 0 ? g.a_row_mod : g.M;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, (int)min((size_t)a_rows * (size_t)g.lda, (size_t)0xFFFFFFF0u), 0x00020000);
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t rbits = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(MASK ? g.a_bits : static_cast<const uint8_t*>(g.A)), 0,
+                                                                        MASK ? (int)min((size_t)g.M * (size_t)g.bits_qw, (size_t)0xFFFFFFF0u) : 0, 0x00020000);
+
+  // ---- this wave's DMA pieces of a stage of A: pieces wave and wave + 8 (where they exist), its keep-bits piece ----
+  uint32_t voff[CF::NA];
+  bool pvalid[CF::NA];
+#pragma unroll
+  for (int i = 0; i < CF::NA; ++i) {
+    const int piece = wave + i * NW;
+    pvalid[i] = piece < CF::A_P;
+    const int q = (min(piece, CF::A_P - 1) << 6) + lane;                 // 16-byte slot inside the tile: [row][k-half'][plane]
+    const int row = q / 6, sl = q - 6 * row;
+    const int hp = sl >= 3 ? 1 : 0, p = sl - 3 * hp;
+    const int h = hp ^ ((row >> 3) & 1);                                 // the k-half this slot holds (swizzle by bit 3 of the row)
+    int r = min(m0 + row, g.M - 1);
+    if (g.a_row_mod > 0) r %= g.a_row_mod;
+    voff[i] = (uint32_t)r * (uint32_t)g.lda + (uint32_t)((kbeg >> 3) + h) * 48u + (uint32_t)p * 16u;
+  }
+  const bool has_bits = MASK && wave < CF::BITS_P;
+  uint32_t bvoff = 0;
+  if constexpr (MASK) bvoff = (uint32_t)min(m0 + (wave << 6) + lane, g.M - 1) * (uint32_t)g.bits_qw + (uint32_t)(kbeg >> 2);
+  int per = 3;                                            // vector-memory operations of this wave per step (wave-uniform)
+#pragma unroll
+  for (int i = 0; i < CF::NA; ++i) per += pvalid[i] ? 1 : 0;
+  per += has_bits ? 1 : 0;
+  auto issue_a = [&](int buf) {
+    char* base = lds + buf * CF::STAGE;
+#pragma unroll
+    for (int i = 0; i < CF::NA; ++i) {
+      if (pvalid[i]) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(base + (wave + i * NW) * 1024), 16, voff[i], 0, 0, 0);
+        voff[i] += ROWB;
+      }
+    }
+    if constexpr (MASK) {
+      if (has_bits) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbits, (lds_void_t*)(base + CF::A_BYTES + wave * 256), 4, bvoff, 0, 0, 0);
+        bvoff += BK / 4;
+      }
+    }
+  };
+  // at most `groups` of this wave's per-step groups outstanding (per is 3 .. 6: B fragments + 0 .. 2 pieces of A + keep-bits)
+  auto wait_groups = [&](auto groups_c) {
+    constexpr int G = decltype(groups_c)::value;
+    if (per == 3) __builtin_amdgcn_s_waitcnt(waitcnt_vm(G * 3));
+    else if (per == 4) __builtin_amdgcn_s_waitcnt(waitcnt_vm(G * 4));
+    else if (per == 5) __builtin_amdgcn_s_waitcnt(waitcnt_vm(G * 5));
+    else __builtin_amdgcn_s_waitcnt(waitcnt_vm(G * 6));
+  };
+
+  // ---- B: fragment-major [N / 32][K / 16][3 planes][64 lanes][16 bytes]; this wave's block, its lane's 16 bytes ----
+  const char* bptr = static_cast<const char*>(g.B) + (size_t)(tile_n * 8 + wave) * (size_t)g.ldb + (size_t)(kbeg >> 4) * FRAG_KT + lane * 16;
+  u32x4 pb[NBS][3];
+  auto load_b = [&](auto set_c) {
+    constexpr int S = decltype(set_c)::value;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) pb[S][p] = *reinterpret_cast<const u32x4*>(bptr + p * 1024);
+    bptr += FRAG_KT;
+  };
+
+  f32x16 acc[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+  // a lane's MFMA operand of a 32-row block of A: 8 consecutive k (k-half lh) of row li, the three planes side by side (48 bytes)
+  const int lane_off = li * ROWB + ((lh ^ ((li >> 3) & 1)) * 48);
+  auto op = [](const u32x4& v) { return __builtin_bit_cast(bf16x8, v); };
+  u32x4 pa[2][TM][3];
+  uint32_t kb[2][TM];
+  auto load_a = [&](const char* base, auto par) {
+    constexpr int P = decltype(par)::value;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) pa[P][i][2] = *reinterpret_cast<const u32x4*>(base + i * 32 * ROWB + lane_off + 32);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) pa[P][i][0] = *reinterpret_cast<const u32x4*>(base + i * 32 * ROWB + lane_off);
+#pragma unroll
+    for (int i = 0; i < TM; ++i) pa[P][i][1] = *reinterpret_cast<const u32x4*>(base + i * 32 * ROWB + lane_off + 16);
+    if constexpr (MASK) {      // keep-bits of (row, k-half): two bytes, low nibbles = elements 0..3 and 4..7
+#pragma unroll
+      for (int i = 0; i < TM; ++i) kb[P][i] = *reinterpret_cast<const uint16_t*>(base + CF::A_BYTES + (32 * i + li) * 4 + 2 * lh);
+    }
+  };
+  auto mfmas = [&](auto par, auto set_c) {
+    constexpr int P = decltype(par)::value, S = decltype(set_c)::value;
+    if constexpr (MASK) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const uint32_t u = kb[P][i];
+        const uint32_t b8 = (u & 0xFu) | ((u >> 4) & 0xF0u);
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const uint32_t lo = 0u - ((b8 >> (2 * d)) & 1u), hi = 0u - ((b8 >> (2 * d + 1)) & 1u);
+          const uint32_t m = (lo & 0xFFFFu) | (hi << 16);
+          pa[P][i][0][d] &= m;
+          pa[P][i][1][d] &= m;
+          pa[P][i][2][d] &= m;
+        }
+      }
+    }
+    // smallest terms first: (a2 b0), (a0 b2), (a1 b1), (a1 b0), (a0 b1), (a0 b0); term-major over the TM accumulator tiles, so
+    // consecutive MFMAs never depend on each other
+    constexpr int TA[6] = {2, 0, 1, 1, 0, 0}, TB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+    for (int t = 0; t < 6; ++t)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(pa[P][i][TA[t]]), op(pb[S][TB[t]]), acc[i], 0, 0, 0);
+  };
+  auto interleave = [&]() {      // one memory instruction in the shadow of every MFMA as long as there are any
+#pragma unroll
+    for (int u = 0; u < 6 * TM; ++u) {
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
+      __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
+    }
+  };
+
+  // ---- prologue: the queue as the steady state leaves it -- A0, [A1, B0], [A2, B1], [A3, B2] ----
+  static_assert(NST == 4 && DB == 3 && NBS == 4, "the prologue and the unrolled steps are written for these depths");
+  issue_a(0);
+  issue_a(1);
+  load_b(std::integral_constant<int, 0>{});
+  issue_a(2);
+  load_b(std::integral_constant<int, 1>{});
+  issue_a(3);
+  load_b(std::integral_constant<int, 2>{});
+  wait_groups(std::integral_constant<int, 3>{});          // stage 0 has landed
+  __builtin_amdgcn_s_barrier();
+  load_a(lds, std::integral_constant<int, 0>{});
+  int nbuf = 1;                                           // buffer of stage t + 1; stage t's (refilled with t + NST) is the one before it
+  // step t: STEADY = stage t + NST and k-tile t + DB exist (every step issues, waits with the same count, has no tail logic)
+  auto step = [&](int t, auto par, auto set_c, auto steady_c) {
+    constexpr int P = decltype(par)::value, S = decltype(set_c)::value;
+    constexpr bool STEADY = decltype(steady_c)::value;
+    const bool more = STEADY || t + 1 < nk;
+    if (STEADY) wait_groups(std::integral_constant<int, DB - 1>{});
+    else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
+    if (more) {
+      __builtin_amdgcn_s_waitcnt(0xC07F);                 // lgkmcnt(0): this wave's reads of stage t's buffer are done (it is refilled below)
+      __builtin_amdgcn_s_barrier();
+      if (STEADY || t + NST < nk) issue_a(nbuf == 0 ? NST - 1 : nbuf - 1);
+      if (STEADY || t + DB < nk) load_b(std::integral_constant<int, (S + DB) % NBS>{});
+      load_a(lds + nbuf * CF::STAGE, std::integral_constant<int, P ^ 1>{});
+      nbuf = nbuf + 1 == NST ? 0 : nbuf + 1;
+    }
+    mfmas(par, set_c);
+    if (STEADY) interleave();
+  };
+  int t = 0;
+  for (; t + 3 + NST < nk; t += 4) {
+    step(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::true_type{});
+    step(t + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, std::true_type{});
+    step(t + 2, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, std::true_type{});
+    step(t + 3, std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{}, std::true_type{});
+  }
+  for (; t < nk; t += 4) {
+    step(t, std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, std::false_type{});
+    step(t + 1, std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}, std::false_type{});
+    step(t + 2, std::integral_constant<int, 0>{}, std::integral_constant<int, 2>{}, std::false_type{});
+    step(t + 3, std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{}, std::false_type{});
+  }
+
+  // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5).  The tile turns
+  //      through LDS (the ring is free) so that a lane owns 8 consecutive columns of a row: 32-byte fp32 stores, and the P3 copy
+  //      of the same values as one 48-byte chunk ----
+  const bool to_slab = a.nsplit > 1;
+  const float mscale = MASK ? g.a_scale : 1.f;
+  constexpr int LDT = 36;                                   // floats per staged row (keeps the b128 reads aligned, spreads banks)
+  float* tw = reinterpret_cast<float*>(lds) + wave * 32 * LDT;
+  const int colw = n0 + 32 * wave;
+  float bv[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) bv[c] = (!to_slab && g.bias) ? g.bias[colw + 8 * (lane & 3) + c] : 0.f;
+  __syncthreads();                                          // every wave is done reading the last k-tile
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) tw[((e & 3) + 8 * (e >> 2) + 4 * lh) * LDT + li] = acc[i][e] * mscale;
+    __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): this wave's own LDS writes (no other wave reads them)
+#pragma unroll
+    for (int u = lane; u < 128; u += 64) {
+      const int r = u >> 2, cq = u & 3;
+      const int row = m0 + 32 * i + r, col = colw + 8 * cq;
+      if (row < g.M) {
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(tw + r * LDT + 8 * cq), a1 = *reinterpret_cast<const f32x4*>(tw + r * LDT + 8 * cq + 4);
+        float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        if (to_slab) {
+          float* dst = g.workspace + ((size_t)ks * g.M + row) * g.N + col;
+          *reinterpret_cast<f32x4*>(dst) = a0;
+          *reinterpret_cast<f32x4*>(dst + 4) = a1;
+        } else {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            float x = v[c] + bv[c];
+            if (g.act == SDUMC_ACT_TANH) x = fast_tanh(x);
+            else if (g.act == SDUMC_ACT_RELU) x = fmaxf(x, 0.f);
+            v[c] = x;
+          }
+          if (g.C) {
+            float* dst = g.C + (size_t)row * g.ldc + col;
+            *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+          }
+          if (g.C_p3) {
+            u32x4 pl[3];
+            split8(v, pl);
+            char* dst = static_cast<char*>(g.C_p3) + (size_t)row * (size_t)g.ldc_p3 + (size_t)(col >> 3) * 48;
+            *reinterpret_cast<u32x4*>(dst) = pl[0];
+            *reinterpret_cast<u32x4*>(dst + 16) = pl[1];
+            *reinterpret_cast<u32x4*>(dst + 32) = pl[2];
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_s_waitcnt(0xC07F);                     // reads done before the next 32 rows overwrite the staging
+  }
+#endif
+}
+
+// ordered reduction of the split-K slabs + the epilogue the tiles skipped (bias, activation, fp32 and / or P3 output)
+__global__ __launch_bounds__(256) void p3_splitk_reduce_kernel(const sdumc_gemm_p3 g, const int nsplit) {
+  const size_t u = (size_t)blockIdx.x * 256 + threadIdx.x;       // one 8-column chunk of one row
+  const int cpr = g.N >> 3;
+  if (u >= (size_t)g.M * cpr) return;
+  const int row = (int)(u / cpr), col = (int)(u - (size_t)row * cpr) * 8;
+  float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float* s = g.workspace + (size_t)row * g.N + col;
+  for (int z = 0; z < nsplit; ++z) {
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(s + (size_t)z * g.M * g.N), a1 = *reinterpret_cast<const f32x4*>(s + (size_t)z * g.M * g.N + 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) { v[c] += a0[c]; v[4 + c] += a1[c]; }
+  }
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float x = v[c] + (g.bias ? g.bias[col + c] : 0.f);
+    if (g.act == SDUMC_ACT_TANH) x = sdumc_p3::fast_tanh(x);
+    else if (g.act == SDUMC_ACT_RELU) x = fmaxf(x, 0.f);
+    v[c] = x;
+  }
+  if (g.C) {
+    float* dst = g.C + (size_t)row * g.ldc + col;
+    *reinterpret_cast<f32x4*>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(dst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  }
+  if (g.C_p3) {
+    u32x4 pl[3];
+    split8(v, pl);
+    char* dst = static_cast<char*>(g.C_p3) + (size_t)row * (size_t)g.ldc_p3 + (size_t)(col >> 3) * 48;
+    *reinterpret_cast<u32x4*>(dst) = pl[0];
+    *reinterpret_cast<u32x4*>(dst + 16) = pl[1];
+    *reinterpret_cast<u32x4*>(dst + 32) = pl[2];
+  }
+}
+
+// fp32 [rows][cols] (row stride ld floats) -> P3 (row stride ldp bytes); one thread per 8-column chunk
+__global__ __launch_bounds__(256) void p3_split_kernel(const float* __restrict__ src, int64_t ld, char* __restrict__ dst, int64_t ldp, int64_t rows,
+                                                       int cols) {
+  const int cpr = cols >> 3;
+  const int64_t total = rows * cpr;
+  for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < total; u += (int64_t)gridDim.x * 256) {
+    const int64_t row = u / cpr;
+    const int c = (int)(u - row * cpr);
+    const float* s = src + row * ld + 8 * c;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(s), a1 = *reinterpret_cast<const f32x4*>(s + 4);
+    const float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    u32x4 pl[3];
+    split8(v, pl);
+    char* d = dst + row * ldp + (int64_t)c * 48;
+    *reinterpret_cast<u32x4*>(d) = pl[0];
+    *reinterpret_cast<u32x4*>(d + 16) = pl[1];
+    *reinterpret_cast<u32x4*>(d + 32) = pl[2];
+  }
+}
+// fp32 weight [rows][cols] (rows % 32 == 0, cols % 16 == 0) -> fragment-major P3: [rows / 32][cols / 16][3 planes][64 lanes][16 bytes],
+// lane (li = lane & 31, lh = lane >> 5) of block (rb, kt) holds W[32 rb + li][16 kt + 8 lh .. + 7] -- a wave's MFMA B operand of a
+// k-tile is three contiguous KiB.  One thread per (row, 8-column chunk).
+__global__ __launch_bounds__(256) void p3_split_frag_kernel(const float* __restrict__ src, int64_t ld, char* __restrict__ dst, int rows, int cols) {
+  const int cpr = cols >> 3;
+  const int64_t total = (int64_t)rows * cpr;
+  for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < total; u += (int64_t)gridDim.x * 256) {
+    const int row = (int)(u / cpr), c = (int)(u - (int64_t)row * cpr);
+    const float* sp = src + (int64_t)row * ld + 8 * c;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(sp), a1 = *reinterpret_cast<const f32x4*>(sp + 4);
+    const float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    u32x4 pl[3];
+    split8(v, pl);
+    const int rb = row >> 5, li = row & 31, kt = c >> 1, lh = c & 1;
+    char* d = dst + ((int64_t)rb * (cols >> 4) + kt) * FRAG_KT + (lh * 32 + li) * 16;
+    *reinterpret_cast<u32x4*>(d) = pl[0];
+    *reinterpret_cast<u32x4*>(d + 1024) = pl[1];
+    *reinterpret_cast<u32x4*>(d + 2048) = pl[2];
+  }
+}
+
+// P3 -> fp32: (p0 + p1) + p2, exact (the parts' bits do not overlap)
+__global__ __launch_bounds__(256) void p3_join_kernel(const char* __restrict__ src, int64_t ldp, float* __restrict__ dst, int64_t ld, int64_t rows,
+                                                      int cols) {
+  const int cpr = cols >> 3;
+  const int64_t total = rows * cpr;
+  for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < total; u += (int64_t)gridDim.x * 256) {
+    const int64_t row = u / cpr;
+    const int c = (int)(u - row * cpr);
+    const char* s = src + row * ldp + (int64_t)c * 48;
+    const u32x4 p0 = *reinterpret_cast<const u32x4*>(s), p1 = *reinterpret_cast<const u32x4*>(s + 16), p2 = *reinterpret_cast<const u32x4*>(s + 32);
+    float v[8];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      v[2 * d] = (__uint_as_float(p0[d] << 16) + __uint_as_float(p1[d] << 16)) + __uint_as_float(p2[d] << 16);
+      v[2 * d + 1] = (__uint_as_float(p0[d] & 0xFFFF0000u) + __uint_as_float(p1[d] & 0xFFFF0000u)) + __uint_as_float(p2[d] & 0xFFFF0000u);
+    }
+    float* o = dst + row * ld + 8 * c;
+    *reinterpret_cast<f32x4*>(o) = f32x4{v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<f32x4*>(o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+  }
+}
+
+struct Plan {
+  int bm, nsplit, kchunk;
+};
+// BM: the tile height whose tile count fills 256 CUs in whole rounds with the least idle share; split K (fp32 slabs + an ordered
+// reduce) only when even 64-row tiles leave most of the chip idle and K is long.  k-tiles come in groups of four (the unrolled loop).
+inline Plan plan(const sdumc_gemm_p3& g, size_t have) {
+  const int forced = g.tile_m;
+  const int tiles_n = g.N / BN;
+  Plan best{64, 1, g.K};
+  double best_cost = 1e30;
+  const int cands[3] = {128, 96, 64};
+  for (int ci = 0; ci < 3; ++ci) {
+    const int bm = cands[ci];
+    if (forced && forced != bm) continue;
+    const long tiles = (long)((g.M + bm - 1) / bm) * tiles_n;
+    const long rounds = (tiles + 255) / 256;
+    // time ~ rounds * (rows per tile + a fixed prologue / epilogue share); smaller tiles pay more B traffic per row
+    const double cost = (double)rounds * (bm + 24.0) * (1.0 + 8.0 / bm);
+    if (cost < best_cost) { best_cost = cost; best.bm = bm; }
+  }
+  const int kq = g.K / (4 * BK);                       // groups of four k-tiles
+  int s = 1;
+  if (g.splitk >= 1) s = std::min(g.splitk, kq);
+  else {
+    const long tiles = (long)((g.M + best.bm - 1) / best.bm) * tiles_n;
+    if (tiles <= 64 && kq >= 16) s = (int)std::min<long>(256 / std::max<long>(1, tiles), kq / 4);
+    if (s < 1) s = 1;
+  }
+  while (s > 1 && (size_t)s * g.M * g.N * sizeof(float) > have) --s;
+  best.kchunk = ((kq + s - 1) / s) * 4 * BK;
+  best.nsplit = (g.K + best.kchunk - 1) / best.kchunk;
+  return best;
+}
+
+template <class CF>
+int launch(const sdumc_gemm_p3& g, const Plan& p, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p3_nt_kernel<CF>), hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES) != hipSuccess)
+      return SDUMC_ELAUNCH;
+    attr_set = true;
+  }
+  Args a{g, p.nsplit, p.kchunk};
+  const dim3 grid((unsigned)(((g.M + CF::BM - 1) / CF::BM) * (g.N / BN)), (unsigned)p.nsplit);
+  hipLaunchKernelGGL((gemm_p3_nt_kernel<CF>), grid, dim3(NTHR), CF::LDS_BYTES, st, a);
+  return SDUMC_OK;
+}
+
+}  // namespace sdumc_p3
+
+extern "C" int sdumc_prof_begin_(int variant, double flops, void* stream);     // gemm_f32.hip: bench.py's per-launch HIP events
+extern "C" void sdumc_prof_end_(int token, void* stream);
+
+extern "C" size_t sdumc_gemm_p3_workspace_bytes(const sdumc_gemm_p3* g) {
+  if (!g || g->M <= 0 || g->N <= 0 || g->K <= 0 || (g->K % (4 * sdumc_p3::BK))) return 0;
+  const sdumc_p3::Plan p = sdumc_p3::plan(*g, (size_t)-1);
+  return p.nsplit > 1 ? (size_t)p.nsplit * g->M * g->N * sizeof(float) : 0;
+}
+
+extern "C" int sdumc_gemm_p3_nt(const sdumc_gemm_p3* gp, void* stream) {
+  using namespace sdumc_p3;
+  if (!gp) return SDUMC_EINVAL;
+  const sdumc_gemm_p3& g = *gp;
+  if (g.M <= 0 || g.N <= 0 || g.K <= 0 || (g.N % BN) || (g.K % (4 * BK))) return SDUMC_EINVAL;
+  if (!g.A || !g.B || (!g.C && !g.C_p3)) return SDUMC_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(g.A) | reinterpret_cast<uintptr_t>(g.B) | reinterpret_cast<uintptr_t>(g.C) | reinterpret_cast<uintptr_t>(g.C_p3)) & 15) return SDUMC_EINVAL;
+  if (g.lda < 6 * (int64_t)g.K || (g.lda & 15)) return SDUMC_EINVAL;
+  if (g.ldb < (int64_t)(g.K / BK) * FRAG_KT || (g.ldb & 15)) return SDUMC_EINVAL;
+  if (g.C && ((g.ldc & 3) || g.ldc < g.N)) return SDUMC_EINVAL;
+  if (g.C_p3 && ((g.ldc_p3 & 15) || g.ldc_p3 < 6 * (int64_t)g.N)) return SDUMC_EINVAL;
+  if (g.tile_m != 0 && g.tile_m != 64 && g.tile_m != 96 && g.tile_m != 128) return SDUMC_EINVAL;
+  if (g.act != SDUMC_ACT_NONE && g.act != SDUMC_ACT_TANH && g.act != SDUMC_ACT_RELU) return SDUMC_EINVAL;
+  const size_t a_bytes = (size_t)(g.a_row_mod > 0 ? g.a_row_mod : g.M) * (size_t)g.lda;
+  if (a_bytes >= 0xFFFFFFF0u) return SDUMC_EINVAL;
+  const bool mask = g.a_bits != nullptr;
+  if (mask && (g.bits_qw < g.K / 4 || (g.bits_qw & 3) || (reinterpret_cast<uintptr_t>(g.a_bits) & 3) || (size_t)g.M * g.bits_qw >= 0xFFFFFFF0u)) return SDUMC_EINVAL;
+  const Plan p = plan(g, g.workspace ? g.workspace_bytes : 0);
+  if (p.nsplit > 1 && (!g.workspace || (reinterpret_cast<uintptr_t>(g.workspace) & 15))) return SDUMC_ENOMEM;
+  hipStream_t st = as_stream(stream);
+  const int tok = sdumc_prof_begin_(26, 2.0 * g.M * (double)g.N * g.K, stream);
+  int rc;
+  if (mask) {
+    rc = p.bm == 128 ? launch<PCfg<128, 4, true>>(g, p, st) : p.bm == 96 ? launch<PCfg<96, 4, true>>(g, p, st) : launch<PCfg<64, 4, true>>(g, p, st);
+  } else {
+    rc = p.bm == 128 ? launch<PCfg<128, 4, false>>(g, p, st) : p.bm == 96 ? launch<PCfg<96, 4, false>>(g, p, st) : launch<PCfg<64, 4, false>>(g, p, st);
+  }
+  if (rc != SDUMC_OK) return rc;
+  SDUMC_CHECK_LAUNCH();
+  sdumc_prof_end_(tok, stream);
+  if (p.nsplit > 1) {
+    const size_t units = (size_t)g.M * (g.N >> 3);
+    hipLaunchKernelGGL(p3_splitk_reduce_kernel, dim3((unsigned)((units + 255) / 256)), dim3(256), 0, st, g, p.nsplit);
+    SDUMC_CHECK_LAUNCH();
+  }
+  return SDUMC_OK;
+}
+
+extern "C" int sdumc_p3_split(const float* src, int64_t ld, void* dst, int64_t ld_bytes, int64_t rows, int32_t cols, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || (cols & 7) || (ld & 3) || ld < cols || (ld_bytes & 15) || ld_bytes < 6 * (int64_t)cols) return SDUMC_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) return SDUMC_EINVAL;
+  const int64_t units = rows * (cols >> 3);
+  const unsigned blocks = (unsigned)std::min<int64_t>((units + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(sdumc_p3::p3_split_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, ld, static_cast<char*>(dst), ld_bytes, rows, (int)cols);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+extern "C" int sdumc_p3_split_frag(const float* src, int64_t ld, void* dst, int32_t rows, int32_t cols, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || (rows & 31) || (cols & 15) || (ld & 3) || ld < cols) return SDUMC_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) return SDUMC_EINVAL;
+  const int64_t units = (int64_t)rows * (cols >> 3);
+  const unsigned blocks = (unsigned)std::min<int64_t>((units + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(sdumc_p3::p3_split_frag_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, ld, static_cast<char*>(dst), (int)rows, (int)cols);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+extern "C" int sdumc_p3_join(const void* src, int64_t ld_bytes, float* dst, int64_t ld, int64_t rows, int32_t cols, void* stream) {
+  if (!src || !dst || rows <= 0 || cols <= 0 || (cols & 7) || (ld & 3) || ld < cols || (ld_bytes & 15) || ld_bytes < 6 * (int64_t)cols) return SDUMC_EINVAL;
+  if ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15) return SDUMC_EINVAL;
+  const int64_t units = rows * (cols >> 3);
+  const unsigned blocks = (unsigned)std::min<int64_t>((units + 255) / 256, 256 * 16);
+  hipLaunchKernelGGL(sdumc_p3::p3_join_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), static_cast<const char*>(src), ld_bytes, dst, ld, rows, (int)cols);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}

@@ -113,6 +113,72 @@ def gemm_group_tn(problems, workspace=None):
     return [q["C"] for q in problems]
 
 
+def p3_split(x, out=None):
+    """fp32 [rows, cols] (cols % 8 == 0) -> its P3 tensor: three bf16 planes, chunk-interleaved ([rows][cols / 8][3][8] bf16 =
+    6 bytes per element, include/sdumc_hip.h: sdumc_gemm_p3); returned as a uint8 tensor [rows, 6 * cols]."""
+    rows, cols = x.shape
+    if out is None:
+        out = torch.empty(rows, 6 * cols, dtype=torch.uint8, device=x.device)
+    check(lib.sdumc_p3_split(ptr(x), x.stride(0), ptr(out), out.stride(0), rows, cols, _st()), "sdumc_p3_split")
+    return out
+
+
+def p3_split_frag(w, out=None):
+    """fp32 weight [rows, cols] (rows % 32 == 0, cols % 16 == 0) -> its fragment-major P3 tensor (the B operand of gemm_p3_nt):
+    uint8 [rows / 32, cols / 16 * 3072]."""
+    rows, cols = w.shape
+    if out is None:
+        out = torch.empty(rows // 32, cols // 16 * 3072, dtype=torch.uint8, device=w.device)
+    check(lib.sdumc_p3_split_frag(ptr(w), w.stride(0), ptr(out), rows, cols, _st()), "sdumc_p3_split_frag")
+    return out
+
+
+def p3_join(p3, cols):
+    """P3 tensor -> fp32 [rows, cols], bit-exact inverse of p3_split"""
+    rows = p3.shape[0]
+    out = torch.empty(rows, cols, device=p3.device)
+    check(lib.sdumc_p3_join(ptr(p3), p3.stride(0), ptr(out), out.stride(0), rows, cols, _st()), "sdumc_p3_join")
+    return out
+
+
+def gemm_p3_nt_call(A3, B3, M, N, K, bias=None, act=ACT_NONE, a_row_mod=0, bits=None, scale=1.0, C_out=None, want_f32=True,
+                    want_p3=False, splitk=0, tile_m=0):
+    """The prepared call of gemm_p3_nt: returns (launch, results) -- launch() enqueues sdumc_gemm_p3_nt on the current stream
+    (a few microseconds of host time: benches), results = the output tensor(s)."""
+    dev = A3.device
+    g = _lib.GemmP3()
+    g.M, g.N, g.K = M, N, K
+    g.A, g.B, g.lda, g.ldb = ptr(A3), ptr(B3), A3.stride(0), B3.stride(0)
+    g.a_row_mod = a_row_mod
+    if bits is not None:
+        g.a_bits, g.bits_qw, g.a_scale = ptr(bits), bits.stride(0), scale
+    g.bias, g.act = ptr(bias), act
+    Cf = C_out if C_out is not None else (torch.empty(M, N, device=dev) if want_f32 else None)
+    Cp = torch.empty(M, 6 * N, dtype=torch.uint8, device=dev) if want_p3 else None
+    if Cf is not None:
+        g.C, g.ldc = ptr(Cf), Cf.stride(0)
+    if Cp is not None:
+        g.C_p3, g.ldc_p3 = ptr(Cp), Cp.stride(0)
+    g.splitk, g.tile_m = splitk, tile_m
+    need = lib.sdumc_gemm_p3_workspace_bytes(C.byref(g))
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+    g.workspace, g.workspace_bytes = ptr(ws), need
+    keep = (A3, B3, bias, bits, ws, Cf, Cp)
+
+    def launch(_keep=keep):
+        check(lib.sdumc_gemm_p3_nt(C.byref(g), _st()), "sdumc_gemm_p3_nt")
+    res = (Cf, Cp) if (want_p3 and Cf is not None) else (Cp if Cf is None else Cf)
+    return launch, res
+
+
+def gemm_p3_nt(*args, **kw):
+    """C[M, N] = act((A . keep) B^T * scale + bias) on P3 operands (sdumc_gemm_p3_nt).  Returns C (fp32), or (C, C_p3) with
+    want_p3, or C_p3 alone with want_f32=False."""
+    launch, res = gemm_p3_nt_call(*args, **kw)
+    launch()
+    return res
+
+
 def gemm_rows256(problems):
     """The tall 256 x 256 products of the frame-level part in one persistent launch (sdumc_gemm_rows256).
 
