@@ -729,6 +729,15 @@ typedef struct sdumc_net_io {
    * (maxT - pad_len of toolkit/data/feat_data.py:232-253's `pads`); when given, the six attention poolings mask the
    * padded frames (sdumc_attnpool.lengths).  All four (three when streams == 1) or none. */
   const int32_t* lengths[4];
+  /* Optional, fp32 storage only: the same features as P3 tensors (sdumc_p3_split: three bf16 planes, 6 bytes per element, rows of
+   * 6 d bytes, 16-byte aligned) -- all of them (audio_p3, video_p3, text_p3[0 .. streams - 1]) or none.  When given, the frame
+   * projections (model :282-284) and the Cross_Attention key projections (model :82) read planes that were split ONCE -- the
+   * features when the batch was installed (they do not change across epochs), the projected frames by the projection's own epilogue --
+   * instead of splitting fp32 operands per workgroup per k-tile (csrc/gemm_p3.hip).  The fp32 tensors above are still read by the
+   * weight gradients.  Same arithmetic, same results to the last fp32 rounding or two (another summation order). */
+  const void* audio_p3;
+  const void* video_p3;
+  const void* text_p3[2];
   /* Optional caller-owned execution context (sdumc_ctx_create): the internal side streams and the event ring the call forks
    * its branches on.  NULL = the default context of the current device (one per device, created on first use).  Two host
    * threads that run steps concurrently -- on distinct streams of one device, or on two devices -- give each its own

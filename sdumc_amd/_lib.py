@@ -118,6 +118,7 @@ class NetIO(C.Structure):
                 ("vals", C.c_void_p), ("fused", C.c_void_p), ("rnc", C.c_void_p),
                 ("text_hidden", C.c_void_p), ("cross_text", C.c_void_p),
                 ("lengths", C.c_void_p * 4),
+                ("audio_p3", C.c_void_p), ("video_p3", C.c_void_p), ("text_p3", C.c_void_p * 2),   # optional bf16-plane copies of the features
                 ("ctx", C.c_void_p)]          # optional caller-owned execution context (sdumc_ctx_create); None = device default
 
 

@@ -127,6 +127,9 @@ int sdumc_split_on_(int bit);
 int sdumc_split_scope_(int mask);   // this host thread's override for the duration of a network-level call (-1 = none); returns the previous value
 int sdumc_gemm_rows256_capped_(const sdumc_rows_problem* probs, int32_t n, int32_t max_wg, void* stream);   // sdumc_gemm_rows256 on <= max_wg workgroups
 int sdumc_gemm_rows256_bf16_capped_(const sdumc_rows_problem* probs, int32_t n, int32_t max_wg, void* stream);
+// gemm_p3.hip: n <= 12 weights of the flat parameter buffer -> fragment-major bf16 planes (the B operand of sdumc_gemm_p3_nt)
+int sdumc_p3_split_frag_multi_(const float* P, void* dst, const int64_t* src_off, const int64_t* dst_off, const int32_t* rows,
+                               const int32_t* cols, int n, void* stream);
 int sdumc_chain_transpose_(const float* src, float* dst, const int64_t* offs, const int32_t* outs, const int32_t* ins, int n,
                            void* stream);
 }

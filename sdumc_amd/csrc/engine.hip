@@ -198,6 +198,12 @@ struct Plan {
   int64_t wh = 0, wht = 0;   // [live] bf16 each: weights as stored / transposed (input_proj only), parameter offsets
   int64_t tickets = 0;   // per-sample arrival counters of the attention kernels
   int64_t fold_ws[2][3] = {{0, 0, 0}, {0, 0, 0}};   // softmax partials of site (k, m), kept until the clustered stage behind them has combined them (fra_fold)
+  // fp32 storage, features given as bf16 planes too (sdumc_net_io.*_p3; gemm_p3.hip): fragment-major planes of the frame-level weights
+  // (refreshed at the head of each forward) and P3 copies of the projected frames (written by the frame projection's epilogue)
+  int64_t wp3 = 0;                     // float offset of the weight-plane region
+  int64_t wp3_frame[3] = {0, 0, 0};    // byte offsets inside it
+  int64_t wp3_key[2][3] = {{0, 0, 0}, {0, 0, 0}};
+  int64_t xp3[3][2] = {{0, 0}, {0, 0}, {0, 0}};      // float offsets: [rows][256] planes = 1536 bytes per row
   int64_t dq_ws = 0;        // per-chunk dq slabs of the grouped Cross_Attention pooling backward, kept until the clustered stage 7'-3' has summed them
                             // (their own allocation: with one lane every "lane" shares scratch[0], and early_keys() may use it in between)
   int64_t scratch[4] = {0, 0, 0, 0}, scratch_floats = 0;   // one scratch per lane (stream)
@@ -344,6 +350,22 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
       for (const Seg& sg : p.segs[m])
         sum += ((int64_t)(sdumc_attnpool_bwd_workspace_bytes(sg.V, sg.T, NQ) / sizeof(float)) + 63) / 64 * 64;
     p.dq_ws = p.alloc(sum);
+  }
+  if (d.bf16 == 0 && D == 256 && ((d.da | d.dt | d.dv) & 63) == 0) {      // planes for sdumc_gemm_p3_nt (used when the caller passes feature planes)
+    const int din_[3] = {d.da, d.dt, d.dv};
+    int64_t bytes = 0;
+    for (int m = 0; m < 3; ++m) { p.wp3_frame[m] = bytes; bytes += (int64_t)D * din_[m] * 6; }
+    for (int k = 0; k < 2; ++k)
+      for (int m = 0; m < 3; ++m) { p.wp3_key[k][m] = bytes; bytes += (int64_t)D * D * 6; }
+    p.wp3 = p.alloc(bytes / 4);
+    p.xp3[0][0] = p.xp3[0][1] = p.alloc((int64_t)B * d.Ta * D * 6 / 4);
+    p.xp3[2][0] = p.xp3[2][1] = p.alloc((int64_t)B * d.Tv * D * 6 / 4);
+    {
+      const int64_t n0 = (int64_t)B * p.T[1][0] * D * 6 / 4;
+      const int64_t n1 = S == 2 ? (int64_t)B * p.T[1][1] * D * 6 / 4 : 0;
+      p.xp3[1][0] = p.alloc(n0 + n1);
+      p.xp3[1][1] = p.xp3[1][0] + n0;
+    }
   }
   p.wt = p.alloc(build_params(d.da, d.dt, d.dv).live);   // transposed mirror: utterance-level layers (chain) + the six input_proj
   if (p.hf) {
@@ -823,6 +845,15 @@ int check_io(const sdumc_net_dims* d, const sdumc_net_io* io) {
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || static_cast<const LaneSet*>(io->ctx)->device != dev) return SDUMC_EINVAL;
   }
+  {   // bf16-plane copies of the features: all of them or none; fp32 storage only
+    const int need = 2 + d->streams;
+    int have = (io->audio_p3 != nullptr) + (io->video_p3 != nullptr);
+    for (int s = 0; s < d->streams; ++s) have += io->text_p3[s] != nullptr;
+    if (have != 0 && (have != need || d->bf16 == 2)) return SDUMC_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(io->audio_p3) | reinterpret_cast<uintptr_t>(io->video_p3) | reinterpret_cast<uintptr_t>(io->text_p3[0]) |
+         reinterpret_cast<uintptr_t>(io->text_p3[1])) & 15)
+      return SDUMC_EINVAL;
+  }
   {   // key-padding lengths: all of (audio, text, video[, feat4]) or none
     const int need = d->streams == 2 ? 4 : 3;
     int have = 0;
@@ -926,8 +957,70 @@ int keys_gemm_fwd_h(const Ctx& c, int m, int k0, int k1) {
   return SDUMC_OK;
 }
 
+// fp32 storage with the features also given as bf16 planes (sdumc_net_io.*_p3): the frame projections and the key projections that
+// go through the wide NT kernel run on operands split once per tensor (gemm_p3.hip).  SDUMC_P3=0: A/B against the in-kernel split.
+bool p3_mode(const Ctx& c) {
+  static const int on = [] { const char* e = getenv("SDUMC_P3"); return e ? atoi(e) : 1; }();
+  return on && c.d.bf16 == 0 && c.pl.wp3 != 0 && c.io.audio_p3 != nullptr && sdumc_split_on_(SDUMC_SPLIT_WIDE);
+}
+char* wp3_ptr(const Ctx& c, int64_t byte_off) { return reinterpret_cast<char*>(c.p(c.pl.wp3)) + byte_off; }
+// fragment-major planes of the nine frame-level weights, one launch (the weights change every step)
+int p3_refresh_weights(const Ctx& c) {
+  const int din[3] = {c.d.da, c.d.dt, c.d.dv};
+  int64_t so[9], dofs[9];
+  int32_t rows[9], cols[9];
+  int n = 0;
+  for (int m = 0; m < 3; ++m) { so[n] = c.pm.frame[m].w; dofs[n] = c.pl.wp3_frame[m]; rows[n] = D; cols[n] = din[m]; ++n; }
+  for (int m = 0; m < 3; ++m) {
+    so[n] = c.pm.fra_proj[m].w; dofs[n] = c.pl.wp3_key[0][m]; rows[n] = D; cols[n] = D; ++n;
+    so[n] = c.pm.ca_in[m].w; dofs[n] = c.pl.wp3_key[1][m]; rows[n] = D; cols[n] = D; ++n;
+  }
+  return sdumc_p3_split_frag_multi_(c.P, wp3_ptr(c, 0), so, dofs, rows, cols, n, c.st);
+}
+// frame_dim_reshape_m on feature planes: x (fp32, for the pooling kernels and K3) and its planes (for the key projections)
+int p3_frame_proj(const Ctx& c, int m, int s, const void* feat_p3, int rows, int splitk) {
+  const int din[3] = {c.d.da, c.d.dt, c.d.dv};
+  sdumc_gemm_p3 g;
+  memset(&g, 0, sizeof(g));
+  g.M = rows; g.N = D; g.K = din[m];
+  g.A = feat_p3; g.lda = (int64_t)din[m] * 6;
+  g.B = wp3_ptr(c, c.pl.wp3_frame[m]); g.ldb = (int64_t)(din[m] / 16) * 3072;
+  g.bias = c.P + c.pm.frame[m].b;
+  g.act = SDUMC_ACT_NONE;
+  g.C = c.p(c.pl.x[m][s]); g.ldc = D;
+  g.C_p3 = c.p(c.pl.xp3[m][s]); g.ldc_p3 = (int64_t)D * 6;
+  g.splitk = splitk;
+  g.workspace = c.scr;
+  g.workspace_bytes = (size_t)c.pl.scratch_floats * sizeof(float);
+  return sdumc_gemm_p3_nt(&g, c.st);
+}
+// input_proj of site (k, m) on the projected frames' planes: keys = tanh(drop(x) W^T + b)
+int p3_keys_fwd(const Ctx& c, int m, int k) {
+  for (const Seg& sg : c.pl.segs[m]) {
+    const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
+    const sdumc_dropout dr = in_drop(c, k, m, sg.T, sg.s0, sg.row0);
+    sdumc_gemm_p3 g;
+    memset(&g, 0, sizeof(g));
+    g.M = sg.V * sg.T; g.N = D; g.K = D;
+    g.A = c.p(c.pl.xp3[m][sg.s0]); g.lda = (int64_t)D * 6;
+    g.a_row_mod = sg.x_samples < sg.V ? sg.x_samples * sg.T : 0;
+    if (dr.enabled) { g.a_bits = dr.bits; g.bits_qw = D / 4; g.a_scale = dr.scale; }
+    g.B = wp3_ptr(c, c.pl.wp3_key[k][m]); g.ldb = (int64_t)(D / 16) * 3072;
+    g.bias = c.P + L.b;
+    g.act = SDUMC_ACT_TANH;
+    g.C = c.p(c.pl.keys[k][m]) + sg.row0 * D; g.ldc = D;
+    g.splitk = 1;
+    RET(sdumc_gemm_p3_nt(&g, c.st));
+  }
+  return SDUMC_OK;
+}
+
 int keys_gemm_fwd(const Ctx& c, int m, int k0, int k1) {
   if (c.h()) return keys_gemm_fwd_h(c, m, k0, k1);
+  if (p3_mode(c)) {
+    for (int k = k0; k < k1; ++k) RET(p3_keys_fwd(c, m, k));
+    return SDUMC_OK;
+  }
   for (const Seg& sg : c.pl.segs[m]) {
     sdumc_gemm g = G_(SDUMC_NT, sg.V * sg.T, D, D, k1 - k0);
     for (int k = k0; k < k1; ++k) {
@@ -1225,6 +1318,10 @@ int forward(const Ctx& c) {
     }
     RET(fork_all(c));      // (the lanes forked above did not see these launches)
   }
+  if (p3_mode(c)) {   // fragment-major planes of the frame-level weights: first kernel of the step, every lane waits for it
+    RET(p3_refresh_weights(c));
+    RET(fork_all(c));
+  }
   if (chain) {   // transposed mirror (first needed after the frame-level part): lane 3
     RET(link(c, 0, 3));
     c.use(3);
@@ -1283,6 +1380,14 @@ int forward(const Ctx& c) {
       // fp32 C2 step 1.665-1.669 vs 1.671-1.676 ms (split 4: 1.674-1.678, split 2: 1.705-1.710).  With the products on the bf16
       // matrix pipe the k-loop is shorter and half as many slabs win: split 4 1.424-1.438 against split 8 1.444-1.450 and split
       // 2 1.440-1.450 (three alternations).  SDUMC_TEXT_WIDE=S: A/B, 0 = off
+      if (p3_mode(c)) {
+        // (the text slot: 2048 x 256 x 4096 per stream -- K split over workgroups; measured alone: split 8 34.6 us, 4 37.9, 2 63.8)
+        static const int p3_text_split = [] { const char* e = getenv("SDUMC_P3_TEXT_SPLIT"); return e ? atoi(e) : 8; }();
+        const void* fp = m == 0 ? c.io.audio_p3 : (m == 2 ? c.io.video_p3 : c.io.text_p3[s]);
+        const int rows_p = B * pl.T[m][s];
+        RET(p3_frame_proj(c, m, s, fp, rows_p, rows_p < 8192 && din[m] >= 2048 ? p3_text_split : 1));
+        continue;
+      }
       static const int text_wide = [] { const char* e = getenv("SDUMC_TEXT_WIDE"); return e ? atoi(e) : 4; }();
       const int rows_ms = B * pl.T[m][s];
       const bool wide_split = text_wide > 0 && !c.d.bf16 && rows_ms < 8192 && din[m] >= 2048 && (din[m] % (16 * text_wide)) == 0 && (rows_ms % 64) == 0;

@@ -62,7 +62,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&pl)[3]) {
 }
 
 constexpr int BN = 256, NW = 8, NTHR = 512, BK = 16, ROWB = 96;      // ROWB: bytes of one row of a k-tile (16 k x 3 planes x 2)
-constexpr int NBS = 4, DB = 3;      // register sets of B fragments / how many k-tiles ahead B is requested
+[[maybe_unused]] constexpr int NBS = 4, DB = 3;      // register sets of B fragments / how many k-tiles ahead B is requested
 constexpr int FRAG_KT = 3 * 1024;   // bytes of one (32-row block, k-tile) of a fragment-major tensor: 3 planes x 64 lanes x 16 bytes
 
 template <int BM_, int NST_, bool MASK_>
@@ -119,6 +119,9 @@ __global__ __launch_bounds__(NTHR, 1) void gemm_p3_nt_kernel(const Args a) {
   const int kbeg = ks * a.kchunk, kend = min(g.K, kbeg + a.kchunk);
   const int nk = (kend - kbeg) / BK;                      // a multiple of 4 (the launcher checks K and the split)
 
+#if defined(SDUMC_P3_DBG) && (SDUMC_P3_DBG & 8)
+  const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int a_rows = g.a_row_mod > 0 ? g.a_row_mod : g.M;
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, (int)min((size_t)a_rows * (size_t)g.lda, (size_t)0xFFFFFFF0u), 0x00020000);
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t rbits = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(MASK ? g.a_bits : static_cast<const uint8_t*>(g.A)), 0,
@@ -150,7 +153,10 @@ __global__ __launch_bounds__(NTHR, 1) void gemm_p3_nt_kernel(const Args a) {
     char* base = lds + buf * CF::STAGE;
 #pragma unroll
     for (int i = 0; i < CF::NA; ++i) {
-      if (pvalid[i]) {
+#ifndef SDUMC_P3_DBG
+#define SDUMC_P3_DBG 0      /* measurement builds only: bit 0 = no DMA of A, bit 1 = no loads of B, bit 2 = no MFMAs */
+#endif
+      if (pvalid[i] && !(SDUMC_P3_DBG & 1)) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(base + (wave + i * NW) * 1024), 16, voff[i], 0, 0, 0);
         voff[i] += ROWB;
       }
@@ -177,7 +183,8 @@ __global__ __launch_bounds__(NTHR, 1) void gemm_p3_nt_kernel(const Args a) {
   auto load_b = [&](auto set_c) {
     constexpr int S = decltype(set_c)::value;
 #pragma unroll
-    for (int p = 0; p < 3; ++p) pb[S][p] = *reinterpret_cast<const u32x4*>(bptr + p * 1024);
+    for (int p = 0; p < 3; ++p)
+      if (!(SDUMC_P3_DBG & 2)) pb[S][p] = *reinterpret_cast<const u32x4*>(bptr + p * 1024);
     bptr += FRAG_KT;
   };
 
@@ -228,7 +235,10 @@ __global__ __launch_bounds__(NTHR, 1) void gemm_p3_nt_kernel(const Args a) {
 #pragma unroll
     for (int t = 0; t < 6; ++t)
 #pragma unroll
-      for (int i = 0; i < TM; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(pa[P][i][TA[t]]), op(pb[S][TB[t]]), acc[i], 0, 0, 0);
+      for (int i = 0; i < TM; ++i) {
+        if (SDUMC_P3_DBG & 4) acc[i][t] += __uint_as_float(pa[P][i][TA[t]][0] ^ pb[S][TB[t]][1]);
+        else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(pa[P][i][TA[t]]), op(pb[S][TB[t]]), acc[i], 0, 0, 0);
+      }
   };
   auto interleave = [&]() {      // one memory instruction in the shadow of every MFMA as long as there are any
 #pragma unroll
@@ -239,15 +249,17 @@ __global__ __launch_bounds__(NTHR, 1) void gemm_p3_nt_kernel(const Args a) {
     }
   };
 
-  // ---- prologue: the queue as the steady state leaves it -- A0, [A1, B0], [A2, B1], [A3, B2] ----
-  static_assert(NST == 4 && DB == 3 && NBS == 4, "the prologue and the unrolled steps are written for these depths");
-  issue_a(0);
-  issue_a(1);
+  // ---- prologue: the queue as the steady state leaves it -- A0 .. A(NST-4), [A(NST-3), B0], [A(NST-2), B1], [A(NST-1), B2] ----
+  static_assert(NST >= 4 && DB == 3 && NBS == 4, "the prologue and the unrolled steps are written for these depths");
+#pragma unroll
+  for (int s0 = 0; s0 <= NST - 4; ++s0) issue_a(s0);
+  issue_a(NST - 3);
   load_b(std::integral_constant<int, 0>{});
-  issue_a(2);
+  issue_a(NST - 2);
   load_b(std::integral_constant<int, 1>{});
-  issue_a(3);
+  issue_a(NST - 1);
   load_b(std::integral_constant<int, 2>{});
+  if constexpr (NST > 4) __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
   wait_groups(std::integral_constant<int, 3>{});          // stage 0 has landed
   __builtin_amdgcn_s_barrier();
   load_a(lds, std::integral_constant<int, 0>{});
@@ -338,6 +350,17 @@ __global__ __launch_bounds__(NTHR, 1) void gemm_p3_nt_kernel(const Args a) {
     }
     __builtin_amdgcn_s_waitcnt(0xC07F);                     // reads done before the next 32 rows overwrite the staging
   }
+#if defined(SDUMC_P3_DBG) && (SDUMC_P3_DBG & 8)
+  __syncthreads();
+  if (tid == 0 && g.C) {      // shader-clock and 100 MHz stamps of this workgroup, over its tile's first four outputs
+    const uint64_t t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    uint32_t* o = reinterpret_cast<uint32_t*>(g.C + (size_t)m0 * g.ldc + n0);
+    o[0] = (uint32_t)(t1 - dbg_t0);
+    o[1] = (uint32_t)(r1 - dbg_r0);
+    o[2] = (uint32_t)(dbg_r0 & 0xFFFFFFFFu);
+    o[3] = (uint32_t)(r1 & 0xFFFFFFFFu);
+  }
+#endif
 #endif
 }
 
@@ -416,6 +439,31 @@ __global__ __launch_bounds__(256) void p3_split_frag_kernel(const float* __restr
   }
 }
 
+// up to 12 weights of the flat parameter buffer in one launch (the engine's head-of-forward refresh): blockIdx.y = tensor
+struct FragList {
+  int64_t src_off[12], dst_off[12];      // floats into the parameter buffer / bytes into the destination
+  int32_t rows[12], cols[12];
+};
+__global__ __launch_bounds__(256) void p3_split_frag_multi_kernel(const float* __restrict__ P, char* __restrict__ dst, const FragList L) {
+  const int i = blockIdx.y;
+  const int rows = L.rows[i], cols = L.cols[i], cpr = cols >> 3;
+  const float* src = P + L.src_off[i];
+  char* out = dst + L.dst_off[i];
+  const int64_t total = (int64_t)rows * cpr;
+  for (int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x; u < total; u += (int64_t)gridDim.x * 256) {
+    const int row = (int)(u / cpr), c = (int)(u - (int64_t)row * cpr);
+    const float* sp = src + (int64_t)row * cols + 8 * c;
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(sp), a1 = *reinterpret_cast<const f32x4*>(sp + 4);
+    const float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+    u32x4 pl[3];
+    split8(v, pl);
+    const int rb = row >> 5, li = row & 31, kt = c >> 1, lh = c & 1;
+    char* d = out + ((int64_t)rb * (cols >> 4) + kt) * FRAG_KT + (lh * 32 + li) * 16;
+    *reinterpret_cast<u32x4*>(d) = pl[0];
+    *reinterpret_cast<u32x4*>(d + 1024) = pl[1];
+    *reinterpret_cast<u32x4*>(d + 2048) = pl[2];
+  }
+}
 // P3 -> fp32: (p0 + p1) + p2, exact (the parts' bits do not overlap)
 __global__ __launch_bounds__(256) void p3_join_kernel(const char* __restrict__ src, int64_t ldp, float* __restrict__ dst, int64_t ld, int64_t rows,
                                                       int cols) {
@@ -519,7 +567,10 @@ extern "C" int sdumc_gemm_p3_nt(const sdumc_gemm_p3* gp, void* stream) {
   hipStream_t st = as_stream(stream);
   const int tok = sdumc_prof_begin_(26, 2.0 * g.M * (double)g.N * g.K, stream);
   int rc;
-  if (mask) {
+  static const int nst_env = [] { const char* e = getenv("SDUMC_P3_NST"); return e ? atoi(e) : 0; }();     // (measurement: depth of the A ring)
+  if (!mask && nst_env == 8) {
+    rc = p.bm == 128 ? launch<PCfg<128, 8, false>>(g, p, st) : p.bm == 96 ? launch<PCfg<96, 8, false>>(g, p, st) : launch<PCfg<64, 8, false>>(g, p, st);
+  } else if (mask) {
     rc = p.bm == 128 ? launch<PCfg<128, 4, true>>(g, p, st) : p.bm == 96 ? launch<PCfg<96, 4, true>>(g, p, st) : launch<PCfg<64, 4, true>>(g, p, st);
   } else {
     rc = p.bm == 128 ? launch<PCfg<128, 4, false>>(g, p, st) : p.bm == 96 ? launch<PCfg<96, 4, false>>(g, p, st) : launch<PCfg<64, 4, false>>(g, p, st);
@@ -550,6 +601,22 @@ extern "C" int sdumc_p3_split_frag(const float* src, int64_t ld, void* dst, int3
   const int64_t units = (int64_t)rows * (cols >> 3);
   const unsigned blocks = (unsigned)std::min<int64_t>((units + 255) / 256, 256 * 16);
   hipLaunchKernelGGL(sdumc_p3::p3_split_frag_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), src, ld, static_cast<char*>(dst), (int)rows, (int)cols);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+// n <= 12 weights [rows_i][cols_i] at P + src_off[i] (row stride cols_i) -> fragment-major P3 at dst + dst_off[i] (bytes)
+extern "C" int sdumc_p3_split_frag_multi_(const float* P, void* dst, const int64_t* src_off, const int64_t* dst_off, const int32_t* rows,
+                                          const int32_t* cols, int n, void* stream) {
+  if (!P || !dst || n < 1 || n > 12) return SDUMC_EINVAL;
+  sdumc_p3::FragList L;
+  int64_t most = 0;
+  for (int i = 0; i < n; ++i) {
+    if ((rows[i] & 31) || (cols[i] & 15) || (src_off[i] & 3) || (dst_off[i] & 15)) return SDUMC_EINVAL;
+    L.src_off[i] = src_off[i]; L.dst_off[i] = dst_off[i]; L.rows[i] = rows[i]; L.cols[i] = cols[i];
+    most = std::max<int64_t>(most, (int64_t)rows[i] * (cols[i] >> 3));
+  }
+  const unsigned bx = (unsigned)std::min<int64_t>((most + 255) / 256, 128);
+  hipLaunchKernelGGL(sdumc_p3::p3_split_frag_multi_kernel, dim3(bx, n), dim3(256), 0, as_stream(stream), P, static_cast<char*>(dst), L);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
 }

@@ -83,6 +83,24 @@ def bf16_mode(bf16, dims):
     return 2 if all(int(d) % 64 == 0 for d in dims[:3]) else 1
 
 
+def planes_wanted(planes, dims, bf16):
+    """Whether a step / call keeps bf16-plane copies of its fp32 features (sdumc_net_io.*_p3; csrc/gemm_p3.hip: the frame and key
+    projections then run on operands split once per tensor).  Default (None): yes in fp32 storage when the feature widths are whole
+    64-element k-tiles; costs 1.5x the features' bytes on top of them.  SDUMC_P3=0 turns the default off (A/B)."""
+    import os
+    if planes is None:
+        planes = os.environ.get("SDUMC_P3", "1") != "0"
+    return bool(planes) and bf16_mode(bf16, dims) == 0 and all(int(d) % 64 == 0 for d in dims[:3])
+
+
+def p3_split_into(src, dst):
+    """src fp32 [..., d] contiguous -> dst uint8 [rows, 6 d]: the three bf16 planes of every value (exact: they sum to it)"""
+    d = src.shape[-1]
+    rows = src.numel() // d
+    check(lib.sdumc_p3_split(ptr(src), d, ptr(dst), 6 * d, rows, d, _lib.current_stream()), "sdumc_p3_split")
+    return dst
+
+
 def make_dims(B, streams, Ta, Tv, Tt, dims, train, sample0=0, p_mlp=P_MLP, bf16=False):
     d = _lib.NetDims()
     d.B, d.streams, d.Ta, d.Tv = B, streams, Ta, Tv
@@ -164,7 +182,7 @@ class NetCall:
     padded frames are then masked out of the six attention poolings."""
 
     def __init__(self, flat_params, audio, texts, video, train, rng, sample0=0, p_mlp=P_MLP, bf16=False, lengths=None,
-                 ctx=None):
+                 ctx=None, planes=None):
         texts = list(texts)
         _require_cuda(flat_params)
         _require_cuda(audio, video, *texts, dtypes=(torch.float32, torch.bfloat16))
@@ -214,7 +232,26 @@ class NetCall:
                 io.lengths[i] = ptr(t)
         self._ctx = ctx
         io.ctx = ctx.handle if ctx is not None else None
+        self._planes = None
+        if planes_wanted(planes, (da, dt, dv), bf16):      # bf16-plane copies of the features, split once for the life of this call object
+            mk = lambda t: torch.empty(t.shape[0] * t.shape[1], 6 * t.shape[2], dtype=torch.uint8, device=dev)
+            self._planes = (mk(audio), mk(video), [mk(t) for t in texts])
+            io.audio_p3, io.video_p3 = ptr(self._planes[0]), ptr(self._planes[1])
+            for i, t in enumerate(self._planes[2]):
+                io.text_p3[i] = ptr(t)
         self.io = io
+        self.refresh_planes()
+
+    def refresh_planes(self):
+        """Re-split the feature tensors this call object was built on (a caller that overwrites them in place -- the data-parallel
+        backend's resident batch buffers -- calls this after every new batch)."""
+        if self._planes is None:
+            return
+        _, audio, texts, video, _ = self._keep
+        p3_split_into(audio, self._planes[0])
+        p3_split_into(video, self._planes[1])
+        for t, dst in zip(texts, self._planes[2]):
+            p3_split_into(t, dst)
 
     def set_lengths(self, lengths):
         """Key-padding extension for the next forward: per-modality valid frame counts, or None = the reference's behaviour."""
@@ -277,7 +314,7 @@ class TrainStep(_OptStateMixin):
     optionally captured into a hipGraph (torch.cuda.CUDAGraph) and replayed."""
 
     def __init__(self, flat_params, B, T, dims, weights=DEFAULT_WEIGHTS, lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=1e-5, seed=0, train=True, sample0=0, bf16=False, share=None, arena=None, ctx=None):
+                 weight_decay=1e-5, seed=0, train=True, sample0=0, bf16=False, share=None, arena=None, ctx=None, planes=None):
         """share: an object with .params .rng .adam_m .adam_v .hyper .losses (another TrainStep over the SAME flat_params, or
         FusedTrainer's run state) whose optimiser state this step uses instead of allocating its own -- steps of different
         (B, T) shapes then continue one training run.
@@ -344,6 +381,13 @@ class TrainStep(_OptStateMixin):
         io.text_hidden, io.cross_text = ptr(self.text_hidden), ptr(self.cross_text)
         self._ctx = ctx       # ExecContext or None (= the device's default lanes)
         io.ctx = ctx.handle if ctx is not None else None
+        # fp32 storage: resident bf16-plane copies of the four feature tensors, refreshed by set_batch (features do not change across
+        # epochs: the split is paid when a batch is installed, not in the step) -- 1.5x the features' bytes on top of them
+        self._planes = None
+        if arena is None and planes_wanted(planes, dims, bf16):
+            self._planes = [torch.empty(t.shape[0] * t.shape[1], 6 * t.shape[2], dtype=torch.uint8, device=dev)
+                            for t in (self.audio, self.text, self.video, self.feat4)]
+            io.audio_p3, io.text_p3[0], io.video_p3, io.text_p3[1] = (ptr(t) for t in self._planes)
         self.io = io
         cfg = _lib.StepCfg()
         for i, w in enumerate(weights):
@@ -368,6 +412,9 @@ class TrainStep(_OptStateMixin):
         self.video.copy_(video, non_blocking=True)
         self.feat4.copy_(feat4, non_blocking=True)
         self.labels.copy_(labels.reshape(-1), non_blocking=True)
+        if self._planes is not None:
+            for src, dst in zip((self.audio, self.text, self.video, self.feat4), self._planes):
+                p3_split_into(src, dst)
 
     def set_lengths(self, lengths):
         """Key-padding extension: (audio, text, video, feat4) valid frame counts of the current batch, or None to go back

@@ -27,7 +27,7 @@ class _NetFn(torch.autograd.Function):
     def forward(ctx, module, audio, text, video, call_index, lengths, *live_params):
         rng = engine.RngState(module.seed, audio.device, call=call_index)
         call = engine.NetCall(module._flat, audio, [text], video, True, rng, sample0=module.sample0,
-                              p_mlp=module.dropout_p, lengths=lengths)
+                              p_mlp=module.dropout_p, lengths=lengths, planes=False)     # (fresh features every call: a plane copy would be split for one use)
         outs = call.forward()
         ctx.call, ctx.module = call, module
         return tuple(outs)
@@ -133,10 +133,10 @@ class WengnetMOSEIMultViewsTextMissing(nn.Module):
                 rng = engine.RngState(self.seed, audio.device, call=call_index)
                 vals, fused, rnc, th, ct = engine.NetCall(self._flat, audio, [text], video, True, rng,
                                                           sample0=self.sample0, p_mlp=self.dropout_p,
-                                                          lengths=lengths).forward()
+                                                          lengths=lengths, planes=False).forward()
         else:
             vals, fused, rnc, th, ct = engine.NetCall(self._flat, audio, [text], video, False, None,
-                                                      p_mlp=self.dropout_p, lengths=lengths).forward()
+                                                      p_mlp=self.dropout_p, lengths=lengths, planes=False).forward()
         return vals, [fused, rnc, th, ct]
 
 

@@ -99,6 +99,7 @@ class HipBackend:
         self.video.copy_(video, non_blocking=True)
         self.feat4.copy_(feat4, non_blocking=True)
         self.labels.copy_(labels.reshape(-1), non_blocking=True)
+        self.call.refresh_planes()      # (fp32 storage: the bf16-plane copies the frame projections read)
 
     def set_lengths(self, lengths):
         """Key-padding extension (default None = the reference's behaviour): (audio, text, video, feat4) valid frame counts."""
