@@ -240,6 +240,8 @@ typedef struct sdumc_gemm_p3 {
   const void* B;            /* fragment-major P3 of the weight [N][K] (sdumc_p3_split_frag) */
   int64_t lda, ldb;         /* ldb: bytes between two 32-row blocks of B (>= K / 16 * 3072) */
   int32_t a_row_mod;        /* >0: A's source row = m % a_row_mod (the two streams share x_audio / x_video) */
+  const void* A2;           /* optional second A tensor: rows [a2_row0, M) are its rows 0 .. (the two streams' text features live in */
+  int32_t a2_row0;          /* separate tensors, their projections in adjacent rows of one C); a multiple of 64; no a_row_mod */
   const uint8_t* a_bits;    /* optional keep-bits of a dropout fused on A: byte [m * bits_qw + k/4], bit k%4 (rows = VIRTUAL rows m) */
   int32_t bits_qw;          /* bytes per row of a_bits (>= K/4, multiple of 4) */
   float a_scale;            /* 1 / (1 - p); read only with a_bits */
@@ -250,7 +252,9 @@ typedef struct sdumc_gemm_p3 {
   void* C_p3;               /* optional: the same values as a P3 tensor, row stride ldc_p3 bytes (>= 6 N) */
   int64_t ldc_p3;
   int32_t splitk;           /* 0 auto, 1 none, > 1: K split over workgroups (fp32 slabs in workspace + an ordered reduce) */
-  int32_t tile_m;           /* 0 auto (64 / 96 / 128 rows per workgroup, whichever fills 256 CUs in whole rounds) */
+  int32_t tile_m;           /* 0 = 64-row tiles on 256-thread workgroups, two per CU (the form the step uses: it shares a CU with other lanes'
+                               kernels); 64 / 96 / 128 = that many rows per 512-thread workgroup (one per CU: fastest alone on shapes that fill
+                               the chip in one round) */
   float* workspace;         /* >= sdumc_gemm_p3_workspace_bytes */
   size_t workspace_bytes;
 } sdumc_gemm_p3;

@@ -65,7 +65,8 @@ class GGProblem(C.Structure):
 class GemmP3(C.Structure):
     _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
                 ("A", C.c_void_p), ("B", C.c_void_p), ("lda", C.c_int64), ("ldb", C.c_int64),
-                ("a_row_mod", C.c_int32), ("a_bits", C.c_void_p), ("bits_qw", C.c_int32), ("a_scale", C.c_float),
+                ("a_row_mod", C.c_int32), ("A2", C.c_void_p), ("a2_row0", C.c_int32),
+                ("a_bits", C.c_void_p), ("bits_qw", C.c_int32), ("a_scale", C.c_float),
                 ("bias", C.c_void_p), ("act", C.c_int32),
                 ("C", C.c_void_p), ("ldc", C.c_int32), ("C_p3", C.c_void_p), ("ldc_p3", C.c_int64),
                 ("splitk", C.c_int32), ("tile_m", C.c_int32),

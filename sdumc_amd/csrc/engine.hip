@@ -964,26 +964,25 @@ bool p3_mode(const Ctx& c) {
   return on && c.d.bf16 == 0 && c.pl.wp3 != 0 && c.io.audio_p3 != nullptr && sdumc_split_on_(SDUMC_SPLIT_WIDE);
 }
 char* wp3_ptr(const Ctx& c, int64_t byte_off) { return reinterpret_cast<char*>(c.p(c.pl.wp3)) + byte_off; }
-// fragment-major planes of the nine frame-level weights, one launch (the weights change every step)
-int p3_refresh_weights(const Ctx& c) {
+// fragment-major planes of modality m's three frame-level weights (frame_dim_reshape_m, the two input_proj): one small launch at the
+// head of the modality's lane (the weights change every step)
+int p3_refresh_weights(const Ctx& c, int m) {
   const int din[3] = {c.d.da, c.d.dt, c.d.dv};
-  int64_t so[9], dofs[9];
-  int32_t rows[9], cols[9];
-  int n = 0;
-  for (int m = 0; m < 3; ++m) { so[n] = c.pm.frame[m].w; dofs[n] = c.pl.wp3_frame[m]; rows[n] = D; cols[n] = din[m]; ++n; }
-  for (int m = 0; m < 3; ++m) {
-    so[n] = c.pm.fra_proj[m].w; dofs[n] = c.pl.wp3_key[0][m]; rows[n] = D; cols[n] = D; ++n;
-    so[n] = c.pm.ca_in[m].w; dofs[n] = c.pl.wp3_key[1][m]; rows[n] = D; cols[n] = D; ++n;
-  }
-  return sdumc_p3_split_frag_multi_(c.P, wp3_ptr(c, 0), so, dofs, rows, cols, n, c.st);
+  int64_t so[3], dofs[3];
+  int32_t rows[3], cols[3];
+  so[0] = c.pm.frame[m].w; dofs[0] = c.pl.wp3_frame[m]; rows[0] = D; cols[0] = din[m];
+  so[1] = c.pm.fra_proj[m].w; dofs[1] = c.pl.wp3_key[0][m]; rows[1] = D; cols[1] = D;
+  so[2] = c.pm.ca_in[m].w; dofs[2] = c.pl.wp3_key[1][m]; rows[2] = D; cols[2] = D;
+  return sdumc_p3_split_frag_multi_(c.P, wp3_ptr(c, 0), so, dofs, rows, cols, 3, c.st);
 }
 // frame_dim_reshape_m on feature planes: x (fp32, for the pooling kernels and K3) and its planes (for the key projections)
-int p3_frame_proj(const Ctx& c, int m, int s, const void* feat_p3, int rows, int splitk) {
+int p3_frame_proj(const Ctx& c, int m, int s, const void* feat_p3, int rows, int splitk, const void* feat2_p3 = nullptr, int rows2 = 0) {
   const int din[3] = {c.d.da, c.d.dt, c.d.dv};
   sdumc_gemm_p3 g;
   memset(&g, 0, sizeof(g));
-  g.M = rows; g.N = D; g.K = din[m];
+  g.M = rows + rows2; g.N = D; g.K = din[m];
   g.A = feat_p3; g.lda = (int64_t)din[m] * 6;
+  if (feat2_p3) { g.A2 = feat2_p3; g.a2_row0 = rows; }      // (the second stream's rows follow the first's in x)
   g.B = wp3_ptr(c, c.pl.wp3_frame[m]); g.ldb = (int64_t)(din[m] / 16) * 3072;
   g.bias = c.P + c.pm.frame[m].b;
   g.act = SDUMC_ACT_NONE;
@@ -1318,10 +1317,6 @@ int forward(const Ctx& c) {
     }
     RET(fork_all(c));      // (the lanes forked above did not see these launches)
   }
-  if (p3_mode(c)) {   // fragment-major planes of the frame-level weights: first kernel of the step, every lane waits for it
-    RET(p3_refresh_weights(c));
-    RET(fork_all(c));
-  }
   if (chain) {   // transposed mirror (first needed after the frame-level part): lane 3
     RET(link(c, 0, 3));
     c.use(3);
@@ -1358,9 +1353,29 @@ int forward(const Ctx& c) {
     }
   }
   hipEvent_t fra_done[3] = {nullptr, nullptr, nullptr}, ca_done[3] = {nullptr, nullptr, nullptr};
+  // frame_dim_reshape_m on feature planes (gemm_p3.hip), all streams of the modality, on the current lane
+  auto p3_frames = [&](int m) -> int {
+    // (the text slot: 2048 x 256 x 4096 per stream -- K split over workgroups; both streams in one launch, their x rows are adjacent)
+    static const int p3_text_split = [] { const char* e = getenv("SDUMC_P3_TEXT_SPLIT"); return e ? atoi(e) : 4; }();
+    RET(p3_refresh_weights(c, m));
+    for (int s = 0; s < (m == 1 ? S : 1); ++s) {
+      const void* fp = m == 0 ? c.io.audio_p3 : (m == 2 ? c.io.video_p3 : c.io.text_p3[s]);
+      const int rows_p = B * pl.T[m][s];
+      const bool few = rows_p < 8192 && din[m] >= 2048;
+      if (m == 1 && S == 2 && few && rows_p % 64 == 0) {
+        RET(p3_frame_proj(c, m, 0, fp, rows_p, p3_text_split, c.io.text_p3[1], B * pl.T[1][1]));
+        break;
+      }
+      RET(p3_frame_proj(c, m, s, fp, rows_p, few ? 2 * p3_text_split : 1));
+    }
+    return SDUMC_OK;
+  };
+  // (measured and dropped: the three modalities' projections one after the other on one lane, every modality's lane waiting for
+  //  its own -- 1.50-1.53 against 1.37-1.39 ms: side by side the lanes' kernels do fill each other's bandwidth bursts)
   for (int m = 0; m < 3; ++m) {
     c.use(LANE_OF[m]);
-    for (int s = 0; s < (m == 1 ? S : 1); ++s) {
+    if (p3_mode(c)) RET(p3_frames(m));
+    for (int s = 0; s < (m == 1 ? S : 1) && !p3_mode(c); ++s) {
       const float* in = m == 0 ? c.io.audio : (m == 2 ? c.io.video : c.io.text[s]);
       if (c.h()) {    // features and projected frames in bf16
         sdumc_gemm_bf16 g = GH_(SDUMC_NT, B * pl.T[m][s], D, din[m]);
@@ -1380,14 +1395,6 @@ int forward(const Ctx& c) {
       // fp32 C2 step 1.665-1.669 vs 1.671-1.676 ms (split 4: 1.674-1.678, split 2: 1.705-1.710).  With the products on the bf16
       // matrix pipe the k-loop is shorter and half as many slabs win: split 4 1.424-1.438 against split 8 1.444-1.450 and split
       // 2 1.440-1.450 (three alternations).  SDUMC_TEXT_WIDE=S: A/B, 0 = off
-      if (p3_mode(c)) {
-        // (the text slot: 2048 x 256 x 4096 per stream -- K split over workgroups; measured alone: split 8 34.6 us, 4 37.9, 2 63.8)
-        static const int p3_text_split = [] { const char* e = getenv("SDUMC_P3_TEXT_SPLIT"); return e ? atoi(e) : 8; }();
-        const void* fp = m == 0 ? c.io.audio_p3 : (m == 2 ? c.io.video_p3 : c.io.text_p3[s]);
-        const int rows_p = B * pl.T[m][s];
-        RET(p3_frame_proj(c, m, s, fp, rows_p, rows_p < 8192 && din[m] >= 2048 ? p3_text_split : 1));
-        continue;
-      }
       static const int text_wide = [] { const char* e = getenv("SDUMC_TEXT_WIDE"); return e ? atoi(e) : 4; }();
       const int rows_ms = B * pl.T[m][s];
       const bool wide_split = text_wide > 0 && !c.d.bf16 && rows_ms < 8192 && din[m] >= 2048 && (din[m] % (16 * text_wide)) == 0 && (rows_ms % 64) == 0;
@@ -2193,6 +2200,9 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
       fq.ldb = din[m];
       fq.ldc = din[m];
       fq.b_scale = 1.f;
+      // (measured and dropped, round 5: the text slot's frame dW -- its dx is final long before audio's -- as a launch of its own on
+      //  text's lane, beside the other modalities' dX launches: 1.425-1.431 against 1.390-1.395 ms; a persistent launch in the middle
+      //  of the backward holds the CUs the dX chain is waiting for)
       (c.h() ? c.ggh : c.gg).push_back(fq);
     }
   }

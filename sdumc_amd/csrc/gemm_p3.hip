@@ -61,13 +61,17 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4 (&pl)[3]) {
   }
 }
 
-constexpr int BN = 256, NW = 8, NTHR = 512, BK = 16, ROWB = 96;      // ROWB: bytes of one row of a k-tile (16 k x 3 planes x 2)
+constexpr int BN = 256, BK = 16, ROWB = 96;      // ROWB: bytes of one row of a k-tile (16 k x 3 planes x 2)
 [[maybe_unused]] constexpr int NBS = 4, DB = 3;      // register sets of B fragments / how many k-tiles ahead B is requested
 constexpr int FRAG_KT = 3 * 1024;   // bytes of one (32-row block, k-tile) of a fragment-major tensor: 3 planes x 64 lanes x 16 bytes
 
-template <int BM_, int NST_, bool MASK_>
+// NW_ = 8: wave w owns columns [32 w, 32 w + 32) (TN = 1), one workgroup per CU (tall tiles: least B traffic per row).
+// NW_ = 4: wave w owns 64 columns (TN = 2); a 256-thread workgroup takes half a CU's registers, so TWO are resident per CU -- of one
+//          launch or of two: the prologue / epilogue bursts of one overlap the k-loop of the other, and kernels of different lanes
+//          share a CU the way the step's schedule expects (a 512-thread workgroup holds its CU alone).
+template <int BM_, int NST_, bool MASK_, int NW_ = 8>
 struct PCfg {
-  static constexpr int BM = BM_, NST = NST_, TM = BM_ / 32;
+  static constexpr int BM = BM_, NST = NST_, TM = BM_ / 32, NW = NW_, TN = BN / (32 * NW_), NTHR = 64 * NW_;
   static constexpr bool MASK = MASK_;
   static constexpr int A_BYTES = BM * ROWB;
   static constexpr int A_P = A_BYTES / 1024;                                 // 1-KiB DMA pieces of A per stage: wave w takes w and w + 8
@@ -76,11 +80,13 @@ struct PCfg {
   static constexpr int BITS_P = (BITS_BYTES + 255) / 256;                    // 256-byte pieces (4 bytes per lane): wave w < BITS_P takes piece w
   static constexpr int BITS_LDS = MASK ? BITS_P * 256 : 0;
   static constexpr int STAGE = A_BYTES + BITS_LDS;
-  static constexpr int EPI_BYTES = NW * 32 * 36 * 4;                         // epilogue staging (overlays the ring)
+  static constexpr int LDT = 32 * TN + 4;                                    // floats per staged row of the epilogue (keeps b128 reads aligned)
+  static constexpr int EPI_BYTES = NW * 32 * LDT * 4;                        // epilogue staging (overlays the ring)
   static constexpr int LDS_BYTES = NST * STAGE > EPI_BYTES ? NST * STAGE : EPI_BYTES;
-  static_assert(BM % 32 == 0 && A_BYTES % 1024 == 0 && NA <= 2, "tile shape");
+  static_assert(BM % 32 == 0 && A_BYTES % 1024 == 0 && NA <= 2 && (NW == 4 || NW == 8), "tile shape");
+  static_assert(BITS_P <= NW, "one keep-bits piece per wave");
   static_assert(NST >= DB + 1, "the A stage a step needs must be older in the queue than the B fragments it needs");
-  static_assert(3 * (3 + NA + 1) < 64, "vmcnt is a 6-bit counter");
+  static_assert(3 * (3 * TN + NA + 1) < 64, "vmcnt is a 6-bit counter");
 };
 
 struct Args {
@@ -102,9 +108,9 @@ struct Args {
 // needs stage t + 1 in LDS and B(t) in registers; both belong to step t - DB's group or older (NST >= DB + 1), so the wait is
 // "at most DB - 1 groups outstanding".
 template <class CF>
-__global__ __launch_bounds__(NTHR, 1) void gemm_p3_nt_kernel(const Args a) {
+__global__ __launch_bounds__(CF::NTHR, CF::NW == 4 ? 2 : 1) void gemm_p3_nt_kernel(const Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BM = CF::BM, NST = CF::NST, TM = CF::TM;
+  constexpr int BM = CF::BM, NST = CF::NST, TM = CF::TM, TN = CF::TN, NW = CF::NW;
   constexpr bool MASK = CF::MASK;
   const sdumc_gemm_p3& g = a.g;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -122,8 +128,11 @@ __global__ __launch_bounds__(NTHR, 1) void gemm_p3_nt_kernel(const Args a) {
 #if defined(SDUMC_P3_DBG) && (SDUMC_P3_DBG & 8)
   const uint64_t dbg_t0 = __builtin_amdgcn_s_memtime(), dbg_r0 = __builtin_amdgcn_s_memrealtime();
 #endif
-  const int a_rows = g.a_row_mod > 0 ? g.a_row_mod : g.M;
-  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(g.A), 0, (int)min((size_t)a_rows * (size_t)g.lda, (size_t)0xFFFFFFF0u), 0x00020000);
+  // rows [a2_row0, M) of A live in a second tensor (the two streams' text features): a tile lies on one side (a2_row0 % BM == 0)
+  const bool second = g.A2 != nullptr && m0 >= g.a2_row0;
+  const int arow0 = second ? g.a2_row0 : 0;                                  // tile rows are m - arow0 inside the chosen tensor
+  const int a_rows = g.a_row_mod > 0 ? g.a_row_mod : (g.A2 ? (second ? g.M - g.a2_row0 : g.a2_row0) : g.M);
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(second ? g.A2 : g.A), 0, (int)min((size_t)a_rows * (size_t)g.lda, (size_t)0xFFFFFFF0u), 0x00020000);
   [[maybe_unused]] const __amdgpu_buffer_rsrc_t rbits = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(MASK ? g.a_bits : static_cast<const uint8_t*>(g.A)), 0,
                                                                         MASK ? (int)min((size_t)g.M * (size_t)g.bits_qw, (size_t)0xFFFFFFF0u) : 0, 0x00020000);
 
@@ -138,14 +147,14 @@ __global__ __launch_bounds__(NTHR, 1) void gemm_p3_nt_kernel(const Args a) {
     const int row = q / 6, sl = q - 6 * row;
     const int hp = sl >= 3 ? 1 : 0, p = sl - 3 * hp;
     const int h = hp ^ ((row >> 3) & 1);                                 // the k-half this slot holds (swizzle by bit 3 of the row)
-    int r = min(m0 + row, g.M - 1);
+    int r = min(m0 + row, g.M - 1) - arow0;
     if (g.a_row_mod > 0) r %= g.a_row_mod;
     voff[i] = (uint32_t)r * (uint32_t)g.lda + (uint32_t)((kbeg >> 3) + h) * 48u + (uint32_t)p * 16u;
   }
   const bool has_bits = MASK && wave < CF::BITS_P;
   uint32_t bvoff = 0;
   if constexpr (MASK) bvoff = (uint32_t)min(m0 + (wave << 6) + lane, g.M - 1) * (uint32_t)g.bits_qw + (uint32_t)(kbeg >> 2);
-  int per = 3;                                            // vector-memory operations of this wave per step (wave-uniform)
+  int per = 3 * TN;                                       // vector-memory operations of this wave per step (wave-uniform)
 #pragma unroll
   for (int i = 0; i < CF::NA; ++i) per += pvalid[i] ? 1 : 0;
   per += has_bits ? 1 : 0;
@@ -168,31 +177,36 @@ __global__ __launch_bounds__(NTHR, 1) void gemm_p3_nt_kernel(const Args a) {
       }
     }
   };
-  // at most `groups` of this wave's per-step groups outstanding (per is 3 .. 6: B fragments + 0 .. 2 pieces of A + keep-bits)
+  // at most `groups` of this wave's per-step groups outstanding (per = 3 TN B fragments + 0 .. 2 pieces of A + keep-bits)
   auto wait_groups = [&](auto groups_c) {
-    constexpr int G = decltype(groups_c)::value;
-    if (per == 3) __builtin_amdgcn_s_waitcnt(waitcnt_vm(G * 3));
-    else if (per == 4) __builtin_amdgcn_s_waitcnt(waitcnt_vm(G * 4));
-    else if (per == 5) __builtin_amdgcn_s_waitcnt(waitcnt_vm(G * 5));
-    else __builtin_amdgcn_s_waitcnt(waitcnt_vm(G * 6));
+    constexpr int G = decltype(groups_c)::value, B0 = 3 * TN;
+    if (per == B0) __builtin_amdgcn_s_waitcnt(waitcnt_vm(G * B0));
+    else if (per == B0 + 1) __builtin_amdgcn_s_waitcnt(waitcnt_vm(G * (B0 + 1)));
+    else if (per == B0 + 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm(G * (B0 + 2)));
+    else __builtin_amdgcn_s_waitcnt(waitcnt_vm(G * (B0 + 3)));
   };
 
   // ---- B: fragment-major [N / 32][K / 16][3 planes][64 lanes][16 bytes]; this wave's block, its lane's 16 bytes ----
-  const char* bptr = static_cast<const char*>(g.B) + (size_t)(tile_n * 8 + wave) * (size_t)g.ldb + (size_t)(kbeg >> 4) * FRAG_KT + lane * 16;
-  u32x4 pb[NBS][3];
+  const char* bptr = static_cast<const char*>(g.B) + (size_t)(tile_n * 8 + wave * TN) * (size_t)g.ldb + (size_t)(kbeg >> 4) * FRAG_KT + lane * 16;
+  const size_t bblk = (size_t)g.ldb;                      // the wave's second 32-column block (TN = 2)
+  u32x4 pb[NBS][TN][3];
   auto load_b = [&](auto set_c) {
     constexpr int S = decltype(set_c)::value;
 #pragma unroll
-    for (int p = 0; p < 3; ++p)
-      if (!(SDUMC_P3_DBG & 2)) pb[S][p] = *reinterpret_cast<const u32x4*>(bptr + p * 1024);
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+        if (!(SDUMC_P3_DBG & 2)) pb[S][j][p] = *reinterpret_cast<const u32x4*>(bptr + j * bblk + p * 1024);
     bptr += FRAG_KT;
   };
 
-  f32x16 acc[TM];
+  f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   // a lane's MFMA operand of a 32-row block of A: 8 consecutive k (k-half lh) of row li, the three planes side by side (48 bytes)
   const int lane_off = li * ROWB + ((lh ^ ((li >> 3) & 1)) * 48);
@@ -235,14 +249,16 @@ __global__ __launch_bounds__(NTHR, 1) void gemm_p3_nt_kernel(const Args a) {
 #pragma unroll
     for (int t = 0; t < 6; ++t)
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        if (SDUMC_P3_DBG & 4) acc[i][t] += __uint_as_float(pa[P][i][TA[t]][0] ^ pb[S][TB[t]][1]);
-        else acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(pa[P][i][TA[t]]), op(pb[S][TB[t]]), acc[i], 0, 0, 0);
-      }
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          if (SDUMC_P3_DBG & 4) acc[i][j][t] += __uint_as_float(pa[P][i][TA[t]][0] ^ pb[S][j][TB[t]][1]);
+          else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(pa[P][i][TA[t]]), op(pb[S][j][TB[t]]), acc[i][j], 0, 0, 0);
+        }
   };
   auto interleave = [&]() {      // one memory instruction in the shadow of every MFMA as long as there are any
 #pragma unroll
-    for (int u = 0; u < 6 * TM; ++u) {
+    for (int u = 0; u < 6 * TM * TN; ++u) {
       __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
       __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // DS read
       __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);     // VMEM read
@@ -262,6 +278,9 @@ __global__ __launch_bounds__(NTHR, 1) void gemm_p3_nt_kernel(const Args a) {
   if constexpr (NST > 4) __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
   wait_groups(std::integral_constant<int, 3>{});          // stage 0 has landed
   __builtin_amdgcn_s_barrier();
+#if defined(SDUMC_P3_DBG) && (SDUMC_P3_DBG & 8)
+  const uint64_t dbg_r1 = __builtin_amdgcn_s_memrealtime();
+#endif
   load_a(lds, std::integral_constant<int, 0>{});
   int nbuf = 1;                                           // buffer of stage t + 1; stage t's (refilled with t + NST) is the one before it
   // step t: STEADY = stage t + NST and k-tile t + DB exist (every step issues, waits with the same count, has no tail logic)
@@ -296,26 +315,31 @@ __global__ __launch_bounds__(NTHR, 1) void gemm_p3_nt_kernel(const Args a) {
     step(t + 3, std::integral_constant<int, 1>{}, std::integral_constant<int, 3>{}, std::false_type{});
   }
 
+#if defined(SDUMC_P3_DBG) && (SDUMC_P3_DBG & 8)
+  const uint64_t dbg_r2 = __builtin_amdgcn_s_memrealtime();
+#endif
   // ---- epilogue.  C/D layout of the 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5).  The tile turns
   //      through LDS (the ring is free) so that a lane owns 8 consecutive columns of a row: 32-byte fp32 stores, and the P3 copy
   //      of the same values as one 48-byte chunk ----
   const bool to_slab = a.nsplit > 1;
   const float mscale = MASK ? g.a_scale : 1.f;
-  constexpr int LDT = 36;                                   // floats per staged row (keeps the b128 reads aligned, spreads banks)
+  constexpr int LDT = CF::LDT, WCOLS = 32 * TN, CPW = WCOLS / 8;      // a wave's columns, its 8-column chunks per row
   float* tw = reinterpret_cast<float*>(lds) + wave * 32 * LDT;
-  const int colw = n0 + 32 * wave;
+  const int colw = n0 + WCOLS * wave;
   float bv[8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) bv[c] = (!to_slab && g.bias) ? g.bias[colw + 8 * (lane & 3) + c] : 0.f;
+  for (int c = 0; c < 8; ++c) bv[c] = (!to_slab && g.bias) ? g.bias[colw + 8 * (lane & (CPW - 1)) + c] : 0.f;
   __syncthreads();                                          // every wave is done reading the last k-tile
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
-    for (int e = 0; e < 16; ++e) tw[((e & 3) + 8 * (e >> 2) + 4 * lh) * LDT + li] = acc[i][e] * mscale;
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) tw[((e & 3) + 8 * (e >> 2) + 4 * lh) * LDT + 32 * j + li] = acc[i][j][e] * mscale;
     __builtin_amdgcn_s_waitcnt(0xC07F);                     // lgkmcnt(0): this wave's own LDS writes (no other wave reads them)
 #pragma unroll
-    for (int u = lane; u < 128; u += 64) {
-      const int r = u >> 2, cq = u & 3;
+    for (int u = lane; u < 32 * CPW; u += 64) {
+      const int r = u / CPW, cq = u % CPW;
       const int row = m0 + 32 * i + r, col = colw + 8 * cq;
       if (row < g.M) {
         const f32x4 a0 = *reinterpret_cast<const f32x4*>(tw + r * LDT + 8 * cq), a1 = *reinterpret_cast<const f32x4*>(tw + r * LDT + 8 * cq + 4);
@@ -357,8 +381,8 @@ __global__ __launch_bounds__(NTHR, 1) void gemm_p3_nt_kernel(const Args a) {
     uint32_t* o = reinterpret_cast<uint32_t*>(g.C + (size_t)m0 * g.ldc + n0);
     o[0] = (uint32_t)(t1 - dbg_t0);
     o[1] = (uint32_t)(r1 - dbg_r0);
-    o[2] = (uint32_t)(dbg_r0 & 0xFFFFFFFFu);
-    o[3] = (uint32_t)(r1 & 0xFFFFFFFFu);
+    o[2] = (uint32_t)(dbg_r1 - dbg_r0);      // prologue: start -> stage 0 landed
+    o[3] = (uint32_t)(r1 - dbg_r2);          // epilogue
   }
 #endif
 #endif
@@ -372,8 +396,22 @@ __global__ __launch_bounds__(256) void p3_splitk_reduce_kernel(const sdumc_gemm_
   const int row = (int)(u / cpr), col = (int)(u - (size_t)row * cpr) * 8;
   float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const float* s = g.workspace + (size_t)row * g.N + col;
-  for (int z = 0; z < nsplit; ++z) {
-    const f32x4 a0 = *reinterpret_cast<const f32x4*>(s + (size_t)z * g.M * g.N), a1 = *reinterpret_cast<const f32x4*>(s + (size_t)z * g.M * g.N + 4);
+  const size_t slab = (size_t)g.M * g.N;
+  int z = 0;
+  for (; z + 4 <= nsplit; z += 4) {      // four slabs in flight; summed in ascending order
+    f32x4 a[4][2];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      a[q][0] = *reinterpret_cast<const f32x4*>(s + (size_t)(z + q) * slab);
+      a[q][1] = *reinterpret_cast<const f32x4*>(s + (size_t)(z + q) * slab + 4);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) { v[c] += a[q][0][c]; v[4 + c] += a[q][1][c]; }
+  }
+  for (; z < nsplit; ++z) {
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(s + (size_t)z * slab), a1 = *reinterpret_cast<const f32x4*>(s + (size_t)z * slab + 4);
 #pragma unroll
     for (int c = 0; c < 4; ++c) { v[c] += a0[c]; v[4 + c] += a1[c]; }
   }
@@ -491,8 +529,12 @@ struct Plan {
 };
 // BM: the tile height whose tile count fills 256 CUs in whole rounds with the least idle share; split K (fp32 slabs + an ordered
 // reduce) only when even 64-row tiles leave most of the chip idle and K is long.  k-tiles come in groups of four (the unrolled loop).
+inline bool tall_forms() {
+  static const int tall_env = [] { const char* e = getenv("SDUMC_P3_TALL"); return e ? atoi(e) : 0; }();
+  return tall_env != 0;
+}
 inline Plan plan(const sdumc_gemm_p3& g, size_t have) {
-  const int forced = g.tile_m;
+  const int forced = g.tile_m ? g.tile_m : (tall_forms() ? 0 : 64);
   const int tiles_n = g.N / BN;
   Plan best{64, 1, g.K};
   double best_cost = 1e30;
@@ -500,6 +542,7 @@ inline Plan plan(const sdumc_gemm_p3& g, size_t have) {
   for (int ci = 0; ci < 3; ++ci) {
     const int bm = cands[ci];
     if (forced && forced != bm) continue;
+    if (g.A2 && g.a2_row0 % bm) continue;                 // a tile must not straddle the two A tensors
     const long tiles = (long)((g.M + bm - 1) / bm) * tiles_n;
     const long rounds = (tiles + 255) / 256;
     // time ~ rounds * (rows per tile + a fixed prologue / epilogue share); smaller tiles pay more B traffic per row
@@ -530,7 +573,7 @@ int launch(const sdumc_gemm_p3& g, const Plan& p, hipStream_t st) {
   }
   Args a{g, p.nsplit, p.kchunk};
   const dim3 grid((unsigned)(((g.M + CF::BM - 1) / CF::BM) * (g.N / BN)), (unsigned)p.nsplit);
-  hipLaunchKernelGGL((gemm_p3_nt_kernel<CF>), grid, dim3(NTHR), CF::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((gemm_p3_nt_kernel<CF>), grid, dim3(CF::NTHR), CF::LDS_BYTES, st, a);
   return SDUMC_OK;
 }
 
@@ -557,8 +600,9 @@ extern "C" int sdumc_gemm_p3_nt(const sdumc_gemm_p3* gp, void* stream) {
   if (g.C && ((g.ldc & 3) || g.ldc < g.N)) return SDUMC_EINVAL;
   if (g.C_p3 && ((g.ldc_p3 & 15) || g.ldc_p3 < 6 * (int64_t)g.N)) return SDUMC_EINVAL;
   if (g.tile_m != 0 && g.tile_m != 64 && g.tile_m != 96 && g.tile_m != 128) return SDUMC_EINVAL;
+  if (g.A2 && (g.a_row_mod || g.a2_row0 <= 0 || g.a2_row0 >= g.M || (g.a2_row0 % 64) || (g.tile_m && g.a2_row0 % g.tile_m) || (reinterpret_cast<uintptr_t>(g.A2) & 15))) return SDUMC_EINVAL;
   if (g.act != SDUMC_ACT_NONE && g.act != SDUMC_ACT_TANH && g.act != SDUMC_ACT_RELU) return SDUMC_EINVAL;
-  const size_t a_bytes = (size_t)(g.a_row_mod > 0 ? g.a_row_mod : g.M) * (size_t)g.lda;
+  const size_t a_bytes = (size_t)(g.a_row_mod > 0 ? g.a_row_mod : (g.A2 ? std::max(g.a2_row0, g.M - g.a2_row0) : g.M)) * (size_t)g.lda;
   if (a_bytes >= 0xFFFFFFF0u) return SDUMC_EINVAL;
   const bool mask = g.a_bits != nullptr;
   if (mask && (g.bits_qw < g.K / 4 || (g.bits_qw & 3) || (reinterpret_cast<uintptr_t>(g.a_bits) & 3) || (size_t)g.M * g.bits_qw >= 0xFFFFFFF0u)) return SDUMC_EINVAL;
@@ -567,9 +611,13 @@ extern "C" int sdumc_gemm_p3_nt(const sdumc_gemm_p3* gp, void* stream) {
   hipStream_t st = as_stream(stream);
   const int tok = sdumc_prof_begin_(26, 2.0 * g.M * (double)g.N * g.K, stream);
   int rc;
-  static const int nst_env = [] { const char* e = getenv("SDUMC_P3_NST"); return e ? atoi(e) : 0; }();     // (measurement: depth of the A ring)
-  if (!mask && nst_env == 8) {
-    rc = p.bm == 128 ? launch<PCfg<128, 8, false>>(g, p, st) : p.bm == 96 ? launch<PCfg<96, 8, false>>(g, p, st) : launch<PCfg<64, 8, false>>(g, p, st);
+  // tile_m = 0: 64-row tiles on 256-thread workgroups, two per CU -- slower alone than the tall 512-thread forms on a shape that fills
+  // the chip in one round (audio frame projection: 76 against 62 us at 96 rows), faster inside the step, where three lanes' kernels
+  // share the chip (fp32 C2 step 1.370 against 1.386-1.391 ms, two alternations) -- a 512-thread workgroup holds its CU alone.
+  // SDUMC_P3_TALL=1 (A/B) / an explicit tile_m: the 512-thread forms.
+  static const int tall_env = [] { const char* e = getenv("SDUMC_P3_TALL"); return e ? atoi(e) : 0; }();
+  if (!g.tile_m && !tall_env) {
+    rc = mask ? launch<PCfg<64, 4, true, 4>>(g, p, st) : launch<PCfg<64, 4, false, 4>>(g, p, st);
   } else if (mask) {
     rc = p.bm == 128 ? launch<PCfg<128, 4, true>>(g, p, st) : p.bm == 96 ? launch<PCfg<96, 4, true>>(g, p, st) : launch<PCfg<64, 4, true>>(g, p, st);
   } else {

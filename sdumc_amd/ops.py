@@ -142,7 +142,7 @@ def p3_join(p3, cols):
 
 
 def gemm_p3_nt_call(A3, B3, M, N, K, bias=None, act=ACT_NONE, a_row_mod=0, bits=None, scale=1.0, C_out=None, want_f32=True,
-                    want_p3=False, splitk=0, tile_m=0):
+                    want_p3=False, splitk=0, tile_m=0, A3_second=None, second_row0=0):
     """The prepared call of gemm_p3_nt: returns (launch, results) -- launch() enqueues sdumc_gemm_p3_nt on the current stream
     (a few microseconds of host time: benches), results = the output tensor(s)."""
     dev = A3.device
@@ -150,6 +150,8 @@ def gemm_p3_nt_call(A3, B3, M, N, K, bias=None, act=ACT_NONE, a_row_mod=0, bits=
     g.M, g.N, g.K = M, N, K
     g.A, g.B, g.lda, g.ldb = ptr(A3), ptr(B3), A3.stride(0), B3.stride(0)
     g.a_row_mod = a_row_mod
+    if A3_second is not None:
+        g.A2, g.a2_row0 = ptr(A3_second), second_row0
     if bits is not None:
         g.a_bits, g.bits_qw, g.a_scale = ptr(bits), bits.stride(0), scale
     g.bias, g.act = ptr(bias), act
@@ -163,7 +165,7 @@ def gemm_p3_nt_call(A3, B3, M, N, K, bias=None, act=ACT_NONE, a_row_mod=0, bits=
     need = lib.sdumc_gemm_p3_workspace_bytes(C.byref(g))
     ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
     g.workspace, g.workspace_bytes = ptr(ws), need
-    keep = (A3, B3, bias, bits, ws, Cf, Cp)
+    keep = (A3, B3, bias, bits, ws, Cf, Cp, A3_second)
 
     def launch(_keep=keep):
         check(lib.sdumc_gemm_p3_nt(C.byref(g), _st()), "sdumc_gemm_p3_nt")

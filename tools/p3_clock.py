@@ -19,7 +19,7 @@ torch.cuda.synchronize()
 st = c.view(torch.int32)[::tm, :4].cpu().long() & 0xFFFFFFFF
 cyc, real = st[:, 0].double(), st[:, 1].double()
 mhz = cyc / real * 100.0
-start = (st[:, 2] - st[:, 2].min()) & 0xFFFFFFFF
-end = (st[:, 3] - st[:, 2].min()) & 0xFFFFFFFF
+pro, epi = st[:, 2].double() / 100, st[:, 3].double() / 100
 print(f"M={M} K={K} tile_m={tm}: launch {t:.1f} us; per workgroup: {float(real.mean()) / 100:.1f} us (min {float(real.min()) / 100:.1f}, max {float(real.max()) / 100:.1f}), "
-      f"shader clock {float(mhz.mean()):.0f} MHz (min {float(mhz.min()):.0f}, max {float(mhz.max()):.0f}); starts spread {float(start.max()) / 100:.1f} us, last end {float(end.max()) / 100:.1f} us")
+      f"shader clock {float(mhz.mean()):.0f} MHz (min {float(mhz.min()):.0f}, max {float(mhz.max()):.0f}); prologue {float(pro.mean()):.2f} us (max {float(pro.max()):.2f}), "
+      f"epilogue {float(epi.mean()):.2f} us (max {float(epi.max()):.2f})")
