@@ -260,7 +260,8 @@ typedef struct sdumc_gemm_p3 {
 } sdumc_gemm_p3;
 size_t sdumc_gemm_p3_workspace_bytes(const sdumc_gemm_p3* g);
 int sdumc_gemm_p3_nt(const sdumc_gemm_p3* g, void* stream);
-/* fp32 [rows][cols] (row stride ld floats, cols % 8 == 0, 16-byte aligned) <-> P3 (row stride ld_bytes); join is bit-exact */
+/* fp32 [rows][cols] (row stride ld floats, cols % 8 == 0, 16-byte aligned) <-> P3 (row stride ld_bytes); join(split(x)) == x bit for
+ * bit for every finite non-zero x below 0x1.FEp127 in magnitude; -0 comes back as +0 */
 int sdumc_p3_split(const float* src, int64_t ld, void* dst, int64_t ld_bytes, int64_t rows, int32_t cols, void* stream);
 /* fp32 weight [rows][cols] (rows % 32 == 0, cols % 16 == 0) -> fragment-major P3, 6 rows cols bytes, blocks of 32 rows contiguous */
 int sdumc_p3_split_frag(const float* src, int64_t ld, void* dst, int32_t rows, int32_t cols, void* stream);
@@ -386,6 +387,11 @@ typedef struct sdumc_umca {
   sdumc_attnpool a;      /* as for sdumc_attnpool_fwd; a.keys = OUTPUT [V, T, 256] or NULL */
   const float* w_in;     /* input_proj.weight [256, 256] as stored (model :60 / :82) */
   const float* b_in;     /* input_proj.bias [256] */
+  /* optional, both or neither: the projection's operands split once per tensor (sdumc_gemm_p3): the frames a.x as a P3 tensor
+   * ([x_samples * T][256], rows of 1536 bytes) and w_in fragment-major (sdumc_p3_split_frag).  a.x (fp32) is still read by the
+   * pooling part.  Needs the split arithmetic on (sdumc_set_split_ bit 2), else SDUMC_EINVAL. */
+  const void* x_p3;
+  const void* w_in_p3f;
 } sdumc_umca;
 int sdumc_umca_fwd(const sdumc_umca* p, void* stream);
 

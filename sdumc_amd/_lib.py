@@ -89,7 +89,7 @@ class AttnPool(C.Structure):
 
 
 class Umca(C.Structure):
-    _fields_ = [("a", AttnPool), ("w_in", C.c_void_p), ("b_in", C.c_void_p)]
+    _fields_ = [("a", AttnPool), ("w_in", C.c_void_p), ("b_in", C.c_void_p), ("x_p3", C.c_void_p), ("w_in_p3f", C.c_void_p)]
 
 
 class AttnPoolBwd(C.Structure):

@@ -21,6 +21,7 @@
 #include <type_traits>
 
 #include "common.h"
+#include "p3_loop.h"
 #include <cstring>
 
 namespace {
@@ -1492,8 +1493,62 @@ __global__ __launch_bounds__(256, 2) void umca_fwd_split_kernel(const sdumc_umca
   umca_fwd_body<MASK, true>(u, nchunk, lds);
 }
 
+// The same kernel with the key projection on operands split ONCE PER TENSOR (gemm_p3.hip; round 5): A = the projected frames' bf16
+// planes (written by the frame projection's epilogue), B = the fragment-major planes of W_in, straight into registers -- the k-loop
+// is p3_mainloop (p3_loop.h) on a 64 x 256 tile, 256 threads, two workgroups per CU as before; the pooling part is unchanged and
+// still reads the fp32 frames.  No split of x or W per workgroup per k-tile: the in-kernel form spent ~10 VALU instructions per MFMA.
+using K3P3Cfg_m = sdumc_p3::PCfg<64, 4, true, 4>;
+using K3P3Cfg_n = sdumc_p3::PCfg<64, 4, false, 4>;
+static_assert(K3P3Cfg_m::LDS_BYTES <= TOP_BYTES, "the P3 ring lies inside the key tile's memory");
+template <bool MASK>
+__global__ __launch_bounds__(256, 2) void umca_fwd_p3_kernel(const sdumc_umca u, const int nchunk) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  using CF = std::conditional_t<MASK, K3P3Cfg_m, K3P3Cfg_n>;
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const sdumc_attnpool& p = u.a;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  const int wn0 = wave * 64;
+  const int chunk = blockIdx.x, v = blockIdx.y;
+  const int T = p.T, t0 = chunk * CH, vx = v % p.x_samples;
+  const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(u.x_p3), 0,
+      (int)min((size_t)p.x_samples * T * D * 6, (size_t)0xFFFFFFF0u), 0x00020000);
+  const uint32_t qw = (p.x_drop.width + 3u) >> 2;
+  const __amdgpu_buffer_rsrc_t rbits = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(MASK ? p.x_drop.bits : static_cast<const uint8_t*>(u.x_p3)), 0,
+      MASK ? (int)min((size_t)p.V * T * qw, (size_t)0xFFFFFFF0u) : 0, 0x00020000);
+  f32x16 acc[2][2];
+  sdumc_p3::p3_mainloop<CF>(lds, ra, (int64_t)D * 6, [&](int row) { return vx * T + min(t0 + row, T - 1); },      // rows beyond T: the last row
+                            rbits, (int)qw, [&](int row) { return v * T + min(t0 + row, T - 1); },
+                            static_cast<const char*>(u.w_in_p3f) + (size_t)(wave * 2) * (size_t)((D / 16) * sdumc_p3::FRAG_KT), (size_t)((D / 16) * sdumc_p3::FRAG_KT),
+                            0, D / sdumc_p3::BK, acc);
+  __syncthreads();      // every wave has read its last fragments: the ring's memory becomes the key tile
+  const float mscale = MASK ? p.x_drop.scale : 1.f;
+  float* K_s = reinterpret_cast<float*>(lds);
+  float* q_s = reinterpret_cast<float*>(lds + TOP_BYTES);
+  float* keys_out = const_cast<float*>(p.keys);
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = wn0 + 32 * j + li;
+      const float bv = u.b_in[col];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int row = 32 * i + (e & 3) + 8 * (e >> 2) + 4 * lh;
+        const float kv = fast_tanh(acc[i][j][e] * mscale + bv);
+        K_s[row * UMCA_LDK + col] = kv;
+        if (keys_out && t0 + row < T) keys_out[((size_t)v * T + t0 + row) * D + col] = kv;
+      }
+    }
+  __syncthreads();
+  attn_fwd_partial_body<false, 1, false, true>(p, static_cast<float*>(p.workspace), nchunk, chunk, v, K_s, q_s, K_s);
+#endif
+}
+
 }  // namespace sdumc_k3
 
+static inline uint32_t qw_of(const sdumc_dropout& d) { return (d.width + 3u) >> 2; }
 extern "C" int sdumc_umca_fwd(const sdumc_umca* up, void* stream) {
   if (!up) return SDUMC_EINVAL;
   sdumc_umca u = *up;
@@ -1520,7 +1575,22 @@ extern "C" int sdumc_umca_fwd(const sdumc_umca* up, void* stream) {
   hipStream_t st = as_stream(stream);
   const int nchunk = (p.T + CH - 1) / CH;
   const dim3 grid(nchunk, p.V), blk(256);
-  if (sdumc_split_on_(SDUMC_SPLIT_UMCA)) {
+  if (u.x_p3 && u.w_in_p3f) {      // the projection on operands split once per tensor
+    if (!sdumc_split_on_(SDUMC_SPLIT_UMCA)) return SDUMC_EINVAL;                      // planes ARE the split arithmetic
+    if ((reinterpret_cast<uintptr_t>(u.x_p3) | reinterpret_cast<uintptr_t>(u.w_in_p3f)) & 15) return SDUMC_EINVAL;
+    if (p.x_drop.enabled && (qw_of(p.x_drop) & 3)) return SDUMC_EINVAL;
+    static bool attr_p3 = false;
+    if (!attr_p3) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sdumc_k3::umca_fwd_p3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              sdumc_k3::LDS_BYTES) != hipSuccess ||
+          hipFuncSetAttribute(reinterpret_cast<const void*>(&sdumc_k3::umca_fwd_p3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              sdumc_k3::LDS_BYTES) != hipSuccess)
+        return SDUMC_ELAUNCH;
+      attr_p3 = true;
+    }
+    if (p.x_drop.enabled) hipLaunchKernelGGL(sdumc_k3::umca_fwd_p3_kernel<true>, grid, blk, sdumc_k3::LDS_BYTES, st, u, nchunk);
+    else hipLaunchKernelGGL(sdumc_k3::umca_fwd_p3_kernel<false>, grid, blk, sdumc_k3::LDS_BYTES, st, u, nchunk);
+  } else if (sdumc_split_on_(SDUMC_SPLIT_UMCA)) {
     if (p.x_drop.enabled) hipLaunchKernelGGL(sdumc_k3::umca_fwd_split_kernel<true>, grid, blk, sdumc_k3::LDS_BYTES, st, u, nchunk);
     else hipLaunchKernelGGL(sdumc_k3::umca_fwd_split_kernel<false>, grid, blk, sdumc_k3::LDS_BYTES, st, u, nchunk);
   } else if (p.x_drop.enabled) hipLaunchKernelGGL(sdumc_k3::umca_fwd_kernel<true>, grid, blk, sdumc_k3::LDS_BYTES, st, u, nchunk);

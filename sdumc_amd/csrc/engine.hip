@@ -1101,6 +1101,11 @@ int umca_site(const Ctx& c, int k, int m, bool keep) {
     const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
     u.w_in = c.P + L.w;
     u.b_in = c.P + L.b;
+    static const int k3_p3 = [] { const char* e = getenv("SDUMC_K3_P3"); return e ? atoi(e) : 1; }();      // (A/B: the fused kernel's projection on planes)
+    if (k3_p3 && p3_mode(c) && sdumc_split_on_(SDUMC_SPLIT_UMCA)) {
+      u.x_p3 = c.p(c.pl.xp3[m][sg.s0]);
+      u.w_in_p3f = wp3_ptr(c, c.pl.wp3_key[k][m]);
+    }
     RET(sdumc_umca_fwd(&u, c.st));
   }
   return SDUMC_OK;

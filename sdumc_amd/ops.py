@@ -304,7 +304,8 @@ def attnpool_bwd(desc, dout, keep, shared_q_sum=False):
     return dz, dxd, dq
 
 
-def umca_fwd(x, W, b, q, nq, x_samples=None, q_shared=False, x_drop=None, out_drop=None, lengths=None, want_keys=True, V=None):
+def umca_fwd(x, W, b, q, nq, x_samples=None, q_shared=False, x_drop=None, out_drop=None, lengths=None, want_keys=True, V=None,
+             planes=False):
     """K3 (sdumc_umca_fwd): key projection + scores + softmax partials + pooling in one kernel.  x [x_samples, T, 256] fp32,
     W [256, 256], b [256]; x_drop must carry keep-bits (dropout_bits).  -> (out, attn, pooled, keys or None, desc); the desc
     (with keys attached) is what attnpool_bwd takes."""
@@ -323,9 +324,13 @@ def umca_fwd(x, W, b, q, nq, x_samples=None, q_shared=False, x_drop=None, out_dr
     u = _lib.Umca()
     u.a = a
     u.w_in, u.b_in = ptr(W), ptr(b)
+    x3 = w3 = None
+    if planes:      # the projection's operands split once per tensor (sdumc_umca.x_p3 / w_in_p3f)
+        x3, w3 = p3_split(x.reshape(xs * T, Dm)), p3_split_frag(W)
+        u.x_p3, u.w_in_p3f = ptr(x3), ptr(w3)
     check(lib.sdumc_umca_fwd(C.byref(u), _st()), "sdumc_umca_fwd")
     torch.cuda.current_stream().synchronize()
-    a._keep = (ws, keys, x, q, W, b, lengths)
+    a._keep = (ws, keys, x, q, W, b, lengths, x3, w3)
     return out, attn, pooled, keys, a
 
 

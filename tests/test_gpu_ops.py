@@ -332,6 +332,16 @@ def test_umca_fused_forward_k3(ops, nq, T, shared_q, mask):
     close(keys, keys_f, 5e-6)
     close(out, out_f, 1e-5)
     close(attn, attn_f, 1e-5)
+    # round 5: the projection on operands split once per tensor (x as a P3 tensor, W fragment-major; csrc/p3_loop.h) -- the form the
+    # step runs: as close to fp64 as the other two, within 5e-6 / 1e-5 of the in-kernel split form
+    out_p, attn_p, pooled_p, keys_p, _ = ops.umca_fwd(xg, Wg, bg, qg, nq, x_samples=B, q_shared=shared_q, x_drop=xdrop if mask else None,
+                                                      out_drop=odrop, V=V, planes=True)
+    close(keys_p, keys_ref, 2e-5)
+    close(attn_p, a_ref, 2e-5)
+    close(pooled_p, pooled_ref, 2e-5)
+    close(out_p, out_ref, 2e-5)
+    close(keys_p, keys, 5e-6)
+    close(out_p, out, 1e-5)
     # inference form: no keys tensor at all, same outputs
     out3, attn3, pooled3, none, _ = ops.umca_fwd(xg, Wg, bg, qg, nq, x_samples=B, q_shared=shared_q, x_drop=xdrop if mask else None,
                                                  out_drop=odrop, want_keys=False, V=V)
