@@ -224,6 +224,11 @@ __device__ __forceinline__ void cxm_selfcheck(const CRing& ring, const float* M,
 // for the writes to HBM (the stage's input tensor, pooled) and for the in-place normalisation of the stored weights.
 // s_rows: [3][R * NQT][256]; s_fac: scratch [3 R][FOLD_MAXCHUNK][8]; out: [3][V][NQT][256].
 constexpr int FOLD_MAXCHUNK = 32;
+// (round 5: every loop below requests its loads in batches of 8 before it uses the first -- as written first, one dependent
+//  L2 / fabric round trip per chunk, these folds were most of their stages: 19 + 17 us of stage A forward's 77 incl. the wait for the
+//  slowest member at the first exchange, 29 of stage B forward's 60, 57 of stage A backward's 120 (profiles/r4z_step_marks_fp32.txt);
+//  the in-place normalisation of the stored weights is dealt to the members by ELEMENT range, not by (modality, sample) pair: the
+//  member that drew audio's 375 frames kept the other three waiting at the first exchange)
 template <int R, int NQT>
 __device__ __forceinline__ void fold_combine(const sdumc_chain_fold& f, float* out, float* s_rows, float* s_fac, const int v0, const int V,
                                              const int member, const DropRT& dbase) {
@@ -234,12 +239,32 @@ __device__ __forceinline__ void fold_combine(const sdumc_chain_fold& f, float* o
     if (v < V) {
       const int nc = f.nchunk[m];
       const float* st = f.stats[m] + (size_t)v * nc * 16 + i;
-      float mx = -INFINITY;
-      for (int c = 0; c < nc; ++c) mx = fmaxf(mx, st[c * 16]);
-      float l = 0.f;
-      for (int c = 0; c < nc; ++c) l += st[c * 16 + 8] * expf(st[c * 16] - mx);
-      const float inv = 1.f / l;
-      for (int c = 0; c < nc; ++c) s_fac[(mr * FOLD_MAXCHUNK + c) * 8 + i] = expf(st[c * 16] - mx) * inv;
+      if (nc <= 8) {      // the chunk statistics of a row in registers: 16 independent loads
+        float cm[8], cs[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          cm[c] = c < nc ? st[c * 16] : -INFINITY;
+          cs[c] = c < nc ? st[c * 16 + 8] : 0.f;
+        }
+        float mx = -INFINITY;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) mx = fmaxf(mx, cm[c]);
+        float l = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (c < nc) l += cs[c] * expf(cm[c] - mx);      // ascending c, as attn_fwd_combine_body
+        const float inv = 1.f / l;
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+          if (c < nc) s_fac[(mr * FOLD_MAXCHUNK + c) * 8 + i] = expf(cm[c] - mx) * inv;
+      } else {
+        float mx = -INFINITY;
+        for (int c = 0; c < nc; ++c) mx = fmaxf(mx, st[c * 16]);
+        float l = 0.f;
+        for (int c = 0; c < nc; ++c) l += st[c * 16 + 8] * expf(st[c * 16] - mx);
+        const float inv = 1.f / l;
+        for (int c = 0; c < nc; ++c) s_fac[(mr * FOLD_MAXCHUNK + c) * 8 + i] = expf(st[c * 16] - mx) * inv;
+      }
     }
   }
   __syncthreads();
@@ -250,9 +275,18 @@ __device__ __forceinline__ void fold_combine(const sdumc_chain_fold& f, float* o
     f32x4 o = {0.f, 0.f, 0.f, 0.f};
     if (v < V) {
       const int nc = f.nchunk[m];
+      const float* src = f.part[m] + ((size_t)v * nc * NQT + i) * D + 4 * cq;
+      const float* fac = s_fac + (mr * FOLD_MAXCHUNK) * 8 + i;
       f32x4 sum = {0.f, 0.f, 0.f, 0.f};
-      for (int c = 0; c < nc; ++c)
-        sum += ld4(f.part[m] + (((size_t)v * nc + c) * NQT + i) * D + 4 * cq) * s_fac[(mr * FOLD_MAXCHUNK + c) * 8 + i];
+      for (int c0 = 0; c0 < nc; c0 += 8) {      // eight chunks' rows in flight, summed in ascending c
+        f32x4 pv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (c0 + j < nc) pv[j] = ld4(src + (size_t)(c0 + j) * NQT * D);
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          if (c0 + j < nc) sum += pv[j] * fac[(c0 + j) * 8];
+      }
       o = sum;
       if (dbase.enabled) {
         DropRT od = mkdrop_rt(dbase, (uint32_t)f.site[m], NQT, D);
@@ -267,14 +301,27 @@ __device__ __forceinline__ void fold_combine(const sdumc_chain_fold& f, float* o
     }
     st4(s_rows + (size_t)row * D + 4 * cq, o);
   }
-  for (int mr = member; mr < 3 * R; mr += CL) {
+  // stored weights *= fac: every (modality, sample) row range is cut into CL equal parts, one per member; four elements per thread in flight
+  for (int mr = 0; mr < 3 * R; ++mr) {
     const int m = mr / R, v = v0 + (mr - m * R);
     if (v >= V) continue;
-    const int T = f.T[m];
-    float* w = f.attn[m] + (size_t)v * T * NQT;
-    for (int e = tid; e < T * NQT; e += NTHR) {
-      const int t = e / NQT, i = e - t * NQT;
-      w[e] *= s_fac[(mr * FOLD_MAXCHUNK + (t >> 6)) * 8 + i];
+    const int n = f.T[m] * NQT, per = (n + CL - 1) / CL;
+    const int e0 = member * per, e1 = min(n, e0 + per);
+    float* w = f.attn[m] + (size_t)v * n;
+    const float* fac = s_fac + (mr * FOLD_MAXCHUNK) * 8;
+    for (int e = e0 + tid; e < e1; e += 4 * NTHR) {
+      float wv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (e + j * NTHR < e1) wv[j] = w[e + j * NTHR];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int ee = e + j * NTHR;
+        if (ee < e1) {
+          const int t = ee / NQT, i = ee - t * NQT;
+          w[ee] = wv[j] * fac[(t >> 6) * 8 + i];
+        }
+      }
     }
   }
 }
@@ -959,7 +1006,15 @@ __device__ __forceinline__ void chain_bwd_a_cl_body(const sdumc_chain_args a, co
       if (v < V) {
         const int nc = a.dq_nchunk[m];
         const float* src = a.dq_part[m] + ((size_t)v * nc * NQ + i) * D + 4 * cq;
-        for (int c = 0; c < nc; ++c) sum += ld4(src + (size_t)c * NQ * D);
+        for (int c0 = 0; c0 < nc; c0 += 8) {      // eight chunks' slabs in flight (one dependent round trip per chunk made this loop 57 us of the stage)
+          f32x4 pv[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (c0 + j < nc) pv[j] = ld4(src + (size_t)(c0 + j) * NQ * D);
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (c0 + j < nc) sum += pv[j];      // ascending c, as dq_reduce_multi
+        }
         if ((mr & (CL - 1)) == member) st4(a.d_qp + (((size_t)m * V + v) * NQ + i) * D + 4 * cq, sum);
       }
       st4(s_x + (size_t)row * D + 4 * cq, sum);

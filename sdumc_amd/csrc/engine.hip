@@ -767,6 +767,11 @@ int flush_dw_on(const Ctx& c, int after, int lane, int slab) {
   return SDUMC_OK;
 }
 int flush_dw(const Ctx& c) { return flush_dw_on(c, 0, 3, 0); }
+// (measured and dropped, round 5: the three weight gradients the grouped launch refuses -- fc_att, cross_fc_att, fc_out_v: 3 / 7 / 1
+//  output rows, four-workgroup launches that sit in front of the first grouped launch on lane 3 and take 13-44 us each there --
+//  issued as soon as they are queued, on a side lane that idles through the utterance-level backward: 1.402-1.409 against 1.374-1.388 ms
+//  fp32, 0.961-0.969 against 0.948-0.961 bf16; the two extra event records on the caller's stream cost the latency-bound chain
+//  more than the grouped launch's earlier start gives back)
 
 // backward of y = act(x W^T + b) given dzv = gradient w.r.t. the pre-activation, [M, L.out] with ld lddz:
 //   dW = dz^T x, db = colsum(dz), dx (=|+=) dz W
