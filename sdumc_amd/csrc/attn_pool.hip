@@ -979,13 +979,10 @@ __global__ __launch_bounds__(256, 4) void attn_fwd_partial_v2_multi_kernel(const
   attn_fwd_partial_v2<HF, NQT>(p, static_cast<float*>(p.workspace), nchunk, chunk, v);
 }
 
-// the v2 kernels take: 256-channel rows, nq = 1 or 7, keep-bits (or no input mask), the two-pass combine.  SDUMC_ATTN_V2=0 keeps
-// the round-3 kernels (A/B measurements)
-int g_v2 = -1;     // -1: not read yet (SDUMC_ATTN_V2, default on); sdumc_attnpool_set_v2_ (tests, A/B tools)
-bool v2_on() {
-  if (g_v2 < 0) { const char* e = getenv("SDUMC_ATTN_V2"); g_v2 = (e && e[0] == '0') ? 0 : 1; }
-  return g_v2 != 0;
-}
+// the v2 kernels take: 256-channel rows, nq = 1 or 7, keep-bits (or no input mask), the two-pass combine; everything else (wider
+// rows, Philox masks, tickets) runs on the round-3 kernels.  sdumc_attnpool_set_v2_(0): the bit-for-bit comparison of the tests
+int g_v2 = 1;
+bool v2_on() { return g_v2 != 0; }
 bool v2_takes(const sdumc_attnpool& p) {
   return v2_on() && row_dim(p) == D && (p.nq == 1 || p.nq == 7) && !p.tickets && !(p.x_drop.enabled && !p.x_drop.bits) &&
          (!p.bf16 || !p.x_drop.enabled);

@@ -133,11 +133,8 @@ __device__ __forceinline__ void chain_fwd_a_body(const sdumc_chain_args a) {
     rxm_run<NQ * R, D, D, WT>(ring, s_q, D, a.caq_w[m], D, part, epi, [&] { if (m < 2) rxm_prefetch<D, D, WT>(ring, a.caq_w[m + 1], D); });
   }
 }
-// (two entry points: with packed FP32 VALU instructions, and without -- SDUMC_NO_PACKED_FP32, chain_common.h)
 template <int R, class WT>
 __global__ __launch_bounds__(NTHR) void chain_fwd_a_kernel(const sdumc_chain_args a) { chain_fwd_a_body<R, WT>(a); }
-template <int R, class WT>
-__global__ SDUMC_NO_PACKED_FP32 __launch_bounds__(NTHR) void chain_fwd_a_np_kernel(const sdumc_chain_args a) { chain_fwd_a_body<R, WT>(a); }
 
 // ------------------------------------------------------------------------------------------------------------------
 // stage B forward (model :338-368)
@@ -278,11 +275,8 @@ __device__ __forceinline__ void chain_fwd_b_body(const sdumc_chain_args a) {
     rows_x_matrix<R, RD, RD>(s_r1, RD, a.rnc2_w, RD, part, epi);
   }
 }
-// (two entry points: with packed FP32 VALU instructions, and without -- SDUMC_NO_PACKED_FP32, chain_common.h)
 template <int R, class WT>
 __global__ __launch_bounds__(NTHR) void chain_fwd_b_kernel(const sdumc_chain_args a) { chain_fwd_b_body<R, WT>(a); }
-template <int R, class WT>
-__global__ SDUMC_NO_PACKED_FP32 __launch_bounds__(NTHR) void chain_fwd_b_np_kernel(const sdumc_chain_args a) { chain_fwd_b_body<R, WT>(a); }
 
 // ------------------------------------------------------------------------------------------------------------------
 // stage B backward: d(vals, fused, rnc, cross_text) -> d_ca_out [3][V,7,256], d_alpha (second-level part), and every
@@ -423,11 +417,8 @@ __device__ __forceinline__ void chain_bwd_b_body(const sdumc_chain_args a) {
     }
   }
 }
-// (two entry points: with packed FP32 VALU instructions, and without -- SDUMC_NO_PACKED_FP32, chain_common.h)
 template <int R, class WT>
 __global__ __launch_bounds__(NTHR) void chain_bwd_b_kernel(const sdumc_chain_args a) { chain_bwd_b_body<R, WT>(a); }
-template <int R, class WT>
-__global__ SDUMC_NO_PACKED_FP32 __launch_bounds__(NTHR) void chain_bwd_b_np_kernel(const sdumc_chain_args a) { chain_bwd_b_body<R, WT>(a); }
 
 // ------------------------------------------------------------------------------------------------------------------
 // stage A backward: d_qp [3][V,7,256] (+ d text_hidden, + d_alpha from stage B) -> d_hpre [3][V,256] and the
@@ -559,11 +550,8 @@ __device__ __forceinline__ void chain_bwd_a_body(const sdumc_chain_args a) {
     }
   }
 }
-// (two entry points: with packed FP32 VALU instructions, and without -- SDUMC_NO_PACKED_FP32, chain_common.h)
 template <int R, class WT>
 __global__ __launch_bounds__(NTHR) void chain_bwd_a_kernel(const sdumc_chain_args a) { chain_bwd_a_body<R, WT>(a); }
-template <int R, class WT>
-__global__ SDUMC_NO_PACKED_FP32 __launch_bounds__(NTHR) void chain_bwd_a_np_kernel(const sdumc_chain_args a) { chain_bwd_a_body<R, WT>(a); }
 
 // transposed mirror of the utterance-level weights: dst[i][o] = src[o][i] for up to 40 matrices in one launch
 struct TransposeList {
@@ -605,30 +593,21 @@ extern "C" int sdumc_chain_launch_(const sdumc_chain_args* a, int which, void* s
   if (!attr) {
     if (set_smem(chain_fwd_a_kernel<R, float>, smem_fwd_a<R>()) || set_smem(chain_fwd_b_kernel<R, float>, smem_fwd_b<R>()) ||
         set_smem(chain_bwd_b_kernel<R, float>, smem_bwd_b<R>()) || set_smem(chain_bwd_a_kernel<R, float>, smem_bwd_a<R>()) ||
-        set_smem(chain_fwd_a_np_kernel<R, float>, smem_fwd_a<R>()) || set_smem(chain_fwd_b_np_kernel<R, float>, smem_fwd_b<R>()) ||
-        set_smem(chain_bwd_b_np_kernel<R, float>, smem_bwd_b<R>()) || set_smem(chain_bwd_a_np_kernel<R, float>, smem_bwd_a<R>()) ||
-        set_smem(chain_fwd_a_np_kernel<R, bf>, smem_fwd_a<R>()) || set_smem(chain_fwd_b_np_kernel<R, bf>, smem_fwd_b<R>()) ||
-        set_smem(chain_bwd_b_np_kernel<R, bf>, smem_bwd_b<R>()) || set_smem(chain_bwd_a_np_kernel<R, bf>, smem_bwd_a<R>()))
+        set_smem(chain_fwd_a_kernel<R, bf>, smem_fwd_a<R>()) || set_smem(chain_fwd_b_kernel<R, bf>, smem_fwd_b<R>()) ||
+        set_smem(chain_bwd_b_kernel<R, bf>, smem_bwd_b<R>()) || set_smem(chain_bwd_a_kernel<R, bf>, smem_bwd_a<R>()))
       return SDUMC_ELAUNCH;
     attr = true;
   }
   const dim3 grid((a->V + R - 1) / R), blk(NTHR);
   hipStream_t st = as_stream(stream);
-  // bf16 weight streams exist in bf16-storage mode only, where bf16 MFMA kernels run beside these: always the entry points without
-  // packed FP32 ops; fp32 weights: by the caller's flag (engine: sdumc_net_dims.bf16 != 0)
+  // (one entry point per stage and weight type: the whole device build carries no packed fp32 operations -- Makefile, NOPACK --,
+  //  so the "_np_" twins of round 4 compiled to the same code and are gone)
   if (a->w_bf16) {
     switch (which) {
-      case 0: hipLaunchKernelGGL((chain_fwd_a_np_kernel<R, bf>), grid, blk, smem_fwd_a<R>(), st, *a); break;
-      case 1: hipLaunchKernelGGL((chain_fwd_b_np_kernel<R, bf>), grid, blk, smem_fwd_b<R>(), st, *a); break;
-      case 2: hipLaunchKernelGGL((chain_bwd_b_np_kernel<R, bf>), grid, blk, smem_bwd_b<R>(), st, *a); break;
-      default: hipLaunchKernelGGL((chain_bwd_a_np_kernel<R, bf>), grid, blk, smem_bwd_a<R>(), st, *a); break;
-    }
-  } else if (a->no_packed_fp32) {
-    switch (which) {
-      case 0: hipLaunchKernelGGL((chain_fwd_a_np_kernel<R, float>), grid, blk, smem_fwd_a<R>(), st, *a); break;
-      case 1: hipLaunchKernelGGL((chain_fwd_b_np_kernel<R, float>), grid, blk, smem_fwd_b<R>(), st, *a); break;
-      case 2: hipLaunchKernelGGL((chain_bwd_b_np_kernel<R, float>), grid, blk, smem_bwd_b<R>(), st, *a); break;
-      default: hipLaunchKernelGGL((chain_bwd_a_np_kernel<R, float>), grid, blk, smem_bwd_a<R>(), st, *a); break;
+      case 0: hipLaunchKernelGGL((chain_fwd_a_kernel<R, bf>), grid, blk, smem_fwd_a<R>(), st, *a); break;
+      case 1: hipLaunchKernelGGL((chain_fwd_b_kernel<R, bf>), grid, blk, smem_fwd_b<R>(), st, *a); break;
+      case 2: hipLaunchKernelGGL((chain_bwd_b_kernel<R, bf>), grid, blk, smem_bwd_b<R>(), st, *a); break;
+      default: hipLaunchKernelGGL((chain_bwd_a_kernel<R, bf>), grid, blk, smem_bwd_a<R>(), st, *a); break;
     }
   } else {
     switch (which) {

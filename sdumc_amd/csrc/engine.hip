@@ -1106,8 +1106,7 @@ int umca_site(const Ctx& c, int k, int m, bool keep) {
     const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
     u.w_in = c.P + L.w;
     u.b_in = c.P + L.b;
-    static const int k3_p3 = [] { const char* e = getenv("SDUMC_K3_P3"); return e ? atoi(e) : 1; }();      // (A/B: the fused kernel's projection on planes)
-    if (k3_p3 && p3_mode(c) && sdumc_split_on_(SDUMC_SPLIT_UMCA)) {
+    if (p3_mode(c) && sdumc_split_on_(SDUMC_SPLIT_UMCA)) {      // the fused kernel's projection on planes (1.361-1.364 against 1.374-1.376 ms)
       u.x_p3 = c.p(c.pl.xp3[m][sg.s0]);
       u.w_in_p3f = wp3_ptr(c, c.pl.wp3_key[k][m]);
     }
@@ -1150,10 +1149,9 @@ bool use_cluster(const Ctx& c) {
 // The clustered stage A combines the FRA2UTT sites' softmax partials in its own prologue (chain_cluster.hip::fra_combine): the
 // pooling launches of the three modality lanes then stop after their per-chunk pass (sdumc_attnpool.partial_only) and the three
 // combine launches -- 31-39 us each inside the step, on every lane's way to this stage -- are gone.  One run per modality (equal
-// text / feat4 lengths), at most 32 chunks per sample; SDUMC_FRA_FOLD=0 keeps the separate combine launches (A/B).
+// text / feat4 lengths), at most 32 chunks per sample (the separate combine launches remain the path of the plain kernels).
 bool fra_fold(const Ctx& c) {
-  static const int on = [] { const char* e = getenv("SDUMC_FRA_FOLD"); return e ? atoi(e) : 1; }();
-  if (!on || !use_cluster(c)) return false;
+  if (!use_cluster(c)) return false;
   for (int m = 0; m < 3; ++m)
     if (c.pl.segs[m].size() != 1 || (c.pl.segs[m][0].T + 63) / 64 > 32) return false;
   return true;
@@ -1223,9 +1221,8 @@ sdumc_chain_args chain_args(const Ctx& c, bool fwd, const sdumc_net_grads* og, b
   const bool wb = c.h() && stage_a && !use_cluster(c);
   a.w_bf16 = wb ? 1 : 0;
   // bf16 MFMA kernels run beside the utterance-level stages (chain_common.h): in the bf16 modes always, in fp32 when the GEMM
-  // kernels compute their products on the bf16 matrix pipe (sdumc_set_split_).  SDUMC_NO_PACKED=0/1 overrides (diagnosis).
-  static const int np_env = [] { const char* e = getenv("SDUMC_NO_PACKED"); return e ? atoi(e) : -1; }();
-  a.no_packed_fp32 = np_env >= 0 ? np_env : ((c.d.bf16 != 0 || sdumc_split_on_(SDUMC_SPLIT_ALL)) ? 1 : 0);
+  // kernels compute their products on the bf16 matrix pipe (sdumc_set_split_).
+  a.no_packed_fp32 = 1;      // (the whole device build carries no packed fp32 operations since round 4: one entry point per stage)
   auto W = [&](const Lin& L) -> const float* {
     if (wb) return reinterpret_cast<const float*>(c.ph(fwd ? pl.wht : pl.wh, L.w));
     return WB + L.w;
@@ -1366,7 +1363,7 @@ int forward(const Ctx& c) {
   // frame_dim_reshape_m on feature planes (gemm_p3.hip), all streams of the modality, on the current lane
   auto p3_frames = [&](int m) -> int {
     // (the text slot: 2048 x 256 x 4096 per stream -- K split over workgroups; both streams in one launch, their x rows are adjacent)
-    static const int p3_text_split = [] { const char* e = getenv("SDUMC_P3_TEXT_SPLIT"); return e ? atoi(e) : 4; }();
+    constexpr int p3_text_split = 4;      // (alone: split 8 34.6 us, 4 37.9, 2 63.8 per stream; both streams in one launch: 4)
     RET(p3_refresh_weights(c, m));
     for (int s = 0; s < (m == 1 ? S : 1); ++s) {
       const void* fp = m == 0 ? c.io.audio_p3 : (m == 2 ? c.io.video_p3 : c.io.text_p3[s]);
@@ -1404,8 +1401,8 @@ int forward(const Ctx& c) {
       // 8 ways over workgroups (512 of them, 32 k-tiles each) instead of the 64x64 register-staged kernel's automatic split:
       // fp32 C2 step 1.665-1.669 vs 1.671-1.676 ms (split 4: 1.674-1.678, split 2: 1.705-1.710).  With the products on the bf16
       // matrix pipe the k-loop is shorter and half as many slabs win: split 4 1.424-1.438 against split 8 1.444-1.450 and split
-      // 2 1.440-1.450 (three alternations).  SDUMC_TEXT_WIDE=S: A/B, 0 = off
-      static const int text_wide = [] { const char* e = getenv("SDUMC_TEXT_WIDE"); return e ? atoi(e) : 4; }();
+      // 2 1.440-1.450 (three alternations)
+      constexpr int text_wide = 4;
       const int rows_ms = B * pl.T[m][s];
       const bool wide_split = text_wide > 0 && !c.d.bf16 && rows_ms < 8192 && din[m] >= 2048 && (din[m] % (16 * text_wide)) == 0 && (rows_ms % 64) == 0;
       RET(lin_fwd(c, pm.frame[m], in, din[m], rows_ms, c.p(pl.x[m][s]), D, SDUMC_ACT_NONE, nullptr, c.d.bf16 != 0,
@@ -1830,9 +1827,8 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     // Only the dX of the early modality's Cross_Attention site runs early (it feeds that modality's mask-sum); its dW rides in the
     // grouped launch like every other weight gradient.  Round 3 measured the per-layer dW + dX PAIR ahead (1.787 vs 1.816 ms);
     // with the round-4 pooling kernels and reduce launches the order flipped: fp32 C2 1.690-1.698 vs 1.701-1.706 ms with the pair,
-    // bf16 storage 0.956-0.959 vs 1.019-1.021 (three alternations on one box).  SDUMC_EARLY_DW=1 restores the pair.
-    static const int early_dw = [] { const char* e = getenv("SDUMC_EARLY_DW"); return e ? atoi(e) : 0; }();
-    if (ca_dw_grouped && keys_dw_groupable(c, m) && (!(bgb & (1 << m)) || !early_dw)) ca_dw_mask |= 1 << m;
+    // bf16 storage 0.956-0.959 vs 1.019-1.021 (three alternations on one box).
+    if (ca_dw_grouped && keys_dw_groupable(c, m)) ca_dw_mask |= 1 << m;
     if (ggf && keys_dw_groupable(c, m)) fra_dw_mask |= 1 << m;
   }
   // early_done[m]: lane 3 has finished modality m's early key-projection backward (dxd of its Cross_Attention site).  The
@@ -1855,9 +1851,9 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
       // the FRA2UTT pooling backward of the three modality lanes -- the next link of the critical chain, HBM-bound, issued while
       // this launch is still running -- crawled beside it (86-104 us instead of ~60); the early dX itself has slack until its
       // modality's mask-sum.  Measured, fp32 C2, three alternations on one box: 128 workgroups 1.670-1.680 ms, 64: 1.675-1.679,
-      // 256 (every CU): 1.686-1.689, the tiled 64x64 kernel: 1.689-1.695.  (SDUMC_EARLY_DX: N workgroups, 0 = every CU, -1 = tiled)
+      // 256 (every CU): 1.686-1.689, the tiled 64x64 kernel: 1.689-1.695.
       // (round 4, rows launch on the bf16 matrix pipe: 160 workgroups 1.414-1.427 against 128 1.424-1.438 and 192 1.425-1.438)
-      static const int early_dx = [] { const char* e = getenv("SDUMC_EARLY_DX"); return e ? atoi(e) : 160; }();
+      constexpr int early_dx = 160;
       RET(keys_gemm_bwd(c, m, 1, 2, (ca_dw_mask & (1 << m)) ? 2 : 3, early_dx));
       if (lane == 3) RET(record_early(m));
       c.use(0);
@@ -2444,9 +2440,8 @@ int loss_backward_impl(const sdumc_net_dims* d, const sdumc_net_io* io, const sd
   float* L = cfg->losses;
   const float* w = cfg->weights;
   // single GPU (no global sums / features handed in): the distillation terms and RnC share their two passes (loss.hip)
-  static const int fused = [] { const char* e = getenv("SDUMC_LOSS_FUSED"); return e ? atoi(e) : 1; }();
   bool done = false;
-  if (fused && !cfg->rnc_feats_global && !cfg->ssd_global && Bg == B) {
+  if (!cfg->rnc_feats_global && !cfg->ssd_global && Bg == B) {
     const int rc = sdumc_losses_fused_(B, io->vals, cfg->labels, io->text_hidden, io->cross_text, io->fused, io->rnc, RD,
                                        cfg->temperature, w, dv, dth, dct, df, dr, L, ls.ssd_ws, ls.rnc_ws,
                                        total_pending ? hyper : nullptr, (double)cfg->beta1, (double)cfg->beta2, stream);

@@ -124,9 +124,8 @@ struct Frag {
   uint32_t mb[4];         // keep-bits bytes of the B fragment (masked problems)
 };
 
-// SPLIT: the products run on the bf16 matrix pipe at fp32 accuracy -- see "fp32 products on the bf16 pipe" below.
 // (no packed fp32 VALU operations anywhere in the library: Makefile, NOPACK)
-template <int NST, bool SPLIT>
+template <int NST>
 __device__ __forceinline__ void gg_tn_body(const Launch& L, char* lds) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -196,15 +195,6 @@ __device__ __forceinline__ void gg_tn_body(const Launch& L, char* lds) {
   auto wait_stages = [&](int stages) {
     if (stages >= 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm(2 * PER));
     else if (stages == 1) __builtin_amdgcn_s_waitcnt(waitcnt_vm(PER));
-    else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
-  };
-
-  // all but the n youngest stages of this wave's LDS-DMA have landed (n up to NST - 1)
-  auto wait_n = [&](int n) {
-    if (n >= 4) __builtin_amdgcn_s_waitcnt(waitcnt_vm(4 * PER));
-    else if (n == 3) __builtin_amdgcn_s_waitcnt(waitcnt_vm(3 * PER));
-    else if (n == 2) __builtin_amdgcn_s_waitcnt(waitcnt_vm(2 * PER));
-    else if (n == 1) __builtin_amdgcn_s_waitcnt(waitcnt_vm(PER));
     else __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
   };
 
@@ -321,7 +311,7 @@ __device__ __forceinline__ void gg_tn_body(const Launch& L, char* lds) {
           ibuf = ibuf + 1 == NST ? 0 : ibuf + 1;
         }
       };
-      // ---- fp32 products on the bf16 pipe (SPLIT) ------------------------------------------------------------------------
+      // ---- fp32 products on the bf16 pipe (the arithmetic of gg_tn_split2_kernel below, of gemm_wide / gemm_rows / gemm_p3 / K3) ------------------------------------------------------------------------
       // v_mfma_f32_32x32x2_f32 runs at 1/16 of the bf16 rate (157 TF against 2.5 PF dense).  An fp32 value is the EXACT sum of
       // three bf16 values -- a0 = a truncated to its top 16 bits, a1 = (a - a0) truncated, a2 = a - a0 - a1 (8 + 8 + 8
       // significand bits; both subtractions are exact) -- so a b = sum of nine bf16 x bf16 products, each exact in fp32.  The six
@@ -332,110 +322,10 @@ __device__ __forceinline__ void gg_tn_body(const Launch& L, char* lds) {
       // pack two values' top halves into one operand dword), which run beside the MFMAs of the previous k-tile.
       // A lane's eight k of one operand are k = 4 lh + s and 8 + 4 lh + s (s < 4) -- the two fp32 fragments of the k-tile side
       // by side; A and B use the same assignment, which is all a contraction needs.
-      typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-      struct Planes {
-        u32x4 a[TM][3], b[TN][3];
-      };
-      typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-      typedef float f32x2s __attribute__((ext_vector_type(2)));
-      // two values -> one dword of two bf16 (round to nearest even: v_cvt_pk_bf16_f32), low half = first value
-      auto pk = [](float x, float y) -> uint32_t {
-        const f32x2s v = {x, y};
-        return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
-      };
-      auto split8 = [&](const f32x4 lo, const f32x4 hi, u32x4* pl) {
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {   // dword d = this lane's k elements 2 d (low half) and 2 d + 1 (high half)
-          const float x = d < 2 ? lo[2 * d] : hi[2 * d - 4], y = d < 2 ? lo[2 * d + 1] : hi[2 * d - 3];
-          const uint32_t p0 = pk(x, y);
-          const float x1 = x - __uint_as_float(p0 << 16), y1 = y - __uint_as_float(p0 & 0xFFFF0000u);       // exact
-          const uint32_t p1 = pk(x1, y1);
-          const float x2 = x1 - __uint_as_float(p1 << 16), y2 = y1 - __uint_as_float(p1 & 0xFFFF0000u);     // exact
-          pl[0][d] = p0;
-          pl[1][d] = p1;
-          pl[2][d] = pk(x2, y2);
-        }
-      };
-      auto mask_b = [&](Frag& f0, Frag& f1) {
-        const uint32_t pos = 2u * (li & 1);
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-          const uint32_t m00 = (uint32_t)__builtin_amdgcn_sbfe((int)f0.mb[s], pos, 1u), m01 = (uint32_t)__builtin_amdgcn_sbfe((int)f0.mb[s], pos + 1u, 1u);
-          const uint32_t m10 = (uint32_t)__builtin_amdgcn_sbfe((int)f1.mb[s], pos, 1u), m11 = (uint32_t)__builtin_amdgcn_sbfe((int)f1.mb[s], pos + 1u, 1u);
-          f0.b[0][s] = __uint_as_float(__float_as_uint(f0.b[0][s]) & m00);
-          f0.b[1][s] = __uint_as_float(__float_as_uint(f0.b[1][s]) & m01);
-          f1.b[0][s] = __uint_as_float(__float_as_uint(f1.b[0][s]) & m10);
-          f1.b[1][s] = __uint_as_float(__float_as_uint(f1.b[1][s]) & m11);
-        }
-      };
-      auto split_a = [&](const Frag& f0, const Frag& f1, Planes& P, int i) {
-        float t = 0.f;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) t += f0.a[i][s] + f1.a[i][s];
-        csum[i] += t;
-        split8(f0.a[i], f1.a[i], P.a[i]);
-      };
-      auto op = [](const u32x4& v) { return __builtin_bit_cast(bf16x8, v); };
-      auto mma6 = [&](const Planes& P, int i, int j) {   // smallest terms first
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(P.a[i][2]), op(P.b[j][0]), acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(P.a[i][0]), op(P.b[j][2]), acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(P.a[i][1]), op(P.b[j][1]), acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(P.a[i][1]), op(P.b[j][0]), acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(P.a[i][0]), op(P.b[j][1]), acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(op(P.a[i][0]), op(P.b[j][0]), acc[i][j], 0, 0, 0);
-      };
-      // One k-tile of a wave: split a0, b0 | 6 MFMAs (0,0) beside the split of b1 | 6 MFMAs (0,1) beside the split of a1 |
-      // 6 MFMAs (1,0) | the ring's barrier, the LDS-DMA issue and the fragment reads of the next k-tile | 6 MFMAs (1,1).  One
-      // set of operand registers: every part is consumed in the iteration that makes it.  The two waves of a SIMD fill each
-      // other's gaps (the VALU work, ~230 operations per wave and k-tile, is what bounds the loop, not the matrix pipe).
-      auto ring_split = [&](auto mask_c) {
-        constexpr bool MASK = decltype(mask_c)::value;
-        Frag f0, f1;
-        Planes P;
-#pragma unroll
-        for (int s = 0; s < NST; ++s)
-          if (s < nk) issue(s);
-        wait_n(min(nk, NST) - 1);
-        __builtin_amdgcn_s_barrier();
-        read_frag(lds, 0, f0, mask_c);
-        read_frag(lds, 1, f1, mask_c);
-        int rbuf = 1 % NST, ibuf = 0;
-#pragma nounroll
-        for (int t = 0; t < nk; ++t) {
-          __builtin_amdgcn_sched_barrier(0);
-          if constexpr (MASK) mask_b(f0, f1);
-          split_a(f0, f1, P, 0);
-          split8(f0.b[0], f1.b[0], P.b[0]);
-          __builtin_amdgcn_sched_barrier(0);
-          mma6(P, 0, 0);
-          split8(f0.b[1], f1.b[1], P.b[1]);
-          __builtin_amdgcn_sched_barrier(0);
-          mma6(P, 0, 1);
-          split_a(f0, f1, P, 1);
-          __builtin_amdgcn_sched_barrier(0);
-          mma6(P, 1, 0);
-          __builtin_amdgcn_sched_barrier(0);
-          if (t + 1 < nk) {
-            wait_n(min(nk - t - 2, NST - 2));
-            __builtin_amdgcn_s_barrier();
-            if (t + NST < nk) issue(ibuf);
-            read_frag(lds + rbuf * STAGE_BYTES, 0, f0, mask_c);
-            read_frag(lds + rbuf * STAGE_BYTES, 1, f1, mask_c);
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          mma6(P, 1, 1);
-          rbuf = rbuf + 1 == NST ? 0 : rbuf + 1;
-          ibuf = ibuf + 1 == NST ? 0 : ibuf + 1;
-        }
-      };
-      if constexpr (SPLIT) {
-        if (masked) ring_split(std::true_type{});
-        else ring_split(std::false_type{});
-      } else {
-        if (masked) ring(std::true_type{});
-        else ring(std::false_type{});
-      }
+      // (the in-fragment form of this kernel -- every wave splitting the fragments it multiplies, 136-147 TF -- was superseded by
+      //  gg_tn_split2_kernel in round 4 and removed in round 5; this body is the fp32-MFMA form, sdumc_set_split_ bit 0 off)
+      if (masked) ring(std::true_type{});
+      else ring(std::false_type{});
       seg_masked = masked;
       __builtin_amdgcn_s_barrier();          // every wave is done reading the ring before the next sub-piece refills it
     }
@@ -509,17 +399,12 @@ __device__ __forceinline__ void gg_tn_body(const Launch& L, char* lds) {
 template <int NST, int OCC>
 __global__ __launch_bounds__(NTHR, OCC) void gg_tn_kernel(const Launch L) {
   extern __shared__ __attribute__((aligned(16))) char lds[];
-  gg_tn_body<NST, false>(L, lds);
-}
-template <int NST, int OCC>
-__global__ __launch_bounds__(NTHR, OCC) void gg_tn_split_kernel(const Launch L) {
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-  gg_tn_body<NST, true>(L, lds);
+  gg_tn_body<NST>(L, lds);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------
-// The split form with the operands split ONCE per workgroup (gg_tn_split2_kernel; SDUMC_GG_SPLIT2=0 selects the in-fragment form
-// above).  In the in-fragment form every wave splits the fragments it multiplies -- a 64-row block of A is split by two waves,
+// The split form with the operands split ONCE per workgroup (gg_tn_split2_kernel).  In the in-fragment form of round 4 (removed) every
+// wave split the fragments it multiplied -- a 64-row block of A is split by two waves,
 // a 64-column block of B by four -- and the ~230 VALU operations per wave and k-tile, not the 24 MFMAs, bound the loop
 // (9.7 VALU instructions per MFMA in the counters; 136-147 TF).  Here, per k-tile:
 //   1. the raw fp32 stage (the same LDS-DMA ring) is converted by all 512 threads: a thread takes 8 k of one A row and 4 k of one
@@ -1126,8 +1011,6 @@ bool set_lds_attr() {   // the dynamic-LDS limit is a per-device function attrib
   if (!done[dev]) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_tn_kernel<5, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * STAGE_BYTES) != hipSuccess)
       return false;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_tn_split_kernel<5, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 5 * STAGE_BYTES) != hipSuccess)
-      return false;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_tn_bf16_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, hf::HNST * hf::HSTAGE) != hipSuccess)
       return false;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gg_tn_split2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, s2::LDS2) != hipSuccess)
@@ -1225,10 +1108,6 @@ extern "C" void sdumc_prof_end_(int token, void* stream);
 
 namespace {
 bool split_products() { return sdumc_split_on_(SDUMC_SPLIT_GROUP) != 0; }
-bool split2_form() {
-  static const int on = [] { const char* e = getenv("SDUMC_GG_SPLIT2"); return e ? atoi(e) : 1; }();
-  return on != 0;
-}
 size_t gg_workspace_bytes(const sdumc_gg_problem* probs, int32_t n, bool hf) {
   if (!probs || n <= 0) return 0;
   const int nwg = cu_count();
@@ -1259,7 +1138,7 @@ int gg_run(const sdumc_gg_problem* probs, int32_t n, void* workspace, size_t wor
     const int cnt = std::min(MAXP, n - first);
     Launch L;
     int units = 0;
-    const bool wide = !hf && split_products() && split2_form();
+    const bool wide = !hf && split_products();
     const int tiles = plan(probs + first, cnt, nwg, hf, wide, L, units);
     if ((long long)L.line0[cnt] * (L.nwg + 1) >= (1LL << 31)) return SDUMC_EINVAL;   // 32-bit index arithmetic in the kernels
     L.slab = static_cast<float*>(workspace);
@@ -1269,8 +1148,7 @@ int gg_run(const sdumc_gg_problem* probs, int32_t n, void* workspace, size_t wor
     if (hf) hipLaunchKernelGGL(gg_tn_bf16_kernel, dim3(L.nwg), dim3(NTHR), hf::HNST * hf::HSTAGE, st, L);
     else if (wide) {
       hipLaunchKernelGGL(gg_tn_split2_kernel, dim3(L.nwg), dim3(NTHR), s2::LDS2, st, L);
-    } else if (split_products()) hipLaunchKernelGGL((gg_tn_split_kernel<5, 2>), dim3(L.nwg), dim3(NTHR), 5 * STAGE_BYTES, st, L);
-    else hipLaunchKernelGGL((gg_tn_kernel<5, 2>), dim3(L.nwg), dim3(NTHR), 5 * STAGE_BYTES, st, L);
+    } else hipLaunchKernelGGL((gg_tn_kernel<5, 2>), dim3(L.nwg), dim3(NTHR), 5 * STAGE_BYTES, st, L);
     sdumc_prof_end_(tok, stream);
     SDUMC_CHECK_LAUNCH();
     hipLaunchKernelGGL(gg_reduce_kernel, dim3(tiles, wide ? 33 : 17), dim3(NTHR), 0, st, L, tiles);

@@ -286,12 +286,8 @@ struct Plan {
 };
 // BM: the tile height whose tile count fills 256 CUs in whole rounds with the least idle share; split K (fp32 slabs + an ordered
 // reduce) only when even 64-row tiles leave most of the chip idle and K is long.  k-tiles come in groups of four (the unrolled loop).
-inline bool tall_forms() {
-  static const int tall_env = [] { const char* e = getenv("SDUMC_P3_TALL"); return e ? atoi(e) : 0; }();
-  return tall_env != 0;
-}
 inline Plan plan(const sdumc_gemm_p3& g, size_t have) {
-  const int forced = g.tile_m ? g.tile_m : (tall_forms() ? 0 : 64);
+  const int forced = g.tile_m ? g.tile_m : 64;
   const int tiles_n = g.N / BN;
   Plan best{64, 1, g.K};
   double best_cost = 1e30;
@@ -366,14 +362,13 @@ extern "C" int sdumc_gemm_p3_nt(const sdumc_gemm_p3* gp, void* stream) {
   const Plan p = plan(g, g.workspace ? g.workspace_bytes : 0);
   if (p.nsplit > 1 && (!g.workspace || (reinterpret_cast<uintptr_t>(g.workspace) & 15))) return SDUMC_ENOMEM;
   hipStream_t st = as_stream(stream);
-  const int tok = sdumc_prof_begin_(26, 2.0 * g.M * (double)g.N * g.K, stream);
+  const int tok = sdumc_prof_begin_(mask ? 27 : 26, 2.0 * g.M * (double)g.N * g.K, stream);
   int rc;
   // tile_m = 0: 64-row tiles on 256-thread workgroups, two per CU -- slower alone than the tall 512-thread forms on a shape that fills
   // the chip in one round (audio frame projection: 76 against 62 us at 96 rows), faster inside the step, where three lanes' kernels
   // share the chip (fp32 C2 step 1.370 against 1.386-1.391 ms, two alternations) -- a 512-thread workgroup holds its CU alone.
-  // SDUMC_P3_TALL=1 (A/B) / an explicit tile_m: the 512-thread forms.
-  static const int tall_env = [] { const char* e = getenv("SDUMC_P3_TALL"); return e ? atoi(e) : 0; }();
-  if (!g.tile_m && !tall_env) {
+  // An explicit tile_m: the 512-thread forms.
+  if (!g.tile_m) {
     rc = mask ? launch<PCfg<64, 4, true, 4>>(g, p, st) : launch<PCfg<64, 4, false, 4>>(g, p, st);
   } else if (mask) {
     rc = p.bm == 128 ? launch<PCfg<128, 4, true>>(g, p, st) : p.bm == 96 ? launch<PCfg<96, 4, true>>(g, p, st) : launch<PCfg<64, 4, true>>(g, p, st);
