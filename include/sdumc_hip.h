@@ -268,6 +268,37 @@ int sdumc_p3_split_frag(const float* src, int64_t ld, void* dst, int32_t rows, i
 int sdumc_p3_join(const void* src, int64_t ld_bytes, float* dst, int64_t ld, int64_t rows, int32_t cols, void* stream);
 
 /* ------------------------------------------------------------------------
+ * The same NT product for the bf16-STORAGE step (sdumc_net_dims.bf16 = 2; csrc/gemm_b1.hip): A and the weight are bf16, fp32
+ * accumulation, C bf16 or fp32.  The weight is stored fragment-major -- [N / 32][K / 16][64 lanes][16 bytes], lane (li, lh) of block
+ * (rb, kt) holds W[32 rb + li][16 kt + 8 lh .. + 7] (sdumc_b1_frag_multi writes it from the fp32 parameters, round to nearest even)
+ * -- and goes straight into registers; only A passes through LDS.
+ *   C[M, N] = act(A[M, K] . B[N, K]^T + bias),  N % 256 == 0, K % 128 == 0
+ * ---------------------------------------------------------------------- */
+typedef struct sdumc_gemm_b1 {
+  int32_t M, N, K;
+  const void* A;            /* bf16 [M or a_row_mod rows][K], row stride lda ELEMENTS (>= K, multiple of 8; operand below 4 GiB) */
+  const void* B;            /* fragment-major bf16 of the weight [N][K] */
+  int64_t lda, ldb;         /* ldb: BYTES between two 32-row blocks of B (>= K / 16 * 1024) */
+  int32_t a_row_mod;        /* >0: A's source row = m % a_row_mod */
+  const void* A2;           /* optional second A tensor holding rows [a2_row0, M) (a2_row0 % 64 == 0; no a_row_mod) */
+  int32_t a2_row0;
+  const float* bias;        /* [N] fp32 or NULL */
+  int32_t act;              /* SDUMC_ACT_* */
+  void* C;                  /* [M][N], row stride ldc elements (multiple of 8) */
+  int32_t ldc;
+  int32_t c_bf16;           /* 1: C is bf16 (round to nearest even), 0: fp32 */
+  int32_t splitk;           /* 0 auto, 1 none, > 1: K split over workgroups (fp32 slabs in workspace + an ordered reduce) */
+  float* workspace;         /* >= sdumc_gemm_b1_workspace_bytes */
+  size_t workspace_bytes;
+} sdumc_gemm_b1;
+size_t sdumc_gemm_b1_workspace_bytes(const sdumc_gemm_b1* g);
+int sdumc_gemm_b1_nt(const sdumc_gemm_b1* g, void* stream);
+/* n <= 12 fp32 weights [rows_i][cols_i] at P + src_off[i] floats (contiguous rows; rows % 32 == 0, cols % 16 == 0) -> fragment-major
+ * bf16 at dst + dst_off[i] bytes (2 rows cols bytes each), one launch */
+int sdumc_b1_frag_multi(const float* P, void* dst, const int64_t* src_off, const int64_t* dst_off, const int32_t* rows,
+                        const int32_t* cols, int n, void* stream);
+
+/* ------------------------------------------------------------------------
  * The tall 256 x 256 products of the frame-level part in one persistent launch (gemm_rows.hip):
  *   C[M x 256] = act((A . keep) B * a_scale + bias) (+ C),   K = N = 256
  * - the key projections  keys = tanh(drop(x) W^T + b)  of FRA2UTT_new / Cross_Attention (model :60, :82; main :144 in train

@@ -73,6 +73,15 @@ class GemmP3(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
 
 
+class GemmB1(C.Structure):
+    _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("A", C.c_void_p), ("B", C.c_void_p), ("lda", C.c_int64), ("ldb", C.c_int64),
+                ("a_row_mod", C.c_int32), ("A2", C.c_void_p), ("a2_row0", C.c_int32),
+                ("bias", C.c_void_p), ("act", C.c_int32),
+                ("C", C.c_void_p), ("ldc", C.c_int32), ("c_bf16", C.c_int32), ("splitk", C.c_int32),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+
+
 class RowsProblem(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("a_bits", C.c_void_p), ("bias", C.c_void_p), ("C", C.c_void_p),
                 ("M", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32), ("a_row_mod", C.c_int32),
@@ -196,6 +205,10 @@ _SIGS = {
     "sdumc_p3_split": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
     "sdumc_p3_split_frag": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "sdumc_p3_join": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p]),
+    "sdumc_gemm_b1_workspace_bytes": (C.c_size_t, [C.POINTER(GemmB1)]),
+    "sdumc_gemm_b1_nt": (C.c_int, [C.POINTER(GemmB1), C.c_void_p]),
+    "sdumc_b1_frag_multi": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(C.c_int32),
+                                      C.POINTER(C.c_int32), C.c_int, C.c_void_p]),
     "sdumc_gemm_rows256": (C.c_int, [C.POINTER(RowsProblem), C.c_int32, C.c_void_p]),
     "sdumc_gemm_rows256_bf16": (C.c_int, [C.POINTER(RowsProblem), C.c_int32, C.c_void_p]),
     "sdumc_attnpool_fwd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),

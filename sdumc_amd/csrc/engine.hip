@@ -200,6 +200,7 @@ struct Plan {
   int64_t fold_ws[2][3] = {{0, 0, 0}, {0, 0, 0}};   // softmax partials of site (k, m), kept until the clustered stage behind them has combined them (fra_fold)
   // fp32 storage, features given as bf16 planes too (sdumc_net_io.*_p3; gemm_p3.hip): fragment-major planes of the frame-level weights
   // (refreshed at the head of each forward) and P3 copies of the projected frames (written by the frame projection's epilogue)
+  int64_t wb1 = 0;                     // bf16 storage: float offset of the fragment-major bf16 weights (wp3_frame / wp3_key: byte offsets inside it)
   int64_t wp3 = 0;                     // float offset of the weight-plane region
   int64_t wp3_frame[3] = {0, 0, 0};    // byte offsets inside it
   int64_t wp3_key[2][3] = {{0, 0, 0}, {0, 0, 0}};
@@ -350,6 +351,14 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
       for (const Seg& sg : p.segs[m])
         sum += ((int64_t)(sdumc_attnpool_bwd_workspace_bytes(sg.V, sg.T, NQ) / sizeof(float)) + 63) / 64 * 64;
     p.dq_ws = p.alloc(sum);
+  }
+  if (d.bf16 == 2 && D == 256 && ((d.da | d.dt | d.dv) & 127) == 0) {      // fragment-major bf16 weights for sdumc_gemm_b1_nt
+    const int din_[3] = {d.da, d.dt, d.dv};
+    int64_t bytes = 0;
+    for (int m = 0; m < 3; ++m) { p.wp3_frame[m] = bytes; bytes += (int64_t)D * din_[m] * 2; }
+    for (int k = 0; k < 2; ++k)
+      for (int m = 0; m < 3; ++m) { p.wp3_key[k][m] = bytes; bytes += (int64_t)D * D * 2; }
+    p.wb1 = p.alloc(bytes / 4);
   }
   if (d.bf16 == 0 && D == 256 && ((d.da | d.dt | d.dv) & 63) == 0) {      // planes for sdumc_gemm_p3_nt (used when the caller passes feature planes)
     const int din_[3] = {d.da, d.dt, d.dv};
@@ -936,9 +945,63 @@ sdumc_gemm_bf16 GH_(int layout, int M, int N, int K, int groups = 1) {
   return g;
 }
 
+// bf16 storage: the NT products of the frame-level forward through gemm_b1.hip (the weight fragment-major, straight into registers).
+// SDUMC_B1=0: A/B against gemm_bf16.hip's LDS-staged tiles.
+bool b1_mode(const Ctx& c) {
+  static const int on = [] { const char* e = getenv("SDUMC_B1"); return e ? atoi(e) : 1; }();
+  return on && c.h() && c.pl.wb1 != 0;
+}
+char* wb1_ptr(const Ctx& c, int64_t byte_off) { return reinterpret_cast<char*>(c.p(c.pl.wb1)) + byte_off; }
+// modality m's three frame-level weights (frame_dim_reshape_m, the two input_proj) -> fragment-major bf16: one small launch at the head
+// of the modality's lane
+int b1_refresh_weights(const Ctx& c, int m) {
+  const int din[3] = {c.d.da, c.d.dt, c.d.dv};
+  int64_t so[3], dofs[3];
+  int32_t rows[3], cols[3];
+  so[0] = c.pm.frame[m].w; dofs[0] = c.pl.wp3_frame[m]; rows[0] = D; cols[0] = din[m];
+  so[1] = c.pm.fra_proj[m].w; dofs[1] = c.pl.wp3_key[0][m]; rows[1] = D; cols[1] = D;
+  so[2] = c.pm.ca_in[m].w; dofs[2] = c.pl.wp3_key[1][m]; rows[2] = D; cols[2] = D;
+  return sdumc_b1_frag_multi(c.P, wb1_ptr(c, 0), so, dofs, rows, cols, 3, c.st);
+}
+// frame_dim_reshape_m on bf16 features: x (bf16) of stream s (and, with feat2, of the next stream in the adjacent rows)
+int b1_frame_proj(const Ctx& c, int m, int s, const void* feat, int rows, const void* feat2 = nullptr, int rows2 = 0) {
+  const int din[3] = {c.d.da, c.d.dt, c.d.dv};
+  sdumc_gemm_b1 g;
+  memset(&g, 0, sizeof(g));
+  g.M = rows + rows2; g.N = D; g.K = din[m];
+  g.A = feat; g.lda = din[m];
+  if (feat2) { g.A2 = feat2; g.a2_row0 = rows; }
+  g.B = wb1_ptr(c, c.pl.wp3_frame[m]); g.ldb = (int64_t)(din[m] / 16) * 1024;
+  g.bias = c.P + c.pm.frame[m].b;
+  g.act = SDUMC_ACT_NONE;
+  g.C = c.ph(c.pl.x[m][s]); g.ldc = D; g.c_bf16 = 1;
+  g.workspace = c.scr;
+  g.workspace_bytes = (size_t)c.pl.scratch_floats * sizeof(float);
+  return sdumc_gemm_b1_nt(&g, c.st);
+}
+
 // bf16-storage mode: keys = tanh(xd W^T + b) of the sites [k0, k1), xd = drop(x) materialised by forward() (train) or x (eval)
 int keys_gemm_fwd_h(const Ctx& c, int m, int k0, int k1) {
   const Plan& pl = c.pl;
+  if (b1_mode(c)) {
+    for (int k = k0; k < k1; ++k)
+      for (const Seg& sg : pl.segs[m]) {
+        const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
+        sdumc_gemm_b1 g;
+        memset(&g, 0, sizeof(g));
+        g.M = sg.V * sg.T; g.N = D; g.K = D;
+        g.A = c.d.train ? c.ph(pl.xd[k][m], sg.row0 * D) : c.ph(sg.x_off);
+        g.lda = D;
+        g.a_row_mod = (!c.d.train && sg.x_samples < sg.V) ? sg.x_samples * sg.T : 0;
+        g.B = wb1_ptr(c, pl.wp3_key[k][m]); g.ldb = (int64_t)(D / 16) * 1024;
+        g.bias = c.P + L.b;
+        g.act = SDUMC_ACT_TANH;
+        g.C = c.ph(pl.keys[k][m], sg.row0 * D); g.ldc = D; g.c_bf16 = 1;
+        g.splitk = 1;
+        RET(sdumc_gemm_b1_nt(&g, c.st));
+      }
+    return SDUMC_OK;
+  }
   for (const Seg& sg : pl.segs[m]) {
     const int64_t rows = (int64_t)sg.V * sg.T;
     sdumc_gemm_bf16 g = GH_(SDUMC_NT, (int)rows, D, D, k1 - k0);
@@ -1310,6 +1373,9 @@ int forward(const Ctx& c) {
       offs[n] = pm.fra_proj[m].w; outs[n] = D; ins[n] = D; wantt[n] = 1; ++n;
       offs[n] = pm.ca_in[m].w; outs[n] = D; ins[n] = D; wantt[n] = 1; ++n;
     }
+    // (with gemm_b1.hip the forward reads fragment-major copies made on each modality's own lane; these row-major / transposed
+    //  copies are first read by the backward dX products: lane 3, off the head of the step)
+    if (b1_mode(c)) { RET(link(c, 0, 3)); c.use(3); }
     RET(sdumc_weights_to_bf16_(c.P, c.ph(pl.wh), c.ph(pl.wht), offs, outs, ins, wantt, n, c.st));
     if (chain && !use_cluster(c)) {   // + the utterance-level matrices chain.hip streams (both layouts: forward and backward)
       const std::vector<const Lin*> ls = chain_lins(pm);
@@ -1322,7 +1388,8 @@ int forward(const Ctx& c) {
         if (i < ls.size()) { offs[n] = ls[i]->w; outs[n] = ls[i]->out; ins[n] = ls[i]->in; wantt[n] = 1; ++n; }
       }
     }
-    RET(fork_all(c));      // (the lanes forked above did not see these launches)
+    if (b1_mode(c)) c.use(0);
+    else RET(fork_all(c));      // (the lanes forked above did not see these launches)
   }
   if (chain) {   // transposed mirror (first needed after the frame-level part): lane 3
     RET(link(c, 0, 3));
@@ -1382,8 +1449,18 @@ int forward(const Ctx& c) {
   for (int m = 0; m < 3; ++m) {
     c.use(LANE_OF[m]);
     if (p3_mode(c)) RET(p3_frames(m));
+    if (b1_mode(c)) RET(b1_refresh_weights(c, m));
     for (int s = 0; s < (m == 1 ? S : 1) && !p3_mode(c); ++s) {
       const float* in = m == 0 ? c.io.audio : (m == 2 ? c.io.video : c.io.text[s]);
+      if (b1_mode(c)) {    // (the text slot's two streams in one launch: their x rows are adjacent)
+        const int rows_p = B * pl.T[m][s];
+        if (m == 1 && S == 2 && rows_p % 64 == 0) {
+          RET(b1_frame_proj(c, m, 0, in, rows_p, c.io.text[1], B * pl.T[1][1]));
+          break;
+        }
+        RET(b1_frame_proj(c, m, s, in, rows_p));
+        continue;
+      }
       if (c.h()) {    // features and projected frames in bf16
         sdumc_gemm_bf16 g = GH_(SDUMC_NT, B * pl.T[m][s], D, din[m]);
         g.A[0] = in;

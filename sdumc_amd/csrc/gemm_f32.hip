@@ -37,7 +37,7 @@ struct ProfRec {
 bool g_prof_on = false;
 std::vector<ProfRec> g_prof;
 std::mutex g_prof_mu;
-constexpr int kNumVariants = 28;
+constexpr int kNumVariants = 29;
 const char* const kVariantName[kNumVariants] = {"gemm_nt_128x128", "gemm_nt_64x64",  "gemm_nn_128x128",
                                                 "gemm_nn_64x64",   "gemm_tn_128x128", "gemm_tn_64x64",
                                                 "gemm_small_nt",   "gemm_small_nn",   "gemm_small_tn",
@@ -50,7 +50,8 @@ const char* const kVariantName[kNumVariants] = {"gemm_nt_128x128", "gemm_nt_64x6
                                                 "gemm_rows256", "gemm_rows256_bf16",      // gemm_rows.hip
                                                 // fp32 operands, products on the bf16 matrix pipe from exactly split operands (sdumc_set_split_)
                                                 "gemm_wide_nt_bf16x3", "gemm_group_tn_bf16x3", "gemm_rows256_bf16x3",
-                                                "gemm_p3_nt_bf16x3", "gemm_p3_nt_masked_bf16x3"};     // gemm_p3.hip: operands pre-split into bf16 planes (P3 tensors); the two
+                                                "gemm_p3_nt_bf16x3", "gemm_p3_nt_masked_bf16x3",
+                                                "gemm_b1_nt_bf16"};     // gemm_p3.hip: operands pre-split into bf16 planes (P3 tensors); the two
                                                 // instantiations rocprof lists too: plain (frame projections), keep-bits on A (key projections)
 
 constexpr int BK = 32;

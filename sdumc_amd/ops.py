@@ -181,6 +181,48 @@ def gemm_p3_nt(*args, **kw):
     return res
 
 
+def b1_frag(W):
+    """fp32 weight [rows, cols] -> the fragment-major bf16 operand of gemm_b1_nt (sdumc_b1_frag_multi): uint8 [rows / 32, 64 cols]."""
+    rows, cols = W.shape
+    W = W.contiguous()
+    out = torch.empty(rows // 32, 64 * cols, dtype=torch.uint8, device=W.device)
+    so, do = (C.c_int64 * 1)(0), (C.c_int64 * 1)(0)
+    r, c = (C.c_int32 * 1)(rows), (C.c_int32 * 1)(cols)
+    check(lib.sdumc_b1_frag_multi(ptr(W), ptr(out), so, do, r, c, 1, _st()), "sdumc_b1_frag_multi")
+    return out
+
+
+def gemm_b1_nt_call(A, Bf, M, N, K, bias=None, act=ACT_NONE, a_row_mod=0, out_dtype=torch.bfloat16, splitk=0, A_second=None,
+                    second_row0=0):
+    """The prepared call of sdumc_gemm_b1_nt (bf16 A [rows, K], fragment-major bf16 weight): returns (launch, C)."""
+    dev = A.device
+    g = _lib.GemmB1()
+    g.M, g.N, g.K = M, N, K
+    g.A, g.B, g.lda, g.ldb = ptr(A), ptr(Bf), A.stride(0), Bf.stride(0)
+    g.a_row_mod = a_row_mod
+    if A_second is not None:
+        g.A2, g.a2_row0 = ptr(A_second), second_row0
+    g.bias, g.act = ptr(bias), act
+    Cm = torch.empty(M, N, dtype=out_dtype, device=dev)
+    g.C, g.ldc, g.c_bf16 = ptr(Cm), Cm.stride(0), int(out_dtype == torch.bfloat16)
+    g.splitk = splitk
+    need = lib.sdumc_gemm_b1_workspace_bytes(C.byref(g))
+    ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
+    g.workspace, g.workspace_bytes = ptr(ws), need
+    keep = (A, Bf, bias, ws, Cm, A_second)
+
+    def launch(_keep=keep):
+        check(lib.sdumc_gemm_b1_nt(C.byref(g), _st()), "sdumc_gemm_b1_nt")
+    return launch, Cm
+
+
+def gemm_b1_nt(*args, **kw):
+    """C[M, N] = act(A B^T + bias), A bf16, B the fragment-major bf16 weight (b1_frag), C bf16 or fp32 (sdumc_gemm_b1_nt)."""
+    launch, res = gemm_b1_nt_call(*args, **kw)
+    launch()
+    return res
+
+
 def gemm_rows256(problems):
     """The tall 256 x 256 products of the frame-level part in one persistent launch (sdumc_gemm_rows256).
 
