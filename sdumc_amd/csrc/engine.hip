@@ -975,6 +975,9 @@ int b1_frame_proj(const Ctx& c, int m, int s, const void* feat, int rows, const 
   g.bias = c.P + c.pm.frame[m].b;
   g.act = SDUMC_ACT_NONE;
   g.C = c.ph(c.pl.x[m][s]); g.ldc = D; g.c_bf16 = 1;
+  // (the text slot, 4096 rows x 4096: K over 4 workgroups -- 0.8748-0.8841 ms against 0.8832-0.8871 with the 8 the plan picks for a launch
+  //  alone, 0.8763-0.8837 with 2, 0.8778-0.8917 with none: in the step a half-filled chip is filled by the other lanes)
+  if (g.M < 8192 && g.K >= 2048) g.splitk = 4;
   g.workspace = c.scr;
   g.workspace_bytes = (size_t)c.pl.scratch_floats * sizeof(float);
   return sdumc_gemm_b1_nt(&g, c.st);
