@@ -321,6 +321,15 @@ typedef struct sdumc_rows_problem {
   float a_scale;            /* 1 / (1 - p); read only with a_bits */
   int32_t accumulate;
   int32_t act;              /* SDUMC_ACT_NONE or SDUMC_ACT_TANH */
+  /* optional rank-nq term of the attention pooling's own input gradient, folded into the product as one more k-tile:
+   *   C[r] = A[r] B + sum_i pool_w[r][i] * pool_g[r / pool_T][i][:]
+   * pool_w = the attention weights [M][pool_nq] of the site, pool_g = dout * out-dropout mask [M / pool_T][pool_nq][256]
+   * (sdumc_attnpool_bwd.dout_masked).  dxd = dz W + (pooling part) then leaves this kernel in ONE pass: the pooling backward
+   * does not write dxd and this launch does not read it back.  Needs pool_nq <= 8, pool_T >= 63 or pool_T == 32 (a 64-row tile
+   * spans at most two samples), no a_bits, no accumulate, M % pool_T == 0. */
+  const float* pool_w;
+  const float* pool_g;
+  int32_t pool_nq, pool_T;
 } sdumc_rows_problem;
 int sdumc_gemm_rows256(const sdumc_rows_problem* probs, int32_t n, void* stream);
 /* The same on bf16 STORAGE (sdumc_net_dims.bf16 = 2): A ([M][256]), B and C are bf16 tensors (lda / ldb / ldc in elements, lda
@@ -404,6 +413,8 @@ typedef struct sdumc_attnpool_bwd {
                             sum over v of the per-sample gradients, written by ONE launch that reduces the per-chunk slabs of
                             every sample in a fixed order; dq is then NOT written.  NULL = per-sample dq as above.  Single-site
                             sdumc_attnpool_bwd only (the _multi form requires NULL). */
+  float* dout_masked;    /* optional [V, nq, 256]: dout * out-dropout mask as the kernel uses it -- for a consumer that adds the pooling
+                            part of dxd itself (sdumc_rows_problem.pool_g); dxd may then be NULL and is not written */
 } sdumc_attnpool_bwd_t;
 
 size_t sdumc_attnpool_bwd_workspace_bytes(int32_t V, int32_t T, int32_t nq);

@@ -85,7 +85,8 @@ class GemmB1(C.Structure):
 class RowsProblem(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("a_bits", C.c_void_p), ("bias", C.c_void_p), ("C", C.c_void_p),
                 ("M", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32), ("a_row_mod", C.c_int32),
-                ("a_scale", C.c_float), ("accumulate", C.c_int32), ("act", C.c_int32)]
+                ("a_scale", C.c_float), ("accumulate", C.c_int32), ("act", C.c_int32),
+                ("pool_w", C.c_void_p), ("pool_g", C.c_void_p), ("pool_nq", C.c_int32), ("pool_T", C.c_int32)]
 
 
 class AttnPool(C.Structure):
@@ -103,7 +104,8 @@ class Umca(C.Structure):
 
 class AttnPoolBwd(C.Structure):
     _fields_ = [("f", AttnPool), ("dout", C.c_void_p), ("dz", C.c_void_p), ("dxd", C.c_void_p),
-                ("dq", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("dq_sum", C.c_void_p)]
+                ("dq", C.c_void_p), ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t), ("dq_sum", C.c_void_p),
+                ("dout_masked", C.c_void_p)]
 
 
 class DropSum(C.Structure):

@@ -734,6 +734,7 @@ __device__ __forceinline__ void attnpool_bwd_v2(const sdumc_attnpool_bwd_t b, fl
       f32x4 g = gq[u];
       if (i < NQT && od.enabled) g *= drop_mask4(od, (uint32_t)(v * NQT + i), (uint32_t)cq);
       st4(dO_s + i * LDQ + 4 * cq, g);
+      if (b.dout_masked && chunk == 0 && i < NQT) st4(b.dout_masked + ((size_t)v * NQT + i) * D + 4 * cq, g);
     }
   }
   __syncthreads();
@@ -797,7 +798,7 @@ __device__ __forceinline__ void attnpool_bwd_v2(const sdumc_attnpool_bwd_t b, fl
     if (tw + r < T) {
       const size_t row = (size_t)v * T + tw + r;
       stx<HF>(b.dz, row * D + 4 * lane, dk * (one - k * k));
-      stx<HF>(b.dxd, row * D + 4 * lane, dx);
+      if (b.dxd) stx<HF>(b.dxd, row * D + 4 * lane, dx);
     }
   }
   // ---- 5. dQ partial of the chunk: four waves summed in a fixed order ----------------------------------------------------
@@ -1127,8 +1128,9 @@ extern "C" int sdumc_attnpool_bwd(const sdumc_attnpool_bwd_t* bp, void* stream) 
   const sdumc_attnpool_bwd_t& b = *bp;
   int rc = check(b.f);
   if (rc) return rc;
-  if (!b.dout || !b.dz || !b.dxd || (!b.dq && !b.dq_sum) || !b.workspace) return SDUMC_EINVAL;
+  if (!b.dout || !b.dz || (!b.dq && !b.dq_sum) || !b.workspace) return SDUMC_EINVAL;
   const sdumc_attnpool& p = b.f;
+  if ((!b.dxd || b.dout_masked) && !v2_takes(p)) return SDUMC_EINVAL;      // (dxd left to the consumer: the wavefront-tiled kernels only)
   if (b.dq_sum && (p.q_stride != 0 || p.tickets)) return SDUMC_EINVAL;      // the sum over samples is the gradient of a SHARED query
   const int nchunk = (p.T + CH - 1) / CH;
   const int DD = row_dim(p);
@@ -1227,7 +1229,7 @@ extern "C" int sdumc_attnpool_bwd_multi(const sdumc_attnpool_bwd_t* bs, int32_t 
       const sdumc_attnpool& p = b.f;
       int rc = check(p);
       if (rc) return rc;
-      if (!b.dout || !b.dz || !b.dxd || !b.dq || !b.workspace || b.dq_sum || p.partial_only != bs[0].f.partial_only) return SDUMC_EINVAL;
+      if (!b.dout || !b.dz || !b.dq || !b.workspace || b.dq_sum || p.partial_only != bs[0].f.partial_only) return SDUMC_EINVAL;
       if (row_dim(p) != D || (p.x_drop.enabled && !p.x_drop.bits) || p.bf16 != bs[0].f.bf16) return SDUMC_EINVAL;
       if ((p.tickets != nullptr) != (bs[0].f.tickets != nullptr)) return SDUMC_EINVAL;
       if (b.workspace_bytes < sdumc_attnpool_bwd_workspace_bytes_dim(p.V, p.T, p.nq, D)) return SDUMC_ENOMEM;
@@ -1242,6 +1244,8 @@ extern "C" int sdumc_attnpool_bwd_multi(const sdumc_attnpool_bwd_t* bs, int32_t 
   hipStream_t st = as_stream(stream);
   bool v2 = true;
   for (int i = 0; i < n; ++i) v2 = v2 && v2_takes(bs[i].f) && bs[i].f.nq == bs[0].f.nq;
+  for (int i = 0; i < n && !v2; ++i)
+    if (!bs[i].dxd || bs[i].dout_masked) return SDUMC_EINVAL;      // (dxd left to the consumer: the wavefront-tiled kernels only)
   if (v2) {
     if (bs[0].f.bf16) {
       if (bs[0].f.nq == 1) hipLaunchKernelGGL((attnpool_bwd_v2_multi_kernel<true, 1>), dim3(wg), dim3(256), 0, st, m);

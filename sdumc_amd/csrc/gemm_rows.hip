@@ -301,20 +301,28 @@ constexpr int C_TILE = BM * DN * 4;                  // `accumulate`: the C tile
                                                      // so it starts where the keep-bits would lie) -- 32 registers a wave does not have
 constexpr int LDS_BYTES2 = RING + 2 * PL_STAGE + (C_TILE > 2 * BITS_TILE ? C_TILE : 2 * BITS_TILE);
 constexpr int C_OPS = BM / NW;                       // LDS-DMA instructions per wave for the C tile: one row each
-template <bool MASK, bool ACC>
-constexpr int ops_at(int t) { return 1 + ((MASK && t == T_BITS2) ? 2 : 0) + ((ACC && t == T_C2) ? C_OPS : 0); }
+// POOL (sdumc_rows_problem.pool_w / pool_g): the operands of the tile's extra k-tile -- its 64 rows of attention weights (<= 2 KB)
+// and the masked dout rows of the <= 2 samples it spans (2 x 8 x 1 KB) -- ride in by LDS-DMA at issue point 1 of the tile itself
+// (three instructions per wave) and are multiplied behind stage 7: the wait of stage 7 is for a piece issued after them.
+constexpr int T_P2 = 1, P_OPS = 3;
+constexpr int POOL_W = BM * 8 * 4, POOL_G = 2 * 8 * DN * 4;      // LDS bytes (where the keep-bits / the C tile lie in the other variants)
+template <bool MASK, bool ACC, bool POOL = false>
+constexpr int ops_at(int t) { return 1 + ((MASK && t == T_BITS2) ? 2 : 0) + ((ACC && t == T_C2) ? C_OPS : 0) + ((POOL && t == T_P2) ? P_OPS : 0); }
 // the wait in stage s is for the A piece of stage s + 2, issued at issue point s + 2 - PF2: what was issued after it
-template <bool MASK, bool ACC>
+template <bool MASK, bool ACC, bool POOL = false>
 constexpr int younger(int s) {
   const int t0 = ((s + 2 - PF2) % NS + NS) % NS;
-  int n = (ACC && t0 == T_C2) ? C_OPS : 0;            // what followed the A piece at its own issue point (the bits precede it)
-  for (int t = 1; t < PF2 - 2; ++t) n += ops_at<MASK, ACC>((t0 + t) % NS);
+  int n = ((ACC && t0 == T_C2) ? C_OPS : 0) + ((POOL && t0 == T_P2) ? P_OPS : 0);      // what followed the A piece at its own issue point (the bits precede it)
+  for (int t = 1; t < PF2 - 2; ++t) n += ops_at<MASK, ACC, POOL>((t0 + t) % NS);
   return n;
 }
 static_assert(younger<false, false>(0) == 4 && younger<false, false>(7) == 4, "plain: four issue points of one piece");
+static_assert(younger<false, false, true>(7) == 4 && younger<false, false, true>(6) == 7 && younger<false, false, true>(2) == 7 && younger<false, false, true>(1) == 4,
+              "pool: the three loads are behind the piece of issue point 1 (waited for in stage 6) and ahead of every later piece");
+static_assert(POOL_W + POOL_G <= (C_TILE > 2 * BITS_TILE ? C_TILE : 2 * BITS_TILE), "the pool operands fit where the C tile would lie");
 }  // namespace sp
 
-template <bool MASK, bool ACC>
+template <bool MASK, bool ACC, bool POOL = false>
 __global__ __launch_bounds__(NTHR, 2) void gr_split_kernel(const Launch L) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using namespace sp;
@@ -381,6 +389,11 @@ __global__ __launch_bounds__(NTHR, 2) void gr_split_kernel(const Launch L) {
     const __amdgpu_buffer_rsrc_t rbits = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(MASK ? pr.a_bits : (const uint8_t*)pr.A), 0,
                                                                            MASK ? (int)((uint32_t)pr.M * QW) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(pr.C, 0, (int)((uint32_t)pr.M * ldc4), 0x00020000);
+    const int pnq = POOL ? pr.pool_nq : 0, pT = POOL ? pr.pool_T : 1;
+    const __amdgpu_buffer_rsrc_t rpw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(POOL ? pr.pool_w : pr.A), 0,
+                                                                         POOL ? (int)((uint32_t)pr.M * (uint32_t)pnq * 4u) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rpg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(POOL ? pr.pool_g : pr.A), 0,
+                                                                         POOL ? (int)((uint32_t)(pr.M / pT) * (uint32_t)pnq * (DN * 4u)) : 0, 0x00020000);
 
     // B: register j = 16 s + 8 h + e  <->  k = 32 s + 16 h + 8 lh + e
     float breg[DK / 2];
@@ -408,6 +421,19 @@ __global__ __launch_bounds__(NTHR, 2) void gr_split_kernel(const Launch L) {
     auto issue_bits = [&](uint32_t off, int par) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rbits, (lds_void_t*)(bits_lds + par * BITS_TILE + wave * 512), 4, off, 0, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rbits, (lds_void_t*)(bits_lds + par * BITS_TILE + wave * 512 + 256), 4, off, 256, 0, 0);
+    };
+    // POOL: wave w brings 256 bytes of the tile's attention weights (rows r0 .. r0 + 63, pnq floats each: contiguous) and row w of
+    // both samples' masked dout ([slot][8][256] in LDS; rows >= pnq and samples past the last one: outside the descriptor, zeros)
+    auto issue_pool = [&](int t) {
+      const uint32_t r0 = (uint32_t)(t - tile0) * BM, v0 = r0 / (uint32_t)pT;
+      const uint32_t wb = 256u * (uint32_t)wave + 4u * (uint32_t)lane;
+      const uint32_t woff = wb < (uint32_t)(BM * pnq * 4) ? r0 * (uint32_t)pnq * 4u + wb : SDUMC_GR_NULL_OFF;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rpw, (lds_void_t*)(bits_lds + wave * 256), 4, woff, 0, 0, 0);
+#pragma unroll
+      for (int slot = 0; slot < 2; ++slot) {
+        const uint32_t goff = wave < pnq ? ((v0 + slot) * (uint32_t)pnq + (uint32_t)wave) * (DN * 4u) + 16u * (uint32_t)lane : SDUMC_GR_NULL_OFF;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rpg, (lds_void_t*)(bits_lds + POOL_W + (slot * 8 + wave) * (DN * 4)), 16, goff, 0, 0, 0);
+      }
     };
     // raw stage `slot` (keep-bits parity `par`) -> planes buffer `pb`
     auto convert = [&](int slot, int par, int pb) {
@@ -509,12 +535,15 @@ __global__ __launch_bounds__(NTHR, 2) void gr_split_kernel(const Launch L) {
         __builtin_amdgcn_sched_barrier(0);
         mma6(1, a1, bh1);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(waitcnt_vm(sp::younger<MASK, ACC>(s)));
+        __builtin_amdgcn_s_waitcnt(waitcnt_vm(sp::younger<MASK, ACC, POOL>(s)));
         __builtin_amdgcn_s_barrier();
         if constexpr (MASK) {
           if constexpr (s == T_BITS2) issue_bits(b_nxt, par ^ 1);
         }
         issue_a(s + PF2 < NS ? o_cur : o_nxt, (s + PF2) % NS);
+        if constexpr (POOL) {
+          if constexpr (s == T_P2) issue_pool(u);
+        }
         if constexpr (ACC) {
           if constexpr (s == T_C2) {   // this wave's rows 8 wave .. + 7 of the C tile (rows past M: outside the descriptor, zeros)
 #pragma unroll
@@ -532,6 +561,39 @@ __global__ __launch_bounds__(NTHR, 2) void gr_split_kernel(const Launch L) {
       stage(std::integral_constant<int, 5>{});
       stage(std::integral_constant<int, 6>{});
       stage(std::integral_constant<int, 7>{});
+      if constexpr (POOL) {      // the extra k-tile: k = 8 slot + j  <->  (sample v0 + slot, query j); a row multiplies its own sample's slot only
+        const uint32_t r0 = (uint32_t)(u - tile0) * BM, v0 = r0 / (uint32_t)pT;
+        const int rb = (int)((v0 + 1u) * (uint32_t)pT - r0);                 // first row of the tile that belongs to sample v0 + 1
+        const float* wl = reinterpret_cast<const float*>(bits_lds);
+        const float* gl = reinterpret_cast<const float*>(bits_lds + POOL_W) + lh * (8 * DN) + n0 + li;
+        Parts pb_, pa_;
+        {
+          float g[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) g[j] = gl[j * DN];
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            uint32_t q0, q1, q2;
+            split2(g[2 * d], g[2 * d + 1], q0, q1, q2);
+            pb_.p[0][d] = q0; pb_.p[1][d] = q1; pb_.p[2][d] = q2;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = 32 * i + li;
+          const bool mine = (row >= rb ? 1 : 0) == lh;
+          float w[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) w[j] = (mine && j < pnq) ? wl[row * pnq + j] : 0.f;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            uint32_t q0, q1, q2;
+            split2(w[2 * d], w[2 * d + 1], q0, q1, q2);
+            pa_.p[0][d] = q0; pa_.p[1][d] = q1; pa_.p[2][d] = q2;
+          }
+          mma6(i, pa_, pb_);
+        }
+      }
       auto epilogue = [&](auto tanh_c) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -769,8 +831,8 @@ bool set_lds_attr() {   // the dynamic-LDS limit is a per-device function attrib
                          reinterpret_cast<const void*>(&gr_kernel<false, true>)};
     for (const void* k : ks)
       if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return false;
-    const void* ks2[3] = {reinterpret_cast<const void*>(&gr_split_kernel<false, false>), reinterpret_cast<const void*>(&gr_split_kernel<true, false>),
-                          reinterpret_cast<const void*>(&gr_split_kernel<false, true>)};
+    const void* ks2[4] = {reinterpret_cast<const void*>(&gr_split_kernel<false, false>), reinterpret_cast<const void*>(&gr_split_kernel<true, false>),
+                          reinterpret_cast<const void*>(&gr_split_kernel<false, true>), reinterpret_cast<const void*>(&gr_split_kernel<false, false, true>)};
     for (const void* k : ks2)
       if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, sp::LDS_BYTES2) != hipSuccess) return false;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gr_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, RING) != hipSuccess) return false;
@@ -806,15 +868,22 @@ extern "C" int sdumc_gemm_rows256(const sdumc_rows_problem* probs, int32_t n, vo
 // max_wg > 0: at most that many (persistent) workgroups -- a launch that should leave part of the chip to a neighbour
 extern "C" int sdumc_gemm_rows256_capped_(const sdumc_rows_problem* probs, int32_t n, int32_t max_wg, void* stream) {
   if (!probs || n <= 0 || n > MAXP) return SDUMC_EINVAL;
-  const bool mask = probs[0].a_bits != nullptr, accum = probs[0].accumulate != 0;
+  const bool mask = probs[0].a_bits != nullptr, accum = probs[0].accumulate != 0, pool = probs[0].pool_w != nullptr;
   if (mask && accum) return SDUMC_EINVAL;
+  if (pool && (mask || accum || !sdumc_split_on_(SDUMC_SPLIT_ROWS))) return SDUMC_EINVAL;      // (the pooling k-tile: split arithmetic only)
   Launch L;
   memset(&L, 0, sizeof(L));
   int units = 0;
   double flops = 0.0;
   for (int i = 0; i < n; ++i) {
     if (!valid(probs[i])) return SDUMC_EINVAL;
-    if ((probs[i].a_bits != nullptr) != mask || (probs[i].accumulate != 0) != accum) return SDUMC_EINVAL;   // one kernel variant per launch
+    if ((probs[i].a_bits != nullptr) != mask || (probs[i].accumulate != 0) != accum || (probs[i].pool_w != nullptr) != pool) return SDUMC_EINVAL;   // one kernel variant per launch
+    if (pool) {
+      const sdumc_rows_problem& q = probs[i];
+      if (!q.pool_g || q.pool_nq < 1 || q.pool_nq > 8 || !(q.pool_T >= 63 || q.pool_T == 32) || (q.M % q.pool_T) || q.a_row_mod || q.bias || q.act != SDUMC_ACT_NONE) return SDUMC_EINVAL;
+      if ((reinterpret_cast<uintptr_t>(q.pool_w) | reinterpret_cast<uintptr_t>(q.pool_g)) & 15) return SDUMC_EINVAL;
+      if (((int64_t)q.pool_nq * 64 * 4) & 15) return SDUMC_EINVAL;
+    }
     L.p[i] = probs[i];
     L.unit0[i] = units;
     units += (probs[i].M + BM - 1) / BM;
@@ -829,7 +898,8 @@ extern "C" int sdumc_gemm_rows256_capped_(const sdumc_rows_problem* probs, int32
   hipStream_t st = as_stream(stream);
   const int tok = sdumc_prof_begin_(sdumc_split_on_(SDUMC_SPLIT_ROWS) ? 25 : 21, flops, stream);
   if (sdumc_split_on_(SDUMC_SPLIT_ROWS)) {
-    if (mask) hipLaunchKernelGGL((gr_split_kernel<true, false>), dim3(L.nwg), dim3(NTHR), sp::LDS_BYTES2, st, L);
+    if (pool) hipLaunchKernelGGL((gr_split_kernel<false, false, true>), dim3(L.nwg), dim3(NTHR), sp::LDS_BYTES2, st, L);
+    else if (mask) hipLaunchKernelGGL((gr_split_kernel<true, false>), dim3(L.nwg), dim3(NTHR), sp::LDS_BYTES2, st, L);
     else if (accum) hipLaunchKernelGGL((gr_split_kernel<false, true>), dim3(L.nwg), dim3(NTHR), sp::LDS_BYTES2, st, L);
     else hipLaunchKernelGGL((gr_split_kernel<false, false>), dim3(L.nwg), dim3(NTHR), sp::LDS_BYTES2, st, L);
   } else if (mask) hipLaunchKernelGGL((gr_kernel<true, false>), dim3(L.nwg), dim3(NTHR), LDS_BYTES, st, L);

@@ -249,6 +249,9 @@ def gemm_rows256(problems):
         g.C, g.ldc = ptr(Cm), Cm.stride(0)
         g.accumulate = 1 if q.get("accumulate") else 0
         g.act = q.get("act", ACT_NONE)
+        if q.get("pool_w") is not None:      # + sum_i pool_w[r, i] * pool_g[r // pool_T, i, :]  (sdumc_rows_problem.pool_*)
+            pw, pg = q["pool_w"], q["pool_g"]
+            g.pool_w, g.pool_g, g.pool_nq, g.pool_T = ptr(pw), ptr(pg), pw.shape[1], q["pool_T"]
     hf = problems[0]["A"].dtype == torch.bfloat16
     check((lib.sdumc_gemm_rows256_bf16 if hf else lib.sdumc_gemm_rows256)(arr, n, _st()), "sdumc_gemm_rows256")
     return [q["C"] for q in problems]

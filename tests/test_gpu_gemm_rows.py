@@ -120,6 +120,45 @@ def test_c2_shapes(ops):
     run_case(ops, [{"M": 48000, "accumulate": True}, {"M": 28800, "accumulate": True}], seed=10)
 
 
+def run_pool(ops, specs, seed):
+    """C = A B + sum_i pool_w[r, i] * pool_g[r // T, i, :] -- dxd = dz W + the attention pooling's own input gradient in one pass."""
+    g = torch.Generator().manual_seed(seed)
+    probs, refs = [], []
+    for (V, T, nq) in specs:
+        M = V * T
+        A, B = (torch.randn(M, 256, generator=g) * 0.5).cuda(), (torch.randn(256, 256, generator=g) / 16).cuda()
+        pw = torch.softmax(torch.randn(V, T, nq, generator=g), dim=1).reshape(M, nq).contiguous().cuda()
+        pg = (torch.randn(V, nq, 256, generator=g) * (torch.rand(V, nq, 256, generator=g) > 0.3)).cuda()
+        probs.append({"A": A, "B": B, "pool_w": pw, "pool_g": pg, "pool_T": T, "C": torch.full((M, 256), 7.0).cuda()})
+        refs.append(A.double().cpu() @ B.double().cpu()
+                    + torch.einsum("vti,vic->vtc", pw.double().cpu().view(V, T, nq), pg.double().cpu()).reshape(M, 256))
+    out = [c.clone() for c in ops.gemm_rows256(probs)]
+    for got, ref, sp in zip(out, refs, specs):
+        close(got, ref, msg=str(sp))
+    again = ops.gemm_rows256(probs)
+    for a, b in zip(out, again):
+        assert torch.equal(a, b)
+
+
+def test_pooling_term_as_an_extra_k_tile(ops):
+    """Sites of 7 queries and of 1; samples of 375 / 225 frames (tiles straddle sample boundaries), of 32 (two samples per tile), of 63 and 64;
+    a ragged last tile; several problems per launch."""
+    run_pool(ops, [(4, 375, 7)], seed=21)
+    run_pool(ops, [(6, 225, 1)], seed=22)
+    run_pool(ops, [(10, 32, 7), (3, 64, 7), (5, 63, 1)], seed=23)
+    run_pool(ops, [(128, 375, 7), (128, 225, 7)], seed=24)      # the C2 audio and video sites
+
+
+def test_pooling_term_refuses_what_it_cannot_tile(ops):
+    from sdumc_amd._lib import SdumcError
+    A, B = torch.zeros(100, 256).cuda(), torch.zeros(256, 256).cuda()
+    pw, pg = torch.zeros(100, 7).cuda(), torch.zeros(2, 7, 256).cuda()
+    with pytest.raises(SdumcError):      # 50-frame samples: a 64-row tile can span three
+        ops.gemm_rows256([{"A": A, "B": B, "pool_w": pw, "pool_g": pg, "pool_T": 50}])
+    with pytest.raises(SdumcError):      # with accumulate
+        ops.gemm_rows256([{"A": A, "B": B, "pool_w": pw, "pool_g": pg, "pool_T": 100, "accumulate": True, "C": torch.zeros(100, 256).cuda()}])
+
+
 def test_mixed_variants_are_refused(ops):
     g = torch.Generator().manual_seed(0)
     A = torch.randn(128, 256, generator=g).cuda()
