@@ -200,6 +200,8 @@ struct Plan {
   int64_t fold_ws[2][3] = {{0, 0, 0}, {0, 0, 0}};   // softmax partials of site (k, m), kept until the clustered stage behind them has combined them (fra_fold)
   // fp32 storage, features given as bf16 planes too (sdumc_net_io.*_p3; gemm_p3.hip): fragment-major planes of the frame-level weights
   // (refreshed at the head of each forward) and P3 copies of the projected frames (written by the frame projection's epilogue)
+  int64_t dom[2][3] = {{0, 0, 0}, {0, 0, 0}};      // dout * out-dropout mask of attention site (k, m) ([V][nq][D]), written by its pooling backward (dxfold)
+  bool dxfold = false;                 // dxd = dz W + the pooling's own input gradient in ONE pass of the rows launch (no dxd write by the pooling backward)
   int64_t wb1 = 0;                     // bf16 storage: float offset of the fragment-major bf16 weights (wp3_frame / wp3_key: byte offsets inside it)
   int64_t wp3 = 0;                     // float offset of the weight-plane region
   int64_t wp3_frame[3] = {0, 0, 0};    // byte offsets inside it
@@ -317,6 +319,16 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
       p.dz[k][m] = p.alloc(p.rows[m] * D / HS);
       p.dxd[k][m] = p.alloc(p.rows[m] * D / HS);
     }
+  {
+    // the rows launch adds the rank-nq pooling term as one more k-tile when a 64-row tile spans at most two samples (sdumc_rows_problem)
+    bool ok = D == 256 && d.bf16 == 0;
+    for (int m = 0; m < 3; ++m)
+      for (const Seg& sg : p.segs[m]) ok = ok && (sg.T >= 63 || sg.T == 32) && (int64_t)sg.V * sg.T * D * 4 < 0x7FFF0000LL;
+    p.dxfold = ok;
+    if (ok)
+      for (int k = 0; k < 2; ++k)
+        for (int m = 0; m < 3; ++m) p.dom[k][m] = p.alloc((int64_t)V * (k == 0 ? 1 : NQ) * D);
+  }
   p.dx[0][0] = p.dx[0][1] = p.alloc((int64_t)B * d.Ta * D / HS);
   p.dx[2][0] = p.dx[2][1] = p.alloc((int64_t)B * d.Tv * D / HS);
   p.dx[1][0] = p.alloc((int64_t)B * p.T[1][0] * D / HS);
@@ -703,6 +715,12 @@ bool rows_on() {
   return on;
 }
 bool rows_ok(const Ctx& c) { return D == 256 && !c.h() && c.d.bf16 == 0; }
+// dxd of a site leaves the rows launch in one pass: dz W + sum_i attn_i * (dout_i * mask) (the pooling backward then writes no dxd and
+// this launch reads none back: -2 KB of HBM traffic per virtual row and site).  SDUMC_DXFOLD=0: A/B against the two-pass form.
+bool dxfold(const Ctx& c) {
+  static const int on = [] { const char* e = getenv("SDUMC_DXFOLD"); return e ? atoi(e) : 1; }();
+  return on && c.pl.dxfold && rows_on() && rows_ok(c) && sdumc_split_on_(SDUMC_SPLIT_ROWS);
+}
 
 // one group of a queued TN descriptor as a problem of the grouped launch; false = the grouped kernel does not take it
 bool gg_from_gemm(const sdumc_gemm& g, int grp, sdumc_gg_problem& q) {
@@ -1707,6 +1725,7 @@ int pool_bwd(const Ctx& c, int k, int m, const float* dout_base /* [V, nq, D] */
       b.dz = reinterpret_cast<float*>(c.ph(pl.dz[k][m], sg.row0 * D));
       b.dxd = reinterpret_cast<float*>(c.ph(pl.dxd[k][m], sg.row0 * D));
     }
+    if (dxfold(c)) { b.dxd = nullptr; b.dout_masked = c.p(pl.dom[k][m]) + voff; }
     b.dq = dq_base + voff;
     b.dq_sum = dq_sum;
     b.workspace = c.scr;
@@ -1811,11 +1830,29 @@ void keys_dw_queue(const Ctx& c, int m, int k0, int k1) {
   }
 }
 
-// dxd += dz W of sites [k0, k1) of modality m as problems of a rows launch
+// dxd += dz W of sites [k0, k1) of modality m as problems of a rows launch (dxfold: dxd = dz W + the pooling term, one problem per run)
 int keys_dx_rows(const Ctx& c, int m, int k0, int k1, sdumc_rows_problem* q) {
   int n = 0;
+  const bool fold = dxfold(c);
   for (int k = k0; k < k1; ++k) {
     const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
+    if (fold) {
+      const int nq = k == 0 ? 1 : NQ;
+      for (const Seg& sg : c.pl.segs[m]) {
+        sdumc_rows_problem& r = q[n++];
+        memset(&r, 0, sizeof(r));
+        r.A = c.p(c.pl.dz[k][m]) + sg.row0 * D;
+        r.B = c.P + L.w;
+        r.C = c.p(c.pl.dxd[k][m]) + sg.row0 * D;
+        r.M = sg.V * sg.T;
+        r.lda = r.ldb = r.ldc = D;
+        r.pool_w = c.p(c.pl.attn[k][m]) + sg.row0 * nq;
+        r.pool_g = c.p(c.pl.dom[k][m]) + (int64_t)sg.s0 * c.pl.B * nq * D;
+        r.pool_nq = nq;
+        r.pool_T = sg.T;
+      }
+      continue;
+    }
     sdumc_rows_problem& r = q[n++];
     memset(&r, 0, sizeof(r));
     r.A = c.p(c.pl.dz[k][m]);
@@ -1857,12 +1894,13 @@ int keys_gemm_bwd(const Ctx& c, int m, int k0, int k1, int parts = 3, int rows_c
   }
   if (!(parts & 2)) return SDUMC_OK;
   // dxd += dz W (the key-projection path joins the pooling path)
-  if (parts == 2 && rows_cap >= 0 && rows_on() && rows_ok(c)) {   // (the early dW + dX pair keeps the small-footprint kernels: it runs beside
+  if (dxfold(c) || (parts == 2 && rows_cap >= 0 && rows_on() && rows_ok(c))) {   // (the early dW + dX pair keeps the small-footprint kernels: it runs beside
                                                          //  the co-resident utterance-level stage, which a persistent launch would stall)
-    sdumc_rows_problem q[2];
+    sdumc_rows_problem q[8];
     const int n = keys_dx_rows(c, m, k0, k1, q);
-    const int rc = sdumc_gemm_rows256_capped_(q, n, rows_cap, c.st);
-    if (rc != SDUMC_EINVAL) return rc;      // (a shape the rows launch refuses -- 2 GiB of rows -- takes the tiled kernel below)
+    const int rc = sdumc_gemm_rows256_capped_(q, n, rows_cap > 0 ? rows_cap : 0, c.st);
+    if (rc != SDUMC_EINVAL || dxfold(c)) return rc;      // (a shape the rows launch refuses -- 2 GiB of rows -- takes the tiled kernel below;
+                                                          //  dxfold: the plan checked the shapes, a refusal is an error -- nothing else wrote dxd)
   }
   sdumc_gemm g = G_(SDUMC_NN, (int)pl.rows[m], D, D, k1 - k0);
   for (int k = k0; k < k1; ++k) {
@@ -2018,6 +2056,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
           b.dz = c.p(pl.dz[1][m]) + sg.row0 * D;
           b.dxd = c.p(pl.dxd[1][m]) + sg.row0 * D;
         }
+        if (dxfold(c)) { b.dxd = nullptr; b.dout_masked = c.p(pl.dom[1][m]) + voff; }
         const size_t bytes = sdumc_attnpool_bwd_workspace_bytes(sg.V, sg.T, NQ);
         b.workspace = ws;
         b.workspace_bytes = bytes;

@@ -881,8 +881,7 @@ extern "C" int sdumc_gemm_rows256_capped_(const sdumc_rows_problem* probs, int32
     if (pool) {
       const sdumc_rows_problem& q = probs[i];
       if (!q.pool_g || q.pool_nq < 1 || q.pool_nq > 8 || !(q.pool_T >= 63 || q.pool_T == 32) || (q.M % q.pool_T) || q.a_row_mod || q.bias || q.act != SDUMC_ACT_NONE) return SDUMC_EINVAL;
-      if ((reinterpret_cast<uintptr_t>(q.pool_w) | reinterpret_cast<uintptr_t>(q.pool_g)) & 15) return SDUMC_EINVAL;
-      if (((int64_t)q.pool_nq * 64 * 4) & 15) return SDUMC_EINVAL;
+      if ((reinterpret_cast<uintptr_t>(q.pool_w) & 3) || (reinterpret_cast<uintptr_t>(q.pool_g) & 15)) return SDUMC_EINVAL;
     }
     L.p[i] = probs[i];
     L.unit0[i] = units;
