@@ -330,6 +330,15 @@ typedef struct sdumc_rows_problem {
   const float* pool_w;
   const float* pool_g;
   int32_t pool_nq, pool_T;
+  /* optional, with the pooling term (fp32 split arithmetic only): the mask-sum of the frame-level input dropouts folded in as well --
+   *   C[r] (+)= sum_{s < fold} keep_s[r] . (A[s R + r] B + pooling term of row s R + r) * c_scale,   R = M / fold rows of C
+   * i.e. dx of a modality = the sum over the streams that share its frames (fold = 2; 1 for separate frames) of the masked dxd of one
+   * attention site, written ONCE: dxd never exists in memory.  c_bits = the keep-bits of the site's input dropout over the M virtual
+   * rows ([M][64], as a_bits; NULL = keep everything, c_scale unused); accumulate = 1 adds onto C (the second site of the modality).
+   * fold = 0: off.  R % pool_T == 0. */
+  const uint8_t* c_bits;
+  float c_scale;
+  int32_t fold;
 } sdumc_rows_problem;
 int sdumc_gemm_rows256(const sdumc_rows_problem* probs, int32_t n, void* stream);
 /* The same on bf16 STORAGE (sdumc_net_dims.bf16 = 2): A ([M][256]), B and C are bf16 tensors (lda / ldb / ldc in elements, lda

@@ -86,7 +86,8 @@ class RowsProblem(C.Structure):
     _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("a_bits", C.c_void_p), ("bias", C.c_void_p), ("C", C.c_void_p),
                 ("M", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32), ("a_row_mod", C.c_int32),
                 ("a_scale", C.c_float), ("accumulate", C.c_int32), ("act", C.c_int32),
-                ("pool_w", C.c_void_p), ("pool_g", C.c_void_p), ("pool_nq", C.c_int32), ("pool_T", C.c_int32)]
+                ("pool_w", C.c_void_p), ("pool_g", C.c_void_p), ("pool_nq", C.c_int32), ("pool_T", C.c_int32),
+                ("c_bits", C.c_void_p), ("c_scale", C.c_float), ("fold", C.c_int32)]
 
 
 class AttnPool(C.Structure):

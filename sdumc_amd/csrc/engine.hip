@@ -331,8 +331,11 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
   }
   p.dx[0][0] = p.dx[0][1] = p.alloc((int64_t)B * d.Ta * D / HS);
   p.dx[2][0] = p.dx[2][1] = p.alloc((int64_t)B * d.Tv * D / HS);
-  p.dx[1][0] = p.alloc((int64_t)B * p.T[1][0] * D / HS);
-  p.dx[1][1] = S == 2 ? p.alloc((int64_t)B * p.T[1][1] * D / HS) : p.dx[1][0];
+  {      // (the text slot's two streams adjacent, like their x: one run of 2 B samples when the streams share T)
+    const int64_t n0 = (int64_t)B * p.T[1][0] * D / HS;
+    p.dx[1][0] = p.alloc(n0 + (S == 2 ? (int64_t)B * p.T[1][1] * D / HS : 0));
+    p.dx[1][1] = S == 2 ? p.dx[1][0] + n0 : p.dx[1][0];
+  }
   p.d_hpre = p.alloc(3LL * V * D);
   p.d_u1 = p.alloc(3LL * V * D);
   p.d_u = p.alloc(3LL * V * D);
@@ -717,8 +720,16 @@ bool rows_on() {
 bool rows_ok(const Ctx& c) { return D == 256 && !c.h() && c.d.bf16 == 0; }
 // dxd of a site leaves the rows launch in one pass: dz W + sum_i attn_i * (dout_i * mask) (the pooling backward then writes no dxd and
 // this launch reads none back: -2 KB of HBM traffic per virtual row and site).  SDUMC_DXFOLD=0: A/B against the two-pass form.
+// ... and the mask-sum of the input dropouts as well: every site's launch adds keep . dxd of its streams straight into dx (the
+// Cross_Attention site writes, the FRA2UTT site adds onto it) -- dxd is never in memory and there is no mask-sum launch.
+// SDUMC_DXFOLD=1: the pooling term only.
+bool dxfold(const Ctx& c);
+bool dxsum(const Ctx& c) {
+  static const int on = [] { const char* e = getenv("SDUMC_DXFOLD"); return e ? atoi(e) : 2; }();
+  return on >= 2 && dxfold(c);
+}
 bool dxfold(const Ctx& c) {
-  static const int on = [] { const char* e = getenv("SDUMC_DXFOLD"); return e ? atoi(e) : 1; }();
+  static const int on = [] { const char* e = getenv("SDUMC_DXFOLD"); return e ? atoi(e) : 2; }();
   return on && c.pl.dxfold && rows_on() && rows_ok(c) && sdumc_split_on_(SDUMC_SPLIT_ROWS);
 }
 
@@ -1865,6 +1876,35 @@ int keys_dx_rows(const Ctx& c, int m, int k0, int k1, sdumc_rows_problem* q) {
   return n;
 }
 
+// dxsum: dx of modality m (+)= sum over the streams of keep . (dz W + pooling term) of site k, one rows launch (the Cross_Attention
+// site of a modality always runs first and writes, the FRA2UTT site adds onto it)
+int keys_dx_sum(const Ctx& c, int m, int k, int rows_cap) {
+  const Plan& pl = c.pl;
+  const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
+  const int nq = k == 0 ? 1 : NQ;
+  sdumc_rows_problem q[4];
+  int n = 0;
+  for (const Seg& sg : pl.segs[m]) {
+    sdumc_rows_problem& r = q[n++];
+    memset(&r, 0, sizeof(r));
+    const int fold = sg.V / sg.x_samples;              // streams that share the run's frames: 2 (audio, video), 1 (the text slot: dx rows = virtual rows)
+    r.A = c.p(pl.dz[k][m]) + sg.row0 * D;
+    r.B = c.P + L.w;
+    r.C = c.p(pl.dx[m][sg.s0]);
+    r.M = sg.V * sg.T;
+    r.lda = r.ldb = r.ldc = D;
+    r.accumulate = k == 0 ? 1 : 0;
+    r.pool_w = c.p(pl.attn[k][m]) + sg.row0 * nq;
+    r.pool_g = c.p(pl.dom[k][m]) + (int64_t)sg.s0 * pl.B * nq * D;
+    r.pool_nq = nq;
+    r.pool_T = sg.T;
+    r.fold = fold;
+    const sdumc_dropout dr = in_drop(c, k, m, sg.T, sg.s0, sg.row0);
+    if (dr.enabled) { r.c_bits = dr.bits; r.c_scale = dr.scale; }
+  }
+  return sdumc_gemm_rows256_capped_(q, n, rows_cap > 0 ? rows_cap : 0, c.st);
+}
+
 // rows_cap (fp32 dX through the persistent rows launch): > 0 = at most that many workgroups, < 0 = the tiled 64x64 kernel instead
 int keys_gemm_bwd(const Ctx& c, int m, int k0, int k1, int parts = 3, int rows_cap = 0) {
   if (c.h()) return keys_gemm_bwd_h(c, m, k0, k1, parts, 0);      // (bf16 storage: the cap measured 0.957-0.966 vs 0.951-0.959 ms: every CU)
@@ -1894,6 +1934,10 @@ int keys_gemm_bwd(const Ctx& c, int m, int k0, int k1, int parts = 3, int rows_c
   }
   if (!(parts & 2)) return SDUMC_OK;
   // dxd += dz W (the key-projection path joins the pooling path)
+  if (dxsum(c)) {      // (site 1 first: it writes dx)
+    for (int k = k1 - 1; k >= k0; --k) RET(keys_dx_sum(c, m, k, rows_cap));
+    return SDUMC_OK;
+  }
   if (dxfold(c) || (parts == 2 && rows_cap >= 0 && rows_on() && rows_ok(c))) {   // (the early dW + dX pair keeps the small-footprint kernels: it runs beside
                                                          //  the co-resident utterance-level stage, which a persistent launch would stall)
     sdumc_rows_problem q[8];
@@ -2213,8 +2257,16 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     RET(flush_dw(c));
     if (c.capturing) RET(fork_all(c));
   }
+  const bool sum_in_dx = dxsum(c);      // the rows launches add keep . dxd straight into dx: no mask-sum launch, and the FRA2UTT site's
+                                        // launch (which adds onto dx) has to follow the modality's early Cross_Attention one
+  auto await_early = [&](int m) -> int {
+    if (!(bgb & ~own_lane & (1 << m))) return SDUMC_OK;   // dxd of this modality's Cross_Attention site (issued early on lane 3)
+    if (early_done[m]) return hipStreamWaitEvent(c.st, early_done[m], 0) == hipSuccess ? SDUMC_OK : SDUMC_ELAUNCH;
+    return link(c, 3, LANE_OF[m]);
+  };
   for (int m = 0; m < 3; ++m) {       // pass 2: dX of the key projections, the mask-sum, the frame projection's dW
     c.use(LANE_OF[m]);
+    if (sum_in_dx) RET(await_early(m));
     {
       const int k1 = (bgb & (1 << m)) ? 1 : 2;
       // which of this modality's key-projection dW products are already on their way in a grouped launch
@@ -2238,13 +2290,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
       }
     }
     mark(c.st, 13 + 5 * m);
-    if (bgb & ~own_lane & (1 << m)) {   // dxd of this modality's Cross_Attention site (issued early on lane 3)
-      if (early_done[m]) {
-        if (hipStreamWaitEvent(c.st, early_done[m], 0) != hipSuccess) return SDUMC_ELAUNCH;
-      } else {
-        RET(link(c, 3, LANE_OF[m]));
-      }
-    }
+    if (!sum_in_dx) RET(await_early(m));
     sdumc_gg_problem fq;          // grouped mode: this modality's frame_dim_reshape dW, the streams as K segments
     memset(&fq, 0, sizeof(fq));
     // grouped or per-layer is decided ONCE per modality: the grouped problem overwrites its output (accumulate = 0) after the
@@ -2275,7 +2321,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
       ds.terms = nt;
       if (c.h()) ds.bf16 = 1;          // (dx is a half-length buffer: its float offset is its start either way)
       if (s == 0) mark(c.st, 14 + 5 * m);     // (after the wait for the early key-projection backward)
-      RET(sdumc_dropsum_bwd(&ds, c.st));
+      if (!sum_in_dx) RET(sdumc_dropsum_bwd(&ds, c.st));
       if (s == 0) mark(c.st, 15 + 5 * m);
       const float* in = m == 0 ? c.io.audio : (m == 2 ? c.io.video : c.io.text[s]);
       const int rows = B * T;

@@ -306,24 +306,38 @@ constexpr int C_OPS = BM / NW;                       // LDS-DMA instructions per
 // (three instructions per wave) and are multiplied behind stage 7: the wait of stage 7 is for a piece issued after them.
 constexpr int T_P2 = 1, P_OPS = 3;
 constexpr int POOL_W = BM * 8 * 4, POOL_G = 2 * 8 * DN * 4;      // LDS bytes (where the keep-bits / the C tile lie in the other variants)
-template <bool MASK, bool ACC, bool POOL = false>
-constexpr int ops_at(int t) { return 1 + ((MASK && t == T_BITS2) ? 2 : 0) + ((ACC && t == T_C2) ? C_OPS : 0) + ((POOL && t == T_P2) ? P_OPS : 0); }
+// FOLD (sdumc_rows_problem.fold): `fold` row blocks of A add up, each under its own keep-bits, into ONE C tile -- the mask-sum of the
+// frame-level input dropouts (dx = sum over sites and streams of keep . dxd) folded into the launch that produces dxd.  The partial
+// tile waits in LDS where the C tile of `accumulate` lies (and is that tile when both are on); the keep-bits of the tile's rows (4 KB)
+// ride with the attention weights at issue point 1 (three instructions per wave again), the masked dout rows come straight into
+// eight registers at issue point 5 (no LDS left for them: ring 64 + planes 24 + tile 64 + weights 2 + bits 4 + a dummy row 1 = 159 KB).
+constexpr int T_G2 = 5, G_OPS = 7;      // (fold: at most 7 queries -- k = 7 of a slot is a zero)
+constexpr int LDS_FOLD = RING + 2 * PL_STAGE + C_TILE + POOL_W + BITS_TILE + DN * 4;
+static_assert(LDS_FOLD <= 160 * 1024, "LDS of the folding variant");
+template <bool MASK, bool ACC, bool POOL = false, bool FOLD = false>
+constexpr int ops_at(int t) {
+  return 1 + ((MASK && t == T_BITS2) ? 2 : 0) + ((ACC && t == T_C2) ? C_OPS : 0) + ((POOL && t == T_P2) ? P_OPS : 0) + ((FOLD && t == T_G2) ? G_OPS : 0);
+}
 // the wait in stage s is for the A piece of stage s + 2, issued at issue point s + 2 - PF2: what was issued after it
-template <bool MASK, bool ACC, bool POOL = false>
+template <bool MASK, bool ACC, bool POOL = false, bool FOLD = false>
 constexpr int younger(int s) {
   const int t0 = ((s + 2 - PF2) % NS + NS) % NS;
-  int n = ((ACC && t0 == T_C2) ? C_OPS : 0) + ((POOL && t0 == T_P2) ? P_OPS : 0);      // what followed the A piece at its own issue point (the bits precede it)
-  for (int t = 1; t < PF2 - 2; ++t) n += ops_at<MASK, ACC, POOL>((t0 + t) % NS);
+  // what followed the A piece at its own issue point (the bits of MASK precede it)
+  int n = ((ACC && t0 == T_C2) ? C_OPS : 0) + ((POOL && t0 == T_P2) ? P_OPS : 0) + ((FOLD && t0 == T_G2) ? G_OPS : 0);
+  for (int t = 1; t < PF2 - 2; ++t) n += ops_at<MASK, ACC, POOL, FOLD>((t0 + t) % NS);
   return n;
 }
+static_assert(younger<false, true, true, true>(7) == 11 && younger<false, true, true, true>(6) == 22 && younger<false, false, true, true>(2) == 14,
+              "fold: 3 + 8 (+ 8) loads behind the piece of issue point 1, 8 behind the piece of issue point 5");
 static_assert(younger<false, false>(0) == 4 && younger<false, false>(7) == 4, "plain: four issue points of one piece");
 static_assert(younger<false, false, true>(7) == 4 && younger<false, false, true>(6) == 7 && younger<false, false, true>(2) == 7 && younger<false, false, true>(1) == 4,
               "pool: the three loads are behind the piece of issue point 1 (waited for in stage 6) and ahead of every later piece");
 static_assert(POOL_W + POOL_G <= (C_TILE > 2 * BITS_TILE ? C_TILE : 2 * BITS_TILE), "the pool operands fit where the C tile would lie");
 }  // namespace sp
 
-template <bool MASK, bool ACC, bool POOL = false>
+template <bool MASK, bool ACC, bool POOL = false, bool FOLD = false>
 __global__ __launch_bounds__(NTHR, 2) void gr_split_kernel(const Launch L) {
+  static_assert(!FOLD || (POOL && !MASK), "the folding variant carries the pooling term");
 #if defined(__HIP_DEVICE_COMPILE__)
   using namespace sp;
   extern __shared__ __attribute__((aligned(16))) char lds[];
@@ -374,6 +388,10 @@ __global__ __launch_bounds__(NTHR, 2) void gr_split_kernel(const Launch L) {
   char* const planes = lds + RING;
   char* const bits_lds = planes + 2 * PL_STAGE;       // MASK: the keep-bits of two tiles; ACC: the C tile
   char* const c_lds = bits_lds;
+  // FOLD: [C / partial tile 64 KB][attention weights 2 KB][keep-bits 4 KB][dummy row 1 KB]; POOL alone: [weights 2 KB][dout rows 16 KB]
+  char* const pw_lds = FOLD ? c_lds + C_TILE : bits_lds;
+  char* const cb_lds = pw_lds + POOL_W;
+  // (the dummy row: c_lds + C_TILE + POOL_W + BITS_TILE)
 
   f32x16 acc[2];
 
@@ -385,10 +403,18 @@ __global__ __launch_bounds__(NTHR, 2) void gr_split_kernel(const Launch L) {
     const int tile0 = L.unit0[p];
     const uint32_t lda4 = (uint32_t)pr.lda * 4u, ldc4 = (uint32_t)pr.ldc * 4u;
     const int a_rows = pr.a_row_mod > 0 ? pr.a_row_mod : pr.M;
+    // FOLD: unit w of the problem = (output tile w / fold, row block w % fold); R = rows of C = rows of one block
+    const int fold = FOLD ? pr.fold : 1;
+    const int R = FOLD ? pr.M / fold : pr.M;
+    const bool cmask = FOLD && pr.c_bits != nullptr;
+    const float cscale = cmask ? pr.c_scale : 1.f;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.A), 0, (int)((uint32_t)a_rows * lda4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rbits = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(MASK ? pr.a_bits : (const uint8_t*)pr.A), 0,
-                                                                           MASK ? (int)((uint32_t)pr.M * QW) : 0, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(pr.C, 0, (int)((uint32_t)pr.M * ldc4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rbits = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(MASK ? pr.a_bits : (cmask ? pr.c_bits : (const uint8_t*)pr.A)), 0,
+                                                                           (MASK || cmask) ? (int)((uint32_t)pr.M * QW) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(pr.C, 0, (int)((uint32_t)R * ldc4), 0x00020000);
+    auto blk_of = [&](int w) -> int { return fold == 2 ? (w & 1) : 0; };
+    auto tile_of = [&](int w) -> int { return fold == 2 ? (w >> 1) : w; };
+    auto vrow0 = [&](int w) -> uint32_t { return (uint32_t)(blk_of(w) * R + tile_of(w) * BM); };      // first (virtual) row of unit w
     const int pnq = POOL ? pr.pool_nq : 0, pT = POOL ? pr.pool_T : 1;
     const __amdgpu_buffer_rsrc_t rpw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(POOL ? pr.pool_w : pr.A), 0,
                                                                          POOL ? (int)((uint32_t)pr.M * (uint32_t)pnq * 4u) : 0, 0x00020000);
@@ -409,12 +435,12 @@ __global__ __launch_bounds__(NTHR, 2) void gr_split_kernel(const Launch L) {
     const float scale = MASK ? pr.a_scale : 1.f;
     const bool do_tanh = pr.act == SDUMC_ACT_TANH;
 
-    auto a_off = [&](int t) -> uint32_t {
-      int r = (t - tile0) * BM + dr;
+    auto a_off = [&](int w) -> uint32_t {      // (w: unit of this problem)
+      int r = (int)vrow0(w) + dr;
       if (pr.a_row_mod > 0) r %= pr.a_row_mod;
       return (uint32_t)r * lda4 + dq16;
     };
-    auto bits_off = [&](int t) -> uint32_t { return (uint32_t)((t - tile0) * BM + 8 * wave) * QW + 4u * lane; };
+    auto bits_off = [&](int w) -> uint32_t { return (vrow0(w) + 8u * (uint32_t)wave) * QW + 4u * lane; };
     auto issue_a = [&](uint32_t off, int chunk) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(lds + chunk * A_STAGE + wave * 1024), 16, off, chunk * (BK * 4), 0, 0);
     };
@@ -424,11 +450,18 @@ __global__ __launch_bounds__(NTHR, 2) void gr_split_kernel(const Launch L) {
     };
     // POOL: wave w brings 256 bytes of the tile's attention weights (rows r0 .. r0 + 63, pnq floats each: contiguous) and row w of
     // both samples' masked dout ([slot][8][256] in LDS; rows >= pnq and samples past the last one: outside the descriptor, zeros)
-    auto issue_pool = [&](int t) {
-      const uint32_t r0 = (uint32_t)(t - tile0) * BM, v0 = r0 / (uint32_t)pT;
+    auto issue_pool = [&](int w) {
+      const uint32_t r0 = vrow0(w), v0 = r0 / (uint32_t)pT;
       const uint32_t wb = 256u * (uint32_t)wave + 4u * (uint32_t)lane;
       const uint32_t woff = wb < (uint32_t)(BM * pnq * 4) ? r0 * (uint32_t)pnq * 4u + wb : SDUMC_GR_NULL_OFF;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rpw, (lds_void_t*)(bits_lds + wave * 256), 4, woff, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rpw, (lds_void_t*)(pw_lds + wave * 256), 4, woff, 0, 0, 0);
+      if constexpr (FOLD) {      // the keep-bits of the unit's 64 rows (all-zero rows past the end; unused without c_bits)
+        // (the uniform part of the address in the scalar offset: no lane-dependent offset register lives across the stages)
+        const uint32_t bs = cmask ? (r0 + 8u * (uint32_t)wave) * QW : SDUMC_GR_NULL_OFF;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbits, (lds_void_t*)(cb_lds + wave * 512), 4, 4u * (uint32_t)lane, bs, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbits, (lds_void_t*)(cb_lds + wave * 512 + 256), 4, 4u * (uint32_t)lane, bs + 256u, 0, 0);      // (an immediate offset would move the LDS address too)
+        return;
+      }
 #pragma unroll
       for (int slot = 0; slot < 2; ++slot) {
         const uint32_t goff = wave < pnq ? ((v0 + slot) * (uint32_t)pnq + (uint32_t)wave) * (DN * 4u) + 16u * (uint32_t)lane : SDUMC_GR_NULL_OFF;
@@ -491,9 +524,11 @@ __global__ __launch_bounds__(NTHR, 2) void gr_split_kernel(const Launch L) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
     int par = 0;
+    int w = (u - tile0) * fold;                    // this workgroup's units of the problem: [w, w_end)
+    const int w_end = (ub - tile0) * fold;
     {
-      const uint32_t o = a_off(u);
-      if constexpr (MASK) issue_bits(bits_off(u), 0);
+      const uint32_t o = a_off(w);
+      if constexpr (MASK) issue_bits(bits_off(w), 0);
 #pragma unroll
       for (int s = 0; s < PF2; ++s) issue_a(o, s);
     }
@@ -506,12 +541,15 @@ __global__ __launch_bounds__(NTHR, 2) void gr_split_kernel(const Launch L) {
 
     // ---- steady state: 8 stages per tile, one barrier per stage ----
 #pragma nounroll
-    for (; u < ub; ++u) {
-      const uint32_t o_cur = a_off(u);
-      const uint32_t o_nxt = u + 1 < ub ? a_off(u + 1) : SDUMC_GR_NULL_OFF;
-      const uint32_t b_nxt = u + 1 < ub ? bits_off(u + 1) : SDUMC_GR_NULL_OFF;
-      const uint32_t c_off = (uint32_t)((u - tile0) * BM + 4 * lh) * ldc4 + (uint32_t)(n0 + li) * 4u;
-      const uint32_t c_row0 = (uint32_t)((u - tile0) * BM + 8 * wave) * ldc4 + 16u * (uint32_t)lane;
+    for (; w < w_end; ++w) {
+      const uint32_t o_cur = a_off(w);
+      const uint32_t o_nxt = w + 1 < w_end ? a_off(w + 1) : SDUMC_GR_NULL_OFF;
+      const uint32_t b_nxt = w + 1 < w_end ? bits_off(w + 1) : SDUMC_GR_NULL_OFF;
+      const int to = tile_of(w);
+      const bool first = blk_of(w) == 0, last = blk_of(w) == fold - 1;      // FOLD: the unit opens / closes its output tile
+      const uint32_t c_off = (uint32_t)(to * BM + 4 * lh) * ldc4 + (uint32_t)(n0 + li) * 4u;
+      const uint32_t c_row0 = (uint32_t)(to * BM + 8 * wave) * ldc4 + 16u * (uint32_t)lane;
+      float gq[8];      // FOLD: this lane's masked dout values G[v0 + lh][j][n0 + li] (issue point 5)
       auto stage = [&](auto sc) {
         constexpr int s = decltype(sc)::value;
         // raw stage s + 1 (published by the previous barrier) -> the other planes buffer; stage 8 = the next tile's first
@@ -535,20 +573,34 @@ __global__ __launch_bounds__(NTHR, 2) void gr_split_kernel(const Launch L) {
         __builtin_amdgcn_sched_barrier(0);
         mma6(1, a1, bh1);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(waitcnt_vm(sp::younger<MASK, ACC, POOL>(s)));
+        __builtin_amdgcn_s_waitcnt(waitcnt_vm(sp::younger<MASK, ACC, POOL, FOLD>(s)));
         __builtin_amdgcn_s_barrier();
         if constexpr (MASK) {
           if constexpr (s == T_BITS2) issue_bits(b_nxt, par ^ 1);
         }
         issue_a(s + PF2 < NS ? o_cur : o_nxt, (s + PF2) % NS);
         if constexpr (POOL) {
-          if constexpr (s == T_P2) issue_pool(u);
+          if constexpr (s == T_P2) issue_pool(w);
+        }
+        if constexpr (FOLD) {
+          if constexpr (s == T_G2) {
+            const uint32_t v0 = vrow0(w) / (uint32_t)pT;
+            const uint32_t gv = (uint32_t)lh * (uint32_t)pnq * (DN * 4u) + (uint32_t)(n0 + li) * 4u;
+#pragma unroll
+            for (int j = 0; j < G_OPS; ++j)
+              gq[j] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rpg, gv, j < pnq ? (v0 * (uint32_t)pnq + (uint32_t)j) * (DN * 4u) : SDUMC_GR_NULL_OFF, 0));
+            gq[7] = 0.f;
+          }
         }
         if constexpr (ACC) {
           if constexpr (s == T_C2) {   // this wave's rows 8 wave .. + 7 of the C tile (rows past M: outside the descriptor, zeros)
+            // (FOLD: only the unit that opens the tile fetches it; the others send their eight loads, from nowhere, to a dummy row --
+            //  the queue of every unit holds the same operations)
+            const bool real = !FOLD || first;
 #pragma unroll
             for (int j = 0; j < C_OPS; ++j)
-              __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, (lds_void_t*)(c_lds + (8 * wave + j) * (DN * 4)), 16, c_row0 + (uint32_t)j * ldc4, 0, 0, 0);
+              __builtin_amdgcn_raw_ptr_buffer_load_lds(rc, (lds_void_t*)(c_lds + (real ? (8 * wave + j) * (DN * 4) : C_TILE + POOL_W + BITS_TILE)), 16,
+                                                       real ? c_row0 + (uint32_t)j * ldc4 : SDUMC_GR_NULL_OFF, 0, 0, 0);
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -562,15 +614,15 @@ __global__ __launch_bounds__(NTHR, 2) void gr_split_kernel(const Launch L) {
       stage(std::integral_constant<int, 6>{});
       stage(std::integral_constant<int, 7>{});
       if constexpr (POOL) {      // the extra k-tile: k = 8 slot + j  <->  (sample v0 + slot, query j); a row multiplies its own sample's slot only
-        const uint32_t r0 = (uint32_t)(u - tile0) * BM, v0 = r0 / (uint32_t)pT;
+        const uint32_t r0 = vrow0(w), v0 = r0 / (uint32_t)pT;
         const int rb = (int)((v0 + 1u) * (uint32_t)pT - r0);                 // first row of the tile that belongs to sample v0 + 1
-        const float* wl = reinterpret_cast<const float*>(bits_lds);
+        const float* wl = reinterpret_cast<const float*>(pw_lds);
         const float* gl = reinterpret_cast<const float*>(bits_lds + POOL_W) + lh * (8 * DN) + n0 + li;
         Parts pb_, pa_;
         {
           float g[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) g[j] = gl[j * DN];
+          for (int j = 0; j < 8; ++j) g[j] = FOLD ? gq[j] : gl[j * DN];
 #pragma unroll
           for (int d = 0; d < 4; ++d) {
             uint32_t q0, q1, q2;
@@ -594,7 +646,40 @@ __global__ __launch_bounds__(NTHR, 2) void gr_split_kernel(const Launch L) {
           mma6(i, pa_, pb_);
         }
       }
+      if constexpr (FOLD) {      // keep . (A B + pooling term) * scale, summed over the tile's row blocks in LDS; the closing unit stores
+        // (one lane-dependent base per array, the element's row as an immediate offset; the uniform conditions select one of eight
+        //  straight-line bodies -- per-element address registers spilled, and a spill reload waits for the whole load queue)
+        const uint8_t* cb = reinterpret_cast<const uint8_t*>(cb_lds) + 8 * wave + (li >> 2) + 4 * lh * QW;
+        char* cl = c_lds + (4 * lh) * (DN * 4) + (n0 + li) * 4;
+        const uint32_t sh = (uint32_t)(li & 3);
+        auto body = [&](auto cm, auto ap, auto la) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+              const int rc_ = 32 * i + (e & 3) + 8 * (e >> 2);      // the element's row without the lane's 4 lh
+              float v = acc[i][e];
+              if constexpr (decltype(cm)::value) v = ((cb[rc_ * QW] >> sh) & 1u) ? v * cscale : 0.f;
+              float* slot = reinterpret_cast<float*>(cl + rc_ * (DN * 4));
+              if constexpr (decltype(ap)::value) v += *slot;
+              if constexpr (decltype(la)::value) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, c_off, rc_ * ldc4, 0);
+              else *slot = v;
+              acc[i][e] = 0.f;
+            }
+        };
+        const bool ap = ACC || !first;
+        using T_ = std::true_type;
+        using F_ = std::false_type;
+        if (cmask) {
+          if (ap) { if (last) body(T_{}, T_{}, T_{}); else body(T_{}, T_{}, F_{}); }
+          else { if (last) body(T_{}, F_{}, T_{}); else body(T_{}, F_{}, F_{}); }
+        } else {
+          if (ap) { if (last) body(F_{}, T_{}, T_{}); else body(F_{}, T_{}, F_{}); }
+          else { if (last) body(F_{}, F_{}, T_{}); else body(F_{}, F_{}, F_{}); }
+        }
+      }
       auto epilogue = [&](auto tanh_c) {
+        if constexpr (FOLD) return;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -613,6 +698,7 @@ __global__ __launch_bounds__(NTHR, 2) void gr_split_kernel(const Launch L) {
       __builtin_amdgcn_sched_barrier(0);
       par ^= 1;
     }
+    u = ub;
     __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
     __builtin_amdgcn_s_barrier();
   }
@@ -835,6 +921,9 @@ bool set_lds_attr() {   // the dynamic-LDS limit is a per-device function attrib
                           reinterpret_cast<const void*>(&gr_split_kernel<false, true>), reinterpret_cast<const void*>(&gr_split_kernel<false, false, true>)};
     for (const void* k : ks2)
       if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, sp::LDS_BYTES2) != hipSuccess) return false;
+    const void* ks3[2] = {reinterpret_cast<const void*>(&gr_split_kernel<false, false, true, true>), reinterpret_cast<const void*>(&gr_split_kernel<false, true, true, true>)};
+    for (const void* k : ks3)
+      if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, sp::LDS_FOLD) != hipSuccess) return false;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gr_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, RING) != hipSuccess) return false;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gr_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, RING) != hipSuccess) return false;
     done[dev] = true;
@@ -870,7 +959,9 @@ extern "C" int sdumc_gemm_rows256_capped_(const sdumc_rows_problem* probs, int32
   if (!probs || n <= 0 || n > MAXP) return SDUMC_EINVAL;
   const bool mask = probs[0].a_bits != nullptr, accum = probs[0].accumulate != 0, pool = probs[0].pool_w != nullptr;
   if (mask && accum) return SDUMC_EINVAL;
-  if (pool && (mask || accum || !sdumc_split_on_(SDUMC_SPLIT_ROWS))) return SDUMC_EINVAL;      // (the pooling k-tile: split arithmetic only)
+  const bool fold = probs[0].fold > 0;
+  if (pool && (mask || (accum && !fold) || !sdumc_split_on_(SDUMC_SPLIT_ROWS))) return SDUMC_EINVAL;      // (the pooling k-tile: split arithmetic only)
+  if (fold && !pool) return SDUMC_EINVAL;
   Launch L;
   memset(&L, 0, sizeof(L));
   int units = 0;
@@ -883,9 +974,14 @@ extern "C" int sdumc_gemm_rows256_capped_(const sdumc_rows_problem* probs, int32
       if (!q.pool_g || q.pool_nq < 1 || q.pool_nq > 8 || !(q.pool_T >= 63 || q.pool_T == 32) || (q.M % q.pool_T) || q.a_row_mod || q.bias || q.act != SDUMC_ACT_NONE) return SDUMC_EINVAL;
       if ((reinterpret_cast<uintptr_t>(q.pool_w) & 3) || (reinterpret_cast<uintptr_t>(q.pool_g) & 15)) return SDUMC_EINVAL;
     }
+    if ((probs[i].fold > 0) != fold) return SDUMC_EINVAL;
+    if (fold) {
+      const sdumc_rows_problem& q = probs[i];
+      if (q.fold > 2 || q.pool_nq > 7 || (q.M % q.fold) || ((q.M / q.fold) % q.pool_T) || (reinterpret_cast<uintptr_t>(q.c_bits) & 3)) return SDUMC_EINVAL;
+    }
     L.p[i] = probs[i];
     L.unit0[i] = units;
-    units += (probs[i].M + BM - 1) / BM;
+    units += ((fold ? probs[i].M / probs[i].fold : probs[i].M) + BM - 1) / BM;      // (fold: a unit of the launch = an OUTPUT tile)
     flops += 2.0 * probs[i].M * (double)DK * DN;
   }
   L.unit0[n] = units;
@@ -897,7 +993,9 @@ extern "C" int sdumc_gemm_rows256_capped_(const sdumc_rows_problem* probs, int32
   hipStream_t st = as_stream(stream);
   const int tok = sdumc_prof_begin_(sdumc_split_on_(SDUMC_SPLIT_ROWS) ? 25 : 21, flops, stream);
   if (sdumc_split_on_(SDUMC_SPLIT_ROWS)) {
-    if (pool) hipLaunchKernelGGL((gr_split_kernel<false, false, true>), dim3(L.nwg), dim3(NTHR), sp::LDS_BYTES2, st, L);
+    if (fold && accum) hipLaunchKernelGGL((gr_split_kernel<false, true, true, true>), dim3(L.nwg), dim3(NTHR), sp::LDS_FOLD, st, L);
+    else if (fold) hipLaunchKernelGGL((gr_split_kernel<false, false, true, true>), dim3(L.nwg), dim3(NTHR), sp::LDS_FOLD, st, L);
+    else if (pool) hipLaunchKernelGGL((gr_split_kernel<false, false, true>), dim3(L.nwg), dim3(NTHR), sp::LDS_BYTES2, st, L);
     else if (mask) hipLaunchKernelGGL((gr_split_kernel<true, false>), dim3(L.nwg), dim3(NTHR), sp::LDS_BYTES2, st, L);
     else if (accum) hipLaunchKernelGGL((gr_split_kernel<false, true>), dim3(L.nwg), dim3(NTHR), sp::LDS_BYTES2, st, L);
     else hipLaunchKernelGGL((gr_split_kernel<false, false>), dim3(L.nwg), dim3(NTHR), sp::LDS_BYTES2, st, L);

@@ -252,6 +252,8 @@ def gemm_rows256(problems):
         if q.get("pool_w") is not None:      # + sum_i pool_w[r, i] * pool_g[r // pool_T, i, :]  (sdumc_rows_problem.pool_*)
             pw, pg = q["pool_w"], q["pool_g"]
             g.pool_w, g.pool_g, g.pool_nq, g.pool_T = ptr(pw), ptr(pg), pw.shape[1], q["pool_T"]
+            if q.get("fold"):                # the mask-sum over `fold` row blocks folded in (sdumc_rows_problem.fold)
+                g.fold, g.c_bits, g.c_scale = q["fold"], ptr(q.get("c_bits")), q.get("c_scale", 1.0)
     hf = problems[0]["A"].dtype == torch.bfloat16
     check((lib.sdumc_gemm_rows256_bf16 if hf else lib.sdumc_gemm_rows256)(arr, n, _st()), "sdumc_gemm_rows256")
     return [q["C"] for q in problems]

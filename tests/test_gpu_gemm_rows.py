@@ -149,6 +149,48 @@ def test_pooling_term_as_an_extra_k_tile(ops):
     run_pool(ops, [(128, 375, 7), (128, 225, 7)], seed=24)      # the C2 audio and video sites
 
 
+def run_fold(ops, specs, seed, accumulate=False, masked=True):
+    """C[r] (+)= sum_s keep_s[r] . (A[s R + r] B + pooling term) * scale: the mask-sum of the input dropouts folded into the launch."""
+    g = torch.Generator().manual_seed(seed)
+    probs, refs = [], []
+    for (fold, Bn, T, nq) in specs:
+        R, V = Bn * T, fold * Bn
+        M = fold * R
+        A, B = (torch.randn(M, 256, generator=g) * 0.5).cuda(), (torch.randn(256, 256, generator=g) / 16).cuda()
+        pw = torch.softmax(torch.randn(V, T, nq, generator=g), dim=1).reshape(M, nq).contiguous().cuda()
+        pg = (torch.randn(V, nq, 256, generator=g) * (torch.rand(V, nq, 256, generator=g) > 0.3)).cuda()
+        bits, mask = keep_bits(M, g)
+        C0 = torch.randn(R, 256, generator=g).cuda()
+        q = {"A": A, "B": B, "pool_w": pw, "pool_g": pg, "pool_T": T, "fold": fold, "C": C0.clone(), "accumulate": accumulate}
+        if masked:
+            q["c_bits"], q["c_scale"] = bits.cuda(), 2.0
+        probs.append(q)
+        dxd = (A.double().cpu() @ B.double().cpu()
+               + torch.einsum("vti,vic->vtc", pw.double().cpu().view(V, T, nq), pg.double().cpu()).reshape(M, 256))
+        if masked:
+            dxd = dxd * mask * 2.0
+        refs.append(dxd.view(fold, R, 256).sum(0) + (C0.double().cpu() if accumulate else 0.0))
+    out = [c.clone() for c in ops.gemm_rows256(probs)]
+    for got, ref, sp in zip(out, refs, specs):
+        assert got.shape == ref.shape
+        close(got, ref, msg=str(sp))
+    return out
+
+
+def test_mask_sum_folded_into_the_launch(ops):
+    """Two streams over shared frames (fold 2), separate frames (fold 1); with and without keep-bits; onto an existing C; ragged tiles;
+    bit-identical repeats."""
+    a = run_fold(ops, [(2, 5, 375, 7)], seed=31)
+    b = run_fold(ops, [(2, 5, 375, 7)], seed=31)
+    assert torch.equal(a[0], b[0])
+    run_fold(ops, [(2, 6, 225, 1)], seed=32, accumulate=True)
+    run_fold(ops, [(1, 9, 32, 7), (1, 9, 32, 7)], seed=33)
+    run_fold(ops, [(1, 7, 63, 1), (2, 3, 100, 7)], seed=34, accumulate=True)
+    run_fold(ops, [(2, 4, 375, 7)], seed=35, masked=False)
+    run_fold(ops, [(2, 64, 375, 7)], seed=36)                       # the C2 audio Cross_Attention site
+    run_fold(ops, [(2, 64, 225, 1)], seed=37, accumulate=True)      # the C2 video FRA2UTT site onto it
+
+
 def test_pooling_term_refuses_what_it_cannot_tile(ops):
     from sdumc_amd._lib import SdumcError
     A, B = torch.zeros(100, 256).cuda(), torch.zeros(256, 256).cuda()
