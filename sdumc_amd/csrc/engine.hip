@@ -1878,11 +1878,10 @@ int keys_dx_rows(const Ctx& c, int m, int k0, int k1, sdumc_rows_problem* q) {
 
 // dxsum: dx of modality m (+)= sum over the streams of keep . (dz W + pooling term) of site k, one rows launch (the Cross_Attention
 // site of a modality always runs first and writes, the FRA2UTT site adds onto it)
-int keys_dx_sum(const Ctx& c, int m, int k, int rows_cap) {
+int keys_dx_sum_problems(const Ctx& c, int m, int k, sdumc_rows_problem* q) {
   const Plan& pl = c.pl;
   const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
   const int nq = k == 0 ? 1 : NQ;
-  sdumc_rows_problem q[4];
   int n = 0;
   for (const Seg& sg : pl.segs[m]) {
     sdumc_rows_problem& r = q[n++];
@@ -1902,6 +1901,11 @@ int keys_dx_sum(const Ctx& c, int m, int k, int rows_cap) {
     const sdumc_dropout dr = in_drop(c, k, m, sg.T, sg.s0, sg.row0);
     if (dr.enabled) { r.c_bits = dr.bits; r.c_scale = dr.scale; }
   }
+  return n;
+}
+int keys_dx_sum(const Ctx& c, int m, int k, int rows_cap) {
+  sdumc_rows_problem q[4];
+  const int n = keys_dx_sum_problems(c, m, k, q);
   return sdumc_gemm_rows256_capped_(q, n, rows_cap > 0 ? rows_cap : 0, c.st);
 }
 
@@ -1980,7 +1984,10 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   for (int m = 0; m < 3; ++m)
     if (phases != 3 && (c.bgb & (1 << m)) && c.multi && LANE_OF[m] != 0) own_lane |= 1 << m;
   // (in a single call the lane-3 route measured 0.15 % faster than the own-lane route; phased calls gain 0.6 % from the latter)
-  const int bgb = phases == 3 ? c.bgb : own_lane;
+  // (dxsum: audio's AND video's Cross_Attention sites go early, in one launch -- each site is a launch of its own there, the first of
+  //  a modality writes dx, and two of them back to back on video's lane made it the longest: 1.2917-1.2925 ms against 1.307-1.308
+  //  with audio's alone, 1.2946-1.2986 with all three)
+  const int bgb = phases == 3 ? ((c.bgb && dxsum(c)) ? 5 : c.bgb) : own_lane;
   // grouped mode: the dW of the Cross_Attention input_proj layers rides in the launch right behind the (grouped) pooling backward
   // of phase 0 (bit m of ca_dw_mask), the dW of the FRA2UTT ones in the launch behind the FRA2UTT pooling backward of phase 1
   const bool ca_dw_grouped = ggf && attn_multi_ok(c);
@@ -2004,6 +2011,20 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   };
   // the early key-projection backward of the Cross_Attention sites (bit m of bgb), ordered after what lane 0 has issued so far
   auto early_keys = [&]() -> int {
+    constexpr int ecap = 160;      // (workgroups of the merged early launch: 160 1.3266-1.3297 ms, 128 1.3304-1.3345, 96 1.3645-1.3712, 200 / 256 +1.5 %)
+    if (dxsum(c) && !own_lane && bgb && !(bgb & ~ca_dw_mask)) {      // the early Cross_Attention sites of every early modality: ONE rows launch on lane 3
+      sdumc_rows_problem q[8];
+      int n = 0;
+      for (int m = 0; m < 3; ++m)
+        if (bgb & (1 << m)) n += keys_dx_sum_problems(c, m, 1, q + n);
+      RET(link(c, 0, 3));
+      c.use(3);
+      RET(sdumc_gemm_rows256_capped_(q, n, ecap, c.st));
+      for (int m = 0; m < 3; ++m)
+        if (bgb & (1 << m)) RET(record_early(m));
+      c.use(0);
+      return SDUMC_OK;
+    }
     for (int m = 0; m < 3; ++m) {
       if (!(bgb & (1 << m))) continue;
       const int lane = (own_lane & (1 << m)) ? LANE_OF[m] : 3;

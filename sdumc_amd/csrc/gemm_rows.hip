@@ -656,15 +656,27 @@ __global__ __launch_bounds__(NTHR, 2) void gr_split_kernel(const Launch L) {
 #pragma unroll
           for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-              const int rc_ = 32 * i + (e & 3) + 8 * (e >> 2);      // the element's row without the lane's 4 lh
-              float v = acc[i][e];
-              if constexpr (decltype(cm)::value) v = ((cb[rc_ * QW] >> sh) & 1u) ? v * cscale : 0.f;
-              float* slot = reinterpret_cast<float*>(cl + rc_ * (DN * 4));
-              if constexpr (decltype(ap)::value) v += *slot;
-              if constexpr (decltype(la)::value) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, c_off, rc_ * ldc4, 0);
-              else *slot = v;
-              acc[i][e] = 0.f;
+            for (int eb = 0; eb < 16; eb += 8) {      // eight elements at a time: their LDS reads first, in one batch (element by element they serialise)
+              uint32_t kb[8];
+              float pv[8];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const int e = eb + q, rc_ = 32 * i + (e & 3) + 8 * (e >> 2);      // the element's row without the lane's 4 lh
+                if constexpr (decltype(cm)::value) kb[q] = cb[rc_ * QW];
+                if constexpr (decltype(ap)::value) pv[q] = *reinterpret_cast<const float*>(cl + rc_ * (DN * 4));
+              }
+              __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const int e = eb + q, rc_ = 32 * i + (e & 3) + 8 * (e >> 2);
+                float v = acc[i][e];
+                if constexpr (decltype(cm)::value) v = ((kb[q] >> sh) & 1u) ? v * cscale : 0.f;
+                if constexpr (decltype(ap)::value) v += pv[q];
+                if constexpr (decltype(la)::value) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, c_off, rc_ * ldc4, 0);
+                else *reinterpret_cast<float*>(cl + rc_ * (DN * 4)) = v;
+                acc[i][e] = 0.f;
+              }
+              __builtin_amdgcn_sched_barrier(0);
             }
         };
         const bool ap = ACC || !first;
