@@ -321,7 +321,7 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
     }
   {
     // the rows launch adds the rank-nq pooling term as one more k-tile when a 64-row tile spans at most two samples (sdumc_rows_problem)
-    bool ok = D == 256 && d.bf16 == 0;
+    bool ok = D == 256 && (d.bf16 == 0 || p.hf);
     for (int m = 0; m < 3; ++m)
       for (const Seg& sg : p.segs[m]) ok = ok && (sg.T >= 63 || sg.T == 32) && (int64_t)sg.V * sg.T * D * 4 < 0x7FFF0000LL;
     p.dxfold = ok;
@@ -723,15 +723,17 @@ bool rows_ok(const Ctx& c) { return D == 256 && !c.h() && c.d.bf16 == 0; }
 // ... and the mask-sum of the input dropouts as well: every site's launch adds keep . dxd of its streams straight into dx (the
 // Cross_Attention site writes, the FRA2UTT site adds onto it) -- dxd is never in memory and there is no mask-sum launch.
 // SDUMC_DXFOLD=1: the pooling term only.
-bool dxfold(const Ctx& c);
-bool dxsum(const Ctx& c) {
+// bf16 storage: the same through gr_bf16_kernel's folding variants (no pooling-term-only form there).
+int dxfold_level() {
   static const int on = [] { const char* e = getenv("SDUMC_DXFOLD"); return e ? atoi(e) : 2; }();
-  return on >= 2 && dxfold(c);
+  return on;
 }
 bool dxfold(const Ctx& c) {
-  static const int on = [] { const char* e = getenv("SDUMC_DXFOLD"); return e ? atoi(e) : 2; }();
-  return on && c.pl.dxfold && rows_on() && rows_ok(c) && sdumc_split_on_(SDUMC_SPLIT_ROWS);
+  if (!c.pl.dxfold || !rows_on()) return false;
+  if (c.h()) return dxfold_level() >= 2;
+  return dxfold_level() >= 1 && rows_ok(c) && sdumc_split_on_(SDUMC_SPLIT_ROWS);
 }
+bool dxsum(const Ctx& c) { return dxfold_level() >= 2 && dxfold(c); }
 
 // one group of a queued TN descriptor as a problem of the grouped launch; false = the grouped kernel does not take it
 bool gg_from_gemm(const sdumc_gemm& g, int grp, sdumc_gg_problem& q) {
@@ -1747,6 +1749,7 @@ int pool_bwd(const Ctx& c, int k, int m, const float* dout_base /* [V, nq, D] */
 }
 
 // input_proj backward of the sites [k0, k1) of modality m (grouped when both): dW = dz^T drop(x) (+ db), dxd += dz W
+int keys_dx_sum(const Ctx& c, int m, int k, int rows_cap);
 // parts: bit 0 = dW (off every critical path: feeds only the gradient bucket), bit 1 = dX
 int keys_gemm_bwd_h(const Ctx& c, int m, int k0, int k1, int parts, int rows_cap = 0) {
   const Plan& pl = c.pl;
@@ -1770,6 +1773,10 @@ int keys_gemm_bwd_h(const Ctx& c, int m, int k0, int k1, int parts, int rows_cap
     }
   }
   if (!(parts & 2)) return SDUMC_OK;
+  if (dxsum(c)) {      // (site 1 first: it writes dx)
+    for (int k = k1 - 1; k >= k0; --k) RET(keys_dx_sum(c, m, k, rows_cap));
+    return SDUMC_OK;
+  }
   sdumc_gemm_bf16 g = GH_(SDUMC_NT, (int)pl.rows[m], D, D, k1 - k0);      // dxd += dz W: NT on the transposed weight copy
   for (int k = k0; k < k1; ++k) {
     const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
@@ -1890,6 +1897,11 @@ int keys_dx_sum_problems(const Ctx& c, int m, int k, sdumc_rows_problem* q) {
     r.A = c.p(pl.dz[k][m]) + sg.row0 * D;
     r.B = c.P + L.w;
     r.C = c.p(pl.dx[m][sg.s0]);
+    if (c.h()) {      // bf16 dz / dx; B = the transposed bf16 weight copy (its rows are the output columns)
+      r.A = reinterpret_cast<const float*>(c.ph(pl.dz[k][m], sg.row0 * D));
+      r.B = reinterpret_cast<const float*>(c.ph(pl.wht, L.w));
+      r.C = reinterpret_cast<float*>(c.ph(pl.dx[m][sg.s0]));
+    }
     r.M = sg.V * sg.T;
     r.lda = r.ldb = r.ldc = D;
     r.accumulate = k == 0 ? 1 : 0;
@@ -1903,10 +1915,13 @@ int keys_dx_sum_problems(const Ctx& c, int m, int k, sdumc_rows_problem* q) {
   }
   return n;
 }
+int dx_sum_launch(const Ctx& c, const sdumc_rows_problem* q, int n, int rows_cap) {
+  return c.h() ? sdumc_gemm_rows256_bf16_capped_(q, n, rows_cap > 0 ? rows_cap : 0, c.st) : sdumc_gemm_rows256_capped_(q, n, rows_cap > 0 ? rows_cap : 0, c.st);
+}
 int keys_dx_sum(const Ctx& c, int m, int k, int rows_cap) {
   sdumc_rows_problem q[4];
   const int n = keys_dx_sum_problems(c, m, k, q);
-  return sdumc_gemm_rows256_capped_(q, n, rows_cap > 0 ? rows_cap : 0, c.st);
+  return dx_sum_launch(c, q, n, rows_cap);
 }
 
 // rows_cap (fp32 dX through the persistent rows launch): > 0 = at most that many workgroups, < 0 = the tiled 64x64 kernel instead
@@ -2019,7 +2034,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
         if (bgb & (1 << m)) n += keys_dx_sum_problems(c, m, 1, q + n);
       RET(link(c, 0, 3));
       c.use(3);
-      RET(sdumc_gemm_rows256_capped_(q, n, ecap, c.st));
+      RET(dx_sum_launch(c, q, n, ecap));
       for (int m = 0; m < 3; ++m)
         if (bgb & (1 << m)) RET(record_early(m));
       c.use(0);

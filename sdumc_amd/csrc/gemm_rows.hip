@@ -730,15 +730,26 @@ namespace hf {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 #define SDUMC_GR_HNS 4                            /* stages per tile (64 k each) */
 constexpr int T_C0 = 1, T_C1 = 5;               // issue points (of the pair's 8) that carry the C prefetch of tile 0 / tile 1
-template <bool ACC>
-constexpr int ops_at(int t) { return 1 + ((ACC && (t == T_C0 || t == T_C1)) ? 32 : 0); }
-template <bool ACC>
+// FOLD (1 or 2 = sdumc_rows_problem.fold, one value per launch): the pooling term as one more k-tile (split arithmetic: its operands are
+// fp32) and the mask-sum of the input dropouts, as in gr_split_kernel.  A unit's operands -- 64 rows of attention weights (2 KB), the
+// masked dout rows of its <= 2 samples (16 KB), its keep-bits (4 KB) -- ride in by LDS-DMA six stages before the unit's last one:
+// at issue point 5 for the first unit of the NEXT pair, at issue point 1 for the second unit of this one (five instructions per
+// wave; one LDS buffer per unit of the pair).  FOLD = 2: the pair IS one output tile -- its first unit opens the running sum (the C
+// prefetch registers; with `accumulate` they start from C), its second closes and stores it: no C prefetch at issue point 5.
+constexpr int HP_OPS = 5;
+constexpr int HP_W = BM * 8 * 4, HP_G = 2 * 8 * DN * 4, HP_BUF = HP_W + HP_G + BITS_TILE;
+template <bool ACC, int FOLD = 0>
+constexpr int ops_at(int t) {
+  return 1 + ((ACC && (t == T_C0 || (t == T_C1 && FOLD != 2))) ? 32 : 0) + ((FOLD && (t == T_C0 || t == T_C1)) ? HP_OPS : 0);
+}
+template <bool ACC, int FOLD = 0>
 constexpr int younger(int s) {
   const int t0 = ((s + 1 - PF) % NS + NS) % NS;
-  int n = (ACC && (t0 == T_C0 || t0 == T_C1)) ? 32 : 0;
-  for (int t = 1; t < PF - 1; ++t) n += ops_at<ACC>((t0 + t) % NS);
+  int n = ops_at<ACC, FOLD>(t0) - 1;            // what followed the A piece at its own issue point
+  for (int t = 1; t < PF - 1; ++t) n += ops_at<ACC, FOLD>((t0 + t) % NS);
   return n;
 }
+static_assert(younger<false, 1>(0) == 4 + HP_OPS && younger<false, 2>(2) == 4 + 2 * HP_OPS && younger<true, 2>(2) == 4 + 2 * HP_OPS + 32, "bf16 fold");
 __device__ __forceinline__ float bf2f(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
 __device__ __forceinline__ unsigned short f2bf(float f) {
   __bf16 h = (__bf16)f;      // v_cvt_pk_bf16_f32: round to nearest even, NaN stays NaN
@@ -750,7 +761,7 @@ __device__ __forceinline__ unsigned short f2bf(float f) {
 static_assert(hf::younger<false>(0) == 4 && hf::younger<true>(0) == 36 && hf::younger<true>(1) == 36 && hf::younger<true>(2) == 68 &&
               hf::younger<true>(3) == 36 && hf::younger<true>(6) == 68 && hf::younger<true>(7) == 36, "bf16 pair: C prefetch at stages 1 and 5");
 
-template <bool ACC>
+template <bool ACC, int FOLD = 0>
 __global__ __launch_bounds__(NTHR, 2) void gr_bf16_kernel(const Launch L) {
 #if defined(__HIP_DEVICE_COMPILE__)
   using namespace hf;
@@ -779,7 +790,18 @@ __global__ __launch_bounds__(NTHR, 2) void gr_bf16_kernel(const Launch L) {
     const uint32_t lda2 = (uint32_t)pr.lda * 2u, ldc2 = (uint32_t)pr.ldc * 2u;
     const int a_rows = pr.a_row_mod > 0 ? pr.a_row_mod : pr.M;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.A), 0, (int)((uint32_t)a_rows * lda2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(pr.C, 0, (int)((uint32_t)pr.M * ldc2), 0x00020000);
+    // FOLD: unit w of the problem = (output tile w / FOLD, row block w % FOLD); R = rows of C = rows of one block
+    const int R = FOLD ? pr.M / FOLD : pr.M;
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(pr.C, 0, (int)((uint32_t)R * ldc2), 0x00020000);
+    const bool cmask = FOLD && pr.c_bits != nullptr;
+    const float cscale = cmask ? pr.c_scale : 1.f;
+    const int pnq = FOLD ? pr.pool_nq : 0, pT = FOLD ? pr.pool_T : 1;
+    const __amdgpu_buffer_rsrc_t rbits = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(cmask ? pr.c_bits : (const uint8_t*)pr.A), 0,
+                                                                           cmask ? (int)((uint32_t)pr.M * QW) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rpw = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(FOLD ? pr.pool_w : pr.A), 0,
+                                                                         FOLD ? (int)((uint32_t)pr.M * (uint32_t)pnq * 4u) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rpg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(FOLD ? pr.pool_g : pr.A), 0,
+                                                                         FOLD ? (int)((uint32_t)(pr.M / pT) * (uint32_t)pnq * (DN * 4u)) : 0, 0x00020000);
     // B: the MFMA operand of step j = 4 s + c is k = 64 s + 16 c + 8 lh .. + 7 of row n0 + li: one 16-byte load
     bf16x8 breg[16];
     {
@@ -796,15 +818,41 @@ __global__ __launch_bounds__(NTHR, 2) void gr_bf16_kernel(const Launch L) {
     const float bias = pr.bias ? pr.bias[n0 + li] : 0.f;
     const bool do_tanh = pr.act == SDUMC_ACT_TANH;
 
+    // (t: unit of the launch for FOLD = 0 -- a tile -- and unit of this problem for FOLD > 0; t_end: the end of this workgroup's run)
+    const int t_end = FOLD ? (ub - tile0) * FOLD : ub;
+    auto vrow0 = [&](int t) -> uint32_t {      // first (virtual) row of unit t
+      if constexpr (FOLD == 2) return (uint32_t)((t & 1) * R + (t >> 1) * BM);
+      else if constexpr (FOLD == 1) return (uint32_t)(t * BM);
+      else return (uint32_t)((t - tile0) * BM);
+    };
     auto a_off = [&](int t) -> uint32_t {      // tiles at and past the end of this workgroup's run of the problem: nothing
-      if (t >= ub) return SDUMC_GR_NULL_OFF;
-      int r = (t - tile0) * BM + dr;
+      if (t >= t_end) return SDUMC_GR_NULL_OFF;
+      int r = (int)vrow0(t) + dr;
       if (pr.a_row_mod > 0) r %= pr.a_row_mod;
       return (uint32_t)r * lda2 + dq16;
     };
     auto c_off_of = [&](int t) -> uint32_t {
-      if (t >= ub) return SDUMC_GR_NULL_OFF;
-      return (uint32_t)((t - tile0) * BM + 4 * lh) * ldc2 + (uint32_t)(n0 + li) * 2u;
+      if (t >= t_end) return SDUMC_GR_NULL_OFF;
+      const int row0 = FOLD == 2 ? (t >> 1) * BM : (FOLD == 1 ? t * BM : (t - tile0) * BM);
+      return (uint32_t)(row0 + 4 * lh) * ldc2 + (uint32_t)(n0 + li) * 2u;
+    };
+    // FOLD: the operands of unit t's extra k-tile and its keep-bits -> LDS buffer `buf` (past the run's end: from nowhere, zeros)
+    char* const pool_lds = lds + RING;
+    auto issue_pool = [&](int t, int buf) {
+      char* base = pool_lds + buf * HP_BUF;
+      const bool live = t < t_end;
+      const uint32_t r0 = live ? vrow0(t) : 0u, v0 = r0 / (uint32_t)pT;
+      const uint32_t wb = 256u * (uint32_t)wave + 4u * (uint32_t)lane;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rpw, (lds_void_t*)(base + wave * 256), 4,
+                                               (live && wb < (uint32_t)(BM * pnq * 4)) ? r0 * (uint32_t)pnq * 4u + wb : SDUMC_GR_NULL_OFF, 0, 0, 0);
+#pragma unroll
+      for (int slot = 0; slot < 2; ++slot)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rpg, (lds_void_t*)(base + HP_W + (slot * 8 + wave) * (DN * 4)), 16,
+                                                 (live && wave < pnq) ? ((v0 + slot) * (uint32_t)pnq + (uint32_t)wave) * (DN * 4u) + 16u * (uint32_t)lane : SDUMC_GR_NULL_OFF,
+                                                 0, 0, 0);
+      const uint32_t bo = (live && cmask) ? (r0 + 8u * (uint32_t)wave) * QW + 4u * (uint32_t)lane : SDUMC_GR_NULL_OFF;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rbits, (lds_void_t*)(base + HP_W + HP_G + wave * 512), 4, bo, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rbits, (lds_void_t*)(base + HP_W + HP_G + wave * 512 + 256), 4, bo, 256, 0, 0);
     };
     auto issue_a = [&](uint32_t off, int chunk, int slot) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(lds + slot * A_STAGE + wave * 1024), 16, off, chunk * 128, 0, 0);
@@ -831,10 +879,12 @@ __global__ __launch_bounds__(NTHR, 2) void gr_bf16_kernel(const Launch L) {
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+    int w = FOLD ? (u - tile0) * FOLD : u;      // the unit counter of the loop below
     {
-      const uint32_t o0 = a_off(u), o1 = a_off(u + 1);
+      const uint32_t o0 = a_off(w), o1 = a_off(w + 1);
 #pragma unroll
       for (int s = 0; s < PF; ++s) issue_a(s < SDUMC_GR_HNS ? o0 : o1, s % SDUMC_GR_HNS, s);
+      if constexpr (FOLD) issue_pool(w, 0);
     }
     __builtin_amdgcn_s_waitcnt(waitcnt_vm(0));
     __builtin_amdgcn_s_barrier();
@@ -842,10 +892,90 @@ __global__ __launch_bounds__(NTHR, 2) void gr_bf16_kernel(const Launch L) {
     read_frag(0, 0, fa);
 
 #pragma nounroll
-    for (; u < ub; u += 2) {
-      const uint32_t o[4] = {a_off(u), a_off(u + 1), a_off(u + 2), a_off(u + 3)};
-      const uint32_t co[2] = {c_off_of(u), c_off_of(u + 1)};
-      float cpre[ACC ? 32 : 1];
+    for (; w < t_end; w += 2) {
+      const uint32_t o[4] = {a_off(w), a_off(w + 1), a_off(w + 2), a_off(w + 3)};
+      const uint32_t co[2] = {c_off_of(w), c_off_of(w + 1)};
+      float cpre[(ACC || FOLD == 2) ? 32 : 1];
+      // FOLD: the extra k-tile of unit w + U (k = 8 slot + j  <->  sample v0 + slot, query j; a row multiplies its own sample's slot only),
+      // then keep . (...) * scale into the running sum / out to C
+      auto fold_tail = [&](auto uc) {
+        constexpr int U = decltype(uc)::value;
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+        typedef float f32x2s __attribute__((ext_vector_type(2)));
+        auto pk = [](float x, float y) -> uint32_t {
+          const f32x2s v = {x, y};
+          return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+        };
+        auto split8 = [&](const float (&x)[8], u32x4 (&pp)[3]) {
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const float a = x[2 * d], b = x[2 * d + 1];
+            const uint32_t p0 = pk(a, b);
+            const float a1 = a - __uint_as_float(p0 << 16), b1 = b - __uint_as_float(p0 & 0xFFFF0000u);
+            const uint32_t p1 = pk(a1, b1);
+            const float a2 = a1 - __uint_as_float(p1 << 16), b2 = b1 - __uint_as_float(p1 & 0xFFFF0000u);
+            pp[0][d] = p0; pp[1][d] = p1; pp[2][d] = pk(a2, b2);
+          }
+        };
+        auto opb = [](const u32x4& v) { return __builtin_bit_cast(bf16x8, v); };
+        const char* base = pool_lds + U * HP_BUF;
+        const uint32_t r0 = vrow0(w + U), v0 = r0 / (uint32_t)pT;
+        const int rb = (int)((v0 + 1u) * (uint32_t)pT - r0);                 // first row of the unit that belongs to sample v0 + 1
+        const float* wl = reinterpret_cast<const float*>(base);
+        const float* gl = reinterpret_cast<const float*>(base + HP_W) + lh * (8 * DN) + n0 + li;
+        u32x4 pb_[3], pa_[3];
+        {
+          float g[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) g[j] = gl[j * DN];
+          split8(g, pb_);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int row = 32 * i + li;
+          const bool mine = (row >= rb ? 1 : 0) == lh;
+          float x[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) x[j] = (mine && j < pnq) ? wl[row * pnq + j] : 0.f;
+          split8(x, pa_);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(opb(pa_[2]), opb(pb_[0]), acc[i], 0, 0, 0);      // smallest terms first
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(opb(pa_[0]), opb(pb_[2]), acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(opb(pa_[1]), opb(pb_[1]), acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(opb(pa_[1]), opb(pb_[0]), acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(opb(pa_[0]), opb(pb_[1]), acc[i], 0, 0, 0);
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(opb(pa_[0]), opb(pb_[0]), acc[i], 0, 0, 0);
+        }
+        const uint8_t* cb = reinterpret_cast<const uint8_t*>(base + HP_W + HP_G) + 8 * wave + (li >> 2) + 4 * lh * QW;
+        const uint32_t sh = (uint32_t)(li & 3);
+        const uint32_t c_off = co[U];
+        constexpr bool opens = FOLD == 1 || U == 0, closes = FOLD == 1 || U == 1;
+        auto run = [&](auto cm) {
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int eb = 0; eb < 16; eb += 8) {
+              uint32_t kb[8];
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const int e = eb + q;
+                if constexpr (decltype(cm)::value) kb[q] = cb[(32 * i + (e & 3) + 8 * (e >> 2)) * QW];
+              }
+#pragma unroll
+              for (int q = 0; q < 8; ++q) {
+                const int e = eb + q;
+                float v = acc[i][e];
+                if constexpr (decltype(cm)::value) v = ((kb[q] >> sh) & 1u) ? v * cscale : 0.f;
+                if constexpr (ACC || !opens) v += cpre[i * 16 + e];
+                if constexpr (closes) __builtin_amdgcn_raw_buffer_store_b16(f2bf(v), rc, c_off, (32 * i + (e & 3) + 8 * (e >> 2)) * ldc2, 0);
+                else cpre[i * 16 + e] = v;
+                acc[i][e] = 0.f;
+              }
+            }
+        };
+        if (cmask) run(std::true_type{});
+        else run(std::false_type{});
+      };
       auto epilogue = [&](uint32_t c_off, auto tanh_c) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -864,11 +994,11 @@ __global__ __launch_bounds__(NTHR, 2) void gr_bf16_kernel(const Launch L) {
         __builtin_amdgcn_sched_barrier(0);
         mma(fa, 0, s % SDUMC_GR_HNS);
         __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(waitcnt_vm(hf::younger<ACC>(s)));
+        __builtin_amdgcn_s_waitcnt(waitcnt_vm(hf::younger<ACC, FOLD>(s)));
         __builtin_amdgcn_s_barrier();
         issue_a(o[(s + PF) / SDUMC_GR_HNS], (s + PF) % SDUMC_GR_HNS, (s + PF) % NS);
         if constexpr (ACC) {
-          if constexpr (s == T_C0 || s == T_C1) {
+          if constexpr (s == T_C0 || (s == T_C1 && FOLD != 2)) {
             const uint32_t c_off = co[s == T_C0 ? 0 : 1];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -877,14 +1007,22 @@ __global__ __launch_bounds__(NTHR, 2) void gr_bf16_kernel(const Launch L) {
                 cpre[i * 16 + e] = bf2f(__builtin_amdgcn_raw_buffer_load_b16(rc, c_off, (32 * i + (e & 3) + 8 * (e >> 2)) * ldc2, 0));
           }
         }
+        if constexpr (FOLD != 0) {      // (behind the C prefetch; issue point 1: this pair's second unit, 5: the next pair's first)
+          if constexpr (s == T_C0) issue_pool(w + 1, 1);
+          if constexpr (s == T_C1) issue_pool(w + 2, 0);
+        }
         __builtin_amdgcn_sched_barrier(0);
         read_frag((s + 1) % NS, 0, fa);
         __builtin_amdgcn_sched_barrier(0);
         mma(fb, 1, s % SDUMC_GR_HNS);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (s % SDUMC_GR_HNS == SDUMC_GR_HNS - 1) {       // a tile is complete (the next one's stages are in flight behind its epilogue)
-          if (do_tanh) epilogue(co[s / SDUMC_GR_HNS], std::true_type{});
-          else epilogue(co[s / SDUMC_GR_HNS], std::false_type{});
+          if constexpr (FOLD != 0) {
+            fold_tail(std::integral_constant<int, s / SDUMC_GR_HNS>{});
+          } else {
+            if (do_tanh) epilogue(co[s / SDUMC_GR_HNS], std::true_type{});
+            else epilogue(co[s / SDUMC_GR_HNS], std::false_type{});
+          }
           __builtin_amdgcn_sched_barrier(0);
         }
       };
@@ -938,6 +1076,10 @@ bool set_lds_attr() {   // the dynamic-LDS limit is a per-device function attrib
       if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, sp::LDS_FOLD) != hipSuccess) return false;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gr_bf16_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, RING) != hipSuccess) return false;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gr_bf16_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, RING) != hipSuccess) return false;
+    const void* kf[4] = {reinterpret_cast<const void*>(&gr_bf16_kernel<false, 1>), reinterpret_cast<const void*>(&gr_bf16_kernel<true, 1>),
+                         reinterpret_cast<const void*>(&gr_bf16_kernel<false, 2>), reinterpret_cast<const void*>(&gr_bf16_kernel<true, 2>)};
+    for (const void* k : kf)
+      if (hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, RING + 2 * hf::HP_BUF) != hipSuccess) return false;
     done[dev] = true;
   }
   return true;
@@ -1027,6 +1169,7 @@ extern "C" int sdumc_gemm_rows256_bf16(const sdumc_rows_problem* probs, int32_t 
 extern "C" int sdumc_gemm_rows256_bf16_capped_(const sdumc_rows_problem* probs, int32_t n, int32_t max_wg, void* stream) {
   if (!probs || n <= 0 || n > MAXP) return SDUMC_EINVAL;
   const bool accum = probs[0].accumulate != 0;
+  const int fold = probs[0].fold;
   Launch L;
   memset(&L, 0, sizeof(L));
   int units = 0;
@@ -1040,10 +1183,16 @@ extern "C" int sdumc_gemm_rows256_bf16_capped_(const sdumc_rows_problem* probs, 
     if (p.act != SDUMC_ACT_NONE && p.act != SDUMC_ACT_TANH) return SDUMC_EINVAL;
     const size_t rows = (size_t)p.M + 4 * BM;
     if (rows * p.lda * 2 >= 0x7FFFFFF0u || rows * p.ldc * 2 >= 0x7FFFFFF0u) return SDUMC_EINVAL;
-    if ((p.accumulate != 0) != accum) return SDUMC_EINVAL;
+    if ((p.accumulate != 0) != accum || p.fold != fold) return SDUMC_EINVAL;
+    if (fold) {      // the pooling term and the mask-sum folded in (sdumc_rows_problem.fold; fp32 pool_w / pool_g, bf16 A / B / C)
+      if (fold > 2 || !p.pool_w || !p.pool_g || p.pool_nq < 1 || p.pool_nq > 7 || !(p.pool_T >= 63 || p.pool_T == 32) || (p.M % fold) ||
+          ((p.M / fold) % p.pool_T) || p.a_row_mod || p.bias || p.act != SDUMC_ACT_NONE)
+        return SDUMC_EINVAL;
+      if ((reinterpret_cast<uintptr_t>(p.pool_w) & 3) || (reinterpret_cast<uintptr_t>(p.pool_g) & 15) || (reinterpret_cast<uintptr_t>(p.c_bits) & 3)) return SDUMC_EINVAL;
+    } else if (p.pool_w) return SDUMC_EINVAL;      // (the pooling term alone: fp32 launches only)
     L.p[i] = p;
     L.unit0[i] = units;
-    units += (p.M + BM - 1) / BM;
+    units += ((fold ? p.M / fold : p.M) + BM - 1) / BM;      // (fold: a unit of the launch = an OUTPUT tile)
     flops += 2.0 * p.M * (double)DK * DN;
   }
   L.unit0[n] = units;
@@ -1054,7 +1203,12 @@ extern "C" int sdumc_gemm_rows256_bf16_capped_(const sdumc_rows_problem* probs, 
   if (!set_lds_attr()) return SDUMC_ELAUNCH;
   hipStream_t st = as_stream(stream);
   const int tok = sdumc_prof_begin_(22, flops, stream);
-  if (accum) hipLaunchKernelGGL((gr_bf16_kernel<true>), dim3(L.nwg), dim3(NTHR), RING, st, L);
+  const size_t lds_fold = RING + 2 * hf::HP_BUF;
+  if (fold == 2 && accum) hipLaunchKernelGGL((gr_bf16_kernel<true, 2>), dim3(L.nwg), dim3(NTHR), lds_fold, st, L);
+  else if (fold == 2) hipLaunchKernelGGL((gr_bf16_kernel<false, 2>), dim3(L.nwg), dim3(NTHR), lds_fold, st, L);
+  else if (fold == 1 && accum) hipLaunchKernelGGL((gr_bf16_kernel<true, 1>), dim3(L.nwg), dim3(NTHR), lds_fold, st, L);
+  else if (fold == 1) hipLaunchKernelGGL((gr_bf16_kernel<false, 1>), dim3(L.nwg), dim3(NTHR), lds_fold, st, L);
+  else if (accum) hipLaunchKernelGGL((gr_bf16_kernel<true>), dim3(L.nwg), dim3(NTHR), RING, st, L);
   else hipLaunchKernelGGL((gr_bf16_kernel<false>), dim3(L.nwg), dim3(NTHR), RING, st, L);
   sdumc_prof_end_(tok, stream);
   SDUMC_CHECK_LAUNCH();

@@ -191,6 +191,50 @@ def test_mask_sum_folded_into_the_launch(ops):
     run_fold(ops, [(2, 64, 225, 1)], seed=37, accumulate=True)      # the C2 video FRA2UTT site onto it
 
 
+def run_fold_bf16(ops, specs, seed, accumulate=False, masked=True):
+    """The same on bf16 storage: A (dz), B ([256 n][256 k]: C = A B^T) and C (dx) bf16, attention weights / masked dout fp32."""
+    g = torch.Generator().manual_seed(seed)
+    bf = torch.bfloat16
+    probs, refs = [], []
+    fold = specs[0][0]
+    for (f, Bn, T, nq) in specs:
+        assert f == fold
+        R, V = Bn * T, fold * Bn
+        M = fold * R
+        A, B = (torch.randn(M, 256, generator=g) * 0.5).to(bf).cuda(), (torch.randn(256, 256, generator=g) / 16).to(bf).cuda()
+        pw = torch.softmax(torch.randn(V, T, nq, generator=g), dim=1).reshape(M, nq).contiguous().cuda()
+        pg = (torch.randn(V, nq, 256, generator=g) * (torch.rand(V, nq, 256, generator=g) > 0.3)).cuda()
+        bits, mask = keep_bits(M, g)
+        C0 = torch.randn(R, 256, generator=g).to(bf).cuda()
+        q = {"A": A, "B": B, "pool_w": pw, "pool_g": pg, "pool_T": T, "fold": fold, "C": C0.clone(), "accumulate": accumulate}
+        if masked:
+            q["c_bits"], q["c_scale"] = bits.cuda(), 2.0
+        probs.append(q)
+        dxd = (A.double().cpu() @ B.double().cpu().t()
+               + torch.einsum("vti,vic->vtc", pw.double().cpu().view(V, T, nq), pg.double().cpu()).reshape(M, 256))
+        if masked:
+            dxd = dxd * mask * 2.0
+        refs.append(dxd.view(fold, R, 256).sum(0) + (C0.double().cpu() if accumulate else 0.0))
+    out = [c.clone() for c in ops.gemm_rows256(probs)]
+    for got, ref, sp in zip(out, refs, specs):
+        assert got.dtype == bf and got.shape == ref.shape
+        close(got, ref, tol=6e-3, msg=str(sp))      # (one bf16 rounding of the output)
+    return out
+
+
+def test_bf16_mask_sum_folded_into_the_launch(ops):
+    a = run_fold_bf16(ops, [(2, 5, 375, 7)], seed=41)
+    b = run_fold_bf16(ops, [(2, 5, 375, 7)], seed=41)
+    assert torch.equal(a[0], b[0])
+    run_fold_bf16(ops, [(2, 6, 225, 1)], seed=42, accumulate=True)
+    run_fold_bf16(ops, [(1, 9, 32, 7), (1, 9, 32, 7)], seed=43)
+    run_fold_bf16(ops, [(1, 7, 63, 1), (1, 3, 100, 7)], seed=44, accumulate=True)
+    run_fold_bf16(ops, [(2, 4, 375, 7), (2, 3, 70, 1)], seed=45, masked=False)
+    run_fold_bf16(ops, [(2, 64, 375, 7), (2, 64, 225, 7)], seed=46)      # the C2 audio and video Cross_Attention sites, one launch
+    run_fold_bf16(ops, [(2, 64, 225, 1)], seed=47, accumulate=True)
+    run_fold_bf16(ops, [(1, 128, 32, 1)], seed=48, accumulate=True)     # the C2 text slot
+
+
 def test_pooling_term_refuses_what_it_cannot_tile(ops):
     from sdumc_amd._lib import SdumcError
     A, B = torch.zeros(100, 256).cuda(), torch.zeros(256, 256).cuda()
