@@ -1326,15 +1326,16 @@ extern "C" int sdumc_chain_cluster_launch_(const sdumc_chain_args* ap, int which
 // A stream that is about to be destroyed (sdumc_ctx_destroy: the context's lanes) must not stay behind as "the stream of the last
 // clustered launch": the next launch would record its ordering event on a dead handle.  Waits for the stream's work and forgets it.
 // (Caller-owned streams: a caller that destroys the stream of its last step must have synchronised it -- include/sdumc_hip.h.)
+// (every device's record is searched: the context may be destroyed while another device is current)
 extern "C" int sdumc_chain_cluster_forget_stream_(void* stream) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return SDUMC_ELAUNCH;
-  ClusterDev& d = g_cl[dev];
-  std::lock_guard<std::mutex> lk(d.mu);
-  if (d.any && d.last == as_stream(stream)) {
-    if (hipStreamSynchronize(d.last) != hipSuccess) return SDUMC_ELAUNCH;
-    d.any = false;
-    d.last = nullptr;
+  for (int dev = 0; dev < 16; ++dev) {
+    ClusterDev& d = g_cl[dev];
+    std::lock_guard<std::mutex> lk(d.mu);
+    if (d.any && d.last == as_stream(stream)) {
+      if (hipStreamSynchronize(d.last) != hipSuccess) return SDUMC_ELAUNCH;
+      d.any = false;
+      d.last = nullptr;
+    }
   }
   return SDUMC_OK;
 }

@@ -977,11 +977,12 @@ sdumc_gemm_bf16 GH_(int layout, int M, int N, int K, int groups = 1) {
 }
 
 // bf16 storage: the NT products of the frame-level forward through gemm_b1.hip (the weight fragment-major, straight into registers).
-// SDUMC_B1=0: A/B against gemm_bf16.hip's LDS-staged tiles.
-bool b1_mode(const Ctx& c) {
-  static const int on = [] { const char* e = getenv("SDUMC_B1"); return e ? atoi(e) : 1; }();
-  return on && c.h() && c.pl.wb1 != 0;
+// SDUMC_P3=0 (the switch of "operands prepared once per tensor", shared with the fp32 planes path): A/B against gemm_bf16.hip's LDS-staged tiles.
+bool prepared_operands_on() {
+  static const int on = [] { const char* e = getenv("SDUMC_P3"); return e ? atoi(e) : 1; }();
+  return on != 0;
 }
+bool b1_mode(const Ctx& c) { return prepared_operands_on() && c.h() && c.pl.wb1 != 0; }
 char* wb1_ptr(const Ctx& c, int64_t byte_off) { return reinterpret_cast<char*>(c.p(c.pl.wb1)) + byte_off; }
 // modality m's three frame-level weights (frame_dim_reshape_m, the two input_proj) -> fragment-major bf16: one small launch at the head
 // of the modality's lane
@@ -1062,8 +1063,7 @@ int keys_gemm_fwd_h(const Ctx& c, int m, int k0, int k1) {
 // fp32 storage with the features also given as bf16 planes (sdumc_net_io.*_p3): the frame projections and the key projections that
 // go through the wide NT kernel run on operands split once per tensor (gemm_p3.hip).  SDUMC_P3=0: A/B against the in-kernel split.
 bool p3_mode(const Ctx& c) {
-  static const int on = [] { const char* e = getenv("SDUMC_P3"); return e ? atoi(e) : 1; }();
-  return on && c.d.bf16 == 0 && c.pl.wp3 != 0 && c.io.audio_p3 != nullptr && sdumc_split_on_(SDUMC_SPLIT_WIDE);
+  return prepared_operands_on() && c.d.bf16 == 0 && c.pl.wp3 != 0 && c.io.audio_p3 != nullptr && sdumc_split_on_(SDUMC_SPLIT_WIDE);
 }
 char* wp3_ptr(const Ctx& c, int64_t byte_off) { return reinterpret_cast<char*>(c.p(c.pl.wp3)) + byte_off; }
 // fragment-major planes of modality m's three frame-level weights (frame_dim_reshape_m, the two input_proj): one small launch at the
@@ -1145,12 +1145,11 @@ int keys_gemm_fwd(const Ctx& c, int m, int k0, int k1) {
 
 // softmax-over-time pooling of site (k, m) given its keys (and, for k = 1, the projected queries)
 // Sites (k, m = 0..2) in one launch on the current lane (sdumc_attnpool_fwd_multi / _bwd_multi); false = take the per-lane path
-// (SDUMC_ATTN_MULTI=0, or more than four runs).
+// (more than four runs).
 bool attn_multi_ok(const Ctx& c) {
-  static const int on = [] { const char* e = getenv("SDUMC_ATTN_MULTI"); return e ? atoi(e) : 1; }();
   size_t n = 0;
   for (int m = 0; m < 3; ++m) n += c.pl.segs[m].size();
-  return on && n <= 4;
+  return n <= 4;
 }
 
 bool fra_fold(const Ctx& c);                                        // (defined with the chain launch helpers below)

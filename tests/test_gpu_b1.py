@@ -85,7 +85,7 @@ def test_step_matches_the_lds_staged_kernels(ops, monkeypatch):
             "print(json.dumps([float(ts.run()[0]) for _ in range(3)]))") % root
     out = []
     for v in ("0", "1"):
-        env = dict(os.environ, SDUMC_B1=v)
+        env = dict(os.environ, SDUMC_P3=v)
         out.append(json.loads(subprocess.check_output([sys.executable, "-c", code], env=env, cwd=root).decode().strip().splitlines()[-1]))
     for a, b in zip(*out):
         assert abs(a - b) <= 1e-3 * abs(a), out

@@ -1,3 +1,4 @@
+import os
 """fp32 products on the bf16 matrix pipe (sdumc_hip.h: sdumc_set_split_; csrc/gemm_group.hip has the arithmetic).
 
 Every fp32 GEMM kernel of the frame-level part splits its operands exactly into three bf16 parts and accumulates six of the
@@ -32,7 +33,7 @@ def both(lib, run):
             out[mask] = [t.clone() for t in run()]
             torch.cuda.synchronize()
     finally:
-        lib.sdumc_set_split_(15)
+        lib.sdumc_set_split_(int(os.environ.get("SDUMC_SPLIT", 15)))
     return out[0], out[15]
 
 
@@ -175,7 +176,7 @@ def test_train_step_split_against_fp32_mfma(env):
             res[mask] = (losses, ts.grads.clone().cpu())
             del ts
     finally:
-        _lib.lib.sdumc_set_split_(15)
+        _lib.lib.sdumc_set_split_(int(os.environ.get("SDUMC_SPLIT", 15)))
     np.testing.assert_allclose(res[15][0].numpy(), res[0][0].numpy(), rtol=1e-5, atol=1e-6)
     worst = 0.0
     for k in lay.live_names():

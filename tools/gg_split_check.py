@@ -63,4 +63,4 @@ for name, mk in (("frame dW", GP.frame_problems), ("key dW, 6 sites (masked)", G
         e, ecs = res[split][0][1], res[split][0][2]
         print(f"{name:28s} {f / 1e9:7.2f} GF  {'split bf16 x6' if split else 'fp32 MFMA    '} {t:8.1f} us = {f / t / 1e6:6.1f} TF   "
               f"max |C - fp64| / max |C| {e:.2e}   column sums {ecs:.2e}", flush=True)
-_lib.lib.sdumc_set_split_(15)
+_lib.lib.sdumc_set_split_(int(os.environ.get("SDUMC_SPLIT", 15)))

@@ -45,7 +45,7 @@ def case(name, M, N, K, tile, tanh=False, drop=False, row_mod=0, splitk=0):
         t = min(r[0] for r in res[split])
         print(f"{name:28s} M={M:6d} K={K:5d} tile {tile} {'split bf16 x6' if split else 'fp32 MFMA    '} {t:7.1f} us = {fl / t / 1e6:6.1f} TF   "
               f"max |C - fp64| / max |C| {res[split][0][1]:.2e}", flush=True)
-    _lib.lib.sdumc_set_split_(15)
+    _lib.lib.sdumc_set_split_(int(os.environ.get("SDUMC_SPLIT", 15)))
 
 
 for t in (11, 12, 13):
