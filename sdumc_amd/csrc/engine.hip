@@ -2033,6 +2033,11 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
         if (bgb & (1 << m)) n += keys_dx_sum_problems(c, m, 1, q + n);
       RET(link(c, 0, 3));
       c.use(3);
+      bool one_fold = true;      // (a bf16 launch takes one fold: runs of shared and of separate frames go in separate launches there)
+      for (int i = 1; i < n; ++i) one_fold = one_fold && q[i].fold == q[0].fold;
+      if (c.h() && !one_fold) {
+        for (int i = 0; i < n; ++i) RET(dx_sum_launch(c, q + i, 1, ecap));
+      } else
       RET(dx_sum_launch(c, q, n, ecap));
       for (int m = 0; m < 3; ++m)
         if (bgb & (1 << m)) RET(record_early(m));
