@@ -37,6 +37,11 @@ def short(name):
     m = re.search(r"gemm_wide(_split)?_kernel<sdumc_wide::WideCfg<\d+, \d+, \d+, \d+, \d+, \d+, (true|false), (true|false)", name)
     if m:
         return "gemm_wide_" + ("nt" if m.group(2) == "true" else "tn") + ("_bf16x3" if m.group(1) else "")
+    m = re.search(r"gemm_p3_nt_kernel<sdumc_p3::PCfg<\d+, \d+, (true|false)", name)
+    if m:                                     # the names of bench.py's event variants (gemm_f32.hip kVariantName)
+        return "gemm_p3_nt_masked_bf16x3" if m.group(1) == "true" else "gemm_p3_nt_bf16x3"
+    if "gemm_b1_nt_kernel" in name:
+        return "gemm_b1_nt_bf16"
     if "gg_tn_kernel" in name:
         return "gemm_group_tn"
     name = re.sub(r"\(anonymous namespace\)::", "", name)
