@@ -201,7 +201,7 @@ struct Plan {
   // fp32 storage, features given as bf16 planes too (sdumc_net_io.*_p3; gemm_p3.hip): fragment-major planes of the frame-level weights
   // (refreshed at the head of each forward) and P3 copies of the projected frames (written by the frame projection's epilogue)
   int64_t dom[2][3] = {{0, 0, 0}, {0, 0, 0}};      // dout * out-dropout mask of attention site (k, m) ([V][nq][D]), written by its pooling backward (dxfold)
-  bool dxfold = false;                 // dxd = dz W + the pooling's own input gradient in ONE pass of the rows launch (no dxd write by the pooling backward)
+  bool dxfold[3] = {false, false, false};   // per modality: dxd = dz W + the pooling's own input gradient in ONE pass of the rows launch (no dxd write by the pooling backward)
   int64_t wb1 = 0;                     // bf16 storage: float offset of the fragment-major bf16 weights (wp3_frame / wp3_key: byte offsets inside it)
   int64_t wp3 = 0;                     // float offset of the weight-plane region
   int64_t wp3_frame[3] = {0, 0, 0};    // byte offsets inside it
@@ -321,13 +321,14 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
     }
   {
     // the rows launch adds the rank-nq pooling term as one more k-tile when a 64-row tile spans at most two samples (sdumc_rows_problem)
-    bool ok = D == 256 && (d.bf16 == 0 || p.hf);
-    for (int m = 0; m < 3; ++m)
+    // (decided per modality: a ragged epoch's text runs are often shorter than 63 frames, its audio / video runs hardly ever)
+    for (int m = 0; m < 3; ++m) {
+      bool ok = D == 256 && (d.bf16 == 0 || p.hf);
       for (const Seg& sg : p.segs[m]) ok = ok && (sg.T >= 63 || sg.T == 32) && (int64_t)sg.V * sg.T * D * 4 < 0x7FFF0000LL;
-    p.dxfold = ok;
-    if (ok)
-      for (int k = 0; k < 2; ++k)
-        for (int m = 0; m < 3; ++m) p.dom[k][m] = p.alloc((int64_t)V * (k == 0 ? 1 : NQ) * D);
+      p.dxfold[m] = ok;
+      if (ok)
+        for (int k = 0; k < 2; ++k) p.dom[k][m] = p.alloc((int64_t)V * (k == 0 ? 1 : NQ) * D);
+    }
   }
   p.dx[0][0] = p.dx[0][1] = p.alloc((int64_t)B * d.Ta * D / HS);
   p.dx[2][0] = p.dx[2][1] = p.alloc((int64_t)B * d.Tv * D / HS);
@@ -728,12 +729,12 @@ int dxfold_level() {
   static const int on = [] { const char* e = getenv("SDUMC_DXFOLD"); return e ? atoi(e) : 2; }();
   return on;
 }
-bool dxfold(const Ctx& c) {
-  if (!c.pl.dxfold || !rows_on()) return false;
+bool dxfold(const Ctx& c, int m) {
+  if (!c.pl.dxfold[m] || !rows_on()) return false;
   if (c.h()) return dxfold_level() >= 2;
   return dxfold_level() >= 1 && rows_ok(c) && sdumc_split_on_(SDUMC_SPLIT_ROWS);
 }
-bool dxsum(const Ctx& c) { return dxfold_level() >= 2 && dxfold(c); }
+bool dxsum(const Ctx& c, int m) { return dxfold_level() >= 2 && dxfold(c, m); }
 
 // one group of a queued TN descriptor as a problem of the grouped launch; false = the grouped kernel does not take it
 bool gg_from_gemm(const sdumc_gemm& g, int grp, sdumc_gg_problem& q) {
@@ -1737,7 +1738,7 @@ int pool_bwd(const Ctx& c, int k, int m, const float* dout_base /* [V, nq, D] */
       b.dz = reinterpret_cast<float*>(c.ph(pl.dz[k][m], sg.row0 * D));
       b.dxd = reinterpret_cast<float*>(c.ph(pl.dxd[k][m], sg.row0 * D));
     }
-    if (dxfold(c)) { b.dxd = nullptr; b.dout_masked = c.p(pl.dom[k][m]) + voff; }
+    if (dxfold(c, m)) { b.dxd = nullptr; b.dout_masked = c.p(pl.dom[k][m]) + voff; }
     b.dq = dq_base + voff;
     b.dq_sum = dq_sum;
     b.workspace = c.scr;
@@ -1772,7 +1773,7 @@ int keys_gemm_bwd_h(const Ctx& c, int m, int k0, int k1, int parts, int rows_cap
     }
   }
   if (!(parts & 2)) return SDUMC_OK;
-  if (dxsum(c)) {      // (site 1 first: it writes dx)
+  if (dxsum(c, m)) {      // (site 1 first: it writes dx)
     for (int k = k1 - 1; k >= k0; --k) RET(keys_dx_sum(c, m, k, rows_cap));
     return SDUMC_OK;
   }
@@ -1850,7 +1851,7 @@ void keys_dw_queue(const Ctx& c, int m, int k0, int k1) {
 // dxd += dz W of sites [k0, k1) of modality m as problems of a rows launch (dxfold: dxd = dz W + the pooling term, one problem per run)
 int keys_dx_rows(const Ctx& c, int m, int k0, int k1, sdumc_rows_problem* q) {
   int n = 0;
-  const bool fold = dxfold(c);
+  const bool fold = dxfold(c, m);
   for (int k = k0; k < k1; ++k) {
     const Lin& L = k == 0 ? c.pm.fra_proj[m] : c.pm.ca_in[m];
     if (fold) {
@@ -1952,16 +1953,16 @@ int keys_gemm_bwd(const Ctx& c, int m, int k0, int k1, int parts = 3, int rows_c
   }
   if (!(parts & 2)) return SDUMC_OK;
   // dxd += dz W (the key-projection path joins the pooling path)
-  if (dxsum(c)) {      // (site 1 first: it writes dx)
+  if (dxsum(c, m)) {      // (site 1 first: it writes dx)
     for (int k = k1 - 1; k >= k0; --k) RET(keys_dx_sum(c, m, k, rows_cap));
     return SDUMC_OK;
   }
-  if (dxfold(c) || (parts == 2 && rows_cap >= 0 && rows_on() && rows_ok(c))) {   // (the early dW + dX pair keeps the small-footprint kernels: it runs beside
+  if (dxfold(c, m) || (parts == 2 && rows_cap >= 0 && rows_on() && rows_ok(c))) {   // (the early dW + dX pair keeps the small-footprint kernels: it runs beside
                                                          //  the co-resident utterance-level stage, which a persistent launch would stall)
     sdumc_rows_problem q[8];
     const int n = keys_dx_rows(c, m, k0, k1, q);
     const int rc = sdumc_gemm_rows256_capped_(q, n, rows_cap > 0 ? rows_cap : 0, c.st);
-    if (rc != SDUMC_EINVAL || dxfold(c)) return rc;      // (a shape the rows launch refuses -- 2 GiB of rows -- takes the tiled kernel below;
+    if (rc != SDUMC_EINVAL || dxfold(c, m)) return rc;      // (a shape the rows launch refuses -- 2 GiB of rows -- takes the tiled kernel below;
                                                           //  dxfold: the plan checked the shapes, a refusal is an error -- nothing else wrote dxd)
   }
   sdumc_gemm g = G_(SDUMC_NN, (int)pl.rows[m], D, D, k1 - k0);
@@ -2001,7 +2002,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   // (dxsum: audio's AND video's Cross_Attention sites go early, in one launch -- each site is a launch of its own there, the first of
   //  a modality writes dx, and two of them back to back on video's lane made it the longest: 1.2917-1.2925 ms against 1.307-1.308
   //  with audio's alone, 1.2946-1.2986 with all three)
-  const int bgb = phases == 3 ? ((c.bgb && dxsum(c)) ? 5 : c.bgb) : own_lane;
+  const int bgb = phases == 3 ? ((c.bgb && dxsum(c, 0) && dxsum(c, 2)) ? 5 : c.bgb) : own_lane;
   // grouped mode: the dW of the Cross_Attention input_proj layers rides in the launch right behind the (grouped) pooling backward
   // of phase 0 (bit m of ca_dw_mask), the dW of the FRA2UTT ones in the launch behind the FRA2UTT pooling backward of phase 1
   const bool ca_dw_grouped = ggf && attn_multi_ok(c);
@@ -2026,7 +2027,9 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   // the early key-projection backward of the Cross_Attention sites (bit m of bgb), ordered after what lane 0 has issued so far
   auto early_keys = [&]() -> int {
     constexpr int ecap = 160;      // (workgroups of the merged early launch: 160 1.3266-1.3297 ms, 128 1.3304-1.3345, 96 1.3645-1.3712, 200 / 256 +1.5 %)
-    if (dxsum(c) && !own_lane && bgb && !(bgb & ~ca_dw_mask)) {      // the early Cross_Attention sites of every early modality: ONE rows launch on lane 3
+    bool all_sum = true;
+    for (int m = 0; m < 3; ++m) all_sum = all_sum && (!(bgb & (1 << m)) || dxsum(c, m));
+    if (all_sum && !own_lane && bgb && !(bgb & ~ca_dw_mask)) {      // the early Cross_Attention sites of every early modality: ONE rows launch on lane 3
       sdumc_rows_problem q[8];
       int n = 0;
       for (int m = 0; m < 3; ++m)
@@ -2140,7 +2143,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
           b.dz = c.p(pl.dz[1][m]) + sg.row0 * D;
           b.dxd = c.p(pl.dxd[1][m]) + sg.row0 * D;
         }
-        if (dxfold(c)) { b.dxd = nullptr; b.dout_masked = c.p(pl.dom[1][m]) + voff; }
+        if (dxfold(c, m)) { b.dxd = nullptr; b.dout_masked = c.p(pl.dom[1][m]) + voff; }
         const size_t bytes = sdumc_attnpool_bwd_workspace_bytes(sg.V, sg.T, NQ);
         b.workspace = ws;
         b.workspace_bytes = bytes;
@@ -2297,7 +2300,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
     RET(flush_dw(c));
     if (c.capturing) RET(fork_all(c));
   }
-  const bool sum_in_dx = dxsum(c);      // the rows launches add keep . dxd straight into dx: no mask-sum launch, and the FRA2UTT site's
+  const bool sum_in_dx_m[3] = {dxsum(c, 0), dxsum(c, 1), dxsum(c, 2)};      // the rows launches add keep . dxd straight into dx: no mask-sum launch, and the FRA2UTT site's
                                         // launch (which adds onto dx) has to follow the modality's early Cross_Attention one
   auto await_early = [&](int m) -> int {
     if (!(bgb & ~own_lane & (1 << m))) return SDUMC_OK;   // dxd of this modality's Cross_Attention site (issued early on lane 3)
@@ -2306,6 +2309,7 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
   };
   for (int m = 0; m < 3; ++m) {       // pass 2: dX of the key projections, the mask-sum, the frame projection's dW
     c.use(LANE_OF[m]);
+    const bool sum_in_dx = sum_in_dx_m[m];
     if (sum_in_dx) RET(await_early(m));
     {
       const int k1 = (bgb & (1 << m)) ? 1 : 2;
@@ -2797,6 +2801,15 @@ extern "C" int32_t sdumc_debug_plan_table(const sdumc_net_dims* d, char* buf, si
   put("c", p.c, 3 * V * NQ * H); put("h", p.h, V * NQ * H); put("e1", p.e1, V * D); put("e2", p.e2, V * H);
   put("beta", p.beta, V * NQ); put("z", p.z, V * H); put("vals", p.vals, V); put("r1", p.r1, V * RD); put("r", p.r, V * RD);
   put("wt", p.wt, build_params(d->da, d->dt, d->dv).early);
+  for (int m = 0; m < 3; ++m) {      // backward (train-mode steps): per site dz and dout * mask, per modality dx
+    for (int k = 0; k < 2; ++k) {
+      const std::string sfx = std::to_string(k) + mod[m];
+      put("dz" + sfx, p.dz[k][m], p.rows[m] * D / HS);
+      if (p.dom[k][m]) put("dom" + sfx, p.dom[k][m], V * (k == 0 ? 1 : NQ) * D);
+    }
+    put(std::string("dx_") + mod[m], p.dx[m][0], p.rows[m] / (m == 1 ? 1 : p.S) * D / HS);
+  }
+  put("d_hpre", p.d_hpre, 3 * V * D); put("d_ca_out", p.d_ca_out, 3 * V * NQ * D);
   if (!buf || s.size() + 1 > buflen) return -(int32_t)(s.size() + 1);
   memcpy(buf, s.c_str(), s.size() + 1);
   return (int32_t)s.size();

@@ -37,6 +37,17 @@ def flat_from(E, P, dims):
     return flat.cuda(), lay
 
 
+def close_norm(got, want, tol, msg):
+    """Tensor-wise relative error: gradients of this path are 1e-5 and smaller, an absolute tolerance tied to 1.0 says nothing about them."""
+    got, want = got.detach().cpu().double(), want.detach().cpu().double().reshape(got.shape)
+    ref = float(want.norm())
+    if ref < 1e-7:       # (analytically zero up to rounding: the RnC head's biases -- the loss is translation invariant)
+        assert float(got.norm()) < 1e-6, msg
+        return
+    err = float((got - want).norm()) / ref
+    assert err < tol, f"{msg}: relative error {err:.3e} (norms {float(got.norm()):.3e} vs {ref:.3e})"
+
+
 def test_c1_mosi_shapes_full_step_vs_oracle(E):
     """BASELINE configs[0] (C1): B = 16, T = (200, 16, 120, 16), full feature widths, train mode with Philox masks:
     loss, the six terms, the five outputs of both streams, every gradient and the Adam update against the oracle."""
@@ -59,9 +70,33 @@ def test_c1_mosi_shapes_full_step_vs_oracle(E):
     gv = lay.views(torch.cat([ts.grads.cpu(), torch.zeros(lay.total - lay.live)]))
     for k in lay.live_names():
         close(gv[k], grads[k], 1e-3, k)
+        close_norm(gv[k], grads[k], 2e-4, k)
     pv = lay.views(flat.cpu())
     for k in ("frame_dim_reshape_0.weight", "cross_att_fra2utt_2.input_proj.weight", "cross_attention_mlp.0.weight"):
         close((pv[k] - P[k]) * 1e4, (Pd[k] - P[k]) * 1e4, 2e-2, k)
+
+
+@pytest.mark.parametrize("Tn", [(70, 64, 65, 96), (100, 40, 64, 40), (63, 32, 130, 32)])
+def test_dx_in_one_pass_over_mixed_run_shapes_vs_oracle(E, Tn):
+    """The rows launches that write dx directly (pooling term + mask-sum folded in) are chosen per modality: text streams
+    of different lengths (two runs, one launch), a text slot too short for the fold beside audio / video that take it, the 63- and
+    32-frame edges.  Every gradient against the oracle."""
+    from oracle import sdumc_oracle as O
+    dims = (1024, 4096, 1024, 4096)
+    B = 6
+    P = O.init_params(dims, seed=3)
+    flat, lay = flat_from(E, P, dims)
+    audio, text, video, feat4, vals = O.synthetic_batch(B, Tn, dims, seed=77)
+    ts = E.TrainStep(flat, B, Tn, dims, seed=5)
+    ts.set_batch(audio.cuda(), text.cuda(), video.cuda(), feat4.cuda(), vals.cuda())
+    losses = ts.run().cpu().numpy()
+    Pd = {k: v.clone() for k, v in P.items()}
+    loss, terms, grads, outs = O.train_step(Pd, {}, audio, text, video, feat4, vals, mode="philox", seed=5, step=0)
+    np.testing.assert_allclose(losses[0], float(loss), rtol=1e-3)
+    gv = lay.views(torch.cat([ts.grads.cpu(), torch.zeros(lay.total - lay.live)]))
+    for k in lay.live_names():
+        close(gv[k], grads[k], 1e-3, k)
+        close_norm(gv[k], grads[k], 2e-4, k)
 
 
 def test_c4_global_batch_512_on_one_gpu_and_two_simulated_ranks(E):

@@ -79,8 +79,16 @@ def main():
     tot_f = 2.0 * sum(sum(v) for v in fetch.values())
     tot_w = sum(sum(v) for v in write.values())
     out["run_total"] = {"fetch_bytes": round(tot_f), "write_bytes": round(tot_w)}
+    # launches of the profiled command that are NOT part of a step: installing the batch (torch copies, the feature-plane split
+    # of set_batch -- once per batch, features do not change across epochs) and torch's own fills
+    setup = lambda k: k.startswith("__amd_rocclr") or k.startswith("at::native") or k == "sdumc_p3::p3_split_kernel"
+    set_f = 2.0 * sum(sum(v) for k, v in fetch.items() if setup(k))
+    set_w = sum(sum(v) for k, v in write.items() if setup(k))
+    out["setup_total"] = {"fetch_bytes": round(set_f), "write_bytes": round(set_w),
+                          "kernels": sorted(k for k in set(fetch) | set(write) if setup(k))}
     if steps:
-        out["per_step"] = {"steps_in_run": steps, "fetch_bytes": round(tot_f / steps), "write_bytes": round(tot_w / steps)}
+        out["per_step"] = {"steps_in_run": steps, "fetch_bytes": round((tot_f - set_f) / steps), "write_bytes": round((tot_w - set_w) / steps),
+                           "note": "the step's own launches; batch installation (setup_total) excluded"}
     json.dump(out, open(sys.argv[3], "w"), indent=1)
     top = sorted(out["kernels"].items(), key=lambda kv: -kv[1]["traffic_bytes"] * kv[1]["launches"])[:8]
     for k, v in top:
