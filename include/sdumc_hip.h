@@ -325,12 +325,13 @@ typedef struct sdumc_rows_problem {
    *   C[r] = A[r] B + sum_i pool_w[r][i] * pool_g[r / pool_T][i][:]
    * pool_w = the attention weights [M][pool_nq] of the site, pool_g = dout * out-dropout mask [M / pool_T][pool_nq][256]
    * (sdumc_attnpool_bwd.dout_masked).  dxd = dz W + (pooling part) then leaves this kernel in ONE pass: the pooling backward
-   * does not write dxd and this launch does not read it back.  Needs pool_nq <= 8, pool_T >= 63 or pool_T == 32 (a 64-row tile
-   * spans at most two samples), no a_bits, no accumulate, M % pool_T == 0. */
+   * does not write dxd and this launch does not read it back.  Needs pool_nq <= 8 (<= 7 with fold), pool_T >= 63 or pool_T == 32 (a
+   * 64-row tile spans at most two samples), no a_bits, no bias / act / a_row_mod, M % pool_T == 0; accumulate only together with fold. */
   const float* pool_w;
   const float* pool_g;
   int32_t pool_nq, pool_T;
-  /* optional, with the pooling term (fp32 split arithmetic only): the mask-sum of the frame-level input dropouts folded in as well --
+  /* optional, with the pooling term (fp32: split arithmetic only; sdumc_gemm_rows256_bf16 takes it too -- pool_w / pool_g stay fp32,
+   * every problem of a launch the same fold): the mask-sum of the frame-level input dropouts folded in as well --
    *   C[r] (+)= sum_{s < fold} keep_s[r] . (A[s R + r] B + pooling term of row s R + r) * c_scale,   R = M / fold rows of C
    * i.e. dx of a modality = the sum over the streams that share its frames (fold = 2; 1 for separate frames) of the masked dxd of one
    * attention site, written ONCE: dxd never exists in memory.  c_bits = the keep-bits of the site's input dropout over the M virtual

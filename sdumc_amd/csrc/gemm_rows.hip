@@ -24,7 +24,10 @@
 //     MFMAs per stage and wave against 8 ds_read_b128 and one DMA instruction;
 //   * the input-dropout keep-bits of a tile (64 rows x 64 bytes) ride ahead of it as two 256-byte pieces per wave
 //     (double-buffered) and are applied to the A fragments; the scale 1 / (1 - p) multiplies the tile once, in the epilogue;
-//   * `accumulate`: the C tile is prefetched into registers two stages before the epilogue needs it.
+//   * `accumulate`: the C tile is prefetched into registers two stages before the epilogue needs it;
+//   * round 5 (split and bf16 kernels): the attention pooling's own input gradient as one more k-tile (`pool_w` / `pool_g`) and the
+//     mask-sum of the frame-level input dropouts as the epilogue (`c_bits`, `fold`): dx of a modality leaves the launch in one pass
+//     (gr_split_kernel<.., POOL, FOLD>, gr_bf16_kernel<ACC, FOLD>; sdumc_hip.h: sdumc_rows_problem).
 // The vector-memory queue of a wave holds, in issue order, LDS-DMA loads, the C prefetch and the epilogue's stores; the waits
 // are counted (s_waitcnt vmcnt(n) with n = the loads issued after the one waited for -- loads return in order; stores only make
 // a wait conservative), so nothing ever drains the queue inside a problem.
