@@ -1560,8 +1560,8 @@ extern "C" int sdumc_umca_fwd(const sdumc_umca* up, void* stream) {
   if (p.x_drop.enabled && !p.x_drop.bits) return SDUMC_EINVAL;                       // the input mask comes as keep-bits
   if ((p.T + CH - 1) / CH > 4096) return SDUMC_EINVAL;
   if (!p.workspace || p.workspace_bytes < sdumc_attnpool_fwd_workspace_bytes_dim(p.V, p.T, p.nq, D)) return SDUMC_ENOMEM;
-  static bool attr = false;
-  if (!attr) {
+  static std::atomic<uint64_t> attr{0};
+  if (sdumc_first_on_device(attr)) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sdumc_k3::umca_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             sdumc_k3::LDS_BYTES) != hipSuccess ||
         hipFuncSetAttribute(reinterpret_cast<const void*>(&sdumc_k3::umca_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1571,7 +1571,6 @@ extern "C" int sdumc_umca_fwd(const sdumc_umca* up, void* stream) {
         hipFuncSetAttribute(reinterpret_cast<const void*>(&sdumc_k3::umca_fwd_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                             sdumc_k3::LDS_BYTES) != hipSuccess)
       return SDUMC_ELAUNCH;
-    attr = true;
   }
   hipStream_t st = as_stream(stream);
   const int nchunk = (p.T + CH - 1) / CH;
@@ -1580,14 +1579,13 @@ extern "C" int sdumc_umca_fwd(const sdumc_umca* up, void* stream) {
     if (!sdumc_split_on_(SDUMC_SPLIT_UMCA)) return SDUMC_EINVAL;                      // planes ARE the split arithmetic
     if ((reinterpret_cast<uintptr_t>(u.x_p3) | reinterpret_cast<uintptr_t>(u.w_in_p3f)) & 15) return SDUMC_EINVAL;
     if (p.x_drop.enabled && (qw_of(p.x_drop) & 3)) return SDUMC_EINVAL;
-    static bool attr_p3 = false;
-    if (!attr_p3) {
+    static std::atomic<uint64_t> attr_p3{0};
+    if (sdumc_first_on_device(attr_p3)) {
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sdumc_k3::umca_fwd_p3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               sdumc_k3::LDS_BYTES) != hipSuccess ||
           hipFuncSetAttribute(reinterpret_cast<const void*>(&sdumc_k3::umca_fwd_p3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               sdumc_k3::LDS_BYTES) != hipSuccess)
         return SDUMC_ELAUNCH;
-      attr_p3 = true;
     }
     if (p.x_drop.enabled) hipLaunchKernelGGL(sdumc_k3::umca_fwd_p3_kernel<true>, grid, blk, sdumc_k3::LDS_BYTES, st, u, nchunk);
     else hipLaunchKernelGGL(sdumc_k3::umca_fwd_p3_kernel<false>, grid, blk, sdumc_k3::LDS_BYTES, st, u, nchunk);

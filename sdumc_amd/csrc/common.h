@@ -14,6 +14,18 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 
+// The dynamic-LDS limit of a kernel is a PER-DEVICE function attribute: `done` holds one bit per device; true the first time the
+// current device asks (a process that drives several GPUs sets the attribute on each of them).
+#ifdef __cplusplus
+#include <atomic>
+static inline bool sdumc_first_on_device(std::atomic<uint64_t>& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  const uint64_t bit = 1ull << dev;
+  return (done.fetch_or(bit) & bit) == 0;
+}
+#endif
+
 // ---------------------------------------------------------------------------
 // Internal entry points (not part of include/sdumc_hip.h): fused variants the engine's train step uses to take
 // ~6.6 us dependent launches off its critical chain (measured: five such launches removed = 2.152 -> 2.119 ms).
@@ -112,6 +124,7 @@ int sdumc_chain_cluster_forget_stream_(void* stream);    // before a stream is d
 const int32_t* sdumc_chain_cluster_err_ptr_(void);    // device address of the error word (nullptr before the first cluster launch)
 // dst[off ..] = transpose of the n listed [out][in] matrices of src (same offsets in both buffers)
 // fp32 parameters -> bf16 copies as stored (dst) and, where want_t[i], transposed (dst_t); same element offsets as in src
+int sdumc_gemm_small_tn_multi_(const sdumc_gemm* gs, int n, void* stream);
 int sdumc_weights_to_bf16_(const float* src, void* dst, void* dst_t, const int64_t* offs, const int32_t* outs, const int32_t* ins,
                            const int32_t* want_t, int n, void* stream);
 size_t sdumc_gg_slab_bytes_(int tiles);   // gemm_group.hip: workspace bound for sdumc_gemm_group_tn by output-tile count

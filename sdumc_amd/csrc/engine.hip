@@ -778,6 +778,7 @@ int flush_dw_on(const Ctx& c, int after, int lane, int slab) {
   RET(link(c, after, lane));
   c.use(lane);
   const bool grouped = gg_utt(c);
+  std::vector<sdumc_gemm> rest;      // what the grouped launch does not take
   for (sdumc_gemm& g : c.deferred) {
     bool taken = grouped;
     if (grouped) {
@@ -791,8 +792,14 @@ int flush_dw_on(const Ctx& c, int after, int lane, int slab) {
     }
     // (fc_att, cross_fc_att, fc_out_v: 3 / 7 / 1 output rows.  They stay IN FRONT of the grouped launch: behind it -- so that the
     //  persistent launch starts 11-41 us x 3 earlier -- measured 1.684-1.687 vs 1.673-1.680 ms fp32, 0.954-0.956 vs 0.952-0.957 bf16)
-    if (!taken) RET(run(c, g));
+    if (!taken) rest.push_back(g);
   }
+  // (round 5: the three of them -- different shapes, four to eight workgroups each -- in ONE launch when the small-problem kernel takes
+  //  them, in bf16 storage only: the grouped launch behind them then starts ~20 us earlier, which pays where the dX launches beside it
+  //  are short (bf16 0.8475-0.8488 against 0.8607-0.8654 ms) and costs where they are not (fp32 1.3144-1.3151 against 1.2882-1.2907:
+  //  the persistent launch takes the CUs the dX chain is waiting for -- the same sign as moving the three behind it did in round 4))
+  if (c.h() && rest.size() >= 2 && rest.size() <= 3 && sdumc_gemm_small_tn_multi_(rest.data(), (int)rest.size(), c.st) == SDUMC_OK) rest.clear();
+  for (sdumc_gemm& g : rest) RET(run(c, g));
   c.deferred.clear();
   if (!c.gg.empty()) {
     const int rc = gg_launch(c, c.gg.data(), (int)c.gg.size(), false, slab);

@@ -341,11 +341,10 @@ extern "C" int sdumc_gemm_b1_nt(const sdumc_gemm_b1* gp, void* stream) {
   if (a_bytes >= 0xFFFFFFF0u) return SDUMC_EINVAL;
   const Plan p = plan(g, g.workspace ? g.workspace_bytes : 0);
   if (p.nsplit > 1 && (!g.workspace || (reinterpret_cast<uintptr_t>(g.workspace) & 15))) return SDUMC_ENOMEM;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_b1_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess) return SDUMC_ELAUNCH;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> attr_set{0};
+  if (sdumc_first_on_device(attr_set) &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_b1_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+    return SDUMC_ELAUNCH;
   hipStream_t st = as_stream(stream);
   const int tok = sdumc_prof_begin_(28, 2.0 * g.M * (double)g.N * g.K, stream);
   Args a{g, p.nsplit, p.kchunk};

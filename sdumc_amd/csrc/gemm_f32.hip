@@ -20,6 +20,7 @@
 //     source-row modulo (the two streams share x_audio/x_video), bias + ReLU/tanh + dropout epilogue,
 //     accumulate, deterministic split-K (slabs + ordered reduce; no float atomics).
 #include <algorithm>
+#include <cstring>
 #include <mutex>
 #include <type_traits>
 #include <vector>
@@ -571,12 +572,13 @@ __global__ __launch_bounds__(256, (BM == 64 ? SDUMC_GEMM_WPE64 : SDUMC_GEMM_WPE1
 // partial tiles are summed through LDS in a fixed order and the usual fused epilogue runs.
 // ------------------------------------------------------------------------------------------------
 template <bool A_K, bool B_K, int NW>
-__global__ __launch_bounds__(64 * NW) void gemm_small_kernel(const sdumc_gemm g, const int kq /* k per wave, multiple of 8 */) {
+__device__ __forceinline__ void gemm_small_body(const sdumc_gemm& g, const int kq /* k per wave, multiple of 8 */, const int grp,
+                                                const int by, const int bx) {
   __shared__ float part[NW][32 * 33];
   __shared__ float cs_s[NW][32];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 31, lh = lane >> 5;
-  const int grp = blockIdx.z, m0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+  const int m0 = by * 32, n0 = bx * 32;
   const float* A = g.A[grp];
   const float* B = g.B[grp];
   const int K = g.K;
@@ -587,7 +589,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_small_kernel(const sdumc_gemm g,
   // k-contiguous operand ([R][K]): this lane's row; row-contiguous operand ([K][R]): this lane's column
   const float* ap = A_K ? A + (size_t)(m0 + li) * g.lda : A + m0 + li;
   const float* bp = B_K ? B + (size_t)(n0 + li) * g.ldb : B + n0 + li;
-  const bool do_cs = !A_K && g.colsum_a[grp] != nullptr && blockIdx.x == 0;
+  const bool do_cs = !A_K && g.colsum_a[grp] != nullptr && bx == 0;
   float csum = 0.f;
 
   f32x16 acc;
@@ -671,6 +673,27 @@ __global__ __launch_bounds__(64 * NW) void gemm_small_kernel(const sdumc_gemm g,
     if (cy) v = cy[(size_t)row * g.ldc + col] > 0.f ? v * g.c_mask_scale : 0.f;
     *dst = v;
   }
+}
+
+template <bool A_K, bool B_K, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_small_kernel(const sdumc_gemm g, const int kq) {
+  gemm_small_body<A_K, B_K, NW>(g, kq, blockIdx.z, blockIdx.y, blockIdx.x);
+}
+// up to three TN problems of DIFFERENT shapes in one launch (the weight gradients whose outputs have 3 / 7 / 1 rows: fc_att,
+// cross_fc_att, fc_out_v -- three dependent 10-us launches in front of the grouped dW launch otherwise): workgroup -> (problem, tile)
+struct SmallMulti {
+  sdumc_gemm g[3];
+  int32_t kq[3], blk_end[3], tiles_n[3];
+};
+__global__ __launch_bounds__(256) void gemm_small_tn_multi_kernel(const SmallMulti m) {
+  sdumc_gemm g = m.g[0];      // uniform select, by value (a dynamically indexed kernel argument goes through scratch)
+  int i = 0;
+  if ((int)blockIdx.x >= m.blk_end[0]) { g = m.g[1]; i = 1; }
+  if ((int)blockIdx.x >= m.blk_end[1]) { g = m.g[2]; i = 2; }
+  const int kq = i == 0 ? m.kq[0] : (i == 1 ? m.kq[1] : m.kq[2]);
+  const int tn = i == 0 ? m.tiles_n[0] : (i == 1 ? m.tiles_n[1] : m.tiles_n[2]);
+  const int local = (int)blockIdx.x - (i == 0 ? 0 : (i == 1 ? m.blk_end[0] : m.blk_end[1]));
+  gemm_small_body<false, false, 4>(g, kq, 0, local / tn, local - (local / tn) * tn);
 }
 
 // ordered (deterministic) reduction of the split-K slabs + the epilogue
@@ -857,6 +880,36 @@ extern "C" int sdumc_gemm_wide_(const sdumc_gemm* gp, int cfg, int nsplit, int k
 extern "C" size_t sdumc_gemm_workspace_bytes(const sdumc_gemm* g) {
   if (!g || g->M <= 0 || g->N <= 0 || g->K <= 0 || g->groups < 1) return 0;
   return plan_ws_bytes(*g, plan_gemm(*g, (size_t)-1).nsplit);
+}
+
+// n = 2 or 3 single-group TN problems that sdumc_gemm_f32 would each hand to the small-problem kernel: one launch for all of them.
+// SDUMC_EINVAL = not such a set (the caller launches them one by one).
+extern "C" int sdumc_gemm_small_tn_multi_(const sdumc_gemm* gs, int n, void* stream) {
+  if (!gs || n < 2 || n > 3) return SDUMC_EINVAL;
+  SmallMulti m;
+  memset(&m, 0, sizeof(m));
+  int blocks = 0;
+  double flops = 0.0;
+  for (int i = 0; i < 3; ++i) {
+    if (i >= n) { m.blk_end[i] = blocks; m.tiles_n[i] = 1; continue; }
+    const sdumc_gemm& g = gs[i];
+    if (g.layout != SDUMC_TN || g.groups != 1 || g.batch > 1 || g.bf16 || g.M <= 0 || g.N <= 0 || g.K <= 0 || !g.A[0] || !g.B[0] || !g.C[0]) return SDUMC_EINVAL;
+    if (g.accumulate && (g.act != SDUMC_ACT_NONE || g.c_drop.enabled)) return SDUMC_EINVAL;
+    if (g.c_drop.enabled && (g.c_drop.width & 3)) return SDUMC_EINVAL;
+    const GemmPlan pl = plan_gemm(g, 0);
+    if (pl.tile != 3 || pl.waves != 4) return SDUMC_EINVAL;
+    m.g[i] = g;
+    m.kq[i] = pl.kchunk;
+    m.tiles_n[i] = (g.N + 31) / 32;
+    blocks += m.tiles_n[i] * ((g.M + 31) / 32);
+    m.blk_end[i] = blocks;
+    flops += 2.0 * g.M * (double)g.N * g.K;
+  }
+  const int tok = sdumc_prof_begin_(8, flops, stream);      // (gemm_small_tn)
+  hipLaunchKernelGGL(gemm_small_tn_multi_kernel, dim3(blocks), dim3(256), 0, as_stream(stream), m);
+  SDUMC_CHECK_LAUNCH();
+  sdumc_prof_end_(tok, stream);
+  return SDUMC_OK;
 }
 
 extern "C" int sdumc_gemm_f32(const sdumc_gemm* gp, void* stream) {

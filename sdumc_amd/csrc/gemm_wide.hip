@@ -444,23 +444,21 @@ int launch_cfg(const sdumc_gemm& g, int nsplit, int kchunk, bool mask, bool cs, 
   const size_t shm = CF::LDS_BYTES;
 #define SDUMC_WIDE_LAUNCH(MK, CSV)                                                                                           \
   do {                                                                                                                       \
-    static bool attr_set = false;                                                                                            \
-    if (!attr_set) {                                                                                                         \
+    static std::atomic<uint64_t> attr_set{0};                                                                                            \
+    if (sdumc_first_on_device(attr_set)) {                                                                                                         \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wide_kernel<CF, MK, CSV>),                                \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)                         \
         return SDUMC_ELAUNCH;                                                                                                \
-      attr_set = true;                                                                                                       \
     }                                                                                                                        \
     hipLaunchKernelGGL((gemm_wide_kernel<CF, MK, CSV>), grid, blk, shm, st, g, nsplit, kchunk);                              \
   } while (0)
 #define SDUMC_WIDE_LAUNCH_SPLIT(MK)                                                                                           \
   do {                                                                                                                       \
-    static bool attr_set = false;                                                                                            \
-    if (!attr_set) {                                                                                                         \
+    static std::atomic<uint64_t> attr_set{0};                                                                                            \
+    if (sdumc_first_on_device(attr_set)) {                                                                                                         \
       if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wide_split_kernel<CF, MK>),                               \
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)                         \
         return SDUMC_ELAUNCH;                                                                                                \
-      attr_set = true;                                                                                                       \
     }                                                                                                                        \
     hipLaunchKernelGGL((gemm_wide_split_kernel<CF, MK>), grid, blk, shm, st, g, nsplit, kchunk);                             \
   } while (0)
