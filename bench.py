@@ -445,6 +445,7 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--prewarm-s", type=float, default=0.3,
                     help="seconds of untimed steps on a throwaway step object before --warmup (clock ramp; 0 = off)")
+    ap.add_argument("--no-bits-next", action="store_true", help="A/B: generate every step's keep-bits at its head (no sdumc_net_io.bits_next)")
     ap.add_argument("--no-side", action="store_true", help="skip the configs[2] (bf16 storage) side leg of the default line (profiling runs)")
     args = ap.parse_args()
     global B_PER_GPU, T_MOSEI, DIMS, TRAIN_FLOPS_PER_SAMPLE, WORKLOAD_TEXT
@@ -501,7 +502,7 @@ def main():
     prewarm_s, prewarm_steps = prewarm_leg(engine, flat0, batch, args.bf16, args.prewarm_s)
 
     if world == 1 and not force_dp:
-        step = engine.TrainStep(flat, B_PER_GPU, T_MOSEI, DIMS, seed=2024, bf16=args.bf16)
+        step = engine.TrainStep(flat, B_PER_GPU, T_MOSEI, DIMS, seed=2024, bf16=args.bf16, bits_next=not args.no_bits_next)
         step.set_batch(*batch)
         if args.graph:
             step.capture()

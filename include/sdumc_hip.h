@@ -800,6 +800,16 @@ typedef struct sdumc_net_io {
   const void* audio_p3;
   const void* video_p3;
   const void* text_p3[2];
+  /* Optional, train mode in fp32 storage: sdumc_net_bits_next_bytes(dims) bytes the caller keeps ACROSS calls of the same dims (its
+   * own allocation, not part of `workspace`; zero it once) -- TWO sets of keep-bits for the frame-level input dropouts, each with a
+   * {seed, call} tag.  A call reads set (bits_phase & 1); in its latency-bound middle, where the chip idles, it fills the OTHER set
+   * for the next call (Philox call index + 2: what sdumc_train_step advances by) and tags it.  The caller flips bits_phase from call
+   * to call (forward and backward of one step take the same value); the next call's head launch then finds its set tagged with its
+   * own {seed, call} and has nothing to generate -- at the head the Philox launches compete with the frame projections.
+   * Bit-identical masks either way: a set whose tag names another seed or call (first call, a reset counter, a different advance, a
+   * phase that was not flipped) is generated as ever. */
+  void* bits_next;
+  int32_t bits_phase;
   /* Optional caller-owned execution context (sdumc_ctx_create): the internal side streams and the event ring the call forks
    * its branches on.  NULL = the default context of the current device (one per device, created on first use).  Two host
    * threads that run steps concurrently -- on distinct streams of one device, or on two devices -- give each its own
@@ -812,6 +822,7 @@ typedef struct sdumc_net_io {
  * the previous such launch with an event recorded on THAT launch's stream -- a caller that destroys the stream it ran its last
  * step on must have synchronised it first (torch's pooled streams are never destroyed; the library's own lanes are handled by
  * sdumc_ctx_destroy). */
+size_t sdumc_net_bits_next_bytes(const sdumc_net_dims* d);   /* 0 = the dims do not use it (eval, bf16 storage) */
 int sdumc_ctx_create(void** ctx);
 int sdumc_ctx_destroy(void* ctx);
 /* Schedule options of ONE execution context (ctx NULL = the current device's default context): nothing process-wide changes, so

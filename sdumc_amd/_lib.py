@@ -132,6 +132,7 @@ class NetIO(C.Structure):
                 ("text_hidden", C.c_void_p), ("cross_text", C.c_void_p),
                 ("lengths", C.c_void_p * 4),
                 ("audio_p3", C.c_void_p), ("video_p3", C.c_void_p), ("text_p3", C.c_void_p * 2),   # optional bf16-plane copies of the features
+                ("bits_next", C.c_void_p), ("bits_phase", C.c_int32),   # optional: two sets of keep-bits, the next call's generated in this call's middle
                 ("ctx", C.c_void_p)]          # optional caller-owned execution context (sdumc_ctx_create); None = device default
 
 
@@ -298,6 +299,7 @@ _SIGS = {
     "sdumc_attnpool_set_v2_": (C.c_int, [C.c_int]),
     "sdumc_debug_plan_table": (C.c_int32, [C.POINTER(NetDims), C.c_char_p, C.c_size_t]),
     "sdumc_net_workspace_bytes": (C.c_size_t, [C.POINTER(NetDims)]),
+    "sdumc_net_bits_next_bytes": (C.c_size_t, [C.POINTER(NetDims)]),
     "sdumc_net_forward": (C.c_int, [C.POINTER(NetDims), C.POINTER(NetIO), C.c_void_p]),
     "sdumc_net_backward": (C.c_int, [C.POINTER(NetDims), C.POINTER(NetIO), C.POINTER(NetGrads), C.c_void_p]),
     "sdumc_net_backward_phase": (C.c_int, [C.POINTER(NetDims), C.POINTER(NetIO), C.POINTER(NetGrads), C.c_int32, C.c_void_p]),

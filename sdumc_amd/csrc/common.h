@@ -125,6 +125,9 @@ const int32_t* sdumc_chain_cluster_err_ptr_(void);    // device address of the e
 // dst[off ..] = transpose of the n listed [out][in] matrices of src (same offsets in both buffers)
 // fp32 parameters -> bf16 copies as stored (dst) and, where want_t[i], transposed (dst_t); same element offsets as in src
 int sdumc_gemm_small_tn_multi_(const sdumc_gemm* gs, int n, void* stream);
+int sdumc_dropout_bits_multi_ex_(const sdumc_dropout* d, int32_t streams, int32_t nsite, int32_t site_stride, uint8_t* const* bits,
+                                 const uint32_t* tag, int32_t call_add, void* stream);
+int sdumc_bits_tag_(const sdumc_dropout* d, uint32_t* tag, int32_t call_add, void* stream);
 int sdumc_weights_to_bf16_(const float* src, void* dst, void* dst_t, const int64_t* offs, const int32_t* outs, const int32_t* ins,
                            const int32_t* want_t, int n, void* stream);
 size_t sdumc_gg_slab_bytes_(int tiles);   // gemm_group.hip: workspace bound for sdumc_gemm_group_tn by output-tile count

@@ -219,23 +219,42 @@ __global__ void dropout_mask_kernel(const sdumc_dropout d, int64_t nquads, float
 struct BitsOut {
   uint8_t* p[4];
 };
-__global__ void dropout_bits_kernel(const sdumc_dropout d, int64_t nwords, int nsite, int site_stride, BitsOut out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nwords) return;
-  DropRT r = drop_resolve(d);
-  r.bits = nullptr;   // always from Philox
-  const uint32_t wpr = r.qwidth >> 2;                      // 32-bit words per row
-  const uint32_t vrow = (uint32_t)(i / wpr), w = (uint32_t)(i - (int64_t)vrow * wpr);
-  for (int s = 0; s < nsite; ++s) {
-    uint32_t word = 0;
+// `call_add`: the keep-bits of the call that many Philox calls AHEAD (the next step's, generated in this step's idle middle).
+// `tag`: the {seed, call, magic} the buffers were last filled for: when it names the call this launch is for, there is nothing to do
+// (the launch is a tag read per thread); any other tag: generated as ever.
+__global__ void dropout_bits_kernel(const sdumc_dropout d, int64_t nwords, int nsite, int site_stride, BitsOut out,
+                                    const uint32_t* __restrict__ tag, int call_add) {
+  DropRT r0 = drop_resolve(d);
+  r0.bits = nullptr;   // always from Philox
+  r0.call0 += (uint32_t)call_add;
+  if (tag != nullptr && tag[0] == r0.k0 && tag[1] == r0.k1 && tag[2] == r0.call0 && tag[3] == 0x5D0Cb175u) return;
+  const uint32_t wpr = r0.qwidth >> 2;                     // 32-bit words per row
+  // (grid-stride: with a tag the launch is capped at 1024 workgroups -- as fast when it generates, a third of the workgroups to
+  //  retire when it has nothing to do)
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (int64_t)gridDim.x * blockDim.x) {
+    DropRT r = r0;
+    const uint32_t vrow = (uint32_t)(i / wpr), w = (uint32_t)(i - (int64_t)vrow * wpr);
+    for (int s = 0; s < nsite; ++s) {
+      uint32_t word = 0;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 m = drop_mask4(r, vrow, 4 * w + q);
-      word |= (uint32_t)((m[0] != 0.f) | ((m[1] != 0.f) << 1) | ((m[2] != 0.f) << 2) | ((m[3] != 0.f) << 3)) << (8 * q);
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 m = drop_mask4(r, vrow, 4 * w + q);
+        word |= (uint32_t)((m[0] != 0.f) | ((m[1] != 0.f) << 1) | ((m[2] != 0.f) << 2) | ((m[3] != 0.f) << 3)) << (8 * q);
+      }
+      reinterpret_cast<uint32_t*>(out.p[s])[i] = word;
+      r.site += (uint32_t)site_stride;
     }
-    reinterpret_cast<uint32_t*>(out.p[s])[i] = word;
-    r.site += (uint32_t)site_stride;
   }
+}
+
+// the tag of pre-generated keep-bits: {seed_lo, seed_hi, call, magic}; call_add < 0: invalidate (written before the buffers are refilled)
+__global__ void bits_tag_kernel(const sdumc_dropout d, uint32_t* tag, int call_add) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const DropRT r = drop_resolve(d);
+  tag[0] = r.k0;
+  tag[1] = r.k1;
+  tag[2] = r.call0 + (uint32_t)(call_add < 0 ? 0 : call_add);
+  tag[3] = call_add < 0 ? 0u : 0x5D0Cb175u;
 }
 
 // bf16-storage mode: the keep-bits of TWO sites that share a row space (fra2utt_m and cross_att_fra2utt_m read the same frames)
@@ -542,8 +561,9 @@ extern "C" int sdumc_dropout_mask(const sdumc_dropout* d, int32_t streams, float
   return SDUMC_OK;
 }
 
-extern "C" int sdumc_dropout_bits_multi(const sdumc_dropout* d, int32_t streams, int32_t nsite, int32_t site_stride,
-                                        uint8_t* const* bits, void* stream) {
+// tag: the launch is a no-op when it names this call (see the kernel); call_add: generate for the call that many ahead
+extern "C" int sdumc_dropout_bits_multi_ex_(const sdumc_dropout* d, int32_t streams, int32_t nsite, int32_t site_stride,
+                                            uint8_t* const* bits, const uint32_t* tag, int32_t call_add, void* stream) {
   if (!d || !bits || streams < 1 || nsite < 1 || nsite > 4 || (d->width & 15) || d->width == 0) return SDUMC_EINVAL;
   BitsOut out;
   for (int s = 0; s < 4; ++s) {
@@ -551,8 +571,21 @@ extern "C" int sdumc_dropout_bits_multi(const sdumc_dropout* d, int32_t streams,
     if (s < nsite && (!bits[s] || (reinterpret_cast<uintptr_t>(bits[s]) & 3))) return SDUMC_EINVAL;
   }
   const int64_t nwords = (int64_t)streams * d->samples * (d->rows ? d->rows : 1) * (d->width / 16);
-  hipLaunchKernelGGL(dropout_bits_kernel, dim3(nblk(nwords)), dim3(256), 0, as_stream(stream), *d, nwords, nsite,
-                     site_stride, out);
+  constexpr unsigned cap = 1024;      // (with a tag: 1.2536-1.2572 ms per fp32 C2 step; uncapped 1.255-1.2617; 512 / 256: 1.257-1.2594)
+  unsigned grid = (unsigned)nblk(nwords);
+  if (tag && grid > cap) grid = cap;
+  hipLaunchKernelGGL(dropout_bits_kernel, dim3(grid), dim3(256), 0, as_stream(stream), *d, nwords, nsite,
+                     site_stride, out, tag, call_add);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+extern "C" int sdumc_dropout_bits_multi(const sdumc_dropout* d, int32_t streams, int32_t nsite, int32_t site_stride,
+                                        uint8_t* const* bits, void* stream) {
+  return sdumc_dropout_bits_multi_ex_(d, streams, nsite, site_stride, bits, nullptr, 0, stream);
+}
+extern "C" int sdumc_bits_tag_(const sdumc_dropout* d, uint32_t* tag, int32_t call_add, void* stream) {
+  if (!d || !tag) return SDUMC_EINVAL;
+  hipLaunchKernelGGL(bits_tag_kernel, dim3(1), dim3(64), 0, as_stream(stream), *d, tag, call_add);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
 }

@@ -633,11 +633,30 @@ sdumc_dropout mkdrop(const Ctx& c, int site, double prob, int rows, int width, i
   return r;
 }
 
+// sdumc_net_io.bits_next: TWO sets of [tag 64 B][site 0: audio, text, video rows x 64 B][site 1: ...]: the keep-bits this call reads
+// (set bits_phase & 1) and the ones it fills for the next call (the other set).  (k = 2: the size of a set.)
+int64_t bits_next_off(const Plan& pl, int k, int m) {
+  int64_t off = 64;
+  for (int kk = 0; kk < 2; ++kk)
+    for (int mm = 0; mm < 3; ++mm) {
+      if (kk == k && mm == m) return off;
+      off += pl.rows[mm] * (D / 4);
+    }
+  return (off + 255) & ~(int64_t)255;
+}
+bool bits_pregen(const Ctx& c) { return c.io.bits_next != nullptr && c.d.train && !c.h() && c.d.p_frame > 0.0; }
+uint8_t* bits_set(const Ctx& c, int other) {
+  return static_cast<uint8_t*>(c.io.bits_next) + (((c.io.bits_phase & 1) ^ other) ? bits_next_off(c.pl, 2, 0) : 0);
+}
+// where the keep-bits of attention site (k, m) live for this call
+uint8_t* bits_ptr(const Ctx& c, int k, int m) {
+  return bits_pregen(c) ? bits_set(c, 0) + bits_next_off(c.pl, k, m) : reinterpret_cast<uint8_t*>(c.p(c.pl.bits[k][m]));
+}
 // the input dropout of attention site (k, m) over run `sg`, with its precomputed keep-bits in train mode
 struct Seg;
 sdumc_dropout in_drop(const Ctx& c, int k, int m, int T, int s0, int64_t row0) {
   sdumc_dropout d = mkdrop(c, SITE_IN[k][m], c.d.p_frame, T, D, s0);
-  if (d.enabled) d.bits = reinterpret_cast<const uint8_t*>(c.p(c.pl.bits[k][m])) + row0 * (D / 4);
+  if (d.enabled) d.bits = bits_ptr(c, k, m) + row0 * (D / 4);
   return d;
 }
 
@@ -894,6 +913,7 @@ int check_io(const sdumc_net_dims* d, const sdumc_net_io* io) {
   if (d->train && !io->rng_state) return SDUMC_EINVAL;
   if (reinterpret_cast<uintptr_t>(io->workspace) & 255) return SDUMC_EINVAL;
   if (reinterpret_cast<uintptr_t>(io->params) & 15) return SDUMC_EINVAL;
+  if (reinterpret_cast<uintptr_t>(io->bits_next) & 15) return SDUMC_EINVAL;
   if (io->ctx) {   // a caller-owned context belongs to the device it was created on
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || static_cast<const LaneSet*>(io->ctx)->device != dev) return SDUMC_EINVAL;
@@ -1449,6 +1469,7 @@ int forward(const Ctx& c) {
   // bf16 storage: the keep-bits are produced together with the masked frames xd of both sites, behind the modality's frame
   // projection on the modality's own lane (one pass over x instead of a bits launch on lane 3 plus one mask_apply per site)
   const bool bits_with_xd = c.h() && c.d.train;
+  const bool pregen = bits_pregen(c);
   if (c.d.train && !bits_with_xd) {
     RET(link(c, 0, 3));
     c.use(3);
@@ -1457,9 +1478,10 @@ int forward(const Ctx& c) {
       const int m = order[oi];
       for (const Seg& sg : pl.segs[m]) {   // both sites (fra2utt_m, cross_att_fra2utt_m) in one launch
         sdumc_dropout d = mkdrop(c, SITE_IN[0][m], c.d.p_frame, sg.T, D, sg.s0);
-        uint8_t* outs[2] = {reinterpret_cast<uint8_t*>(c.p(pl.bits[0][m])) + sg.row0 * (D / 4),
-                            reinterpret_cast<uint8_t*>(c.p(pl.bits[1][m])) + sg.row0 * (D / 4)};
-        RET(sdumc_dropout_bits_multi(&d, sg.V / B, 2, SITE_IN[1][m] - SITE_IN[0][m], outs, c.st));
+        uint8_t* outs[2] = {bits_ptr(c, 0, m) + sg.row0 * (D / 4), bits_ptr(c, 1, m) + sg.row0 * (D / 4)};
+        // (bits_next: nothing to do when the previous call filled this set for this call -- its tag says so)
+        RET(sdumc_dropout_bits_multi_ex_(&d, sg.V / B, 2, SITE_IN[1][m] - SITE_IN[0][m], outs,
+                                         pregen ? reinterpret_cast<const uint32_t*>(bits_set(c, 0)) : nullptr, 0, c.st));
       }
       if (c.sts[3] != c.sts[LANE_OF[m]]) {
         bits_done[m] = next_event(c);
@@ -1580,6 +1602,29 @@ int forward(const Ctx& c) {
     } else {
       RET(link(c, lane, 0));
     }
+  }
+  if (pregen) {
+    // The keep-bits of the NEXT call (call index + 2: sdumc_train_step's advance) into the OTHER set, on lane 3 -- idle from here to
+    // the backward's early launch -- beside the latency-bound utterance-level stages: the Philox launches (VALU-bound, ~100 us of lane
+    // time at C2 where they competed with the frame projections, 23 + 17 + 7 us here) leave the head of the step.  The other set's tag
+    // is cleared before the set is refilled and written behind it, all on this lane; the next call -- the caller flips bits_phase --
+    // reads that set, and its head launch finds the tag on the same lane, behind its fork.
+    c.use(3);
+    uint8_t* const nx = bits_set(c, 1);
+    uint32_t* tag = reinterpret_cast<uint32_t*>(nx);
+    const sdumc_dropout d0 = mkdrop(c, SITE_IN[0][0], c.d.p_frame, pl.segs[0][0].T, D, 0);
+    RET(sdumc_bits_tag_(&d0, tag, -1, c.st));
+    const int order[3] = {0, 2, 1};
+    for (int oi = 0; oi < 3; ++oi) {
+      const int m = order[oi];
+      for (const Seg& sg : pl.segs[m]) {
+        sdumc_dropout d = mkdrop(c, SITE_IN[0][m], c.d.p_frame, sg.T, D, sg.s0);
+        uint8_t* outs[2] = {nx + bits_next_off(pl, 0, m) + sg.row0 * (D / 4), nx + bits_next_off(pl, 1, m) + sg.row0 * (D / 4)};
+        RET(sdumc_dropout_bits_multi_ex_(&d, sg.V / B, 2, SITE_IN[1][m] - SITE_IN[0][m], outs, nullptr, 2, c.st));
+      }
+    }
+    RET(sdumc_bits_tag_(&d0, tag, 2, c.st));
+    c.use(0);
   }
   if (chain) {   // steps 3-7 in one launch
     if (wt_done && hipStreamWaitEvent(c.st, wt_done, 0) != hipSuccess) return SDUMC_ELAUNCH;
@@ -2717,6 +2762,12 @@ StepLayout step_layout(const sdumc_net_dims& d) {
   return s;
 }
 }  // namespace
+
+extern "C" size_t sdumc_net_bits_next_bytes(const sdumc_net_dims* d) {
+  Plan p;
+  if (!d || !d->train || d->bf16 == 2 || !make_plan(*d, p) || p.hf) return 0;
+  return 2 * (size_t)bits_next_off(p, 2, 0);      // (two sets)
+}
 
 extern "C" size_t sdumc_step_workspace_bytes(const sdumc_net_dims* d) {
   if (!d || d->streams != 2) return 0;

@@ -314,7 +314,8 @@ class TrainStep(_OptStateMixin):
     optionally captured into a hipGraph (torch.cuda.CUDAGraph) and replayed."""
 
     def __init__(self, flat_params, B, T, dims, weights=DEFAULT_WEIGHTS, lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=1e-5, seed=0, train=True, sample0=0, bf16=False, share=None, arena=None, ctx=None, planes=None):
+                 weight_decay=1e-5, seed=0, train=True, sample0=0, bf16=False, share=None, arena=None, ctx=None, planes=None,
+                 bits_next=True):
         """share: an object with .params .rng .adam_m .adam_v .hyper .losses (another TrainStep over the SAME flat_params, or
         FusedTrainer's run state) whose optimiser state this step uses instead of allocating its own -- steps of different
         (B, T) shapes then continue one training run.
@@ -388,6 +389,13 @@ class TrainStep(_OptStateMixin):
             self._planes = [torch.empty(t.shape[0] * t.shape[1], 6 * t.shape[2], dtype=torch.uint8, device=dev)
                             for t in (self.audio, self.text, self.video, self.feat4)]
             io.audio_p3, io.text_p3[0], io.video_p3, io.text_p3[1] = (ptr(t) for t in self._planes)
+        # fp32 train steps: a buffer of its own for the NEXT step's keep-bits (generated in this step's idle middle, copied at the next
+        # step's head when its {seed, call} tag matches; bit-identical masks) -- not in the workspace: it must survive whatever else
+        # runs between two steps of this shape
+        nb = lib.sdumc_net_bits_next_bytes(C.byref(self.dims)) if (bits_next and arena is None) else 0      # (an arena's shapes change every step)
+        self._bits_next = torch.zeros(nb, dtype=torch.uint8, device=dev) if nb else None
+        if self._bits_next is not None:
+            io.bits_next = ptr(self._bits_next)
         self.io = io
         cfg = _lib.StepCfg()
         for i, w in enumerate(weights):
@@ -441,6 +449,7 @@ class TrainStep(_OptStateMixin):
     def launch(self, stream=None):
         st = _lib.current_stream() if stream is None else stream
         check(lib.sdumc_train_step(C.byref(self.dims), C.byref(self.io), C.byref(self.cfg), st), "sdumc_train_step")
+        self.io.bits_phase ^= 1      # (the next step reads the keep-bits set this one filled in its middle: sdumc_net_io.bits_next)
 
     def capture(self):
         """Capture one step into a hipGraph; run() then replays it.  For embedding the step in a captured region, not for speed:
@@ -451,6 +460,7 @@ class TrainStep(_OptStateMixin):
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         # the capture itself does not execute; state (params, Adam, rng) is untouched by it
+        self.io.bits_next = None      # (a replayed graph cannot alternate the two keep-bits sets: every replay generates its own)
         with torch.cuda.graph(g, stream=s):
             self.launch()
         self.graph = g

@@ -179,3 +179,40 @@ def test_one_lane_step_equals_the_four_lane_step(E, bf16):
     ctx.close()
     assert torch.equal(four[0], one[0])
     assert torch.equal(four[1], one[1])
+
+
+def test_next_step_keep_bits_are_the_same_bits(E):
+    """sdumc_net_io.bits_next: a train step generates the NEXT step's keep-bits in its middle and the next step copies them when the
+    {seed, call} tag matches.  Ten steps with and without the buffer: losses, gradients and parameters bit for bit; a reset of the
+    call counter (tag mismatch -> generated as ever) and a repeat of the same call (tag match on stale-but-identical bits) included."""
+    dims = (1024, 4096, 1024)
+    lay = E.ParamLayout.get(*dims)
+    g = torch.Generator().manual_seed(11)
+    flat0 = (torch.randn(lay.total, generator=g) * 0.02).cuda()
+    B, T = 8, (130, 32, 70, 32)
+    batch = [torch.randn(B, T[0], 1024, generator=g), torch.randn(B, T[1], 4096, generator=g), torch.randn(B, T[2], 1024, generator=g),
+             torch.randn(B, T[3], 4096, generator=g), torch.randn(B, generator=g)]
+    runs = []
+    for use in (False, True):
+        flat = flat0.clone()
+        ts = E.TrainStep(flat, B, T, dims, seed=5, bits_next=use)
+        assert (ts._bits_next is not None) == use
+        ts.set_batch(*[t.cuda() for t in batch])
+        out = []
+        for step in range(10):
+            if step == 4:
+                ts.rng.set_call(2)          # back to an earlier call: the tag names another one
+            if step == 7:
+                ts.rng.set_call(2 * 6)      # the same call again: the tag matches, the bits are that call's
+            out.append((ts.run().clone(), ts.grads.clone()))
+        if use:      # the tag left behind names the call after the last one: {seed, call + 2, magic}; the buffers behind it are filled
+            half = ts._bits_next.numel() // 2
+            tags = [ts._bits_next[o:o + 16].view(torch.int32).cpu() for o in (0, half)]
+            calls = sorted(int(t[2]) for t in tags)
+            assert calls == [2 * 6 + 2 * 2, 2 * 6 + 2 * 3], calls      # the set the last step read (its own call) and the one it filled (the next)
+            assert all((int(t[3]) & 0xFFFFFFFF) == 0x5D0CB175 for t in tags)
+            assert int(ts._bits_next.count_nonzero()) > ts._bits_next.numel() // 4
+        runs.append((out, flat.clone()))
+    for (la, ga), (lb, gb) in zip(runs[0][0], runs[1][0]):
+        assert torch.equal(la, lb) and torch.equal(ga, gb)
+    assert torch.equal(runs[0][1], runs[1][1])
