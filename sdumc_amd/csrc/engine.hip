@@ -1603,29 +1603,6 @@ int forward(const Ctx& c) {
       RET(link(c, lane, 0));
     }
   }
-  if (pregen) {
-    // The keep-bits of the NEXT call (call index + 2: sdumc_train_step's advance) into the OTHER set, on lane 3 -- idle from here to
-    // the backward's early launch -- beside the latency-bound utterance-level stages: the Philox launches (VALU-bound, ~100 us of lane
-    // time at C2 where they competed with the frame projections, 23 + 17 + 7 us here) leave the head of the step.  The other set's tag
-    // is cleared before the set is refilled and written behind it, all on this lane; the next call -- the caller flips bits_phase --
-    // reads that set, and its head launch finds the tag on the same lane, behind its fork.
-    c.use(3);
-    uint8_t* const nx = bits_set(c, 1);
-    uint32_t* tag = reinterpret_cast<uint32_t*>(nx);
-    const sdumc_dropout d0 = mkdrop(c, SITE_IN[0][0], c.d.p_frame, pl.segs[0][0].T, D, 0);
-    RET(sdumc_bits_tag_(&d0, tag, -1, c.st));
-    const int order[3] = {0, 2, 1};
-    for (int oi = 0; oi < 3; ++oi) {
-      const int m = order[oi];
-      for (const Seg& sg : pl.segs[m]) {
-        sdumc_dropout d = mkdrop(c, SITE_IN[0][m], c.d.p_frame, sg.T, D, sg.s0);
-        uint8_t* outs[2] = {nx + bits_next_off(pl, 0, m) + sg.row0 * (D / 4), nx + bits_next_off(pl, 1, m) + sg.row0 * (D / 4)};
-        RET(sdumc_dropout_bits_multi_ex_(&d, sg.V / B, 2, SITE_IN[1][m] - SITE_IN[0][m], outs, nullptr, 2, c.st));
-      }
-    }
-    RET(sdumc_bits_tag_(&d0, tag, 2, c.st));
-    c.use(0);
-  }
   if (chain) {   // steps 3-7 in one launch
     if (wt_done && hipStreamWaitEvent(c.st, wt_done, 0) != hipSuccess) return SDUMC_ELAUNCH;
     const sdumc_chain_args ca = chain_args(c, true, nullptr, true);
@@ -1702,6 +1679,30 @@ int forward(const Ctx& c) {
   for (int m = 0; m < 3; ++m)
     if (ca_done[m] && hipStreamWaitEvent(c.sts[3], ca_done[m], 0) != hipSuccess) return SDUMC_ELAUNCH;
   RET(link(c, 3, 0));
+  if (pregen) {
+    // The keep-bits of the NEXT call (call index + 2: sdumc_train_step's advance) into the OTHER set, on lane 3 -- idle from here to
+    // the backward's early launch -- beside the latency-bound utterance-level stages: the Philox launches (VALU-bound, ~100 us of lane
+    // time at C2 where they competed with the frame projections, 23 + 17 + 7 us here) leave the head of the step.  The other set's tag
+    // is cleared before the set is refilled and written behind it, all on this lane; the next call -- the caller flips bits_phase --
+    // reads that set, and its head launch finds the tag on the same lane, behind its fork.  Issued BEHIND the event the caller's
+    // stream waits for in front of the Cross_Attention pooling: that wait must not include these launches.
+    c.use(3);
+    uint8_t* const nx = bits_set(c, 1);
+    uint32_t* tag = reinterpret_cast<uint32_t*>(nx);
+    const sdumc_dropout d0 = mkdrop(c, SITE_IN[0][0], c.d.p_frame, pl.segs[0][0].T, D, 0);
+    RET(sdumc_bits_tag_(&d0, tag, -1, c.st));
+    const int order[3] = {0, 2, 1};
+    for (int oi = 0; oi < 3; ++oi) {
+      const int m = order[oi];
+      for (const Seg& sg : pl.segs[m]) {
+        sdumc_dropout d = mkdrop(c, SITE_IN[0][m], c.d.p_frame, sg.T, D, sg.s0);
+        uint8_t* outs[2] = {nx + bits_next_off(pl, 0, m) + sg.row0 * (D / 4), nx + bits_next_off(pl, 1, m) + sg.row0 * (D / 4)};
+        RET(sdumc_dropout_bits_multi_ex_(&d, sg.V / B, 2, SITE_IN[1][m] - SITE_IN[0][m], outs, nullptr, 2, c.st));
+      }
+    }
+    RET(sdumc_bits_tag_(&d0, tag, 2, c.st));
+    c.use(0);
+  }
   if (attn_multi_ok(c)) {
     RET(pool_fwd_multi(c, 1));
   } else {
