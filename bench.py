@@ -56,9 +56,15 @@ WORKLOADS = {   # name: (batch per GPU, T, dims, algorithmic train FLOPs per sam
             "both streams with self-distillation"),
 }
 WORKLOAD_TEXT = WORKLOADS["c2"][4]
-EPOCH_TEXT = ("ragged epoch at BASELINE configs[1] widths: 200 batches of 64 utterances with per-sample lengths U{ceil(T/4)..T}, assembled "
-              "on the device by DeviceFeatureStore.batch_into (right-zero-padded to the batch maximum like read_data.py:223-248) and "
-              "stepped through engine.FusedTrainer inside one capacity-sized arena")
+N_RESIDENT = 4     # distinct batches the timed loop of the default line rotates through
+RESIDENT_TEXT = ("; the timed loop rotates through {k} DISTINCT batches resident in HBM in the layout DeviceFeatureStore(planes=True) holds "
+                 "and gathers (f32 rows for the weight gradients + three-bf16-plane rows, split once when the batch was installed, for the "
+                 "frame projections; bf16 storage: bf16 rows) -- per step only input pointers change, nothing per-batch is outside the clock")
+EPOCH_TEXT = ("ragged epoch at BASELINE configs[1] widths: batches of 64 utterances drawn from a 2048-utterance DeviceFeatureStore with per-sample "
+              "lengths U{ceil(T/4)..T} (f32 rows + bf16 planes split once per dataset; bf16 storage: bf16 rows), every batch right-zero-padded to "
+              "its own maximum like read_data.py:223-248 and assembled ON THE DEVICE by ONE gather launch that the previous step issues beside "
+              "its own middle and backward (engine.FusedTrainer.run_epoch: index vectors uploaded once per epoch, two input sets, next shape's "
+              "keep-bits laid out by the running step), all inside one capacity-sized arena")
 
 
 def source_sha():
@@ -136,9 +142,9 @@ def spawn_ranks(n, timeout_s=None):
     return 0
 
 
-def synthetic_shard(B, rank, seed=1234):
-    """SURVEY §8(d) synthetic inputs (features ~N(0,1), labels ~U(-3,3)); one generator per rank."""
-    g = torch.Generator().manual_seed(seed + rank)
+def synthetic_shard(B, rank, seed=1234, k=0):
+    """SURVEY §8(d) synthetic inputs (features ~N(0,1), labels ~U(-3,3)); one generator per rank (and per resident batch k)."""
+    g = torch.Generator().manual_seed(seed + rank + 7919 * k)
     feats = [torch.randn(B, T_MOSEI[i], DIMS[i], generator=g) for i in range(4)]
     vals = torch.rand(B, generator=g) * 6 - 3
     return feats[0], feats[1], feats[2], feats[3], vals
@@ -199,7 +205,16 @@ def roofline_leg(_lib, launch, steps, traffic_ok=True):
     bf16_kernel = top["kernel"].startswith("gemm_bf16") or top["kernel"].endswith("_bf16")   # bf16-operand / bf16-storage kernels
     split_kernel = top["kernel"].endswith("_bf16x3")                                          # f32 operands, six bf16 MFMA terms per product
     peak = PEAK_BF16_MFMA_TFLOPS if bf16_kernel else round(PEAK_F32_ON_BF16_PIPE_TFLOPS, 1) if split_kernel else PEAK_F32_MFMA_TFLOPS
-    return {"bound": "mfma", "achieved": round(top["tflops"], 2), "peak": peak, "unit": "TFLOP/s",
+    # the profiler's clock for the same kernel, when profiles/rocprof_kernel_avg.json (tools/kstats_summary.py over a rocprofv3
+    # --kernel-trace --stats run of this command with --serial-lanes) was collected on these kernel sources: the two clocks differ by
+    # box and by the profiler's own overhead, so the line carries both and the fraction each gives
+    rp = recorded_rocprof(top["kernel"])
+    rocprof = {}
+    if rp is not None:
+        rp_tf = top["gflop_per_launch"] / (rp["avg_us"] * 1e-6) / 1e3
+        rocprof = {"rocprof_avg_us": rp["avg_us"], "rocprof_calls": rp["calls"], "rocprof_tflops": round(rp_tf, 2),
+                   "frac_rocprof": round(rp_tf / peak, 4), "rocprof_source": rp["source"]}
+    return {"bound": "mfma", "achieved": round(top["tflops"], 2), "peak": peak, "unit": "TFLOP/s", **rocprof,
             "peak_note": ("dense bf16 MFMA peak / 6: this kernel computes every f32 product as six bf16 MFMA terms (f32-equivalent FLOPs counted)"
                           if split_kernel else "dense bf16 MFMA peak" if bf16_kernel else "dense f32 MFMA peak"),
             "frac_of_f32_mfma_peak": round(top["tflops"] / PEAK_F32_MFMA_TFLOPS, 4),
@@ -209,6 +224,36 @@ def roofline_leg(_lib, launch, steps, traffic_ok=True):
             "launches_per_step": top["launches_per_step"],
             "gemm_ms_per_step": round(sum(r["ms_per_step"] for r in rows), 4),
             "all_gemm_variants": [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]}
+
+
+def resident_step(engine, flat, batches, bf16=False, seed=2024, planes=True, bits_next=True):
+    """One TrainStep over an arena with len(batches) input sets, each holding one installed batch (f32 / bf16 rows, and P3 planes in
+    fp32 storage): `run()` points the step at the next set and launches it -- the loop a training epoch over resident features runs."""
+    K = len(batches)
+    arena = engine.StepArena(flat, B_PER_GPU, T_MOSEI, DIMS, bf16=bf16, sets=K, planes=planes, bits_next=bits_next)
+    ts = engine.TrainStep(flat, B_PER_GPU, T_MOSEI, DIMS, seed=seed, bf16=bf16, arena=arena)
+    for k in range(K):
+        ts.use_set(k)
+        ts.set_batch(*batches[k])
+    count = [0]
+
+    def run():
+        ts.use_set(count[0] % K)
+        count[0] += 1
+        ts.launch()
+        return ts.losses
+    return ts, run
+
+
+def timed(run, steps, warmup):
+    for _ in range(warmup):
+        run()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        run()
+    torch.cuda.synchronize()
+    return time.perf_counter() - t0
 
 
 def hbm_roofline_bf16(ms_per_step, mfma):
@@ -234,50 +279,57 @@ def hbm_roofline_bf16(ms_per_step, mfma):
             "kernel": "whole step (HBM-side bytes of every launch)", "mfma": mfma}
 
 
-def c3_bf16_side_leg(engine, flat0, batch, args):
+def c3_bf16_side_leg(engine, flat0, batches, args):
     """BASELINE configs[2] (MOSEI shapes, B = 64, text-missing stream + self-distillation, bf16) under the same clock as the
-    headline: the bf16-storage step on the same batch, same --steps / --warmup, timed the same way, right after the headline's
-    timed region.  A side block of the one JSON line; the headline keys stay those of configs[1]."""
-    step = engine.TrainStep(flat0.clone(), B_PER_GPU, T_MOSEI, DIMS, seed=2024, bf16=True)
-    step.set_batch(*batch)
-    for _ in range(args.warmup):
-        step.run()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step.run()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    headline: the bf16-storage step over the same rotating resident batches, same --steps / --warmup, timed the same way, right after
+    the headline's timed region.  A side block of the one JSON line; the headline keys stay those of configs[1]."""
+    step, run = resident_step(engine, flat0.clone(), batches, bf16=True)
+    dt = timed(run, args.steps, args.warmup)
     losses = step.losses.cpu()
     if not torch.isfinite(losses).all():
         raise SystemExit(f"non-finite loss in the bf16-storage side leg: {losses.tolist()}")
     ms = 1e3 * dt / args.steps
     roof = hbm_roofline_bf16(ms, None)
     roof.pop("mfma", None)
-    return {"workload": "BASELINE configs[2]: the headline's batch in bf16 storage of features / frames / keys / frame-level gradients, "
+    return {"workload": "BASELINE configs[2]: the headline's rotating batches in bf16 storage of features / frames / keys / frame-level gradients, "
                         "f32 accumulation, softmax, utterance-level layers, losses and Adam",
             "value": round(B_PER_GPU * args.steps / dt, 2), "unit": "samples/s", "ms_per_step": round(ms, 4),
             "steps": args.steps, "warmup": args.warmup, "final_loss": round(float(losses[0]), 5), "roofline": roof}
 
 
-def c2_f32_mfma_side_leg(engine, _lib, flat0, batch, args, headline_losses):
+def set_batch_loop_side_leg(engine, flat0, batches, args):
+    """The loop of INTEGRATION.md section 2 -- `for data in loader: step.set_batch(...); step.run()` -- with set_batch INSIDE the clock:
+    every step copies a fresh batch (device to device here: the loader's tensors are already on the GPU) into the step's buffers; planes
+    off (the default of TrainStep: a split for one use costs more than it saves)."""
+    step = engine.TrainStep(flat0.clone(), B_PER_GPU, T_MOSEI, DIMS, seed=2024)
+    K = len(batches)
+    count = [0]
+
+    def run():
+        step.set_batch(*batches[count[0] % K])
+        count[0] += 1
+        step.run()
+    dt = timed(run, args.steps, args.warmup)
+    losses = step.losses.cpu()
+    if not torch.isfinite(losses).all():
+        raise SystemExit(f"non-finite loss in the set_batch-loop side leg: {losses.tolist()}")
+    return {"workload": "the headline's batches through TrainStep.set_batch + run per step (a 224 MB device copy per step inside the clock, "
+                        "no planes: frame projections split in-kernel)",
+            "value": round(B_PER_GPU * args.steps / dt, 2), "unit": "samples/s", "ms_per_step": round(1e3 * dt / args.steps, 4),
+            "steps": args.steps, "warmup": args.warmup, "final_loss": round(float(losses[0]), 5)}
+
+
+def c2_f32_mfma_side_leg(engine, _lib, flat0, batches, args, headline_losses):
     """The headline step with every GEMM product on v_mfma_f32_32x32x2_f32 (sdumc_set_split_(0)): what the default's products on
     the bf16 matrix pipe buy, under the same clock.  It starts from a clone of the INITIAL parameters and runs the same number of
-    steps as the headline, so `loss_abs_diff_vs_headline` is a driver-run cross-check of the split arithmetic against the f32 MFMAs."""
+    steps over the same rotating batches as the headline, so `loss_abs_diff_vs_headline` is a driver-run cross-check of the split
+    arithmetic against the f32 MFMAs."""
     lib = _lib.lib
     prev = split_mask_default()
     try:
         lib.sdumc_set_split_(0)
-        step = engine.TrainStep(flat0.clone(), B_PER_GPU, T_MOSEI, DIMS, seed=2024)
-        step.set_batch(*batch)
-        for _ in range(args.warmup):
-            step.run()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step.run()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        step, run = resident_step(engine, flat0.clone(), batches, planes=False)
+        dt = timed(run, args.steps, args.warmup)
         losses = step.losses.cpu()
     finally:
         lib.sdumc_set_split_(prev)
@@ -304,7 +356,7 @@ def prewarm_leg(engine, flat0, batch, bf16, min_s):
     step object starts from the initial parameters and step counter afterwards."""
     if min_s <= 0:
         return 0.0, 0
-    st = engine.TrainStep(flat0.clone(), B_PER_GPU, T_MOSEI, DIMS, seed=2024, bf16=bf16)
+    st = engine.TrainStep(flat0.clone(), B_PER_GPU, T_MOSEI, DIMS, seed=2024, bf16=bf16, planes=True)
     st.set_batch(*batch)
     t0 = time.perf_counter()
     n = 0
@@ -334,6 +386,24 @@ def recorded_traffic(kernel):
     if doc.get("source_sha") != source_sha():     # collected on other kernel sources: stale, not reported
         return None, f"profiles/pmc_traffic.json is stale (collected on sources {doc.get('source_sha')}, this build is {source_sha()})"
     return k["traffic_bytes"], "profiles/pmc_traffic.json (rocprofv3 PMC passes on these sources, fetch x2 gfx950 correction, average per launch)"
+
+
+def recorded_rocprof(kernel):
+    """Average launch duration of `kernel` from the committed rocprofv3 summary (profiles/rocprof_kernel_avg.json); None when absent
+    or collected on other kernel sources."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "rocprof_kernel_avg.json")
+    try:
+        with open(path) as f:
+            doc = json.load(f)
+        if doc.get("source_sha") != source_sha():
+            return None
+        k = doc["kernels"].get(kernel)
+        if not k:
+            return None
+        return {"avg_us": k["avg_us"], "calls": k["calls"],
+                "source": f"profiles/rocprof_kernel_avg.json <- {doc.get('from')} (rocprofv3 --kernel-trace --stats, serial lanes, these sources)"}
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def cpu_baseline_leg(steps=3):
@@ -376,51 +446,49 @@ def cpu_baseline_leg(steps=3):
             "sec_per_step": round(best, 4)}
 
 
-def epoch_leg(args, engine, flat, lay, dev):
-    """Side measurement (never the driver's default line): one epoch of REAL loader behaviour -- every batch has its own
-    padded shape -- against the static-shape step at the same mean padded frame counts."""
+def epoch_leg(args, engine, flat, lay, dev, bf16=None, nb=None, warmup=None):
+    """One epoch of REAL loader behaviour -- every batch has its own padded shape and is assembled from the resident store inside the
+    clock -- against the static-shape step on one resident batch at the same mean padded frame counts."""
     from sdumc_amd.data import DeviceFeatureStore
-    nb, B = max(args.steps, 1), B_PER_GPU
     from sdumc_amd.engine import bf16_mode
-    store = DeviceFeatureStore.synthetic(2048, T_MOSEI, DIMS, seed=1234, device=dev, bf16=bf16_mode(args.bf16, DIMS) == 2)
+    bf16 = args.bf16 if bf16 is None else bf16
+    nb, B = max(args.steps if nb is None else nb, 1), B_PER_GPU
+    warmup = args.warmup if warmup is None else warmup
+    hf = bf16_mode(bf16, DIMS) == 2
+    store = DeviceFeatureStore.synthetic(2048, T_MOSEI, DIMS, seed=1234, device=dev, bf16=hf, planes=not hf)
     g = torch.Generator().manual_seed(7)
-    batches = [torch.randperm(len(store), generator=g)[:B] for _ in range(nb + args.warmup)]
-    tr = engine.FusedTrainer(flat, DIMS, capacity=(B, T_MOSEI), seed=2024, bf16=args.bf16)
-    shapes = [store.batch_shape(ix)[1] for ix in batches]
-    for ix in batches[:args.warmup]:
-        tr.step_from_store(store, ix)
+    batches = [torch.randperm(len(store), generator=g)[:B] for _ in range(nb + warmup)]
+    tr = engine.FusedTrainer(flat, DIMS, capacity=(B, T_MOSEI), seed=2024, bf16=bf16)
+    plan_w, plan_t = store.plan_epoch(batches[:warmup]) if warmup else None, store.plan_epoch(batches[warmup:])
+    shapes = [sh[1] for sh in (plan_w.shapes if plan_w else [])] + [sh[1] for sh in plan_t.shapes]
+    if plan_w:
+        tr.run_epoch(store, plan_w)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for ix in batches[args.warmup:]:
-        tr.step_from_store(store, ix)
+    tr.run_epoch(store, plan_t)
+    t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     losses = tr.state.losses.cpu()
     if not torch.isfinite(losses).all():
         raise SystemExit(f"non-finite loss: {losses.tolist()}")
-    # the static-shape step at the epoch's mean padded shape (rounded up)
-    timed = shapes[args.warmup:]
-    mean_T = tuple(int(-(-sum(s[i] for s in timed) // len(timed))) for i in range(4))
+    # the static-shape step at the epoch's mean padded shape (rounded up), on one resident batch (planes split once)
+    tshapes = shapes[warmup:]
+    mean_T = tuple(int(-(-sum(s[i] for s in tshapes) // len(tshapes))) for i in range(4))
     flat2 = flat.clone()
-    st = engine.TrainStep(flat2, B, mean_T, DIMS, seed=2024, bf16=args.bf16)
+    st = engine.TrainStep(flat2, B, mean_T, DIMS, seed=2024, bf16=bf16, planes=True)
     gg = torch.Generator(device=dev).manual_seed(3)
     st.set_batch(*[torch.randn(B, mean_T[i], DIMS[i], device=dev, generator=gg) for i in range(4)],
                  torch.rand(B, device=dev, generator=gg) * 6 - 3)
-    for _ in range(args.warmup):
-        st.run()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(nb):
-        st.run()
-    torch.cuda.synchronize()
-    ds = time.perf_counter() - t1
+    ds = timed(st.run, nb, warmup)
     ev, sv = B * nb / dt, B * nb / ds
     return {"metric": "train samples/sec over a ragged epoch (side measurement)", "value": round(ev, 2), "unit": "samples/s",
-            "n_gpus": 1, "steps": nb, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / nb, 4), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16 storage, f32 accumulation" if args.bf16 else "f32", "data": "synthetic",
+            "n_gpus": 1, "steps": nb, "warmup": warmup, "ms_per_step": round(1e3 * dt / nb, 4),
+            "host_enqueue_ms_per_step": round(1e3 * t_enq / nb, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16 storage, f32 accumulation" if bf16 else "f32", "data": "synthetic",
             "config": {"workload": EPOCH_TEXT, "batch_per_gpu": B, "distinct_batch_shapes": len(set(shapes)),
                        "mean_padded_T": list(mean_T), "capacity_T": list(T_MOSEI), "feature_dims": list(DIMS),
-                       "store_utterances": len(store), "cached_steps": len(tr._steps)},
+                       "store_utterances": len(store), "store_gb": round(store.nbytes / 1e9, 2), "cached_steps": len(tr._steps)},
             "static_shape_at_mean_T": {"value": round(sv, 2), "ms_per_step": round(1e3 * ds / nb, 4)},
             "epoch_over_static": round(ev / sv, 4)}
 
@@ -446,7 +514,9 @@ def main():
     ap.add_argument("--prewarm-s", type=float, default=0.3,
                     help="seconds of untimed steps on a throwaway step object before --warmup (clock ramp; 0 = off)")
     ap.add_argument("--no-bits-next", action="store_true", help="A/B: generate every step's keep-bits at its head (no sdumc_net_io.bits_next)")
-    ap.add_argument("--no-side", action="store_true", help="skip the configs[2] (bf16 storage) side leg of the default line (profiling runs)")
+    ap.add_argument("--no-side", action="store_true", help="skip the side legs of the default line (profiling runs)")
+    ap.add_argument("--resident", type=int, default=N_RESIDENT, help="distinct resident batches the timed loop rotates through (single GPU)")
+    ap.add_argument("--epoch-batches", type=int, default=200, help="batches of the ragged-epoch side legs")
     args = ap.parse_args()
     global B_PER_GPU, T_MOSEI, DIMS, TRAIN_FLOPS_PER_SAMPLE, WORKLOAD_TEXT
     epoch = args.workload == "epoch"
@@ -497,20 +567,26 @@ def main():
             raise SystemExit("--workload epoch is a single-GPU side measurement")
         print(json.dumps(epoch_leg(args, engine, flat, lay, dev)), flush=True)
         return
-    batch = [t.to(dev) for t in synthetic_shard(B_PER_GPU, rank)]
+    single = world == 1 and not force_dp
+    rotate = single and not args.graph
+    nres = max(1, args.resident) if rotate else 1
+    batches = [[t.to(dev) for t in synthetic_shard(B_PER_GPU, rank, k=k)] for k in range(nres)]
+    batch = batches[0]
     flat0 = flat.clone()          # the initial parameters: what the side legs start from (the step updates `flat` in place)
     prewarm_s, prewarm_steps = prewarm_leg(engine, flat0, batch, args.bf16, args.prewarm_s)
 
-    if world == 1 and not force_dp:
-        step = engine.TrainStep(flat, B_PER_GPU, T_MOSEI, DIMS, seed=2024, bf16=args.bf16, bits_next=not args.no_bits_next)
+    if rotate:
+        # K distinct batches installed up front in the store's layout; the loop below only switches input pointers between steps
+        step, run = resident_step(engine, flat, batches, bf16=args.bf16, bits_next=not args.no_bits_next)
+    elif single:
+        step = engine.TrainStep(flat, B_PER_GPU, T_MOSEI, DIMS, seed=2024, bf16=args.bf16, bits_next=not args.no_bits_next, planes=True)
         step.set_batch(*batch)
-        if args.graph:
-            step.capture()
+        step.capture()
         run = step.run
     else:
         from sdumc_amd.trainer import DataParallelStep
         step = DataParallelStep(flat, B_PER_GPU, T_MOSEI, DIMS, seed=2024, exact=True, bf16=args.bf16,
-                                force_collectives=force_dp)
+                                force_collectives=force_dp, planes=True)      # (one resident shard per rank)
         step.set_batch(*batch)
         run = step.step
 
@@ -563,7 +639,9 @@ def main():
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": "bf16 storage of features / frames / keys / frame-level gradients with f32 accumulation; f32 softmax, utterance-level layers, losses and Adam (f32 master weights)" if args.bf16 else "f32", "data": "synthetic",
         **({} if args.bf16 else {"arithmetic": F32_ARITHMETIC}),
-        "config": {"workload": ("bf16 storage (--bf16, the dtype of BASELINE configs[2]/[4]) on: " if args.bf16 else "") + WORKLOAD_TEXT,
+        "config": {"workload": ("bf16 storage (--bf16, the dtype of BASELINE configs[2]/[4]) on: " if args.bf16 else "") + WORKLOAD_TEXT
+                               + (RESIDENT_TEXT.format(k=nres) if rotate else "; one resident batch per rank (f32 rows + bf16 planes split when it was installed), replayed"),
+                   "resident_batches": nres,
                    "batch_per_gpu": B_PER_GPU, "global_batch": world * B_PER_GPU,
                    "T_audio_text_video_feat4": list(T_MOSEI), "feature_dims": list(DIMS),
                    "parallelism": f"dp{world}" if world > 1 else ("dp1 (one-rank RCCL communicator, all collectives issued)" if force_dp else "single"),
@@ -575,11 +653,19 @@ def main():
     }
     if dp_extra is not None:
         out["data_parallel"] = dp_extra
-    if world == 1 and not force_dp and args.workload == "c2" and not args.bf16 and not args.graph and not args.serial_lanes and not args.no_side:
-        out["side"] = {"c3_bf16": c3_bf16_side_leg(engine, flat0, batch, args),
-                       "c2_f32_mfma": c2_f32_mfma_side_leg(engine, _lib, flat0, batch, args, losses)}
+    if rotate and args.workload == "c2" and not args.bf16 and not args.serial_lanes and not args.no_side:
+        out["side"] = {"c3_bf16": c3_bf16_side_leg(engine, flat0, batches, args),
+                       "c2_f32_mfma": c2_f32_mfma_side_leg(engine, _lib, flat0, batches, args, losses),
+                       "set_batch_loop": set_batch_loop_side_leg(engine, flat0, batches, args)}
+        # the ragged epoch (every batch assembled from the store inside the clock) in both storage modes, 200 batches each
+        for name, hf in (("epoch", False), ("epoch_bf16", True)):
+            e = epoch_leg(args, engine, flat0.clone(), lay, dev, bf16=hf, nb=args.epoch_batches, warmup=10)
+            out["side"][name] = {k: e[k] for k in ("value", "unit", "ms_per_step", "host_enqueue_ms_per_step", "steps", "warmup", "dtype",
+                                                   "static_shape_at_mean_T", "epoch_over_static")}
+            out["side"][name]["workload"] = e["config"]["workload"]
+            out["side"][name]["config"] = {k: e["config"][k] for k in ("distinct_batch_shapes", "mean_padded_T", "store_utterances", "store_gb")}
     if not args.no_roofline:     # every rank runs it (the DP step has collectives); rank 0 reports
-        roof = roofline_leg(_lib, step.launch if (world == 1 and not force_dp) else step.step, max(3, min(10, args.steps)),
+        roof = roofline_leg(_lib, run if single else step.step, max(3, min(10, args.steps)),
                             traffic_ok=(args.workload == "c2" and not args.bf16))
         if rank == 0:
             out["roofline"] = hbm_roofline_bf16(out["ms_per_step"], roof) if (args.bf16 and args.workload == "c2" and world == 1) else roof

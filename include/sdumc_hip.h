@@ -591,6 +591,34 @@ int sdumc_gather_pad(const float* packed, const int64_t* start, const int32_t* l
 int sdumc_gather_pad_idx(const float* packed, const int64_t* start_all, const int32_t* len_all, const int64_t* idx, int32_t B,
                          int32_t Tmax, int32_t d, float* out, int32_t* len_out, void* stream);
 
+/* A WHOLE batch in one launch (the collater above for every modality at once, toolkit/data/feat_data.py:232-253): up to
+ * SDUMC_GATHER_MAX_SEGS packed tensors -- the four modalities' features and, when the store holds them, their P3 planes
+ * (sdumc_p3_split of the packed tensor, made once per dataset: the planes of a zero row are zero bytes, so gathering plane rows
+ * equals splitting the gathered batch bit for bit) -- into the step's input buffers, the labels (labels_out[b] =
+ * labels_all[idx[b]], both or neither) and the valid frame counts (seg.len_out, optional).  A segment's rows are `d4` 16-byte
+ * units wide (fp32 rows: d / 4; bf16 rows: d / 8; P3 rows: 3 d / 8), whatever they hold.  max_workgroups > 0 caps the grid (the
+ * kernel strides): a capped launch on a side stream fills the NEXT step's buffers beside the running step without queueing in
+ * front of its kernels (sdumc_amd/engine.py, FusedTrainer); 0 = one pass.  seg.unit0 and total are filled by the call. */
+#define SDUMC_GATHER_MAX_SEGS 8
+typedef struct sdumc_gather_seg {
+  const void* packed;        /* [sum T, 16 d4 bytes] */
+  const int64_t* start_all;  /* [N] first row of utterance e */
+  const int32_t* len_all;    /* [N] its frames */
+  void* out;                 /* [B, Tmax, 16 d4 bytes] */
+  int32_t* len_out;          /* optional [B] */
+  int32_t Tmax, d4;
+  int64_t unit0;
+} sdumc_gather_seg;
+typedef struct sdumc_gather_desc {
+  sdumc_gather_seg seg[SDUMC_GATHER_MAX_SEGS];
+  int32_t nseg, B;
+  const int64_t* idx;        /* device [B] */
+  const float* labels_all;   /* [N] or NULL */
+  float* labels_out;         /* [B] or NULL */
+  int64_t total;
+} sdumc_gather_desc;
+int sdumc_gather_batch(const sdumc_gather_desc* g, int32_t max_workgroups, void* stream);
+
 /* ------------------------------------------------------------------------
  * Generic fairseq-style multi-head attention and the pieces of the pre-LN Transformer encoder
  * (toolkit/models/modules/transformers_encoder/, all three files).
@@ -806,10 +834,28 @@ typedef struct sdumc_net_io {
    * for the next call (Philox call index + 2: what sdumc_train_step advances by) and tags it.  The caller flips bits_phase from call
    * to call (forward and backward of one step take the same value); the next call's head launch then finds its set tagged with its
    * own {seed, call} and has nothing to generate -- at the head the Philox launches compete with the frame projections.
-   * Bit-identical masks either way: a set whose tag names another seed or call (first call, a reset counter, a different advance, a
-   * phase that was not flipped) is generated as ever. */
+   * Bit-identical masks either way: a set whose tag names another seed, call or batch shape (first call, a reset counter, a different
+   * advance, a phase that was not flipped, a ragged epoch's next shape that was not announced) is regenerated at the head of the call
+   * that reads it, and re-tagged for that call.
+   * Shapes that change from call to call (toolkit/utils/read_data.py:223-248 pads every batch to its own maximum): the buffer is
+   * sized for the LARGEST dims of the run (bits_next_bytes = sdumc_net_bits_next_bytes of those; 0 = exactly this call's, the set
+   * stride then follows the call's own dims), and bits_next_dims names the dims of the NEXT call (same widths, streams, train and
+   * bf16 fields; B, sample0 and the frame counts may differ; NULL = the same as this call): the middle of this call lays the other
+   * set out for them.
+   * Ordering: sdumc_net_forward returns with the fill of the other set ordered before `stream` (a caller may then advance the
+   * counter, or free / re-zero the buffer, behind `stream`); inside sdumc_train_step that join is left to the backward. */
   void* bits_next;
   int32_t bits_phase;
+  size_t bits_next_bytes;
+  const struct sdumc_net_dims* bits_next_dims;
+  /* Optional: the assembly of the NEXT batch (sdumc_gather_batch's descriptor; its output buffers must not be ones this call reads),
+   * issued by the call itself on an internal lowest-priority stream at the start of its utterance-level middle -- from there to the
+   * end of the backward the chip's HBM is mostly idle (the step is latency- and matrix-bound there), so the 2 x (features + planes)
+   * bytes of a batch move beside the step instead of in front of the next one.  sdumc_train_step (and a sdumc_net_forward on its
+   * own) returns with the gather ordered before `stream`.  prefetch_workgroups caps its grid (0 = 512: two small workgroups per CU
+   * leave every CU room for the step's own kernels).  The descriptor is read during the call only. */
+  const sdumc_gather_desc* prefetch;
+  int32_t prefetch_workgroups;
   /* Optional caller-owned execution context (sdumc_ctx_create): the internal side streams and the event ring the call forks
    * its branches on.  NULL = the default context of the current device (one per device, created on first use).  Two host
    * threads that run steps concurrently -- on distinct streams of one device, or on two devices -- give each its own

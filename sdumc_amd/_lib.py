@@ -133,6 +133,8 @@ class NetIO(C.Structure):
                 ("lengths", C.c_void_p * 4),
                 ("audio_p3", C.c_void_p), ("video_p3", C.c_void_p), ("text_p3", C.c_void_p * 2),   # optional bf16-plane copies of the features
                 ("bits_next", C.c_void_p), ("bits_phase", C.c_int32),   # optional: two sets of keep-bits, the next call's generated in this call's middle
+                ("bits_next_bytes", C.c_size_t), ("bits_next_dims", C.c_void_p),   # its capacity (0 = this call's dims) / dims of the NEXT call (NULL = the same)
+                ("prefetch", C.c_void_p), ("prefetch_workgroups", C.c_int32),      # optional: the NEXT batch's gather descriptor, issued in this call's middle
                 ("ctx", C.c_void_p)]          # optional caller-owned execution context (sdumc_ctx_create); None = device default
 
 
@@ -149,6 +151,19 @@ class StepCfg(C.Structure):
                 ("losses", C.c_void_p),
                 ("B_global", C.c_int32), ("ssd_global", C.c_void_p), ("rnc_feats_global", C.c_void_p),
                 ("rnc_labels_global", C.c_void_p), ("rnc_row0", C.c_int32 * 2)]
+
+
+GATHER_MAX_SEGS = 8
+
+
+class GatherSeg(C.Structure):
+    _fields_ = [("packed", C.c_void_p), ("start_all", C.c_void_p), ("len_all", C.c_void_p), ("out", C.c_void_p),
+                ("len_out", C.c_void_p), ("Tmax", C.c_int32), ("d4", C.c_int32), ("unit0", C.c_int64)]
+
+
+class GatherBatch(C.Structure):
+    _fields_ = [("seg", GatherSeg * GATHER_MAX_SEGS), ("nseg", C.c_int32), ("B", C.c_int32), ("idx", C.c_void_p),
+                ("labels_all", C.c_void_p), ("labels_out", C.c_void_p), ("total", C.c_int64)]
 
 
 class Softmax(C.Structure):
@@ -263,6 +278,7 @@ _SIGS = {
     "sdumc_ctx_set_option": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "sdumc_gather_pad_idx": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                        C.c_void_p, C.c_void_p]),
+    "sdumc_gather_batch": (C.c_int, [C.POINTER(GatherBatch), C.c_int32, C.c_void_p]),
     "sdumc_fill": (C.c_int, [C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
     "sdumc_rng_advance": (C.c_int, [C.c_void_p, C.c_uint32, C.c_void_p]),
     "sdumc_dropout_bits": (C.c_int, [C.POINTER(Dropout), C.c_int32, C.c_void_p, C.c_void_p]),

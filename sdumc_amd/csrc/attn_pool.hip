@@ -1560,18 +1560,12 @@ extern "C" int sdumc_umca_fwd(const sdumc_umca* up, void* stream) {
   if (p.x_drop.enabled && !p.x_drop.bits) return SDUMC_EINVAL;                       // the input mask comes as keep-bits
   if ((p.T + CH - 1) / CH > 4096) return SDUMC_EINVAL;
   if (!p.workspace || p.workspace_bytes < sdumc_attnpool_fwd_workspace_bytes_dim(p.V, p.T, p.nq, D)) return SDUMC_ENOMEM;
-  static std::atomic<uint64_t> attr{0};
-  if (sdumc_first_on_device(attr)) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sdumc_k3::umca_fwd_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            sdumc_k3::LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&sdumc_k3::umca_fwd_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            sdumc_k3::LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&sdumc_k3::umca_fwd_split_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            sdumc_k3::LDS_BYTES) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void*>(&sdumc_k3::umca_fwd_split_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            sdumc_k3::LDS_BYTES) != hipSuccess)
-      return SDUMC_ELAUNCH;
-  }
+  static sdumc_dev_once attr;
+  if (sdumc_once_per_device(attr, [] {
+        return sdumc_set_dyn_lds(&sdumc_k3::umca_fwd_kernel<true>, sdumc_k3::LDS_BYTES) && sdumc_set_dyn_lds(&sdumc_k3::umca_fwd_kernel<false>, sdumc_k3::LDS_BYTES) &&
+               sdumc_set_dyn_lds(&sdumc_k3::umca_fwd_split_kernel<true>, sdumc_k3::LDS_BYTES) && sdumc_set_dyn_lds(&sdumc_k3::umca_fwd_split_kernel<false>, sdumc_k3::LDS_BYTES);
+      }) != SDUMC_OK)
+    return SDUMC_ELAUNCH;
   hipStream_t st = as_stream(stream);
   const int nchunk = (p.T + CH - 1) / CH;
   const dim3 grid(nchunk, p.V), blk(256);
@@ -1579,14 +1573,11 @@ extern "C" int sdumc_umca_fwd(const sdumc_umca* up, void* stream) {
     if (!sdumc_split_on_(SDUMC_SPLIT_UMCA)) return SDUMC_EINVAL;                      // planes ARE the split arithmetic
     if ((reinterpret_cast<uintptr_t>(u.x_p3) | reinterpret_cast<uintptr_t>(u.w_in_p3f)) & 15) return SDUMC_EINVAL;
     if (p.x_drop.enabled && (qw_of(p.x_drop) & 3)) return SDUMC_EINVAL;
-    static std::atomic<uint64_t> attr_p3{0};
-    if (sdumc_first_on_device(attr_p3)) {
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sdumc_k3::umca_fwd_p3_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              sdumc_k3::LDS_BYTES) != hipSuccess ||
-          hipFuncSetAttribute(reinterpret_cast<const void*>(&sdumc_k3::umca_fwd_p3_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              sdumc_k3::LDS_BYTES) != hipSuccess)
-        return SDUMC_ELAUNCH;
-    }
+    static sdumc_dev_once attr_p3;
+    if (sdumc_once_per_device(attr_p3, [] {
+          return sdumc_set_dyn_lds(&sdumc_k3::umca_fwd_p3_kernel<true>, sdumc_k3::LDS_BYTES) && sdumc_set_dyn_lds(&sdumc_k3::umca_fwd_p3_kernel<false>, sdumc_k3::LDS_BYTES);
+        }) != SDUMC_OK)
+      return SDUMC_ELAUNCH;
     if (p.x_drop.enabled) hipLaunchKernelGGL(sdumc_k3::umca_fwd_p3_kernel<true>, grid, blk, sdumc_k3::LDS_BYTES, st, u, nchunk);
     else hipLaunchKernelGGL(sdumc_k3::umca_fwd_p3_kernel<false>, grid, blk, sdumc_k3::LDS_BYTES, st, u, nchunk);
   } else if (sdumc_split_on_(SDUMC_SPLIT_UMCA)) {

@@ -589,14 +589,14 @@ extern "C" int sdumc_chain_launch_(const sdumc_chain_args* a, int which, void* s
   if (!a || a->V <= 0 || which < 0 || which > 3) return SDUMC_EINVAL;
   constexpr int R = 2;
   typedef unsigned short bf;
-  static std::atomic<uint64_t> attr{0};
-  if (sdumc_first_on_device(attr)) {
-    if (set_smem(chain_fwd_a_kernel<R, float>, smem_fwd_a<R>()) || set_smem(chain_fwd_b_kernel<R, float>, smem_fwd_b<R>()) ||
-        set_smem(chain_bwd_b_kernel<R, float>, smem_bwd_b<R>()) || set_smem(chain_bwd_a_kernel<R, float>, smem_bwd_a<R>()) ||
-        set_smem(chain_fwd_a_kernel<R, bf>, smem_fwd_a<R>()) || set_smem(chain_fwd_b_kernel<R, bf>, smem_fwd_b<R>()) ||
-        set_smem(chain_bwd_b_kernel<R, bf>, smem_bwd_b<R>()) || set_smem(chain_bwd_a_kernel<R, bf>, smem_bwd_a<R>()))
-      return SDUMC_ELAUNCH;
-  }
+  static sdumc_dev_once attr;
+  if (sdumc_once_per_device(attr, [] {
+        return !(set_smem(chain_fwd_a_kernel<R, float>, smem_fwd_a<R>()) || set_smem(chain_fwd_b_kernel<R, float>, smem_fwd_b<R>()) ||
+                 set_smem(chain_bwd_b_kernel<R, float>, smem_bwd_b<R>()) || set_smem(chain_bwd_a_kernel<R, float>, smem_bwd_a<R>()) ||
+                 set_smem(chain_fwd_a_kernel<R, bf>, smem_fwd_a<R>()) || set_smem(chain_fwd_b_kernel<R, bf>, smem_fwd_b<R>()) ||
+                 set_smem(chain_bwd_b_kernel<R, bf>, smem_bwd_b<R>()) || set_smem(chain_bwd_a_kernel<R, bf>, smem_bwd_a<R>()));
+      }) != SDUMC_OK)
+    return SDUMC_ELAUNCH;
   const dim3 grid((a->V + R - 1) / R), blk(NTHR);
   hipStream_t st = as_stream(stream);
   // (one entry point per stage and weight type: the whole device build carries no packed fp32 operations -- Makefile, NOPACK --,

@@ -14,15 +14,32 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 static inline hipStream_t as_stream(void* s) { return (hipStream_t)s; }
 
-// The dynamic-LDS limit of a kernel is a PER-DEVICE function attribute: `done` holds one bit per device; true the first time the
-// current device asks (a process that drives several GPUs sets the attribute on each of them).
+// The dynamic-LDS limit of a kernel is a PER-DEVICE function attribute (a process that drives several GPUs sets it on each of
+// them).  sdumc_once_per_device runs `setup` (returns true on success) the first time the CURRENT device asks: under a lock, and the
+// device's bit is set only AFTER the setup has succeeded -- a second host thread on the same device either finds the attribute applied
+// or waits for it, and a failed setup is retried by the next call instead of being remembered as done.
 #ifdef __cplusplus
 #include <atomic>
-static inline bool sdumc_first_on_device(std::atomic<uint64_t>& done) {
+#include <mutex>
+struct sdumc_dev_once {
+  std::mutex mu;
+  std::atomic<uint64_t> done{0};
+};
+template <class F>
+static inline int sdumc_once_per_device(sdumc_dev_once& o, F&& setup) {
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return setup() ? SDUMC_OK : SDUMC_ELAUNCH;   // (idempotent: set again)
   const uint64_t bit = 1ull << dev;
-  return (done.fetch_or(bit) & bit) == 0;
+  if (o.done.load(std::memory_order_acquire) & bit) return SDUMC_OK;
+  std::lock_guard<std::mutex> lk(o.mu);
+  if (o.done.load(std::memory_order_relaxed) & bit) return SDUMC_OK;
+  if (!setup()) return SDUMC_ELAUNCH;
+  o.done.fetch_or(bit, std::memory_order_release);
+  return SDUMC_OK;
+}
+template <class K>
+static inline bool sdumc_set_dyn_lds(K kernel, size_t bytes) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess;
 }
 #endif
 
@@ -125,9 +142,13 @@ const int32_t* sdumc_chain_cluster_err_ptr_(void);    // device address of the e
 // dst[off ..] = transpose of the n listed [out][in] matrices of src (same offsets in both buffers)
 // fp32 parameters -> bf16 copies as stored (dst) and, where want_t[i], transposed (dst_t); same element offsets as in src
 int sdumc_gemm_small_tn_multi_(const sdumc_gemm* gs, int n, void* stream);
+// the shape words of a keep-bits tag: {B, sample0, Ta, Tv, Tt[0], Tt[1]} of the call the set is laid out for
+struct sdumc_bits_shape {
+  uint32_t w[6];
+};
 int sdumc_dropout_bits_multi_ex_(const sdumc_dropout* d, int32_t streams, int32_t nsite, int32_t site_stride, uint8_t* const* bits,
-                                 const uint32_t* tag, int32_t call_add, void* stream);
-int sdumc_bits_tag_(const sdumc_dropout* d, uint32_t* tag, int32_t call_add, void* stream);
+                                 const uint32_t* tag, int32_t call_add, const struct sdumc_bits_shape* shape, void* stream);
+int sdumc_bits_tag_(const sdumc_dropout* d, uint32_t* tag, int32_t call_add, const struct sdumc_bits_shape* shape, void* stream);
 int sdumc_weights_to_bf16_(const float* src, void* dst, void* dst_t, const int64_t* offs, const int32_t* outs, const int32_t* ins,
                            const int32_t* want_t, int n, void* stream);
 size_t sdumc_gg_slab_bytes_(int tiles);   // gemm_group.hip: workspace bound for sdumc_gemm_group_tn by output-tile count

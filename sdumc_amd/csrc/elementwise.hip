@@ -2,6 +2,7 @@
 // network (model :293-368) and of its backward.  All HBM/L2-streaming: 16-B accesses where the
 // layout allows, wave64 shuffles for the per-sample dot products.
 #include <algorithm>
+#include <cstring>
 
 #include "common.h"
 
@@ -123,6 +124,53 @@ __global__ void gather_pad_idx_kernel(const float* packed, const int64_t* start_
   if (len_out && t == 0 && c == 0) len_out[b] = n < Tmax ? n : Tmax;
 }
 
+// One launch assembles a WHOLE batch: up to SDUMC_GATHER_MAX_SEGS packed tensors (the four modalities' features, and their bf16
+// planes when the store holds them) gathered / right-zero-padded into the step's input buffers, plus the labels and the valid frame
+// counts.  Grid-stride over 16-byte units with four independent loads in flight per thread and a CAPPED number of workgroups: the
+// launch is meant to run on a side stream BESIDE the previous step (engine.FusedTrainer prefetches the next batch), where an
+// uncapped grid would queue tens of thousands of workgroups in front of the step's own kernels.
+__global__ __launch_bounds__(256) void gather_batch_kernel(const sdumc_gather_desc g) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i0 < g.B) {
+    const int64_t e = g.idx[i0];
+    if (g.labels_out) g.labels_out[i0] = g.labels_all[e];
+    for (int s = 0; s < g.nseg; ++s)
+      if (g.seg[s].len_out) {
+        const int n = g.seg[s].len_all[e];
+        g.seg[s].len_out[i0] = n < g.seg[s].Tmax ? n : g.seg[s].Tmax;
+      }
+  }
+  for (int64_t i = i0; i < g.total; i += 4 * stride) {
+    f32x4 v[4];
+    int64_t dst[4];
+    int sid[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int64_t j = i + u * stride;
+      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+      sid[u] = -1;
+      dst[u] = 0;
+      if (j < g.total) {
+        int s = 0;
+        while (s + 1 < g.nseg && g.seg[s + 1].unit0 <= j) ++s;
+        const sdumc_gather_seg& sg = g.seg[s];
+        const int64_t l = j - sg.unit0;
+        const int c = (int)(l % sg.d4);
+        const int64_t r = l / sg.d4;
+        const int t = (int)(r % sg.Tmax), b = (int)(r / sg.Tmax);
+        const int64_t e = g.idx[b];
+        sid[u] = s;
+        dst[u] = l;
+        if (t < sg.len_all[e]) v[u] = ld4(static_cast<const float*>(sg.packed) + ((size_t)(sg.start_all[e] + t) * sg.d4 + c) * 4);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (sid[u] >= 0) st4(static_cast<float*>(g.seg[sid[u]].out) + 4 * dst[u], v[u]);
+  }
+}
+
 // ---- bf16-storage mode helpers ---------------------------------------------------------------------------------------
 // xd[row, :] = bf16( x[row % x_rows, :] * keep * scale ): the masked frames of one (site, stream set), materialised once so
 // that every consumer (key projection, pooling, their backward) reads plain bf16 rows.  One thread per 8 channels.
@@ -222,12 +270,22 @@ struct BitsOut {
 // `call_add`: the keep-bits of the call that many Philox calls AHEAD (the next step's, generated in this step's idle middle).
 // `tag`: the {seed, call, magic} the buffers were last filled for: when it names the call this launch is for, there is nothing to do
 // (the launch is a tag read per thread); any other tag: generated as ever.
+// The tag also names the SHAPE the set was laid out for (sdumc_bits_shape: batch, shard offset, frames per modality): the keep-bit of
+// (sample, frame, channel) does not depend on the batch's padded lengths, but its position in the buffer does, so a set filled for
+// another shape is a foreign set (a ragged epoch changes shape from step to step).
+__device__ __forceinline__ bool bits_tag_matches(const uint32_t* __restrict__ tag, const DropRT& r, const sdumc_bits_shape& sh) {
+  if (!(tag[0] == r.k0 && tag[1] == r.k1 && tag[2] == r.call0 && tag[3] == 0x5D0Cb175u)) return false;
+#pragma unroll
+  for (int i = 0; i < 6; ++i)
+    if (tag[4 + i] != sh.w[i]) return false;
+  return true;
+}
 __global__ void dropout_bits_kernel(const sdumc_dropout d, int64_t nwords, int nsite, int site_stride, BitsOut out,
-                                    const uint32_t* __restrict__ tag, int call_add) {
+                                    const uint32_t* __restrict__ tag, int call_add, const sdumc_bits_shape shape) {
   DropRT r0 = drop_resolve(d);
   r0.bits = nullptr;   // always from Philox
   r0.call0 += (uint32_t)call_add;
-  if (tag != nullptr && tag[0] == r0.k0 && tag[1] == r0.k1 && tag[2] == r0.call0 && tag[3] == 0x5D0Cb175u) return;
+  if (tag != nullptr && bits_tag_matches(tag, r0, shape)) return;
   const uint32_t wpr = r0.qwidth >> 2;                     // 32-bit words per row
   // (grid-stride: with a tag the launch is capped at 1024 workgroups -- as fast when it generates, a third of the workgroups to
   //  retire when it has nothing to do)
@@ -247,13 +305,16 @@ __global__ void dropout_bits_kernel(const sdumc_dropout d, int64_t nwords, int n
   }
 }
 
-// the tag of pre-generated keep-bits: {seed_lo, seed_hi, call, magic}; call_add < 0: invalidate (written before the buffers are refilled)
-__global__ void bits_tag_kernel(const sdumc_dropout d, uint32_t* tag, int call_add) {
+// the tag of pre-generated keep-bits: {seed_lo, seed_hi, call, magic, shape[6]}; call_add < 0: invalidate (written before the buffers
+// are refilled)
+__global__ void bits_tag_kernel(const sdumc_dropout d, uint32_t* tag, int call_add, const sdumc_bits_shape shape) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const DropRT r = drop_resolve(d);
   tag[0] = r.k0;
   tag[1] = r.k1;
   tag[2] = r.call0 + (uint32_t)(call_add < 0 ? 0 : call_add);
+#pragma unroll
+  for (int i = 0; i < 6; ++i) tag[4 + i] = shape.w[i];
   tag[3] = call_add < 0 ? 0u : 0x5D0Cb175u;
 }
 
@@ -518,6 +579,28 @@ extern "C" int sdumc_gather_pad_idx(const float* packed, const int64_t* start_al
   return SDUMC_OK;
 }
 
+extern "C" int sdumc_gather_batch(const sdumc_gather_desc* gp, int32_t max_workgroups, void* stream) {
+  if (!gp || gp->nseg < 1 || gp->nseg > SDUMC_GATHER_MAX_SEGS || gp->B <= 0 || !gp->idx) return SDUMC_EINVAL;
+  if ((gp->labels_out != nullptr) != (gp->labels_all != nullptr)) return SDUMC_EINVAL;
+  sdumc_gather_desc g = *gp;
+  int64_t total = 0;
+  for (int s = 0; s < g.nseg; ++s) {
+    sdumc_gather_seg& sg = g.seg[s];
+    if (!sg.packed || !sg.start_all || !sg.len_all || !sg.out || sg.Tmax <= 0 || sg.d4 <= 0) return SDUMC_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(sg.packed) | reinterpret_cast<uintptr_t>(sg.out)) & 15) return SDUMC_EINVAL;
+    sg.unit0 = total;
+    total += (int64_t)g.B * sg.Tmax * sg.d4;
+  }
+  g.total = total;
+  int64_t blocks = (total + 4 * 256 - 1) / (4 * 256);
+  if (max_workgroups > 0 && blocks > max_workgroups) blocks = max_workgroups;
+  if (blocks < (g.B + 255) / 256) blocks = (g.B + 255) / 256;
+  if (blocks > 0x7FFFFFFF) return SDUMC_EINVAL;
+  hipLaunchKernelGGL(gather_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), g);
+  SDUMC_CHECK_LAUNCH();
+  return SDUMC_OK;
+}
+
 extern "C" int sdumc_gather_pad(const float* packed, const int64_t* start, const int32_t* len, int32_t B, int32_t Tmax,
                                 int32_t d, float* out, void* stream) {
   if (!packed || !start || !len || !out || B <= 0 || Tmax <= 0 || d <= 0 || (d & 3)) return SDUMC_EINVAL;
@@ -563,7 +646,8 @@ extern "C" int sdumc_dropout_mask(const sdumc_dropout* d, int32_t streams, float
 
 // tag: the launch is a no-op when it names this call (see the kernel); call_add: generate for the call that many ahead
 extern "C" int sdumc_dropout_bits_multi_ex_(const sdumc_dropout* d, int32_t streams, int32_t nsite, int32_t site_stride,
-                                            uint8_t* const* bits, const uint32_t* tag, int32_t call_add, void* stream) {
+                                            uint8_t* const* bits, const uint32_t* tag, int32_t call_add, const sdumc_bits_shape* shape,
+                                            void* stream) {
   if (!d || !bits || streams < 1 || nsite < 1 || nsite > 4 || (d->width & 15) || d->width == 0) return SDUMC_EINVAL;
   BitsOut out;
   for (int s = 0; s < 4; ++s) {
@@ -574,18 +658,24 @@ extern "C" int sdumc_dropout_bits_multi_ex_(const sdumc_dropout* d, int32_t stre
   constexpr unsigned cap = 1024;      // (with a tag: 1.2536-1.2572 ms per fp32 C2 step; uncapped 1.255-1.2617; 512 / 256: 1.257-1.2594)
   unsigned grid = (unsigned)nblk(nwords);
   if (tag && grid > cap) grid = cap;
+  sdumc_bits_shape sh;
+  memset(&sh, 0, sizeof(sh));
+  if (shape) sh = *shape;
   hipLaunchKernelGGL(dropout_bits_kernel, dim3(grid), dim3(256), 0, as_stream(stream), *d, nwords, nsite,
-                     site_stride, out, tag, call_add);
+                     site_stride, out, tag, call_add, sh);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
 }
 extern "C" int sdumc_dropout_bits_multi(const sdumc_dropout* d, int32_t streams, int32_t nsite, int32_t site_stride,
                                         uint8_t* const* bits, void* stream) {
-  return sdumc_dropout_bits_multi_ex_(d, streams, nsite, site_stride, bits, nullptr, 0, stream);
+  return sdumc_dropout_bits_multi_ex_(d, streams, nsite, site_stride, bits, nullptr, 0, nullptr, stream);
 }
-extern "C" int sdumc_bits_tag_(const sdumc_dropout* d, uint32_t* tag, int32_t call_add, void* stream) {
+extern "C" int sdumc_bits_tag_(const sdumc_dropout* d, uint32_t* tag, int32_t call_add, const sdumc_bits_shape* shape, void* stream) {
   if (!d || !tag) return SDUMC_EINVAL;
-  hipLaunchKernelGGL(bits_tag_kernel, dim3(1), dim3(64), 0, as_stream(stream), *d, tag, call_add);
+  sdumc_bits_shape sh;
+  memset(&sh, 0, sizeof(sh));
+  if (shape) sh = *shape;
+  hipLaunchKernelGGL(bits_tag_kernel, dim3(1), dim3(64), 0, as_stream(stream), *d, tag, call_add, sh);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;
 }

@@ -446,6 +446,8 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
 struct LaneSet {
   hipStream_t s[2] = {nullptr, nullptr};
   hipStream_t bg = nullptr;   // lane 3: dW batches, keep-bits, the forward Cross_Attention key GEMMs
+  hipStream_t pf = nullptr;   // lowest priority: the next batch's assembly (sdumc_net_io.prefetch), beside the step's middle and backward
+  hipEvent_t pf_done = nullptr;
   static constexpr unsigned NEV = 256;
   hipEvent_t ev[NEV];
   std::atomic<unsigned> next{0};
@@ -484,7 +486,6 @@ bool create_lanes(LaneSet& S) {
   if (hipGetDevice(&S.device) != hipSuccess) return false;
   int least = 0, greatest = 0;
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return false;
-  (void)least;
   const int prio = greatest;
   for (int i = 0; i < 2; ++i)
     if (hipStreamCreateWithPriority(&S.s[i], hipStreamNonBlocking, prio) != hipSuccess) return false;
@@ -493,6 +494,8 @@ bool create_lanes(LaneSet& S) {
   // (lane 3 at the lowest priority, so that the grouped weight-gradient launches would only fill what the critical lanes
   //  leave: measured 1.877 vs 1.784 ms per step -- the launches then start late and end up as the step's tail)
   if (hipStreamCreateWithPriority(&S.bg, hipStreamNonBlocking, prio) != hipSuccess) return false;
+  if (hipStreamCreateWithPriority(&S.pf, hipStreamNonBlocking, least) != hipSuccess) return false;
+  if (hipEventCreateWithFlags(&S.pf_done, hipEventDisableTiming) != hipSuccess) return false;
   S.ok = true;
   return true;
 }
@@ -500,6 +503,8 @@ void destroy_lanes(LaneSet& S) {
   for (int i = 0; i < 2; ++i)
     if (S.s[i]) { (void)sdumc_chain_cluster_forget_stream_(S.s[i]); (void)hipStreamDestroy(S.s[i]); }
   if (S.bg) { (void)sdumc_chain_cluster_forget_stream_(S.bg); (void)hipStreamDestroy(S.bg); }
+  if (S.pf) (void)hipStreamDestroy(S.pf);
+  if (S.pf_done) (void)hipEventDestroy(S.pf_done);
   if (S.ok)
     for (unsigned i = 0; i < LaneSet::NEV; ++i) (void)hipEventDestroy(S.ev[i]);
   S.ok = false;
@@ -645,8 +650,21 @@ int64_t bits_next_off(const Plan& pl, int k, int m) {
   return (off + 255) & ~(int64_t)255;
 }
 bool bits_pregen(const Ctx& c) { return c.io.bits_next != nullptr && c.d.train && !c.h() && c.d.p_frame > 0.0; }
+// (a buffer sized for the run's largest dims keeps its two sets half the buffer apart whatever the call's own shape is)
+int64_t bits_set_stride(const Ctx& c) { return c.io.bits_next_bytes ? (int64_t)((c.io.bits_next_bytes / 2) & ~(size_t)255) : bits_next_off(c.pl, 2, 0); }
 uint8_t* bits_set(const Ctx& c, int other) {
-  return static_cast<uint8_t*>(c.io.bits_next) + (((c.io.bits_phase & 1) ^ other) ? bits_next_off(c.pl, 2, 0) : 0);
+  return static_cast<uint8_t*>(c.io.bits_next) + (((c.io.bits_phase & 1) ^ other) ? bits_set_stride(c) : 0);
+}
+// the shape words of a keep-bits tag (elementwise.hip): a set laid out for another batch shape or shard offset is a foreign set
+sdumc_bits_shape bits_shape(const sdumc_net_dims& d) {
+  sdumc_bits_shape sh;
+  sh.w[0] = (uint32_t)d.B;
+  sh.w[1] = (uint32_t)d.sample0;
+  sh.w[2] = (uint32_t)d.Ta;
+  sh.w[3] = (uint32_t)d.Tv;
+  sh.w[4] = (uint32_t)d.Tt[0];
+  sh.w[5] = (uint32_t)(d.streams == 2 ? d.Tt[1] : 0);
+  return sh;
 }
 // where the keep-bits of attention site (k, m) live for this call
 uint8_t* bits_ptr(const Ctx& c, int k, int m) {
@@ -906,6 +924,13 @@ int lin_bwd_grouped(const Ctx& c, const Lin* L, int ng, int M, const GroupPtrs& 
   return SDUMC_OK;
 }
 
+// bytes of ONE keep-bits set of sdumc_net_io.bits_next for dims `d` (= bits_next_off(plan, 2, 0) without building the plan)
+size_t bits_set_bytes(const sdumc_net_dims& d) {
+  const int64_t V = (int64_t)d.B * d.streams;
+  const int64_t rows = V * d.Ta + V * d.Tv + (int64_t)d.B * (d.Tt[0] + (d.streams == 2 ? d.Tt[1] : 0));
+  return (size_t)((64 + 2 * rows * (D / 4) + 255) & ~(int64_t)255);
+}
+
 int check_io(const sdumc_net_dims* d, const sdumc_net_io* io) {
   if (!d || !io) return SDUMC_EINVAL;
   if (!io->audio || !io->video || !io->text[0] || !io->params || !io->workspace) return SDUMC_EINVAL;
@@ -914,6 +939,16 @@ int check_io(const sdumc_net_dims* d, const sdumc_net_io* io) {
   if (reinterpret_cast<uintptr_t>(io->workspace) & 255) return SDUMC_EINVAL;
   if (reinterpret_cast<uintptr_t>(io->params) & 15) return SDUMC_EINVAL;
   if (reinterpret_cast<uintptr_t>(io->bits_next) & 15) return SDUMC_EINVAL;
+  if (io->bits_next && d->train && d->bf16 != 2) {
+    const sdumc_net_dims* nd = io->bits_next_dims;
+    if (nd && (nd->streams != d->streams || nd->da != d->da || nd->dt != d->dt || nd->dv != d->dv || nd->train != d->train || nd->bf16 != d->bf16 ||
+               nd->p_frame != d->p_frame))
+      return SDUMC_EINVAL;
+    if (nd && (nd->B <= 0 || nd->Ta <= 0 || nd->Tv <= 0 || nd->Tt[0] <= 0 || (nd->streams == 2 && nd->Tt[1] <= 0))) return SDUMC_EINVAL;
+    // a set must fit its half of a stated capacity; with none stated the buffer is exactly this call's size
+    const size_t half = io->bits_next_bytes ? ((io->bits_next_bytes / 2) & ~(size_t)255) : bits_set_bytes(*d);
+    if (bits_set_bytes(*d) > half || (nd && bits_set_bytes(*nd) > half)) return SDUMC_ENOMEM;
+  }
   if (io->ctx) {   // a caller-owned context belongs to the device it was created on
     int dev = -1;
     if (hipGetDevice(&dev) != hipSuccess || static_cast<const LaneSet*>(io->ctx)->device != dev) return SDUMC_EINVAL;
@@ -1408,6 +1443,29 @@ sdumc_chain_args chain_args(const Ctx& c, bool fwd, const sdumc_net_grads* og, b
   return a;
 }
 
+// sdumc_net_io.prefetch: the next batch's gather on the lane set's lowest-priority stream, behind what the caller's stream has issued
+// so far (the frame-level head of this call: its projections are the step's heaviest HBM readers).  Without real lanes (concurrency
+// off, capture) it runs on the caller's stream, in place.
+int issue_prefetch(const Ctx& c) {
+  if (!c.io.prefetch) return SDUMC_OK;
+  const int wgs = c.io.prefetch_workgroups > 0 ? c.io.prefetch_workgroups : 512;
+  if (!c.multi || c.capturing || !c.lanes || !c.lanes->pf) return sdumc_gather_batch(c.io.prefetch, wgs, c.sts[0]);
+  hipEvent_t e = next_event(c);
+  if (hipEventRecord(e, c.sts[0]) != hipSuccess || hipStreamWaitEvent(c.lanes->pf, e, 0) != hipSuccess) return SDUMC_ELAUNCH;
+  return sdumc_gather_batch(c.io.prefetch, wgs, c.lanes->pf);
+}
+// ... and its completion ordered before the caller's stream (end of sdumc_train_step / of a forward on its own)
+int join_prefetch(const sdumc_net_io* io, hipStream_t stream) {
+  if (!io->prefetch) return SDUMC_OK;
+  LaneSet* S = io->ctx ? static_cast<LaneSet*>(io->ctx) : default_lanes();
+  if (!S || !S->pf) return SDUMC_OK;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) return SDUMC_OK;   // (issued in place: issue_prefetch)
+  // (one event per lane set: a context is driven by one thread at a time, and the record / wait pair is issued back to back)
+  if (hipEventRecord(S->pf_done, S->pf) != hipSuccess || hipStreamWaitEvent(stream, S->pf_done, 0) != hipSuccess) return SDUMC_ELAUNCH;
+  return SDUMC_OK;
+}
+
 int forward(const Ctx& c) {
   const Plan& pl = c.pl;
   const ParamMap& pm = c.pm;
@@ -1470,6 +1528,7 @@ int forward(const Ctx& c) {
   // projection on the modality's own lane (one pass over x instead of a bits launch on lane 3 plus one mask_apply per site)
   const bool bits_with_xd = c.h() && c.d.train;
   const bool pregen = bits_pregen(c);
+  const sdumc_bits_shape shape_now = bits_shape(c.d);
   if (c.d.train && !bits_with_xd) {
     RET(link(c, 0, 3));
     c.use(3);
@@ -1479,14 +1538,21 @@ int forward(const Ctx& c) {
       for (const Seg& sg : pl.segs[m]) {   // both sites (fra2utt_m, cross_att_fra2utt_m) in one launch
         sdumc_dropout d = mkdrop(c, SITE_IN[0][m], c.d.p_frame, sg.T, D, sg.s0);
         uint8_t* outs[2] = {bits_ptr(c, 0, m) + sg.row0 * (D / 4), bits_ptr(c, 1, m) + sg.row0 * (D / 4)};
-        // (bits_next: nothing to do when the previous call filled this set for this call -- its tag says so)
+        // (bits_next: nothing to do when the previous call filled this set for this call and shape -- its tag says so)
         RET(sdumc_dropout_bits_multi_ex_(&d, sg.V / B, 2, SITE_IN[1][m] - SITE_IN[0][m], outs,
-                                         pregen ? reinterpret_cast<const uint32_t*>(bits_set(c, 0)) : nullptr, 0, c.st));
+                                         pregen ? reinterpret_cast<const uint32_t*>(bits_set(c, 0)) : nullptr, 0, &shape_now, c.st));
       }
       if (c.sts[3] != c.sts[LANE_OF[m]]) {
         bits_done[m] = next_event(c);
         if (hipEventRecord(bits_done[m], c.st) != hipSuccess) return SDUMC_ELAUNCH;
       }
+    }
+    if (pregen) {
+      // Whatever the set's tag said, the set now holds THIS call's masks: say so (behind the three launches that read the tag, on their
+      // lane).  A set regenerated under a foreign tag would otherwise keep naming the call it was once filled for, and a counter that
+      // comes back to that value (a rewind, a phase that was not flipped) would find stale masks under a matching tag.
+      const sdumc_dropout d0 = mkdrop(c, SITE_IN[0][0], c.d.p_frame, pl.segs[0][0].T, D, 0);
+      RET(sdumc_bits_tag_(&d0, reinterpret_cast<uint32_t*>(bits_set(c, 0)), 0, &shape_now, c.st));
     }
   }
   hipEvent_t fra_done[3] = {nullptr, nullptr, nullptr}, ca_done[3] = {nullptr, nullptr, nullptr};
@@ -1603,6 +1669,7 @@ int forward(const Ctx& c) {
       RET(link(c, lane, 0));
     }
   }
+  RET(issue_prefetch(c));      // the NEXT batch's assembly, beside everything from here on (sdumc_net_io.prefetch)
   if (chain) {   // steps 3-7 in one launch
     if (wt_done && hipStreamWaitEvent(c.st, wt_done, 0) != hipSuccess) return SDUMC_ELAUNCH;
     const sdumc_chain_args ca = chain_args(c, true, nullptr, true);
@@ -1689,18 +1756,30 @@ int forward(const Ctx& c) {
     c.use(3);
     uint8_t* const nx = bits_set(c, 1);
     uint32_t* tag = reinterpret_cast<uint32_t*>(nx);
-    const sdumc_dropout d0 = mkdrop(c, SITE_IN[0][0], c.d.p_frame, pl.segs[0][0].T, D, 0);
-    RET(sdumc_bits_tag_(&d0, tag, -1, c.st));
+    // the NEXT call's dims (a ragged epoch announces them: sdumc_net_io.bits_next_dims) decide the layout of the set it will read
+    const sdumc_net_dims& nd = c.io.bits_next_dims ? *c.io.bits_next_dims : c.d;
+    Plan pn_own;
+    if (c.io.bits_next_dims && !make_plan(nd, pn_own)) return SDUMC_EINVAL;
+    const Plan& pn = c.io.bits_next_dims ? pn_own : pl;
+    const sdumc_bits_shape shape_next = bits_shape(nd);
+    auto mkdrop_next = [&](int site, int T, int s0) {
+      sdumc_dropout d = mkdrop(c, site, c.d.p_frame, T, D, s0);
+      d.samples = (uint32_t)nd.B;
+      d.sample0 = (uint32_t)nd.sample0;
+      return d;
+    };
+    const sdumc_dropout d0 = mkdrop_next(SITE_IN[0][0], pn.segs[0][0].T, 0);
+    RET(sdumc_bits_tag_(&d0, tag, -1, &shape_next, c.st));
     const int order[3] = {0, 2, 1};
     for (int oi = 0; oi < 3; ++oi) {
       const int m = order[oi];
-      for (const Seg& sg : pl.segs[m]) {
-        sdumc_dropout d = mkdrop(c, SITE_IN[0][m], c.d.p_frame, sg.T, D, sg.s0);
-        uint8_t* outs[2] = {nx + bits_next_off(pl, 0, m) + sg.row0 * (D / 4), nx + bits_next_off(pl, 1, m) + sg.row0 * (D / 4)};
-        RET(sdumc_dropout_bits_multi_ex_(&d, sg.V / B, 2, SITE_IN[1][m] - SITE_IN[0][m], outs, nullptr, 2, c.st));
+      for (const Seg& sg : pn.segs[m]) {
+        sdumc_dropout d = mkdrop_next(SITE_IN[0][m], sg.T, sg.s0);
+        uint8_t* outs[2] = {nx + bits_next_off(pn, 0, m) + sg.row0 * (D / 4), nx + bits_next_off(pn, 1, m) + sg.row0 * (D / 4)};
+        RET(sdumc_dropout_bits_multi_ex_(&d, sg.V / pn.B, 2, SITE_IN[1][m] - SITE_IN[0][m], outs, nullptr, 2, nullptr, c.st));
       }
     }
-    RET(sdumc_bits_tag_(&d0, tag, 2, c.st));
+    RET(sdumc_bits_tag_(&d0, tag, 2, &shape_next, c.st));
     c.use(0);
   }
   if (attn_multi_ok(c)) {
@@ -2616,7 +2695,11 @@ extern "C" size_t sdumc_net_workspace_bytes(const sdumc_net_dims* d) {
   return (size_t)p.cur * sizeof(float);
 }
 
-extern "C" int sdumc_net_forward(const sdumc_net_dims* d, const sdumc_net_io* io, void* stream) {
+namespace {
+// join_bits: order the middle's fill of the other keep-bits set (lane 3, issued behind the last lane-3 -> caller link of forward())
+// before `stream` on return.  sdumc_train_step leaves that to its backward's final join; a forward on its own must not return with
+// lane 3 still reading rng_state / writing bits_next behind the caller's back (and, under capture, with an unjoined branch).
+int net_forward_impl(const sdumc_net_dims* d, const sdumc_net_io* io, void* stream, bool join_bits) {
   RET(check_io(d, io));
   const SplitScope split_scope(io);
   Ctx c{*d, *io, as_stream(stream), build_params(d->da, d->dt, d->dv), Plan(), nullptr, nullptr, nullptr};
@@ -2625,7 +2708,14 @@ extern "C" int sdumc_net_forward(const sdumc_net_dims* d, const sdumc_net_io* io
   c.W = static_cast<float*>(io->workspace);
   c.P = io->params;
   c.init_lanes();
-  return forward(c);
+  RET(forward(c));
+  if (join_bits && bits_pregen(c)) RET(link(c, 3, 0));
+  if (join_bits) RET(join_prefetch(io, as_stream(stream)));
+  return SDUMC_OK;
+}
+}  // namespace
+extern "C" int sdumc_net_forward(const sdumc_net_dims* d, const sdumc_net_io* io, void* stream) {
+  return net_forward_impl(d, io, stream, true);
 }
 
 extern "C" int sdumc_net_backward(const sdumc_net_dims* d, const sdumc_net_io* io, const sdumc_net_grads* g,
@@ -2767,7 +2857,7 @@ StepLayout step_layout(const sdumc_net_dims& d) {
 extern "C" size_t sdumc_net_bits_next_bytes(const sdumc_net_dims* d) {
   Plan p;
   if (!d || !d->train || d->bf16 == 2 || !make_plan(*d, p) || p.hf) return 0;
-  return 2 * (size_t)bits_next_off(p, 2, 0);      // (two sets)
+  return 2 * bits_set_bytes(*d);      // (two sets; == 2 * bits_next_off(p, 2, 0))
 }
 
 extern "C" size_t sdumc_step_workspace_bytes(const sdumc_net_dims* d) {
@@ -2788,7 +2878,7 @@ extern "C" int sdumc_train_step(const sdumc_net_dims* d, const sdumc_net_io* io,
   nio.workspace = base + sl.net;
   nio.workspace_bytes = sl.total - sl.net;
   mark(static_cast<hipStream_t>(stream), 0);
-  RET(sdumc_net_forward(d, &nio, stream));
+  RET(net_forward_impl(d, &nio, stream, false));
   const size_t V = (size_t)d->B * 2;
   float* dout = reinterpret_cast<float*>(base + sl.dout);
   sdumc_net_grads g;
@@ -2812,6 +2902,7 @@ extern "C" int sdumc_train_step(const sdumc_net_dims* d, const sdumc_net_io* io,
                         cfg->eps, cfg->weight_decay, 1.0f, d->train ? const_cast<uint32_t*>(io->rng_state) : nullptr, 2u,
                         total_pending ? &tl : nullptr, stream));
   mark(static_cast<hipStream_t>(stream), 10);
+  RET(join_prefetch(io, static_cast<hipStream_t>(stream)));      // the next batch is assembled before anything behind this step reads it
   return SDUMC_OK;
 }
 

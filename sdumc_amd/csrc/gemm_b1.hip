@@ -341,10 +341,8 @@ extern "C" int sdumc_gemm_b1_nt(const sdumc_gemm_b1* gp, void* stream) {
   if (a_bytes >= 0xFFFFFFF0u) return SDUMC_EINVAL;
   const Plan p = plan(g, g.workspace ? g.workspace_bytes : 0);
   if (p.nsplit > 1 && (!g.workspace || (reinterpret_cast<uintptr_t>(g.workspace) & 15))) return SDUMC_ENOMEM;
-  static std::atomic<uint64_t> attr_set{0};
-  if (sdumc_first_on_device(attr_set) &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_b1_nt_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
-    return SDUMC_ELAUNCH;
+  static sdumc_dev_once attr_set;
+  if (sdumc_once_per_device(attr_set, [] { return sdumc_set_dyn_lds(&gemm_b1_nt_kernel, LDS_BYTES); }) != SDUMC_OK) return SDUMC_ELAUNCH;
   hipStream_t st = as_stream(stream);
   const int tok = sdumc_prof_begin_(28, 2.0 * g.M * (double)g.N * g.K, stream);
   Args a{g, p.nsplit, p.kchunk};

@@ -396,12 +396,9 @@ int launch(const sdumc_gemm_bf16& g, const Plan& p, bool cs, hipStream_t st) {
   const size_t shm = CF::LDS_BYTES;
 #define SDUMC_H_LAUNCH(CSV)                                                                                                  \
   do {                                                                                                                       \
-    static std::atomic<uint64_t> attr_set{0};                                                                                            \
-    if (sdumc_first_on_device(attr_set)) {                                                                                                         \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<CF, CSV>), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              (int)shm) != hipSuccess)                                                                       \
-        return SDUMC_ELAUNCH;                                                                                                \
-    }                                                                                                                        \
+    static sdumc_dev_once attr_set;                                                                                          \
+    if (sdumc_once_per_device(attr_set, [&] { return sdumc_set_dyn_lds(&gemm_bf16_kernel<CF, CSV>, shm); }) != SDUMC_OK)     \
+      return SDUMC_ELAUNCH;                                                                                                  \
     hipLaunchKernelGGL((gemm_bf16_kernel<CF, CSV>), grid, dim3(CF::NTHR), shm, st, g, p.nsplit, p.kchunk);                   \
   } while (0)
   if (cs) SDUMC_H_LAUNCH(true);

@@ -318,10 +318,8 @@ inline Plan plan(const sdumc_gemm_p3& g, size_t have) {
 
 template <class CF>
 int launch(const sdumc_gemm_p3& g, const Plan& p, hipStream_t st) {
-  static std::atomic<uint64_t> attr_set{0};
-  if (sdumc_first_on_device(attr_set) &&
-      hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_p3_nt_kernel<CF>), hipFuncAttributeMaxDynamicSharedMemorySize, CF::LDS_BYTES) != hipSuccess)
-    return SDUMC_ELAUNCH;
+  static sdumc_dev_once attr_set;
+  if (sdumc_once_per_device(attr_set, [] { return sdumc_set_dyn_lds(&gemm_p3_nt_kernel<CF>, CF::LDS_BYTES); }) != SDUMC_OK) return SDUMC_ELAUNCH;
   Args a{g, p.nsplit, p.kchunk};
   const dim3 grid((unsigned)(((g.M + CF::BM - 1) / CF::BM) * (g.N / BN)), (unsigned)p.nsplit);
   hipLaunchKernelGGL((gemm_p3_nt_kernel<CF>), grid, dim3(CF::NTHR), CF::LDS_BYTES, st, a);

@@ -794,7 +794,7 @@ __global__ __launch_bounds__(NTHR, 2) void gr_bf16_kernel(const Launch L) {
     const int a_rows = pr.a_row_mod > 0 ? pr.a_row_mod : pr.M;
     const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.A), 0, (int)((uint32_t)a_rows * lda2), 0x00020000);
     // FOLD: unit w of the problem = (output tile w / FOLD, row block w % FOLD); R = rows of C = rows of one block
-    const int R = FOLD ? pr.M / FOLD : pr.M;
+    const int R = FOLD ? pr.M / (FOLD > 0 ? FOLD : 1) : pr.M;
     const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(pr.C, 0, (int)((uint32_t)R * ldc2), 0x00020000);
     const bool cmask = FOLD && pr.c_bits != nullptr;
     const float cscale = cmask ? pr.c_scale : 1.f;

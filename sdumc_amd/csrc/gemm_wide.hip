@@ -444,22 +444,16 @@ int launch_cfg(const sdumc_gemm& g, int nsplit, int kchunk, bool mask, bool cs, 
   const size_t shm = CF::LDS_BYTES;
 #define SDUMC_WIDE_LAUNCH(MK, CSV)                                                                                           \
   do {                                                                                                                       \
-    static std::atomic<uint64_t> attr_set{0};                                                                                            \
-    if (sdumc_first_on_device(attr_set)) {                                                                                                         \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wide_kernel<CF, MK, CSV>),                                \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)                         \
-        return SDUMC_ELAUNCH;                                                                                                \
-    }                                                                                                                        \
+    static sdumc_dev_once attr_set;                                                                                          \
+    if (sdumc_once_per_device(attr_set, [&] { return sdumc_set_dyn_lds(&gemm_wide_kernel<CF, MK, CSV>, shm); }) != SDUMC_OK) \
+      return SDUMC_ELAUNCH;                                                                                                  \
     hipLaunchKernelGGL((gemm_wide_kernel<CF, MK, CSV>), grid, blk, shm, st, g, nsplit, kchunk);                              \
   } while (0)
 #define SDUMC_WIDE_LAUNCH_SPLIT(MK)                                                                                           \
   do {                                                                                                                       \
-    static std::atomic<uint64_t> attr_set{0};                                                                                            \
-    if (sdumc_first_on_device(attr_set)) {                                                                                                         \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_wide_split_kernel<CF, MK>),                               \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)                         \
-        return SDUMC_ELAUNCH;                                                                                                \
-    }                                                                                                                        \
+    static sdumc_dev_once attr_set;                                                                                          \
+    if (sdumc_once_per_device(attr_set, [&] { return sdumc_set_dyn_lds(&gemm_wide_split_kernel<CF, MK>, shm); }) != SDUMC_OK) \
+      return SDUMC_ELAUNCH;                                                                                                  \
     hipLaunchKernelGGL((gemm_wide_split_kernel<CF, MK>), grid, blk, shm, st, g, nsplit, kchunk);                             \
   } while (0)
   if constexpr (CF::A_KC) {       // NT: optional mask on A

@@ -70,17 +70,37 @@ def unpack(data, device):
             data[-2].float().to(device, non_blocking=True), data[-1])
 
 
+class EpochPlan:
+    """The batches of one epoch as the device sees them: ONE index tensor uploaded once (no per-batch host -> device copy inside the
+    loop -- a pageable upload per step costs the host a synchronisation with the previous step), the host-side offsets into it and the
+    padded shape (B, (T_audio, T_text, T_video, T_feat4)) of every batch."""
+
+    def __init__(self, idx_d, offsets, shapes):
+        self.idx_d, self.offsets, self.shapes = idx_d, offsets, shapes
+
+    def __len__(self):
+        return len(self.shapes)
+
+    def idx_ptr(self, i):
+        return self.idx_d.data_ptr() + 8 * self.offsets[i]
+
+
 class DeviceFeatureStore:
     """All pre-extracted features of a split, packed per modality into ONE device tensor [sum T, d]
     (MOSEI train at WavLM/Vicuna/MANet widths is tens of GB: it fits the 288 GB of one MI355X many times).
     `batch(indices)` assembles the reference's batch tuple on the GPU with a HIP gather/pad kernel
     (sdumc_gather_pad), so no feature bytes cross PCIe inside the training loop.  Replaces the roles of
     Data_Feat_MOSEI_EmoVal_4F.collater + pad_to_maxlen_pre_modality_tensor_4 (feat_data.py:232-253,
-    read_data.py:223-248) for the hot path; the on-disk format is the reference's (read_feature)."""
+    read_data.py:223-248) for the hot path; the on-disk format is the reference's (read_feature).
+
+    planes=True (fp32 storage): every utterance is ALSO held as P3 planes (sdumc_p3_split of the packed tensor, three bf16 parts per
+    value, 6 d bytes per row) -- split ONCE per dataset, where the reference re-reads the feature files every epoch; the store then
+    takes 2.5x the fp32 bytes (the fp32 rows the weight gradients read + 1.5x for the planes the frame projections read).  A batch's
+    planes are gathered like its fp32 rows (a padded row is zero in both, so this equals splitting the gathered batch bit for bit)."""
 
     MODS = ('audio', 'text', 'video', 'feat4')
 
-    def __init__(self, instances, device='cuda', bf16=False):
+    def __init__(self, instances, device='cuda', bf16=False, planes=False):
         """instances: iterable of dicts with 'audio','text','video','feat4' ([T, d] arrays), 'emo', 'val', 'name'.
         bf16=True holds the features as bf16 (half the HBM; what the engine's bf16-storage mode reads; widths % 8 == 0)."""
         import ctypes as C
@@ -108,14 +128,40 @@ class DeviceFeatureStore:
             self.length[m] = torch.tensor(lens, dtype=torch.int32)
             self.dim[m] = d
         self._device_tables()
+        self.packed_p3 = None
+        if planes:
+            self.make_planes()
 
     def _device_tables(self):
-        # store-wide tables on the device: a batch is then named by its index vector alone (sdumc_gather_pad_idx)
+        # store-wide tables on the device: a batch is then named by its index vector alone (sdumc_gather_batch)
         self.start_d = {m: self.start[m].to(self.device) for m in self.MODS}
         self.length_d = {m: self.length[m].to(self.device) for m in self.MODS}
+        self._len_np = {m: self.length[m].numpy() for m in self.MODS}
+
+    def make_planes(self):
+        """The P3 planes of every packed tensor (fp32 storage, widths in whole 64-element k-tiles: what csrc/gemm_p3.hip reads)."""
+        _lib = self._lib
+        if any(t.dtype != torch.float32 for t in self.packed.values()):
+            raise _lib.SdumcError("planes: the store holds bf16 features (the bf16-storage step reads them as they are)")
+        if any(self.dim[m] % 64 for m in self.MODS):
+            raise _lib.SdumcError("planes: feature widths must be multiples of 64")
+        self.packed_p3 = {}
+        for m in self.MODS:
+            src, d = self.packed[m], self.dim[m]
+            dst = torch.empty(src.shape[0], 6 * d, dtype=torch.uint8, device=self.device)
+            _lib.check(_lib.lib.sdumc_p3_split(_lib.ptr(src), d, _lib.ptr(dst), 6 * d, src.shape[0], d, _lib.current_stream()), "sdumc_p3_split")
+            self.packed_p3[m] = dst
+        return self
+
+    @property
+    def nbytes(self):
+        n = sum(t.numel() * t.element_size() for t in self.packed.values())
+        if self.packed_p3 is not None:
+            n += sum(t.numel() for t in self.packed_p3.values())
+        return n
 
     @classmethod
-    def synthetic(cls, n, T, dims, seed=1234, device='cuda', min_frac=0.25, bf16=False):
+    def synthetic(cls, n, T, dims, seed=1234, device='cuda', min_frac=0.25, bf16=False, planes=False):
         """n utterances with per-sample lengths ~ U{ceil(min_frac * T_m) .. T_m} and N(0, 1) features, generated on the device
         (SURVEY §8d's variable-length synthetic inputs; no host copy of the tens of GB a real split holds)."""
         import ctypes as C
@@ -136,6 +182,9 @@ class DeviceFeatureStore:
             self.packed[m] = torch.randn(int(lens.sum()), d, device=self.device, generator=gd).to(torch.bfloat16 if bf16 else torch.float32)
             self.start[m], self.length[m], self.dim[m] = starts, lens, int(d)
         self._device_tables()
+        self.packed_p3 = None
+        if planes:
+            self.make_planes()
         return self
 
     def batch_shape(self, indices):
@@ -151,10 +200,47 @@ class DeviceFeatureStore:
             raise self._lib.SdumcError(f"sample index out of range [0, {n})")
         return idx
 
-    def batch_into(self, indices, outs, labels_out, lengths_out=None):
+    def plan_epoch(self, batches):
+        """batches: the epoch's index vectors (what a BatchSampler yields) -> EpochPlan: every index range-checked, one upload."""
+        idxs = [self._checked(b) for b in batches]
+        if not idxs:
+            raise self._lib.SdumcError("plan_epoch: no batches")
+        offsets = np.concatenate([[0], np.cumsum([i.numel() for i in idxs])]).astype(np.int64)
+        shapes = []
+        for i in idxs:
+            ii = i.numpy()
+            shapes.append((int(ii.size), tuple(int(self._len_np[m][ii].max()) for m in self.MODS)))
+        return EpochPlan(torch.cat(idxs).to(self.device), [int(o) for o in offsets[:-1]], shapes)
+
+    def gather_desc(self, idx_ptr, B, T, outs, labels_out, lengths_out=None, planes_out=None):
+        """The sdumc_gather_batch descriptor of one batch: idx_ptr = device address of its int64 [B] index vector, T its padded frame
+        counts, outs = 4 device buffers of >= B * T_m * d_m elements (fp32, or bf16 for a bf16 store), planes_out = 4 uint8 buffers of
+        >= B * T_m * 6 d_m bytes (needs the store's planes), labels_out [>= B], lengths_out = optional 4 int32 [>= B]."""
+        _lib = self._lib
+        if planes_out is not None and self.packed_p3 is None:
+            raise _lib.SdumcError("this store holds no planes (DeviceFeatureStore(planes=True))")
+        g = _lib.GatherBatch()
+        n = 0
+        for k, m in enumerate(self.MODS):
+            srcs = [(self.packed[m], outs[k], self.dim[m] * self.packed[m].element_size() // 16)]
+            if planes_out is not None:
+                srcs.append((self.packed_p3[m], planes_out[k], 6 * self.dim[m] // 16))
+            for j, (src, dst, d4) in enumerate(srcs):
+                sg = g.seg[n]
+                sg.packed, sg.start_all, sg.len_all = _lib.ptr(src), _lib.ptr(self.start_d[m]), _lib.ptr(self.length_d[m])
+                sg.out = _lib.ptr(dst)
+                sg.len_out = _lib.ptr(lengths_out[k]) if (lengths_out is not None and j == 0) else None
+                sg.Tmax, sg.d4 = int(T[k]), int(d4)
+                n += 1
+        g.nseg, g.B, g.idx = n, int(B), idx_ptr
+        g.labels_all, g.labels_out = _lib.ptr(self.vals), _lib.ptr(labels_out)
+        return g
+
+    def batch_into(self, indices, outs, labels_out, lengths_out=None, planes_out=None):
         """Assembles the batch `indices` into caller-owned buffers: outs = 4 device tensors [B, Tmax_m, d_m] (e.g. the input
         buffers of an engine.TrainStep), labels_out [B]; lengths_out = optional 4 int32 device tensors (>= B) that receive the
-        valid frame counts.  One index-vector upload, four gather/pad launches, nothing else."""
+        valid frame counts; planes_out = optional 4 uint8 tensors (>= B * Tmax_m * 6 d_m bytes) that receive the batch's P3 planes.
+        One index-vector upload, ONE gather launch, nothing else."""
         _lib = self._lib
         idx = self._checked(indices)
         B = idx.numel()
@@ -163,13 +249,10 @@ class DeviceFeatureStore:
             dst = outs[k]
             if dst.shape[0] != B or dst.shape[2] != self.dim[m] or not dst.is_contiguous() or dst.dtype != self.packed[m].dtype:
                 raise _lib.SdumcError("batch_into: output buffer does not match the batch (shape / dtype)")
-            # the kernel moves 16-byte units: a bf16 row of d elements is a row of d / 2 "floats"
-            dw = self.dim[m] if dst.dtype == torch.float32 else self.dim[m] // 2
-            _lib.check(_lib.lib.sdumc_gather_pad_idx(_lib.ptr(self.packed[m]), _lib.ptr(self.start_d[m]), _lib.ptr(self.length_d[m]),
-                                                     _lib.ptr(idx_d), B, dst.shape[1], dw, _lib.ptr(dst),
-                                                     _lib.ptr(lengths_out[k]) if lengths_out is not None else None,
-                                                     _lib.current_stream()), "sdumc_gather_pad_idx")
-        torch.index_select(self.vals, 0, idx_d, out=labels_out)
+            if planes_out is not None and (planes_out[k].dtype != torch.uint8 or planes_out[k].numel() < B * dst.shape[1] * 6 * self.dim[m]):
+                raise _lib.SdumcError("batch_into: planes buffer too small")
+        g = self.gather_desc(idx_d.data_ptr(), B, [o.shape[1] for o in outs], outs, labels_out, lengths_out, planes_out)
+        _lib.check(_lib.lib.sdumc_gather_batch(self._C.byref(g), 0, _lib.current_stream()), "sdumc_gather_batch")
         self._keep_idx = idx_d
         return lengths_out
 

@@ -85,11 +85,15 @@ def bf16_mode(bf16, dims):
 
 def planes_wanted(planes, dims, bf16):
     """Whether a step / call keeps bf16-plane copies of its fp32 features (sdumc_net_io.*_p3; csrc/gemm_p3.hip: the frame and key
-    projections then run on operands split once per tensor).  Default (None): yes in fp32 storage when the feature widths are whole
-    64-element k-tiles; costs 1.5x the features' bytes on top of them.  SDUMC_P3=0 turns the default off (A/B)."""
+    projections then run on operands split once per tensor).  OPT-IN (planes=True): the caller states that the installed batch is
+    RESIDENT -- run many times, or assembled from a DeviceFeatureStore(planes=True) whose planes were split once per dataset.  A loop
+    that installs a fresh batch per step (set_batch per step) would re-split ~224 MB per step at C2 for one use,
+    ~0.15-0.2 ms against the ~0.015 ms the planes save: there the default (False = the in-kernel split of csrc/gemm_wide.hip) is the
+    faster path.  None: the environment's SDUMC_P3 (A/B runs), else False.  Needs fp32 storage and widths in whole 64-element k-tiles;
+    costs 1.5x the features' bytes on top of them."""
     import os
     if planes is None:
-        planes = os.environ.get("SDUMC_P3", "1") != "0"
+        planes = os.environ.get("SDUMC_P3", "0") == "1"
     return bool(planes) and bf16_mode(bf16, dims) == 0 and all(int(d) % 64 == 0 for d in dims[:3])
 
 
@@ -320,7 +324,9 @@ class TrainStep(_OptStateMixin):
         FusedTrainer's run state) whose optimiser state this step uses instead of allocating its own -- steps of different
         (B, T) shapes then continue one training run.
         arena: a _StepArena sized for the largest batch of the run: workspace, input and output buffers are views into it
-        instead of fresh allocations (a C2 step owns ~1.2 GB of workspace: one arena per run, not one per batch shape)."""
+        instead of fresh allocations (a C2 step owns ~1.2 GB of workspace: one arena per run, not one per batch shape); the arena
+        decides about planes and owns the keep-bits buffer (its shapes change from step to step: use_set / launch(next_step=)).
+        planes=True: the batch installed by set_batch is RESIDENT (run many times): its bf16 planes are split once, there (planes_wanted)."""
         Ta, Tt, Tv, T4 = T
         self.layout = ParamLayout.get(dims[0], dims[1], dims[2])
         dev = flat_params.device
@@ -334,9 +340,19 @@ class TrainStep(_OptStateMixin):
             raise _lib.SdumcError("share: both steps must update the same flat parameter buffer")
         self.rng = share.rng if share is not None else RngState(seed, dev)
         V = 2 * B
-        self.B, self.V = B, V
+        self.B, self.V, self.T = B, V, (Ta, Tt, Tv, T4)
+        self._fdims = (dims[0], dims[1], dims[2], dims[1])
         fdt = torch.bfloat16 if self.dims.bf16 == 2 else torch.float32      # dtype the features are held in
         self.feature_dtype = fdt
+        self._arena = arena
+        self._lengths = None      # key-padding extension off (set_lengths / use_lengths)
+        self._use_planes = False
+        io = _lib.NetIO()
+        self.io = io
+        cfg = _lib.StepCfg()
+        self.cfg = cfg
+        self._planes = None
+        self._bits_next = None
         if arena is not None:
             if arena.feature_dtype != fdt:
                 raise _lib.SdumcError("arena and step disagree on the feature dtype")
@@ -344,16 +360,15 @@ class TrainStep(_OptStateMixin):
                 raise _lib.SdumcError("arena too small for this batch shape")
             self.workspace = arena.workspace
             nbytes = arena.workspace.numel()
-            self.audio = arena.inputs[0][:B * Ta * dims[0]].view(B, Ta, dims[0])
-            self.text = arena.inputs[1][:B * Tt * dims[1]].view(B, Tt, dims[1])
-            self.video = arena.inputs[2][:B * Tv * dims[2]].view(B, Tv, dims[2])
-            self.feat4 = arena.inputs[3][:B * T4 * dims[1]].view(B, T4, dims[1])
-            self.labels = arena.labels[:B]
             self.vals = arena.outs[0][:V].view(V, 1)
             self.fused = arena.outs[1][:V * H].view(V, H)
             self.rnc = arena.outs[2][:V * RNC_DIM].view(V, RNC_DIM)
             self.text_hidden = arena.outs[3][:V * D].view(V, D)
             self.cross_text = arena.outs[4][:V * NQ * H].view(V, NQ, H)
+            self._views = {}
+            self.use_set(0)
+            if arena.bits is not None and train:
+                io.bits_next, io.bits_next_bytes = ptr(arena.bits), arena.bits.numel()
         else:
             self.workspace = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             self.audio = torch.empty(B, Ta, dims[0], device=dev, dtype=fdt)
@@ -366,6 +381,23 @@ class TrainStep(_OptStateMixin):
             self.rnc = torch.empty(V, RNC_DIM, device=dev)
             self.text_hidden = torch.empty(V, D, device=dev)
             self.cross_text = torch.empty(V, NQ, H, device=dev)
+            io.audio, io.video = ptr(self.audio), ptr(self.video)
+            io.text[0], io.text[1] = ptr(self.text), ptr(self.feat4)
+            cfg.labels = ptr(self.labels)
+            # fp32 storage, a RESIDENT batch (planes=True): bf16-plane copies of the four feature tensors, split once by set_batch --
+            # 1.5x the features' bytes on top of them
+            if planes_wanted(planes, dims, bf16):
+                self._use_planes = True
+                self._planes = [torch.empty(t.shape[0] * t.shape[1], 6 * t.shape[2], dtype=torch.uint8, device=dev)
+                                for t in (self.audio, self.text, self.video, self.feat4)]
+                io.audio_p3, io.text_p3[0], io.video_p3, io.text_p3[1] = (ptr(t) for t in self._planes)
+            # fp32 train steps: a buffer of its own for the NEXT step's keep-bits (generated in this step's idle middle, found at the next
+            # step's head under its {seed, call, shape} tag; bit-identical masks) -- not in the workspace: it must survive whatever else
+            # runs between two steps of this shape
+            nb = lib.sdumc_net_bits_next_bytes(C.byref(self.dims)) if bits_next else 0
+            self._bits_next = torch.zeros(nb, dtype=torch.uint8, device=dev) if nb else None
+            if self._bits_next is not None:
+                io.bits_next = ptr(self._bits_next)
         if share is not None:
             self.adam_m, self.adam_v, self.hyper, self.losses = share.adam_m, share.adam_v, share.hyper, share.losses
         else:
@@ -373,55 +405,66 @@ class TrainStep(_OptStateMixin):
             self.adam_v = torch.zeros(self.layout.live, device=dev)
             self.hyper = torch.tensor([lr, 0.0, 0.0, 0.0], device=dev)
             self.losses = torch.zeros(8, device=dev)
-        io = _lib.NetIO()
-        io.audio, io.video = ptr(self.audio), ptr(self.video)
-        io.text[0], io.text[1] = ptr(self.text), ptr(self.feat4)
         io.params, io.rng_state = ptr(flat_params), ptr(self.rng.t)
         io.workspace, io.workspace_bytes = ptr(self.workspace), nbytes
         io.vals, io.fused, io.rnc = ptr(self.vals), ptr(self.fused), ptr(self.rnc)
         io.text_hidden, io.cross_text = ptr(self.text_hidden), ptr(self.cross_text)
         self._ctx = ctx       # ExecContext or None (= the device's default lanes)
         io.ctx = ctx.handle if ctx is not None else None
-        # fp32 storage: resident bf16-plane copies of the four feature tensors, refreshed by set_batch (features do not change across
-        # epochs: the split is paid when a batch is installed, not in the step) -- 1.5x the features' bytes on top of them
-        self._planes = None
-        if arena is None and planes_wanted(planes, dims, bf16):
-            self._planes = [torch.empty(t.shape[0] * t.shape[1], 6 * t.shape[2], dtype=torch.uint8, device=dev)
-                            for t in (self.audio, self.text, self.video, self.feat4)]
-            io.audio_p3, io.text_p3[0], io.video_p3, io.text_p3[1] = (ptr(t) for t in self._planes)
-        # fp32 train steps: a buffer of its own for the NEXT step's keep-bits (generated in this step's idle middle, copied at the next
-        # step's head when its {seed, call} tag matches; bit-identical masks) -- not in the workspace: it must survive whatever else
-        # runs between two steps of this shape
-        nb = lib.sdumc_net_bits_next_bytes(C.byref(self.dims)) if (bits_next and arena is None) else 0      # (an arena's shapes change every step)
-        self._bits_next = torch.zeros(nb, dtype=torch.uint8, device=dev) if nb else None
-        if self._bits_next is not None:
-            io.bits_next = ptr(self._bits_next)
-        self.io = io
-        cfg = _lib.StepCfg()
         for i, w in enumerate(weights):
             cfg.weights[i] = w
         cfg.temperature = 2.0
         cfg.beta1, cfg.beta2, cfg.eps, cfg.weight_decay = betas[0], betas[1], eps, weight_decay
-        cfg.labels, cfg.adam_m, cfg.adam_v = ptr(self.labels), ptr(self.adam_m), ptr(self.adam_v)
+        cfg.adam_m, cfg.adam_v = ptr(self.adam_m), ptr(self.adam_v)
         cfg.hyper, cfg.losses = ptr(self.hyper), ptr(self.losses)
-        self.cfg = cfg
         self.graph = None
-        self._lengths = None      # key-padding extension off (set_lengths)
         goff = lib.sdumc_step_grads_offset(C.byref(self.dims))      # the same for every shape: the bucket leads the workspace
         self.grads = self.workspace[goff:goff + 4 * self.layout.live].view(torch.float32)
         if arena is None:
             self.grads.zero_()      # alignment padding between tensors is never written by the kernels (an arena zeroes it once)
 
+    def use_set(self, k, planes=True):
+        """Arena steps: read the batch held in input set `k` of the arena (FusedTrainer alternates two sets -- the next batch is
+        assembled in the other one while this step runs; bench.py rotates K resident batches).  planes=False: this batch has no
+        planes in the set (fresh tensors handed to step(): splitting them for one use costs more than it saves).  Pointers only."""
+        a = self._arena
+        if a is None:
+            raise _lib.SdumcError("use_set: this step owns its input buffers (no arena)")
+        st = a.sets[k]
+        v = self._views.get(k)
+        if v is None:
+            B, T, fd = self.B, self.T, self._fdims
+            v = tuple(st.inputs[i][:B * T[i] * fd[i]].view(B, T[i], fd[i]) for i in range(4)) + (st.labels[:B],)
+            self._views[k] = v
+        self.audio, self.text, self.video, self.feat4, self.labels = v
+        io = self.io
+        io.audio, io.text[0], io.video, io.text[1] = (ptr(t) for t in st.inputs)
+        self._use_planes = bool(planes) and st.planes is not None
+        if self._use_planes:
+            io.audio_p3, io.text_p3[0], io.video_p3, io.text_p3[1] = (ptr(t) for t in st.planes)
+        else:
+            io.audio_p3 = io.video_p3 = io.text_p3[0] = io.text_p3[1] = None
+        self.cfg.labels = ptr(st.labels)
+        self._set = k
+        return self
+
+    def _point_lengths(self, tensors):
+        for i in range(4):
+            self.io.lengths[i] = ptr(tensors[i]) if tensors is not None else None
+
     def set_batch(self, audio, text, video, feat4, labels):
         """Copies one batch into the step's resident input buffers (shapes are fixed per TrainStep); in bf16-storage mode the
-        buffers are bf16 and fp32 inputs are rounded by the copy."""
+        buffers are bf16 and fp32 inputs are rounded by the copy.  With planes (a resident batch) the bf16 planes are split here."""
         self.audio.copy_(audio, non_blocking=True)
         self.text.copy_(text, non_blocking=True)
         self.video.copy_(video, non_blocking=True)
         self.feat4.copy_(feat4, non_blocking=True)
         self.labels.copy_(labels.reshape(-1), non_blocking=True)
-        if self._planes is not None:
-            for src, dst in zip((self.audio, self.text, self.video, self.feat4), self._planes):
+        planes = None
+        if self._use_planes:
+            planes = self._planes if self._arena is None else self._arena.sets[self._set].planes
+        if planes is not None:
+            for src, dst in zip((self.audio, self.text, self.video, self.feat4), planes):
                 p3_split_into(src, dst)
 
     def set_lengths(self, lengths):
@@ -433,23 +476,47 @@ class TrainStep(_OptStateMixin):
                                   + ("on" if self._lengths is not None else "off") + ": switch it before capture()")
         if new is None:
             self._lengths = None
-            for i in range(4):
-                self.io.lengths[i] = None
+            self._point_lengths(None)
             return
         if self._lengths is None:
             self._lengths = [torch.empty(self.B, dtype=torch.int32, device=self.params.device) for _ in range(4)]
-            for i, t in enumerate(self._lengths):
-                self.io.lengths[i] = ptr(t)
+        self._point_lengths(self._lengths)
         for dst, src in zip(self._lengths, new):
             dst.copy_(src, non_blocking=True)      # resident buffers: a captured graph keeps reading the same addresses
+
+    def use_lengths(self, tensors):
+        """Arena steps: the key-padding lengths as four device int32 buffers the batch's assembly already filled (or None = off)."""
+        self._lengths = list(tensors) if tensors is not None else None
+        self._point_lengths(self._lengths)
 
     def set_lr(self, lr):
         self.hyper[0] = lr
 
-    def launch(self, stream=None):
+    def launch(self, stream=None, next_step=None, prefetch=None, pregen=True):
+        """Enqueues the step.  next_step: the TrainStep that runs NEXT in this arena (its dims decide how this step's middle lays out
+        the next keep-bits set); prefetch: the sdumc_gather_batch descriptor of the next batch, issued by the step beside its middle
+        and backward; pregen=False: no keep-bits for a next step this time (the caller does not expect a step of a known shape to follow)."""
         st = _lib.current_stream() if stream is None else stream
-        check(lib.sdumc_train_step(C.byref(self.dims), C.byref(self.io), C.byref(self.cfg), st), "sdumc_train_step")
-        self.io.bits_phase ^= 1      # (the next step reads the keep-bits set this one filled in its middle: sdumc_net_io.bits_next)
+        io = self.io
+        a = self._arena
+        shared = a is not None and a.bits is not None and io.bits_next
+        if shared:
+            io.bits_phase = a.bits_phase
+        saved = io.bits_next
+        if not pregen and self.graph is None:
+            io.bits_next = None
+        io.bits_next_dims = C.addressof(next_step.dims) if next_step is not None else None
+        io.prefetch = C.addressof(prefetch) if prefetch is not None else None
+        io.prefetch_workgroups = a.prefetch_workgroups if a is not None else 0
+        try:
+            check(lib.sdumc_train_step(C.byref(self.dims), C.byref(io), C.byref(self.cfg), st), "sdumc_train_step")
+        finally:
+            io.bits_next, io.bits_next_dims, io.prefetch = saved, None, None
+        if pregen or self.graph is not None:
+            if shared:
+                a.bits_phase ^= 1
+            else:
+                io.bits_phase ^= 1      # (the next step reads the keep-bits set this one filled in its middle: sdumc_net_io.bits_next)
 
     def capture(self):
         """Capture one step into a hipGraph; run() then replays it.  For embedding the step in a captured region, not for speed:
@@ -487,12 +554,24 @@ class _RunState(_OptStateMixin):
         self.losses = torch.zeros(8, device=dev)
 
 
+class _InputSet:
+    """One resident batch slot of an arena: the four feature buffers (flat, capacity-sized), their P3 planes (fp32 storage, planes on),
+    the labels and the valid frame counts."""
+
+    def __init__(self, n, planes_bytes, B, dtype, dev):
+        self.inputs = [torch.empty(k, device=dev, dtype=dtype) for k in n]
+        self.planes = [torch.empty(k, device=dev, dtype=torch.uint8) for k in planes_bytes] if planes_bytes is not None else None
+        self.labels = torch.empty(B, device=dev)
+        self.lengths = [torch.empty(B, dtype=torch.int32, device=dev) for _ in range(4)]
+
+
 class _StepArena:
     """Device memory of one training run, sized once for its largest batch (B, T_audio, T_text, T_video, T_feat4):
-    the step workspace (whose leading gradient bucket is zeroed here, once), the four input buffers the batches are
-    assembled in -- DeviceFeatureStore.batch_into gathers straight into them -- the labels and the five outputs."""
+    the step workspace (whose leading gradient bucket is zeroed here, once), `sets` input sets the batches are assembled in --
+    DeviceFeatureStore gathers straight into them; two sets let the NEXT batch be assembled while a step runs --, the five outputs,
+    and (fp32 train steps) the two keep-bits sets every shape of the run shares (their tags name the shape they were laid out for)."""
 
-    def __init__(self, flat_params, B, T, dims, bf16=False):
+    def __init__(self, flat_params, B, T, dims, bf16=False, sets=1, planes=False, bits_next=True, prefetch_workgroups=0):
         dev = flat_params.device
         self.B, self.T, self.dims = int(B), tuple(int(t) for t in T), tuple(dims)
         d = make_dims(self.B, 2, self.T[0], self.T[2], (self.T[1], self.T[3]), dims, True, 0, bf16=bf16)
@@ -503,16 +582,51 @@ class _StepArena:
         lay = ParamLayout.get(dims[0], dims[1], dims[2])
         goff = lib.sdumc_step_grads_offset(C.byref(d))
         self.workspace[goff:goff + 4 * lay.live].zero_()
-        n = [self.B * self.T[0] * dims[0], self.B * self.T[1] * dims[1], self.B * self.T[2] * dims[2], self.B * self.T[3] * dims[1]]
+        fd = (dims[0], dims[1], dims[2], dims[1])
+        n = [self.B * self.T[i] * fd[i] for i in range(4)]
         self.feature_dtype = torch.bfloat16 if d.bf16 == 2 else torch.float32
-        self.inputs = [torch.empty(k, device=dev, dtype=self.feature_dtype) for k in n]
-        self.labels = torch.empty(self.B, device=dev)
+        # planes: True = the input sets carry P3 planes from the start; None = as soon as a store with planes (or a resident batch)
+        # asks for them (ensure_planes); False = never
+        self._planes_ok = planes is not False and planes_wanted(True, dims, bf16)
+        self._n = n
+        self.sets = [_InputSet(n, None, self.B, self.feature_dtype, dev) for _ in range(max(1, int(sets)))]
+        if planes is True:
+            self.ensure_planes()
         V = 2 * self.B
         self.outs = [torch.empty(V * k, device=dev) for k in (1, H, RNC_DIM, D, NQ * H)]
-        self.lengths = [torch.empty(self.B, dtype=torch.int32, device=dev) for _ in range(4)]
+        nb = lib.sdumc_net_bits_next_bytes(C.byref(d)) if bits_next else 0
+        self.bits = torch.zeros(nb, dtype=torch.uint8, device=dev) if nb else None
+        self.bits_phase = 0
+        self.prefetch_workgroups = int(prefetch_workgroups)
+
+    def ensure_planes(self):
+        """The plane buffers of every input set (1.5x the fp32 input bytes each), allocated on first need; False when the arena's
+        mode has none (bf16 storage, widths that are not whole k-tiles, planes=False)."""
+        if not self._planes_ok:
+            return False
+        for st in self.sets:
+            if st.planes is None:
+                st.planes = [torch.empty(6 * k, device=self.workspace.device, dtype=torch.uint8) for k in self._n]
+        return True
+
+    # (the single-set views older callers used)
+    @property
+    def inputs(self):
+        return self.sets[0].inputs
+
+    @property
+    def labels(self):
+        return self.sets[0].labels
+
+    @property
+    def lengths(self):
+        return self.sets[0].lengths
 
     def fits(self, B, T, nbytes):
         return B <= self.B and all(t <= c for t, c in zip(T, self.T)) and nbytes <= self.workspace.numel()
+
+
+StepArena = _StepArena      # (public name: bench.py and callers that rotate resident batches build one directly)
 
 
 class FusedTrainer:
@@ -520,12 +634,20 @@ class FusedTrainer:
     batch (every modality is padded to its batch maximum, read_data.py:223-248; the last batch of an epoch is short):
     one TrainStep per shape, created on first use, all sharing one optimiser state, so `step()` over a data loader is one
     continuous run of main_frame_val_text_missing.py:119-150.  At most `max_cached` shapes keep their workspace (least
-    recently used first out); a shape seen again after eviction is simply rebuilt."""
+    recently used first out); a shape seen again after eviction is simply rebuilt.
 
-    def __init__(self, flat_params, dims, max_cached=8, lr=1e-4, seed=0, capacity=None, **step_kwargs):
+    With capacity= and a DeviceFeatureStore, `run_epoch` is the replacement for the reference's loop over its DataLoader
+    (main :89-109 over feat_data.py:232-253): the epoch's index vectors are uploaded once, every batch is assembled on the device
+    straight into one of the arena's two input sets -- by the PREVIOUS step, beside its latency-bound middle and its backward
+    (sdumc_net_io.prefetch) -- and every step tells the engine the next batch's shape, so that the next keep-bits are laid out for it."""
+
+    def __init__(self, flat_params, dims, max_cached=8, lr=1e-4, seed=0, capacity=None, planes=None, sets=2, prefetch_workgroups=0,
+                 **step_kwargs):
         """capacity = (B_max, (T_audio, T_text, T_video, T_feat4) maxima) of the run: ONE arena then backs every batch shape
         (no per-shape workspace, the per-shape step is a few ctypes structs and tensor views: cache as many as you like) and
-        `step_from_store` assembles batches straight into it.  Without it every cached shape owns its workspace."""
+        `step_from_store` / `run_epoch` assemble batches straight into it.  Without it every cached shape owns its workspace.
+        planes (arena only): None (default) = follow the store -- batches assembled from a DeviceFeatureStore(planes=True) bring their
+        P3 planes along (the same gather as the fp32 rows) and the step's frame projections read them; False = never."""
         _require_cuda(flat_params)
         self.params, self.dims, self.max_cached = flat_params, tuple(dims), max(1, int(max_cached))
         self.kw = dict(step_kwargs, lr=lr, seed=seed)
@@ -533,9 +655,16 @@ class FusedTrainer:
         self.state = _RunState(flat_params, lay.live, lr, seed)     # (params, rng, adam_m, adam_v, hyper, losses)
         self._steps = {}          # shape -> TrainStep, insertion order = recency
         self.arena = None
+        self._arena_kw = dict(bf16=step_kwargs.get("bf16", False), sets=sets, planes=planes,
+                              bits_next=step_kwargs.get("bits_next", True), prefetch_workgroups=prefetch_workgroups)
+        self._last_shape = None
         if capacity is not None:
-            self.arena = _StepArena(flat_params, capacity[0], capacity[1], dims, bf16=step_kwargs.get("bf16", False))
+            self.arena = _StepArena(flat_params, capacity[0], capacity[1], dims, **self._arena_kw)
             self.max_cached = max(self.max_cached, 4096)
+        else:
+            # per-shape steps own their buffers and see a fresh batch per step: no planes to re-split, and no keep-bits set kept per
+            # shape (the next step is usually another shape with another buffer: its tag would never match)
+            self.kw.update(planes=False, bits_next=False)
 
     def _get(self, B, T):
         key = (B,) + tuple(T)
@@ -546,9 +675,10 @@ class FusedTrainer:
             if self.arena is not None and not (B <= self.arena.B and all(t <= c for t, c in zip(T, self.arena.T))):
                 # a batch beyond the declared capacity: grow the arena (every cached step pointed into the old one)
                 cap_T = tuple(max(t, c) for t, c in zip(T, self.arena.T))
-                self.arena = _StepArena(self.params, max(B, self.arena.B), cap_T, self.dims, bf16=self.kw.get("bf16", False))
+                self.arena = _StepArena(self.params, max(B, self.arena.B), cap_T, self.dims, **self._arena_kw)
                 self._steps.clear()
-            ts = TrainStep(self.params, B, T, self.dims, share=self.state, arena=self.arena, **self.kw)
+            kw = {k: v for k, v in self.kw.items() if not (self.arena is not None and k in ("planes", "bits_next"))}
+            ts = TrainStep(self.params, B, T, self.dims, share=self.state, arena=self.arena, **kw)
         self._steps[key] = ts
         return ts
 
@@ -561,23 +691,71 @@ class FusedTrainer:
     def optimizer_state(self):
         return self.state.optimizer_state()
 
+    def _launch(self, ts, next_step=None, prefetch=None):
+        # keep-bits for a next step only when its shape is known (run_epoch) or has been repeating (a static-shape loader)
+        key = (ts.B,) + ts.T
+        pregen = next_step is not None or key == self._last_shape
+        self._last_shape = key
+        ts.launch(next_step=next_step, prefetch=prefetch, pregen=pregen)
+        return ts.losses
+
+    def _store_planes(self, store):
+        return store.packed_p3 is not None and self.arena.ensure_planes()
+
+    def _gather_desc(self, store, idx_ptr, ts, k, key_padding, planes):
+        st = self.arena.sets[k]
+        return store.gather_desc(idx_ptr, ts.B, ts.T, st.inputs, st.labels, st.lengths if key_padding else None, st.planes if planes else None)
+
     def step_from_store(self, store, indices, key_padding=False):
         """One optimisation step on the batch `indices` of a data.DeviceFeatureStore: the padded batch is assembled by the
         gather/pad kernel DIRECTLY in the step's input buffers (no intermediate batch tensors, no 224 MB device copy);
-        key_padding=True also hands the valid frame counts to the kernels (extension, default off = the reference)."""
+        key_padding=True also hands the valid frame counts to the kernels (extension, default off = the reference).
+        (One batch at a time: the assembly runs in front of the step.  run_epoch overlaps it with the previous step.)"""
         if self.arena is None:
             raise _lib.SdumcError("step_from_store needs FusedTrainer(capacity=...)")
         B, T = store.batch_shape(indices)
         ts = self._get(B, T)
-        lens = store.batch_into(indices, (ts.audio, ts.text, ts.video, ts.feat4), ts.labels,
-                                self.arena.lengths if key_padding else None)
-        ts.set_lengths([l[:B] for l in lens] if key_padding else None)
-        return ts.run()
+        planes = self._store_planes(store)
+        ts.use_set(0, planes=planes)
+        st = self.arena.sets[0]
+        store.batch_into(indices, (ts.audio, ts.text, ts.video, ts.feat4), ts.labels, st.lengths if key_padding else None,
+                         st.planes if planes else None)
+        ts.use_lengths(st.lengths if key_padding else None)
+        return self._launch(ts)
+
+    def run_epoch(self, store, batches, key_padding=False, on_step=None):
+        """Every batch of `batches` (index vectors into `store`, or a data.EpochPlan), in order: main :89-150's loop.  The first batch
+        is assembled in front of the first step; from then on step i assembles batch i + 1 in the other input set while it runs.
+        on_step(i, losses) is called after step i has been ENQUEUED (losses = the device vector the step will write: clone it to keep
+        it).  Returns the number of steps."""
+        if self.arena is None or len(self.arena.sets) < 2:
+            raise _lib.SdumcError("run_epoch needs FusedTrainer(capacity=..., sets=2)")
+        from .data import EpochPlan
+        plan = batches if isinstance(batches, EpochPlan) else store.plan_epoch(batches)
+        n = len(plan)
+        steps = [self._get(B, T) for (B, T) in plan.shapes]      # (may grow the arena: before any descriptor is built)
+        if any(ts._arena is not self.arena for ts in steps):
+            steps = [self._get(B, T) for (B, T) in plan.shapes]
+        planes = self._store_planes(store)
+        g0 = self._gather_desc(store, plan.idx_ptr(0), steps[0], 0, key_padding, planes)
+        check(lib.sdumc_gather_batch(C.byref(g0), 0, _lib.current_stream()), "sdumc_gather_batch")
+        for i in range(n):
+            ts = steps[i].use_set(i & 1, planes=planes)
+            ts.use_lengths(self.arena.sets[i & 1].lengths if key_padding else None)
+            nxt = steps[i + 1] if i + 1 < n else None
+            pf = self._gather_desc(store, plan.idx_ptr(i + 1), nxt, (i + 1) & 1, key_padding, planes) if nxt is not None else None
+            losses = self._launch(ts, next_step=nxt, prefetch=pf)
+            if on_step is not None:
+                on_step(i, losses)
+        self._keep_plan = plan      # (the index tensor must outlive the enqueued gathers)
+        return n
 
     def step(self, audio, text, video, feat4, labels, lengths=None):
         """One optimisation step on one batch of any shape; returns the device loss vector
         [total, mse_full, mse_missing, rmse_text, rmse_query, rmse_fused, rnc, 0]."""
         ts = self._get(audio.shape[0], (audio.shape[1], text.shape[1], video.shape[1], feat4.shape[1]))
+        if self.arena is not None:
+            ts.use_set(0, planes=False)      # (fresh tensors: a split for one use costs more than the planes save)
         ts.set_batch(audio, text, video, feat4, labels)
         ts.set_lengths(lengths)
-        return ts.run()
+        return self._launch(ts)

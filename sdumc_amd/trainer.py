@@ -34,9 +34,11 @@ class HipBackend:
     """Per-rank compute on one MI355X through the C ABI."""
 
     def __init__(self, flat_params, B, T, dims, weights, lr, betas, eps, weight_decay, seed, sample0, B_global,
-                 bf16=False, share=None):
+                 bf16=False, share=None, planes=False):
         """share: the run state (engine._RunState: rng, Adam moments, hyper, losses, gradient bucket) of the training run
-        this backend belongs to.  The reference's loader pads every batch to its own max T and ends an epoch on a short
+        this backend belongs to.  planes=True: the batches installed by set_batch are RESIDENT (each runs many steps): their bf16
+        planes are split once per set_batch (engine.planes_wanted); default off -- a fresh batch per step would pay the split for one use.
+        The reference's loader pads every batch to its own max T and ends an epoch on a short
         batch (read_data.py:223-248), so a run needs one backend per (B, T) shape; they must all continue ONE optimiser
         state, step count and dropout call counter (DataParallelStep keeps them in an LRU and passes the same `share`)."""
         from . import _lib, engine
@@ -59,7 +61,7 @@ class HipBackend:
         self.state = st
         self.rng = st.rng
         self.call = engine.NetCall(flat_params, self.audio, [self.text, self.feat4], self.video, True, self.rng,
-                                   sample0=sample0, bf16=bf16)
+                                   sample0=sample0, bf16=bf16, planes=planes)
         V = 2 * B
         self.d_vals = torch.empty(V, 1, device=dev)
         self.d_fused = torch.empty(V, engine.H, device=dev)
@@ -206,7 +208,7 @@ class DataParallelStep:
 
     def __init__(self, flat_params, B, T, dims, weights=(0.5, 0.5, 0.1, 0.7, 0.1, 0.8), lr=1e-4, betas=(0.9, 0.999),
                  eps=1e-8, weight_decay=1e-5, seed=0, exact=True, backend_factory=None, bf16=False,
-                 force_collectives=False):
+                 force_collectives=False, planes=False):
         import collections
         import inspect
         self.rank, self.world = _world()
@@ -218,6 +220,8 @@ class DataParallelStep:
         self.B_global = B * self.world if exact else B
         factory = backend_factory or HipBackend
         extra = {"bf16": True} if bf16 else {}
+        if planes:
+            extra["planes"] = True      # (resident batches: HipBackend)
         # One backend per batch shape (B, T_audio, T_text, T_video, T_feat4), least recently used first out, all continuing
         # ONE run state: the reference pads every batch to its own maximum and ends an epoch on a short batch.
         self._shares = "share" in inspect.signature(factory).parameters

@@ -30,11 +30,11 @@ def test_struct_sizes_match_the_header():
     src = r'''
 #include <stdio.h>
 #include "sdumc_hip.h"
-int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(sdumc_gemm_b1), sizeof(sdumc_gemm_p3), sizeof(sdumc_gemm_bf16),
+int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(sdumc_gemm_b1), sizeof(sdumc_gemm_p3), sizeof(sdumc_gemm_bf16),
  sizeof(sdumc_gg_problem), sizeof(sdumc_rows_problem), sizeof(sdumc_umca), sizeof(sdumc_dropout), sizeof(sdumc_gemm),
  sizeof(sdumc_attnpool), sizeof(sdumc_attnpool_bwd_t), sizeof(sdumc_dropsum), sizeof(sdumc_net_dims),
  sizeof(sdumc_net_io), sizeof(sdumc_net_grads), sizeof(sdumc_step_cfg), sizeof(sdumc_softmax), sizeof(sdumc_dropadd),
- sizeof(sdumc_mha), sizeof(sdumc_mha_grads)); return 0;}
+ sizeof(sdumc_mha), sizeof(sdumc_mha_grads), sizeof(sdumc_gather_seg), sizeof(sdumc_gather_desc)); return 0;}
 '''
     with tempfile.TemporaryDirectory() as td:
         open(os.path.join(td, "t.c"), "w").write(src)
@@ -42,7 +42,7 @@ int main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %
         sizes = [int(v) for v in subprocess.check_output([os.path.join(td, "t")]).split()]
     mine = [C.sizeof(c) for c in (_lib.GemmB1, _lib.GemmP3, _lib.GemmBf16, _lib.GGProblem, _lib.RowsProblem, _lib.Umca, _lib.Dropout, _lib.Gemm, _lib.AttnPool, _lib.AttnPoolBwd, _lib.DropSum, _lib.NetDims,
                                   _lib.NetIO, _lib.NetGrads, _lib.StepCfg, _lib.Softmax, _lib.DropAdd, _lib.Mha,
-                                  _lib.MhaGrads)]
+                                  _lib.MhaGrads, _lib.GatherSeg, _lib.GatherBatch)]
     assert sizes == mine
 
 

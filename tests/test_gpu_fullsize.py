@@ -36,17 +36,39 @@ def E():
     return engine
 
 
-def _step_fp32_vs_oracle(E, cfg, pseed, bseed, seed, delta_names):
+# fp32 at full size: every live gradient tensor by its OWN norm (77 of C2's 83 gradient tensors have max |g| < 1e-3 -- frame weights
+# ~1e-5, the smallest 3.5e-10 -- so an absolute tolerance tied to max(1, |g|) passes an all-zero gradient; that was this test until
+# round 6).  Measured on MI355X at C2 / C5: median ~2e-6, worst ~3e-5 (the RnC head's tiny biases are handled by grad_errors:
+# zero by translation invariance, must be as small on the device).  A kernel that drops a term moves its tensors to >= 1e-2.
+FP32_GRAD_TOL = 2e-4
+
+
+_ORACLE_CACHE = {}
+
+
+def _oracle_step(cfg, pseed, bseed, seed):
+    """(P, batch, Pd after Adam, loss, terms, grads, outs): 5-10 s of CPU per call at these sizes, shared by the two product paths"""
     from oracle import sdumc_oracle as O
+    key = (cfg, pseed, bseed, seed)
+    if key not in _ORACLE_CACHE:
+        dims, B, Tn = cfg
+        P = O.init_params(dims, seed=pseed)
+        batch = O.synthetic_batch(B, Tn, dims, seed=bseed)
+        Pd = {k: v.clone() for k, v in P.items()}
+        _ORACLE_CACHE[key] = (P, batch, Pd) + tuple(O.train_step(Pd, {}, *batch, mode="philox", seed=seed, step=0))
+    return _ORACLE_CACHE[key]
+
+
+def _step_fp32_vs_oracle(E, cfg, pseed, bseed, seed, delta_names, planes):
+    """planes=False: the step a set_batch-per-step loop runs (in-kernel operand split, csrc/gemm_wide.hip); planes=True: the step over
+    RESIDENT batches -- bench.py's headline and FusedTrainer.run_epoch -- whose frame / key projections read bf16 planes (csrc/gemm_p3.hip)."""
     dims, B, Tn = cfg
-    P = O.init_params(dims, seed=pseed)
+    P, batch, Pd, loss, terms, grads, outs = _oracle_step(cfg, pseed, bseed, seed)
     flat, lay = flat_from(E, P, dims)
-    batch = O.synthetic_batch(B, Tn, dims, seed=bseed)
-    ts = E.TrainStep(flat, B, Tn, dims, seed=seed)
+    ts = E.TrainStep(flat, B, Tn, dims, seed=seed, planes=planes)
+    assert (ts._planes is not None) == planes
     ts.set_batch(*[t.cuda() for t in batch])
     losses = ts.run().cpu().numpy()
-    Pd = {k: v.clone() for k, v in P.items()}
-    loss, terms, grads, outs = O.train_step(Pd, {}, *batch, mode="philox", seed=seed, step=0)
     np.testing.assert_allclose(losses[0], float(loss), rtol=1e-3)              # north-star tolerance: 1e-3
     np.testing.assert_allclose(losses[1:7], [float(t) for t in terms], rtol=1e-3, atol=1e-5)
     for s in range(2):
@@ -55,23 +77,32 @@ def _step_fp32_vs_oracle(E, cfg, pseed, bseed, seed, delta_names):
     gv = lay.views(torch.cat([ts.grads.cpu(), torch.zeros(lay.total - lay.live)]))
     assert set(grads) == set(lay.live_names())
     for k in lay.live_names():
-        close(gv[k], grads[k], 1e-3, k)
+        close(gv[k], grads[k], 1e-3, k)           # (the north-star's absolute bar; says little about tensors far below 1e-3 ...)
+    errs = grad_errors(lay, gv, grads)            # (... so: every tensor relative to its own norm)
+    worst = max(errs, key=errs.get)
+    vals = sorted(errs.values())
+    print("fp32 %s, planes=%s: gradient errors relative to each tensor's norm: median %.3g, p90 %.3g, worst %s = %.3g" %
+          ("C2" if cfg is C2 else "C5", planes, float(np.median(vals)), vals[int(0.9 * len(vals))], worst, errs[worst]))
+    for k, e in errs.items():
+        assert e < FP32_GRAD_TOL, f"{k}: relative gradient error {e:.3e} (|g| = {float(grads[k].norm()):.3e})"
     pv = lay.views(flat.cpu())
     for k in delta_names:          # post-Adam deltas (first step: lr * g / (|g| + eps))
         close((pv[k] - P[k]) * 1e4, (Pd[k] - P[k]) * 1e4, 2e-2, k)
 
 
-def test_c2_fp32_step_at_batch_64_vs_oracle(E):
-    """BASELINE configs[1] at its stated batch: loss + six terms, five outputs of both streams, EVERY live gradient tensor and
-    the post-Adam deltas of three tensors against oracle.train_step(mode="philox")."""
+@pytest.mark.parametrize("planes", [True, False])
+def test_c2_fp32_step_at_batch_64_vs_oracle(E, planes):
+    """BASELINE configs[1] at its stated batch: loss + six terms, five outputs of both streams, EVERY live gradient tensor (relative to
+    its own norm) and the post-Adam deltas of three tensors against oracle.train_step(mode="philox"), on both product paths."""
     _step_fp32_vs_oracle(E, C2, 0, 1234, 777,
-                         ("frame_dim_reshape_1.weight", "cross_att_fra2utt_0.input_proj.weight", "fc_out_v.weight"))
+                         ("frame_dim_reshape_1.weight", "cross_att_fra2utt_0.input_proj.weight", "fc_out_v.weight"), planes)
 
 
-def test_c5_fp32_step_at_per_gpu_batch_32_vs_oracle(E):
+@pytest.mark.parametrize("planes", [True, False])
+def test_c5_fp32_step_at_per_gpu_batch_32_vs_oracle(E, planes):
     """BASELINE configs[4]'s per-GPU slice (B = 32, T = 512 for every modality, d = 1024) in fp32 against the oracle."""
     _step_fp32_vs_oracle(E, C5, 4, 21, 11,
-                         ("frame_dim_reshape_0.weight", "cross_att_fra2utt_2.input_proj.weight", "cross_attention_mlp.0.weight"))
+                         ("frame_dim_reshape_0.weight", "cross_att_fra2utt_2.input_proj.weight", "cross_attention_mlp.0.weight"), planes)
 
 
 def _step_bf16_vs_oracles(E, cfg, pseed, bseed, seed):

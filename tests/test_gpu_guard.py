@@ -44,10 +44,12 @@ class Neighbour:
                 self.dst.copy_(self.src)
 
 
-def test_fp32_split_train_step_is_bit_reproducible_over_200_runs(E):
+@pytest.mark.parametrize("planes", [True, False])
+def test_fp32_split_train_step_is_bit_reproducible_over_200_runs(E, planes):
     """200 C2 train steps (B = 64, fp32 tensors, the default split arithmetic) from IDENTICAL state -- parameters, Adam moments,
     step counter and dropout call counter reset before each: the 8 loss values, the whole flat gradient bucket and the updated
-    parameters are bit-identical to the first run's."""
+    parameters are bit-identical to the first run's.  planes=True: the step over a resident batch (bench.py's headline, the epoch
+    path: projections on bf16 planes, csrc/gemm_p3.hip); False: the set_batch-per-step path (in-kernel split, csrc/gemm_wide.hip)."""
     from oracle import sdumc_oracle as O
     from sdumc_amd import _lib
     assert _lib.lib.sdumc_get_split_() == 15 or True      # (an SDUMC_SPLIT=<mask> suite run guards that mask instead)
@@ -58,7 +60,8 @@ def test_fp32_split_train_step_is_bit_reproducible_over_200_runs(E):
     feats = [torch.randn(B, T_C2[i], DIMS[i], device="cuda", generator=g) for i in range(4)]
     vals = torch.rand(B, device="cuda", generator=g) * 6 - 3
     flat = flat0.clone()
-    ts = E.TrainStep(flat, B, T_C2, DIMS, seed=5)
+    ts = E.TrainStep(flat, B, T_C2, DIMS, seed=5, planes=planes)
+    assert (ts._planes is not None) == planes
     ts.set_batch(*feats, vals)
     nb = Neighbour()
     ref, bad = None, []
@@ -91,7 +94,8 @@ def test_fp32_split_c4_eval_forward_is_bit_reproducible_over_200_runs(E):
     flat, lay = flat_from(E, P, DIMS)
     g = torch.Generator(device="cuda").manual_seed(43)
     audio, text, video, feat4 = [torch.randn(B, T_C2[i], DIMS[i], device="cuda", generator=g) for i in range(4)]
-    nc = E.NetCall(flat, audio, [text, feat4], video, False, None)
+    nc = E.NetCall(flat, audio, [text, feat4], video, False, None, planes=True)
+    assert nc._planes is not None
     nb = Neighbour()
     ref, bad = None, []
     for rep in range(200):
