@@ -607,7 +607,7 @@ typedef struct sdumc_gather_seg {
   void* out;                 /* [B, Tmax, 16 d4 bytes] */
   int32_t* len_out;          /* optional [B] */
   int32_t Tmax, d4;
-  int64_t unit0;
+  int64_t unit0;            /* (filled by the call: first output row of the segment in the launch's row space) */
 } sdumc_gather_seg;
 typedef struct sdumc_gather_desc {
   sdumc_gather_seg seg[SDUMC_GATHER_MAX_SEGS];
@@ -615,7 +615,7 @@ typedef struct sdumc_gather_desc {
   const int64_t* idx;        /* device [B] */
   const float* labels_all;   /* [N] or NULL */
   float* labels_out;         /* [B] or NULL */
-  int64_t total;
+  int64_t total;             /* (filled by the call: output rows of all segments) */
 } sdumc_gather_desc;
 int sdumc_gather_batch(const sdumc_gather_desc* g, int32_t max_workgroups, void* stream);
 

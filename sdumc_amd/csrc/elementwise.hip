@@ -126,12 +126,12 @@ __global__ void gather_pad_idx_kernel(const float* packed, const int64_t* start_
 
 // One launch assembles a WHOLE batch: up to SDUMC_GATHER_MAX_SEGS packed tensors (the four modalities' features, and their bf16
 // planes when the store holds them) gathered / right-zero-padded into the step's input buffers, plus the labels and the valid frame
-// counts.  Grid-stride over 16-byte units with four independent loads in flight per thread and a CAPPED number of workgroups: the
-// launch is meant to run on a side stream BESIDE the previous step (engine.FusedTrainer prefetches the next batch), where an
-// uncapped grid would queue tens of thousands of workgroups in front of the step's own kernels.
+// counts.  One wave per output ROW at a time (the row's source -- utterance, frame, or "padding" -- is resolved once per row, in
+// 32-bit arithmetic; the lanes then stream its 16-byte units, four loads in flight each), waves striding over the rows of all
+// segments, and a CAPPED number of workgroups: the launch is meant to run on a side stream BESIDE a step (engine.FusedTrainer
+// prefetches the next batch), where an uncapped grid would queue tens of thousands of workgroups in front of the step's own kernels.
 __global__ __launch_bounds__(256) void gather_batch_kernel(const sdumc_gather_desc g) {
-  const int64_t stride = (int64_t)gridDim.x * 256;
-  const int64_t i0 = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int i0 = blockIdx.x * 256 + threadIdx.x;
   if (i0 < g.B) {
     const int64_t e = g.idx[i0];
     if (g.labels_out) g.labels_out[i0] = g.labels_all[e];
@@ -141,33 +141,30 @@ __global__ __launch_bounds__(256) void gather_batch_kernel(const sdumc_gather_de
         g.seg[s].len_out[i0] = n < g.seg[s].Tmax ? n : g.seg[s].Tmax;
       }
   }
-  for (int64_t i = i0; i < g.total; i += 4 * stride) {
-    f32x4 v[4];
-    int64_t dst[4];
-    int sid[4];
+  const int lane = threadIdx.x & 63;
+  const uint32_t nwaves = gridDim.x * 4u, total = (uint32_t)g.total;
+  for (uint32_t row = blockIdx.x * 4u + (threadIdx.x >> 6); row < total; row += nwaves) {
+    int s = 0;
+    while (s + 1 < g.nseg && (uint32_t)g.seg[s + 1].unit0 <= row) ++s;
+    const sdumc_gather_seg& sg = g.seg[s];
+    const uint32_t r = row - (uint32_t)sg.unit0;
+    const uint32_t b = r / (uint32_t)sg.Tmax, t = r - b * (uint32_t)sg.Tmax;
+    const int64_t e = g.idx[b];
+    const bool valid = (int)t < sg.len_all[e];
+    const int d4 = sg.d4;
+    const float* src = static_cast<const float*>(sg.packed) + (size_t)(valid ? sg.start_all[e] + t : 0) * d4 * 4;
+    float* dst = static_cast<float*>(sg.out) + (size_t)r * d4 * 4;
+    for (int c = lane; c < d4; c += 256) {
+      f32x4 v[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int64_t j = i + u * stride;
-      v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
-      sid[u] = -1;
-      dst[u] = 0;
-      if (j < g.total) {
-        int s = 0;
-        while (s + 1 < g.nseg && g.seg[s + 1].unit0 <= j) ++s;
-        const sdumc_gather_seg& sg = g.seg[s];
-        const int64_t l = j - sg.unit0;
-        const int c = (int)(l % sg.d4);
-        const int64_t r = l / sg.d4;
-        const int t = (int)(r % sg.Tmax), b = (int)(r / sg.Tmax);
-        const int64_t e = g.idx[b];
-        sid[u] = s;
-        dst[u] = l;
-        if (t < sg.len_all[e]) v[u] = ld4(static_cast<const float*>(sg.packed) + ((size_t)(sg.start_all[e] + t) * sg.d4 + c) * 4);
+      for (int u = 0; u < 4; ++u) {
+        v[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (valid && c + 64 * u < d4) v[u] = ld4(src + 4 * (c + 64 * u));
       }
-    }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (sid[u] >= 0) st4(static_cast<float*>(g.seg[sid[u]].out) + 4 * dst[u], v[u]);
+      for (int u = 0; u < 4; ++u)
+        if (c + 64 * u < d4) st4(dst + 4 * (c + 64 * u), v[u]);
+    }
   }
 }
 
@@ -583,19 +580,19 @@ extern "C" int sdumc_gather_batch(const sdumc_gather_desc* gp, int32_t max_workg
   if (!gp || gp->nseg < 1 || gp->nseg > SDUMC_GATHER_MAX_SEGS || gp->B <= 0 || !gp->idx) return SDUMC_EINVAL;
   if ((gp->labels_out != nullptr) != (gp->labels_all != nullptr)) return SDUMC_EINVAL;
   sdumc_gather_desc g = *gp;
-  int64_t total = 0;
+  int64_t total = 0;      // output rows of all segments
   for (int s = 0; s < g.nseg; ++s) {
     sdumc_gather_seg& sg = g.seg[s];
     if (!sg.packed || !sg.start_all || !sg.len_all || !sg.out || sg.Tmax <= 0 || sg.d4 <= 0) return SDUMC_EINVAL;
     if ((reinterpret_cast<uintptr_t>(sg.packed) | reinterpret_cast<uintptr_t>(sg.out)) & 15) return SDUMC_EINVAL;
     sg.unit0 = total;
-    total += (int64_t)g.B * sg.Tmax * sg.d4;
+    total += (int64_t)g.B * sg.Tmax;
   }
+  if (total >= 0x7FFFFFFF) return SDUMC_EINVAL;
   g.total = total;
-  int64_t blocks = (total + 4 * 256 - 1) / (4 * 256);
+  int64_t blocks = (total + 3) / 4;      // one wave per row
   if (max_workgroups > 0 && blocks > max_workgroups) blocks = max_workgroups;
   if (blocks < (g.B + 255) / 256) blocks = (g.B + 255) / 256;
-  if (blocks > 0x7FFFFFFF) return SDUMC_EINVAL;
   hipLaunchKernelGGL(gather_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, as_stream(stream), g);
   SDUMC_CHECK_LAUNCH();
   return SDUMC_OK;

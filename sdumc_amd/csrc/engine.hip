@@ -1449,7 +1449,12 @@ sdumc_chain_args chain_args(const Ctx& c, bool fwd, const sdumc_net_grads* og, b
 int issue_prefetch(const Ctx& c) {
   if (!c.io.prefetch) return SDUMC_OK;
   const int wgs = c.io.prefetch_workgroups > 0 ? c.io.prefetch_workgroups : 512;
-  if (!c.multi || c.capturing || !c.lanes || !c.lanes->pf) return sdumc_gather_batch(c.io.prefetch, wgs, c.sts[0]);
+  static const int mode = [] { const char* e = getenv("SDUMC_PF_MODE"); return e ? atoi(e) : 1; }();      // (A/B: 0 in place, 2 lane 3)
+  if (!c.multi || c.capturing || !c.lanes || !c.lanes->pf || mode == 0) return sdumc_gather_batch(c.io.prefetch, wgs, c.sts[0]);
+  if (mode == 2) {
+    RET(link(c, 0, 3));
+    return sdumc_gather_batch(c.io.prefetch, wgs, c.sts[3]);
+  }
   hipEvent_t e = next_event(c);
   if (hipEventRecord(e, c.sts[0]) != hipSuccess || hipStreamWaitEvent(c.lanes->pf, e, 0) != hipSuccess) return SDUMC_ELAUNCH;
   return sdumc_gather_batch(c.io.prefetch, wgs, c.lanes->pf);

@@ -148,19 +148,19 @@ def test_c4_global_batch_512_on_one_gpu_and_two_simulated_ranks(E):
         np.testing.assert_allclose(l[3:7].numpy(), ref_losses[3:7].numpy(), rtol=1e-4)
     gv, rv = gsum.cpu(), ref_grads.cpu()
     worst = (0.0, "")
-    for k in lay.live_names():
-        off, shape, _ = lay.entries[k]
-        n = int(np.prod(shape))
+    span = {k: (lay.entries[k][0], int(np.prod(lay.entries[k][1]))) for k in lay.live_names()}
+    G = max(float(rv[o:o + n].double().norm()) / np.sqrt(n) for o, n in span.values())      # the largest per-element rms of a tensor
+    for k, (off, n) in span.items():
         close(gv[off:off + n], rv[off:off + n], 1e-3, k)
         # ... and relative to the tensor's own norm (most gradient tensors are far below the absolute bar: it would pass zeros).  The two
         # sides differ by summation order only (two K ranges of 256 rows against one of 512): measured <= 1e-5
         ref = float(rv[off:off + n].double().norm())
         err = float((gv[off:off + n].double() - rv[off:off + n].double()).norm())
-        if ref > 1e-9:
+        if ref / np.sqrt(n) >= 1e-6 * G:
             assert err / ref < 2e-4, f"{k}: DP(2 x 256) vs single(512) relative gradient error {err / ref:.3e} (|g| = {ref:.3e})"
             worst = max(worst, (err / ref, k))
-        else:      # (the RnC head's biases: zero by translation invariance)
-            assert err < 1e-7, (k, err)
+        else:      # (the RnC head's biases: zero by translation invariance -- rounding noise on both sides)
+            assert err / np.sqrt(n) < 1e-5 * G, (k, err, G)
     print("C4: DP(2 x 256) vs single process, worst relative gradient error %.3g (%s)" % worst)
     for be in bes:
         be.grads.copy_(gsum)
