@@ -177,6 +177,12 @@ typedef struct sdumc_gg_problem {
   int32_t bits_qw;          /* bytes per row of b_bits */
   float b_scale;            /* 1 / (1 - p) of the fused dropout */
   int32_t accumulate;       /* C += ..., colsum_a += ... */
+  /* Optional row maps (fp32 operands with the products on the bf16 matrix pipe, i.e. the default arithmetic; else SDUMC_EINVAL):
+   * B[s] is then the packed tensor of a RESIDENT feature store, of any size, and k-row r of segment s is ITS row b_map[s][r] (int32,
+   * device) -- the frame projections' weight gradient reads the batch in place.  No b_row_mod with it.  The bf16 form
+   * (sdumc_gemm_group_tn_bf16) takes maps too; it fetches entries four at a time: b_map[s] must be readable up to 4 * ceil(K[s] / 4)
+   * entries. */
+  const int32_t* b_map[2];
 } sdumc_gg_problem;
 size_t sdumc_gemm_group_workspace_bytes(const sdumc_gg_problem* probs, int32_t n);
 int sdumc_gemm_group_tn(const sdumc_gg_problem* probs, int32_t n, void* workspace, size_t workspace_bytes, void* stream);
@@ -257,6 +263,15 @@ typedef struct sdumc_gemm_p3 {
                                the chip in one round) */
   float* workspace;         /* >= sdumc_gemm_p3_workspace_bytes */
   size_t workspace_bytes;
+  /* Optional row maps: A (and A2) are then the packed P3 tensors of a RESIDENT feature store, of any size, and virtual row m reads
+   * A's row a_map[m] (m < a2_row0 or no A2) / A2's row a2_map[m - a2_row0]: the batch is read in place (a padded frame's entry names
+   * an all-zero row the store keeps).  Rows are fetched by 64-bit address (global_load_lds), so the 4 GiB operand limit does not
+   * apply.  Without a_bits / a_row_mod / tile_m; a2_map if and only if A2.  a_map_rows (optional): rows of the packed tensor(s) (the
+   * larger of the two): when a_map_rows * lda stays below 4 GiB the kernel keeps its descriptor addressing (faster than 64-bit
+   * addresses); 0 = unknown. */
+  const int32_t* a_map;
+  const int32_t* a2_map;
+  int64_t a_map_rows;
 } sdumc_gemm_p3;
 size_t sdumc_gemm_p3_workspace_bytes(const sdumc_gemm_p3* g);
 int sdumc_gemm_p3_nt(const sdumc_gemm_p3* g, void* stream);
@@ -290,6 +305,11 @@ typedef struct sdumc_gemm_b1 {
   int32_t splitk;           /* 0 auto, 1 none, > 1: K split over workgroups (fp32 slabs in workspace + an ordered reduce) */
   float* workspace;         /* >= sdumc_gemm_b1_workspace_bytes */
   size_t workspace_bytes;
+  /* Optional row maps, as in sdumc_gemm_p3: A (and A2) are the packed bf16 tensors of a resident feature store and virtual row m reads
+   * row a_map[m] (a2_map[m - a2_row0]); a_map_rows = rows of the packed tensor(s), 0 = unknown (64-bit addressing). */
+  const int32_t* a_map;
+  const int32_t* a2_map;
+  int64_t a_map_rows;
 } sdumc_gemm_b1;
 size_t sdumc_gemm_b1_workspace_bytes(const sdumc_gemm_b1* g);
 int sdumc_gemm_b1_nt(const sdumc_gemm_b1* g, void* stream);
@@ -596,7 +616,8 @@ int sdumc_gather_pad_idx(const float* packed, const int64_t* start_all, const in
  * (sdumc_p3_split of the packed tensor, made once per dataset: the planes of a zero row are zero bytes, so gathering plane rows
  * equals splitting the gathered batch bit for bit) -- into the step's input buffers, the labels (labels_out[b] =
  * labels_all[idx[b]], both or neither) and the valid frame counts (seg.len_out, optional).  A segment's rows are `d4` 16-byte
- * units wide (fp32 rows: d / 4; bf16 rows: d / 8; P3 rows: 3 d / 8), whatever they hold.  max_workgroups > 0 caps the grid (the
+ * units wide (fp32 rows: d / 4; bf16 rows: d / 8; P3 rows: 3 d / 8), whatever they hold.  A segment with map_out writes the batch's
+ * ROW MAP instead of (or beside) the padded copy: 4 bytes per frame instead of its 10 d.  max_workgroups > 0 caps the grid (the
  * kernel strides): a capped launch on a side stream fills the NEXT step's buffers beside the running step without queueing in
  * front of its kernels (sdumc_amd/engine.py, FusedTrainer); 0 = one pass.  seg.unit0 and total are filled by the call. */
 #define SDUMC_GATHER_MAX_SEGS 8
@@ -604,8 +625,11 @@ typedef struct sdumc_gather_seg {
   const void* packed;        /* [sum T, 16 d4 bytes] */
   const int64_t* start_all;  /* [N] first row of utterance e */
   const int32_t* len_all;    /* [N] its frames */
-  void* out;                 /* [B, Tmax, 16 d4 bytes] */
+  void* out;                 /* [B, Tmax, 16 d4 bytes]; NULL (with d4 = 0 and map_out given): no padded copy, the map only */
   int32_t* len_out;          /* optional [B] */
+  int32_t* map_out;          /* optional int32 [B * Tmax]: store row of batch row (b, t) = start_all[e] + t, or zero_row for padding
+                                (sdumc_net_io.row_map: the step then reads the batch in place) */
+  int32_t zero_row;          /* index of an all-zero row of the packed tensor (the store appends one) */
   int32_t Tmax, d4;
   int64_t unit0;            /* (filled by the call: first output row of the segment in the launch's row space) */
 } sdumc_gather_seg;
@@ -828,6 +852,19 @@ typedef struct sdumc_net_io {
   const void* audio_p3;
   const void* video_p3;
   const void* text_p3[2];
+  /* Optional, fp32 storage with planes: the batch is read IN PLACE from a resident feature store.  audio / video / text[s] (and the
+   * *_p3 pointers) are then the store's PACKED tensors [rows + 1][d] -- every utterance's frames one after the other, of any total size
+   * (tens of GB: 64-bit addressing), the last row all zero -- and row_map[i] (i = audio, text, video, feat4 as in `lengths`; device
+   * int32 [B * T_i]) names, for batch row b * T_i + t, the store row it is: start of utterance b + t for a valid frame, the zero row for
+   * padding (sdumc_gather_batch writes such maps: sdumc_gather_seg.map_out).  No padded copy of the batch exists anywhere: the frame
+   * projections fetch their A rows through the map (sdumc_gemm_p3.a_map), the frame projections' weight gradients their B rows
+   * (sdumc_gg_problem.b_map); nothing else reads the features.  All four (three when streams == 1) or none; fp32 storage: needs the
+   * *_p3 planes and the default split arithmetic; bf16 storage (audio / video / text[s] = the store's packed bf16 tensors): feature
+   * widths multiples of 128; else SDUMC_EINVAL.  The bf16 weight-gradient kernel reads map entries four at a time: each map must be
+   * readable up to a multiple of four entries.  store_rows[i] (optional): rows of packed tensor i -- tensors (and planes) below
+   * 4 GiB keep the kernels' descriptor addressing, which is faster than 64-bit addresses; 0 = unknown. */
+  const int32_t* row_map[4];
+  int64_t store_rows[4];
   /* Optional, train mode in fp32 storage: sdumc_net_bits_next_bytes(dims) bytes the caller keeps ACROSS calls of the same dims (its
    * own allocation, not part of `workspace`; zero it once) -- TWO sets of keep-bits for the frame-level input dropouts, each with a
    * {seed, call} tag.  A call reads set (bits_phase & 1); in its latency-bound middle, where the chip idles, it fills the OTHER set
@@ -848,12 +885,12 @@ typedef struct sdumc_net_io {
   int32_t bits_phase;
   size_t bits_next_bytes;
   const struct sdumc_net_dims* bits_next_dims;
-  /* Optional: the assembly of the NEXT batch (sdumc_gather_batch's descriptor; its output buffers must not be ones this call reads),
-   * issued by the call itself on an internal lowest-priority stream at the start of its utterance-level middle -- from there to the
-   * end of the backward the chip's HBM is mostly idle (the step is latency- and matrix-bound there), so the 2 x (features + planes)
-   * bytes of a batch move beside the step instead of in front of the next one.  sdumc_train_step (and a sdumc_net_forward on its
-   * own) returns with the gather ordered before `stream`.  prefetch_workgroups caps its grid (0 = 512: two small workgroups per CU
-   * leave every CU room for the step's own kernels).  The descriptor is read during the call only. */
+  /* Optional: the assembly of the NEXT batch (sdumc_gather_batch's descriptor: its row maps, or its padded copy; the output buffers
+   * must not be ones this call reads), issued by the call itself on its background lane at the start of its utterance-level middle --
+   * from there to the backward's frame-level tail the chip's HBM is mostly idle (the step is latency- and matrix-bound there), so the
+   * batch is put together beside the step instead of in front of the next one.  sdumc_train_step (and a sdumc_net_forward on its own)
+   * returns with the gather ordered before `stream`.  prefetch_workgroups caps its grid (0 = 512: two small workgroups per CU leave
+   * every CU room for the step's own kernels).  The descriptor is read during the call only. */
   const sdumc_gather_desc* prefetch;
   int32_t prefetch_workgroups;
   /* Optional caller-owned execution context (sdumc_ctx_create): the internal side streams and the event ring the call forks

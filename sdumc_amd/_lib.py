@@ -59,7 +59,7 @@ class GGProblem(C.Structure):
                 ("K", C.c_int32 * 2), ("b_row_mod", C.c_int32 * 2),
                 ("C", C.c_void_p), ("colsum_a", C.c_void_p),
                 ("M", C.c_int32), ("N", C.c_int32), ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
-                ("bits_qw", C.c_int32), ("b_scale", C.c_float), ("accumulate", C.c_int32)]
+                ("bits_qw", C.c_int32), ("b_scale", C.c_float), ("accumulate", C.c_int32), ("b_map", C.c_void_p * 2)]
 
 
 class GemmP3(C.Structure):
@@ -70,7 +70,8 @@ class GemmP3(C.Structure):
                 ("bias", C.c_void_p), ("act", C.c_int32),
                 ("C", C.c_void_p), ("ldc", C.c_int32), ("C_p3", C.c_void_p), ("ldc_p3", C.c_int64),
                 ("splitk", C.c_int32), ("tile_m", C.c_int32),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("a_map", C.c_void_p), ("a2_map", C.c_void_p), ("a_map_rows", C.c_int64)]
 
 
 class GemmB1(C.Structure):
@@ -79,7 +80,8 @@ class GemmB1(C.Structure):
                 ("a_row_mod", C.c_int32), ("A2", C.c_void_p), ("a2_row0", C.c_int32),
                 ("bias", C.c_void_p), ("act", C.c_int32),
                 ("C", C.c_void_p), ("ldc", C.c_int32), ("c_bf16", C.c_int32), ("splitk", C.c_int32),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+                ("a_map", C.c_void_p), ("a2_map", C.c_void_p), ("a_map_rows", C.c_int64)]
 
 
 class RowsProblem(C.Structure):
@@ -132,6 +134,8 @@ class NetIO(C.Structure):
                 ("text_hidden", C.c_void_p), ("cross_text", C.c_void_p),
                 ("lengths", C.c_void_p * 4),
                 ("audio_p3", C.c_void_p), ("video_p3", C.c_void_p), ("text_p3", C.c_void_p * 2),   # optional bf16-plane copies of the features
+                ("row_map", C.c_void_p * 4),      # optional: the features are a resident store's packed tensors, read in place through these maps
+                ("store_rows", C.c_int64 * 4),    # ... and those tensors' row counts (0 = unknown)
                 ("bits_next", C.c_void_p), ("bits_phase", C.c_int32),   # optional: two sets of keep-bits, the next call's generated in this call's middle
                 ("bits_next_bytes", C.c_size_t), ("bits_next_dims", C.c_void_p),   # its capacity (0 = this call's dims) / dims of the NEXT call (NULL = the same)
                 ("prefetch", C.c_void_p), ("prefetch_workgroups", C.c_int32),      # optional: the NEXT batch's gather descriptor, issued in this call's middle
@@ -158,7 +162,8 @@ GATHER_MAX_SEGS = 8
 
 class GatherSeg(C.Structure):
     _fields_ = [("packed", C.c_void_p), ("start_all", C.c_void_p), ("len_all", C.c_void_p), ("out", C.c_void_p),
-                ("len_out", C.c_void_p), ("Tmax", C.c_int32), ("d4", C.c_int32), ("unit0", C.c_int64)]
+                ("len_out", C.c_void_p), ("map_out", C.c_void_p), ("zero_row", C.c_int32), ("Tmax", C.c_int32), ("d4", C.c_int32),
+                ("unit0", C.c_int64)]
 
 
 class GatherBatch(C.Structure):

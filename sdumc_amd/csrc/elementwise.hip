@@ -152,6 +152,8 @@ __global__ __launch_bounds__(256) void gather_batch_kernel(const sdumc_gather_de
     const int64_t e = g.idx[b];
     const bool valid = (int)t < sg.len_all[e];
     const int d4 = sg.d4;
+    if (sg.map_out && lane == 0) sg.map_out[r] = valid ? (int32_t)(sg.start_all[e] + t) : sg.zero_row;
+    if (!sg.out) continue;      // (the map only: the step reads the batch in place)
     const float* src = static_cast<const float*>(sg.packed) + (size_t)(valid ? sg.start_all[e] + t : 0) * d4 * 4;
     float* dst = static_cast<float*>(sg.out) + (size_t)r * d4 * 4;
     for (int c = lane; c < d4; c += 256) {
@@ -583,7 +585,9 @@ extern "C" int sdumc_gather_batch(const sdumc_gather_desc* gp, int32_t max_workg
   int64_t total = 0;      // output rows of all segments
   for (int s = 0; s < g.nseg; ++s) {
     sdumc_gather_seg& sg = g.seg[s];
-    if (!sg.packed || !sg.start_all || !sg.len_all || !sg.out || sg.Tmax <= 0 || sg.d4 <= 0) return SDUMC_EINVAL;
+    if (!sg.start_all || !sg.len_all || sg.Tmax <= 0 || (!sg.out && !sg.map_out)) return SDUMC_EINVAL;
+    if (sg.out && (!sg.packed || sg.d4 <= 0)) return SDUMC_EINVAL;
+    if (sg.map_out && ((reinterpret_cast<uintptr_t>(sg.map_out) & 3) || sg.zero_row < 0)) return SDUMC_EINVAL;
     if ((reinterpret_cast<uintptr_t>(sg.packed) | reinterpret_cast<uintptr_t>(sg.out)) & 15) return SDUMC_EINVAL;
     sg.unit0 = total;
     total += (int64_t)g.B * sg.Tmax;

@@ -446,8 +446,6 @@ bool make_plan(const sdumc_net_dims& d, Plan& p) {
 struct LaneSet {
   hipStream_t s[2] = {nullptr, nullptr};
   hipStream_t bg = nullptr;   // lane 3: dW batches, keep-bits, the forward Cross_Attention key GEMMs
-  hipStream_t pf = nullptr;   // lowest priority: the next batch's assembly (sdumc_net_io.prefetch), beside the step's middle and backward
-  hipEvent_t pf_done = nullptr;
   static constexpr unsigned NEV = 256;
   hipEvent_t ev[NEV];
   std::atomic<unsigned> next{0};
@@ -486,6 +484,7 @@ bool create_lanes(LaneSet& S) {
   if (hipGetDevice(&S.device) != hipSuccess) return false;
   int least = 0, greatest = 0;
   if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return false;
+  (void)least;
   const int prio = greatest;
   for (int i = 0; i < 2; ++i)
     if (hipStreamCreateWithPriority(&S.s[i], hipStreamNonBlocking, prio) != hipSuccess) return false;
@@ -494,8 +493,6 @@ bool create_lanes(LaneSet& S) {
   // (lane 3 at the lowest priority, so that the grouped weight-gradient launches would only fill what the critical lanes
   //  leave: measured 1.877 vs 1.784 ms per step -- the launches then start late and end up as the step's tail)
   if (hipStreamCreateWithPriority(&S.bg, hipStreamNonBlocking, prio) != hipSuccess) return false;
-  if (hipStreamCreateWithPriority(&S.pf, hipStreamNonBlocking, least) != hipSuccess) return false;
-  if (hipEventCreateWithFlags(&S.pf_done, hipEventDisableTiming) != hipSuccess) return false;
   S.ok = true;
   return true;
 }
@@ -503,8 +500,6 @@ void destroy_lanes(LaneSet& S) {
   for (int i = 0; i < 2; ++i)
     if (S.s[i]) { (void)sdumc_chain_cluster_forget_stream_(S.s[i]); (void)hipStreamDestroy(S.s[i]); }
   if (S.bg) { (void)sdumc_chain_cluster_forget_stream_(S.bg); (void)hipStreamDestroy(S.bg); }
-  if (S.pf) (void)hipStreamDestroy(S.pf);
-  if (S.pf_done) (void)hipEventDestroy(S.pf_done);
   if (S.ok)
     for (unsigned i = 0; i < LaneSet::NEV; ++i) (void)hipEventDestroy(S.ev[i]);
   S.ok = false;
@@ -962,6 +957,14 @@ int check_io(const sdumc_net_dims* d, const sdumc_net_io* io) {
          reinterpret_cast<uintptr_t>(io->text_p3[1])) & 15)
       return SDUMC_EINVAL;
   }
+  {   // row maps (the batch read in place from a resident store): all of (audio, text, video[, feat4]) or none; fp32 storage with planes
+    const int need = d->streams == 2 ? 4 : 3;
+    int have = 0;
+    for (int i = 0; i < need; ++i) have += io->row_map[i] != nullptr;
+    if (have != 0 && (have != need || d->bf16 == 1 || (d->bf16 == 0 && !io->audio_p3))) return SDUMC_EINVAL;
+    for (int i = 0; i < 4; ++i)
+      if ((reinterpret_cast<uintptr_t>(io->row_map[i]) & 15) || io->store_rows[i] < 0) return SDUMC_EINVAL;
+  }
   {   // key-padding lengths: all of (audio, text, video[, feat4]) or none
     const int need = d->streams == 2 ? 4 : 3;
     int have = 0;
@@ -1059,13 +1062,17 @@ int b1_refresh_weights(const Ctx& c, int m) {
   return sdumc_b1_frag_multi(c.P, wb1_ptr(c, 0), so, dofs, rows, cols, 3, c.st);
 }
 // frame_dim_reshape_m on bf16 features: x (bf16) of stream s (and, with feat2, of the next stream in the adjacent rows)
+const int32_t* feat_map(const Ctx& c, int m, int s);
+int64_t feat_store_rows(const Ctx& c, int m, int s, bool both);
 int b1_frame_proj(const Ctx& c, int m, int s, const void* feat, int rows, const void* feat2 = nullptr, int rows2 = 0) {
   const int din[3] = {c.d.da, c.d.dt, c.d.dv};
   sdumc_gemm_b1 g;
   memset(&g, 0, sizeof(g));
   g.M = rows + rows2; g.N = D; g.K = din[m];
   g.A = feat; g.lda = din[m];
-  if (feat2) { g.A2 = feat2; g.a2_row0 = rows; }
+  g.a_map = feat_map(c, m, s);      // (a resident store's packed bf16 rows, read in place)
+  g.a_map_rows = feat_store_rows(c, m, s, feat2 != nullptr);
+  if (feat2) { g.A2 = feat2; g.a2_row0 = rows; g.a2_map = feat_map(c, m, 1); }
   g.B = wb1_ptr(c, c.pl.wp3_frame[m]); g.ldb = (int64_t)(din[m] / 16) * 1024;
   g.bias = c.P + c.pm.frame[m].b;
   g.act = SDUMC_ACT_NONE;
@@ -1141,13 +1148,23 @@ int p3_refresh_weights(const Ctx& c, int m) {
   return sdumc_p3_split_frag_multi_(c.P, wp3_ptr(c, 0), so, dofs, rows, cols, 3, c.st);
 }
 // frame_dim_reshape_m on feature planes: x (fp32, for the pooling kernels and K3) and its planes (for the key projections)
+// the row map of modality m's features, stream s (sdumc_net_io.row_map is ordered audio, text, video, feat4) or nullptr
+int feat_slot(int m, int s) { return m == 0 ? 0 : (m == 2 ? 2 : (s == 0 ? 1 : 3)); }
+const int32_t* feat_map(const Ctx& c, int m, int s) { return c.io.row_map[feat_slot(m, s)]; }
+// rows of the packed tensor(s) a mapped launch reads (the larger when it reads two; 0 = unknown: 64-bit addressing)
+int64_t feat_store_rows(const Ctx& c, int m, int s, bool both) {
+  const int64_t a = c.io.store_rows[feat_slot(m, s)], b = both ? c.io.store_rows[feat_slot(m, 1)] : a;
+  return (a > 0 && b > 0) ? std::max(a, b) : 0;
+}
 int p3_frame_proj(const Ctx& c, int m, int s, const void* feat_p3, int rows, int splitk, const void* feat2_p3 = nullptr, int rows2 = 0) {
   const int din[3] = {c.d.da, c.d.dt, c.d.dv};
   sdumc_gemm_p3 g;
   memset(&g, 0, sizeof(g));
   g.M = rows + rows2; g.N = D; g.K = din[m];
   g.A = feat_p3; g.lda = (int64_t)din[m] * 6;
-  if (feat2_p3) { g.A2 = feat2_p3; g.a2_row0 = rows; }      // (the second stream's rows follow the first's in x)
+  g.a_map = feat_map(c, m, s);      // (a resident store's packed planes, read in place)
+  g.a_map_rows = feat_store_rows(c, m, s, feat2_p3 != nullptr);
+  if (feat2_p3) { g.A2 = feat2_p3; g.a2_row0 = rows; g.a2_map = feat_map(c, m, 1); }      // (the second stream's rows follow the first's in x)
   g.B = wp3_ptr(c, c.pl.wp3_frame[m]); g.ldb = (int64_t)(din[m] / 16) * 3072;
   g.bias = c.P + c.pm.frame[m].b;
   g.act = SDUMC_ACT_NONE;
@@ -1443,32 +1460,17 @@ sdumc_chain_args chain_args(const Ctx& c, bool fwd, const sdumc_net_grads* og, b
   return a;
 }
 
-// sdumc_net_io.prefetch: the next batch's gather on the lane set's lowest-priority stream, behind what the caller's stream has issued
-// so far (the frame-level head of this call: its projections are the step's heaviest HBM readers).  Without real lanes (concurrency
-// off, capture) it runs on the caller's stream, in place.
+// sdumc_net_io.prefetch: the next batch's assembly on lane 3, behind what the caller's stream has issued so far (the frame-level head
+// of this call: its projections are the step's heaviest HBM readers) -- lane 3 idles from here to the backward's early launch, and the
+// step's final join of that lane orders the gather before whatever follows the step.  (Measured, round 6: a stream of its own at
+// the LOWEST priority starves -- the gather then ends behind the step, 2.14 against 1.55 ms per step with padded copies and 1.68
+// against 1.33 with row maps; in place on the caller's stream 1.70 / 1.33; profiles/README.md.)
 int issue_prefetch(const Ctx& c) {
   if (!c.io.prefetch) return SDUMC_OK;
   const int wgs = c.io.prefetch_workgroups > 0 ? c.io.prefetch_workgroups : 512;
-  static const int mode = [] { const char* e = getenv("SDUMC_PF_MODE"); return e ? atoi(e) : 1; }();      // (A/B: 0 in place, 2 lane 3)
-  if (!c.multi || c.capturing || !c.lanes || !c.lanes->pf || mode == 0) return sdumc_gather_batch(c.io.prefetch, wgs, c.sts[0]);
-  if (mode == 2) {
-    RET(link(c, 0, 3));
-    return sdumc_gather_batch(c.io.prefetch, wgs, c.sts[3]);
-  }
-  hipEvent_t e = next_event(c);
-  if (hipEventRecord(e, c.sts[0]) != hipSuccess || hipStreamWaitEvent(c.lanes->pf, e, 0) != hipSuccess) return SDUMC_ELAUNCH;
-  return sdumc_gather_batch(c.io.prefetch, wgs, c.lanes->pf);
-}
-// ... and its completion ordered before the caller's stream (end of sdumc_train_step / of a forward on its own)
-int join_prefetch(const sdumc_net_io* io, hipStream_t stream) {
-  if (!io->prefetch) return SDUMC_OK;
-  LaneSet* S = io->ctx ? static_cast<LaneSet*>(io->ctx) : default_lanes();
-  if (!S || !S->pf) return SDUMC_OK;
-  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusActive) return SDUMC_OK;   // (issued in place: issue_prefetch)
-  // (one event per lane set: a context is driven by one thread at a time, and the record / wait pair is issued back to back)
-  if (hipEventRecord(S->pf_done, S->pf) != hipSuccess || hipStreamWaitEvent(stream, S->pf_done, 0) != hipSuccess) return SDUMC_ELAUNCH;
-  return SDUMC_OK;
+  if (!c.multi || c.capturing) return sdumc_gather_batch(c.io.prefetch, wgs, c.sts[0]);
+  RET(link(c, 0, 3));
+  return sdumc_gather_batch(c.io.prefetch, wgs, c.sts[3]);
 }
 
 int forward(const Ctx& c) {
@@ -1485,6 +1487,7 @@ int forward(const Ctx& c) {
   // 1+2. three independent per-modality chains, one per lane:
   //      keep-bits of the two frame-level input dropouts -> frame_dim_reshape_m (model :282-284; audio/video once
   //      for both streams) -> keys of fra2utt_m AND cross_att_fra2utt_m -> FRA2UTT pooling (model :288-290)
+  if (c.io.row_map[0] && !p3_mode(c) && !b1_mode(c)) return SDUMC_EINVAL;      // (only gemm_p3 / gemm_b1 fetch their rows through a map)
   RET(fork_all(c));
   const bool chain = use_chain(c);
   hipEvent_t wt_done = nullptr;
@@ -2510,8 +2513,10 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
         fq.A[s] = reinterpret_cast<const float*>(c.ph(pl.dx[m][s]));
         fq.B[s] = in;
         fq.K[s] = rows;
+        fq.b_map[s] = feat_map(c, m, s);      // (a resident store's packed bf16 rows, read in place)
         continue;
       }
+      if (c.h() && c.io.row_map[0]) return SDUMC_EINVAL;      // (only the grouped launch fetches its rows through a map)
       if (c.h()) {     // dW_frame = dx^T features on bf16 storage
         sdumc_gemm_bf16 gh = GH_(SDUMC_TN, D, din[m], rows);
         gh.A[0] = c.ph(pl.dx[m][s]);
@@ -2529,8 +2534,10 @@ int backward(const Ctx& c, const sdumc_net_grads& og, int phases = 3) {
         fq.A[s] = c.p(pl.dx[m][s]);
         fq.B[s] = in;
         fq.K[s] = rows;
+        fq.b_map[s] = feat_map(c, m, s);      // (a resident store's packed rows, read in place)
         continue;
       }
+      if (c.io.row_map[0]) return SDUMC_EINVAL;      // (only the grouped launch fetches its rows through a map)
       sdumc_gemm g = G_(SDUMC_TN, D, din[m], rows);
       g.A[0] = c.p(pl.dx[m][s]);
       g.lda = D;
@@ -2714,8 +2721,7 @@ int net_forward_impl(const sdumc_net_dims* d, const sdumc_net_io* io, void* stre
   c.P = io->params;
   c.init_lanes();
   RET(forward(c));
-  if (join_bits && bits_pregen(c)) RET(link(c, 3, 0));
-  if (join_bits) RET(join_prefetch(io, as_stream(stream)));
+  if (join_bits && (bits_pregen(c) || io->prefetch)) RET(link(c, 3, 0));
   return SDUMC_OK;
 }
 }  // namespace
@@ -2907,8 +2913,7 @@ extern "C" int sdumc_train_step(const sdumc_net_dims* d, const sdumc_net_io* io,
                         cfg->eps, cfg->weight_decay, 1.0f, d->train ? const_cast<uint32_t*>(io->rng_state) : nullptr, 2u,
                         total_pending ? &tl : nullptr, stream));
   mark(static_cast<hipStream_t>(stream), 10);
-  RET(join_prefetch(io, static_cast<hipStream_t>(stream)));      // the next batch is assembled before anything behind this step reads it
-  return SDUMC_OK;
+  return SDUMC_OK;      // (the backward's last act joined lane 3: the next batch's assembly, too, is ordered before whatever follows)
 }
 
 extern "C" int sdumc_debug_marks(int on) {

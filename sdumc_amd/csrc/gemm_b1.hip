@@ -24,6 +24,7 @@
 namespace sdumc_b1 {
 
 typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
@@ -55,6 +56,9 @@ struct Args {
   int nsplit, kchunk;
 };
 
+// MAPPED: the rows of A are named by a row map (sdumc_gemm_b1.a_map: A is a resident store's packed bf16 tensor, the batch is read in
+// place): 1 = the tensor is below 4 GiB, the map entry replaces the row index in the descriptor offset; 2 = rows by 64-bit address
+template <int MAPPED>
 __global__ __launch_bounds__(NTHR, 2) void gemm_b1_nt_kernel(const Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   const sdumc_gemm_b1& g = a.g;
@@ -73,23 +77,33 @@ __global__ __launch_bounds__(NTHR, 2) void gemm_b1_nt_kernel(const Args a) {
   const bool second = g.A2 != nullptr && m0 >= g.a2_row0;      // rows [a2_row0, M) live in a second tensor (the text slot's two streams)
   const int arow0 = second ? g.a2_row0 : 0;
   const int a_rows = g.a_row_mod > 0 ? g.a_row_mod : (g.A2 ? (second ? g.M - g.a2_row0 : g.a2_row0) : g.M);
+  const size_t ra_rows = MAPPED == 1 ? (size_t)g.a_map_rows : (size_t)a_rows;
   const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(second ? g.A2 : g.A), 0,
-                                                                     (int)min((size_t)a_rows * (size_t)g.lda * 2, (size_t)0xFFFFFFF0u), 0x00020000);
+                                                                     (int)min(ra_rows * (size_t)g.lda * 2, (size_t)0xFFFFFFF0u), 0x00020000);
   // ---- A: this wave's two DMA pieces of a stage (pieces wave and wave + 4: 8 rows of 128 bytes each) ----
-  uint32_t voff[2];
+  [[maybe_unused]] uint32_t voff[2];
+  [[maybe_unused]] const char* gaddr[2];
+  [[maybe_unused]] const int32_t* amap = second ? g.a2_map : g.a_map;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int W = ((wave + 4 * i) << 6) + lane, row = W >> 3, up = W & 7, u = up ^ ((row >> 1) & 7);
     int r = min(m0 + row, g.M - 1) - arow0;
-    if (g.a_row_mod > 0) r %= g.a_row_mod;
-    voff[i] = ((uint32_t)r * (uint32_t)g.lda + (uint32_t)(kbeg + 8 * u)) * 2u;
+    if constexpr (MAPPED) r = amap[r];
+    else if (g.a_row_mod > 0) r %= g.a_row_mod;
+    if constexpr (MAPPED == 2) gaddr[i] = static_cast<const char*>(second ? g.A2 : g.A) + ((size_t)r * (size_t)g.lda + (size_t)(kbeg + 8 * u)) * 2u;
+    else voff[i] = ((uint32_t)r * (uint32_t)g.lda + (uint32_t)(kbeg + 8 * u)) * 2u;
   }
   auto issue_a = [&](int buf) {
     char* base = lds + buf * A_STAGE;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(base + (wave + 4 * i) * 1024), 16, voff[i], 0, 0, 0);
-      voff[i] += SK * 2;
+      if constexpr (MAPPED == 2) {
+        __builtin_amdgcn_global_load_lds((gbl_void_t*)gaddr[i], (lds_void_t*)(base + (wave + 4 * i) * 1024), 16, 0, 0);
+        gaddr[i] += SK * 2;
+      } else {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(base + (wave + 4 * i) * 1024), 16, voff[i], 0, 0, 0);
+        voff[i] += SK * 2;
+      }
     }
   };
   // fragment reads: rows 32 i + li, k-step j: unit (2 j + lh) ^ ((row >> 1) & 7)  ((32 i >> 1) & 7 == 0: the swizzle is the lane's)
@@ -337,17 +351,26 @@ extern "C" int sdumc_gemm_b1_nt(const sdumc_gemm_b1* gp, void* stream) {
   if (g.ldb < (int64_t)(g.K / 16) * FRAG_KT || (g.ldb & 15)) return SDUMC_EINVAL;
   if (g.act != SDUMC_ACT_NONE && g.act != SDUMC_ACT_TANH && g.act != SDUMC_ACT_RELU) return SDUMC_EINVAL;
   if (g.A2 && (g.a_row_mod || g.a2_row0 <= 0 || g.a2_row0 >= g.M || (g.a2_row0 % BM))) return SDUMC_EINVAL;
+  const bool mapped = g.a_map != nullptr;
+  if (mapped && (g.a_row_mod || (g.A2 != nullptr) != (g.a2_map != nullptr) || ((reinterpret_cast<uintptr_t>(g.a_map) | reinterpret_cast<uintptr_t>(g.a2_map)) & 3))) return SDUMC_EINVAL;
+  if (!mapped && g.a2_map) return SDUMC_EINVAL;
   const size_t a_bytes = (size_t)(g.a_row_mod > 0 ? g.a_row_mod : (g.A2 ? std::max(g.a2_row0, g.M - g.a2_row0) : g.M)) * (size_t)g.lda * 2;
-  if (a_bytes >= 0xFFFFFFF0u) return SDUMC_EINVAL;
+  if (!mapped && a_bytes >= 0xFFFFFFF0u) return SDUMC_EINVAL;      // (mapped rows beyond 4 GiB are fetched by 64-bit address)
+  const int mode = !mapped ? 0 : (g.a_map_rows > 0 && (size_t)g.a_map_rows * (size_t)g.lda * 2 < 0xFFFFFFF0u) ? 1 : 2;
   const Plan p = plan(g, g.workspace ? g.workspace_bytes : 0);
   if (p.nsplit > 1 && (!g.workspace || (reinterpret_cast<uintptr_t>(g.workspace) & 15))) return SDUMC_ENOMEM;
   static sdumc_dev_once attr_set;
-  if (sdumc_once_per_device(attr_set, [] { return sdumc_set_dyn_lds(&gemm_b1_nt_kernel, LDS_BYTES); }) != SDUMC_OK) return SDUMC_ELAUNCH;
+  if (sdumc_once_per_device(attr_set, [] {
+        return sdumc_set_dyn_lds(&gemm_b1_nt_kernel<0>, LDS_BYTES) && sdumc_set_dyn_lds(&gemm_b1_nt_kernel<1>, LDS_BYTES) && sdumc_set_dyn_lds(&gemm_b1_nt_kernel<2>, LDS_BYTES);
+      }) != SDUMC_OK)
+    return SDUMC_ELAUNCH;
   hipStream_t st = as_stream(stream);
   const int tok = sdumc_prof_begin_(28, 2.0 * g.M * (double)g.N * g.K, stream);
   Args a{g, p.nsplit, p.kchunk};
   const dim3 grid((unsigned)(((g.M + BM - 1) / BM) * (g.N / BN)), (unsigned)p.nsplit);
-  hipLaunchKernelGGL(gemm_b1_nt_kernel, grid, dim3(NTHR), LDS_BYTES, st, a);
+  if (mode == 0) hipLaunchKernelGGL(gemm_b1_nt_kernel<0>, grid, dim3(NTHR), LDS_BYTES, st, a);
+  else if (mode == 1) hipLaunchKernelGGL(gemm_b1_nt_kernel<1>, grid, dim3(NTHR), LDS_BYTES, st, a);
+  else hipLaunchKernelGGL(gemm_b1_nt_kernel<2>, grid, dim3(NTHR), LDS_BYTES, st, a);
   SDUMC_CHECK_LAUNCH();
   sdumc_prof_end_(tok, stream);
   if (p.nsplit > 1) {

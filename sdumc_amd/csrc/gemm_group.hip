@@ -35,6 +35,10 @@
 namespace sdumc_gg {
 
 typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(4))) int32_t const_i32_t;      // (a load through it with a wave-uniform index is a scalar load)
+typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
+typedef const __attribute__((address_space(4))) i32x4 const_i32x4_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
 
 constexpr int waitcnt_vm(int n) { return (n & 0xF) | ((n >> 4) << 14) | (0x7 << 4) | (0xF << 8); }
 
@@ -532,19 +536,24 @@ __global__ __launch_bounds__(NTHR, 2) void gg_tn_split2_kernel(const Launch L) {
       const uint32_t lda4 = (uint32_t)pr.lda * 4u, ldb4 = (uint32_t)pr.ldb * 4u, qw = (uint32_t)pr.bits_qw;
       const bool masked = pr.b_bits[seg] != nullptr;
       const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.A[seg]), 0, (int)((uint32_t)segK * lda4), 0x00020000);
-      const __amdgpu_buffer_rsrc_t rb = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.B[seg]), 0, (int)((uint32_t)(seg_mod > 0 ? seg_mod : segK) * ldb4), 0x00020000);
       const __amdgpu_buffer_rsrc_t rbits = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(masked ? pr.b_bits[seg] : (const uint8_t*)pr.A[seg]), 0,
                                                                              masked ? (int)((uint32_t)segK * qw) : 0, 0x00020000);
-      uint32_t voff[4], bvoff;
-      int srck[2] = {0, 0};
+      uint32_t voff[3], bvoff;
+      // A wave's piece of B is one whole k-row (1 KiB = 256 columns), so the row's address is wave-uniform: a descriptor per row, built
+      // on the scalar unit -- base = B + source row * ldb, one row of records, ZERO records for rows at and beyond K (zeros, as rows
+      // outside a whole-tensor descriptor's range would be).  Source row of k-row r: r, or r % b_row_mod (the streams share x_audio /
+      // x_video), or b_map[r] (B is a resident store's packed tensor, of any size: the batch is read in place; the entry is fetched
+      // with a scalar load one k-tile ahead).
+      const_i32_t* const bmap = (const_i32_t*)(uintptr_t)pr.b_map[seg];
+      const bool mapped = pr.b_map[seg] != nullptr;
+      int kcur[2], srow[2];      // k-row of this wave's two B pieces at the next issue / its source row
 #pragma unroll
       for (int i = 0; i < 2; ++i) voff[i] = (uint32_t)(kbeg + wave + 8 * i) * lda4 + (uint32_t)min(m0 + 4 * lane, pr.M - 4) * 4u;
+      voff[2] = (uint32_t)min(n0 + 4 * lane, pr.N - 4) * 4u;
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
-        int kr = kbeg + wave + 8 * i;
-        if (seg_mod > 0) kr %= seg_mod;
-        srck[i] = kr;
-        voff[2 + i] = (uint32_t)kr * ldb4 + (uint32_t)min(n0 + 4 * lane, pr.N - 4) * 4u;
+        kcur[i] = kbeg + wave + 8 * i;
+        srow[i] = mapped ? bmap[min(kcur[i], segK - 1)] : (seg_mod > 0 ? kcur[i] % seg_mod : kcur[i]);
       }
       {
         const int idx = ((wave & 3) << 6) + lane;               // dword index inside the [16][16 dwords] bits tile
@@ -554,21 +563,22 @@ __global__ __launch_bounds__(NTHR, 2) void gg_tn_split2_kernel(const Launch L) {
         char* base = ring0 + buf * STAGE2;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(base + wave * 1024), 16, voff[0], 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(base + (wave + 8) * 1024), 16, voff[1], 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(base + A_BYTES + wave * 1024), 16, voff[2], 0, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(base + A_BYTES + (wave + 8) * 1024), 16, voff[3], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const __amdgpu_buffer_rsrc_t rrow = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(pr.B[seg]) + (size_t)srow[i] * (size_t)pr.ldb, 0,
+                                                                                kcur[i] < segK ? (int)ldb4 : 0, 0x00020000);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rrow, (lds_void_t*)(base + A_BYTES + (wave + 8 * i) * 1024), 16, voff[2], 0, 0, 0);
+          kcur[i] += BK;
+          if (mapped) srow[i] = bmap[min(kcur[i], segK - 1)];      // (the next k-tile's row: back long before the next issue)
+          else {
+            srow[i] += BK;
+            if (seg_mod > 0 && srow[i] >= seg_mod) srow[i] -= seg_mod;
+          }
+        }
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rbits, (lds_void_t*)(base + A_BYTES + B2_BYTES + (wave & 3) * 256), 4, bvoff, 0, 0, 0);
         voff[0] += (uint32_t)BK * lda4;
         voff[1] += (uint32_t)BK * lda4;
-        voff[2] += (uint32_t)BK * ldb4;
-        voff[3] += (uint32_t)BK * ldb4;
         bvoff += (uint32_t)BK * qw;
-        if (seg_mod > 0) {
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            srck[i] += BK;
-            if (srck[i] >= seg_mod) { srck[i] -= seg_mod; voff[2 + i] -= (uint32_t)seg_mod * ldb4; }
-          }
-        }
       };
       // (`masked` is a runtime branch around eight byte reads here, not a second instantiation of the loop: with two copies
       //  of the k loop the register allocator kept five of the eight accumulator tiles in scratch)
@@ -805,6 +815,21 @@ __global__ __launch_bounds__(NTHR, 2) void gg_tn_bf16_kernel(const Launch L) {
         voff[i] = (uint32_t)(kbeg + krow) * lda2 + (uint32_t)min(m0 + 8 * c, pr.M - 8) * 2u;
       }
       int bk_row[2];
+      // b_map: B is a resident store's packed bf16 tensor (any size) and k-row r of the problem is ITS row b_map[r].  A B piece holds
+      // four CONSECUTIVE k-rows (16 lanes each), so a piece's four map entries are one scalar x4 load, fetched a stage ahead; the lane
+      // picks its row's entry and fetches by 64-bit address (global_load_lds).  Rows at and beyond K: any readable row -- the
+      // matching rows of A are zeros (outside A's descriptor), so they add nothing.
+      const bool mapped = pr.b_map[seg] != nullptr;
+      const int jsel = lane >> 4;                                                     // which of its piece's four k-rows this lane fetches
+      const uint32_t colb = (uint32_t)min(n0 + 8 * ((lane & 15) ^ ((jsel & 3) << 2)), pr.N - 8) * 2u;      // (the same for both pieces: 4 | piece's first k-row)
+      const int kmap_last = max((segK - 1) & ~3, 0);                                  // first k-row of the last group of four that has a valid row
+      int kpiece[2] = {kbeg + 4 * wave, kbeg + 4 * (wave + 8)};                       // first k-row of this wave's two pieces at the next issue
+      i32x4 mnext[2];
+      auto map4 = [&](int k) -> i32x4 {
+        return *(const_i32x4_t*)(uintptr_t)(pr.b_map[seg] + min(k, kmap_last));
+      };
+      if (mapped) { mnext[0] = map4(kpiece[0]); mnext[1] = map4(kpiece[1]); }
+      else { mnext[0] = i32x4{0, 0, 0, 0}; mnext[1] = mnext[0]; }
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         const int q = ((wave + 8 * i) << 6) + lane, krow = q >> 4, cpos = q & 15;
@@ -822,13 +847,25 @@ __global__ __launch_bounds__(NTHR, 2) void gg_tn_bf16_kernel(const Launch L) {
           __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(base + (wave + 8 * i) * 1024), 16, voff[i], 0, 0, 0);
           voff[i] += (uint32_t)HBK * lda2;
         }
+        if (mapped) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(base + HA_BYTES + (wave + 8 * i) * 1024), 16, voff[4 + i], 0, 0, 0);
-          voff[4 + i] += (uint32_t)HBK * ldb2;
-          if (seg_mod > 0) {
-            bk_row[i] += HBK;
-            while (bk_row[i] >= seg_mod) { bk_row[i] -= seg_mod; voff[4 + i] -= (uint32_t)seg_mod * ldb2; }
+          for (int i = 0; i < 2; ++i) {
+            const i32x4 m = mnext[i];
+            const int row = jsel == 0 ? m[0] : (jsel == 1 ? m[1] : (jsel == 2 ? m[2] : m[3]));
+            const char* src = reinterpret_cast<const char*>(pr.B[seg]) + (size_t)(uint32_t)row * (size_t)ldb2 + colb;
+            __builtin_amdgcn_global_load_lds((gbl_void_t*)src, (lds_void_t*)(base + HA_BYTES + (wave + 8 * i) * 1024), 16, 0, 0);
+            kpiece[i] += HBK;
+            mnext[i] = map4(kpiece[i]);      // (the next stage's rows: back long before the next issue)
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_void_t*)(base + HA_BYTES + (wave + 8 * i) * 1024), 16, voff[4 + i], 0, 0, 0);
+            voff[4 + i] += (uint32_t)HBK * ldb2;
+            if (seg_mod > 0) {
+              bk_row[i] += HBK;
+              while (bk_row[i] >= seg_mod) { bk_row[i] -= seg_mod; voff[4 + i] -= (uint32_t)seg_mod * ldb2; }
+            }
           }
         }
       };
@@ -1031,7 +1068,8 @@ bool valid(const sdumc_gg_problem& p) {
     if ((reinterpret_cast<uintptr_t>(p.A[s]) | reinterpret_cast<uintptr_t>(p.B[s])) & 15) return false;
     if (p.b_bits[s] && ((reinterpret_cast<uintptr_t>(p.b_bits[s]) & 3) || (p.bits_qw & 3) || p.bits_qw * 4 < p.N)) return false;
     if (p.b_row_mod[s] < 0 || (p.b_row_mod[s] > 0 && p.b_row_mod[s] < BK)) return false;
-    const size_t brows = p.b_row_mod[s] > 0 ? (size_t)p.b_row_mod[s] : (size_t)p.K[s];
+    if (p.b_map[s] && (p.b_row_mod[s] || (reinterpret_cast<uintptr_t>(p.b_map[s]) & 3))) return false;
+    const size_t brows = p.b_map[s] ? 1 : p.b_row_mod[s] > 0 ? (size_t)p.b_row_mod[s] : (size_t)p.K[s];      // (mapped: a descriptor per row)
     // (32-bit byte offsets that run up to a ring of k-tiles past the last row; descriptor ranges below 2 GiB)
     const size_t pad = 8 * BK;
     if (((size_t)p.K[s] + pad) * p.lda * 4 >= 0x7FFFFFF0u || (brows + pad) * p.ldb * 4 >= 0x7FFFFFF0u) return false;
@@ -1088,9 +1126,10 @@ bool valid_bf16(const sdumc_gg_problem& p) {
   for (int s = 0; s < 2; ++s) {
     if (p.K[s] == 0) continue;
     if (!p.A[s] || !p.B[s] || p.b_bits[s]) return false;      // no fused dropout on bf16 storage: the engine materialises the masked frames
+    if (p.b_map[s] && (p.b_row_mod[s] || (reinterpret_cast<uintptr_t>(p.b_map[s]) & 15))) return false;      // (x4 scalar loads of the map)
     if ((reinterpret_cast<uintptr_t>(p.A[s]) | reinterpret_cast<uintptr_t>(p.B[s])) & 15) return false;
     if (p.b_row_mod[s] < 0 || (p.b_row_mod[s] > 0 && p.b_row_mod[s] < 64)) return false;
-    const size_t brows = p.b_row_mod[s] > 0 ? (size_t)p.b_row_mod[s] : (size_t)p.K[s];
+    const size_t brows = p.b_map[s] ? 1 : p.b_row_mod[s] > 0 ? (size_t)p.b_row_mod[s] : (size_t)p.K[s];      // (mapped: 64-bit addresses)
     const size_t pad = 4 * 64;
     if (((size_t)p.K[s] + pad) * p.lda * 2 >= 0x7FFFFFF0u || (brows + pad) * p.ldb * 2 >= 0x7FFFFFF0u) return false;
   }
@@ -1139,6 +1178,9 @@ int gg_run(const sdumc_gg_problem* probs, int32_t n, void* workspace, size_t wor
     Launch L;
     int units = 0;
     const bool wide = !hf && split_products();
+    if (!wide && !hf)      // row maps are read by gg_tn_split2_kernel and gg_tn_bf16_kernel
+      for (int i = 0; i < cnt; ++i)
+        if (probs[first + i].b_map[0] || probs[first + i].b_map[1]) return SDUMC_EINVAL;
     const int tiles = plan(probs + first, cnt, nwg, hf, wide, L, units);
     if ((long long)L.line0[cnt] * (L.nwg + 1) >= (1LL << 31)) return SDUMC_EINVAL;   // 32-bit index arithmetic in the kernels
     L.slab = static_cast<float*>(workspace);

@@ -36,7 +36,11 @@ struct Args {
   int nsplit, kchunk;
 };
 
-template <class CF>
+// MAPPED: the rows of A are named by a row map (sdumc_gemm_p3.a_map / a2_map: A is a resident store's packed tensor, the batch is read
+// in place).  1: the packed tensor is below 4 GiB (a_map_rows says so): the map entry takes the row index's place in the descriptor
+// offset; 2: any size, rows fetched by 64-bit address (global_load_lds; measured 8-13 % slower on the frame projections than the
+// descriptor form: tools/map_bench.py)
+template <class CF, int MAPPED = 0>
 __global__ __launch_bounds__(CF::NTHR, CF::NW == 4 ? 2 : 1) void gemm_p3_nt_kernel(const Args a) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int BM = CF::BM, TM = CF::TM, TN = CF::TN;
@@ -67,10 +71,23 @@ __global__ __launch_bounds__(CF::NTHR, CF::NW == 4 ? 2 : 1) void gemm_p3_nt_kern
 
   f32x16 acc[TM][TN];
   uint64_t dbg_r1 = 0;
-  p3_mainloop<CF>(lds, ra, g.lda,
-                  [&](int row) { int r = min(m0 + row, g.M - 1) - arow0; if (g.a_row_mod > 0) r %= g.a_row_mod; return r; },
-                  rbits, g.bits_qw, [&](int row) { return min(m0 + row, g.M - 1); },
-                  static_cast<const char*>(g.B) + (size_t)(tile_n * 8 + wave * TN) * (size_t)g.ldb, (size_t)g.ldb, kbeg, nk, acc, &dbg_r1);
+  const char* bw = static_cast<const char*>(g.B) + (size_t)(tile_n * 8 + wave * TN) * (size_t)g.ldb;
+  if constexpr (MAPPED == 2) {
+    const char* abase = static_cast<const char*>(second ? g.A2 : g.A);
+    const int32_t* amap = second ? g.a2_map : g.a_map;
+    p3_mainloop<CF>(lds, ra, g.lda,
+                    [&](int row) -> const char* { return abase + (size_t)amap[min(m0 + row, g.M - 1) - arow0] * (size_t)g.lda; },
+                    rbits, g.bits_qw, [&](int row) { return min(m0 + row, g.M - 1); }, bw, (size_t)g.ldb, kbeg, nk, acc, &dbg_r1);
+  } else if constexpr (MAPPED == 1) {
+    const int32_t* amap = second ? g.a2_map : g.a_map;
+    const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(second ? g.A2 : g.A), 0, (int)min((size_t)g.a_map_rows * (size_t)g.lda, (size_t)0xFFFFFFF0u), 0x00020000);
+    p3_mainloop<CF>(lds, rm, g.lda, [&](int row) { return amap[min(m0 + row, g.M - 1) - arow0]; },
+                    rbits, g.bits_qw, [&](int row) { return min(m0 + row, g.M - 1); }, bw, (size_t)g.ldb, kbeg, nk, acc, &dbg_r1);
+  } else {
+    p3_mainloop<CF>(lds, ra, g.lda,
+                    [&](int row) { int r = min(m0 + row, g.M - 1) - arow0; if (g.a_row_mod > 0) r %= g.a_row_mod; return r; },
+                    rbits, g.bits_qw, [&](int row) { return min(m0 + row, g.M - 1); }, bw, (size_t)g.ldb, kbeg, nk, acc, &dbg_r1);
+  }
   (void)dbg_r1;
 #if defined(SDUMC_P3_DBG) && (SDUMC_P3_DBG & 8)
   const uint64_t dbg_r2 = __builtin_amdgcn_s_memrealtime();
@@ -316,13 +333,13 @@ inline Plan plan(const sdumc_gemm_p3& g, size_t have) {
   return best;
 }
 
-template <class CF>
+template <class CF, int MAPPED = 0>
 int launch(const sdumc_gemm_p3& g, const Plan& p, hipStream_t st) {
   static sdumc_dev_once attr_set;
-  if (sdumc_once_per_device(attr_set, [] { return sdumc_set_dyn_lds(&gemm_p3_nt_kernel<CF>, CF::LDS_BYTES); }) != SDUMC_OK) return SDUMC_ELAUNCH;
+  if (sdumc_once_per_device(attr_set, [] { return sdumc_set_dyn_lds(&gemm_p3_nt_kernel<CF, MAPPED>, CF::LDS_BYTES); }) != SDUMC_OK) return SDUMC_ELAUNCH;
   Args a{g, p.nsplit, p.kchunk};
   const dim3 grid((unsigned)(((g.M + CF::BM - 1) / CF::BM) * (g.N / BN)), (unsigned)p.nsplit);
-  hipLaunchKernelGGL((gemm_p3_nt_kernel<CF>), grid, dim3(CF::NTHR), CF::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((gemm_p3_nt_kernel<CF, MAPPED>), grid, dim3(CF::NTHR), CF::LDS_BYTES, st, a);
   return SDUMC_OK;
 }
 
@@ -351,8 +368,11 @@ extern "C" int sdumc_gemm_p3_nt(const sdumc_gemm_p3* gp, void* stream) {
   if (g.tile_m != 0 && g.tile_m != 64 && g.tile_m != 96 && g.tile_m != 128) return SDUMC_EINVAL;
   if (g.A2 && (g.a_row_mod || g.a2_row0 <= 0 || g.a2_row0 >= g.M || (g.a2_row0 % 64) || (g.tile_m && g.a2_row0 % g.tile_m) || (reinterpret_cast<uintptr_t>(g.A2) & 15))) return SDUMC_EINVAL;
   if (g.act != SDUMC_ACT_NONE && g.act != SDUMC_ACT_TANH && g.act != SDUMC_ACT_RELU) return SDUMC_EINVAL;
+  const bool mapped = g.a_map != nullptr;
+  if (mapped && (g.a_row_mod || g.a_bits || (g.A2 != nullptr) != (g.a2_map != nullptr))) return SDUMC_EINVAL;   // (the frame projections' form)
+  if (!mapped && g.a2_map) return SDUMC_EINVAL;
   const size_t a_bytes = (size_t)(g.a_row_mod > 0 ? g.a_row_mod : (g.A2 ? std::max(g.a2_row0, g.M - g.a2_row0) : g.M)) * (size_t)g.lda;
-  if (a_bytes >= 0xFFFFFFF0u) return SDUMC_EINVAL;
+  if (!mapped && a_bytes >= 0xFFFFFFF0u) return SDUMC_EINVAL;      // (mapped rows are fetched by 64-bit address: no such limit)
   const bool mask = g.a_bits != nullptr;
   if (mask && (g.bits_qw < g.K / 4 || (g.bits_qw & 3) || (reinterpret_cast<uintptr_t>(g.a_bits) & 3) || (size_t)g.M * g.bits_qw >= 0xFFFFFFF0u)) return SDUMC_EINVAL;
   const Plan p = plan(g, g.workspace ? g.workspace_bytes : 0);
@@ -364,7 +384,12 @@ extern "C" int sdumc_gemm_p3_nt(const sdumc_gemm_p3* gp, void* stream) {
   // the chip in one round (audio frame projection: 76 against 62 us at 96 rows), faster inside the step, where three lanes' kernels
   // share the chip (fp32 C2 step 1.370 against 1.386-1.391 ms, two alternations) -- a 512-thread workgroup holds its CU alone.
   // An explicit tile_m: the 512-thread forms.
-  if (!g.tile_m) {
+  // (a map over a packed tensor below 4 GiB keeps the descriptor form; else rows by 64-bit address)
+  const bool map32 = mapped && g.a_map_rows > 0 && (size_t)g.a_map_rows * (size_t)g.lda < 0xFFFFFFF0u;
+  if (mapped && g.tile_m) return SDUMC_EINVAL;      // (row maps: the step's form, 64-row tiles on 256-thread workgroups)
+  if (map32) rc = launch<PCfg<64, 4, false, 4>, 1>(g, p, st);
+  else if (mapped) rc = launch<PCfg<64, 4, false, 4>, 2>(g, p, st);
+  else if (!g.tile_m) {
     rc = mask ? launch<PCfg<64, 4, true, 4>>(g, p, st) : launch<PCfg<64, 4, false, 4>>(g, p, st);
   } else if (mask) {
     rc = p.bm == 128 ? launch<PCfg<128, 4, true>>(g, p, st) : p.bm == 96 ? launch<PCfg<96, 4, true>>(g, p, st) : launch<PCfg<64, 4, true>>(g, p, st);

@@ -8,6 +8,8 @@
 namespace sdumc_p3 {
 
 typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void gbl_void_t;
+typedef const __attribute__((address_space(4))) int32_t const_i32_t;      // loads through it with a wave-uniform index are scalar loads
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2s __attribute__((ext_vector_type(2)));
@@ -79,7 +81,9 @@ struct PCfg {
 // "at most DB - 1 groups outstanding".
 // p3_mainloop: acc[TM][TN] += A_tile[BM, 16 nk] . B_wave[32 TN, 16 nk]^T for this wave (wave w = columns [32 TN w, 32 TN (w + 1)) of the
 // tile).  ra: buffer descriptor of the A tensor (P3 rows, row stride lda bytes); src_row(r): source row of tile row r < BM (clamped
-// by the caller); rbits / bits_qw / bits_row(r): the keep-bits (MASK); bwave: this wave's first 32-row block of the fragment-major
+// by the caller) -- or, when it returns a POINTER, the address of that row's first byte: the rows of a tile then lie anywhere in memory
+// (a batch read in place from a resident feature store through a row map: tens of GB, beyond a descriptor's 32-bit offsets) and A is
+// fetched with global_load_lds from per-lane 64-bit addresses instead of buffer_load ... lds; rbits / bits_qw / bits_row(r): the keep-bits (MASK); bwave: this wave's first 32-row block of the fragment-major
 // weight (bblk = bytes between two blocks); k-tiles [kbeg / 16, kbeg / 16 + nk), nk a multiple of 4.  `lds`: CF::LDS_BYTES of ring.
 // On return every wave has issued its last LDS reads (a workgroup barrier is still needed before the ring's memory is reused).
 template <class CF, class SrcRow, class BitsRow>
@@ -94,7 +98,9 @@ __device__ __forceinline__ void p3_mainloop(char* lds, const __amdgpu_buffer_rsr
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
   // ---- this wave's DMA pieces of a stage of A: pieces wave and wave + 8 (where they exist), its keep-bits piece ----
-  uint32_t voff[CF::NA];
+  constexpr bool GA = std::is_pointer<decltype(src_row(0))>::value;      // A rows by address (global_load_lds) instead of by row index
+  [[maybe_unused]] uint32_t voff[CF::NA];
+  [[maybe_unused]] const char* gaddr[CF::NA];
   bool pvalid[CF::NA];
 #pragma unroll
   for (int i = 0; i < CF::NA; ++i) {
@@ -104,7 +110,8 @@ __device__ __forceinline__ void p3_mainloop(char* lds, const __amdgpu_buffer_rsr
     const int row = q / 6, sl = q - 6 * row;
     const int hp = sl >= 3 ? 1 : 0, p = sl - 3 * hp;
     const int h = hp ^ ((row >> 3) & 1);                                 // the k-half this slot holds (swizzle by bit 3 of the row)
-    voff[i] = (uint32_t)src_row(row) * (uint32_t)lda + (uint32_t)((kbeg >> 3) + h) * 48u + (uint32_t)p * 16u;
+    if constexpr (GA) gaddr[i] = reinterpret_cast<const char*>(src_row(row)) + (size_t)((kbeg >> 3) + h) * 48u + (size_t)p * 16u;
+    else voff[i] = (uint32_t)src_row(row) * (uint32_t)lda + (uint32_t)((kbeg >> 3) + h) * 48u + (uint32_t)p * 16u;
   }
   const bool has_bits = MASK && wave < CF::BITS_P;
   uint32_t bvoff = 0;
@@ -121,8 +128,13 @@ __device__ __forceinline__ void p3_mainloop(char* lds, const __amdgpu_buffer_rsr
 #define SDUMC_P3_DBG 0      /* measurement builds only: bit 0 = no DMA of A, bit 1 = no loads of B, bit 2 = no MFMAs */
 #endif
       if (pvalid[i] && !(SDUMC_P3_DBG & 1)) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(base + (wave + i * NW) * 1024), 16, voff[i], 0, 0, 0);
-        voff[i] += ROWB;
+        if constexpr (GA) {
+          __builtin_amdgcn_global_load_lds((gbl_void_t*)gaddr[i], (lds_void_t*)(base + (wave + i * NW) * 1024), 16, 0, 0);
+          gaddr[i] += ROWB;
+        } else {
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_void_t*)(base + (wave + i * NW) * 1024), 16, voff[i], 0, 0, 0);
+          voff[i] += ROWB;
+        }
       }
     }
     if constexpr (MASK) {

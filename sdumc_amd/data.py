@@ -93,6 +93,9 @@ class DeviceFeatureStore:
     Data_Feat_MOSEI_EmoVal_4F.collater + pad_to_maxlen_pre_modality_tensor_4 (feat_data.py:232-253,
     read_data.py:223-248) for the hot path; the on-disk format is the reference's (read_feature).
 
+    Every packed tensor ends in ONE all-zero row: a step can then read a batch IN PLACE through a row map (sdumc_net_io.row_map; entry
+    of a padded frame = that row) instead of from a padded copy -- gather_desc(maps_out=...) writes the maps, 4 bytes per frame.
+
     planes=True (fp32 storage): every utterance is ALSO held as P3 planes (sdumc_p3_split of the packed tensor, three bf16 parts per
     value, 6 d bytes per row) -- split ONCE per dataset, where the reference re-reads the feature files every epoch; the store then
     takes 2.5x the fp32 bytes (the fp32 rows the weight gradients read + 1.5x for the planes the frame projections read).  A batch's
@@ -118,7 +121,7 @@ class DeviceFeatureStore:
             if d % 4:
                 raise _lib.SdumcError(f"feature width {d} of '{m}' must be a multiple of 4")
             starts = np.concatenate([[0], np.cumsum(lens)[:-1]]).astype(np.int64)
-            host = torch.empty(sum(lens), d, dtype=torch.float32)
+            host = torch.zeros(sum(lens) + 1, d, dtype=torch.float32)      # (+ one all-zero row: what a padded frame's row-map entry names)
             for s, n, inst in zip(starts, lens, instances):
                 host[s:s + n] = torch.as_tensor(inst[m], dtype=torch.float32)
             self.packed[m] = host.to(self.device).to(torch.bfloat16 if bf16 else torch.float32)
@@ -179,7 +182,9 @@ class DeviceFeatureStore:
             lo = max(1, int(np.ceil(Tm * min_frac)))
             lens = torch.randint(lo, Tm + 1, (n,), generator=g, dtype=torch.int32)
             starts = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(lens.to(torch.int64), 0)[:-1]])
-            self.packed[m] = torch.randn(int(lens.sum()), d, device=self.device, generator=gd).to(torch.bfloat16 if bf16 else torch.float32)
+            rows = int(lens.sum())
+            self.packed[m] = torch.zeros(rows + 1, d, device=self.device, dtype=torch.bfloat16 if bf16 else torch.float32)      # (+ the zero row)
+            self.packed[m][:rows] = torch.randn(rows, d, device=self.device, generator=gd)
             self.start[m], self.length[m], self.dim[m] = starts, lens, int(d)
         self._device_tables()
         self.packed_p3 = None
@@ -212,16 +217,28 @@ class DeviceFeatureStore:
             shapes.append((int(ii.size), tuple(int(self._len_np[m][ii].max()) for m in self.MODS)))
         return EpochPlan(torch.cat(idxs).to(self.device), [int(o) for o in offsets[:-1]], shapes)
 
-    def gather_desc(self, idx_ptr, B, T, outs, labels_out, lengths_out=None, planes_out=None):
+    def gather_desc(self, idx_ptr, B, T, outs, labels_out, lengths_out=None, planes_out=None, maps_out=None):
         """The sdumc_gather_batch descriptor of one batch: idx_ptr = device address of its int64 [B] index vector, T its padded frame
         counts, outs = 4 device buffers of >= B * T_m * d_m elements (fp32, or bf16 for a bf16 store), planes_out = 4 uint8 buffers of
-        >= B * T_m * 6 d_m bytes (needs the store's planes), labels_out [>= B], lengths_out = optional 4 int32 [>= B]."""
+        >= B * T_m * 6 d_m bytes (needs the store's planes), labels_out [>= B], lengths_out = optional 4 int32 [>= B].
+        maps_out = 4 int32 buffers of >= B * T_m entries INSTEAD of outs / planes_out (pass outs=None): no padded copy is made, the
+        step reads the store in place through these row maps (sdumc_net_io.row_map)."""
         _lib = self._lib
         if planes_out is not None and self.packed_p3 is None:
             raise _lib.SdumcError("this store holds no planes (DeviceFeatureStore(planes=True))")
+        if (outs is None) == (maps_out is None):
+            raise _lib.SdumcError("gather_desc: padded copies (outs) or row maps (maps_out), one of the two")
         g = _lib.GatherBatch()
         n = 0
         for k, m in enumerate(self.MODS):
+            if maps_out is not None:
+                sg = g.seg[n]
+                sg.start_all, sg.len_all = _lib.ptr(self.start_d[m]), _lib.ptr(self.length_d[m])
+                sg.map_out, sg.zero_row = _lib.ptr(maps_out[k]), int(self.packed[m].shape[0]) - 1
+                sg.len_out = _lib.ptr(lengths_out[k]) if lengths_out is not None else None
+                sg.Tmax, sg.d4 = int(T[k]), 0
+                n += 1
+                continue
             srcs = [(self.packed[m], outs[k], self.dim[m] * self.packed[m].element_size() // 16)]
             if planes_out is not None:
                 srcs.append((self.packed_p3[m], planes_out[k], 6 * self.dim[m] // 16))

@@ -439,6 +439,9 @@ class TrainStep(_OptStateMixin):
         self.audio, self.text, self.video, self.feat4, self.labels = v
         io = self.io
         io.audio, io.text[0], io.video, io.text[1] = (ptr(t) for t in st.inputs)
+        for i in range(4):
+            io.row_map[i] = None
+            io.store_rows[i] = 0
         self._use_planes = bool(planes) and st.planes is not None
         if self._use_planes:
             io.audio_p3, io.text_p3[0], io.video_p3, io.text_p3[1] = (ptr(t) for t in st.planes)
@@ -446,6 +449,30 @@ class TrainStep(_OptStateMixin):
             io.audio_p3 = io.video_p3 = io.text_p3[0] = io.text_p3[1] = None
         self.cfg.labels = ptr(st.labels)
         self._set = k
+        return self
+
+    def use_store(self, store, k):
+        """Arena steps in fp32 storage: read the batch IN PLACE from a DeviceFeatureStore(planes=True) through the row maps held in
+        input set `k` (written by the store's gather_desc(maps_out=...) launch): the step's feature pointers are the store's packed
+        tensors, no padded copy of the batch exists.  Labels / lengths come from the set as with use_set."""
+        a = self._arena
+        hf = self.dims.bf16 == 2
+        if a is None or self.dims.bf16 == 1 or (not hf and store.packed_p3 is None) or store.packed['audio'].dtype != self.feature_dtype:
+            raise _lib.SdumcError("use_store: an arena step in fp32 storage with a store that holds planes, or in bf16 storage with a bf16 store")
+        st = a.sets[k]
+        io = self.io
+        pk = store.packed
+        io.audio, io.text[0], io.video, io.text[1] = ptr(pk['audio']), ptr(pk['text']), ptr(pk['video']), ptr(pk['feat4'])
+        if not hf:
+            p3 = store.packed_p3
+            io.audio_p3, io.text_p3[0], io.video_p3, io.text_p3[1] = ptr(p3['audio']), ptr(p3['text']), ptr(p3['video']), ptr(p3['feat4'])
+        maps = st.ensure_maps()
+        for i, m in enumerate(('audio', 'text', 'video', 'feat4')):
+            io.row_map[i] = ptr(maps[i])
+            io.store_rows[i] = int(pk[m].shape[0])
+        self.labels = st.labels[:self.B]
+        self.cfg.labels = ptr(st.labels)
+        self._use_planes, self._set = not hf, k
         return self
 
     def _point_lengths(self, tensors):
@@ -558,11 +585,19 @@ class _InputSet:
     """One resident batch slot of an arena: the four feature buffers (flat, capacity-sized), their P3 planes (fp32 storage, planes on),
     the labels and the valid frame counts."""
 
-    def __init__(self, n, planes_bytes, B, dtype, dev):
+    def __init__(self, n, planes_bytes, B, dtype, dev, rows):
         self.inputs = [torch.empty(k, device=dev, dtype=dtype) for k in n]
         self.planes = [torch.empty(k, device=dev, dtype=torch.uint8) for k in planes_bytes] if planes_bytes is not None else None
         self.labels = torch.empty(B, device=dev)
         self.lengths = [torch.empty(B, dtype=torch.int32, device=dev) for _ in range(4)]
+        self.maps = None      # row maps (int32 per frame): a batch read in place from a DeviceFeatureStore (ensure_maps)
+        self._rows = rows
+
+    def ensure_maps(self):
+        if self.maps is None:
+            # (+ 64 entries: the bf16 weight-gradient kernel fetches map entries four at a time, past a batch's last row)
+            self.maps = [torch.zeros(r + 64, dtype=torch.int32, device=self.labels.device) for r in self._rows]
+        return self.maps
 
 
 class _StepArena:
@@ -589,7 +624,8 @@ class _StepArena:
         # asks for them (ensure_planes); False = never
         self._planes_ok = planes is not False and planes_wanted(True, dims, bf16)
         self._n = n
-        self.sets = [_InputSet(n, None, self.B, self.feature_dtype, dev) for _ in range(max(1, int(sets)))]
+        rows = [self.B * self.T[i] for i in range(4)]
+        self.sets = [_InputSet(n, None, self.B, self.feature_dtype, dev, rows) for _ in range(max(1, int(sets)))]
         if planes is True:
             self.ensure_planes()
         V = 2 * self.B
@@ -642,12 +678,14 @@ class FusedTrainer:
     (sdumc_net_io.prefetch) -- and every step tells the engine the next batch's shape, so that the next keep-bits are laid out for it."""
 
     def __init__(self, flat_params, dims, max_cached=8, lr=1e-4, seed=0, capacity=None, planes=None, sets=2, prefetch_workgroups=0,
-                 **step_kwargs):
+                 inplace=True, **step_kwargs):
         """capacity = (B_max, (T_audio, T_text, T_video, T_feat4) maxima) of the run: ONE arena then backs every batch shape
         (no per-shape workspace, the per-shape step is a few ctypes structs and tensor views: cache as many as you like) and
         `step_from_store` / `run_epoch` assemble batches straight into it.  Without it every cached shape owns its workspace.
         planes (arena only): None (default) = follow the store -- batches assembled from a DeviceFeatureStore(planes=True) bring their
-        P3 planes along (the same gather as the fp32 rows) and the step's frame projections read them; False = never."""
+        P3 planes along (the same gather as the fp32 rows) and the step's frame projections read them; False = never.
+        inplace (default True): with such a store the batches are not gathered at all -- the step reads the store's packed tensors
+        through per-batch row maps (4 bytes per frame; sdumc_net_io.row_map)."""
         _require_cuda(flat_params)
         self.params, self.dims, self.max_cached = flat_params, tuple(dims), max(1, int(max_cached))
         self.kw = dict(step_kwargs, lr=lr, seed=seed)
@@ -658,6 +696,9 @@ class FusedTrainer:
         self._arena_kw = dict(bf16=step_kwargs.get("bf16", False), sets=sets, planes=planes,
                               bits_next=step_kwargs.get("bits_next", True), prefetch_workgroups=prefetch_workgroups)
         self._last_shape = None
+        # inplace (fp32 storage, a store with planes): batches are read from the store through row maps, no padded copy (use_store);
+        # False: every batch is gathered into the arena's input sets (fp32 rows + plane rows)
+        self.inplace = bool(inplace)
         if capacity is not None:
             self.arena = _StepArena(flat_params, capacity[0], capacity[1], dims, **self._arena_kw)
             self.max_cached = max(self.max_cached, 4096)
@@ -702,8 +743,19 @@ class FusedTrainer:
     def _store_planes(self, store):
         return store.packed_p3 is not None and self.arena.ensure_planes()
 
-    def _gather_desc(self, store, idx_ptr, ts, k, key_padding, planes):
+    def _in_place(self, store):
+        """fp32 storage and a store with planes, or bf16 storage and a bf16 store (widths in whole 128-element tiles): batches are not
+        copied at all -- the step reads the store's packed tensors through row maps."""
+        if not self.inplace:
+            return False
+        if self.arena.feature_dtype == torch.bfloat16:
+            return store.packed['audio'].dtype == torch.bfloat16 and all(int(d) % 128 == 0 for d in self.dims[:3])
+        return store.packed_p3 is not None and self.arena._planes_ok
+
+    def _gather_desc(self, store, idx_ptr, ts, k, key_padding, planes, inplace=False):
         st = self.arena.sets[k]
+        if inplace:
+            return store.gather_desc(idx_ptr, ts.B, ts.T, None, st.labels, st.lengths if key_padding else None, maps_out=st.ensure_maps())
         return store.gather_desc(idx_ptr, ts.B, ts.T, st.inputs, st.labels, st.lengths if key_padding else None, st.planes if planes else None)
 
     def step_from_store(self, store, indices, key_padding=False):
@@ -715,11 +767,18 @@ class FusedTrainer:
             raise _lib.SdumcError("step_from_store needs FusedTrainer(capacity=...)")
         B, T = store.batch_shape(indices)
         ts = self._get(B, T)
-        planes = self._store_planes(store)
-        ts.use_set(0, planes=planes)
         st = self.arena.sets[0]
-        store.batch_into(indices, (ts.audio, ts.text, ts.video, ts.feat4), ts.labels, st.lengths if key_padding else None,
-                         st.planes if planes else None)
+        if self._in_place(store):
+            idx_d = store._checked(indices).to(store.device, non_blocking=True)
+            g = self._gather_desc(store, idx_d.data_ptr(), ts, 0, key_padding, True, inplace=True)
+            check(lib.sdumc_gather_batch(C.byref(g), 0, _lib.current_stream()), "sdumc_gather_batch")
+            self._keep_idx = idx_d
+            ts.use_store(store, 0)
+        else:
+            planes = self._store_planes(store)
+            ts.use_set(0, planes=planes)
+            store.batch_into(indices, (ts.audio, ts.text, ts.video, ts.feat4), ts.labels, st.lengths if key_padding else None,
+                             st.planes if planes else None)
         ts.use_lengths(st.lengths if key_padding else None)
         return self._launch(ts)
 
@@ -736,14 +795,15 @@ class FusedTrainer:
         steps = [self._get(B, T) for (B, T) in plan.shapes]      # (may grow the arena: before any descriptor is built)
         if any(ts._arena is not self.arena for ts in steps):
             steps = [self._get(B, T) for (B, T) in plan.shapes]
-        planes = self._store_planes(store)
-        g0 = self._gather_desc(store, plan.idx_ptr(0), steps[0], 0, key_padding, planes)
+        inplace = self._in_place(store)
+        planes = inplace or self._store_planes(store)
+        g0 = self._gather_desc(store, plan.idx_ptr(0), steps[0], 0, key_padding, planes, inplace)
         check(lib.sdumc_gather_batch(C.byref(g0), 0, _lib.current_stream()), "sdumc_gather_batch")
         for i in range(n):
-            ts = steps[i].use_set(i & 1, planes=planes)
+            ts = steps[i].use_store(store, i & 1) if inplace else steps[i].use_set(i & 1, planes=planes)
             ts.use_lengths(self.arena.sets[i & 1].lengths if key_padding else None)
             nxt = steps[i + 1] if i + 1 < n else None
-            pf = self._gather_desc(store, plan.idx_ptr(i + 1), nxt, (i + 1) & 1, key_padding, planes) if nxt is not None else None
+            pf = self._gather_desc(store, plan.idx_ptr(i + 1), nxt, (i + 1) & 1, key_padding, planes, inplace) if nxt is not None else None
             losses = self._launch(ts, next_step=nxt, prefetch=pf)
             if on_step is not None:
                 on_step(i, losses)

@@ -90,6 +90,7 @@ def gemm_group_tn(problems, workspace=None):
             g.A[1], g.B[1] = ptr(q["A1"]), ptr(q["B1"])
             g.K[1] = q.get("K1", q["A1"].shape[0])
         g.b_row_mod[0], g.b_row_mod[1] = q.get("b_row_mod", 0), q.get("b_row_mod1", 0)
+        g.b_map[0], g.b_map[1] = ptr(q.get("b_map")), ptr(q.get("b_map1"))      # int32 row maps: B / B1 are a store's packed rows
         if q.get("bits") is not None:
             g.b_bits[0] = ptr(q["bits"])
             g.bits_qw = q["bits"].stride(0)
@@ -142,7 +143,7 @@ def p3_join(p3, cols):
 
 
 def gemm_p3_nt_call(A3, B3, M, N, K, bias=None, act=ACT_NONE, a_row_mod=0, bits=None, scale=1.0, C_out=None, want_f32=True,
-                    want_p3=False, splitk=0, tile_m=0, A3_second=None, second_row0=0):
+                    want_p3=False, splitk=0, tile_m=0, A3_second=None, second_row0=0, a_map=None, a2_map=None, a_map_rows=0):
     """The prepared call of gemm_p3_nt: returns (launch, results) -- launch() enqueues sdumc_gemm_p3_nt on the current stream
     (a few microseconds of host time: benches), results = the output tensor(s)."""
     dev = A3.device
@@ -152,6 +153,7 @@ def gemm_p3_nt_call(A3, B3, M, N, K, bias=None, act=ACT_NONE, a_row_mod=0, bits=
     g.a_row_mod = a_row_mod
     if A3_second is not None:
         g.A2, g.a2_row0 = ptr(A3_second), second_row0
+    g.a_map, g.a2_map, g.a_map_rows = ptr(a_map), ptr(a2_map), int(a_map_rows)      # int32 row maps: A / A2 are a store's packed planes, read in place
     if bits is not None:
         g.a_bits, g.bits_qw, g.a_scale = ptr(bits), bits.stride(0), scale
     g.bias, g.act = ptr(bias), act
@@ -165,7 +167,7 @@ def gemm_p3_nt_call(A3, B3, M, N, K, bias=None, act=ACT_NONE, a_row_mod=0, bits=
     need = lib.sdumc_gemm_p3_workspace_bytes(C.byref(g))
     ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
     g.workspace, g.workspace_bytes = ptr(ws), need
-    keep = (A3, B3, bias, bits, ws, Cf, Cp, A3_second)
+    keep = (A3, B3, bias, bits, ws, Cf, Cp, A3_second, a_map, a2_map)
 
     def launch(_keep=keep):
         check(lib.sdumc_gemm_p3_nt(C.byref(g), _st()), "sdumc_gemm_p3_nt")
@@ -193,7 +195,7 @@ def b1_frag(W):
 
 
 def gemm_b1_nt_call(A, Bf, M, N, K, bias=None, act=ACT_NONE, a_row_mod=0, out_dtype=torch.bfloat16, splitk=0, A_second=None,
-                    second_row0=0):
+                    second_row0=0, C_out=None, a_map=None, a2_map=None, a_map_rows=0):
     """The prepared call of sdumc_gemm_b1_nt (bf16 A [rows, K], fragment-major bf16 weight): returns (launch, C)."""
     dev = A.device
     g = _lib.GemmB1()
@@ -203,13 +205,14 @@ def gemm_b1_nt_call(A, Bf, M, N, K, bias=None, act=ACT_NONE, a_row_mod=0, out_dt
     if A_second is not None:
         g.A2, g.a2_row0 = ptr(A_second), second_row0
     g.bias, g.act = ptr(bias), act
-    Cm = torch.empty(M, N, dtype=out_dtype, device=dev)
-    g.C, g.ldc, g.c_bf16 = ptr(Cm), Cm.stride(0), int(out_dtype == torch.bfloat16)
+    Cm = C_out if C_out is not None else torch.empty(M, N, dtype=out_dtype, device=dev)
+    g.C, g.ldc, g.c_bf16 = ptr(Cm), Cm.stride(0), int(Cm.dtype == torch.bfloat16)
+    g.a_map, g.a2_map, g.a_map_rows = ptr(a_map), ptr(a2_map), int(a_map_rows)      # int32 row maps: A / A2 are a store's packed rows
     g.splitk = splitk
     need = lib.sdumc_gemm_b1_workspace_bytes(C.byref(g))
     ws = torch.empty(max(need, 16), dtype=torch.uint8, device=dev)
     g.workspace, g.workspace_bytes = ptr(ws), need
-    keep = (A, Bf, bias, ws, Cm, A_second)
+    keep = (A, Bf, bias, ws, Cm, A_second, a_map, a2_map)
 
     def launch(_keep=keep):
         check(lib.sdumc_gemm_b1_nt(C.byref(g), _st()), "sdumc_gemm_b1_nt")

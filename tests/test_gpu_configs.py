@@ -407,8 +407,10 @@ def test_ragged_epoch_through_store_and_arena_equals_plain_batches(E):
 
 def test_run_epoch_on_a_planes_store_equals_plain_resident_batches_bit_for_bit(E):
     """The production epoch path in fp32 storage -- DeviceFeatureStore(planes=True): every utterance split into bf16 planes ONCE;
-    FusedTrainer.run_epoch: index vectors uploaded once, batch i + 1 gathered (fp32 rows + plane rows, one launch) into the other input
-    set by step i itself (sdumc_net_io.prefetch), the next keep-bits laid out for batch i + 1's shape (bits_next_dims) -- against
+    FusedTrainer.run_epoch: index vectors uploaded once, batch i + 1's ROW MAPS (in place, the default: the step reads the store's
+    packed tensors through them, sdumc_net_io.row_map) or its padded copy (inplace=False: fp32 rows + plane rows gathered, one launch)
+    written into the other input set by step i itself (sdumc_net_io.prefetch), the next keep-bits laid out for batch i + 1's shape
+    (bits_next_dims) -- against
       * the same batches one at a time (step_from_store: gather in front of the step, no announced next shape), and
       * plain batches: store.batch() tensors installed with TrainStep.set_batch(planes=True), which SPLITS the padded batch (a padded
         row's planes are zero bytes, so gathering plane rows must equal splitting the gathered batch), keep-bits at the head of each step.
@@ -437,16 +439,18 @@ def test_run_epoch_on_a_planes_store_equals_plain_resident_batches_bit_for_bit(E
         assert torch.equal(pls[i], E.p3_split_into(outs[i], torch.empty_like(pls[i])))
     assert torch.equal(lab, vals)
     res = {}
-    for mode in ("epoch", "one_by_one", "plain", "epoch_kp", "one_by_one_kp"):
+    for mode in ("epoch", "epoch_gather", "one_by_one", "one_by_one_gather", "plain", "epoch_kp", "one_by_one_kp", "epoch_gather_kp"):
         flat, lay = flat_from(E, P, dims)
         kp = mode.endswith("_kp")
+        inplace = "gather" not in mode      # in place: the step reads the store through row maps; gather: padded copies (rows + planes)
         ls = []
         if mode.startswith("epoch"):
-            tr = E.FusedTrainer(flat, dims, lr=1e-3, seed=11, capacity=(6, Tcap))
+            tr = E.FusedTrainer(flat, dims, lr=1e-3, seed=11, capacity=(6, Tcap), inplace=inplace)
             n = tr.run_epoch(store, batches, key_padding=kp, on_step=lambda i, l: ls.append(l.clone()))
-            assert n == len(batches) and tr.arena.sets[0].planes is not None and len(tr.arena.sets) == 2
+            assert n == len(batches) and len(tr.arena.sets) == 2
+            assert (tr.arena.sets[0].planes is None) == inplace and (tr.arena.sets[0].maps is not None) == inplace
         elif mode.startswith("one_by_one"):
-            tr = E.FusedTrainer(flat, dims, lr=1e-3, seed=11, capacity=(6, Tcap))
+            tr = E.FusedTrainer(flat, dims, lr=1e-3, seed=11, capacity=(6, Tcap), inplace=inplace)
             for ix in batches:
                 ls.append(tr.step_from_store(store, ix, key_padding=kp).clone())
         else:
@@ -461,7 +465,8 @@ def test_run_epoch_on_a_planes_store_equals_plain_resident_batches_bit_for_bit(E
                 torch.cuda.synchronize()
         torch.cuda.synchronize()
         res[mode] = (flat.clone(), ls)
-    for a, b in (("epoch", "one_by_one"), ("epoch", "plain"), ("epoch_kp", "one_by_one_kp")):
+    for a, b in (("epoch", "one_by_one"), ("epoch", "plain"), ("epoch", "epoch_gather"), ("epoch", "one_by_one_gather"),
+                 ("epoch_kp", "one_by_one_kp"), ("epoch_kp", "epoch_gather_kp")):
         for i, (x, y) in enumerate(zip(res[a][1], res[b][1])):
             assert torch.equal(x, y), (a, b, i, x.tolist(), y.tolist())
         assert torch.equal(res[a][0], res[b][0]), (a, b)
@@ -477,6 +482,42 @@ def test_run_epoch_on_a_planes_store_equals_plain_resident_batches_bit_for_bit(E
         np.testing.assert_allclose(x.cpu().numpy()[:7], y.cpu().numpy()[:7], rtol=2e-5, atol=1e-6)
     with pytest.raises(_lib.SdumcError):
         store2.gather_desc(0, 1, (1, 1, 1, 1), [None] * 4, None, planes_out=[None] * 4)
+
+
+def test_bf16_run_epoch_in_place_equals_gathered_batches_bit_for_bit(E):
+    """bf16 storage (BASELINE configs[2] / [4]): a bf16 DeviceFeatureStore read IN PLACE through row maps (gemm_b1's A rows, the bf16
+    grouped weight-gradient kernel's B rows; widths in whole 128-element tiles) against the same epoch on gathered padded copies
+    (inplace=False) and against one batch at a time: losses of every step and the final parameters bit for bit; ragged shapes incl. a
+    short last batch whose row count is not a multiple of four (the weight-gradient kernel fetches map entries four at a time)."""
+    from oracle import sdumc_oracle as O
+    from sdumc_amd.data import DeviceFeatureStore
+    dims = (128, 256, 128, 256)
+    Tcap = (70, 33, 66, 32)
+    P = O.init_params(dims, seed=8)
+    store = DeviceFeatureStore.synthetic(48, Tcap, dims, seed=5, bf16=True)
+    g = torch.Generator().manual_seed(1)
+    batches = [torch.randperm(48, generator=g)[:B] for B in (6, 6, 4, 6, 3, 6, 5)]
+    res = {}
+    for mode in ("epoch", "epoch_gather", "one_by_one", "epoch_kp", "epoch_gather_kp"):
+        flat, lay = flat_from(E, P, dims)
+        kp = mode.endswith("_kp")
+        inplace = "gather" not in mode
+        ls = []
+        tr = E.FusedTrainer(flat, dims, lr=1e-3, seed=11, capacity=(6, Tcap), inplace=inplace, bf16=True)
+        if mode.startswith("epoch"):
+            tr.run_epoch(store, batches, key_padding=kp, on_step=lambda i, l: ls.append(l.clone()))
+            assert (tr.arena.sets[0].maps is not None) == inplace
+        else:
+            for ix in batches:
+                ls.append(tr.step_from_store(store, ix, key_padding=kp).clone())
+        torch.cuda.synchronize()
+        assert all(torch.isfinite(l).all() for l in ls)
+        res[mode] = (flat.clone(), ls)
+    for a, b in (("epoch", "epoch_gather"), ("epoch", "one_by_one"), ("epoch_kp", "epoch_gather_kp")):
+        for i, (x, y) in enumerate(zip(res[a][1], res[b][1])):
+            assert torch.equal(x, y), (a, b, i, x.tolist(), y.tolist())
+        assert torch.equal(res[a][0], res[b][0]), (a, b)
+    assert not torch.equal(res["epoch"][1][0], res["epoch_kp"][1][0])
 
 
 def test_keep_bits_sets_are_tagged_with_call_and_shape(E):

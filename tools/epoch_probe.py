@@ -21,6 +21,7 @@ ap.add_argument("--mode", default="epoch")
 ap.add_argument("--nb", type=int, default=200)
 ap.add_argument("--wgs", type=int, default=0)
 ap.add_argument("--fixed", action="store_true", help="every utterance at full length: one batch shape")
+ap.add_argument("--gather", action="store_true", help="padded copies instead of in-place row maps")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 torch.cuda.set_device(0)
@@ -30,7 +31,7 @@ hf = engine.bf16_mode(args.bf16, DIMS) == 2
 store = DeviceFeatureStore.synthetic(2048, T, DIMS, seed=1234, device=dev, bf16=hf, planes=not hf, min_frac=1.0 if args.fixed else 0.25)
 g = torch.Generator().manual_seed(7)
 batches = [torch.randperm(len(store), generator=g)[:B] for _ in range(args.nb + 10)]
-tr = engine.FusedTrainer(flat, DIMS, capacity=(B, T), seed=2024, bf16=args.bf16, prefetch_workgroups=args.wgs)
+tr = engine.FusedTrainer(flat, DIMS, capacity=(B, T), seed=2024, bf16=args.bf16, prefetch_workgroups=args.wgs, inplace=not args.gather)
 plan_w, plan_t = store.plan_epoch(batches[:10]), store.plan_epoch(batches[10:])
 # every shape's step object up front (host set-up is not what is being measured)
 for (b, t) in plan_w.shapes + plan_t.shapes:
@@ -59,7 +60,7 @@ t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 n = len(plan_t)
-print(f"mode {args.mode} bf16 {args.bf16} fixed {args.fixed} PF_MODE {os.environ.get('SDUMC_PF_MODE', '1')} wgs {args.wgs}: "
+print(f"mode {args.mode} gather {args.gather} bf16 {args.bf16} fixed {args.fixed} PF_MODE {os.environ.get('SDUMC_PF_MODE', '1')} wgs {args.wgs}: "
       f"host {1e3 * (t1 - t0) / n:.4f} ms/step, wall {1e3 * (t2 - t0) / n:.4f} ms/step, loss {float(tr.state.losses[0]):.5f}")
 if pr:
     pstats.Stats(pr).sort_stats("cumulative").print_stats(18)
