@@ -58,6 +58,7 @@ constexpr int MAXP = SDUMC_GG_MAX_PROBLEMS;
 
 struct Launch {
   sdumc_gg_problem p[MAXP];
+  int32_t xcd;               // > 0: the workgroups' ranges follow an XCD-major order of the physical workgroup ids (see wg_logical)
   int32_t line0[MAXP + 1];   // first line position (k-tiles) of problem i; line0[n] = L
   int32_t unit0[MAXP + 1];   // first global unit index of problem i
   int32_t nchunk[MAXP];      // K of a problem's tiles cut into this many chunks, line order (chunk, tile, k): tiles of one chunk
@@ -122,6 +123,15 @@ __device__ __forceinline__ Where locate(const Launch& L, int x) {
   return w;
 }
 
+// Workgroup ids are dealt round-robin over the 8 XCDs (each with its own L2): physical id w runs on XCD w % 8.  With L.xcd the ranges
+// of the line are handed out XCD-major -- the workgroups of ONE XCD hold CONSECUTIVE ranges -- so that the units of one k-chunk (the
+// n-tiles that re-read the same rows of A) run side by side under one L2.
+__device__ __forceinline__ int wg_logical(const Launch& L, int w) {
+  if (L.xcd <= 0) return w;
+  const int per = L.nwg / L.xcd, full = per * L.xcd;      // (ids beyond the last whole round keep their place)
+  return w < full ? (w % L.xcd) * per + w / L.xcd : w;
+}
+
 // what a wave holds of one MFMA group (8 k) of a k-tile: element s of a fragment is k = 8 gq + 4 lh + s
 struct Frag {
   f32x4 a[TM], b[TN];
@@ -137,7 +147,7 @@ __device__ __forceinline__ void gg_tn_body(const Launch& L, char* lds) {
   const int li = lane & 31, lh = lane >> 5;
   const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
   const int LL = L.line0[L.n];
-  const int wg = blockIdx.x;
+  const int wg = wg_logical(L, (int)blockIdx.x);
   int x = range_begin(wg, LL, L.nwg);
   const int x_end = range_begin(wg + 1, LL, L.nwg);
   constexpr int PER = NI + 1;      // vector-memory operations per wave per stage: 2 A rows, 1 B piece, 1 keep-bits piece (issued
@@ -447,7 +457,7 @@ __global__ __launch_bounds__(NTHR, 2) void gg_tn_split2_kernel(const Launch L) {
   const int li = lane & 31, lh = lane >> 5;
   const int wm0 = (wave / WGN2) * WM2, wn0 = (wave % WGN2) * WN2;
   const int LL = L.line0[L.n];
-  const int wg = blockIdx.x;
+  const int wg = wg_logical(L, (int)blockIdx.x);
   int x = range_begin(wg, LL, L.nwg);
   const int x_end = range_begin(wg + 1, LL, L.nwg);
   constexpr int PER = 5;      // 2 A rows, 2 B rows, 1 keep-bits piece per wave and stage
@@ -634,20 +644,23 @@ __global__ __launch_bounds__(NTHR, 2) void gg_tn_split2_kernel(const Launch L) {
           __builtin_amdgcn_sched_barrier(0);
         }
       };
+#ifndef SDUMC_GG_DBG
+#define SDUMC_GG_DBG 0      /* measurement builds only (wrong results): bit 0 = no DMA, bit 1 = no conversion, bit 2 = no MFMAs */
+#endif
       {
 #pragma unroll
         for (int s = 0; s < NST - 1; ++s)
-          if (s < nk) issue(s);
+          if (s < nk && !(SDUMC_GG_DBG & 1)) issue(s);
         int buf = 0, ibuf = NST - 1;
 #pragma nounroll
         for (int t = 0; t < nk; ++t) {
           // stage t has landed (this wave's pieces) / everyone is done with the planes of k-tile t - 1 and has converted stage t - 1
           wait_n(min(nk - t - 1, NST - 2));
           __builtin_amdgcn_s_barrier();
-          if (t + NST - 1 < nk) issue(ibuf);
-          convert(ring0 + buf * STAGE2);
+          if (t + NST - 1 < nk && !(SDUMC_GG_DBG & 1)) issue(ibuf);
+          if (!(SDUMC_GG_DBG & 2)) convert(ring0 + buf * STAGE2);
           __builtin_amdgcn_s_barrier();
-          multiply();
+          if (!(SDUMC_GG_DBG & 4)) multiply();
           buf = buf + 1 == NST ? 0 : buf + 1;
           ibuf = ibuf + 1 == NST ? 0 : ibuf + 1;
         }
@@ -743,7 +756,7 @@ __global__ __launch_bounds__(NTHR, 2) void gg_tn_bf16_kernel(const Launch L) {
   const int li = lane & 31, lh = lane >> 5;
   const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
   const int LL = L.line0[L.n];
-  const int wg = blockIdx.x;
+  const int wg = wg_logical(L, (int)blockIdx.x);
   int x = range_begin(wg, LL, L.nwg);
   const int x_end = range_begin(wg + 1, LL, L.nwg);
   constexpr int PER = HNI;
@@ -1108,6 +1121,12 @@ int plan(const sdumc_gg_problem* probs, int n, int nwg_max, bool hf, bool wide, 
     units += g.ntiles * L.nchunk[i];
     tiles += g.ntiles;
   }
+  // (Measured and dropped again, round 6 -- round 3 had tried it on the fp32-MFMA form: K cut into chunks of 1 / 2 / 4 workgroup
+  //  shares, line order (chunk, tile, k), ranges handed out XCD-major (wg_logical) so that the n-tiles that re-read the same rows of A
+  //  run side by side under one L2: frame launch 195 / 185 / 180 us against 176-177 us, one audio problem 131 / 112 / 104 against 97.
+  //  The in-kernel ablations say why traffic is not the bound: DMA alone 70 us, MFMAs + fragment reads alone 106 us, conversion
+  //  +33 us and ring stalls +23 us on top, nearly additive -- profiles/README.md, round 6.)
+  L.xcd = 0;
   L.line0[n] = line;
   L.unit0[n] = units;
   L.nwg = std::min(nwg_max, line);

@@ -792,17 +792,22 @@ class FusedTrainer:
         from .data import EpochPlan
         plan = batches if isinstance(batches, EpochPlan) else store.plan_epoch(batches)
         n = len(plan)
-        steps = [self._get(B, T) for (B, T) in plan.shapes]      # (may grow the arena: before any descriptor is built)
-        if any(ts._arena is not self.arena for ts in steps):
-            steps = [self._get(B, T) for (B, T) in plan.shapes]
+        # the arena must hold the epoch's largest batch BEFORE the first descriptor is built (growing it invalidates every cached step);
+        # the per-shape step objects themselves are made one step ahead of the GPU, inside the loop: the host runs ahead of the device
+        # anyway, so a shape seen for the first time costs no device time
+        Bm = max(B for B, _ in plan.shapes)
+        Tm = tuple(max(T[i] for _, T in plan.shapes) for i in range(4))
+        if not (Bm <= self.arena.B and all(t <= c for t, c in zip(Tm, self.arena.T))):
+            self._get(max(Bm, self.arena.B), tuple(max(t, c) for t, c in zip(Tm, self.arena.T)))
         inplace = self._in_place(store)
         planes = inplace or self._store_planes(store)
-        g0 = self._gather_desc(store, plan.idx_ptr(0), steps[0], 0, key_padding, planes, inplace)
+        nxt = self._get(*plan.shapes[0])
+        g0 = self._gather_desc(store, plan.idx_ptr(0), nxt, 0, key_padding, planes, inplace)
         check(lib.sdumc_gather_batch(C.byref(g0), 0, _lib.current_stream()), "sdumc_gather_batch")
         for i in range(n):
-            ts = steps[i].use_store(store, i & 1) if inplace else steps[i].use_set(i & 1, planes=planes)
+            ts = nxt.use_store(store, i & 1) if inplace else nxt.use_set(i & 1, planes=planes)
             ts.use_lengths(self.arena.sets[i & 1].lengths if key_padding else None)
-            nxt = steps[i + 1] if i + 1 < n else None
+            nxt = self._get(*plan.shapes[i + 1]) if i + 1 < n else None
             pf = self._gather_desc(store, plan.idx_ptr(i + 1), nxt, (i + 1) & 1, key_padding, planes, inplace) if nxt is not None else None
             losses = self._launch(ts, next_step=nxt, prefetch=pf)
             if on_step is not None:
