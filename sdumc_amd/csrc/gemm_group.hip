@@ -430,6 +430,9 @@ __global__ __launch_bounds__(NTHR, OCC) void gg_tn_kernel(const Launch L) {
 //      that goes into the buffer just converted.
 // The accumulator tiles keep their natural row / column order (Launch.nat: the reduce kernel's index arithmetic).
 // ------------------------------------------------------------------------------------------------------------------------
+#ifndef SDUMC_GG_DBG
+#define SDUMC_GG_DBG 0      /* measurement builds only (wrong results): bit 0 = no DMA, bit 1 = no conversion, bit 2 = no MFMAs */
+#endif
 namespace s2 {
 [[maybe_unused]] constexpr int TM2 = 4;
 constexpr int BN2 = 256, WGN2 = 4, WM2 = 128, WN2 = 64, TN2 = 2;      // 2 x 4 waves, each 128 x 64
@@ -644,9 +647,6 @@ __global__ __launch_bounds__(NTHR, 2) void gg_tn_split2_kernel(const Launch L) {
           __builtin_amdgcn_sched_barrier(0);
         }
       };
-#ifndef SDUMC_GG_DBG
-#define SDUMC_GG_DBG 0      /* measurement builds only (wrong results): bit 0 = no DMA, bit 1 = no conversion, bit 2 = no MFMAs */
-#endif
       {
 #pragma unroll
         for (int s = 0; s < NST - 1; ++s)
@@ -1208,6 +1208,9 @@ int gg_run(const sdumc_gg_problem* probs, int32_t n, void* workspace, size_t wor
     const int tok = sdumc_prof_begin_(hf ? 20 : (split_products() ? 24 : 19), flops, stream);
     if (hf) hipLaunchKernelGGL(gg_tn_bf16_kernel, dim3(L.nwg), dim3(NTHR), hf::HNST * hf::HSTAGE, st, L);
     else if (wide) {
+      // (round 6: a form that converts k-tile t + 1 while it multiplies k-tile t -- double-buffered planes, 8-k raw halves, the two
+      //  waves of a SIMD in opposite convert / multiply order -- measured 178-180 us against this kernel's 170 us on the frame launch,
+      //  its ablations as additive as this one's: tools/experiments/gg_tn_split3.inc, profiles/r6_gg_split3.txt)
       hipLaunchKernelGGL(gg_tn_split2_kernel, dim3(L.nwg), dim3(NTHR), s2::LDS2, st, L);
     } else hipLaunchKernelGGL((gg_tn_kernel<5, 2>), dim3(L.nwg), dim3(NTHR), 5 * STAGE_BYTES, st, L);
     sdumc_prof_end_(tok, stream);
