@@ -2,7 +2,7 @@
 # Collects the round's measurement artefacts on the GPU box into gpurun_out/<tag>/ (copied to profiles/ afterwards):
 #   bench lines (fp32 default, bf16, epoch, c1, c5), serial-lane rocprofv3 kernel stats (fp32 + bf16), PMC traffic passes.
 # usage: bash tools/collect_profiles.sh <tag>
-TAG=${1:-r3}
+TAG=${1:-r6}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$TAG
@@ -19,6 +19,7 @@ SDUMC_FORCE_DP=1 timeout 200 python3 bench.py --steps 30 --warmup 5 --no-cpu-bas
 SDUMC_BENCH_TIMEOUT=90 SDUMC_DIST_BACKEND=gloo timeout 150 python3 bench.py --gpus 2 --steps 5 --warmup 2 --no-roofline > $O/bench_gloo_2ranks_1gpu.json 2>> $O/bench.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 10 --warmup 3 --prewarm-s 0 --serial-lanes --no-cpu-baseline --no-roofline > $O/kt.log 2>&1
 cp $(find $O/kt -name "*kernel_stats.csv" | head -1) $O/kernel_stats_bench_serial_lanes.csv
+python3 tools/kstats_summary.py $O/kernel_stats_bench_serial_lanes.csv $O/rocprof_kernel_avg.json > $O/rocprof_kernel_avg.txt 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/ktb -- python3 bench.py --bf16 --steps 10 --warmup 3 --prewarm-s 0 --serial-lanes --no-cpu-baseline --no-roofline > $O/ktb.log 2>&1
 cp $(find $O/ktb -name "*kernel_stats.csv" | head -1) $O/kernel_stats_bench_bf16_serial_lanes.csv
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmcf -- python3 bench.py --steps 3 --warmup 1 --prewarm-s 0 --serial-lanes --no-cpu-baseline --no-roofline > $O/pmcf.log 2>&1
