@@ -517,6 +517,7 @@ def main():
     ap.add_argument("--no-side", action="store_true", help="skip the side legs of the default line (profiling runs)")
     ap.add_argument("--resident", type=int, default=N_RESIDENT, help="distinct resident batches the timed loop rotates through (single GPU)")
     ap.add_argument("--epoch-batches", type=int, default=200, help="batches of the ragged-epoch side legs")
+    ap.add_argument("--stream-priority", type=int, default=None, help="experiment: run the timed loop on a torch stream of this priority (-1 = high)")
     args = ap.parse_args()
     global B_PER_GPU, T_MOSEI, DIMS, TRAIN_FLOPS_PER_SAMPLE, WORKLOAD_TEXT
     epoch = args.workload == "epoch"
@@ -590,6 +591,13 @@ def main():
         step.set_batch(*batch)
         run = step.step
 
+    import contextlib
+    prio_ctx = contextlib.nullcontext()
+    if args.stream_priority is not None:      # (experiment: the caller's stream in the priority class of the engine's lanes)
+        prio_stream = torch.cuda.Stream(priority=args.stream_priority)
+        prio_stream.wait_stream(torch.cuda.current_stream())
+        prio_ctx = torch.cuda.stream(prio_stream)
+    prio_ctx.__enter__()
     for _ in range(args.warmup):
         run()
     torch.cuda.synchronize()
@@ -601,6 +609,7 @@ def main():
         run()
     t_enq = time.perf_counter() - t0          # host time to ENQUEUE the K steps (the GPU is still running): host-bound if ~= dt
     torch.cuda.synchronize()
+    prio_ctx.__exit__(None, None, None)
     if world > 1 or force_dp:
         dist.barrier()
     torch.cuda.synchronize()
