@@ -347,6 +347,8 @@ class TrainStep(_OptStateMixin):
         self._arena = arena
         self._lengths = None      # key-padding extension off (set_lengths / use_lengths)
         self._use_planes = False
+        self._borrowed = None     # the caller's tensors of a zero-copy hand-over (use_batch)
+        self._set = 0
         io = _lib.NetIO()
         self.io = io
         cfg = _lib.StepCfg()
@@ -449,6 +451,7 @@ class TrainStep(_OptStateMixin):
             io.audio_p3 = io.video_p3 = io.text_p3[0] = io.text_p3[1] = None
         self.cfg.labels = ptr(st.labels)
         self._set = k
+        self._borrowed = None
         return self
 
     def use_store(self, store, k):
@@ -473,6 +476,7 @@ class TrainStep(_OptStateMixin):
         self.labels = st.labels[:self.B]
         self.cfg.labels = ptr(st.labels)
         self._use_planes, self._set = not hf, k
+        self._borrowed = None
         return self
 
     def _point_lengths(self, tensors):
@@ -482,6 +486,7 @@ class TrainStep(_OptStateMixin):
     def set_batch(self, audio, text, video, feat4, labels):
         """Copies one batch into the step's resident input buffers (shapes are fixed per TrainStep); in bf16-storage mode the
         buffers are bf16 and fp32 inputs are rounded by the copy.  With planes (a resident batch) the bf16 planes are split here."""
+        self._restore_own_inputs()
         self.audio.copy_(audio, non_blocking=True)
         self.text.copy_(text, non_blocking=True)
         self.video.copy_(video, non_blocking=True)
@@ -493,6 +498,50 @@ class TrainStep(_OptStateMixin):
         if planes is not None:
             for src, dst in zip((self.audio, self.text, self.video, self.feat4), planes):
                 p3_split_into(src, dst)
+
+    def use_batch(self, audio, text, video, feat4, labels):
+        """Zero-copy hand-over of one batch: the step reads the caller's device tensors where they are (no 224 MB device copy per
+        batch: what `for data in loader: step.use_batch(*unpack(data, 'cuda')[:5]); step.run()` saves over set_batch).  The tensors
+        must have the step's shapes and feature dtype, be contiguous and 16-byte aligned, and stay alive and unchanged until the step
+        has run (the step keeps references until the next hand-over); labels [B] fp32.  Returns False -- and copies, as set_batch --
+        when a tensor does not qualify (fp32 features handed to a bf16-storage step are rounded by the copy).  Not for captured
+        steps (a graph replays the addresses it was recorded with)."""
+        if self.graph is not None:
+            raise _lib.SdumcError("use_batch: the captured hipGraph reads the step's own buffers (set_batch)")
+        ts = (audio, text, video, feat4)
+        ok = labels.is_cuda and labels.dtype == torch.float32 and labels.is_contiguous() and labels.numel() == self.B
+        for t, T, d in zip(ts, self.T, self._fdims):
+            ok = ok and t.is_cuda and t.dtype == self.feature_dtype and t.is_contiguous() and tuple(t.shape) == (self.B, T, d) \
+                and t.data_ptr() % 16 == 0
+        if not ok:
+            self.set_batch(audio, text, video, feat4, labels)
+            return False
+        io = self.io
+        io.audio, io.text[0], io.video, io.text[1] = ptr(audio), ptr(text), ptr(video), ptr(feat4)
+        io.audio_p3 = io.video_p3 = io.text_p3[0] = io.text_p3[1] = None      # (a fresh batch: no planes to split for one use)
+        for i in range(4):
+            io.row_map[i] = None
+            io.store_rows[i] = 0
+        self.cfg.labels = ptr(labels.reshape(-1))
+        self._borrowed = (audio, text, video, feat4, labels)
+        self._use_planes = False
+        return True
+
+    def _restore_own_inputs(self):
+        """after use_batch: point the step back at its own input buffers (set_batch writes those)"""
+        if self._borrowed is None:
+            return
+        self._borrowed = None
+        if self._arena is not None:
+            self.use_set(self._set)
+            return
+        io = self.io
+        io.audio, io.video = ptr(self.audio), ptr(self.video)
+        io.text[0], io.text[1] = ptr(self.text), ptr(self.feat4)
+        self.cfg.labels = ptr(self.labels)
+        if self._planes is not None:
+            io.audio_p3, io.text_p3[0], io.video_p3, io.text_p3[1] = (ptr(t) for t in self._planes)
+            self._use_planes = True
 
     def set_lengths(self, lengths):
         """Key-padding extension: (audio, text, video, feat4) valid frame counts of the current batch, or None to go back
@@ -821,6 +870,7 @@ class FusedTrainer:
         ts = self._get(audio.shape[0], (audio.shape[1], text.shape[1], video.shape[1], feat4.shape[1]))
         if self.arena is not None:
             ts.use_set(0, planes=False)      # (fresh tensors: a split for one use costs more than the planes save)
-        ts.set_batch(audio, text, video, feat4, labels)
+        # the caller's device tensors are read where they are when they qualify (no 224 MB copy per batch); else copied
+        ts.use_batch(audio, text, video, feat4, labels.reshape(-1) if torch.is_tensor(labels) else labels)
         ts.set_lengths(lengths)
         return self._launch(ts)

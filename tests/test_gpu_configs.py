@@ -520,6 +520,66 @@ def test_bf16_run_epoch_in_place_equals_gathered_batches_bit_for_bit(E):
     assert not torch.equal(res["epoch"][1][0], res["epoch_kp"][1][0])
 
 
+def test_zero_copy_hand_over_equals_set_batch(E):
+    """TrainStep.use_batch: the step reads the loader's device tensors where they are (what FusedTrainer.step does since round 6
+    instead of a 224 MB copy per batch) -- losses, gradients and parameters bit for bit equal to set_batch; tensors that do not
+    qualify (not contiguous, fp32 handed to a bf16-storage step) are copied; set_batch after a hand-over writes the step's own
+    buffers again; a resident batch (planes=True) survives a hand-over in between.  Ref: main_frame_val_text_missing.py:94-109."""
+    from oracle import sdumc_oracle as O
+    from sdumc_amd import _lib
+    dims, B, Tn = (64, 128, 64, 128), 5, (70, 32, 66, 33)
+    P = O.init_params(dims, seed=2)
+    b0 = [t.cuda() for t in O.synthetic_batch(B, Tn, dims, seed=60)]
+    b1 = [t.cuda() for t in O.synthetic_batch(B, Tn, dims, seed=61)]
+
+    def run(how, **kw):
+        flat, lay = flat_from(E, P, dims)
+        ts = E.TrainStep(flat, B, Tn, dims, seed=9, lr=1e-3, **kw)
+        out = []
+        for i, b in enumerate((b0, b1, b0)):
+            if how == "set":
+                ts.set_batch(*b)
+            elif how == "use":
+                assert ts.use_batch(*b) is True
+            elif how == "mixed":      # hand-over, copy, hand-over
+                (ts.set_batch if i == 1 else ts.use_batch)(*b)
+            elif how == "strided":    # a non-contiguous view does not qualify: copied, same result
+                wide = torch.cat([b[0], b[0]], dim=2)
+                assert ts.use_batch(wide[:, :, :dims[0]], *b[1:]) is False
+            out.append((ts.run().clone(), ts.grads.clone()))
+            torch.cuda.synchronize()
+        return out, flat.clone()
+
+    want, wflat = run("set")
+    for how in ("use", "mixed", "strided"):
+        got, gflat = run(how)
+        for (la, ga), (lb, gb) in zip(got, want):
+            assert torch.equal(la, lb) and torch.equal(ga, gb), how
+        assert torch.equal(gflat, wflat), how
+    # a resident batch with planes: a hand-over of another batch in between, then set_batch of the first again
+    flat, lay = flat_from(E, P, dims)
+    ts = E.TrainStep(flat, B, Tn, dims, seed=9, lr=1e-3, planes=True)
+    ts.set_batch(*b0)
+    l0 = ts.run().clone()
+    ts.use_batch(*b1)
+    ts.run()
+    ts.set_batch(*b0)
+    assert ts._use_planes and ts.io.audio_p3 == ts._planes[0].data_ptr()
+    flat2, _ = flat_from(E, P, dims)
+    ts2 = E.TrainStep(flat2, B, Tn, dims, seed=9, lr=1e-3, planes=True)
+    ts2.set_batch(*b0)
+    assert torch.equal(ts2.run(), l0)
+    # bf16 storage: fp32 tensors are rounded by the copy, bf16 tensors are read in place
+    flat, lay = flat_from(E, P, dims)
+    th = E.TrainStep(flat, B, Tn, dims, seed=9, bf16=True)
+    assert th.use_batch(*b0) is False
+    la = th.run().clone()
+    flat, lay = flat_from(E, P, dims)
+    th = E.TrainStep(flat, B, Tn, dims, seed=9, bf16=True)
+    assert th.use_batch(*[t.bfloat16() for t in b0[:4]], b0[4]) is True
+    assert torch.equal(th.run(), la)
+
+
 def test_keep_bits_sets_are_tagged_with_call_and_shape(E):
     """sdumc_net_io.bits_next: a set is used only under a tag that names THIS call's {seed, call} AND batch shape, and a set regenerated
     at a step's head is re-tagged for that step.  Driven on purpose: (a) the Philox counter rewound to a value a set was once filled for
