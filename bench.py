@@ -475,7 +475,15 @@ def epoch_leg(args, engine, flat, lay, dev, bf16=None, nb=None, warmup=None):
     plan_w, plan_t = store.plan_epoch(batches[:warmup]) if warmup else None, store.plan_epoch(batches[warmup:])
     shapes = [sh[1] for sh in (plan_w.shapes if plan_w else [])] + [sh[1] for sh in plan_t.shapes]
     if plan_w:
+        # warm-up by the WALL clock as well (the chip ramps its clock for ~0.1 s after an idle spell, and building the store and the
+        # plans is one: ten warm-up batches are 13 ms; a cold start showed as a fixed ~50 ms on the timed epoch, 1.8 instead of 1.29 ms
+        # per step over 100 batches)
+        t_w = time.perf_counter()
         tr.run_epoch(store, plan_w)
+        torch.cuda.synchronize()
+        while time.perf_counter() - t_w < args.prewarm_s:
+            tr.run_epoch(store, plan_w)
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     tr.run_epoch(store, plan_t)

@@ -865,3 +865,13 @@ extern "C" int sdumc_dp_unpack(const float* records, int32_t W, int32_t B, int32
 }
 
 extern "C" const char* sdumc_version(void) { return "sdumc_hip 0.1 (gfx950)"; }
+
+// One empty kernel per source file = per gfx950 code object: sdumc_preload_() asks for its attributes, which makes the HIP runtime load
+// this file's code object NOW (outside any timed or latency-sensitive region) instead of at the first launch of one of its kernels --
+// with deferred loading that first launch stalls the host for tens of milliseconds (seen as a 36-59 ms gap in the middle of an epoch,
+// at the first batch whose shape took a fallback path: profiles/README.md, round 6).
+__global__ void sdumc_preload_elementwise_kernel() {}
+extern "C" int sdumc_preload_elementwise_(void) {
+  hipFuncAttributes a;
+  return hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&sdumc_preload_elementwise_kernel)) == hipSuccess ? SDUMC_OK : SDUMC_ELAUNCH;
+}

@@ -520,6 +520,47 @@ LaneSet* default_lanes() {
   return S;
 }
 void ensure_side_streams() { (void)default_lanes(); }
+}  // namespace
+extern "C" int sdumc_preload_gemm_f32_(void);
+extern "C" int sdumc_preload_gemm_wide_(void);
+extern "C" int sdumc_preload_gemm_p3_(void);
+extern "C" int sdumc_preload_gemm_b1_(void);
+extern "C" int sdumc_preload_gemm_group_(void);
+extern "C" int sdumc_preload_gemm_rows_(void);
+extern "C" int sdumc_preload_gemm_bf16_(void);
+extern "C" int sdumc_preload_attn_pool_(void);
+extern "C" int sdumc_preload_elementwise_(void);
+extern "C" int sdumc_preload_loss_(void);
+extern "C" int sdumc_preload_adam_(void);
+extern "C" int sdumc_preload_chain_(void);
+extern "C" int sdumc_preload_chain_cluster_(void);
+extern "C" int sdumc_preload_transformer_(void);
+namespace {
+__global__ void sdumc_preload_engine_kernel() {}
+// every code object of the library loaded on the current device, once per device (see the note at the end of any kernel source);
+// called from the *_workspace_bytes queries every caller makes first -- never under stream capture, never inside a step
+void preload_code_objects() {
+  static sdumc_dev_once once;
+  (void)sdumc_once_per_device(once, [] {
+    hipFuncAttributes a;
+    bool ok = hipFuncGetAttributes(&a, reinterpret_cast<const void*>(&sdumc_preload_engine_kernel)) == hipSuccess;
+    ok = sdumc_preload_gemm_f32_() == SDUMC_OK && ok;
+    ok = sdumc_preload_gemm_wide_() == SDUMC_OK && ok;
+    ok = sdumc_preload_gemm_p3_() == SDUMC_OK && ok;
+    ok = sdumc_preload_gemm_b1_() == SDUMC_OK && ok;
+    ok = sdumc_preload_gemm_group_() == SDUMC_OK && ok;
+    ok = sdumc_preload_gemm_rows_() == SDUMC_OK && ok;
+    ok = sdumc_preload_gemm_bf16_() == SDUMC_OK && ok;
+    ok = sdumc_preload_attn_pool_() == SDUMC_OK && ok;
+    ok = sdumc_preload_elementwise_() == SDUMC_OK && ok;
+    ok = sdumc_preload_loss_() == SDUMC_OK && ok;
+    ok = sdumc_preload_adam_() == SDUMC_OK && ok;
+    ok = sdumc_preload_chain_() == SDUMC_OK && ok;
+    ok = sdumc_preload_chain_cluster_() == SDUMC_OK && ok;
+    ok = sdumc_preload_transformer_() == SDUMC_OK && ok;
+    return ok;
+  });
+}
 
 // the context's split option for the duration of one network-level call (thread-local: the launchers ask sdumc_split_on_)
 struct SplitScope {
@@ -2701,6 +2742,7 @@ extern "C" int32_t sdumc_param_table(int32_t da, int32_t dt, int32_t dv, char* b
 
 extern "C" size_t sdumc_net_workspace_bytes(const sdumc_net_dims* d) {
   ensure_side_streams();   // never called under stream capture: the place to create the internal lanes
+  preload_code_objects();
   (void)sdumc_gemm_rows_prepare_();
   Plan p;
   if (!d || !make_plan(*d, p)) return 0;

@@ -635,12 +635,18 @@ class _InputSet:
     the labels and the valid frame counts."""
 
     def __init__(self, n, planes_bytes, B, dtype, dev, rows):
-        self.inputs = [torch.empty(k, device=dev, dtype=dtype) for k in n]
+        self._n, self._dtype, self._inputs = n, dtype, None      # (the padded copies' buffers exist only once something is copied)
         self.planes = [torch.empty(k, device=dev, dtype=torch.uint8) for k in planes_bytes] if planes_bytes is not None else None
         self.labels = torch.empty(B, device=dev)
         self.lengths = [torch.empty(B, dtype=torch.int32, device=dev) for _ in range(4)]
         self.maps = None      # row maps (int32 per frame): a batch read in place from a DeviceFeatureStore (ensure_maps)
         self._rows = rows
+
+    @property
+    def inputs(self):
+        if self._inputs is None:
+            self._inputs = [torch.empty(k, device=self.labels.device, dtype=self._dtype) for k in self._n]
+        return self._inputs
 
     def ensure_maps(self):
         if self.maps is None:
