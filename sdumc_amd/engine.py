@@ -186,7 +186,7 @@ class NetCall:
     padded frames are then masked out of the six attention poolings."""
 
     def __init__(self, flat_params, audio, texts, video, train, rng, sample0=0, p_mlp=P_MLP, bf16=False, lengths=None,
-                 ctx=None, planes=None):
+                 ctx=None, planes=None, bits_next=False):
         texts = list(texts)
         _require_cuda(flat_params)
         _require_cuda(audio, video, *texts, dtypes=(torch.float32, torch.bfloat16))
@@ -243,6 +243,15 @@ class NetCall:
             io.audio_p3, io.video_p3 = ptr(self._planes[0]), ptr(self._planes[1])
             for i, t in enumerate(self._planes[2]):
                 io.text_p3[i] = ptr(t)
+        # fp32 train-mode calls that are repeated step after step on this object (the data-parallel backend): the NEXT call's frame-level
+        # keep-bits are generated in this call's middle (sdumc_net_io.bits_next; the Philox counter must advance by 2 between calls,
+        # as HipBackend.adam and sdumc_train_step do) -- bit-identical masks, tagged; any other sequence regenerates at the head
+        self._bits_next = None
+        if bits_next and train and rng is not None:
+            nb = lib.sdumc_net_bits_next_bytes(C.byref(self.dims))
+            if nb:
+                self._bits_next = torch.zeros(nb, dtype=torch.uint8, device=dev)
+                io.bits_next = ptr(self._bits_next)
         self.io = io
         self.refresh_planes()
 
@@ -275,7 +284,14 @@ class NetCall:
 
     def forward(self):
         check(lib.sdumc_net_forward(C.byref(self.dims), C.byref(self.io), _lib.current_stream()), "sdumc_net_forward")
+        self._phase_used = self.io.bits_phase      # (the backward of this call reads the set the forward read)
         return self.vals, self.fused, self.rnc, self.text_hidden, self.cross_text
+
+    def next_call(self):
+        """After the step that this forward / backward pair belongs to (the caller has advanced the Philox counter by 2): the next
+        forward reads the keep-bits set this one filled."""
+        if self._bits_next is not None:
+            self.io.bits_phase ^= 1
 
     def backward(self, d_vals, d_fused, d_rnc, d_text_hidden, d_cross_text, grads=None):
         """Returns the flat gradient bucket [live] (allocated zeroed when not given)."""

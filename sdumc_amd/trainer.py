@@ -61,7 +61,7 @@ class HipBackend:
         self.state = st
         self.rng = st.rng
         self.call = engine.NetCall(flat_params, self.audio, [self.text, self.feat4], self.video, True, self.rng,
-                                   sample0=sample0, bf16=bf16, planes=planes)
+                                   sample0=sample0, bf16=bf16, planes=planes, bits_next=True)
         V = 2 * B
         self.d_vals = torch.empty(V, 1, device=dev)
         self.d_fused = torch.empty(V, engine.H, device=dev)
@@ -193,6 +193,7 @@ class HipBackend:
                                        self.betas[1], self.eps, self.wd, grad_scale, _lib.current_stream()),
                    "sdumc_adam_step")
         _lib.check(lib.sdumc_rng_advance(_lib.ptr(self.rng.t), 2, _lib.current_stream()), "sdumc_rng_advance")
+        self.call.next_call()      # (the next forward finds its keep-bits in the set this step's forward filled)
 
     def set_lr(self, lr):
         self.hyper[0] = lr
