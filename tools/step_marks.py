@@ -12,9 +12,11 @@ from sdumc_amd import engine, _lib
 bf16 = "--bf16" in sys.argv
 dev = torch.device("cuda:0")
 flat, lay = bench.init_flat_params(engine, dev)
-step = engine.TrainStep(flat, bench.B_PER_GPU, bench.T_MOSEI, bench.DIMS, seed=2024, bf16=bf16, planes=True)      # (a resident batch: the headline's kernels)
-step.set_batch(*[t.to(dev) for t in bench.synthetic_shard(bench.B_PER_GPU, 0)])
-for _ in range(10):
+# the headline's loop: bench.N_RESIDENT resident batches in turn, the next step's keep-bits generated in this step's middle
+batches = [[t.to(dev) for t in bench.synthetic_shard(bench.B_PER_GPU, 0, k=k)] for k in range(bench.N_RESIDENT)]
+step, run = bench.resident_step(engine, flat, batches, bf16=bf16)
+step.run = run
+for _ in range(12):
     step.run()
 torch.cuda.synchronize()
 _lib.lib.sdumc_debug_marks(1)
