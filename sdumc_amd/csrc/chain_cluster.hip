@@ -302,6 +302,9 @@ __device__ __forceinline__ void fold_combine(const sdumc_chain_fold& f, float* o
     st4(s_rows + (size_t)row * D + 4 * cq, o);
   }
   // stored weights *= fac: every (modality, sample) row range is cut into CL equal parts, one per member; four elements per thread in flight
+#if defined(SDUMC_FOLD_DBG)
+  if (SDUMC_FOLD_DBG & 1) return;
+#endif
   for (int mr = 0; mr < 3 * R; ++mr) {
     const int m = mr / R, v = v0 + (mr - m * R);
     if (v >= V) continue;
@@ -462,6 +465,7 @@ __device__ __forceinline__ void chain_fwd_a_cl_body(const sdumc_chain_args a, co
   if (a.fra.part[0]) fold_combine<R, 1>(a.fra, a.hpre, s_hpre, s_qin, v0, V, member, dbase);      // (s_qin: free until the fusion algebra)
   else for (int m = 0; m < 3; ++m) load_rows<R>(s_hpre + m * R * D, a.hpre + m * VD, D, D, v0, V);
   __syncthreads();
+  TR(11);
   if ((a.cl_mode & 64) && !a.fra.part[0])
     for (int m = 0; m < 3; ++m) lds_selfcheck<R>(s_hpre + m * R * D, a.hpre + m * VD, D, v0, V, a.cl_dbg, 10 + m);
   // audio / text / video_mlp (model :293-295)
@@ -635,6 +639,7 @@ __device__ __forceinline__ void chain_fwd_b_cl_body(const sdumc_chain_args a, co
   if (a.ca.part[0]) fold_combine<R, NQ>(a.ca, a.ca_out, s_x, s_c, v0, V, member, dbase);      // (s_c: first written by cross_*_mlp.3)
   else for (int m = 0; m < 3; ++m) load_rows<NQ * R>(s_x + m * NQ * R * D, a.ca_out + (int64_t)m * VQ * D, D, D, v0 * NQ, V * NQ);
   __syncthreads();
+  TR(11);
   // cross_{audio,text,video}_mlp (model :338-340), rows = (sample, query)
 #pragma unroll 1
   for (int m = 0; m < 3; ++m) {

@@ -1016,12 +1016,42 @@ __global__ __launch_bounds__(NTHR) void gg_reduce_kernel(const Launch L, const i
   }
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   const size_t off = ((size_t)((wave * nparts + part) * 64 + lane)) * 4;
-  for (int c = 0; c < nc; ++c) {
-    const int k0 = chunk_k(c, g.nk, nc), len = chunk_k(c + 1, g.nk, nc) - k0 + ovh;
-    const int us = L.line0[p] + g.ntiles * (k0 + c * ovh) + tg * len;
-    const int unit = L.unit0[p] + c * g.ntiles + tg;
-    const int wl = wg_of(us + len - 1, LL, L.nwg);
-    for (int w = wg_of(us + ovh, LL, L.nwg); w <= wl; ++w) s += *reinterpret_cast<const f32x4*>(L.slab + (size_t)(w + unit) * slot_floats + off);
+  {
+    // The tile's slots in ascending k order = (chunk c, workgroup w) in ascending (c, w): the walk below is wave-uniform (scalar unit);
+    // eight slots' loads are requested before the first is added (one load per add, as first written, left a wave with 1 KB in flight
+    // and the launch at 2.8 TB/s on slabs the persistent kernel had just written: latency, not bandwidth).  Same sums, same order.
+    int c = 0, w = 0, wl = -1, unit = 0;
+    auto next = [&]() -> const float* {
+      while (w > wl) {
+        if (c == nc) return nullptr;
+        const int k0 = chunk_k(c, g.nk, nc), len = chunk_k(c + 1, g.nk, nc) - k0 + ovh;
+        const int us = L.line0[p] + g.ntiles * (k0 + c * ovh) + tg * len;
+        unit = L.unit0[p] + c * g.ntiles + tg;
+        w = wg_of(us + ovh, LL, L.nwg);
+        wl = wg_of(us + len - 1, LL, L.nwg);
+        ++c;
+      }
+      const float* q = L.slab + (size_t)(w + unit) * slot_floats + off;
+      ++w;
+      return q;
+    };
+    constexpr int NB = 8;
+    for (;;) {
+      const float* src[NB];
+      int n = 0;
+      for (; n < NB; ++n) {
+        src[n] = next();
+        if (!src[n]) break;
+      }
+      f32x4 v[NB];
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        if (j < n) v[j] = *reinterpret_cast<const f32x4*>(src[j]);
+#pragma unroll
+      for (int j = 0; j < NB; ++j)
+        if (j < n) s += v[j];
+      if (n < NB) break;
+    }
   }
   const int li = lane & 31, lh = lane >> 5;
   const int ij = part >> 2, q = part & 3, i = ij / tnx, j = ij - i * tnx;
