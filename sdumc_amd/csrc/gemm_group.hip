@@ -1241,6 +1241,9 @@ int gg_run(const sdumc_gg_problem* probs, int32_t n, void* workspace, size_t wor
       // (round 6: a form that converts k-tile t + 1 while it multiplies k-tile t -- double-buffered planes, 8-k raw halves, the two
       //  waves of a SIMD in opposite convert / multiply order -- measured 178-180 us against this kernel's 170 us on the frame launch,
       //  its ablations as additive as this one's: tools/experiments/gg_tn_split3.inc, profiles/r6_gg_split3.txt)
+      // (a third form, the raw fp32 ring replaced by global -> register loads one k-tile ahead and double-buffered planes with ONE
+      //  barrier per k-tile: 185-187 us against 185-186 on the same box; alone its multiply loop takes 88 us (this kernel's: 106) and its
+      //  loads + conversion 80, together 161: tools/experiments/gg_tn_split4.inc, profiles/r6_gg_split4.txt)
       hipLaunchKernelGGL(gg_tn_split2_kernel, dim3(L.nwg), dim3(NTHR), s2::LDS2, st, L);
     } else hipLaunchKernelGGL((gg_tn_kernel<5, 2>), dim3(L.nwg), dim3(NTHR), 5 * STAGE_BYTES, st, L);
     sdumc_prof_end_(tok, stream);
